@@ -1,0 +1,313 @@
+/*
+ * ra_gpu_batch.h -- C ABI of libra_gpu_batch: a batched, MI355X-resident
+ * evaluator of the per-server Raft state transition that rabbitmq/ra runs
+ * one-process-per-group in ra_server:handle_leader/2, handle_follower/2,
+ * handle_candidate/2, handle_pre_vote/2 and handle_await_condition/2 for
+ * the message classes append_entries_rpc / append_entries_reply /
+ * request_vote_rpc / request_vote_result / {ra_log_event,{written,..}} /
+ * pipeline_rpcs / {commands,..}.
+ *
+ * This header is the drop-in boundary.  The call site
+ * it replaces is ra_server_proc:handle_raft_state/3 and handle_leader/2
+ *   (reference src/ra_server_proc.erl:1356-1397), i.e. the call
+ *   ra_server:RaftState(Msg, ServerState) -> {NextState, ServerState, Effects}
+ *   (reference src/ra_server.erl:530-531, 1281-1282).
+ * An Erlang NIF (ra_amd/csrc/ra_gpu_batch_nif.c) binds exactly these entry
+ * points; INTEGRATION.md shows the Erlang-side stub.
+ *
+ * Plain C: pointers, sizes, fixed-width integers.  No C++/torch types.
+ * All indexes and terms are uint64_t (ra_index()/ra_term() are
+ * non_neg_integer(), reference src/ra.hrl:18-23); Erlang 'undefined' is
+ * RGB_UNDEF; an undefined server id is RGB_NONE.
+ */
+#ifndef RA_GPU_BATCH_H
+#define RA_GPU_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGB_ABI_VERSION   1u
+#define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
+#define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
+#define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
+#define RGB_MAX_RUNS      16u          /* (first_index, term) runs kept per server log  */
+
+/* reference src/ra_server.hrl:7-8 (cfg defaults) */
+#define RGB_AER_CHUNK_SIZE              128u
+#define RGB_DEFAULT_MAX_PIPELINE_COUNT  4096u
+
+/* ra_state(), reference src/ra.hrl:92-100 (subset handled on the device) */
+enum {
+  RGB_ROLE_FOLLOWER        = 0,
+  RGB_ROLE_CANDIDATE       = 1,
+  RGB_ROLE_LEADER          = 2,
+  RGB_ROLE_PRE_VOTE        = 3,
+  RGB_ROLE_AWAIT_CONDITION = 4
+};
+
+/* original reason of follower_catchup_cond_fun/1, reference src/ra_server.erl:2196-2216 */
+enum {
+  RGB_COND_NONE          = 0,
+  RGB_COND_MISSING       = 1,
+  RGB_COND_TERM_MISMATCH = 2
+};
+
+/* message kinds (one inbound ra_msg() for one server) */
+enum {
+  RGB_MSG_NOP           = 0,  /* empty slot in a dense tick                                        */
+  RGB_MSG_AER           = 1,  /* #append_entries_rpc{}       src/ra.hrl:123-129                    */
+  RGB_MSG_AER_REPLY     = 2,  /* {Peer,#append_entries_reply{}} src/ra.hrl:131-142                 */
+  RGB_MSG_REQUEST_VOTE  = 3,  /* #request_vote_rpc{}         src/ra.hrl:145-149                    */
+  RGB_MSG_VOTE_RESULT   = 4,  /* #request_vote_result{}      src/ra.hrl:152-154                    */
+  RGB_MSG_WRITTEN       = 5,  /* {ra_log_event,{written,Term,Seq}} (contiguous Seq = [from..to])    */
+  RGB_MSG_PIPELINE_RPCS = 6,  /* info event pipeline_rpcs    src/ra_server.erl:793-801             */
+  RGB_MSG_APPEND        = 7,  /* {command,_} / {commands,_}: leader appended n entries in its term */
+  RGB_MSG_AWAIT_TIMEOUT = 8   /* await_condition_timeout     src/ra_server.erl:1932-1945           */
+};
+
+/* rgb_msg.flags */
+#define RGB_MF_SUCCESS  0x01u  /* AER_REPLY: success=true; VOTE_RESULT: vote_granted=true */
+#define RGB_MF_FORCE    0x02u  /* APPEND: noop command => Force pipelining (src/ra_server.erl:682-689) */
+
+/*
+ * One inbound message, 64 bytes.  Field use by kind:
+ *   AER           term, from=leader_id, a=prev_log_index, b=prev_log_term, c=leader_commit,
+ *                 entries = n_entries contiguous indexes starting at a+1+gap; the first n_run0
+ *                 carry term run0_term, the remaining carry run1_term (payloads stay on the host)
+ *   AER_REPLY     term, from=peer, flags&SUCCESS, a=next_index, b=last_index, c=last_term
+ *   REQUEST_VOTE  term, from=candidate_id, a=last_log_index, b=last_log_term
+ *   VOTE_RESULT   term, from=voter, flags&SUCCESS=vote_granted
+ *   WRITTEN       term, a=first index of the written range, b=last index of the written range
+ *   APPEND        n_entries = number of commands appended by the leader (flags&FORCE for noop)
+ */
+typedef struct rgb_msg {
+  uint32_t server;      /* target server id = group * n_members + member slot */
+  uint8_t  kind;        /* RGB_MSG_*                                          */
+  uint8_t  from;        /* sender member slot or RGB_NONE                     */
+  uint8_t  flags;       /* RGB_MF_*                                           */
+  uint8_t  gap;         /* AER: first entry index = a + 1 + gap (0 normally)  */
+  uint64_t term;
+  uint64_t a;
+  uint64_t b;
+  uint64_t c;
+  uint32_t n_entries;
+  uint32_t n_run0;
+  uint64_t run0_term;
+  uint64_t run1_term;
+} rgb_msg;
+
+/* rgb_decision.flags: the effects()/state facts the owning gen_statem must act on */
+#define RGB_F_REPLY          (1u << 0)  /* {cast,To,{Id,#append_entries_reply{}}} or {reply,#request_vote_result{}} */
+#define RGB_F_REPLY_SUCCESS  (1u << 1)  /* reply.success / reply.vote_granted                                        */
+#define RGB_F_REPLY_VOTE     (1u << 2)  /* the reply is a #request_vote_result{}                                     */
+#define RGB_F_PERSIST        (1u << 3)  /* update_term_and_voted_for stored term/voted_for (src/ra_server.erl:3041-3058) */
+#define RGB_F_LEADER_MSG     (1u << 4)  /* {record_leader_msg, LeaderId}                                              */
+#define RGB_F_LEADER_CHANGED (1u << 5)  /* leader_id differs from before                                              */
+#define RGB_F_APPLIED        (1u << 6)  /* last_applied advanced: apply (old+1 .. last_applied)                       */
+#define RGB_F_AUX_EVAL       (1u << 7)  /* {aux, eval}                                                                */
+#define RGB_F_WROTE          (1u << 8)  /* follower ra_log:write of entries reply_next_index..reply_last_index        */
+#define RGB_F_TRUNCATED      (1u << 9)  /* ra_log:set_last_index(prev_log_index) was applied                          */
+#define RGB_F_PIPELINE       (1u << 10) /* {next_event, info, pipeline_rpcs}                                          */
+#define RGB_F_REPROCESSED    (1u << 11) /* {next_event, Msg}: role changed and Msg was re-processed in the new role   */
+#define RGB_F_ROLE_CHANGED   (1u << 12)
+#define RGB_F_BECAME_LEADER  (1u << 13) /* candidate won: post_election_effects are the host's                        */
+#define RGB_F_UNHANDLED      (1u << 14) /* catch-all clause: state unchanged                                          */
+#define RGB_F_INVARIANT      (1u << 15) /* the reference would exit/assert; code in .invariant; state unchanged       */
+#define RGB_F_RUNS_OVERFLOW  (1u << 16) /* term-run table overflowed: oldest run dropped, first_index raised          */
+#define RGB_F_SEND_SNAPSHOT  (1u << 17) /* a pipelined peer needs {send_snapshot,..} (rgb_rpc kind RGB_RPC_SNAPSHOT)  */
+
+/* rgb_decision.invariant: exit reasons / failed assertions of the reference */
+enum {
+  RGB_INV_NONE                      = 0,
+  RGB_INV_LEADER_SAW_AER_SAME_TERM  = 1, /* exit(leader_saw_append_entries_rpc_in_same_term) src/ra_server.erl:845-849 */
+  RGB_INV_TRUNCATE_BELOW_APPLIED    = 2, /* ?assertNot(PLIdx < LastApplied)  src/ra_server.erl:1317 */
+  RGB_INV_WRITE_BELOW_APPLIED       = 3, /* ?assertNot(FstIdx < LastApplied) src/ra_server.erl:1370 */
+  RGB_INV_MISMATCH_TERM_UNDEFINED   = 4, /* ?assert(LATerm =/= undefined)    src/ra_server.erl:3616-3617 */
+  RGB_INV_WRITE_INTEGRITY           = 5, /* {error,{integrity_error,_}} -> exit(Err) src/ra_log.erl:592-599 */
+  RGB_INV_SET_LAST_INDEX_NOT_FOUND  = 6, /* {ok,L} = ra_log:set_last_index badmatch  src/ra_log.erl:857-859 */
+  RGB_INV_LAST_WRITTEN_TERM         = 7, /* true = Term =/= undefined        src/ra_log.erl:576, 878 */
+  RGB_INV_NEXT_INDEX_REGRESSED      = 8, /* ?assert(NewNextIdx >= NextIdx)   src/ra_server.erl:2333 */
+  RGB_INV_PIPELINE_PREV_UNDEFINED   = 9  /* make_rpc_effect: no term for NextIdx-1 and no snapshot above it
+                                            (case_clause / ?assert(PrevIdx < SnapIdx)) src/ra_server.erl:2392-2408 */
+};
+
+/*
+ * One decision per message, 64 bytes, same order as the submitted messages.
+ * commit_index / last_applied are the server's values AFTER the transition.
+ * When RGB_F_WROTE is set (non-empty append: the reference sends no reply now,
+ * src/ra_server.erl:1373-1376) reply_next_index/reply_last_index hold the first/last
+ * entry index actually written after drop_existing/3.
+ */
+typedef struct rgb_decision {
+  uint32_t server;
+  uint8_t  role;       /* next ra_state()                          */
+  uint8_t  reply_to;   /* member slot the reply goes to / RGB_NONE */
+  uint8_t  n_rpcs;     /* rgb_rpc records emitted for this message */
+  uint8_t  kind;       /* echo of rgb_msg.kind                     */
+  uint32_t flags;      /* RGB_F_*                                  */
+  uint32_t invariant;  /* RGB_INV_*                                */
+  uint64_t reply_term;
+  uint64_t reply_next_index;
+  uint64_t reply_last_index;
+  uint64_t reply_last_term;
+  uint64_t commit_index;
+  uint64_t last_applied;
+} rgb_decision;
+
+enum { RGB_RPC_AER = 1, RGB_RPC_SNAPSHOT = 2 };
+
+/*
+ * One outbound {send_rpc, Peer, #append_entries_rpc{}} shaped by
+ * make_pipelined_rpc_effects/3 (src/ra_server.erl:2285-2346): entries are
+ * prev_log_index+1 .. prev_log_index+n_entries, read from ra_log by the host.
+ * RGB_RPC_SNAPSHOT: {send_snapshot, Peer, _}; prev_log_index = snapshot index.
+ * Records are emitted unordered; (msg_index, peer) identifies them.
+ */
+typedef struct rgb_rpc {
+  uint32_t msg_index;   /* index of the triggering message in the submitted batch */
+  uint32_t server;
+  uint8_t  peer;
+  uint8_t  kind;        /* RGB_RPC_* */
+  uint16_t n_entries;
+  uint32_t _pad;
+  uint64_t term;
+  uint64_t prev_log_index;
+  uint64_t prev_log_term;
+  uint64_t leader_commit;
+  uint64_t next_index;  /* the peer's next_index after this rpc */
+} rgb_rpc;
+
+/*
+ * Host-visible state of one ra_server (one member of one group): the integer
+ * part of ra_server_state() (src/ra_server.erl:73-112), ra_peer_state()
+ * (src/ra.hrl:61-73) and the ra_log cursors (src/ra_log.erl:830-839, 1166-1200).
+ * The log's index->term map is a run-length table: run i covers indexes
+ * run_start[i] .. run_start[i+1]-1 (the last run ends at last_index) with
+ * term run_term[i]; run_start[0] == first_index when the range is not empty.
+ * The ra_log range is {first_index, last_index}; it is empty (undefined)
+ * iff first_index > last_index, in which case (last_index,last_term) equal
+ * the snapshot's (src/ra_log.erl:831-835).
+ */
+typedef struct rgb_server_state {
+  uint64_t current_term;
+  uint64_t commit_index;
+  uint64_t last_applied;
+  uint64_t last_index;
+  uint64_t last_term;
+  uint64_t last_written_index;
+  uint64_t last_written_term;
+  uint64_t snapshot_index;      /* RGB_UNDEF: no snapshot */
+  uint64_t snapshot_term;
+  uint64_t first_index;
+  uint64_t cond_reply[4];       /* stored timeout reply of await_condition: term,next_index,last_index,last_term */
+  uint64_t match_index[RGB_MAX_MEMBERS];
+  uint64_t next_index[RGB_MAX_MEMBERS];
+  uint64_t commit_index_sent[RGB_MAX_MEMBERS];
+  uint64_t run_start[RGB_MAX_RUNS];
+  uint64_t run_term[RGB_MAX_RUNS];
+  uint8_t  role;                /* RGB_ROLE_*                                             */
+  uint8_t  cond_reason;         /* RGB_COND_* (role == AWAIT_CONDITION)                   */
+  uint8_t  self;                /* own member slot                                        */
+  uint8_t  n_members;
+  uint8_t  voted_for;           /* member slot / RGB_NONE                                 */
+  uint8_t  leader_id;           /* member slot / RGB_NONE                                 */
+  uint8_t  votes;
+  uint8_t  n_runs;
+  uint8_t  present_mask;        /* bit i: member i is a key of the cluster map            */
+  uint8_t  voter_mask;          /* bit i: member i's voter_status is voter (or absent)    */
+  uint8_t  status_mask;         /* bit i: peer i status == normal                         */
+  uint8_t  self_nonvoter;       /* own `membership` =/= voter                             */
+  uint8_t  cond_leader;         /* await_condition: who the stored reply is cast to       */
+  uint8_t  _pad[3];
+} rgb_server_state;
+
+/* ra_leaderboard row + key_metrics gauges per group (src/ra_leaderboard.erl:18-26, src/ra.erl:1242-1250) */
+typedef struct rgb_leaderboard_row {
+  uint32_t leader;        /* member slot of the leader with the highest term, RGB_NONE if none */
+  uint32_t n_leaders;     /* members currently in role leader (split-brain diagnostics)        */
+  uint64_t term;          /* highest current_term among members                                */
+  uint64_t commit_index;  /* the leader's commit_index (max over members when no leader)       */
+  uint64_t last_applied;  /* the leader's last_applied (max over members when no leader)       */
+} rgb_leaderboard_row;
+
+typedef struct rgb_config {
+  uint32_t abi_version;          /* RGB_ABI_VERSION                                             */
+  int32_t  device;               /* HIP device ordinal                                          */
+  uint32_t max_runs;             /* term runs kept per server on the device, 2..RGB_MAX_RUNS    */
+  uint32_t ring_slots;           /* pinned staging ring: batches in flight (>=1)                */
+  uint32_t ring_capacity;        /* messages per ring slot                                      */
+  uint32_t max_pipeline_count;   /* cfg.max_pipeline_count                                      */
+  uint32_t max_aer_batch;        /* cfg.max_append_entries_rpc_batch_size                       */
+  uint32_t flags;                /* reserved, 0                                                 */
+} rgb_config;
+
+typedef struct rgb_ctx rgb_ctx;
+
+/* error codes: 0 ok, negative failure; never aborts */
+enum {
+  RGB_OK            =  0,
+  RGB_E_INVAL       = -1,
+  RGB_E_NOMEM       = -2,
+  RGB_E_HIP         = -3,  /* rgb_last_hip_error() has the hipError_t */
+  RGB_E_STATE       = -4,
+  RGB_E_FULL        = -5,  /* staging ring full: collect first        */
+  RGB_E_EMPTY       = -6,  /* nothing submitted                       */
+  RGB_E_UNSUPPORTED = -7,
+  RGB_E_NODEVICE    = -8   /* no HIP device: there is no CPU fallback */
+};
+
+uint32_t    rgb_abi_version(void);
+/* sizeof() of the ABI structs as compiled: 0 rgb_msg, 1 rgb_decision, 2 rgb_rpc,
+ * 3 rgb_server_state, 4 rgb_leaderboard_row, 5 rgb_config (bindings verify their mirrors) */
+size_t      rgb_struct_size(int which);
+const char *rgb_strerror(int code);
+void        rgb_default_config(rgb_config *cfg);
+
+int  rgb_open(const rgb_config *cfg, rgb_ctx **out);
+void rgb_close(rgb_ctx *ctx);
+int  rgb_last_hip_error(const rgb_ctx *ctx);
+
+/* allocate device state for n_groups x n_members servers, every server = ra_server:init/1 of an
+ * empty log (empty_state: term 0, log [0:0], peers next_index 1 / match_index 0). */
+int  rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members);
+uint32_t rgb_n_servers(const rgb_ctx *ctx);
+
+/* host <-> device state transfer for servers [first, first+n) */
+int  rgb_upload_state(rgb_ctx *ctx, uint32_t first, uint32_t n, const rgb_server_state *in);
+int  rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_state *out);
+
+/* Asynchronous host path: copy n messages into the pinned staging ring, enqueue
+ * H2D + transition kernel(s) + D2H on the context's stream and return.  Messages for the same
+ * server are applied in submission order (serialised over sub-ticks); messages for different
+ * servers are applied in parallel.  rgb_collect waits for the OLDEST submitted batch. */
+int  rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick);
+int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
+                 rgb_rpc *rpc_out, uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out);
+
+/* Device-resident path (benchmarks, device-side producers): d_msgs holds n_ticks dense ticks of
+ * n_per_tick messages each, at most ONE message per server per tick (caller's guarantee);
+ * d_decisions receives n_ticks*n_per_tick decisions; d_rpcs (capacity rpc_cap records) and the
+ * uint32 counter d_rpc_count receive the pipelined rpcs (may be NULL to discard).  Enqueued on
+ * `stream` (a hipStream_t, NULL = the context's stream); returns without synchronising. */
+int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t n_per_tick, uint32_t n_ticks,
+                          void *d_decisions, void *d_rpcs, uint32_t rpc_cap, void *d_rpc_count,
+                          void *stream);
+
+/* leaderboard / metrics snapshot: one row per group */
+int  rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out);
+int  rgb_snapshot_device(rgb_ctx *ctx, void *d_rows, void *stream);
+
+/* 64-bit FNV-style checksum over the canonical state of servers [first, first+n): computed on
+ * the device, used by size-independent parity checks. */
+int  rgb_state_checksum(rgb_ctx *ctx, uint32_t first, uint32_t n, uint64_t *out);
+
+int  rgb_synchronize(rgb_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RA_GPU_BATCH_H */

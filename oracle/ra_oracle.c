@@ -1,0 +1,1091 @@
+/*
+ * ra_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, single-message-at-a-time restatement of the rabbitmq/ra per-server Raft
+ * transition (reference app vsn 3.1.10) for the message classes on the ra_gpu_batch hot
+ * path.  It is the CPU checker the HIP path is compared with: only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it.  The product library
+ * (libra_gpu_batch.so) never links, loads or calls anything in this directory.
+ *
+ * The reference is Erlang and no Erlang/OTP toolchain exists in this environment, so the
+ * reference itself cannot be executed here (no oracle/_ref).  This restatement is pinned by
+ * the known-answer vectors transcribed from the reference's own unit tests
+ * (tests/golden/ra_server_suite_vectors.json <- test/ra_server_SUITE.erl,
+ * src/ra_server.erl:4225-4238, test/ra_log_2_SUITE.erl); clauses no reference test pins are
+ * listed "source-derived" in DESIGN.md.
+ *
+ * Deliberately a different formulation from the device kernel: the log is an explicit
+ * per-index array of terms (one fetch_term per entry, as ra_log does), the quorum is a
+ * real sort, every clause is written in reference order.  All citations are
+ * /root/reference/<path>:<lines>.
+ */
+#include "ra_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define UNDEF RGB_UNDEF
+
+/* ------------------------------------------------------------------ log model ---- */
+/* ra_log state: range (undefined or {first,last}), last_term, last_written_index_term,
+ * current snapshot; terms[] holds the term of every index in the range
+ * (src/ra_log.erl:96-130 record fields range/last_term/last_written_index_term). */
+typedef struct {
+  int      has_range;
+  uint64_t first, last;
+  uint64_t last_term;
+  uint64_t lw_idx, lw_term;
+  uint64_t snap_idx, snap_term;   /* UNDEF = no snapshot */
+  uint64_t base;                  /* index stored at terms[0] */
+  uint64_t *terms;
+  size_t   cap;
+} olog;
+
+typedef struct {
+  uint64_t current_term, commit_index, last_applied;
+  uint64_t cond_reply[4];
+  uint64_t match_index[RGB_MAX_MEMBERS], next_index[RGB_MAX_MEMBERS],
+           commit_index_sent[RGB_MAX_MEMBERS];
+  uint8_t  role, cond_reason, self, n_members, voted_for, leader_id, votes;
+  uint8_t  present_mask, voter_mask, status_mask, self_nonvoter, cond_leader;
+} oscal;
+
+typedef struct {
+  oscal s;
+  olog  log;
+} oserver;
+
+struct ora_ctx {
+  uint32_t n_servers, n_members;
+  uint32_t max_pipeline_count, max_aer_batch;
+  oserver *sv;
+};
+
+static int log_reserve(olog *l, uint64_t idx) {
+  /* make terms[idx - base] addressable */
+  if (l->terms == NULL) {
+    l->cap = 64;
+    l->terms = (uint64_t *)malloc(l->cap * sizeof(uint64_t));
+    if (!l->terms) return -1;
+    l->base = idx;
+  }
+  if (idx < l->base) {
+    size_t shift = (size_t)(l->base - idx);
+    size_t ncap = l->cap + shift;
+    uint64_t *nt = (uint64_t *)malloc(ncap * sizeof(uint64_t));
+    if (!nt) return -1;
+    memcpy(nt + shift, l->terms, l->cap * sizeof(uint64_t));
+    free(l->terms);
+    l->terms = nt; l->cap = ncap; l->base = idx;
+  }
+  if (idx - l->base >= l->cap) {
+    size_t ncap = l->cap;
+    while (idx - l->base >= ncap) ncap *= 2;
+    uint64_t *nt = (uint64_t *)realloc(l->terms, ncap * sizeof(uint64_t));
+    if (!nt) return -1;
+    l->terms = nt; l->cap = ncap;
+  }
+  return 0;
+}
+
+/* ra_log:fetch_term/2, src/ra_log.erl:1186-1200: defined only for Idx in range
+ * (?IS_IN_RANGE, src/ra_log.erl:477-480), else undefined. */
+static uint64_t log_fetch_term(const olog *l, uint64_t idx) {
+  if (l->has_range && idx >= l->first && idx <= l->last)
+    return l->terms[idx - l->base];
+  return UNDEF;
+}
+
+/* ra_log:last_index_term/1, src/ra_log.erl:830-835 */
+static void log_last_index_term(const olog *l, uint64_t *idx, uint64_t *term) {
+  if (l->has_range) { *idx = l->last; *term = l->last_term; }
+  else { *idx = l->snap_idx; *term = l->snap_term; }
+}
+
+/* ra_log:next_index/1, src/ra_log.erl:1166-1174 */
+static uint64_t log_next_index(const olog *l) {
+  if (l->has_range) return l->last + 1;
+  if (l->snap_idx != UNDEF) return l->snap_idx + 1;
+  return 0;
+}
+
+/* ra_log:exists/2, src/ra_log.erl:1459-1467 */
+static int log_exists(const olog *l, uint64_t idx, uint64_t term) {
+  uint64_t t = log_fetch_term(l, idx);
+  return t != UNDEF && t == term;
+}
+
+/* ra_server:fetch_term/2 with the snapshot fallback, src/ra_server.erl:3185-3196 */
+static uint64_t srv_fetch_term(const olog *l, uint64_t idx) {
+  uint64_t t = log_fetch_term(l, idx);
+  if (t == UNDEF) {
+    if (l->snap_idx != UNDEF && l->snap_idx == idx) return l->snap_term;
+    return UNDEF;
+  }
+  return t;
+}
+
+enum { HLE_OK = 0, HLE_MISMATCH = 1, HLE_MISSING = 2 };
+/* has_log_entry_or_snapshot/3, src/ra_server.erl:3168-3183 */
+static int has_log_entry_or_snapshot(const olog *l, uint64_t idx, uint64_t term) {
+  uint64_t t = log_fetch_term(l, idx);
+  if (t == UNDEF) {
+    if (l->snap_idx != UNDEF && l->snap_idx == idx)
+      return l->snap_term == term ? HLE_OK : HLE_MISMATCH;
+    return HLE_MISSING;
+  }
+  return t == term ? HLE_OK : HLE_MISMATCH;
+}
+
+/* entry term of the k-th entry (0-based) of an AER message */
+static uint64_t msg_entry_term(const rgb_msg *m, uint32_t k) {
+  return k < m->n_run0 ? m->run0_term : m->run1_term;
+}
+static uint64_t msg_first_index(const rgb_msg *m) { return m->a + 1 + (uint64_t)m->gap; }
+
+/* ra_log:write/2, src/ra_log.erl:547-599 + wal_write_batch range update :1618-1623.
+ * Writes entries k0..n-1 of message m.  Returns 0 or an RGB_INV_* code; validates first,
+ * mutates only on success (Erlang terms are immutable: a crash leaves the old state). */
+static int log_write(olog *l, const rgb_msg *m, uint32_t k0) {
+  uint64_t fst = msg_first_index(m) + k0;
+  uint64_t lst = msg_first_index(m) + (m->n_entries - 1);
+  if (l->has_range && !(fst <= l->last + 1))              /* guard :557-559 */
+    return RGB_INV_WRITE_INTEGRITY;
+  if (fst == 0) return RGB_INV_WRITE_INTEGRITY;            /* index 0 is never rewritten */
+  /* overwrite lowers last_written, :565-581 */
+  uint64_t lwi = fst - 1 < l->lw_idx ? fst - 1 : l->lw_idx;
+  uint64_t lwt;
+  if (lwi == l->lw_idx) {
+    lwt = l->lw_term;
+  } else if (l->snap_idx != UNDEF && l->snap_idx == lwi) {
+    lwt = l->snap_term;
+  } else if (lwi == 0) {                                   /* _ when LWIdx =< 0 */
+    lwt = 0;
+  } else {
+    lwt = log_fetch_term(l, lwi);
+    if (lwt == UNDEF) return RGB_INV_LAST_WRITTEN_TERM;    /* true = Term2 =/= undefined */
+  }
+  if (log_reserve(l, fst) || log_reserve(l, lst)) return RGB_INV_WRITE_INTEGRITY;
+  for (uint32_t k = k0; k < m->n_entries; k++)
+    l->terms[msg_first_index(m) + k - l->base] = msg_entry_term(m, k);
+  if (!l->has_range) { l->has_range = 1; l->first = fst; }
+  l->last = lst;
+  l->last_term = msg_entry_term(m, m->n_entries - 1);
+  l->lw_idx = lwi; l->lw_term = lwt;
+  return 0;
+}
+
+/* ra_log:append/2 of one leader entry, src/ra_log.erl:482-545 (cursor effect only) */
+static int log_append(olog *l, uint64_t idx, uint64_t term) {
+  if (log_reserve(l, idx)) return -1;
+  l->terms[idx - l->base] = term;
+  if (!l->has_range) { l->has_range = 1; l->first = idx; }
+  l->last = idx; l->last_term = term;
+  return 0;
+}
+
+/* ra_log:set_last_index/2, src/ra_log.erl:842-893 */
+static int log_set_last_index(olog *l, uint64_t idx) {
+  uint64_t t = log_fetch_term(l, idx);
+  int snap_is_idx = (l->snap_idx != UNDEF && l->snap_idx == idx);
+  if (t == UNDEF && !snap_is_idx) return RGB_INV_SET_LAST_INDEX_NOT_FOUND;
+  if (snap_is_idx) {
+    /* range = ra_range:limit(Idx+1, Range), src/ra_range.erl:80-91 */
+    if (l->has_range) {
+      if (idx + 1 <= l->first) l->has_range = 0;
+      else if (idx + 1 <= l->last) l->last = idx;
+    }
+    l->last_term = l->snap_term;
+    l->lw_idx = l->snap_idx; l->lw_term = l->snap_term;
+    return 0;
+  }
+  uint64_t lwi = idx < l->lw_idx ? idx : l->lw_idx;
+  uint64_t lwt;
+  if (l->snap_idx != UNDEF && l->snap_idx == lwi) lwt = l->snap_term;
+  else lwt = log_fetch_term(l, lwi);
+  if (lwt == UNDEF) return RGB_INV_LAST_WRITTEN_TERM;      /* true = LWTerm =/= undefined */
+  if (l->has_range) {
+    if (idx + 1 <= l->first) l->has_range = 0;
+    else if (idx + 1 <= l->last) l->last = idx;
+  }
+  l->last_term = t;
+  l->lw_idx = lwi; l->lw_term = lwt;
+  return 0;
+}
+
+/* ra_log:handle_event({written, Term, Seq}), src/ra_log.erl:897-944, for a contiguous
+ * Seq = [from..to] (pending/resend bookkeeping stays on the host).  Returns 1 if
+ * last_written changed. */
+static int log_written(olog *l, uint64_t term, uint64_t from, uint64_t to) {
+  uint64_t idx = to;
+  for (;;) {
+    uint64_t t = log_fetch_term(l, idx);
+    if (t != UNDEF && t == term) {
+      int changed = !(l->lw_idx == idx && l->lw_term == term);
+      l->lw_idx = idx; l->lw_term = term;
+      return changed;
+    }
+    if (t == UNDEF && l->snap_idx != UNDEF && idx <= l->snap_idx)
+      return 0;                                            /* snapshot overtook the write */
+    /* term mismatch (or undefined above the snapshot): ra_seq:limit(Idx-1, Seq) and retry */
+    if (idx == 0 || idx - 1 < from) return 0;
+    idx -= 1;
+  }
+}
+
+/* --------------------------------------------------------------- server helpers -- */
+typedef struct {
+  uint32_t flags;
+  uint32_t invariant;
+  int      has_reply;
+  uint64_t r_term, r_next, r_last, r_lterm;
+  uint8_t  reply_to;
+  uint64_t w_first, w_last;
+  rgb_rpc *rpcs; uint32_t rpc_cap, n_rpcs_total; uint8_t n_rpcs;
+  uint32_t msg_index;
+} ofx;
+
+static int is_present(const oscal *s, unsigned i) {
+  return i < RGB_MAX_MEMBERS && ((s->present_mask >> i) & 1u);
+}
+
+/* become(follower,_,_) resets every peer status to normal, src/ra_server.erl:2183-2192 */
+static void set_role(oscal *s, uint8_t role, ofx *fx) {
+  if (s->role != role) fx->flags |= RGB_F_ROLE_CHANGED;
+  if (role == RGB_ROLE_FOLLOWER && s->role != RGB_ROLE_FOLLOWER)
+    s->status_mask = 0xFF;
+  if (role != RGB_ROLE_AWAIT_CONDITION) s->cond_reason = RGB_COND_NONE;
+  s->role = role;
+}
+
+/* update_term_and_voted_for/3, src/ra_server.erl:3041-3058 */
+static void update_term_and_voted_for(oscal *s, uint64_t term, uint8_t voted_for, ofx *fx) {
+  if (term == s->current_term && voted_for == s->voted_for) return;
+  fx->flags |= RGB_F_PERSIST;
+  s->current_term = term;
+  s->voted_for = voted_for;
+}
+/* update_term/2, src/ra_server.erl:3060-3064 */
+static void update_term(oscal *s, uint64_t term, ofx *fx) {
+  if (term != UNDEF && term > s->current_term)
+    update_term_and_voted_for(s, term, RGB_NONE, fx);
+}
+
+static void set_leader_id(oscal *s, uint8_t l, ofx *fx) {
+  if (s->leader_id != l) fx->flags |= RGB_F_LEADER_CHANGED;
+  s->leader_id = l;
+}
+
+/* append_entries_reply/3, src/ra_server.erl:3624-3631 */
+static void aer_reply(const oserver *sv, uint64_t term, int success, uint8_t to, ofx *fx) {
+  uint64_t li, lt;
+  log_last_index_term(&sv->log, &li, &lt);
+  fx->has_reply = 1;
+  fx->flags |= RGB_F_REPLY | (success ? RGB_F_REPLY_SUCCESS : 0);
+  fx->r_term = term; fx->r_next = li + 1;
+  fx->r_last = sv->log.lw_idx; fx->r_lterm = sv->log.lw_term;
+  fx->reply_to = to;
+}
+
+static void vote_reply(uint64_t term, int granted, uint8_t to, ofx *fx) {
+  fx->has_reply = 1;
+  fx->flags |= RGB_F_REPLY | RGB_F_REPLY_VOTE | (granted ? RGB_F_REPLY_SUCCESS : 0);
+  fx->r_term = term; fx->r_next = 0; fx->r_last = 0; fx->r_lterm = 0;
+  fx->reply_to = to;
+}
+
+/* apply_to/5, src/ra_server.erl:3250-3282: last_applied := min(LastIdx, ApplyTo) when that
+ * advances it (ra_machine:apply itself runs on the host). Returns 1 when it advanced. */
+static int apply_to(oserver *sv, uint64_t apply_to_idx) {
+  if (apply_to_idx > sv->s.last_applied) {
+    uint64_t li, lt;
+    log_last_index_term(&sv->log, &li, &lt);
+    uint64_t to = li < apply_to_idx ? li : apply_to_idx;
+    if (to >= sv->s.last_applied + 1) { sv->s.last_applied = to; return 1; }
+  }
+  return 0;
+}
+
+/* evaluate_commit_index_follower/2, src/ra_server.erl:2246-2280 */
+static void evaluate_commit_index_follower(oserver *sv, ofx *fx) {
+  if (sv->s.leader_id == RGB_NONE) return;
+  uint64_t li, lt;
+  log_last_index_term(&sv->log, &li, &lt);
+  uint64_t at = li < sv->s.commit_index ? li : sv->s.commit_index;
+  if (apply_to(sv, at)) fx->flags |= RGB_F_APPLIED | RGB_F_AUX_EVAL;
+}
+
+static int cmp_desc(const void *a, const void *b) {
+  uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? 1 : (x > y ? -1 : 0);
+}
+
+/* agreed_commit/1, src/ra_server.erl:3684-3688 */
+uint64_t ora_agreed_commit(const uint64_t *idxs, uint32_t n) {
+  uint64_t tmp[64];
+  if (n == 0 || n > 64) return UNDEF;
+  memcpy(tmp, idxs, n * sizeof(uint64_t));
+  qsort(tmp, n, sizeof(uint64_t), cmp_desc);
+  uint32_t nth = n / 2 + 1;                                /* trunc(length/2) + 1, 1-based */
+  return tmp[nth - 1];
+}
+
+/* match_indexes/1 :3671-3682, increment_commit_index/1 :3648-3657, evaluate_quorum/2 :3633-3646 */
+static void evaluate_quorum(oserver *sv, ofx *fx) {
+  oscal *s = &sv->s;
+  uint64_t list[RGB_MAX_MEMBERS + 1];
+  uint32_t n = 0;
+  list[n++] = sv->log.lw_idx;                              /* the leader's last WRITTEN index */
+  for (unsigned i = 0; i < s->n_members; i++) {
+    if (i == s->self || !is_present(s, i)) continue;
+    if (!((s->voter_mask >> i) & 1u)) continue;            /* non-voters excluded */
+    list[n++] = s->match_index[i];
+  }
+  uint64_t ci0 = s->commit_index;
+  uint64_t p = ora_agreed_commit(list, n);
+  uint64_t t = srv_fetch_term(&sv->log, p);
+  if (t != UNDEF && t == s->current_term)                  /* Raft 5.4.2; NO max(): may decrease */
+    s->commit_index = p;
+  if (s->commit_index > ci0) fx->flags |= RGB_F_AUX_EVAL;
+  if (apply_to(sv, s->commit_index)) fx->flags |= RGB_F_APPLIED;
+}
+
+static void emit_rpc(ofx *fx, const rgb_rpc *r) {
+  if (fx->rpcs && fx->n_rpcs_total < fx->rpc_cap) fx->rpcs[fx->n_rpcs_total] = *r;
+  fx->n_rpcs_total++;
+  fx->n_rpcs++;
+}
+
+/* make_pipelined_rpc_effects/3 :2285-2346, make_rpc_effect/5 :2382-2416,
+ * make_append_entries_rpc/6 :2418-2435.  Returns an RGB_INV_* code or 0; sets *more. */
+static int make_pipelined_rpc_effects(struct ora_ctx *c, oserver *sv, uint32_t srv_id,
+                                      int force, int *more, ofx *fx) {
+  oscal *s = &sv->s;
+  uint64_t next_log_idx = log_next_index(&sv->log);
+  uint64_t max_pipe = c->max_pipeline_count, max_batch = c->max_aer_batch;
+  *more = 0;
+  for (unsigned i = 0; i < s->n_members; i++) {
+    if (i == s->self || !is_present(s, i)) continue;
+    if (!((s->status_mask >> i) & 1u)) continue;           /* status := normal */
+    uint64_t ni = s->next_index[i], mi = s->match_index[i];
+    if (!(ni < next_log_idx || s->commit_index_sent[i] < s->commit_index)) continue;
+    /* NumInFlight = NextIdx - MatchIdx - 1 is an Erlang integer and may be negative */
+    int64_t inflight = (int64_t)(ni - mi) - 1;
+    if (!(inflight < (int64_t)max_pipe || force)) continue;
+    int64_t room = (int64_t)max_pipe - inflight;
+    int64_t bs = (int64_t)max_batch < room ? (int64_t)max_batch : room;
+    if (bs < 1) bs = 1;
+    /* make_rpc_effect */
+    uint64_t prev = ni - 1;
+    uint64_t prev_term = log_fetch_term(&sv->log, prev);
+    rgb_rpc r;
+    memset(&r, 0, sizeof r);
+    r.msg_index = fx->msg_index; r.server = srv_id; r.peer = (uint8_t)i;
+    r.term = s->current_term; r.leader_commit = s->commit_index;
+    uint64_t new_ni;
+    if (prev_term == UNDEF && !(sv->log.snap_idx != UNDEF && sv->log.snap_idx == prev)) {
+      /* {send_snapshot,..}: next index is NOT advanced past SnapIdx, :2403-2415 */
+      if (sv->log.snap_idx == UNDEF || !(prev < sv->log.snap_idx))
+        return RGB_INV_PIPELINE_PREV_UNDEFINED;            /* case_clause / ?assert(PrevIdx < SnapIdx) */
+      r.kind = RGB_RPC_SNAPSHOT;
+      r.prev_log_index = sv->log.snap_idx;
+      r.prev_log_term = sv->log.snap_term;
+      new_ni = sv->log.snap_idx;                           /* {SnapIdx, Effect, State} */
+      fx->flags |= RGB_F_SEND_SNAPSHOT;
+    } else {
+      if (prev_term == UNDEF) prev_term = sv->log.snap_term;
+      uint64_t li, lt;
+      log_last_index_term(&sv->log, &li, &lt);
+      uint64_t to = prev + (uint64_t)bs < li ? prev + (uint64_t)bs : li;
+      r.kind = RGB_RPC_AER;
+      r.prev_log_index = prev; r.prev_log_term = prev_term;
+      r.n_entries = (uint16_t)(to >= prev + 1 ? to - prev : 0);
+      new_ni = to + 1;
+    }
+    if (!(new_ni >= ni)) return RGB_INV_NEXT_INDEX_REGRESSED; /* ?assert(NewNextIdx >= NextIdx) */
+    r.next_index = new_ni;
+    emit_rpc(fx, &r);
+    s->next_index[i] = new_ni;
+    s->commit_index_sent[i] = s->commit_index;
+    int64_t new_inflight = (int64_t)(new_ni - mi) - 1;
+    if (new_ni < next_log_idx && new_inflight < (int64_t)max_pipe) *more = 1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------- follower clauses -- */
+static int follower_aer(oserver *sv, const rgb_msg *m, ofx *fx);
+
+/* handle_follower(#append_entries_rpc{}), src/ra_server.erl:1283-1440 */
+static int follower_aer(oserver *sv, const rgb_msg *m, ofx *fx) {
+  oscal *s = &sv->s;
+  olog *l = &sv->log;
+  uint64_t cur_term = s->current_term;
+  if (!(m->term >= cur_term)) {
+    /* :1431-1440 lower term: reply CurTerm,false; state unchanged */
+    aer_reply(sv, cur_term, 0, m->from, fx);
+    return 0;
+  }
+  uint64_t pli = m->a, plt = m->b, leader_commit = m->c;
+  uint64_t last_applied = s->last_applied;
+  /* State0 = update_term(Term, State00#{leader_id => LeaderId}) :1298 */
+  set_leader_id(s, m->from, fx);
+  update_term(s, m->term, fx);
+  int h = has_log_entry_or_snapshot(l, pli, plt);
+  if (h == HLE_OK) {
+    /* drop_existing/3 :3700-3708 -- one ra_log:exists per entry */
+    uint32_t k = 0;
+    uint64_t last_valid = pli;
+    while (k < m->n_entries) {
+      uint64_t idx = msg_first_index(m) + k;
+      if (!log_exists(l, idx, msg_entry_term(m, k))) break;
+      last_valid = idx;
+      k++;
+    }
+    if (k == m->n_entries) {
+      /* all entries already written, :1304-1364 */
+      uint64_t local_last, lt;
+      log_last_index_term(l, &local_last, &lt);
+      int validated;
+      if (m->n_entries == 0 && local_last > pli) {
+        if (pli < last_applied) return RGB_INV_TRUNCATE_BELOW_APPLIED;
+        int rc = log_set_last_index(l, pli);
+        if (rc) return rc;
+        fx->flags |= RGB_F_TRUNCATED;
+        validated = 1;
+      } else {
+        validated = local_last <= last_valid;
+      }
+      if (validated) {
+        s->commit_index = leader_commit;                   /* NOT clamped, :1331 */
+        fx->flags |= RGB_F_LEADER_MSG;
+        evaluate_commit_index_follower(sv, fx);
+        aer_reply(sv, m->term, 1, m->from, fx);
+      } else {
+        /* :1344-1363: success reply up to what we had; term = PRE-update CurTerm;
+         * the effect list holds only the cast (no record_leader_msg) */
+        uint64_t v = last_applied > last_valid ? last_applied : last_valid;
+        uint64_t vt = srv_fetch_term(l, v);
+        fx->has_reply = 1;
+        fx->flags |= RGB_F_REPLY | RGB_F_REPLY_SUCCESS;
+        fx->r_term = cur_term; fx->r_next = v + 1; fx->r_last = v; fx->r_lterm = vt;
+        fx->reply_to = m->from;
+      }
+      return 0;
+    }
+    /* new entries to write, :1365-1389 */
+    uint64_t fst = msg_first_index(m) + k;
+    s->commit_index = leader_commit;
+    if (fst < last_applied) return RGB_INV_WRITE_BELOW_APPLIED;
+    int rc = log_write(l, m, k);
+    if (rc) return rc;
+    fx->flags |= RGB_F_WROTE | RGB_F_LEADER_MSG;
+    fx->w_first = fst; fx->w_last = msg_first_index(m) + (m->n_entries - 1);
+    evaluate_commit_index_follower(sv, fx);
+    return 0;                                              /* no reply until written */
+  }
+  if (h == HLE_MISSING) {
+    /* :1390-1404 */
+    aer_reply(sv, m->term, 0, m->from, fx);
+    fx->flags |= RGB_F_LEADER_MSG;
+    set_role(s, RGB_ROLE_AWAIT_CONDITION, fx);
+    s->cond_reason = RGB_COND_MISSING;
+  } else {
+    /* term_mismatch :1405-1429, mismatch_append_entries_reply/3 :3614-3622 */
+    uint64_t lat = srv_fetch_term(l, last_applied);
+    if (lat == UNDEF) return RGB_INV_MISMATCH_TERM_UNDEFINED;
+    fx->has_reply = 1;
+    fx->flags |= RGB_F_REPLY | RGB_F_LEADER_MSG;
+    fx->r_term = m->term; fx->r_next = last_applied + 1;
+    fx->r_last = last_applied; fx->r_lterm = lat;
+    fx->reply_to = m->from;
+    set_role(s, RGB_ROLE_AWAIT_CONDITION, fx);
+    s->cond_reason = RGB_COND_TERM_MISMATCH;
+  }
+  /* condition timeout repeats the reply effect, :1398-1403 / :1423-1428 */
+  s->cond_reply[0] = fx->r_term; s->cond_reply[1] = fx->r_next;
+  s->cond_reply[2] = fx->r_last; s->cond_reply[3] = fx->r_lterm;
+  s->cond_leader = m->from;
+  return 0;
+}
+
+/* handle_follower(#request_vote_rpc{}), src/ra_server.erl:1483-1529 */
+static int follower_request_vote(oserver *sv, const rgb_msg *m, ofx *fx) {
+  oscal *s = &sv->s;
+  if (s->self_nonvoter) return 0;                          /* :1483-1488 ignored, no reply */
+  uint8_t cand = m->from;
+  if (m->term == s->current_term && s->voted_for != RGB_NONE && s->voted_for != cand) {
+    vote_reply(m->term, 0, cand, fx);                      /* :1489-1497 */
+    return 0;
+  }
+  if (m->term >= s->current_term) {
+    update_term(s, m->term, fx);
+    uint64_t li, lt;
+    log_last_index_term(&sv->log, &li, &lt);
+    /* is_candidate_log_up_to_date/3 :3157-3166 */
+    int up = (m->b > lt) || (m->b == lt && m->a >= li);
+    if (up) {
+      update_term_and_voted_for(s, m->term, cand, fx);
+      vote_reply(m->term, 1, cand, fx);
+    } else {
+      vote_reply(m->term, 0, cand, fx);
+    }
+    return 0;
+  }
+  vote_reply(s->current_term, 0, cand, fx);                /* :1522-1529 */
+  return 0;
+}
+
+/* handle_follower({ra_log_event,{written,..}}), src/ra_server.erl:1457-1474 */
+static int follower_written(oserver *sv, const rgb_msg *m, ofx *fx) {
+  int changed = log_written(&sv->log, m->term, m->a, m->b);
+  if (changed && sv->s.leader_id != RGB_NONE)
+    aer_reply(sv, sv->s.current_term, 1, sv->s.leader_id, fx);
+  return 0;
+}
+
+static int handle_follower(oserver *sv, const rgb_msg *m, ofx *fx) {
+  switch (m->kind) {
+    case RGB_MSG_AER:          return follower_aer(sv, m, fx);
+    case RGB_MSG_REQUEST_VOTE: return follower_request_vote(sv, m, fx);
+    case RGB_MSG_WRITTEN:      return follower_written(sv, m, fx);
+    case RGB_MSG_AER_REPLY: {
+      /* :1530-1533 Term = max(TheirTerm, CurTerm), update_term */
+      update_term(&sv->s, m->term, fx);
+      return 0;
+    }
+    case RGB_MSG_VOTE_RESULT:  return 0;                   /* :1609-1611 ignored */
+    default:
+      fx->flags |= RGB_F_UNHANDLED;                        /* :1655 catch-all */
+      return 0;
+  }
+}
+
+/* --------------------------------------------------------------- leader clauses -- */
+static int handle_leader(struct ora_ctx *c, oserver *sv, uint32_t srv_id, const rgb_msg *m,
+                         ofx *fx, int *reprocess) {
+  oscal *s = &sv->s;
+  olog *l = &sv->log;
+  switch (m->kind) {
+    case RGB_MSG_AER_REPLY: {
+      unsigned peer = m->from;
+      int success = (m->flags & RGB_MF_SUCCESS) != 0;
+      if (success && m->term == s->current_term) {
+        /* :532-571 */
+        if (!is_present(s, peer)) return 0;
+        if (m->b > s->match_index[peer]) s->match_index[peer] = m->b;
+        if (m->a > s->next_index[peer]) s->next_index[peer] = m->a;
+        evaluate_quorum(sv, fx);
+        fx->flags |= RGB_F_PIPELINE;
+        return 0;
+      }
+      if (m->term > s->current_term) {
+        /* :572-586 */
+        if (!is_present(s, peer)) return 0;
+        set_leader_id(s, RGB_NONE, fx);
+        update_term(s, m->term, fx);
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        return 0;
+      }
+      if (!success) {
+        /* :587-652 (no term guard) */
+        if (!is_present(s, peer)) return 0;
+        uint64_t mi = s->match_index[peer], ni = s->next_index[peer];
+        uint64_t peer_next = m->a, peer_last = m->b, peer_last_term = m->c;
+        uint64_t t = log_fetch_term(l, peer_last);         /* ra_log:fetch_term: NO snapshot fallback */
+        if (t == UNDEF) {
+          s->next_index[peer] = peer_next;
+        } else if (t == peer_last_term && peer_last >= mi) {
+          s->match_index[peer] = peer_last;
+          s->next_index[peer] = peer_next;
+        } else if (peer_last < mi) {
+          s->match_index[peer] = peer_last;
+          s->next_index[peer] = peer_last + 1;
+        } else {
+          /* NextIndex = max(min(NI-1, PeerLastIdx), MI + 1); NI-1 may be -1 in Erlang */
+          int64_t a = (int64_t)ni - 1;
+          int64_t b = (int64_t)peer_last;
+          int64_t mn = a < b ? a : b;
+          int64_t lo = (int64_t)mi + 1;
+          s->next_index[peer] = (uint64_t)(mn > lo ? mn : lo);
+        }
+        int more;
+        return make_pipelined_rpc_effects(c, sv, srv_id, 0, &more, fx);
+      }
+      fx->flags |= RGB_F_UNHANDLED;                        /* stale-term success reply: :1038-1040 */
+      return 0;
+    }
+    case RGB_MSG_AER: {
+      if (m->term > s->current_term) {
+        /* :835-844 */
+        set_leader_id(s, RGB_NONE, fx);
+        update_term(s, m->term, fx);
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      if (m->term == s->current_term) return RGB_INV_LEADER_SAW_AER_SAME_TERM;
+      aer_reply(sv, s->current_term, 0, m->from, fx);      /* :850-854 */
+      return 0;
+    }
+    case RGB_MSG_REQUEST_VOTE: {
+      if (m->term > s->current_term) {
+        /* :928-942 */
+        if (!is_present(s, m->from)) return 0;
+        set_leader_id(s, RGB_NONE, fx);
+        update_term(s, m->term, fx);
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      vote_reply(s->current_term, 0, m->from, fx);         /* :943-945 */
+      return 0;
+    }
+    case RGB_MSG_WRITTEN: {
+      /* :739-744 */
+      log_written(l, m->term, m->a, m->b);
+      evaluate_quorum(sv, fx);
+      fx->flags |= RGB_F_PIPELINE;
+      return 0;
+    }
+    case RGB_MSG_PIPELINE_RPCS: {
+      /* :793-801 */
+      int more;
+      int rc = make_pipelined_rpc_effects(c, sv, srv_id, 0, &more, fx);
+      if (rc) return rc;
+      if (more) fx->flags |= RGB_F_PIPELINE;
+      return 0;
+    }
+    case RGB_MSG_APPEND: {
+      /* {command,_} :653-693 / {commands,_} :695-738: ra_log:append per command at
+       * next_index in the current term, then make_pipelined_rpc_effects */
+      for (uint32_t k = 0; k < m->n_entries; k++)
+        if (log_append(l, log_next_index(l), s->current_term)) return RGB_INV_WRITE_INTEGRITY;
+      int more;
+      return make_pipelined_rpc_effects(c, sv, srv_id, (m->flags & RGB_MF_FORCE) != 0, &more, fx);
+    }
+    default:
+      fx->flags |= RGB_F_UNHANDLED;
+      return 0;
+  }
+}
+
+/* ------------------------------------------------------------ candidate clauses -- */
+static int handle_candidate(oserver *sv, const rgb_msg *m, ofx *fx, int *reprocess) {
+  oscal *s = &sv->s;
+  switch (m->kind) {
+    case RGB_MSG_VOTE_RESULT: {
+      int granted = (m->flags & RGB_MF_SUCCESS) != 0;
+      if (granted && m->term == s->current_term) {
+        /* :1045-1061, required_quorum/1 :3996-3999, count_voters/1 :4001-4009 */
+        unsigned voters = 0;
+        for (unsigned i = 0; i < s->n_members; i++)
+          if (is_present(s, i) && ((s->voter_mask >> i) & 1u)) voters++;
+        unsigned quorum = voters / 2 + 1;
+        unsigned nv = (unsigned)s->votes + 1;
+        if (nv == quorum) {
+          /* initialise_peers/1 :3234-3242: every member next_index = ra_log:next_index,
+           * match_index 0, commit_index_sent 0, status normal */
+          uint64_t ni = log_next_index(&sv->log);
+          for (unsigned i = 0; i < s->n_members; i++) {
+            if (!is_present(s, i)) continue;
+            s->next_index[i] = ni; s->match_index[i] = 0; s->commit_index_sent[i] = 0;
+          }
+          s->status_mask = 0xFF;
+          set_leader_id(s, s->self, fx);
+          s->votes = 0;
+          set_role(s, RGB_ROLE_LEADER, fx);
+          fx->flags |= RGB_F_BECAME_LEADER;
+        } else {
+          s->votes = (uint8_t)nv;
+        }
+        return 0;
+      }
+      if (m->term > s->current_term) {
+        update_term_and_voted_for(s, m->term, RGB_NONE, fx); /* :1062-1069 */
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        return 0;
+      }
+      return 0;                                             /* :1070-1071, :1131-1133 */
+    }
+    case RGB_MSG_AER: {
+      if (m->term >= s->current_term) {
+        update_term_and_voted_for(s, m->term, RGB_NONE, fx); /* :1072-1075 */
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      aer_reply(sv, s->current_term, 0, m->from, fx);       /* :1076-1080 */
+      return 0;
+    }
+    case RGB_MSG_AER_REPLY: {
+      if (m->term > s->current_term) {
+        update_term_and_voted_for(s, m->term, RGB_NONE, fx); /* :1098-1106 */
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        return 0;
+      }
+      fx->flags |= RGB_F_UNHANDLED;
+      return 0;
+    }
+    case RGB_MSG_REQUEST_VOTE: {
+      if (m->term > s->current_term) {
+        update_term_and_voted_for(s, m->term, RGB_NONE, fx); /* :1107-1114 */
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      vote_reply(s->current_term, 0, m->from, fx);          /* :1123-1125 */
+      return 0;
+    }
+    case RGB_MSG_WRITTEN:
+      log_written(&sv->log, m->term, m->a, m->b);           /* :1157-1160 */
+      return 0;
+    default:
+      fx->flags |= RGB_F_UNHANDLED;
+      return 0;
+  }
+}
+
+/* ------------------------------------------------------------- pre_vote clauses -- */
+static int handle_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx, int *reprocess) {
+  oscal *s = &sv->s;
+  switch (m->kind) {
+    case RGB_MSG_AER:
+      if (m->term >= s->current_term) {
+        update_term(s, m->term, fx);                        /* :1192-1197 */
+        s->votes = 0;
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      fx->flags |= RGB_F_UNHANDLED;
+      return 0;
+    case RGB_MSG_REQUEST_VOTE:
+      if (m->term > s->current_term) {
+        update_term(s, m->term, fx);                        /* :1214-1219 */
+        s->votes = 0;
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      fx->flags |= RGB_F_UNHANDLED;
+      return 0;
+    case RGB_MSG_VOTE_RESULT:
+      return 0;                                             /* :1249-1251 */
+    case RGB_MSG_WRITTEN:
+      log_written(&sv->log, m->term, m->a, m->b);           /* :1257-1260 */
+      return 0;
+    default:
+      fx->flags |= RGB_F_UNHANDLED;
+      return 0;
+  }
+}
+
+/* ------------------------------------------------------ await_condition clauses -- */
+static int handle_await_condition(oserver *sv, const rgb_msg *m, ofx *fx, int *reprocess) {
+  oscal *s = &sv->s;
+  switch (m->kind) {
+    case RGB_MSG_REQUEST_VOTE:
+      set_role(s, RGB_ROLE_FOLLOWER, fx);                   /* :1918-1919 */
+      *reprocess = 1;
+      return 0;
+    case RGB_MSG_AWAIT_TIMEOUT: {
+      /* :1932-1945; follower_catchup_cond(_, _Msg, _) -> false :2229-2230: replay the stored
+       * effects [cast reply, record_leader_msg] and return to follower */
+      fx->has_reply = 1;
+      fx->flags |= RGB_F_REPLY | RGB_F_LEADER_MSG;
+      fx->r_term = s->cond_reply[0]; fx->r_next = s->cond_reply[1];
+      fx->r_last = s->cond_reply[2]; fx->r_lterm = s->cond_reply[3];
+      fx->reply_to = s->cond_leader;
+      set_role(s, RGB_ROLE_FOLLOWER, fx);
+      return 0;
+    }
+    case RGB_MSG_WRITTEN:
+      log_written(&sv->log, m->term, m->a, m->b);           /* :1946-1949, no reply */
+      return 0;
+    case RGB_MSG_AER: {
+      /* follower_catchup_cond/3 :2201-2218 */
+      int pred = 0;
+      if (m->term >= s->current_term) {
+        int h = has_log_entry_or_snapshot(&sv->log, m->a, m->b);
+        if (h == HLE_OK) pred = 1;
+        else if (h == HLE_MISMATCH) pred = (s->cond_reason == RGB_COND_MISSING);
+      }
+      if (pred) {
+        set_role(s, RGB_ROLE_FOLLOWER, fx);                 /* :1950-1955 {next_event, Msg} */
+        *reprocess = 1;
+      }
+      return 0;                                             /* false: no effects, state kept */
+    }
+    default:
+      return 0;                                             /* predicate false: stay, no effects */
+  }
+}
+
+/* ------------------------------------------------------------------ dispatcher --- */
+static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
+                        rgb_decision *d, rgb_rpc *rpcs, uint32_t rpc_cap, uint32_t *n_rpcs) {
+  memset(d, 0, sizeof *d);
+  d->server = m->server;
+  d->kind = m->kind;
+  d->reply_to = RGB_NONE;
+  if (m->kind == RGB_MSG_NOP) return;
+  if (m->server >= c->n_servers) { d->flags = RGB_F_UNHANDLED; d->role = 0xFF; return; }
+  oserver *sv = &c->sv[m->server];
+  oscal saved = sv->s;                                      /* a crash leaves the old state */
+  ofx fx;
+  memset(&fx, 0, sizeof fx);
+  fx.reply_to = RGB_NONE;
+  fx.rpcs = rpcs; fx.rpc_cap = rpc_cap; fx.n_rpcs_total = *n_rpcs; fx.msg_index = msg_index;
+  uint32_t rpcs_before = *n_rpcs;
+  int rc = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    int reprocess = 0;
+    switch (sv->s.role) {
+      case RGB_ROLE_FOLLOWER:        rc = handle_follower(sv, m, &fx); break;
+      case RGB_ROLE_LEADER:          rc = handle_leader(c, sv, m->server, m, &fx, &reprocess); break;
+      case RGB_ROLE_CANDIDATE:       rc = handle_candidate(sv, m, &fx, &reprocess); break;
+      case RGB_ROLE_PRE_VOTE:        rc = handle_pre_vote(sv, m, &fx, &reprocess); break;
+      case RGB_ROLE_AWAIT_CONDITION: rc = handle_await_condition(sv, m, &fx, &reprocess); break;
+      default: fx.flags |= RGB_F_UNHANDLED; break;
+    }
+    if (rc || !reprocess) break;
+    fx.flags |= RGB_F_REPROCESSED;                          /* {next_event, Msg}: runs next */
+  }
+  if (rc) {
+    sv->s = saved;
+    d->role = saved.role;
+    d->flags = RGB_F_INVARIANT;
+    d->invariant = (uint32_t)rc;
+    d->commit_index = saved.commit_index;
+    d->last_applied = saved.last_applied;
+    *n_rpcs = rpcs_before;
+    return;
+  }
+  *n_rpcs = fx.n_rpcs_total;
+  d->role = sv->s.role;
+  d->flags = fx.flags;
+  d->n_rpcs = fx.n_rpcs;
+  if (fx.has_reply) {
+    d->reply_to = fx.reply_to;
+    d->reply_term = fx.r_term; d->reply_next_index = fx.r_next;
+    d->reply_last_index = fx.r_last; d->reply_last_term = fx.r_lterm;
+  } else if (fx.flags & RGB_F_WROTE) {
+    d->reply_next_index = fx.w_first; d->reply_last_index = fx.w_last;
+  }
+  d->commit_index = sv->s.commit_index;
+  d->last_applied = sv->s.last_applied;
+}
+
+/* -------------------------------------------------------------------- public ----- */
+static void server_init_empty(oserver *sv, uint32_t n_members, uint32_t self) {
+  /* ra_server:init/1 on an empty log == empty_state/2 of test/ra_server_SUITE.erl:4139-4149:
+   * term 0, log [0:0] written, peers new_peer/0 (src/ra_server.erl:2990-2995) */
+  memset(&sv->s, 0, sizeof sv->s);
+  sv->s.role = RGB_ROLE_FOLLOWER;
+  sv->s.self = (uint8_t)self;
+  sv->s.n_members = (uint8_t)n_members;
+  sv->s.voted_for = RGB_NONE; sv->s.leader_id = RGB_NONE; sv->s.cond_leader = RGB_NONE;
+  sv->s.present_mask = (uint8_t)((1u << n_members) - 1u);
+  sv->s.voter_mask = sv->s.present_mask;
+  sv->s.status_mask = 0xFF;
+  for (unsigned i = 0; i < RGB_MAX_MEMBERS; i++) sv->s.next_index[i] = 1;
+  olog *l = &sv->log;
+  free(l->terms);
+  memset(l, 0, sizeof *l);
+  l->snap_idx = UNDEF; l->snap_term = UNDEF;
+  log_append(l, 0, 0);                                      /* src/ra_log.erl:1637-1647 */
+  l->lw_idx = 0; l->lw_term = 0;
+}
+
+ora_ctx *ora_new(uint32_t n_groups, uint32_t n_members, uint32_t max_pipeline_count,
+                 uint32_t max_aer_batch) {
+  if (n_members == 0 || n_members > RGB_MAX_MEMBERS) return NULL;
+  ora_ctx *c = (ora_ctx *)calloc(1, sizeof *c);
+  if (!c) return NULL;
+  c->n_members = n_members;
+  c->n_servers = n_groups * n_members;
+  c->max_pipeline_count = max_pipeline_count ? max_pipeline_count : RGB_DEFAULT_MAX_PIPELINE_COUNT;
+  c->max_aer_batch = max_aer_batch ? max_aer_batch : RGB_AER_CHUNK_SIZE;
+  c->sv = (oserver *)calloc(c->n_servers ? c->n_servers : 1, sizeof(oserver));
+  if (!c->sv) { free(c); return NULL; }
+  for (uint32_t i = 0; i < c->n_servers; i++) server_init_empty(&c->sv[i], n_members, i % n_members);
+  return c;
+}
+
+void ora_free(ora_ctx *c) {
+  if (!c) return;
+  for (uint32_t i = 0; i < c->n_servers; i++) free(c->sv[i].log.terms);
+  free(c->sv);
+  free(c);
+}
+
+uint32_t ora_n_servers(const ora_ctx *c) { return c->n_servers; }
+
+int ora_set_state(ora_ctx *c, uint32_t first, uint32_t n, const rgb_server_state *in) {
+  if ((uint64_t)first + n > c->n_servers) return RGB_E_INVAL;
+  for (uint32_t k = 0; k < n; k++) {
+    const rgb_server_state *h = &in[k];
+    oserver *sv = &c->sv[first + k];
+    oscal *s = &sv->s;
+    if (h->n_runs > RGB_MAX_RUNS || h->n_members > RGB_MAX_MEMBERS) return RGB_E_INVAL;
+    s->current_term = h->current_term; s->commit_index = h->commit_index;
+    s->last_applied = h->last_applied;
+    memcpy(s->cond_reply, h->cond_reply, sizeof s->cond_reply);
+    memcpy(s->match_index, h->match_index, sizeof s->match_index);
+    memcpy(s->next_index, h->next_index, sizeof s->next_index);
+    memcpy(s->commit_index_sent, h->commit_index_sent, sizeof s->commit_index_sent);
+    s->role = h->role; s->cond_reason = h->cond_reason; s->self = h->self;
+    s->n_members = h->n_members; s->voted_for = h->voted_for; s->leader_id = h->leader_id;
+    s->votes = h->votes; s->present_mask = h->present_mask; s->voter_mask = h->voter_mask;
+    s->status_mask = h->status_mask; s->self_nonvoter = h->self_nonvoter;
+    s->cond_leader = h->cond_leader;
+    olog *l = &sv->log;
+    free(l->terms);
+    memset(l, 0, sizeof *l);
+    l->snap_idx = h->snapshot_index; l->snap_term = h->snapshot_term;
+    l->lw_idx = h->last_written_index; l->lw_term = h->last_written_term;
+    l->last_term = h->last_term;
+    if (h->first_index <= h->last_index) {
+      if (h->n_runs == 0 || h->run_start[0] != h->first_index) return RGB_E_INVAL;
+      l->has_range = 1; l->first = h->first_index; l->last = h->last_index;
+      if (log_reserve(l, l->first) || log_reserve(l, l->last)) return RGB_E_NOMEM;
+      for (unsigned r = 0; r < h->n_runs; r++) {
+        uint64_t a = h->run_start[r];
+        uint64_t b = (r + 1 < h->n_runs) ? h->run_start[r + 1] - 1 : h->last_index;
+        if (b < a || b > h->last_index) return RGB_E_INVAL;
+        for (uint64_t i = a; i <= b; i++) l->terms[i - l->base] = h->run_term[r];
+      }
+    } else {
+      l->has_range = 0; l->first = h->first_index; l->last = h->last_index;
+    }
+  }
+  return RGB_OK;
+}
+
+int ora_get_state(const ora_ctx *c, uint32_t first, uint32_t n, rgb_server_state *out) {
+  if ((uint64_t)first + n > c->n_servers) return RGB_E_INVAL;
+  for (uint32_t k = 0; k < n; k++) {
+    rgb_server_state *h = &out[k];
+    const oserver *sv = &c->sv[first + k];
+    const oscal *s = &sv->s;
+    const olog *l = &sv->log;
+    memset(h, 0, sizeof *h);
+    h->current_term = s->current_term; h->commit_index = s->commit_index;
+    h->last_applied = s->last_applied;
+    log_last_index_term(l, &h->last_index, &h->last_term);
+    h->last_written_index = l->lw_idx; h->last_written_term = l->lw_term;
+    h->snapshot_index = l->snap_idx; h->snapshot_term = l->snap_term;
+    memcpy(h->cond_reply, s->cond_reply, sizeof s->cond_reply);
+    memcpy(h->match_index, s->match_index, sizeof s->match_index);
+    memcpy(h->next_index, s->next_index, sizeof s->next_index);
+    memcpy(h->commit_index_sent, s->commit_index_sent, sizeof s->commit_index_sent);
+    h->role = s->role; h->cond_reason = s->cond_reason; h->self = s->self;
+    h->n_members = s->n_members; h->voted_for = s->voted_for; h->leader_id = s->leader_id;
+    h->votes = s->votes; h->present_mask = s->present_mask; h->voter_mask = s->voter_mask;
+    h->status_mask = s->status_mask; h->self_nonvoter = s->self_nonvoter;
+    h->cond_leader = s->cond_leader;
+    if (l->has_range) {
+      h->first_index = l->first;
+      unsigned nr = 0;
+      int overflow = 0;
+      for (uint64_t i = l->first; i <= l->last; i++) {
+        uint64_t t = l->terms[i - l->base];
+        if (nr == 0 || h->run_term[nr - 1] != t) {
+          if (nr == RGB_MAX_RUNS) { overflow = 1; break; }
+          h->run_start[nr] = i; h->run_term[nr] = t; nr++;
+        }
+      }
+      h->n_runs = (uint8_t)nr;
+      if (overflow) return RGB_E_UNSUPPORTED;
+    } else {
+      h->first_index = h->last_index + 1;
+      h->n_runs = 0;
+    }
+  }
+  return RGB_OK;
+}
+
+int ora_step(ora_ctx *c, const rgb_msg *msgs, uint32_t n, rgb_decision *out,
+             rgb_rpc *rpcs, uint32_t rpc_cap, uint32_t *n_rpcs) {
+  uint32_t nr = 0;
+  for (uint32_t i = 0; i < n; i++)
+    process_one(c, i, &msgs[i], &out[i], rpcs, rpc_cap, &nr);
+  if (n_rpcs) *n_rpcs = nr;
+  return RGB_OK;
+}
+
+/* Parallel form used only for the CPU baseline: a tick holds at most one message per server,
+ * so servers are independent and messages can be processed by any thread.  rpc records are
+ * discarded (counted only).  Compiled with -fopenmp; n_threads <= 0 keeps the default. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int ora_step_parallel(ora_ctx *c, const rgb_msg *msgs, uint32_t n, rgb_decision *out,
+                      int n_threads, uint64_t *n_rpcs_total) {
+  uint64_t total = 0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(static) reduction(+ : total)
+#endif
+  for (int64_t i = 0; i < (int64_t)n; i++) {
+    uint32_t nr = 0;
+    process_one(c, (uint32_t)i, &msgs[i], &out[i], NULL, 0, &nr);
+    total += nr;
+  }
+  if (n_rpcs_total) *n_rpcs_total = total;
+  (void)n_threads;
+  return RGB_OK;
+}
+
+int ora_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* the same canonical-state checksum the device computes (rgb_state_checksum): FNV-1a over the
+ * words of the canonical form; lets full-size runs be compared without downloading state. */
+static uint64_t fnv_word(uint64_t h, uint64_t w) {
+  for (int i = 0; i < 8; i++) { h ^= (w >> (8 * i)) & 0xFFu; h *= 0x100000001B3ull; }
+  return h;
+}
+
+uint64_t ora_server_checksum(const rgb_server_state *h) {
+  uint64_t x = 0xCBF29CE484222325ull;
+  x = fnv_word(x, h->current_term); x = fnv_word(x, h->commit_index);
+  x = fnv_word(x, h->last_applied); x = fnv_word(x, h->last_index);
+  x = fnv_word(x, h->last_term); x = fnv_word(x, h->last_written_index);
+  x = fnv_word(x, h->last_written_term); x = fnv_word(x, h->snapshot_index);
+  x = fnv_word(x, h->snapshot_term); x = fnv_word(x, h->first_index);
+  uint64_t packed = (uint64_t)h->role | ((uint64_t)h->cond_reason << 8) | ((uint64_t)h->self << 16) |
+                    ((uint64_t)h->n_members << 24) | ((uint64_t)h->voted_for << 32) |
+                    ((uint64_t)h->leader_id << 40) | ((uint64_t)h->votes << 48) |
+                    ((uint64_t)h->n_runs << 56);
+  x = fnv_word(x, packed);
+  uint64_t masks = (uint64_t)h->present_mask | ((uint64_t)h->voter_mask << 8) |
+                   ((uint64_t)h->status_mask << 16) | ((uint64_t)h->self_nonvoter << 24);
+  x = fnv_word(x, masks);
+  for (unsigned i = 0; i < h->n_members && i < RGB_MAX_MEMBERS; i++) {
+    x = fnv_word(x, h->match_index[i]); x = fnv_word(x, h->next_index[i]);
+    x = fnv_word(x, h->commit_index_sent[i]);
+  }
+  for (unsigned i = 0; i < h->n_runs && i < RGB_MAX_RUNS; i++) {
+    x = fnv_word(x, h->run_start[i]); x = fnv_word(x, h->run_term[i]);
+  }
+  return x;
+}
+
+size_t ora_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(rgb_msg);
+    case 1: return sizeof(rgb_decision);
+    case 2: return sizeof(rgb_rpc);
+    case 3: return sizeof(rgb_server_state);
+    case 4: return sizeof(rgb_leaderboard_row);
+    case 5: return sizeof(rgb_config);
+    default: return 0;
+  }
+}

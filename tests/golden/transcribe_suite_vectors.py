@@ -1,0 +1,479 @@
+#!/usr/bin/env python3
+"""Known-answer vectors for the ra_gpu_batch hot path, TRANSCRIBED BY HAND from the reference's
+own unit tests (rabbitmq/ra app vsn 3.1.10):
+
+    test/ra_server_SUITE.erl      (state-in / message-in / state-out / effects-out cases)
+    src/ra_server.erl:4225-4238   (agreed_commit_test)
+    test/ra_log_2_SUITE.erl       (real ra_log last_written cursor cases)
+
+The reference is Erlang and cannot be executed in this environment (no OTP), so these vectors
+are transcriptions of what its tests ASSERT, not outputs of running it.  Only facts the
+reference test asserts are recorded as expectations; everything else is left unconstrained.
+Running this script rewrites tests/golden/ra_server_suite_vectors.json.
+
+Vector format
+-------------
+  n_members  cluster size; member names n1..n7 map to member slots 0..6
+  self       name of the server under test
+  init       "empty" = empty_state/2 (SUITE:4139-4149); "base" = base_state/2 (SUITE:4151-4192):
+             CT=5 CI=3 LA=3 leader=n1 log [0:0,1:1,2:3,3:5] all written, every member NI=4 MI=3
+  tweak      overrides applied to the initial state (see tests/vector_runner.py)
+  log_model  "real": authored against src/ra_log.erl; "mem": authored against the fake
+             test/ra_log_memory.erl (asserted facts hold for the real log too)
+  steps      list of {as: ra_state the reference test calls handle_<as>/2 in,
+                      msg: message, expect: asserted facts}
+  msg kinds  aer / aer_reply / request_vote / vote_result / written / pipeline_rpcs /
+             append / await_timeout
+  expect     role; state{field: value}; peers{name:{next_index,match_index}};
+             reply{...} (only the asserted fields) or no_reply; flags_set / flags_clear
+             (names of RGB_F_*); rpcs (exact set when rpcs_exact) each {peer, prev:[i,t],
+             commit, entries:[from,to]}
+"""
+import json
+import os
+
+V = []
+
+
+def vec(id, source, n_members, self, init, steps, tweak=None, log_model="mem", note=None):
+    d = dict(id=id, source=source, n_members=n_members, self=self, init=init,
+             log_model=log_model, steps=steps)
+    if tweak:
+        d["tweak"] = tweak
+    if note:
+        d["note"] = note
+    V.append(d)
+
+
+def aer(term, leader, prev, commit, entries=()):
+    return dict(kind="aer", term=term, **{"from": leader}, prev=list(prev), commit=commit,
+                entries=[list(e) for e in entries])
+
+
+def reply(peer, term, success, next_index, last_index, last_term):
+    return dict(kind="aer_reply", term=term, **{"from": peer}, success=success,
+                next_index=next_index, last_index=last_index, last_term=last_term)
+
+
+def written(term, lo, hi):
+    return dict(kind="written", term=term, range=[lo, hi])
+
+
+def req_vote(term, cand, last):
+    return dict(kind="request_vote", term=term, **{"from": cand}, last=list(last))
+
+
+def vote_result(term, granted, voter="n2"):
+    return dict(kind="vote_result", term=term, granted=granted, **{"from": voter})
+
+
+def step(as_, msg, **expect):
+    return {"as": as_, "msg": msg, "expect": expect}
+
+
+# ---------------------------------------------------------------- A.2 follower AER ----
+vec("F1", "test/ra_server_SUITE.erl:383-456 follower_aer_1", 3, "n1", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(1, 1)]), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=0, last_applied=0)),
+    step("follower", aer(1, "n1", (1, 1), 1, [(2, 1)]), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=1, last_applied=1)),
+    step("follower", written(1, 1, 1), role="follower",
+         state=dict(commit_index=1, last_applied=1),
+         reply=dict(to="n1", next_index=3, last_term=1, last_index=1), effects_only_reply=True),
+    step("follower", aer(1, "n1", (2, 1), 3, [(3, 1)]), role="follower",
+         state=dict(commit_index=3, last_applied=3)),
+    step("follower", written(1, 2, 2), role="follower", state=dict(commit_index=3, last_applied=3),
+         reply=dict(to="n1", next_index=4, last_term=1, last_index=2), effects_only_reply=True),
+    step("follower", aer(1, "n1", (3, 1), 3, []), role="follower",
+         state=dict(commit_index=3, last_applied=3),
+         reply=dict(to="n1", next_index=4, last_term=1, last_index=2)),
+    step("follower", written(1, 3, 3), role="follower", state=dict(commit_index=3, last_applied=3),
+         reply=dict(to="n1", next_index=4, last_term=1, last_index=3), effects_only_reply=True),
+])
+
+vec("F2", "test/ra_server_SUITE.erl:459-489 follower_aer_2", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(1, 1)]), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=0, last_applied=0)),
+    step("follower", written(1, 1, 1), role="follower", state=dict(commit_index=0, last_applied=0),
+         reply=dict(to="n1", next_index=2, last_term=1, last_index=1), effects_only_reply=True),
+    step("follower", aer(1, "n1", (1, 1), 1, []), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=1, last_applied=1)),
+])
+
+vec("F3", "test/ra_server_SUITE.erl:491-556 follower_aer_3", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 1, [(1, 1)]), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=1, last_applied=1)),
+    step("follower", written(1, 1, 1), role="follower", state=dict(commit_index=1, last_applied=1),
+         reply=dict(to="n1", next_index=2, last_term=1, last_index=1), effects_only_reply=True),
+    step("follower", aer(1, "n1", (2, 1), 3, [(3, 1)]), role="await_condition",
+         state=dict(leader_id="n1", current_term=1, commit_index=1, last_applied=1),
+         reply=dict(to="n1", success=False, next_index=2, last_term=1, last_index=1),
+         flags_set=["LEADER_MSG"]),
+    # the reference test feeds the await_condition state straight to handle_follower/2
+    step("follower", aer(1, "n1", (1, 1), 3, [(2, 1), (3, 1), (4, 1)]), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=3, last_applied=3)),
+    step("follower", written(1, 4, 4), role="follower", state=dict(commit_index=3, last_applied=3),
+         reply=dict(to="n1", success=True, next_index=5, last_term=1, last_index=4)),
+    step("follower", aer(1, "n1", (1, 1), 4, [(2, 1), (3, 1), (4, 1)]), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=4, last_applied=4)),
+])
+
+vec("F4", "test/ra_server_SUITE.erl:561-588 follower_aer_4", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 10, [(1, 1), (2, 1), (3, 1), (4, 1)]), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=10, last_applied=4)),
+    step("follower", written(1, 4, 4), role="follower",
+         state=dict(commit_index=10, last_applied=4),
+         reply=dict(to="n1", next_index=5, last_term=1, last_index=4)),
+], note="commit_index is NOT clamped to the log: CI=10, LA=4")
+
+vec("F5", "test/ra_server_SUITE.erl:590-620 follower_aer_5", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 2, [(1, 1), (2, 1), (3, 1), (4, 1)]), role="follower"),
+    step("follower", written(1, 4, 4), role="follower"),
+    step("follower", aer(2, "n5", (3, 1), 3, []), role="follower",
+         reply=dict(to="n5", next_index=4, last_term=1, last_index=3), flags_set=["TRUNCATED"]),
+])
+
+vec("F6", "test/ra_server_SUITE.erl:622-656 follower_aer_6", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 3, [(1, 1), (2, 1), (3, 1), (4, 1)]), role="follower"),
+    step("follower", written(1, 4, 4), role="follower", state=dict(last_applied=3)),
+    step("follower", aer(2, "n5", (3, 1), 3, []), role="follower",
+         reply=dict(to="n5", next_index=4, last_term=1, last_index=3)),
+])
+
+vec("F7", "test/ra_server_SUITE.erl:658-697 follower_aer_7", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 3, [(1, 1), (2, 1), (3, 1), (4, 1)]), role="follower"),
+    step("follower", written(1, 4, 4), role="follower", state=dict(last_applied=3)),
+    step("follower", aer(2, "n5", (3, 1), 4, [(4, 2)]), role="follower"),
+    step("follower", written(2, 4, 4), role="follower", state=dict(last_applied=4),
+         reply=dict(to="n5", next_index=5, last_term=2, last_index=4)),
+])
+
+vec("Fdup", "test/ra_server_SUITE.erl:1292-1323 follower_aer_dupe", 3, "n1", "empty", [
+    step("follower", aer(1, "n2", (0, 0), 1, [(1, 1), (2, 1), (3, 1)]), role="follower",
+         state=dict(leader_id="n2", current_term=1, commit_index=1, last_applied=1)),
+    step("follower", aer(1, "n2", (1, 1), 1, [(2, 1)]), role="follower",
+         state=dict(leader_id="n2", current_term=1, commit_index=1, last_applied=1),
+         reply=dict(to="n2", success=True, next_index=3, last_term=1, last_index=2),
+         effects_only_reply=True),
+], note="not-validated branch: success reply up to max(last_applied, last valid index)")
+
+vec("Fchg", "test/ra_server_SUITE.erl:1325-1368 follower_leader_change_before_written",
+    3, "n3", "empty", [
+        step("follower", aer(1, "n1", (0, 0), 1, [(1, 1), (2, 1)]), role="follower",
+             state=dict(leader_id="n1", current_term=1, commit_index=1, last_applied=1)),
+        step("follower", aer(2, "n2", (0, 0), 1, [(2, 2), (3, 2)]), role="follower",
+             state=dict(leader_id="n2", current_term=2, commit_index=1, last_applied=1)),
+        step("follower", written(1, 1, 2), role="follower", state=dict(leader_id="n2", last_applied=1),
+             reply=dict(to="n2", success=True, term=2, last_index=1, last_term=1),
+             effects_only_reply=True),
+        step("follower", written(2, 2, 3), role="follower", state=dict(leader_id="n2", last_applied=1),
+             reply=dict(to="n2", success=True, term=2, last_index=3, last_term=2),
+             effects_only_reply=True),
+    ])
+
+# ------------------------------------- A.3 follower AER: term checks, mismatch, snapshot ----
+BASE_CI1 = dict(commit_index=1)
+vec("T1-T5", "test/ra_server_SUITE.erl:854-892 follower_handles_append_entries_rpc", 3, "n1", "base",
+    [
+        dict(reset=True, **step("follower", aer(5, "n1", (3, 5), 3, []), role="follower",
+                                 state=dict(leader_id="n1", current_term=5))),
+        dict(reset=True, **step("follower", aer(6, "n1", (3, 5), 3, []), role="follower",
+                                 state=dict(current_term=6),
+                                 reply=dict(to="n1", term=6, success=True, next_index=4,
+                                            last_index=3, last_term=5))),
+        dict(reset=True, **step("follower", aer(4, "n1", (3, 5), 3, []), role="follower",
+                                 reply=dict(to="n1", term=5, success=False),
+                                 effects_only_reply=True)),
+        dict(reset=True, **step("follower", aer(5, "n1", (4, 5), 3, []), role="await_condition",
+                                 reply=dict(to="n1", term=5, success=False),
+                                 flags_set=["LEADER_MSG"])),
+        dict(reset=True, **step("follower", aer(5, "n1", (3, 4), 3, []), role="await_condition",
+                                 reply=dict(to="n1", term=5, success=False),
+                                 flags_set=["LEADER_MSG"])),
+    ], tweak=BASE_CI1, note="each step starts again from the tweaked base state (reset)")
+
+vec("T6", "test/ra_server_SUITE.erl:747-765 follower_aer_term_mismatch", 3, "n1", "base", [
+    step("follower", aer(6, "n1", (3, 6), 3, []), role="await_condition",
+         reply=dict(to="n1", term=6, success=False, next_index=3, last_index=2, last_term=3)),
+], tweak=dict(last_applied=2, commit_index=3))
+
+vec("T7", "test/ra_server_SUITE.erl:818-852 follower_aer_term_mismatch_snapshot", 3, "n1", "base", [
+    step("follower", aer(6, "n1", (3, 6), 3, []), role="await_condition",
+         reply=dict(to="n1", term=6, success=False, next_index=4, last_index=3, last_term=5)),
+], tweak=dict(last_applied=3, commit_index=3, install_snapshot=[3, 5]),
+    note="term of last_applied is served by the snapshot")
+
+vec("T8", "test/ra_server_SUITE.erl:767-816 follower_aer_term_mismatch_at_snapshot", 3, "n1", "base", [
+    step("follower", aer(5, "n1", (3, 5), 3, [(4, 5), (5, 5), (6, 5)]), role="follower"),
+    step("follower", written(5, 4, 6), role="follower",
+         reply=dict(to="n1", term=5, success=True, next_index=7)),
+    step("follower", aer(6, "n2", (3, 5), 3, []), role="follower",
+         state=dict(last_applied=3, commit_index=3),
+         reply=dict(to="n2", term=6, success=True, next_index=4, last_index=3, last_term=5)),
+], tweak=dict(last_applied=3, commit_index=3, install_snapshot=[3, 5]))
+
+vec("T9", "test/ra_server_SUITE.erl:699-745 follower_aer_diverged", 3, "n1", "base", [
+    step("follower", aer(6, "n1", (1, 1), 3, [(2, 3)]), role="follower",
+         state=dict(last_applied=2, commit_index=2),
+         reply=dict(to="n1", success=True, next_index=3)),
+    step("follower", aer(6, "n1", (3, 6), 3, []), role="await_condition",
+         reply=dict(to="n1", success=False, next_index=3)),
+    step("follower", aer(6, "n1", (2, 3), 3, [(3, 6)]), role="follower",
+         state=dict(last_applied=3, commit_index=3), no_reply=True,
+         flags_set=["AUX_EVAL", "LEADER_MSG"]),
+], tweak=dict(last_applied=2, commit_index=2))
+
+vec("T10", "test/ra_server_SUITE.erl:894-912 follower_handles_append_entries_rpc (overwrite)",
+    3, "n1", "base", [
+        step("follower", aer(5, "n1", (1, 1), 2, [(2, 4)]), role="follower"),
+        step("follower", written(4, 2, 2), role="follower",
+             reply=dict(to="n1", term=5, success=True, next_index=3, last_index=2, last_term=4),
+             state=dict(log=[[0, 0], [1, 1], [2, 4]])),
+    ], tweak=dict(commit_index=1, last_applied=1))
+
+vec("T11", "test/ra_server_SUITE.erl:914-931 follower_handles_append_entries_rpc (commit ahead)",
+    3, "n1", "base", [
+        step("follower", aer(5, "n1", (3, 5), 5, [(4, 5)]), role="follower"),
+        step("follower", written(5, 4, 4), role="follower",
+             state=dict(commit_index=5, last_applied=4),
+             reply=dict(to="n1", term=5, success=True, last_index=4, last_term=5)),
+    ], tweak=dict(commit_index=1, last_applied=1))
+
+vec("T12", "test/ra_server_SUITE.erl:3147-3194 snapshotted_follower_received_append_entries",
+    3, "n3", "empty", [
+        step("follower", aer(2, "n1", (3, 2), 4, [(4, 2)]), role="follower"),
+        step("follower", written(2, 4, 4), role="follower",
+             reply=dict(to="n1", success=True), effects_only_reply=True),
+    ], tweak=dict(current_term=2, install_snapshot=[3, 2], last_applied=3, commit_index=3,
+                  leader_id="n1"),
+    note="prev_log matched through the snapshot fallback")
+
+# ------------------------------------------- A.4 await_condition catch-up predicate ----
+AWAIT_TWEAK = dict(commit_index=1, role="await_condition", cond_reason="missing",
+                   cond_reply=[5, 4, 3, 5], cond_leader="n1")
+vec("A4", "test/ra_server_SUITE.erl:934-1001 follower_catchup_condition", 3, "n1", "base", [
+    dict(reset=True, **step("follower", aer(4, "n1", (4, 5), 3, []), role="follower",
+                             reply=dict(success=False), effects_only_reply=True)),
+    dict(reset=True, **step("follower", aer(6, "n1", (3, 4), 3, []), role="await_condition",
+                             reply=dict(success=False), flags_set=["LEADER_MSG"])),
+    dict(reset=True, **step("await_condition", aer(5, "n1", (4, 5), 3, []), role="await_condition",
+                             no_reply=True, flags_clear=["LEADER_MSG", "REPROCESSED", "PERSIST"])),
+    dict(reset=True, **step("await_condition", aer(5, "n1", (3, 5), 3, []), role="follower",
+                             flags_set=["REPROCESSED"])),
+    dict(reset=True, **step("await_condition", written(5, 99, 99), role="await_condition",
+                             no_reply=True)),
+    dict(reset=True, **step("await_condition", req_vote(6, "n2", (3, 5)), role="follower",
+                             flags_set=["REPROCESSED"])),
+    dict(reset=True, **step("await_condition", dict(kind="await_timeout"), role="follower",
+                             reply=dict(to="n1", success=False, next_index=4),
+                             flags_set=["LEADER_MSG"])),
+], tweak=AWAIT_TWEAK,
+    note="state = output of T4 (missing entry at 4); each step restarts from it")
+
+# -------------------------------------------------------- A.5 leader: AER replies ----
+L1_PEERS = dict(n1=dict(next_index=5, match_index=4),
+                n2=dict(next_index=1, match_index=0, commit_index_sent=3),
+                n3=dict(next_index=2, match_index=1))
+vec("L1-L2", "test/ra_server_SUITE.erl:1370-1405 append_entries_reply_success", 3, "n1", "base", [
+    step("leader", reply("n2", 5, True, 4, 3, 5), role="leader",
+         peers=dict(n2=dict(next_index=4, match_index=3)),
+         state=dict(commit_index=3, last_applied=3),
+         flags_set=["PIPELINE", "AUX_EVAL", "APPLIED"], no_reply=True, rpcs=[], rpcs_exact=True),
+    step("leader", dict(kind="pipeline_rpcs"), role="leader",
+         peers=dict(n2=dict(next_index=4, match_index=3)),
+         state=dict(commit_index=3, last_applied=3),
+         rpcs=[dict(peer="n3", term=5, prev=[1, 1], commit=3, entries=[2, 3])], rpcs_exact=True),
+], tweak=dict(commit_index=1, last_applied=1, peers=L1_PEERS))
+
+vec("L3", "test/ra_server_SUITE.erl:1407-1416 append_entries_reply_success (term 7)", 3, "n1", "base", [
+    step("leader", reply("n2", 7, True, 4, 3, 5), role="leader",
+         peers=dict(n2=dict(next_index=4, match_index=3)),
+         state=dict(commit_index=1, last_applied=1, current_term=7)),
+], tweak=dict(commit_index=1, last_applied=1, peers=L1_PEERS, current_term=7),
+    note="Raft 5.4.2: entry 3 has term 5 != current term 7 -> no commit")
+
+vec("L4", "test/ra_server_SUITE.erl:1419-1447 append_entries_reply_no_success", 3, "n1", "base", [
+    step("leader", reply("n2", 5, False, 2, 1, 1), role="leader",
+         peers=dict(n2=dict(next_index=4, match_index=1)),
+         state=dict(commit_index=1, last_applied=1),
+         rpcs=[dict(peer="n3", term=5, prev=[1, 1], commit=1, entries=[2, 3]),
+               dict(peer="n2")], rpcs_exact=True),
+], tweak=dict(commit_index=1, last_applied=1,
+              peers=dict(n1=dict(next_index=1, match_index=0),
+                         n2=dict(next_index=3, match_index=0),
+                         n3=dict(next_index=2, match_index=1, commit_index_sent=1))))
+
+vec("L5", "test/ra_server_SUITE.erl:1449-1462 append_entries_reply_no_success_from_unknown_peer",
+    3, "n1", "base", [
+        step("leader", reply("n2", 5, False, 2, 1, 1), role="leader", state_unchanged=True,
+             no_reply=True, rpcs=[], rpcs_exact=True),
+    ], tweak=dict(commit_index=1, last_applied=1, members_present=["n1"],
+                  peers=dict(n1=dict(next_index=1, match_index=0))))
+
+vec("L6", "test/ra_server_SUITE.erl:3196-3249 leader_received_append_entries_reply_with_stale_last_index",
+    3, "n1", "empty", [
+        step("leader", reply("n2", 2, False, 3, 2, 1), role="leader",
+             peers=dict(n2=dict(next_index=4)),
+             rpcs=[dict(peer="n2", entries=[2, 3])], rpcs_exact=True),
+    ], tweak=dict(current_term=2, commit_index=3, last_applied=4,
+                  log=[[0, 0], [1, 1], [2, 2], [3, 5]], last_written=[3, 5],
+                  peers=dict(n1=dict(next_index=1, match_index=0),
+                             n2=dict(next_index=3, match_index=0),
+                             n3=dict(next_index=4, match_index=3, commit_index_sent=3))),
+    log_model="real")
+
+vec("L7", "test/ra_server_SUITE.erl:1715-1732 leader_does_not_abdicate_to_unknown_peer", 3, "n1", "base", [
+    dict(reset=True, **step("leader", reply("n4", 6, False, 4, 3, 5), role="leader",
+                             state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("leader", req_vote(6, "n4", (3, 5)), role="leader",
+                             state_unchanged=True, no_reply=True)),
+])
+
+vec("L8", "test/ra_server_SUITE.erl:1752-1794 higher_term_detected", 3, "n1", "base", [
+    dict(reset=True, **step("leader", reply("n2", 6, False, 4, 3, 5), role="follower",
+                             state=dict(current_term=6, leader_id=None), no_reply=True,
+                             rpcs=[], rpcs_exact=True)),
+    dict(reset=True, **step("follower", reply("n2", 6, False, 4, 3, 5), role="follower",
+                             state=dict(current_term=6), no_reply=True)),
+    dict(reset=True, **step("candidate", reply("n2", 6, False, 4, 3, 5), role="follower",
+                             state=dict(current_term=6), no_reply=True)),
+    # {follower, #{current_term := 6}, [{next_event, AERpc}]}: the engine runs the next_event
+    # itself (REPROCESSED); role and term are what the reference asserts
+    dict(reset=True, **step("leader", aer(6, "n3", (3, 5), 3, []), role="follower",
+                             state=dict(current_term=6), flags_set=["REPROCESSED"])),
+    dict(reset=True, **step("candidate", aer(6, "n3", (3, 5), 3, []), role="follower",
+                             state=dict(current_term=6), flags_set=["REPROCESSED"])),
+])
+
+vec("L9", "test/ra_server_SUITE.erl:1735-1750 leader_replies_to_append_entries_rpc_with_lower_term",
+    3, "n1", "base", [
+        step("leader", aer(4, "n3", (3, 5), 3, []), role="leader",
+             reply=dict(to="n3", term=5, success=False), effects_only_reply=True,
+             state_unchanged=True),
+    ])
+
+vec("L10", "test/ra_server_SUITE.erl:1203-1290 append_entries_reply_success_promotes_nonvoter",
+    3, "n1", "base", [
+        step("leader", reply("n2", 5, True, 4, 3, 5), role="leader",
+             peers=dict(n2=dict(next_index=4, match_index=3)),
+             state=dict(commit_index=1), flags_set=["PIPELINE"]),
+    ], tweak=dict(commit_index=1, last_applied=1, peers=L1_PEERS, nonvoters=["n2"]),
+    note="non-voter n2 is excluded from match_indexes: [LW=3, n3=1] -> 1")
+
+vec("L11-L12", "test/ra_server_SUITE.erl:2404-2421, 2469-2500 command / written / reply", 3, "n1", "base", [
+    step("leader", dict(kind="append", n=1), role="leader",
+         rpcs=[dict(peer="n3", term=5, prev=[3, 5], commit=3, entries=[4, 4]),
+               dict(peer="n2", term=5, prev=[3, 5], commit=3, entries=[4, 4])], rpcs_exact=True),
+    step("leader", written(5, 4, 4), role="leader", flags_set=["PIPELINE"]),
+    step("leader", reply("n2", 5, True, 5, 4, 5), role="leader",
+         state=dict(commit_index=4, last_applied=4), flags_set=["AUX_EVAL", "APPLIED", "PIPELINE"]),
+])
+
+# ------------------------------------------------------------------- A.6 votes ----
+vec("V1-V3", "test/ra_server_SUITE.erl:1464-1482 follower_request_vote", 3, "n1", "base", [
+    step("follower", req_vote(6, "n2", (3, 5)), role="follower",
+         state=dict(voted_for="n2", current_term=6),
+         reply=dict(vote=True, term=6, success=True), flags_set=["PERSIST"]),
+    step("follower", req_vote(6, "n2", (3, 5)), role="follower",
+         state=dict(voted_for="n2", current_term=6),
+         reply=dict(vote=True, term=6, success=True), flags_clear=["PERSIST"]),
+    step("follower", req_vote(6, "n3", (3, 5)), role="follower",
+         state=dict(voted_for="n2", current_term=6),
+         reply=dict(vote=True, term=6, success=False)),
+])
+
+vec("V4-V7", "test/ra_server_SUITE.erl:1484-1510 follower_request_vote", 3, "n1", "base", [
+    dict(reset=True, **step("follower", req_vote(4, "n2", (3, 5)), role="follower",
+                             state=dict(current_term=5),
+                             reply=dict(vote=True, term=5, success=False))),
+    dict(reset=True, **step("follower", req_vote(6, "n2", (3, 4)), role="follower",
+                             state=dict(current_term=6),
+                             reply=dict(vote=True, term=6, success=False))),
+    dict(reset=True, **step("follower", req_vote(6, "n2", (4, 5)), role="follower",
+                             state=dict(current_term=6, voted_for="n2"),
+                             reply=dict(vote=True, term=6, success=True))),
+])
+
+vec("V7", "test/ra_server_SUITE.erl:1508-1510 follower_request_vote (non-voter)", 3, "n1", "base", [
+    step("follower", req_vote(6, "n2", (3, 5)), role="follower", state_unchanged=True,
+         no_reply=True),
+], tweak=dict(self_nonvoter=True))
+
+vec("V8", "test/ra_server_SUITE.erl:1700-1713 request_vote_rpc_with_lower_term", 3, "n1", "base", [
+    dict(reset=True, **step("candidate", req_vote(5, "n2", (3, 5)), role="candidate",
+                             reply=dict(vote=True, term=6, success=False), state_unchanged=True)),
+    dict(reset=True, **step("leader", req_vote(5, "n2", (3, 5)), role="leader",
+                             reply=dict(vote=True, term=6, success=False), state_unchanged=True)),
+], tweak=dict(current_term=6, voted_for="n1"))
+
+vec("V9", "test/ra_server_SUITE.erl:1779-1787 higher_term_detected (request_vote)", 3, "n1", "base", [
+    dict(reset=True, **step("leader", req_vote(6, "n2", (3, 5)), role="follower",
+                             state=dict(current_term=6), flags_set=["REPROCESSED"])),
+    dict(reset=True, **step("candidate", req_vote(6, "n2", (3, 5)), role="follower",
+                             state=dict(current_term=6), flags_set=["REPROCESSED"])),
+])
+
+vec("V10", "test/ra_server_SUITE.erl:2503-2548 candidate_election", 5, "n1", "base", [
+    step("candidate", vote_result(6, True, "n2"), role="candidate", state=dict(votes=2)),
+    step("candidate", vote_result(6, False, "n3"), role="candidate", state=dict(votes=2)),
+    dict(fork=True, **step("candidate", vote_result(7, False, "n3"), role="follower",
+                            state=dict(current_term=7))),
+    step("candidate", vote_result(6, True, "n4"), role="leader",
+         peers=dict(n2=dict(next_index=4, match_index=0), n3=dict(next_index=4, match_index=0),
+                    n4=dict(next_index=4, match_index=0), n5=dict(next_index=4, match_index=0)),
+         flags_set=["BECAME_LEADER"]),
+], tweak=dict(current_term=6, votes=1),
+    note="5 members: quorum 3; a fork step does not carry its state forward")
+
+# -------------------------------------------- A.7 real-log last_written cursor ----
+vec("R1", "test/ra_log_2_SUITE.erl:189-211 (driven through follower AERs)", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1)]), role="follower"),
+    step("follower", written(1, 1, 2), role="follower",
+         state=dict(last_written=[2, 1])),
+    step("follower", aer(2, "n1", (0, 0), 0, [(1, 2)]), role="follower",
+         state=dict(last_written=[0, 0], last_index=1, last_term=2)),
+], log_model="real", note="overwrite lowers last_written immediately: min(first-1, LW)")
+
+vec("R2", "test/ra_log_2_SUITE.erl:213-265 (driven through follower AERs)", 3, "n2", "empty", [
+    step("follower", aer(2, "n1", (10, 1), 10, [(11, 2), (12, 2), (13, 2), (14, 2), (15, 2)]),
+         role="follower"),
+    step("follower", written(2, 11, 15), role="follower", state=dict(last_written=[15, 2])),
+    step("follower", aer(3, "n1", (12, 2), 10, [(13, 3)]), role="follower",
+         state=dict(last_written=[12, 2], last_index=13, last_term=3)),
+], tweak=dict(current_term=2, install_snapshot=[10, 1], last_applied=10, commit_index=10),
+    log_model="real")
+
+vec("R3", "test/ra_log_2_SUITE.erl:267-293 (driven through follower AERs)", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1)]), role="follower"),
+    step("follower", aer(2, "n1", (0, 0), 0, [(1, 2)]), role="follower",
+         state=dict(last_index=1, last_term=2)),
+    step("follower", aer(2, "n1", (1, 2), 0, [(2, 2)]), role="follower"),
+    step("follower", written(1, 1, 2), role="follower", state=dict(last_written=[0, 0]),
+         no_reply=True),
+    step("follower", written(2, 1, 2), role="follower", state=dict(last_written=[2, 2])),
+], log_model="real")
+
+vec("R4", "test/ra_log_2_SUITE.erl:295-327 (driven through follower AERs)", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1)]), role="follower"),
+    step("follower", aer(3, "n1", (1, 1), 0, []), role="follower",
+         state=dict(last_written=[0, 0], last_index=1, last_term=1), flags_set=["TRUNCATED"]),
+    step("follower", aer(3, "n1", (1, 1), 0, [(2, 3), (3, 3)]), role="follower"),
+    step("follower", written(1, 1, 2), role="follower", state=dict(last_written=[1, 1])),
+    step("follower", written(3, 2, 3), role="follower", state=dict(last_written=[3, 3])),
+], log_model="real")
+
+AGREED_COMMIT = [([4], 4), ([4, 3], 3), ([4, 4, 4], 4), ([4, 4, 3], 4), ([3, 4, 4], 4),
+                 ([4, 2, 3], 3)]
+
+if __name__ == "__main__":
+    out = dict(
+        reference="rabbitmq/ra 3.1.10",
+        transcribed_from=["test/ra_server_SUITE.erl", "src/ra_server.erl:4225-4238",
+                          "test/ra_log_2_SUITE.erl"],
+        agreed_commit=[dict(indexes=i, expected=e) for i, e in AGREED_COMMIT],
+        vectors=V)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                        "ra_server_suite_vectors.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"wrote {len(V)} vectors, {sum(len(v['steps']) for v in V)} steps -> {path}")
