@@ -1,0 +1,465 @@
+/*
+ * rgb_api.hip -- the C ABI of include/ra_gpu_batch.h on top of the HIP kernels.
+ *
+ * Host path (what the Erlang NIF drives): rgb_submit copies the caller's messages into a
+ * slot of a pinned staging ring, then enqueues  H2D -> transition kernel(s) -> D2H  on the
+ * context's stream and returns; rgb_collect waits on the slot's event and hands decisions back
+ * in submission order.  Messages addressed to the same server inside one batch are serialised
+ * into sub-ticks (round r holds every server's r-th message), one kernel launch per round.
+ *
+ * There is no CPU fallback: without a HIP device rgb_open fails with RGB_E_NODEVICE.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rgb_internal.h"
+
+struct rgb_slot {
+  rgb_msg *h_msgs = nullptr;        /* pinned */
+  rgb_decision *h_dec = nullptr;    /* pinned */
+  u32 *h_count = nullptr;           /* pinned */
+  rgb_msg *d_msgs = nullptr;
+  rgb_decision *d_dec = nullptr;
+  rgb_rpc *d_rpcs = nullptr;
+  u32 *d_count = nullptr;
+  std::vector<u32> perm;            /* device position -> submission index */
+  u32 n = 0;
+  uint64_t tick = 0;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+};
+
+struct rgb_ctx {
+  rgb_config cfg;
+  rgb_dev dev;
+  hipStream_t stream = nullptr;
+  int last_hip = 0;
+  bool registered = false;
+  /* state transfer staging */
+  rgb_server_state *d_stage = nullptr;
+  rgb_server_state *h_stage = nullptr;   /* pinned */
+  u32 stage_cap = 0;
+  /* ring */
+  std::vector<rgb_slot> ring;
+  u32 head = 0, tail = 0, in_flight = 0;
+  u32 rpc_cap = 0;
+  std::vector<rgb_rpc> h_rpc_tmp;
+  /* sub-tick scheduling scratch */
+  std::vector<uint16_t> seen;
+  std::vector<u32> touched;
+  std::vector<u32> round_of;
+  /* snapshot / checksum scratch */
+  rgb_leaderboard_row *d_rows = nullptr;
+  u64 *d_sums = nullptr;
+};
+
+#define HIPCHK(ctx, expr)                          \
+  do {                                             \
+    hipError_t e__ = (expr);                       \
+    if (e__ != hipSuccess) {                       \
+      (ctx)->last_hip = (int)e__;                  \
+      return RGB_E_HIP;                            \
+    }                                              \
+  } while (0)
+
+extern "C" {
+
+uint32_t rgb_abi_version(void) { return RGB_ABI_VERSION; }
+
+size_t rgb_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(rgb_msg);
+    case 1: return sizeof(rgb_decision);
+    case 2: return sizeof(rgb_rpc);
+    case 3: return sizeof(rgb_server_state);
+    case 4: return sizeof(rgb_leaderboard_row);
+    case 5: return sizeof(rgb_config);
+    default: return 0;
+  }
+}
+
+const char *rgb_strerror(int code) {
+  switch (code) {
+    case RGB_OK: return "ok";
+    case RGB_E_INVAL: return "invalid argument";
+    case RGB_E_NOMEM: return "out of memory";
+    case RGB_E_HIP: return "HIP runtime error (see rgb_last_hip_error)";
+    case RGB_E_STATE: return "call out of order";
+    case RGB_E_FULL: return "staging ring full";
+    case RGB_E_EMPTY: return "nothing submitted";
+    case RGB_E_UNSUPPORTED: return "unsupported";
+    case RGB_E_NODEVICE: return "no HIP device (there is no CPU fallback)";
+    default: return "unknown error";
+  }
+}
+
+void rgb_default_config(rgb_config *cfg) {
+  if (!cfg) return;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->abi_version = RGB_ABI_VERSION;
+  cfg->device = 0;
+  cfg->max_runs = 8;
+  cfg->ring_slots = 4;
+  cfg->ring_capacity = 65536;
+  cfg->max_pipeline_count = RGB_DEFAULT_MAX_PIPELINE_COUNT;
+  cfg->max_aer_batch = RGB_AER_CHUNK_SIZE;
+  cfg->flags = 0;
+}
+
+int rgb_last_hip_error(const rgb_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+
+static void free_slot(rgb_slot &s) {
+  if (s.h_msgs) (void)hipHostFree(s.h_msgs);
+  if (s.h_dec) (void)hipHostFree(s.h_dec);
+  if (s.h_count) (void)hipHostFree(s.h_count);
+  if (s.d_msgs) (void)hipFree(s.d_msgs);
+  if (s.d_dec) (void)hipFree(s.d_dec);
+  if (s.d_rpcs) (void)hipFree(s.d_rpcs);
+  if (s.d_count) (void)hipFree(s.d_count);
+  if (s.done) (void)hipEventDestroy(s.done);
+  s = rgb_slot();
+}
+
+void rgb_close(rgb_ctx *ctx) {
+  if (!ctx) return;
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto &s : ctx->ring) free_slot(s);
+  if (ctx->dev.hot) (void)hipFree(ctx->dev.hot);
+  if (ctx->dev.peers) (void)hipFree(ctx->dev.peers);
+  if (ctx->dev.runs) (void)hipFree(ctx->dev.runs);
+  if (ctx->dev.cond) (void)hipFree(ctx->dev.cond);
+  if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->d_rows) (void)hipFree(ctx->d_rows);
+  if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int rgb_open(const rgb_config *cfg_in, rgb_ctx **out) {
+  if (!out) return RGB_E_INVAL;
+  *out = nullptr;
+  rgb_config cfg;
+  if (cfg_in) cfg = *cfg_in; else rgb_default_config(&cfg);
+  if (cfg.abi_version != RGB_ABI_VERSION) return RGB_E_INVAL;
+  if (cfg.max_runs < 2 || cfg.max_runs > RGB_MAX_RUNS) return RGB_E_INVAL;
+  if (cfg.ring_slots < 1 || cfg.ring_slots > 64 || cfg.ring_capacity < 1) return RGB_E_INVAL;
+  if (cfg.max_pipeline_count == 0) cfg.max_pipeline_count = RGB_DEFAULT_MAX_PIPELINE_COUNT;
+  if (cfg.max_aer_batch == 0) cfg.max_aer_batch = RGB_AER_CHUNK_SIZE;
+  if (cfg.max_aer_batch > 65535) return RGB_E_INVAL;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return RGB_E_NODEVICE;
+  if (cfg.device < 0 || cfg.device >= ndev) return RGB_E_INVAL;
+  rgb_ctx *ctx = new (std::nothrow) rgb_ctx();
+  if (!ctx) return RGB_E_NOMEM;
+  ctx->cfg = cfg;
+  memset(&ctx->dev, 0, sizeof ctx->dev);
+  e = hipSetDevice(cfg.device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { ctx->last_hip = (int)e; delete ctx; return RGB_E_HIP; }
+  *out = ctx;
+  return RGB_OK;
+}
+
+uint32_t rgb_n_servers(const rgb_ctx *ctx) { return ctx ? ctx->dev.n_servers : 0; }
+
+static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
+  const u32 cap = ctx->cfg.ring_capacity;
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_msgs, (size_t)cap * sizeof(rgb_msg), hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_dec, (size_t)cap * sizeof(rgb_decision), hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_count, sizeof(u32), hipHostMallocDefault));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_msgs, (size_t)cap * sizeof(rgb_msg)));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_dec, (size_t)cap * sizeof(rgb_decision)));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc)));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_count, sizeof(u32)));
+  HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  return RGB_OK;
+}
+
+int rgb_upload_state(rgb_ctx *ctx, uint32_t first, uint32_t n, const rgb_server_state *in);
+
+int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
+  if (!ctx) return RGB_E_INVAL;
+  if (ctx->registered) return RGB_E_STATE;
+  if (n_members < 1 || n_members > RGB_MAX_MEMBERS || n_groups < 1) return RGB_E_INVAL;
+  const uint64_t S64 = (uint64_t)n_groups * n_members;
+  if (S64 > 0x7FFFFFFFull) return RGB_E_INVAL;
+  const u32 S = (u32)S64;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  rgb_dev &d = ctx->dev;
+  d.n_servers = S; d.n_members = n_members; d.max_runs = ctx->cfg.max_runs;
+  d.peer_stride = rgb_peer_stride(n_members);
+  d.max_pipeline_count = ctx->cfg.max_pipeline_count;
+  d.max_aer_batch = ctx->cfg.max_aer_batch;
+  HIPCHK(ctx, hipMalloc((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64)));
+  HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));
+  HIPCHK(ctx, hipMalloc((void **)&d.runs, (size_t)S * d.max_runs * 2 * sizeof(u64)));
+  HIPCHK(ctx, hipMalloc((void **)&d.cond, (size_t)S * 4 * sizeof(u64)));
+  HIPCHK(ctx, hipMemsetAsync(d.runs, 0, (size_t)S * d.max_runs * 2 * sizeof(u64), ctx->stream));
+  ctx->stage_cap = S < 16384u ? S : 16384u;
+  HIPCHK(ctx, hipMalloc((void **)&ctx->d_stage, (size_t)ctx->stage_cap * sizeof(rgb_server_state)));
+  HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stage, (size_t)ctx->stage_cap * sizeof(rgb_server_state),
+                            hipHostMallocDefault));
+  HIPCHK(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)n_groups * sizeof(rgb_leaderboard_row)));
+  HIPCHK(ctx, hipMalloc((void **)&ctx->d_sums, (size_t)S * sizeof(u64)));
+  ctx->rpc_cap = ctx->cfg.ring_capacity * (n_members > 1 ? n_members - 1 : 1);
+  ctx->ring.resize(ctx->cfg.ring_slots);
+  for (auto &s : ctx->ring) {
+    int rc = alloc_slot(ctx, s);
+    if (rc) return rc;
+  }
+  ctx->seen.assign(S, 0);
+  ctx->registered = true;
+  /* every server starts as ra_server:init/1 on an empty log (empty_state of the reference
+   * tests, test/ra_server_SUITE.erl:4139-4149; new_peer/0 src/ra_server.erl:2990-2995) */
+  std::vector<rgb_server_state> init(ctx->stage_cap);
+  for (u32 base = 0; base < S; base += ctx->stage_cap) {
+    u32 cnt = S - base < ctx->stage_cap ? S - base : ctx->stage_cap;
+    for (u32 k = 0; k < cnt; ++k) {
+      rgb_server_state &h = init[k];
+      memset(&h, 0, sizeof h);
+      h.snapshot_index = RGB_UNDEF; h.snapshot_term = RGB_UNDEF;
+      for (unsigned i = 0; i < RGB_MAX_MEMBERS; ++i) h.next_index[i] = 1;
+      h.role = RGB_ROLE_FOLLOWER; h.self = (uint8_t)((base + k) % n_members);
+      h.n_members = (uint8_t)n_members; h.voted_for = RGB_NONE; h.leader_id = RGB_NONE;
+      h.cond_leader = RGB_NONE; h.n_runs = 1;
+      h.present_mask = (uint8_t)((1u << n_members) - 1u); h.voter_mask = h.present_mask;
+      h.status_mask = 0xFF;
+    }
+    int rc = rgb_upload_state(ctx, base, cnt, init.data());
+    if (rc) return rc;
+  }
+  return RGB_OK;
+}
+
+static int validate_state(const rgb_ctx *ctx, const rgb_server_state &h) {
+  if (h.n_members != ctx->dev.n_members) return RGB_E_INVAL;
+  if (h.self >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
+  if (h.role > RGB_ROLE_AWAIT_CONDITION || h.cond_reason > RGB_COND_TERM_MISMATCH) return RGB_E_INVAL;
+  if (h.n_runs > RGB_MAX_RUNS || h.votes > 15) return RGB_E_INVAL;
+  if (h.voted_for != RGB_NONE && h.voted_for >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
+  if (h.leader_id != RGB_NONE && h.leader_id >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
+  if (h.cond_leader != RGB_NONE && h.cond_leader >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
+  if (h.first_index <= h.last_index) {
+    if (h.n_runs == 0 || h.run_start[0] != h.first_index) return RGB_E_INVAL;
+    for (unsigned r = 1; r < h.n_runs; ++r)
+      if (!(h.run_start[r] > h.run_start[r - 1] && h.run_start[r] <= h.last_index)) return RGB_E_INVAL;
+    if (h.run_term[h.n_runs - 1] != h.last_term) return RGB_E_INVAL;
+  }
+  return RGB_OK;
+}
+
+int rgb_upload_state(rgb_ctx *ctx, uint32_t first, uint32_t n, const rgb_server_state *in) {
+  if (!ctx || (!in && n)) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
+  for (u32 k = 0; k < n; ++k) {
+    int rc = validate_state(ctx, in[k]);
+    if (rc) return rc;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  for (u32 base = 0; base < n; base += ctx->stage_cap) {
+    u32 cnt = n - base < ctx->stage_cap ? n - base : ctx->stage_cap;
+    memcpy(ctx->h_stage, in + base, (size_t)cnt * sizeof(rgb_server_state));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, (size_t)cnt * sizeof(rgb_server_state),
+                               hipMemcpyHostToDevice, ctx->stream));
+    int rc = rgb_launch_pack(ctx->dev, ctx->d_stage, first + base, cnt, ctx->stream);
+    if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return RGB_OK;
+}
+
+int rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_state *out) {
+  if (!ctx || (!out && n)) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  for (u32 base = 0; base < n; base += ctx->stage_cap) {
+    u32 cnt = n - base < ctx->stage_cap ? n - base : ctx->stage_cap;
+    int rc = rgb_launch_unpack(ctx->dev, ctx->d_stage, first + base, cnt, ctx->stream);
+    if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_stage, (size_t)cnt * sizeof(rgb_server_state),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out + base, ctx->h_stage, (size_t)cnt * sizeof(rgb_server_state));
+  }
+  return RGB_OK;
+}
+
+static int validate_msg(const rgb_ctx *ctx, const rgb_msg &m) {
+  if (m.kind > RGB_MSG_AWAIT_TIMEOUT) return RGB_E_INVAL;
+  if (m.kind == RGB_MSG_NOP) return RGB_OK;
+  if (m.server >= ctx->dev.n_servers) return RGB_E_INVAL;
+  if (m.from != RGB_NONE && m.from >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
+  if (m.kind == RGB_MSG_AER && m.n_run0 > m.n_entries) return RGB_E_INVAL;
+  if (m.kind == RGB_MSG_WRITTEN && m.a > m.b) return RGB_E_INVAL;
+  return RGB_OK;
+}
+
+int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
+  if (!ctx || (!msgs && n)) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  if (n > ctx->cfg.ring_capacity) return RGB_E_INVAL;
+  if (ctx->in_flight == ctx->ring.size()) return RGB_E_FULL;
+  for (u32 i = 0; i < n; ++i) {
+    int rc = validate_msg(ctx, msgs[i]);
+    if (rc) return rc;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  rgb_slot &s = ctx->ring[ctx->head];
+  /* sub-tick rounds: round r = every server's r-th message of this batch, in order */
+  ctx->round_of.resize(n);
+  ctx->touched.clear();
+  u32 n_rounds = n ? 1 : 0;
+  for (u32 i = 0; i < n; ++i) {
+    u32 r = 0;
+    if (msgs[i].kind != RGB_MSG_NOP) {
+      uint16_t &c = ctx->seen[msgs[i].server];
+      if (c == 0) ctx->touched.push_back(msgs[i].server);
+      r = c;
+      if (c == 0xFFFF) { for (u32 t : ctx->touched) ctx->seen[t] = 0; return RGB_E_UNSUPPORTED; }
+      c++;
+    }
+    ctx->round_of[i] = r;
+    if (r + 1 > n_rounds) n_rounds = r + 1;
+  }
+  for (u32 t : ctx->touched) ctx->seen[t] = 0;
+  std::vector<u32> start(n_rounds + 1, 0);
+  for (u32 i = 0; i < n; ++i) start[ctx->round_of[i] + 1]++;
+  for (u32 r = 0; r < n_rounds; ++r) start[r + 1] += start[r];
+  s.perm.resize(n);
+  {
+    std::vector<u32> pos(start.begin(), start.end() - (n_rounds ? 1 : 0));
+    for (u32 i = 0; i < n; ++i) {
+      u32 p = pos[ctx->round_of[i]]++;
+      s.perm[p] = i;
+      s.h_msgs[p] = msgs[i];
+    }
+  }
+  s.n = n; s.tick = tick;
+  *s.h_count = 0;
+  if (n) {
+    HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice,
+                               ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(s.d_count, 0, sizeof(u32), ctx->stream));
+    for (u32 r = 0; r < n_rounds; ++r) {
+      u32 off = start[r], cnt = start[r + 1] - start[r];
+      int rc = rgb_launch_tick(ctx->dev, s.d_msgs + off, cnt, s.d_dec + off, s.d_rpcs, ctx->rpc_cap,
+                               s.d_count, off, ctx->stream);
+      if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(s.h_count, s.d_count, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
+  s.busy = true;
+  ctx->head = (ctx->head + 1) % (u32)ctx->ring.size();
+  ctx->in_flight++;
+  return RGB_OK;
+}
+
+int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, rgb_rpc *rpc_out,
+                uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out) {
+  if (!ctx) return RGB_E_INVAL;
+  if (n_out) *n_out = 0;
+  if (n_rpc_out) *n_rpc_out = 0;
+  if (ctx->in_flight == 0) return RGB_E_EMPTY;
+  rgb_slot &s = ctx->ring[ctx->tail];
+  if (s.n > cap || (s.n && !out)) return RGB_E_INVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  HIPCHK(ctx, hipEventSynchronize(s.done));
+  for (u32 p = 0; p < s.n; ++p) out[s.perm[p]] = s.h_dec[p];
+  u32 n_rpc = *s.h_count;
+  u32 avail = n_rpc < ctx->rpc_cap ? n_rpc : ctx->rpc_cap;
+  if (avail && rpc_out) {
+    u32 take = avail < rpc_cap ? avail : rpc_cap;
+    ctx->h_rpc_tmp.resize(take);
+    HIPCHK(ctx, hipMemcpy(ctx->h_rpc_tmp.data(), s.d_rpcs, (size_t)take * sizeof(rgb_rpc),
+                          hipMemcpyDeviceToHost));
+    for (u32 k = 0; k < take; ++k) {
+      rgb_rpc r = ctx->h_rpc_tmp[k];
+      if (r.msg_index < s.n) r.msg_index = s.perm[r.msg_index];
+      rpc_out[k] = r;
+    }
+  }
+  if (n_out) *n_out = s.n;
+  if (n_rpc_out) *n_rpc_out = n_rpc;        /* may exceed rpc_cap: the caller sees the overflow */
+  if (tick_out) *tick_out = s.tick;
+  s.busy = false;
+  ctx->tail = (ctx->tail + 1) % (u32)ctx->ring.size();
+  ctx->in_flight--;
+  return RGB_OK;
+}
+
+int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t n_per_tick, uint32_t n_ticks,
+                         void *d_decisions, void *d_rpcs, uint32_t rpc_cap, void *d_rpc_count,
+                         void *stream) {
+  if (!ctx || !d_msgs || !d_decisions) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  void *st = stream ? stream : (void *)ctx->stream;
+  const rgb_msg *m = (const rgb_msg *)d_msgs;
+  rgb_decision *d = (rgb_decision *)d_decisions;
+  for (u32 t = 0; t < n_ticks; ++t) {
+    size_t off = (size_t)t * n_per_tick;
+    int rc = rgb_launch_tick(ctx->dev, m + off, n_per_tick, d + off, (rgb_rpc *)d_rpcs, rpc_cap,
+                             (u32 *)d_rpc_count, (u32)off, st);
+    if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  }
+  return RGB_OK;
+}
+
+int rgb_snapshot_device(rgb_ctx *ctx, void *d_rows, void *stream) {
+  if (!ctx || !d_rows) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  void *st = stream ? stream : (void *)ctx->stream;
+  int rc = rgb_launch_leaderboard(ctx->dev, (rgb_leaderboard_row *)d_rows, st);
+  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  return RGB_OK;
+}
+
+int rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out) {
+  if (!ctx || !out) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  int rc = rgb_snapshot_device(ctx, ctx->d_rows, ctx->stream);
+  if (rc) return rc;
+  u32 g = ctx->dev.n_servers / ctx->dev.n_members;
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_rows, (size_t)g * sizeof(rgb_leaderboard_row), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return RGB_OK;
+}
+
+int rgb_state_checksum(rgb_ctx *ctx, uint32_t first, uint32_t n, uint64_t *out) {
+  if (!ctx || !out) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  int rc = rgb_launch_checksum(ctx->dev, first, n, ctx->d_sums, ctx->stream);
+  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  std::vector<u64> sums(n);
+  HIPCHK(ctx, hipMemcpyAsync(sums.data(), ctx->d_sums, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  /* checksum of checksums: position-weighted sum mod 2^64 */
+  u64 acc = 0;
+  for (u32 k = 0; k < n; ++k) acc += sums[k] * (2ull * (u64)(first + k) + 1ull);
+  *out = acc;
+  return RGB_OK;
+}
+
+int rgb_synchronize(rgb_ctx *ctx) {
+  if (!ctx) return RGB_E_INVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return RGB_OK;
+}
+
+}  /* extern "C" */

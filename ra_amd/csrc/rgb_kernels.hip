@@ -1,0 +1,1177 @@
+/*
+ * rgb_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X): the batched Raft
+ * append/vote transition and its support kernels.  Integer/index work, HBM-bound: no MFMA.
+ *
+ * rgb_tick_kernel<N>: one lane per inbound message; a tick carries at most one message per
+ * server, so lanes never share state.  Per lane: 4x16-B loads of the message, 7x16-B loads
+ * of the server's hot line, lazily the peers line (leader-side messages) and term-run probes
+ * (log-matching repair), the transition itself in registers, then 16-B stores of whatever
+ * changed and of the 64-B decision.  Outbound append_entries_rpc descriptors are compacted
+ * through one wave-aggregated atomic per wave (the compiler folds the per-lane atomicAdd into
+ * a ballot/mbcnt + one atomic).
+ *
+ * Semantics restate (independently of oracle/) the reference clauses cited per function:
+ *   src/ra_server.erl handle_leader/2 :530-1040, handle_candidate/2 :1043-1190,
+ *   handle_pre_vote/2 :1192-1279, handle_follower/2 :1281-1657,
+ *   handle_await_condition/2 :1916-1959, plus the ra_log cursor rules of src/ra_log.erl.
+ */
+#include <hip/hip_runtime.h>
+#include "rgb_internal.h"
+
+#define UNDEF 0xFFFFFFFFFFFFFFFFull
+#define SLOT_NONE4 0xFu
+
+namespace {
+
+__device__ __forceinline__ u64 pk_get(u64 pk, int sh, int w) { return (pk >> sh) & ((1ull << w) - 1ull); }
+__device__ __forceinline__ u64 pk_set(u64 pk, int sh, int w, u64 v) {
+  const u64 m = ((1ull << w) - 1ull) << sh;
+  return (pk & ~m) | ((v << sh) & m);
+}
+__device__ __forceinline__ unsigned slot8to4(unsigned s) { return s >= 8u ? SLOT_NONE4 : s; }
+__device__ __forceinline__ unsigned slot4to8(unsigned s) { return s >= 8u ? (unsigned)RGB_NONE : s; }
+
+/* Everything one lane needs for one message: the server's hot line in registers, the message,
+ * the effects being accumulated and the pending (uncommitted) log-table edits. */
+struct Lane {
+  /* hot line */
+  u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt;
+  /* message */
+  u32 server, n_entries, n_run0;
+  unsigned kind, from, mflags, gap;
+  u64 term, a, b, c, run0_term, run1_term;
+  /* device */
+  const u64 *runs;       /* this server's run table (start,term pairs) */
+  u64 *peers;            /* this server's peers row                    */
+  u32 max_runs;
+  /* effects */
+  u32 flags;
+  u32 inv;
+  bool has_reply;
+  unsigned reply_to;
+  u64 r_term, r_next, r_last, r_lterm;
+  u64 w_first, w_last;
+  /* pending run-table edits: n_runs is the NEW count; the last `push_cnt` runs are not in
+   * memory yet: (ps0,pt0) then (lrs,lrt) */
+  unsigned n_runs;
+  unsigned push_cnt;
+  u64 ps0, pt0;
+  bool cond_dirty;
+  u64 cr0, cr1, cr2, cr3;
+  /* pending peer edit (leader): one peer slot may have new match/next before commit */
+  bool peers_loaded;
+};
+
+__device__ __forceinline__ bool range_nonempty(const Lane &L) { return L.first <= L.li; }
+
+/* ra_log:fetch_term/2 (src/ra_log.erl:1186-1200): defined only inside the range */
+__device__ u64 fetch_term(const Lane &L, u64 idx) {
+  if (!(range_nonempty(L) && idx >= L.first && idx <= L.li)) return UNDEF;
+  if (idx >= L.lrs) return L.lrt;
+  /* older runs are all in memory (only the newest may be pending) */
+  int k = (int)L.n_runs - 2;
+  if (L.push_cnt == 2) {
+    if (idx >= L.ps0) return L.pt0;
+    k -= 1;
+  }
+  for (; k >= 0; --k) {
+    u64 s = L.runs[2 * k];
+    if (idx >= s) return L.runs[2 * k + 1];
+  }
+  return UNDEF;
+}
+
+/* ra_server:fetch_term/2 with the snapshot fallback (src/ra_server.erl:3185-3196) */
+__device__ __forceinline__ u64 srv_fetch_term(const Lane &L, u64 idx) {
+  u64 t = fetch_term(L, idx);
+  if (t == UNDEF && L.si != UNDEF && L.si == idx) return L.st;
+  return t;
+}
+
+/* index of the run holding idx (largest k with start_k <= idx), -1 if none.  Only called
+ * before any edit of this message is pending. */
+__device__ int find_run(const Lane &L, u64 idx) {
+  if (L.n_runs == 0) return -1;
+  if (idx >= L.lrs) return (int)L.n_runs - 1;
+  for (int k = (int)L.n_runs - 2; k >= 0; --k)
+    if (idx >= L.runs[2 * k]) return k;
+  return -1;
+}
+
+/* ra_log:last_index_term/1 (src/ra_log.erl:830-835) is simply (L.li, L.lt): an empty range
+ * keeps them equal to the snapshot's, see rgb_server_state. */
+
+/* ra_log:next_index/1 (src/ra_log.erl:1166-1174) */
+__device__ __forceinline__ u64 next_log_index(const Lane &L) {
+  if (range_nonempty(L)) return L.li + 1;
+  if (L.si != UNDEF) return L.si + 1;
+  return 0;
+}
+
+enum { HLE_OK = 0, HLE_MISMATCH = 1, HLE_MISSING = 2 };
+/* has_log_entry_or_snapshot/3 (src/ra_server.erl:3168-3183) */
+__device__ int has_log_entry_or_snapshot(const Lane &L, u64 idx, u64 term) {
+  u64 t = fetch_term(L, idx);
+  if (t == UNDEF) {
+    if (L.si != UNDEF && L.si == idx) return L.st == term ? HLE_OK : HLE_MISMATCH;
+    return HLE_MISSING;
+  }
+  return t == term ? HLE_OK : HLE_MISMATCH;
+}
+
+/* ---- state word helpers ---- */
+__device__ __forceinline__ unsigned role_of(const Lane &L) { return (unsigned)pk_get(L.pk, PK_ROLE_SH, 3); }
+__device__ __forceinline__ unsigned self_of(const Lane &L) { return (unsigned)pk_get(L.pk, PK_SELF_SH, 4); }
+__device__ __forceinline__ bool present(const Lane &L, unsigned i) {
+  return i < 8u && ((L.pk >> (PK_PRESENT_SH + i)) & 1ull);
+}
+__device__ __forceinline__ bool voter(const Lane &L, unsigned i) { return (L.pk >> (PK_VOTER_SH + i)) & 1ull; }
+__device__ __forceinline__ bool status_normal(const Lane &L, unsigned i) { return (L.pk >> (PK_STATUS_SH + i)) & 1ull; }
+
+/* role change; become(follower,..) resets every peer status to normal
+ * (src/ra_server.erl:2183-2192) */
+__device__ void set_role(Lane &L, unsigned role) {
+  unsigned old = role_of(L);
+  if (old != role) L.flags |= RGB_F_ROLE_CHANGED;
+  if (role == RGB_ROLE_FOLLOWER && old != RGB_ROLE_FOLLOWER)
+    L.pk = pk_set(L.pk, PK_STATUS_SH, 8, 0xFF);
+  if (role != RGB_ROLE_AWAIT_CONDITION) L.pk = pk_set(L.pk, PK_COND_SH, 2, RGB_COND_NONE);
+  L.pk = pk_set(L.pk, PK_ROLE_SH, 3, role);
+}
+
+/* update_term_and_voted_for/3 (src/ra_server.erl:3041-3058); voted4 is a 4-bit slot */
+__device__ void update_term_and_voted_for(Lane &L, u64 term, unsigned voted4) {
+  unsigned cur = (unsigned)pk_get(L.pk, PK_VOTED_SH, 4);
+  if (term == L.ct && voted4 == cur) return;
+  L.flags |= RGB_F_PERSIST;
+  L.ct = term;
+  L.pk = pk_set(L.pk, PK_VOTED_SH, 4, voted4);
+}
+/* update_term/2 (src/ra_server.erl:3060-3064) */
+__device__ __forceinline__ void update_term(Lane &L, u64 term) {
+  if (term != UNDEF && term > L.ct) update_term_and_voted_for(L, term, SLOT_NONE4);
+}
+__device__ __forceinline__ void set_leader_id(Lane &L, unsigned l4) {
+  if ((unsigned)pk_get(L.pk, PK_LEADER_SH, 4) != l4) L.flags |= RGB_F_LEADER_CHANGED;
+  L.pk = pk_set(L.pk, PK_LEADER_SH, 4, l4);
+}
+
+/* append_entries_reply/3 (src/ra_server.erl:3624-3631) */
+__device__ void aer_reply(Lane &L, u64 term, bool success, unsigned to8) {
+  L.has_reply = true;
+  L.flags |= RGB_F_REPLY | (success ? RGB_F_REPLY_SUCCESS : 0u);
+  L.r_term = term; L.r_next = L.li + 1; L.r_last = L.lwi; L.r_lterm = L.lwt;
+  L.reply_to = to8;
+}
+__device__ void vote_reply(Lane &L, u64 term, bool granted, unsigned to8) {
+  L.has_reply = true;
+  L.flags |= RGB_F_REPLY | RGB_F_REPLY_VOTE | (granted ? RGB_F_REPLY_SUCCESS : 0u);
+  L.r_term = term; L.r_next = 0; L.r_last = 0; L.r_lterm = 0;
+  L.reply_to = to8;
+}
+
+/* apply_to/5 (src/ra_server.erl:3250-3282): only the cursor moves on the device */
+__device__ __forceinline__ bool apply_to(Lane &L, u64 upto) {
+  if (upto > L.la) {
+    u64 to = L.li < upto ? L.li : upto;
+    if (to >= L.la + 1) { L.la = to; return true; }
+  }
+  return false;
+}
+
+/* evaluate_commit_index_follower/2 (src/ra_server.erl:2246-2280) */
+__device__ __forceinline__ void evaluate_commit_index_follower(Lane &L) {
+  if (pk_get(L.pk, PK_LEADER_SH, 4) == SLOT_NONE4) return;
+  u64 at = L.li < L.ci ? L.li : L.ci;
+  if (apply_to(L, at)) L.flags |= RGB_F_APPLIED | RGB_F_AUX_EVAL;
+}
+
+/* ---- log edits (register side; memory is touched at commit) ---- */
+
+/* append one segment [s..e] of term t after the current last run */
+__device__ void push_segment(Lane &L, u64 s, u64 t) {
+  if (L.n_runs > 0 && L.lrt == t) return;            /* extends the last run */
+  if (L.push_cnt == 1) { L.ps0 = L.lrs; L.pt0 = L.lrt; }
+  L.push_cnt += 1;
+  L.n_runs += 1;
+  L.lrs = s; L.lrt = t;
+}
+
+/* cut the table so that its last run is the one holding `keep_idx` (largest start <=
+ * keep_idx); runs starting above it disappear.  keep_term = term_at(keep_idx) if known. */
+__device__ void truncate_runs_to(Lane &L, u64 keep_idx) {
+  int k = find_run(L, keep_idx);
+  if (k < 0) { L.n_runs = 0; return; }
+  if ((unsigned)k != L.n_runs - 1) {
+    L.lrs = L.runs[2 * k];
+    L.lrt = L.runs[2 * k + 1];
+    L.n_runs = (unsigned)k + 1;
+  }
+}
+
+/* ra_log:write/2 (src/ra_log.erl:547-599, range update :1618-1623) of entries k0..n-1.
+ * Returns an RGB_INV_* code, 0 on success.  Validates before editing. */
+__device__ int log_write(Lane &L, u32 k0) {
+  const u64 base = L.a + 1 + (u64)L.gap;
+  const u64 fst = base + k0;
+  const u64 lst = base + (L.n_entries - 1);
+  const bool had_range = range_nonempty(L);
+  if (had_range && !(fst <= L.li + 1)) return RGB_INV_WRITE_INTEGRITY;
+  if (fst == 0) return RGB_INV_WRITE_INTEGRITY;
+  u64 lwi = fst - 1 < L.lwi ? fst - 1 : L.lwi;
+  u64 lwt;
+  if (lwi == L.lwi) lwt = L.lwt;
+  else if (L.si != UNDEF && L.si == lwi) lwt = L.st;
+  else if (lwi == 0) lwt = 0;
+  else {
+    lwt = fetch_term(L, lwi);
+    if (lwt == UNDEF) return RGB_INV_LAST_WRITTEN_TERM;
+  }
+  if (!had_range) {
+    L.first = fst; L.n_runs = 0;
+  } else if (fst <= L.li) {
+    /* overwrite: runs starting at or after fst vanish */
+    if (fst == 0 || fst <= L.first) L.n_runs = 0;
+    else truncate_runs_to(L, fst - 1);
+  }
+  /* entries k0.. : first the rest of term run 0, then term run 1 */
+  if (k0 < L.n_run0) {
+    push_segment(L, fst, L.run0_term);
+    if (L.n_run0 < L.n_entries) push_segment(L, base + L.n_run0, L.run1_term);
+  } else {
+    push_segment(L, fst, L.run1_term);
+  }
+  L.li = lst;
+  L.lt = (L.n_entries - 1) < L.n_run0 ? L.run0_term : L.run1_term;
+  L.lwi = lwi; L.lwt = lwt;
+  return 0;
+}
+
+/* ra_log:set_last_index/2 (src/ra_log.erl:842-893) */
+__device__ int log_set_last_index(Lane &L, u64 idx) {
+  u64 t = fetch_term(L, idx);
+  bool snap_is_idx = (L.si != UNDEF && L.si == idx);
+  if (t == UNDEF && !snap_is_idx) return RGB_INV_SET_LAST_INDEX_NOT_FOUND;
+  if (snap_is_idx) {
+    /* ra_range:limit(Idx+1, Range) (src/ra_range.erl:80-91) */
+    if (range_nonempty(L)) {
+      if (idx + 1 <= L.first) { L.n_runs = 0; L.li = idx; L.first = idx + 1; }
+      else if (idx + 1 <= L.li) { truncate_runs_to(L, idx); L.li = idx; }
+    }
+    if (!range_nonempty(L)) L.li = L.si;
+    L.lt = L.st;
+    L.lwi = L.si; L.lwt = L.st;
+    return 0;
+  }
+  u64 lwi = idx < L.lwi ? idx : L.lwi;
+  u64 lwt;
+  if (L.si != UNDEF && L.si == lwi) lwt = L.st;
+  else lwt = fetch_term(L, lwi);
+  if (lwt == UNDEF) return RGB_INV_LAST_WRITTEN_TERM;
+  if (idx + 1 <= L.li) { truncate_runs_to(L, idx); L.li = idx; }
+  L.lt = t;
+  L.lwi = lwi; L.lwt = lwt;
+  return 0;
+}
+
+/* ra_log:handle_event({written,Term,[from..to]}) (src/ra_log.erl:897-944): the highest index
+ * of [from..to] inside the range whose term is Term becomes last_written.  Walking down one
+ * index at a time (as the reference does through ra_seq:limit) stops without change only on
+ * indexes at/below the snapshot, below which nothing can match either. */
+__device__ bool log_written(Lane &L, u64 term, u64 from, u64 to) {
+  if (!range_nonempty(L)) return false;
+  u64 hi = to < L.li ? to : L.li;
+  u64 lo = from > L.first ? from : L.first;
+  if (hi < lo) return false;
+  /* walk runs from the newest: run k covers [start_k, end_k] */
+  u64 end = L.li;
+  for (int k = (int)L.n_runs - 1; k >= 0; --k) {
+    u64 s, t;
+    if ((unsigned)k == L.n_runs - 1) { s = L.lrs; t = L.lrt; }
+    else { s = L.runs[2 * k]; t = L.runs[2 * k + 1]; }
+    u64 rs = s < L.first ? L.first : s;
+    if (rs <= hi && end >= lo && t == term) {
+      u64 idx = end < hi ? end : hi;
+      if (idx >= lo && idx >= rs) {
+        bool changed = !(L.lwi == idx && L.lwt == term);
+        L.lwi = idx; L.lwt = term;
+        return changed;
+      }
+    }
+    if (s <= lo) break;
+    end = s - 1;
+  }
+  return false;
+}
+
+/* ---- quorum ---- */
+
+/* agreed_commit/1 (src/ra_server.erl:3684-3688) over up to 8 values held in registers:
+ * descending order statistic nth = n/2+1 by rank counting (branch-free, no memory) */
+template <int N>
+__device__ u64 agreed_commit(const u64 (&v)[N], const bool (&use)[N], int n) {
+  const int nth = n / 2 + 1;
+  u64 res = UNDEF;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (!use[i]) continue;
+    int greater = 0, geq = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (!use[j]) continue;
+      greater += v[j] > v[i];
+      geq += v[j] >= v[i];
+    }
+    /* v[i] is the nth largest iff greater < nth <= geq */
+    if (greater < nth && nth <= geq) res = v[i];
+  }
+  return res;
+}
+
+/* match_indexes/1 :3671-3682, increment_commit_index/1 :3648-3657, evaluate_quorum/2 :3633-3646 */
+template <int N>
+__device__ void evaluate_quorum(Lane &L, unsigned ov_peer, u64 ov_mi) {
+  u64 v[N + 1];
+  bool use[N + 1];
+  const unsigned self = self_of(L);
+  int n = 1;
+  v[N] = L.lwi; use[N] = true;                     /* the leader's last WRITTEN index */
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    bool u = ((unsigned)i != self) && present(L, i) && voter(L, i);
+    u64 mi = L.peers[i];
+    if ((unsigned)i == ov_peer) mi = ov_mi;
+    v[i] = mi; use[i] = u;
+    n += u ? 1 : 0;
+  }
+  const u64 ci0 = L.ci;
+  u64 p = agreed_commit<N + 1>(v, use, n);
+  u64 t = srv_fetch_term(L, p);
+  if (t != UNDEF && t == L.ct) L.ci = p;           /* Raft 5.4.2; NO max() */
+  if (L.ci > ci0) L.flags |= RGB_F_AUX_EVAL;
+  if (apply_to(L, L.ci)) L.flags |= RGB_F_APPLIED;
+}
+
+/* make_pipelined_rpc_effects/3 :2285-2346 + make_rpc_effect/5 :2382-2416 +
+ * make_append_entries_rpc/6 :2418-2435.  Two passes: EMIT=false validates (assertions of the
+ * reference) without side effects, EMIT=true stores peers and emits rpc records. */
+template <int N, bool EMIT>
+__device__ int pipeline_rpcs(Lane &L, bool force, unsigned ov_peer, u64 ov_mi, u64 ov_ni,
+                             u32 max_pipe, u32 max_batch, bool &more, unsigned &n_out,
+                             rgb_rpc *rpcs, u32 rpc_cap, u32 *rpc_count, u32 msg_index) {
+  const unsigned self = self_of(L);
+  const u64 next_log = next_log_index(L);
+  more = false;
+  n_out = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if ((unsigned)i == self || !present(L, i) || !status_normal(L, i)) continue;
+    u64 mi = L.peers[i], ni = L.peers[N + i], cis = L.peers[2 * N + i];
+    if ((unsigned)i == ov_peer) { mi = ov_mi; ni = ov_ni; }
+    if (!(ni < next_log || cis < L.ci)) {
+      if (EMIT && (unsigned)i == ov_peer) { L.peers[i] = mi; L.peers[N + i] = ni; }
+      continue;
+    }
+    long long inflight = (long long)(ni - mi) - 1;
+    if (!(inflight < (long long)max_pipe || force)) {
+      if (EMIT && (unsigned)i == ov_peer) { L.peers[i] = mi; L.peers[N + i] = ni; }
+      continue;
+    }
+    long long room = (long long)max_pipe - inflight;
+    long long bs = (long long)max_batch < room ? (long long)max_batch : room;
+    if (bs < 1) bs = 1;
+    u64 prev = ni - 1;
+    u64 prev_term = fetch_term(L, prev);
+    u64 new_ni, rp_idx, rp_term;
+    unsigned kind, n_ent = 0;
+    if (prev_term == UNDEF && !(L.si != UNDEF && L.si == prev)) {
+      if (L.si == UNDEF || !(prev < L.si)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
+      kind = RGB_RPC_SNAPSHOT; rp_idx = L.si; rp_term = L.st; new_ni = L.si;
+      if (EMIT) L.flags |= RGB_F_SEND_SNAPSHOT;
+    } else {
+      if (prev_term == UNDEF) prev_term = L.st;
+      u64 to = prev + (u64)bs < L.li ? prev + (u64)bs : L.li;
+      kind = RGB_RPC_AER; rp_idx = prev; rp_term = prev_term;
+      n_ent = (unsigned)(to >= prev + 1 ? to - prev : 0);
+      new_ni = to + 1;
+    }
+    if (!(new_ni >= ni)) return RGB_INV_NEXT_INDEX_REGRESSED;
+    n_out += 1;
+    long long new_inflight = (long long)(new_ni - mi) - 1;
+    if (new_ni < next_log && new_inflight < (long long)max_pipe) more = true;
+    if (EMIT) {
+      L.peers[i] = mi;
+      L.peers[N + i] = new_ni;
+      L.peers[2 * N + i] = L.ci;
+      if (rpc_count != nullptr) {
+        u32 slot = atomicAdd(rpc_count, 1u);
+        if (rpcs != nullptr && slot < rpc_cap) {
+          rgb_rpc r;
+          r.msg_index = msg_index; r.server = L.server; r.peer = (uint8_t)i;
+          r.kind = (uint8_t)kind; r.n_entries = (uint16_t)n_ent; r._pad = 0;
+          r.term = L.ct; r.prev_log_index = rp_idx; r.prev_log_term = rp_term;
+          r.leader_commit = L.ci; r.next_index = new_ni;
+          rpcs[slot] = r;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ follower ---- */
+
+/* drop_existing/3 (src/ra_server.erl:3700-3708) run-wise: number of leading entries of the
+ * message that already exist with the same term.  Equivalent to the per-entry
+ * ra_log:exists loop because run tables are canonical (adjacent runs differ in term). */
+__device__ u32 drop_existing(const Lane &L) {
+  if (L.n_entries == 0) return 0;
+  const u64 base = L.a + 1 + (u64)L.gap;
+  if (!range_nonempty(L) || base > L.li || base < L.first) return 0;
+  u32 k = 0;
+  /* segment 0: [base .. base+n_run0-1] term run0_term; segment 1: the rest, run1_term */
+  for (int seg = 0; seg < 2; ++seg) {
+    u32 cnt = seg == 0 ? L.n_run0 : L.n_entries - L.n_run0;
+    if (seg == 0 && cnt > L.n_entries) cnt = L.n_entries;
+    if (cnt == 0) continue;
+    u64 s = base + k, e = s + cnt - 1;
+    u64 t = seg == 0 ? L.run0_term : L.run1_term;
+    if (s > L.li) return k;
+    int r = find_run(L, s);
+    if (r < 0) return k;
+    u64 rterm = ((unsigned)r == L.n_runs - 1) ? L.lrt : L.runs[2 * r + 1];
+    if (rterm != t) return k;
+    u64 rend = ((unsigned)r == L.n_runs - 1) ? L.li : L.runs[2 * (r + 1)] - 1;
+    if (rend >= e) { k += cnt; continue; }
+    k += (u32)(rend - s + 1);
+    return k;
+  }
+  return k;
+}
+
+/* handle_follower(#append_entries_rpc{}) (src/ra_server.erl:1283-1440) */
+__device__ int follower_aer(Lane &L) {
+  const u64 cur_term = L.ct;
+  if (!(L.term >= cur_term)) {
+    aer_reply(L, cur_term, false, L.from);                          /* :1431-1440 */
+    return 0;
+  }
+  const u64 pli = L.a, plt = L.b, leader_commit = L.c;
+  const u64 last_applied = L.la;
+  set_leader_id(L, slot8to4(L.from));                               /* :1298 */
+  update_term(L, L.term);
+  int h = has_log_entry_or_snapshot(L, pli, plt);
+  if (h == HLE_OK) {
+    u32 k = drop_existing(L);
+    u64 last_valid = k == 0 ? pli : (L.a + (u64)L.gap + k);
+    if (k == L.n_entries) {
+      /* nothing new to write, :1304-1364 */
+      const u64 local_last = L.li;
+      bool validated;
+      if (L.n_entries == 0 && local_last > pli) {
+        if (pli < last_applied) return RGB_INV_TRUNCATE_BELOW_APPLIED;
+        int rc = log_set_last_index(L, pli);
+        if (rc) return rc;
+        L.flags |= RGB_F_TRUNCATED;
+        validated = true;
+      } else {
+        validated = local_last <= last_valid;
+      }
+      if (validated) {
+        L.ci = leader_commit;                                       /* not clamped, :1331 */
+        L.flags |= RGB_F_LEADER_MSG;
+        evaluate_commit_index_follower(L);
+        aer_reply(L, L.term, true, L.from);
+      } else {
+        /* :1344-1363: success reply for what we have, term = PRE-update CurTerm */
+        u64 v = last_applied > last_valid ? last_applied : last_valid;
+        u64 vt = srv_fetch_term(L, v);
+        L.has_reply = true;
+        L.flags |= RGB_F_REPLY | RGB_F_REPLY_SUCCESS;
+        L.r_term = cur_term; L.r_next = v + 1; L.r_last = v; L.r_lterm = vt;
+        L.reply_to = L.from;
+      }
+      return 0;
+    }
+    /* :1365-1389 */
+    const u64 fst = L.a + 1 + (u64)L.gap + k;
+    L.ci = leader_commit;
+    if (fst < last_applied) return RGB_INV_WRITE_BELOW_APPLIED;
+    int rc = log_write(L, k);
+    if (rc) return rc;
+    L.flags |= RGB_F_WROTE | RGB_F_LEADER_MSG;
+    L.w_first = fst; L.w_last = L.li;
+    evaluate_commit_index_follower(L);
+    return 0;                                                       /* reply comes on written */
+  }
+  if (h == HLE_MISSING) {
+    aer_reply(L, L.term, false, L.from);                            /* :1390-1404 */
+    L.flags |= RGB_F_LEADER_MSG;
+    set_role(L, RGB_ROLE_AWAIT_CONDITION);
+    L.pk = pk_set(L.pk, PK_COND_SH, 2, RGB_COND_MISSING);
+  } else {
+    /* :1405-1429, mismatch_append_entries_reply/3 :3614-3622 */
+    u64 lat = srv_fetch_term(L, last_applied);
+    if (lat == UNDEF) return RGB_INV_MISMATCH_TERM_UNDEFINED;
+    L.has_reply = true;
+    L.flags |= RGB_F_REPLY | RGB_F_LEADER_MSG;
+    L.r_term = L.term; L.r_next = last_applied + 1; L.r_last = last_applied; L.r_lterm = lat;
+    L.reply_to = L.from;
+    set_role(L, RGB_ROLE_AWAIT_CONDITION);
+    L.pk = pk_set(L.pk, PK_COND_SH, 2, RGB_COND_TERM_MISMATCH);
+  }
+  L.cr0 = L.r_term; L.cr1 = L.r_next; L.cr2 = L.r_last; L.cr3 = L.r_lterm;
+  L.cond_dirty = true;
+  L.pk = pk_set(L.pk, PK_CONDLDR_SH, 4, slot8to4(L.from));
+  return 0;
+}
+
+/* handle_follower(#request_vote_rpc{}) (src/ra_server.erl:1483-1529) */
+__device__ int follower_request_vote(Lane &L) {
+  if (pk_get(L.pk, PK_NONVOTER_SH, 1)) return 0;
+  const unsigned cand4 = slot8to4(L.from);
+  const unsigned voted = (unsigned)pk_get(L.pk, PK_VOTED_SH, 4);
+  if (L.term == L.ct && voted != SLOT_NONE4 && voted != cand4) {
+    vote_reply(L, L.term, false, L.from);
+    return 0;
+  }
+  if (L.term >= L.ct) {
+    update_term(L, L.term);
+    /* is_candidate_log_up_to_date/3 :3157-3166 */
+    bool up = (L.b > L.lt) || (L.b == L.lt && L.a >= L.li);
+    if (up) {
+      update_term_and_voted_for(L, L.term, cand4);
+      vote_reply(L, L.term, true, L.from);
+    } else {
+      vote_reply(L, L.term, false, L.from);
+    }
+    return 0;
+  }
+  vote_reply(L, L.ct, false, L.from);
+  return 0;
+}
+
+__device__ int handle_follower(Lane &L) {
+  switch (L.kind) {
+    case RGB_MSG_AER:          return follower_aer(L);
+    case RGB_MSG_REQUEST_VOTE: return follower_request_vote(L);
+    case RGB_MSG_WRITTEN: {
+      /* :1457-1474 */
+      bool changed = log_written(L, L.term, L.a, L.b);
+      unsigned l4 = (unsigned)pk_get(L.pk, PK_LEADER_SH, 4);
+      if (changed && l4 != SLOT_NONE4) aer_reply(L, L.ct, true, slot4to8(l4));
+      return 0;
+    }
+    case RGB_MSG_AER_REPLY:    update_term(L, L.term); return 0;     /* :1530-1533 */
+    case RGB_MSG_VOTE_RESULT:  return 0;                             /* :1609-1611 */
+    default: L.flags |= RGB_F_UNHANDLED; return 0;
+  }
+}
+
+/* -------------------------------------------------------------------- leader ---- */
+template <int N>
+__device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_rpc *rpcs,
+                             u32 rpc_cap, u32 *rpc_count, u32 msg_index, unsigned &n_rpcs) {
+  switch (L.kind) {
+    case RGB_MSG_AER_REPLY: {
+      const unsigned peer = L.from;
+      const bool success = (L.mflags & RGB_MF_SUCCESS) != 0;
+      if (success && L.term == L.ct) {
+        /* :532-571 */
+        if (!present(L, peer)) return 0;
+        u64 mi = L.peers[peer], ni = L.peers[N + peer];
+        if (L.b > mi) { mi = L.b; L.peers[peer] = mi; }
+        if (L.a > ni) { L.peers[N + peer] = L.a; }
+        evaluate_quorum<N>(L, peer, mi);
+        L.flags |= RGB_F_PIPELINE;
+        return 0;
+      }
+      if (L.term > L.ct) {
+        /* :572-586 */
+        if (!present(L, peer)) return 0;
+        set_leader_id(L, SLOT_NONE4);
+        update_term(L, L.term);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        return 0;
+      }
+      if (!success) {
+        /* :587-652 */
+        if (!present(L, peer)) return 0;
+        u64 mi = L.peers[peer], ni = L.peers[N + peer];
+        const u64 peer_next = L.a, peer_last = L.b, peer_last_term = L.c;
+        u64 t = fetch_term(L, peer_last);
+        if (t == UNDEF) {
+          ni = peer_next;
+        } else if (t == peer_last_term && peer_last >= mi) {
+          mi = peer_last; ni = peer_next;
+        } else if (peer_last < mi) {
+          mi = peer_last; ni = peer_last + 1;
+        } else {
+          long long x = (long long)ni - 1, y = (long long)peer_last;
+          long long mn = x < y ? x : y;
+          long long lo = (long long)mi + 1;
+          ni = (u64)(mn > lo ? mn : lo);
+        }
+        bool more; unsigned cnt;
+        int rc = pipeline_rpcs<N, false>(L, false, peer, mi, ni, dev.max_pipeline_count,
+                                         dev.max_aer_batch, more, cnt, nullptr, 0, nullptr, 0);
+        if (rc) return rc;
+        pipeline_rpcs<N, true>(L, false, peer, mi, ni, dev.max_pipeline_count, dev.max_aer_batch,
+                               more, cnt, rpcs, rpc_cap, rpc_count, msg_index);
+        /* the peer edit must land even when the peer itself got no rpc */
+        if (!(status_normal(L, peer) && peer != self_of(L))) {
+          L.peers[peer] = mi; L.peers[N + peer] = ni;
+        }
+        n_rpcs = cnt;
+        return 0;
+      }
+      L.flags |= RGB_F_UNHANDLED;                                    /* :1038-1040 */
+      return 0;
+    }
+    case RGB_MSG_AER: {
+      if (L.term > L.ct) {
+        set_leader_id(L, SLOT_NONE4);                                /* :835-844 */
+        update_term(L, L.term);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      if (L.term == L.ct) return RGB_INV_LEADER_SAW_AER_SAME_TERM;   /* :845-849 */
+      aer_reply(L, L.ct, false, L.from);                             /* :850-854 */
+      return 0;
+    }
+    case RGB_MSG_REQUEST_VOTE: {
+      if (L.term > L.ct) {
+        if (!present(L, L.from)) return 0;                           /* :928-942 */
+        set_leader_id(L, SLOT_NONE4);
+        update_term(L, L.term);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      vote_reply(L, L.ct, false, L.from);                            /* :943-945 */
+      return 0;
+    }
+    case RGB_MSG_WRITTEN: {
+      log_written(L, L.term, L.a, L.b);                              /* :739-744 */
+      evaluate_quorum<N>(L, 0xFFu, 0);
+      L.flags |= RGB_F_PIPELINE;
+      return 0;
+    }
+    case RGB_MSG_PIPELINE_RPCS:
+    case RGB_MSG_APPEND: {
+      bool force = false;
+      /* saved cursors for rollback if the pipelining assertion fails */
+      const u64 s_li = L.li, s_lt = L.lt, s_lrs = L.lrs, s_lrt = L.lrt, s_first = L.first;
+      const unsigned s_nr = L.n_runs, s_pc = L.push_cnt;
+      if (L.kind == RGB_MSG_APPEND) {
+        /* {command,_} :653-693 / {commands,_} :695-738: ra_log:append of n entries at
+         * next_index in the current term */
+        force = (L.mflags & RGB_MF_FORCE) != 0;
+        if (L.n_entries > 0) {
+          u64 nidx = next_log_index(L);
+          if (!range_nonempty(L)) { L.first = nidx; L.n_runs = 0; }
+          push_segment(L, nidx, L.ct);
+          L.li = nidx + (L.n_entries - 1);
+          L.lt = L.ct;
+        }
+      }
+      bool more; unsigned cnt;
+      int rc = pipeline_rpcs<N, false>(L, force, 0xFFu, 0, 0, dev.max_pipeline_count,
+                                       dev.max_aer_batch, more, cnt, nullptr, 0, nullptr, 0);
+      if (rc) {
+        L.li = s_li; L.lt = s_lt; L.lrs = s_lrs; L.lrt = s_lrt; L.first = s_first;
+        L.n_runs = s_nr; L.push_cnt = s_pc;
+        return rc;
+      }
+      pipeline_rpcs<N, true>(L, force, 0xFFu, 0, 0, dev.max_pipeline_count, dev.max_aer_batch,
+                             more, cnt, rpcs, rpc_cap, rpc_count, msg_index);
+      n_rpcs = cnt;
+      if (L.kind == RGB_MSG_PIPELINE_RPCS && more) L.flags |= RGB_F_PIPELINE;   /* :793-801 */
+      return 0;
+    }
+    default: L.flags |= RGB_F_UNHANDLED; return 0;
+  }
+}
+
+/* ----------------------------------------------------------------- candidate ---- */
+template <int N>
+__device__ int handle_candidate(Lane &L, bool &reprocess) {
+  switch (L.kind) {
+    case RGB_MSG_VOTE_RESULT: {
+      const bool granted = (L.mflags & RGB_MF_SUCCESS) != 0;
+      if (granted && L.term == L.ct) {
+        /* :1045-1061, required_quorum/1 :3996-3999 */
+        unsigned voters = __popc((unsigned)(pk_get(L.pk, PK_PRESENT_SH, 8) & pk_get(L.pk, PK_VOTER_SH, 8)));
+        unsigned quorum = voters / 2 + 1;
+        unsigned nv = (unsigned)pk_get(L.pk, PK_VOTES_SH, 4) + 1;
+        if (nv == quorum) {
+          /* initialise_peers/1 :3234-3242 */
+          const u64 ni = next_log_index(L);
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            if (!present(L, i)) continue;
+            L.peers[i] = 0; L.peers[N + i] = ni; L.peers[2 * N + i] = 0;
+          }
+          L.pk = pk_set(L.pk, PK_STATUS_SH, 8, 0xFF);
+          set_leader_id(L, self_of(L));
+          L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+          set_role(L, RGB_ROLE_LEADER);
+          L.flags |= RGB_F_BECAME_LEADER;
+        } else {
+          L.pk = pk_set(L.pk, PK_VOTES_SH, 4, nv);
+        }
+        return 0;
+      }
+      if (L.term > L.ct) {
+        update_term_and_voted_for(L, L.term, SLOT_NONE4);            /* :1062-1069 */
+        set_role(L, RGB_ROLE_FOLLOWER);
+      }
+      return 0;
+    }
+    case RGB_MSG_AER:
+      if (L.term >= L.ct) {
+        update_term_and_voted_for(L, L.term, SLOT_NONE4);            /* :1072-1075 */
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      aer_reply(L, L.ct, false, L.from);                             /* :1076-1080 */
+      return 0;
+    case RGB_MSG_AER_REPLY:
+      if (L.term > L.ct) {
+        update_term_and_voted_for(L, L.term, SLOT_NONE4);            /* :1098-1106 */
+        set_role(L, RGB_ROLE_FOLLOWER);
+        return 0;
+      }
+      L.flags |= RGB_F_UNHANDLED;
+      return 0;
+    case RGB_MSG_REQUEST_VOTE:
+      if (L.term > L.ct) {
+        update_term_and_voted_for(L, L.term, SLOT_NONE4);            /* :1107-1114 */
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      vote_reply(L, L.ct, false, L.from);                            /* :1123-1125 */
+      return 0;
+    case RGB_MSG_WRITTEN:
+      log_written(L, L.term, L.a, L.b);                              /* :1157-1160 */
+      return 0;
+    default: L.flags |= RGB_F_UNHANDLED; return 0;
+  }
+}
+
+/* ------------------------------------------------------------------ pre_vote ---- */
+__device__ int handle_pre_vote(Lane &L, bool &reprocess) {
+  switch (L.kind) {
+    case RGB_MSG_AER:
+      if (L.term >= L.ct) {
+        update_term(L, L.term);                                      /* :1192-1197 */
+        L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      L.flags |= RGB_F_UNHANDLED;
+      return 0;
+    case RGB_MSG_REQUEST_VOTE:
+      if (L.term > L.ct) {
+        update_term(L, L.term);                                      /* :1214-1219 */
+        L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      L.flags |= RGB_F_UNHANDLED;
+      return 0;
+    case RGB_MSG_VOTE_RESULT: return 0;                              /* :1249-1251 */
+    case RGB_MSG_WRITTEN:
+      log_written(L, L.term, L.a, L.b);                              /* :1257-1260 */
+      return 0;
+    default: L.flags |= RGB_F_UNHANDLED; return 0;
+  }
+}
+
+/* ----------------------------------------------------------- await_condition ---- */
+__device__ int handle_await_condition(Lane &L, bool &reprocess, const u64 *cond_row) {
+  switch (L.kind) {
+    case RGB_MSG_REQUEST_VOTE:
+      set_role(L, RGB_ROLE_FOLLOWER);                                /* :1918-1919 */
+      reprocess = true;
+      return 0;
+    case RGB_MSG_AWAIT_TIMEOUT: {
+      /* :1932-1945: predicate false -> stored effects, back to follower */
+      L.has_reply = true;
+      L.flags |= RGB_F_REPLY | RGB_F_LEADER_MSG;
+      L.r_term = cond_row[0]; L.r_next = cond_row[1]; L.r_last = cond_row[2]; L.r_lterm = cond_row[3];
+      L.reply_to = slot4to8((unsigned)pk_get(L.pk, PK_CONDLDR_SH, 4));
+      set_role(L, RGB_ROLE_FOLLOWER);
+      return 0;
+    }
+    case RGB_MSG_WRITTEN:
+      log_written(L, L.term, L.a, L.b);                              /* :1946-1949 */
+      return 0;
+    case RGB_MSG_AER: {
+      /* follower_catchup_cond/3 :2201-2218 */
+      bool pred = false;
+      if (L.term >= L.ct) {
+        int h = has_log_entry_or_snapshot(L, L.a, L.b);
+        if (h == HLE_OK) pred = true;
+        else if (h == HLE_MISMATCH) pred = pk_get(L.pk, PK_COND_SH, 2) == RGB_COND_MISSING;
+      }
+      if (pred) { set_role(L, RGB_ROLE_FOLLOWER); reprocess = true; } /* :1950-1955 */
+      return 0;
+    }
+    default: return 0;
+  }
+}
+
+__device__ __forceinline__ void store_decision(rgb_decision *out, u32 server, unsigned role,
+                                               unsigned reply_to, unsigned n_rpcs, unsigned kind,
+                                               u32 flags, u32 inv, u64 w2, u64 w3, u64 w4, u64 w5,
+                                               u64 ci, u64 la) {
+  u64 w0 = (u64)server | ((u64)(role & 0xFF) << 32) | ((u64)(reply_to & 0xFF) << 40) |
+           ((u64)(n_rpcs & 0xFF) << 48) | ((u64)(kind & 0xFF) << 56);
+  u64 w1 = (u64)flags | ((u64)inv << 32);
+  ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out);
+  o[0] = make_ulonglong2(w0, w1);
+  o[1] = make_ulonglong2(w2, w3);
+  o[2] = make_ulonglong2(w4, w5);
+  o[3] = make_ulonglong2(ci, la);
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
+                                                       u32 n, rgb_decision *__restrict__ dec,
+                                                       rgb_rpc *__restrict__ rpcs, u32 rpc_cap,
+                                                       u32 *__restrict__ rpc_count, u32 msg_index_base) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  /* message: 4 x 16 B */
+  const ulonglong2 *mp = reinterpret_cast<const ulonglong2 *>(msgs + i);
+  const ulonglong2 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
+  Lane L;
+  L.server = (u32)(m0.x & 0xFFFFFFFFull);
+  L.kind = (unsigned)((m0.x >> 32) & 0xFF);
+  L.from = (unsigned)((m0.x >> 40) & 0xFF);
+  L.mflags = (unsigned)((m0.x >> 48) & 0xFF);
+  L.gap = (unsigned)((m0.x >> 56) & 0xFF);
+  L.term = m0.y; L.a = m1.x; L.b = m1.y; L.c = m2.x;
+  L.n_entries = (u32)(m2.y & 0xFFFFFFFFull);
+  L.n_run0 = (u32)(m2.y >> 32);
+  L.run0_term = m3.x; L.run1_term = m3.y;
+  if (L.n_run0 > L.n_entries) L.n_run0 = L.n_entries;
+
+  if (L.kind == RGB_MSG_NOP) {
+    store_decision(dec + i, L.server, 0, RGB_NONE, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    return;
+  }
+  if (L.server >= dev.n_servers) {
+    store_decision(dec + i, L.server, 0xFF, RGB_NONE, 0, L.kind, RGB_F_UNHANDLED, 0, 0, 0, 0, 0, 0, 0);
+    return;
+  }
+  /* hot line: 7 x 16 B (13 live words) */
+  u64 *hot = dev.hot + (size_t)L.server * RGB_HOT_WORDS;
+  const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(hot);
+  const ulonglong2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4], h5 = hp[5], h6 = hp[6];
+  L.ct = h0.x; L.ci = h0.y; L.la = h1.x; L.li = h1.y; L.lt = h2.x; L.lwi = h2.y; L.lwt = h3.x;
+  L.pk = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
+  L.runs = dev.runs + (size_t)L.server * dev.max_runs * 2;
+  L.peers = dev.peers + (size_t)L.server * dev.peer_stride;
+  L.max_runs = dev.max_runs;
+  L.flags = 0; L.inv = 0; L.has_reply = false; L.reply_to = RGB_NONE;
+  L.r_term = L.r_next = L.r_last = L.r_lterm = 0; L.w_first = L.w_last = 0;
+  L.n_runs = (unsigned)pk_get(L.pk, PK_NRUNS_SH, 5);
+  L.push_cnt = 0; L.ps0 = L.pt0 = 0;
+  L.cond_dirty = false; L.cr0 = L.cr1 = L.cr2 = L.cr3 = 0;
+  L.peers_loaded = false;
+
+  /* saved copy for invariant roll-back (registers only; memory is written at commit, except
+   * peers rows which are only written after validation) */
+  const Lane S = L;
+  const unsigned n_runs0 = L.n_runs;
+  unsigned n_rpcs = 0;
+  int rc = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    bool reprocess = false;
+    switch (role_of(L)) {
+      case RGB_ROLE_FOLLOWER:        rc = handle_follower(L); break;
+      case RGB_ROLE_LEADER:          rc = handle_leader<N>(L, reprocess, dev, rpcs, rpc_cap, rpc_count,
+                                                           msg_index_base + i, n_rpcs); break;
+      case RGB_ROLE_CANDIDATE:       rc = handle_candidate<N>(L, reprocess); break;
+      case RGB_ROLE_PRE_VOTE:        rc = handle_pre_vote(L, reprocess); break;
+      case RGB_ROLE_AWAIT_CONDITION: rc = handle_await_condition(L, reprocess,
+                                                dev.cond + (size_t)L.server * 4); break;
+      default: L.flags |= RGB_F_UNHANDLED; break;
+    }
+    if (rc || !reprocess) break;
+    L.flags |= RGB_F_REPROCESSED;
+  }
+  if (rc) {
+    store_decision(dec + i, S.server, role_of(S), RGB_NONE, 0, S.kind, RGB_F_INVARIANT, (u32)rc,
+                   0, 0, 0, 0, S.ci, S.la);
+    return;
+  }
+
+  /* ---- commit: run table ---- */
+  if (L.n_runs != n_runs0 || L.push_cnt) {
+    u64 *runs = const_cast<u64 *>(L.runs);
+    unsigned nr = L.n_runs;
+    if (nr > L.max_runs) {
+      /* overflow: drop the oldest run(s); the range now starts at the new first run */
+      unsigned shift = nr - L.max_runs;
+      unsigned in_mem = nr - L.push_cnt;
+      for (unsigned k = shift; k < in_mem; ++k) {
+        runs[2 * (k - shift)] = runs[2 * k];
+        runs[2 * (k - shift) + 1] = runs[2 * k + 1];
+      }
+      nr = L.max_runs;
+      L.flags |= RGB_F_RUNS_OVERFLOW;
+      /* new first index = start of the new oldest run */
+      u64 nf;
+      if (L.push_cnt >= nr) nf = (L.push_cnt == 2 && nr == 2) ? L.ps0 : L.lrs;
+      else nf = runs[0];
+      L.first = nf;
+      L.n_runs = nr;
+    }
+    if (L.push_cnt == 2) { runs[2 * (nr - 2)] = L.ps0; runs[2 * (nr - 2) + 1] = L.pt0; }
+    if (L.push_cnt >= 1) { runs[2 * (nr - 1)] = L.lrs; runs[2 * (nr - 1) + 1] = L.lrt; }
+  }
+  L.pk = pk_set(L.pk, PK_NRUNS_SH, 5, L.n_runs);
+  if (L.cond_dirty) {
+    ulonglong2 *cp = reinterpret_cast<ulonglong2 *>(dev.cond + (size_t)L.server * 4);
+    cp[0] = make_ulonglong2(L.cr0, L.cr1);
+    cp[1] = make_ulonglong2(L.cr2, L.cr3);
+  }
+  /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
+  ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
+  if (L.ct != h0.x || L.ci != h0.y) ho[0] = make_ulonglong2(L.ct, L.ci);
+  if (L.la != h1.x || L.li != h1.y) ho[1] = make_ulonglong2(L.la, L.li);
+  if (L.lt != h2.x || L.lwi != h2.y) ho[2] = make_ulonglong2(L.lt, L.lwi);
+  if (L.lwt != h3.x || L.pk != h3.y) ho[3] = make_ulonglong2(L.lwt, L.pk);
+  if (L.first != h5.x || L.lrs != h5.y) ho[5] = make_ulonglong2(L.first, L.lrs);
+  if (L.lrt != h6.x) ho[6] = make_ulonglong2(L.lrt, h6.y);
+
+  u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
+  if (L.has_reply) { w2 = L.r_term; w3 = L.r_next; w4 = L.r_last; w5 = L.r_lterm; }
+  else if (L.flags & RGB_F_WROTE) { w3 = L.w_first; w4 = L.w_last; }
+  store_decision(dec + i, L.server, role_of(L), L.has_reply ? L.reply_to : (unsigned)RGB_NONE, n_rpcs,
+                 L.kind, L.flags, 0, w2, w3, w4, w5, L.ci, L.la);
+}
+
+/* ------------------------------------------------------------- support kernels -- */
+
+__global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict__ in, u32 first, u32 n) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const rgb_server_state &h = in[k];
+  const u32 s = first + k;
+  u64 *hot = dev.hot + (size_t)s * RGB_HOT_WORDS;
+  const unsigned N = dev.n_members;
+  /* canonical run table: merge adjacent equal-term runs, keep the newest max_runs */
+  u64 *runs = dev.runs + (size_t)s * dev.max_runs * 2;
+  unsigned nr = 0;
+  u64 first_index = h.first_index;
+  u64 lrs = 0, lrt = 0;
+  if (h.first_index <= h.last_index) {
+    unsigned src_n = h.n_runs > RGB_MAX_RUNS ? RGB_MAX_RUNS : h.n_runs;
+    /* count canonical runs */
+    unsigned canon = 0;
+    for (unsigned r = 0; r < src_n; ++r)
+      if (r == 0 || h.run_term[r] != h.run_term[r - 1]) canon++;
+    unsigned skip = canon > dev.max_runs ? canon - dev.max_runs : 0;
+    unsigned ci = 0;
+    for (unsigned r = 0; r < src_n; ++r) {
+      if (!(r == 0 || h.run_term[r] != h.run_term[r - 1])) continue;
+      if (ci >= skip) {
+        if (nr == 0 && skip) first_index = h.run_start[r];
+        runs[2 * nr] = h.run_start[r]; runs[2 * nr + 1] = h.run_term[r];
+        lrs = h.run_start[r]; lrt = h.run_term[r];
+        nr++;
+      }
+      ci++;
+    }
+  }
+  u64 pk = 0;
+  pk = pk_set(pk, PK_ROLE_SH, 3, h.role);
+  pk = pk_set(pk, PK_COND_SH, 2, h.cond_reason);
+  pk = pk_set(pk, PK_SELF_SH, 4, h.self);
+  pk = pk_set(pk, PK_VOTES_SH, 4, h.votes);
+  pk = pk_set(pk, PK_NRUNS_SH, 5, nr);
+  pk = pk_set(pk, PK_NONVOTER_SH, 1, h.self_nonvoter ? 1 : 0);
+  pk = pk_set(pk, PK_VOTED_SH, 4, slot8to4(h.voted_for));
+  pk = pk_set(pk, PK_LEADER_SH, 4, slot8to4(h.leader_id));
+  pk = pk_set(pk, PK_CONDLDR_SH, 4, slot8to4(h.cond_leader));
+  pk = pk_set(pk, PK_PRESENT_SH, 8, h.present_mask);
+  pk = pk_set(pk, PK_VOTER_SH, 8, h.voter_mask);
+  pk = pk_set(pk, PK_STATUS_SH, 8, h.status_mask);
+  hot[HOT_CT] = h.current_term; hot[HOT_CI] = h.commit_index; hot[HOT_LA] = h.last_applied;
+  hot[HOT_LI] = h.last_index; hot[HOT_LT] = h.last_term;
+  hot[HOT_LWI] = h.last_written_index; hot[HOT_LWT] = h.last_written_term;
+  hot[HOT_PK] = pk; hot[HOT_SI] = h.snapshot_index; hot[HOT_ST] = h.snapshot_term;
+  hot[HOT_FIRST] = first_index; hot[HOT_LRS] = lrs; hot[HOT_LRT] = lrt;
+  hot[13] = 0; hot[14] = 0; hot[15] = 0;
+  u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
+  for (unsigned i = 0; i < dev.peer_stride; ++i) pr[i] = 0;
+  for (unsigned i = 0; i < N; ++i) {
+    pr[i] = h.match_index[i]; pr[N + i] = h.next_index[i]; pr[2 * N + i] = h.commit_index_sent[i];
+  }
+  u64 *cd = dev.cond + (size_t)s * 4;
+  for (int i = 0; i < 4; ++i) cd[i] = h.cond_reply[i];
+}
+
+__global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ out, u32 first, u32 n) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const u32 s = first + k;
+  rgb_server_state h;
+  memset(&h, 0, sizeof h);
+  const u64 *hot = dev.hot + (size_t)s * RGB_HOT_WORDS;
+  const unsigned N = dev.n_members;
+  const u64 pk = hot[HOT_PK];
+  h.current_term = hot[HOT_CT]; h.commit_index = hot[HOT_CI]; h.last_applied = hot[HOT_LA];
+  h.last_index = hot[HOT_LI]; h.last_term = hot[HOT_LT];
+  h.last_written_index = hot[HOT_LWI]; h.last_written_term = hot[HOT_LWT];
+  h.snapshot_index = hot[HOT_SI]; h.snapshot_term = hot[HOT_ST];
+  h.first_index = hot[HOT_FIRST];
+  const u64 *cd = dev.cond + (size_t)s * 4;
+  for (int i = 0; i < 4; ++i) h.cond_reply[i] = cd[i];
+  const u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
+  for (unsigned i = 0; i < N; ++i) {
+    h.match_index[i] = pr[i]; h.next_index[i] = pr[N + i]; h.commit_index_sent[i] = pr[2 * N + i];
+  }
+  unsigned nr = (unsigned)pk_get(pk, PK_NRUNS_SH, 5);
+  const u64 *runs = dev.runs + (size_t)s * dev.max_runs * 2;
+  if (!(h.first_index <= h.last_index)) { nr = 0; h.first_index = h.last_index + 1; }
+  for (unsigned r = 0; r < nr && r < RGB_MAX_RUNS; ++r) { h.run_start[r] = runs[2 * r]; h.run_term[r] = runs[2 * r + 1]; }
+  h.role = (uint8_t)pk_get(pk, PK_ROLE_SH, 3);
+  h.cond_reason = (uint8_t)pk_get(pk, PK_COND_SH, 2);
+  h.self = (uint8_t)pk_get(pk, PK_SELF_SH, 4);
+  h.n_members = (uint8_t)N;
+  h.voted_for = (uint8_t)slot4to8((unsigned)pk_get(pk, PK_VOTED_SH, 4));
+  h.leader_id = (uint8_t)slot4to8((unsigned)pk_get(pk, PK_LEADER_SH, 4));
+  h.votes = (uint8_t)pk_get(pk, PK_VOTES_SH, 4);
+  h.n_runs = (uint8_t)nr;
+  h.present_mask = (uint8_t)pk_get(pk, PK_PRESENT_SH, 8);
+  h.voter_mask = (uint8_t)pk_get(pk, PK_VOTER_SH, 8);
+  h.status_mask = (uint8_t)pk_get(pk, PK_STATUS_SH, 8);
+  h.self_nonvoter = (uint8_t)pk_get(pk, PK_NONVOTER_SH, 1);
+  h.cond_leader = (uint8_t)slot4to8((unsigned)pk_get(pk, PK_CONDLDR_SH, 4));
+  out[k] = h;
+}
+
+/* one thread per group: the ra_leaderboard row + key_metrics gauges of that group */
+__global__ void rgb_leaderboard_kernel(rgb_dev dev, rgb_leaderboard_row *__restrict__ rows, u32 n_groups) {
+  const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const unsigned N = dev.n_members;
+  u32 leader = RGB_NONE, n_leaders = 0;
+  u64 term = 0, lead_term = 0, ci = 0, la = 0, max_ci = 0, max_la = 0;
+  for (unsigned m = 0; m < N; ++m) {
+    const u64 *hot = dev.hot + ((size_t)g * N + m) * RGB_HOT_WORDS;
+    const ulonglong2 h0 = reinterpret_cast<const ulonglong2 *>(hot)[0];
+    const ulonglong2 h1 = reinterpret_cast<const ulonglong2 *>(hot)[1];
+    const u64 pk = hot[HOT_PK];
+    const u64 ct = h0.x;
+    if (ct > term) term = ct;
+    if (h0.y > max_ci) max_ci = h0.y;
+    if (h1.x > max_la) max_la = h1.x;
+    if (pk_get(pk, PK_ROLE_SH, 3) == RGB_ROLE_LEADER) {
+      n_leaders++;
+      if (leader == RGB_NONE || ct > lead_term) { leader = m; lead_term = ct; ci = h0.y; la = h1.x; }
+    }
+  }
+  rgb_leaderboard_row r;
+  r.leader = leader; r.n_leaders = n_leaders; r.term = term;
+  r.commit_index = leader == RGB_NONE ? max_ci : ci;
+  r.last_applied = leader == RGB_NONE ? max_la : la;
+  rows[g] = r;
+}
+
+__device__ __forceinline__ u64 fnv_word(u64 h, u64 w) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { h ^= (w >> (8 * i)) & 0xFFull; h *= 0x100000001B3ull; }
+  return h;
+}
+
+/* canonical-state checksum per server; same word order as oracle's ora_server_checksum */
+__global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restrict__ out) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const u32 s = first + k;
+  const u64 *hot = dev.hot + (size_t)s * RGB_HOT_WORDS;
+  const unsigned N = dev.n_members;
+  const u64 pk = hot[HOT_PK];
+  u64 li = hot[HOT_LI], fi = hot[HOT_FIRST];
+  unsigned nr = (unsigned)pk_get(pk, PK_NRUNS_SH, 5);
+  if (!(fi <= li)) { nr = 0; fi = li + 1; }
+  u64 x = 0xCBF29CE484222325ull;
+  x = fnv_word(x, hot[HOT_CT]); x = fnv_word(x, hot[HOT_CI]); x = fnv_word(x, hot[HOT_LA]);
+  x = fnv_word(x, li); x = fnv_word(x, hot[HOT_LT]); x = fnv_word(x, hot[HOT_LWI]);
+  x = fnv_word(x, hot[HOT_LWT]); x = fnv_word(x, hot[HOT_SI]); x = fnv_word(x, hot[HOT_ST]);
+  x = fnv_word(x, fi);
+  u64 packed = pk_get(pk, PK_ROLE_SH, 3) | (pk_get(pk, PK_COND_SH, 2) << 8) |
+               (pk_get(pk, PK_SELF_SH, 4) << 16) | ((u64)N << 24) |
+               ((u64)slot4to8((unsigned)pk_get(pk, PK_VOTED_SH, 4)) << 32) |
+               ((u64)slot4to8((unsigned)pk_get(pk, PK_LEADER_SH, 4)) << 40) |
+               (pk_get(pk, PK_VOTES_SH, 4) << 48) | ((u64)nr << 56);
+  x = fnv_word(x, packed);
+  u64 masks = pk_get(pk, PK_PRESENT_SH, 8) | (pk_get(pk, PK_VOTER_SH, 8) << 8) |
+              (pk_get(pk, PK_STATUS_SH, 8) << 16) | (pk_get(pk, PK_NONVOTER_SH, 1) << 24);
+  x = fnv_word(x, masks);
+  const u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
+  for (unsigned i = 0; i < N; ++i) {
+    x = fnv_word(x, pr[i]); x = fnv_word(x, pr[N + i]); x = fnv_word(x, pr[2 * N + i]);
+  }
+  const u64 *runs = dev.runs + (size_t)s * dev.max_runs * 2;
+  for (unsigned r = 0; r < nr; ++r) { x = fnv_word(x, runs[2 * r]); x = fnv_word(x, runs[2 * r + 1]); }
+  out[k] = x;
+}
+
+}  // namespace
+
+#define RGB_BLOCK 256
+
+int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, rgb_decision *d_dec,
+                    rgb_rpc *d_rpcs, u32 rpc_cap, u32 *d_rpc_count, u32 msg_index_base, void *stream) {
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((n + RGB_BLOCK - 1) / RGB_BLOCK), block(RGB_BLOCK);
+#define LAUNCH(NN)                                                                               \
+  case NN:                                                                                       \
+    hipLaunchKernelGGL(rgb_tick_kernel<NN>, grid, block, 0, st, dev, d_msgs, n, d_dec, d_rpcs,   \
+                       rpc_cap, d_rpc_count, msg_index_base);                                    \
+    break;
+  switch (dev.n_members) {
+    LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
+    default: return -1;
+  }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(rgb_pack_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dev, d_in, first, n);
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u32 n, void *stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(rgb_unpack_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dev, d_out, first, n);
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream) {
+  u32 g = dev.n_servers / dev.n_members;
+  if (g == 0) return 0;
+  hipLaunchKernelGGL(rgb_leaderboard_kernel, dim3((g + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev, d_rows, g);
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_checksum(const rgb_dev &dev, u32 first, u32 n, u64 *d_out, void *stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(rgb_checksum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev, first, n, d_out);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,227 @@
+"""ctypes binding of libra_gpu_batch.so (the C ABI of include/ra_gpu_batch.h).
+
+This is exactly what the Erlang NIF binds (ra_amd/csrc/ra_gpu_batch_nif.c); Python plays the
+role of the gen_statem shell in tests and benchmarks.  No CPU fallback: a missing library or a
+missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libra_gpu_batch.so")
+
+EXPORTS = [
+    "rgb_abi_version", "rgb_struct_size", "rgb_strerror", "rgb_default_config", "rgb_open",
+    "rgb_close", "rgb_last_hip_error", "rgb_register_groups", "rgb_n_servers", "rgb_upload_state",
+    "rgb_download_state", "rgb_submit", "rgb_collect", "rgb_run_ticks_device", "rgb_snapshot",
+    "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize",
+]
+
+
+class RgbError(RuntimeError):
+    def __init__(self, code: int, what: str, hip: int = 0):
+        self.code, self.hip = code, hip
+        super().__init__(f"{what}: rc={code} ({_strerror(code)})" + (f" hipError={hip}" if hip else ""))
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("rgb_kernels.hip", "rgb_api.hip", "rgb_internal.h")]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "ra_gpu_batch.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _CSRC, "libra_gpu_batch.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library and verify the ABI.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C ra_amd/csrc).  ra_gpu_batch has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError(f"libra_gpu_batch.so does not export {name}")
+    vp, u32, u64p = C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)
+    L.rgb_abi_version.restype = C.c_uint32
+    L.rgb_struct_size.restype = C.c_size_t
+    L.rgb_struct_size.argtypes = [C.c_int]
+    L.rgb_strerror.restype = C.c_char_p
+    L.rgb_strerror.argtypes = [C.c_int]
+    L.rgb_default_config.argtypes = [vp]
+    L.rgb_open.argtypes = [vp, C.POINTER(vp)]
+    L.rgb_close.argtypes = [vp]
+    L.rgb_last_hip_error.argtypes = [vp]
+    L.rgb_register_groups.argtypes = [vp, u32, u32]
+    L.rgb_n_servers.restype = C.c_uint32
+    L.rgb_n_servers.argtypes = [vp]
+    L.rgb_upload_state.argtypes = [vp, u32, u32, vp]
+    L.rgb_download_state.argtypes = [vp, u32, u32, vp]
+    L.rgb_submit.argtypes = [vp, vp, u32, C.c_uint64]
+    L.rgb_collect.argtypes = [vp, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), u64p]
+    L.rgb_run_ticks_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp]
+    L.rgb_snapshot.argtypes = [vp, vp]
+    L.rgb_snapshot_device.argtypes = [vp, vp, vp]
+    L.rgb_state_checksum.argtypes = [vp, u32, u32, u64p]
+    L.rgb_synchronize.argtypes = [vp]
+    if L.rgb_abi_version() != abi.ABI_VERSION:
+        raise RuntimeError("ABI version mismatch")
+    for i, dt in enumerate(abi.STRUCT_DTYPES):
+        if L.rgb_struct_size(i) != dt.itemsize:
+            raise RuntimeError(f"struct {i}: C size {L.rgb_struct_size(i)} != numpy {dt.itemsize}")
+    _lib = L
+    return L
+
+
+def _strerror(code: int) -> str:
+    try:
+        return lib().rgb_strerror(code).decode()
+    except Exception:
+        return "?"
+
+
+def default_config() -> np.ndarray:
+    cfg = np.zeros(1, dtype=abi.CONFIG_DTYPE)
+    lib().rgb_default_config(cfg.ctypes.data)
+    return cfg
+
+
+class RaGpuBatch:
+    """One rgb_ctx: the device-resident state of n_groups x n_members ra_servers on one GPU."""
+
+    def __init__(self, n_groups: int, n_members: int, device: int = 0, max_runs: int = 8,
+                 ring_slots: int = 4, ring_capacity: int = 65536, max_pipeline_count: int = 0,
+                 max_aer_batch: int = 0):
+        self._L = lib()
+        cfg = default_config()
+        cfg["device"] = device
+        cfg["max_runs"] = max_runs
+        cfg["ring_slots"] = ring_slots
+        cfg["ring_capacity"] = ring_capacity
+        if max_pipeline_count:
+            cfg["max_pipeline_count"] = max_pipeline_count
+        if max_aer_batch:
+            cfg["max_aer_batch"] = max_aer_batch
+        h = C.c_void_p()
+        rc = self._L.rgb_open(cfg.ctypes.data, C.byref(h))
+        if rc:
+            raise RgbError(rc, "rgb_open")
+        self._h = h
+        self.n_groups, self.n_members = n_groups, n_members
+        self.n_servers = n_groups * n_members
+        self.ring_capacity = ring_capacity
+        self._check(self._L.rgb_register_groups(self._h, n_groups, n_members), "rgb_register_groups")
+
+    # -- plumbing ------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc:
+            raise RgbError(rc, what, self._L.rgb_last_hip_error(self._h) if self._h else 0)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rgb_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- state transfer ----------------------------------------------------------------
+    def set_state(self, first: int, states: np.ndarray):
+        st = np.ascontiguousarray(states, dtype=abi.SERVER_STATE_DTYPE)
+        self._check(self._L.rgb_upload_state(self._h, first, len(st), st.ctypes.data), "rgb_upload_state")
+
+    def get_state(self, first: int = 0, n: int | None = None) -> np.ndarray:
+        n = self.n_servers - first if n is None else n
+        out = np.zeros(n, dtype=abi.SERVER_STATE_DTYPE)
+        self._check(self._L.rgb_download_state(self._h, first, n, out.ctypes.data), "rgb_download_state")
+        return out
+
+    # -- host path -------------------------------------------------------------------
+    def submit(self, msgs: np.ndarray, tick: int = 0):
+        m = np.ascontiguousarray(msgs, dtype=abi.MSG_DTYPE)
+        self._check(self._L.rgb_submit(self._h, m.ctypes.data, len(m), tick), "rgb_submit")
+
+    def collect(self, cap: int | None = None, rpc_cap: int | None = None):
+        cap = self.ring_capacity if cap is None else cap
+        rpc_cap = cap * max(self.n_members - 1, 1) if rpc_cap is None else rpc_cap
+        dec = np.zeros(cap, dtype=abi.DECISION_DTYPE)
+        rpcs = np.zeros(max(rpc_cap, 1), dtype=abi.RPC_DTYPE)
+        n, nr, tick = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        self._check(self._L.rgb_collect(self._h, dec.ctypes.data, cap, C.byref(n), rpcs.ctypes.data,
+                                        rpc_cap, C.byref(nr), C.byref(tick)), "rgb_collect")
+        if nr.value > rpc_cap:
+            raise RgbError(abi.E_FULL, f"rpc buffer overflow ({nr.value} > {rpc_cap})")
+        return dec[:n.value], rpcs[:nr.value], tick.value
+
+    def step(self, msgs: np.ndarray):
+        """submit + collect: decisions in submission order and the pipelined rpcs."""
+        m = np.ascontiguousarray(msgs, dtype=abi.MSG_DTYPE)
+        out_d, out_r = [], []
+        for off in range(0, max(len(m), 1), self.ring_capacity):
+            chunk = m[off:off + self.ring_capacity]
+            self.submit(chunk)
+            d, r, _ = self.collect(cap=max(len(chunk), 1))
+            r = r.copy()
+            r["msg_index"] += off
+            out_d.append(d)
+            out_r.append(r)
+        return np.concatenate(out_d), np.concatenate(out_r)
+
+    # -- device-resident path ------------------------------------------------------------
+    def run_ticks_device(self, d_msgs: int, n_per_tick: int, n_ticks: int, d_decisions: int,
+                         d_rpcs: int = 0, rpc_cap: int = 0, d_rpc_count: int = 0, stream: int = 0):
+        """Raw device pointers (e.g. torch tensors' data_ptr()); enqueues and returns."""
+        self._check(self._L.rgb_run_ticks_device(self._h, d_msgs, n_per_tick, n_ticks, d_decisions,
+                                                 d_rpcs or None, rpc_cap, d_rpc_count or None,
+                                                 stream or None), "rgb_run_ticks_device")
+
+    # -- observability -----------------------------------------------------------------
+    def snapshot(self) -> np.ndarray:
+        rows = np.zeros(self.n_groups, dtype=abi.LEADERBOARD_DTYPE)
+        self._check(self._L.rgb_snapshot(self._h, rows.ctypes.data), "rgb_snapshot")
+        return rows
+
+    def snapshot_device(self, d_rows: int, stream: int = 0):
+        self._check(self._L.rgb_snapshot_device(self._h, d_rows, stream or None), "rgb_snapshot_device")
+
+    def state_checksum(self, first: int = 0, n: int | None = None) -> int:
+        n = self.n_servers - first if n is None else n
+        out = C.c_uint64(0)
+        self._check(self._L.rgb_state_checksum(self._h, first, n, C.byref(out)), "rgb_state_checksum")
+        return out.value
+
+    def synchronize(self):
+        self._check(self._L.rgb_synchronize(self._h), "rgb_synchronize")
+
+
+def combine_checksums(per_server: np.ndarray, first: int = 0) -> int:
+    """The host-side 'checksum of checksums' rgb_state_checksum returns."""
+    acc = 0
+    for k, c in enumerate(per_server.tolist()):
+        acc = (acc + c * (2 * (first + k) + 1)) & 0xFFFFFFFFFFFFFFFF
+    return acc

@@ -1,0 +1,70 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/*.h declares.
+No compute calls here (there is no GPU); the product path must refuse to run without one."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from ra_amd import abi, engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "ra_gpu_batch.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgb_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    engine.build()
+    return engine.lib()
+
+
+def test_header_functions_are_all_exported(L):
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"libra_gpu_batch.so does not export {n}"
+    assert sorted(engine.EXPORTS) == names
+
+
+def test_struct_sizes_match_numpy_mirrors(L):
+    for i, dt in enumerate(abi.STRUCT_DTYPES):
+        assert L.rgb_struct_size(i) == dt.itemsize
+    assert abi.MSG_DTYPE.itemsize == 64 and abi.DECISION_DTYPE.itemsize == 64
+
+
+def test_strerror_and_default_config(L):
+    assert L.rgb_strerror(0) == b"ok"
+    assert b"no CPU fallback" in L.rgb_strerror(abi.E_NODEVICE)
+    cfg = engine.default_config()
+    assert int(cfg["abi_version"][0]) == abi.ABI_VERSION
+    assert int(cfg["max_pipeline_count"][0]) == 4096      # src/ra_server.hrl:8
+    assert int(cfg["max_aer_batch"][0]) == 128            # src/ra_server.hrl:7
+
+
+def test_open_without_gpu_fails_loudly(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = L.rgb_open(None, C.byref(h))
+    assert rc == abi.E_NODEVICE and not h.value
+    with pytest.raises(engine.RgbError):
+        engine.RaGpuBatch(4, 3)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path (ra_amd/, include/) must never import, link or call oracle/."""
+    bad = []
+    for base in ("ra_amd", "include"):
+        for dp, _dn, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".h", ".c", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"ra_oracle|libra_oracle|from oracle|import oracle|ora_step", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

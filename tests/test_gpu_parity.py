@@ -1,0 +1,193 @@
+"""Parity of the HIP path (through the C ABI) with the CPU checker and with the vectors
+transcribed from the reference's own tests.  Bit-exact: decisions, pipelined rpcs and the full
+final state must be identical.  Runs only on the GPU box (-m gpu)."""
+import numpy as np
+import pytest
+
+import fuzz
+import vector_runner as VR
+from ra_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+DATA = VR.load()
+
+
+@pytest.fixture(scope="module")
+def engine_mod():
+    from ra_amd import engine
+    engine.lib()          # raises if the HIP library is missing: no fallback
+    return engine
+
+
+def assert_same(tag, dg, rg, sg, do, ro, so):
+    if dg.tobytes() != do.tobytes():
+        for i in range(len(dg)):
+            if dg[i].tobytes() != do[i].tobytes():
+                raise AssertionError(f"{tag}: decision {i} differs\n gpu={dg[i]}\n cpu={do[i]}")
+    rg, ro = fuzz.sort_rpcs(rg), fuzz.sort_rpcs(ro)
+    assert len(rg) == len(ro), f"{tag}: rpc count gpu={len(rg)} cpu={len(ro)}"
+    if rg.tobytes() != ro.tobytes():
+        for i in range(len(rg)):
+            if rg[i].tobytes() != ro[i].tobytes():
+                raise AssertionError(f"{tag}: rpc {i} differs\n gpu={rg[i]}\n cpu={ro[i]}")
+    if sg.tobytes() != so.tobytes():
+        for i in range(len(sg)):
+            if sg[i].tobytes() != so[i].tobytes():
+                diff = [n for n in sg.dtype.names if np.any(sg[i][n] != so[i][n])]
+                raise AssertionError(f"{tag}: state of server {i} differs in {diff}\n gpu={sg[i]}\n cpu={so[i]}")
+
+
+@pytest.mark.parametrize("v", DATA["vectors"], ids=[v["id"] for v in DATA["vectors"]])
+def test_hip_matches_reference_vector(engine_mod, v):
+    VR.run_vector(lambda g, n: engine_mod.RaGpuBatch(g, n, ring_capacity=64, ring_slots=2), v)
+
+
+@pytest.mark.parametrize("n_members,seed,groups", [(3, 101, 300), (5, 102, 400), (7, 103, 300),
+                                                   (8, 104, 150), (1, 105, 50), (2, 106, 100)])
+def test_hip_equals_oracle_on_random_ticks(engine_mod, oracle_lib, n_members, seed, groups):
+    rng = np.random.default_rng(seed)
+    st = fuzz.random_states(rng, groups, n_members)
+    cpu = oracle_lib.Oracle(groups, n_members)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(groups, n_members, ring_capacity=4096, ring_slots=2) as gpu:
+        gpu.set_state(0, st)
+        assert gpu.get_state().tobytes() == st.tobytes(), "upload/download is not the identity"
+        seen_flags = 0
+        seen_inv = set()
+        for tick in range(10):
+            cur = cpu.get_state()
+            msgs = fuzz.random_msgs(rng, cur, n_members)
+            do, ro = cpu.step(msgs)
+            dg, rg = gpu.step(msgs)
+            assert_same(f"N={n_members} tick {tick}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+            seen_flags |= int(np.bitwise_or.reduce(do["flags"])) if len(do) else 0
+            seen_inv |= set(do["invariant"].tolist())
+            # checksum of checksums agrees with the checker's per-server checksums
+            want = engine_mod.combine_checksums(oracle_lib.server_checksums(cpu.get_state()))
+            assert gpu.state_checksum() == want
+        if n_members >= 3:
+            for f in ("REPLY", "PERSIST", "LEADER_MSG", "APPLIED", "WROTE", "TRUNCATED", "PIPELINE",
+                      "REPROCESSED", "ROLE_CHANGED", "UNHANDLED", "INVARIANT"):
+                assert seen_flags & VR.FLAG[f], f"fuzz never produced {f}"
+
+
+def test_same_server_messages_are_serialised_in_submission_order(engine_mod, oracle_lib):
+    """Several messages for one server inside one submit are applied in order (sub-ticks),
+    exactly like the sequential checker (= the gen_statem mailbox)."""
+    rng = np.random.default_rng(7)
+    G, N = 64, 5
+    st = fuzz.random_states(rng, G, N)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=8192, ring_slots=2) as gpu:
+        gpu.set_state(0, st)
+        for rnd in range(3):
+            parts = [fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.6) for _ in range(4)]
+            msgs = np.concatenate(parts)
+            rng.shuffle(msgs)
+            do, ro = cpu.step(msgs)
+            dg, rg = gpu.step(msgs)
+            assert_same(f"round {rnd}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+
+
+def test_pipelined_ring_keeps_batches_in_order(engine_mod, oracle_lib):
+    """submit/submit/submit then collect x3: the staging ring returns batches oldest first."""
+    rng = np.random.default_rng(9)
+    G, N = 128, 3
+    st = fuzz.random_states(rng, G, N)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=1024, ring_slots=3) as gpu:
+        gpu.set_state(0, st)
+        batches = []
+        for t in range(3):
+            # independent of state evolution on purpose: all built from the initial state
+            batches.append(fuzz.random_msgs(rng, st, N, frac=0.5))
+        for t, b in enumerate(batches):
+            gpu.submit(b, tick=100 + t)
+        with pytest.raises(engine_mod.RgbError):
+            gpu.submit(batches[0])                      # ring full
+        for t, b in enumerate(batches):
+            do, _ = cpu.step(b)
+            dg, _, tick = gpu.collect()
+            assert tick == 100 + t
+            assert dg.tobytes() == do.tobytes()
+        with pytest.raises(engine_mod.RgbError):
+            gpu.collect()                               # nothing submitted
+
+
+def test_device_resident_ticks_match_host_path(engine_mod, oracle_lib):
+    import torch
+    rng = np.random.default_rng(21)
+    G, N = 512, 5
+    st = fuzz.random_states(rng, G, N)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    ticks = []
+    decs = []
+    for t in range(4):
+        m = fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.5)
+        pad = np.zeros(G * N - len(m), dtype=abi.MSG_DTYPE)     # NOP padding to a fixed width
+        m = np.concatenate([m, pad])
+        d, _ = cpu.step(m)
+        ticks.append(m)
+        decs.append(d)
+    allm = np.concatenate(ticks)
+    with engine_mod.RaGpuBatch(G, N) as gpu:
+        gpu.set_state(0, st)
+        dm = torch.from_numpy(allm.view(np.uint8).reshape(-1)).cuda()
+        dd = torch.zeros(len(allm) * 64, dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        gpu.run_ticks_device(dm.data_ptr(), G * N, 4, dd.data_ptr(), 0, 0, cnt.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = dd.cpu().numpy().view(abi.DECISION_DTYPE)
+        want = np.concatenate(decs)
+        assert got.tobytes() == want.tobytes()
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes()
+
+
+def test_leaderboard_snapshot(engine_mod):
+    G, N = 16, 5
+    st = abi.empty_server_states(G, N)
+    st["current_term"] = np.repeat(np.arange(G, dtype=np.uint64) + 1, N)
+    for g in range(G):
+        if g % 4 != 3:
+            l = g % N
+            st["role"][g * N + l] = abi.ROLE_LEADER
+            st["commit_index"][g * N + l] = 10 + g
+            st["last_applied"][g * N + l] = 5 + g
+    with engine_mod.RaGpuBatch(G, N) as gpu:
+        gpu.set_state(0, st)
+        rows = gpu.snapshot()
+    for g in range(G):
+        if g % 4 != 3:
+            assert int(rows["leader"][g]) == g % N and int(rows["n_leaders"][g]) == 1
+            assert int(rows["commit_index"][g]) == 10 + g and int(rows["last_applied"][g]) == 5 + g
+        else:
+            assert int(rows["leader"][g]) == abi.NONE and int(rows["n_leaders"][g]) == 0
+        assert int(rows["term"][g]) == g + 1
+
+
+def test_run_table_overflow_is_flagged(engine_mod):
+    """More term changes than max_runs: the oldest run is dropped, first_index raised, flag set."""
+    with engine_mod.RaGpuBatch(1, 3, max_runs=3, ring_capacity=16, ring_slots=1) as gpu:
+        flags = 0
+        for t in range(1, 6):
+            m = np.zeros(1, dtype=abi.MSG_DTYPE)
+            m["server"] = 1
+            m["kind"] = abi.MSG_AER
+            m["from"] = 0
+            m["term"] = t
+            m["a"], m["b"] = t - 1, (t - 1)
+            m["c"] = 0
+            m["n_entries"], m["n_run0"], m["run0_term"] = 1, 1, t
+            d, _ = gpu.step(m)
+            flags |= int(d["flags"][0])
+            assert int(d["flags"][0]) & abi.F_WROTE
+        st = gpu.get_state()[1]
+        assert flags & abi.F_RUNS_OVERFLOW
+        assert int(st["n_runs"]) == 3 and int(st["last_index"]) == 5 and int(st["last_term"]) == 5
+        assert int(st["first_index"]) == int(st["run_start"][0]) == 3
