@@ -833,6 +833,9 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
   if (m->server >= c->n_servers) { d->flags = RGB_F_UNHANDLED; d->role = 0xFF; return; }
   oserver *sv = &c->sv[m->server];
   oscal saved = sv->s;                                      /* a crash leaves the old state */
+  olog saved_log = sv->log;                                 /* cursors only: ra_log:append (the one
+                                                               edit a later assertion can follow)
+                                                               writes above the old last index */
   ofx fx;
   memset(&fx, 0, sizeof fx);
   fx.reply_to = RGB_NONE;
@@ -854,6 +857,8 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
   }
   if (rc) {
     sv->s = saved;
+    saved_log.terms = sv->log.terms; saved_log.cap = sv->log.cap; saved_log.base = sv->log.base;
+    sv->log = saved_log;
     d->role = saved.role;
     d->flags = RGB_F_INVARIANT;
     d->invariant = (uint32_t)rc;
@@ -889,7 +894,7 @@ static void server_init_empty(oserver *sv, uint32_t n_members, uint32_t self) {
   sv->s.present_mask = (uint8_t)((1u << n_members) - 1u);
   sv->s.voter_mask = sv->s.present_mask;
   sv->s.status_mask = 0xFF;
-  for (unsigned i = 0; i < RGB_MAX_MEMBERS; i++) sv->s.next_index[i] = 1;
+  for (unsigned i = 0; i < n_members; i++) sv->s.next_index[i] = 1;
   olog *l = &sv->log;
   free(l->terms);
   memset(l, 0, sizeof *l);

@@ -117,7 +117,7 @@ def empty_server_states(n_groups: int, n_members: int) -> np.ndarray:
     st = np.zeros(n, dtype=SERVER_STATE_DTYPE)
     st["snapshot_index"] = UNDEF
     st["snapshot_term"] = UNDEF
-    st["next_index"] = 1
+    st["next_index"][:, :n_members] = 1   # slots beyond n_members stay 0 (canonical form)
     st["role"] = ROLE_FOLLOWER
     st["self"] = np.arange(n, dtype=np.uint32) % n_members
     st["n_members"] = n_members

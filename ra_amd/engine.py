@@ -54,6 +54,14 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C ra_amd/csrc).  ra_gpu_batch has no CPU fallback.")
+    # One HIP/HSA runtime per process: when PyTorch is installed its bundled libamdhip64.so.7 must
+    # be the copy in the process (a second HSA runtime cannot open the device), so import torch
+    # BEFORE the library resolves that soname.  The library itself has no torch dependency (the
+    # Erlang NIF uses /opt/rocm's runtime).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the binding
+        pass
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(L, name):

@@ -18,7 +18,8 @@ def test_oracle_fuzz_deterministic_and_roundtrip(oracle_lib, n_members, seed):
     assert got.tobytes() == st.tobytes(), "set_state/get_state is not the identity"
     b.set_state(0, st)
     for _ in range(6):
-        msgs = fuzz.random_msgs(rng, a.get_state(), n_members)
+        before = a.get_state()
+        msgs = fuzz.random_msgs(rng, before, n_members)
         da, ra = a.step(msgs)
         db, rb = b.step(msgs)
         assert da.tobytes() == db.tobytes() and ra.tobytes() == rb.tobytes()
@@ -30,6 +31,9 @@ def test_oracle_fuzz_deterministic_and_roundtrip(oracle_lib, n_members, seed):
         assert np.all(sa["last_applied"] <= np.maximum(sa["last_index"], sa["last_applied"]))
         inv = (da["flags"] & abi.F_INVARIANT) != 0
         assert np.all(da["invariant"][inv] > 0) and np.all(da["invariant"][~inv] == 0)
+        # an exit/assert of the reference leaves the server exactly as it was
+        for srv in msgs["server"][inv]:
+            assert sa[srv].tobytes() == before[srv].tobytes(), f"server {srv} changed on invariant"
 
 
 def test_parallel_step_equals_sequential_on_a_tick(oracle_lib):
