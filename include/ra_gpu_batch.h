@@ -165,7 +165,7 @@ enum { RGB_RPC_AER = 1, RGB_RPC_SNAPSHOT = 2 };
  * make_pipelined_rpc_effects/3 (src/ra_server.erl:2285-2346): entries are
  * prev_log_index+1 .. prev_log_index+n_entries, read from ra_log by the host.
  * RGB_RPC_SNAPSHOT: {send_snapshot, Peer, _}; prev_log_index = snapshot index.
- * Records are emitted unordered; (msg_index, peer) identifies them.
+ * rgb_collect returns them ordered by (msg_index, peer).
  */
 typedef struct rgb_rpc {
   uint32_t msg_index;   /* index of the triggering message in the submitted batch */
@@ -288,14 +288,17 @@ int  rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick);
 int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
                  rgb_rpc *rpc_out, uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out);
 
-/* Device-resident path (benchmarks, device-side producers): d_msgs holds n_ticks dense ticks of
- * n_per_tick messages each, at most ONE message per server per tick (caller's guarantee);
- * d_decisions receives n_ticks*n_per_tick decisions; d_rpcs (capacity rpc_cap records) and the
- * uint32 counter d_rpc_count receive the pipelined rpcs (may be NULL to discard).  Enqueued on
- * `stream` (a hipStream_t, NULL = the context's stream); returns without synchronising. */
-int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t n_per_tick, uint32_t n_ticks,
-                          void *d_decisions, void *d_rpcs, uint32_t rpc_cap, void *d_rpc_count,
-                          void *stream);
+/* Device-resident path (benchmarks, device-side producers): d_msgs holds n_ticks ticks laid out
+ * tick_stride messages apart; tick t carries tick_counts[t] messages (host array; NULL = every
+ * tick carries tick_stride messages), at most ONE message per server per tick (caller's
+ * guarantee).  d_decisions has the same layout.  d_rpcs, when not NULL, receives the pipelined
+ * rpcs of the CURRENT tick in fixed slots: message i owns records [i*(n_members-1),
+ * (i+1)*(n_members-1)) of which the first rgb_decision.n_rpcs are valid; the buffer
+ * (tick_stride*(n_members-1) records) is rewritten every tick.  Enqueued on `stream` (a
+ * hipStream_t, NULL = the context's stream); returns without synchronising. */
+int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
+                          const uint32_t *tick_counts, uint32_t n_ticks, void *d_decisions,
+                          void *d_rpcs, void *stream);
 
 /* leaderboard / metrics snapshot: one row per group */
 int  rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out);

@@ -21,11 +21,9 @@
 struct rgb_slot {
   rgb_msg *h_msgs = nullptr;        /* pinned */
   rgb_decision *h_dec = nullptr;    /* pinned */
-  u32 *h_count = nullptr;           /* pinned */
   rgb_msg *d_msgs = nullptr;
   rgb_decision *d_dec = nullptr;
   rgb_rpc *d_rpcs = nullptr;
-  u32 *d_count = nullptr;
   std::vector<u32> perm;            /* device position -> submission index */
   u32 n = 0;
   uint64_t tick = 0;
@@ -46,7 +44,8 @@ struct rgb_ctx {
   /* ring */
   std::vector<rgb_slot> ring;
   u32 head = 0, tail = 0, in_flight = 0;
-  u32 rpc_cap = 0;
+  u32 rpc_cap = 0;      /* records per ring slot = ring_capacity * rpc_stride */
+  u32 rpc_stride = 1;   /* fixed rpc slots per message = max(n_members-1, 1) */
   std::vector<rgb_rpc> h_rpc_tmp;
   /* sub-tick scheduling scratch */
   std::vector<uint16_t> seen;
@@ -115,11 +114,9 @@ int rgb_last_hip_error(const rgb_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
 static void free_slot(rgb_slot &s) {
   if (s.h_msgs) (void)hipHostFree(s.h_msgs);
   if (s.h_dec) (void)hipHostFree(s.h_dec);
-  if (s.h_count) (void)hipHostFree(s.h_count);
   if (s.d_msgs) (void)hipFree(s.d_msgs);
   if (s.d_dec) (void)hipFree(s.d_dec);
   if (s.d_rpcs) (void)hipFree(s.d_rpcs);
-  if (s.d_count) (void)hipFree(s.d_count);
   if (s.done) (void)hipEventDestroy(s.done);
   s = rgb_slot();
 }
@@ -172,11 +169,9 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   const u32 cap = ctx->cfg.ring_capacity;
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_msgs, (size_t)cap * sizeof(rgb_msg), hipHostMallocDefault));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_dec, (size_t)cap * sizeof(rgb_decision), hipHostMallocDefault));
-  HIPCHK(ctx, hipHostMalloc((void **)&s.h_count, sizeof(u32), hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_msgs, (size_t)cap * sizeof(rgb_msg)));
   HIPCHK(ctx, hipMalloc((void **)&s.d_dec, (size_t)cap * sizeof(rgb_decision)));
   HIPCHK(ctx, hipMalloc((void **)&s.d_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc)));
-  HIPCHK(ctx, hipMalloc((void **)&s.d_count, sizeof(u32)));
   HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   return RGB_OK;
 }
@@ -207,7 +202,8 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
                             hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&ctx->d_rows, (size_t)n_groups * sizeof(rgb_leaderboard_row)));
   HIPCHK(ctx, hipMalloc((void **)&ctx->d_sums, (size_t)S * sizeof(u64)));
-  ctx->rpc_cap = ctx->cfg.ring_capacity * (n_members > 1 ? n_members - 1 : 1);
+  ctx->rpc_stride = n_members > 1 ? n_members - 1 : 1;
+  ctx->rpc_cap = ctx->cfg.ring_capacity * ctx->rpc_stride;
   ctx->ring.resize(ctx->cfg.ring_slots);
   for (auto &s : ctx->ring) {
     int rc = alloc_slot(ctx, s);
@@ -343,20 +339,17 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     }
   }
   s.n = n; s.tick = tick;
-  *s.h_count = 0;
   if (n) {
     HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice,
                                ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(s.d_count, 0, sizeof(u32), ctx->stream));
     for (u32 r = 0; r < n_rounds; ++r) {
       u32 off = start[r], cnt = start[r + 1] - start[r];
-      int rc = rgb_launch_tick(ctx->dev, s.d_msgs + off, cnt, s.d_dec + off, s.d_rpcs, ctx->rpc_cap,
-                               s.d_count, off, ctx->stream);
+      int rc = rgb_launch_tick(ctx->dev, s.d_msgs + off, cnt, s.d_dec + off,
+                               s.d_rpcs + (size_t)off * ctx->rpc_stride, off, ctx->stream);
       if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
     }
     HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost,
                                ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(s.h_count, s.d_count, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
   s.busy = true;
@@ -375,18 +368,28 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
   if (s.n > cap || (s.n && !out)) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   HIPCHK(ctx, hipEventSynchronize(s.done));
-  for (u32 p = 0; p < s.n; ++p) out[s.perm[p]] = s.h_dec[p];
-  u32 n_rpc = *s.h_count;
-  u32 avail = n_rpc < ctx->rpc_cap ? n_rpc : ctx->rpc_cap;
-  if (avail && rpc_out) {
-    u32 take = avail < rpc_cap ? avail : rpc_cap;
-    ctx->h_rpc_tmp.resize(take);
-    HIPCHK(ctx, hipMemcpy(ctx->h_rpc_tmp.data(), s.d_rpcs, (size_t)take * sizeof(rgb_rpc),
-                          hipMemcpyDeviceToHost));
-    for (u32 k = 0; k < take; ++k) {
-      rgb_rpc r = ctx->h_rpc_tmp[k];
-      if (r.msg_index < s.n) r.msg_index = s.perm[r.msg_index];
-      rpc_out[k] = r;
+  /* decisions back in submission order; remember where each one ran on the device */
+  std::vector<u32> pos_of(s.n);
+  u32 n_rpc = 0, last_with = 0;
+  bool any = false;
+  for (u32 p = 0; p < s.n; ++p) {
+    out[s.perm[p]] = s.h_dec[p];
+    pos_of[s.perm[p]] = p;
+    if (s.h_dec[p].n_rpcs) { n_rpc += s.h_dec[p].n_rpcs; last_with = p; any = true; }
+  }
+  if (any && rpc_out) {
+    /* the fixed rpc slots of messages [0, last_with] */
+    size_t recs = (size_t)(last_with + 1) * ctx->rpc_stride;
+    ctx->h_rpc_tmp.resize(recs);
+    HIPCHK(ctx, hipMemcpy(ctx->h_rpc_tmp.data(), s.d_rpcs, recs * sizeof(rgb_rpc), hipMemcpyDeviceToHost));
+    u32 k = 0;
+    for (u32 i = 0; i < s.n && k < rpc_cap; ++i) {           /* ordered by (msg_index, peer) */
+      u32 p = pos_of[i];
+      for (u32 q = 0; q < s.h_dec[p].n_rpcs && k < rpc_cap; ++q) {
+        rgb_rpc r = ctx->h_rpc_tmp[(size_t)p * ctx->rpc_stride + q];
+        r.msg_index = i;
+        rpc_out[k++] = r;
+      }
     }
   }
   if (n_out) *n_out = s.n;
@@ -398,18 +401,19 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
   return RGB_OK;
 }
 
-int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t n_per_tick, uint32_t n_ticks,
-                         void *d_decisions, void *d_rpcs, uint32_t rpc_cap, void *d_rpc_count,
-                         void *stream) {
+int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
+                         const uint32_t *tick_counts, uint32_t n_ticks, void *d_decisions,
+                         void *d_rpcs, void *stream) {
   if (!ctx || !d_msgs || !d_decisions) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   void *st = stream ? stream : (void *)ctx->stream;
   const rgb_msg *m = (const rgb_msg *)d_msgs;
   rgb_decision *d = (rgb_decision *)d_decisions;
   for (u32 t = 0; t < n_ticks; ++t) {
-    size_t off = (size_t)t * n_per_tick;
-    int rc = rgb_launch_tick(ctx->dev, m + off, n_per_tick, d + off, (rgb_rpc *)d_rpcs, rpc_cap,
-                             (u32 *)d_rpc_count, (u32)off, st);
+    size_t off = (size_t)t * tick_stride;
+    u32 cnt = tick_counts ? tick_counts[t] : tick_stride;
+    if (cnt > tick_stride) return RGB_E_INVAL;
+    int rc = rgb_launch_tick(ctx->dev, m + off, cnt, d + off, (rgb_rpc *)d_rpcs, (u32)off, st);
     if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
   }
   return RGB_OK;

@@ -6,9 +6,8 @@
  * server, so lanes never share state.  Per lane: 4x16-B loads of the message, 7x16-B loads
  * of the server's hot line, lazily the peers line (leader-side messages) and term-run probes
  * (log-matching repair), the transition itself in registers, then 16-B stores of whatever
- * changed and of the 64-B decision.  Outbound append_entries_rpc descriptors are compacted
- * through one wave-aggregated atomic per wave (the compiler folds the per-lane atomicAdd into
- * a ballot/mbcnt + one atomic).
+ * changed and of the 64-B decision.  Outbound append_entries_rpc descriptors go to fixed slots
+ * (message index x (N-1) + ordinal): no atomics, deterministic placement.
  *
  * Semantics restate (independently of oracle/) the reference clauses cited per function:
  *   src/ra_server.erl handle_leader/2 :530-1040, handle_candidate/2 :1043-1190,
@@ -358,7 +357,7 @@ __device__ void evaluate_quorum(Lane &L, unsigned ov_peer, u64 ov_mi) {
 template <int N, bool EMIT>
 __device__ int pipeline_rpcs(Lane &L, bool force, unsigned ov_peer, u64 ov_mi, u64 ov_ni,
                              u32 max_pipe, u32 max_batch, bool &more, unsigned &n_out,
-                             rgb_rpc *rpcs, u32 rpc_cap, u32 *rpc_count, u32 msg_index) {
+                             rgb_rpc *rpcs, u32 slot_base, u32 msg_index) {
   const unsigned self = self_of(L);
   const u64 next_log = next_log_index(L);
   more = false;
@@ -403,16 +402,12 @@ __device__ int pipeline_rpcs(Lane &L, bool force, unsigned ov_peer, u64 ov_mi, u
       L.peers[i] = mi;
       L.peers[N + i] = new_ni;
       L.peers[2 * N + i] = L.ci;
-      if (rpc_count != nullptr) {
-        u32 slot = atomicAdd(rpc_count, 1u);
-        if (rpcs != nullptr && slot < rpc_cap) {
-          rgb_rpc r;
-          r.msg_index = msg_index; r.server = L.server; r.peer = (uint8_t)i;
-          r.kind = (uint8_t)kind; r.n_entries = (uint16_t)n_ent; r._pad = 0;
-          r.term = L.ct; r.prev_log_index = rp_idx; r.prev_log_term = rp_term;
-          r.leader_commit = L.ci; r.next_index = new_ni;
-          rpcs[slot] = r;
-        }
+      if (rpcs != nullptr) {
+        /* fixed slot: this message's (n_out-1)-th record; 56 B = 7 x 8-B stores */
+        u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
+        o[0] = (u64)msg_index | ((u64)L.server << 32);
+        o[1] = (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16);
+        o[2] = L.ct; o[3] = rp_idx; o[4] = rp_term; o[5] = L.ci; o[6] = new_ni;
       }
     }
   }
@@ -571,7 +566,7 @@ __device__ int handle_follower(Lane &L) {
 /* -------------------------------------------------------------------- leader ---- */
 template <int N>
 __device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_rpc *rpcs,
-                             u32 rpc_cap, u32 *rpc_count, u32 msg_index, unsigned &n_rpcs) {
+                             u32 slot_base, u32 msg_index, unsigned &n_rpcs) {
   switch (L.kind) {
     case RGB_MSG_AER_REPLY: {
       const unsigned peer = L.from;
@@ -614,10 +609,10 @@ __device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_r
         }
         bool more; unsigned cnt;
         int rc = pipeline_rpcs<N, false>(L, false, peer, mi, ni, dev.max_pipeline_count,
-                                         dev.max_aer_batch, more, cnt, nullptr, 0, nullptr, 0);
+                                         dev.max_aer_batch, more, cnt, nullptr, 0, 0);
         if (rc) return rc;
         pipeline_rpcs<N, true>(L, false, peer, mi, ni, dev.max_pipeline_count, dev.max_aer_batch,
-                               more, cnt, rpcs, rpc_cap, rpc_count, msg_index);
+                               more, cnt, rpcs, slot_base, msg_index);
         /* the peer edit must land even when the peer itself got no rpc */
         if (!(status_normal(L, peer) && peer != self_of(L))) {
           L.peers[peer] = mi; L.peers[N + peer] = ni;
@@ -678,14 +673,14 @@ __device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_r
       }
       bool more; unsigned cnt;
       int rc = pipeline_rpcs<N, false>(L, force, 0xFFu, 0, 0, dev.max_pipeline_count,
-                                       dev.max_aer_batch, more, cnt, nullptr, 0, nullptr, 0);
+                                       dev.max_aer_batch, more, cnt, nullptr, 0, 0);
       if (rc) {
         L.li = s_li; L.lt = s_lt; L.lrs = s_lrs; L.lrt = s_lrt; L.first = s_first;
         L.n_runs = s_nr; L.push_cnt = s_pc;
         return rc;
       }
       pipeline_rpcs<N, true>(L, force, 0xFFu, 0, 0, dev.max_pipeline_count, dev.max_aer_batch,
-                             more, cnt, rpcs, rpc_cap, rpc_count, msg_index);
+                             more, cnt, rpcs, slot_base, msg_index);
       n_rpcs = cnt;
       if (L.kind == RGB_MSG_PIPELINE_RPCS && more) L.flags |= RGB_F_PIPELINE;   /* :793-801 */
       return 0;
@@ -844,8 +839,7 @@ __device__ __forceinline__ void store_decision(rgb_decision *out, u32 server, un
 template <int N>
 __global__ __launch_bounds__(256) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
                                                        u32 n, rgb_decision *__restrict__ dec,
-                                                       rgb_rpc *__restrict__ rpcs, u32 rpc_cap,
-                                                       u32 *__restrict__ rpc_count, u32 msg_index_base) {
+                                                       rgb_rpc *__restrict__ rpcs, u32 msg_index_base) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   /* message: 4 x 16 B */
@@ -897,7 +891,7 @@ __global__ __launch_bounds__(256) void rgb_tick_kernel(rgb_dev dev, const rgb_ms
     bool reprocess = false;
     switch (role_of(L)) {
       case RGB_ROLE_FOLLOWER:        rc = handle_follower(L); break;
-      case RGB_ROLE_LEADER:          rc = handle_leader<N>(L, reprocess, dev, rpcs, rpc_cap, rpc_count,
+      case RGB_ROLE_LEADER:          rc = handle_leader<N>(L, reprocess, dev, rpcs, i * (N > 1 ? N - 1 : 1),
                                                            msg_index_base + i, n_rpcs); break;
       case RGB_ROLE_CANDIDATE:       rc = handle_candidate<N>(L, reprocess); break;
       case RGB_ROLE_PRE_VOTE:        rc = handle_pre_vote(L, reprocess); break;
@@ -1134,14 +1128,14 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
 #define RGB_BLOCK 256
 
 int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, rgb_decision *d_dec,
-                    rgb_rpc *d_rpcs, u32 rpc_cap, u32 *d_rpc_count, u32 msg_index_base, void *stream) {
+                    rgb_rpc *d_rpcs, u32 msg_index_base, void *stream) {
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((n + RGB_BLOCK - 1) / RGB_BLOCK), block(RGB_BLOCK);
 #define LAUNCH(NN)                                                                               \
   case NN:                                                                                       \
     hipLaunchKernelGGL(rgb_tick_kernel<NN>, grid, block, 0, st, dev, d_msgs, n, d_dec, d_rpcs,   \
-                       rpc_cap, d_rpc_count, msg_index_base);                                    \
+                       msg_index_base);                                                          \
     break;
   switch (dev.n_members) {
     LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)

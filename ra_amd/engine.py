@@ -83,7 +83,7 @@ def lib():
     L.rgb_download_state.argtypes = [vp, u32, u32, vp]
     L.rgb_submit.argtypes = [vp, vp, u32, C.c_uint64]
     L.rgb_collect.argtypes = [vp, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), u64p]
-    L.rgb_run_ticks_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp]
+    L.rgb_run_ticks_device.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp]
     L.rgb_snapshot.argtypes = [vp, vp]
     L.rgb_snapshot_device.argtypes = [vp, vp, vp]
     L.rgb_state_checksum.argtypes = [vp, u32, u32, u64p]
@@ -201,12 +201,17 @@ class RaGpuBatch:
         return np.concatenate(out_d), np.concatenate(out_r)
 
     # -- device-resident path ------------------------------------------------------------
-    def run_ticks_device(self, d_msgs: int, n_per_tick: int, n_ticks: int, d_decisions: int,
-                         d_rpcs: int = 0, rpc_cap: int = 0, d_rpc_count: int = 0, stream: int = 0):
-        """Raw device pointers (e.g. torch tensors' data_ptr()); enqueues and returns."""
-        self._check(self._L.rgb_run_ticks_device(self._h, d_msgs, n_per_tick, n_ticks, d_decisions,
-                                                 d_rpcs or None, rpc_cap, d_rpc_count or None,
-                                                 stream or None), "rgb_run_ticks_device")
+    def run_ticks_device(self, d_msgs: int, tick_stride: int, n_ticks: int, d_decisions: int,
+                         d_rpcs: int = 0, stream: int = 0, tick_counts: np.ndarray | None = None):
+        """Raw device pointers (e.g. torch tensors' data_ptr()); enqueues and returns.
+        tick_counts: messages per tick (uint32, host) or None for tick_stride each."""
+        cp = None
+        if tick_counts is not None:
+            tc = np.ascontiguousarray(tick_counts, dtype=np.uint32)
+            assert len(tc) >= n_ticks
+            cp = tc.ctypes.data
+        self._check(self._L.rgb_run_ticks_device(self._h, d_msgs, tick_stride, cp, n_ticks, d_decisions,
+                                                 d_rpcs or None, stream or None), "rgb_run_ticks_device")
 
     # -- observability -----------------------------------------------------------------
     def snapshot(self) -> np.ndarray:

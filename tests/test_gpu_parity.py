@@ -140,11 +140,19 @@ def test_device_resident_ticks_match_host_path(engine_mod, oracle_lib):
         gpu.set_state(0, st)
         dm = torch.from_numpy(allm.view(np.uint8).reshape(-1)).cuda()
         dd = torch.zeros(len(allm) * 64, dtype=torch.uint8, device="cuda")
-        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        dr = torch.zeros(G * N * (N - 1) * 56, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.Stream()
         torch.cuda.synchronize()
-        gpu.run_ticks_device(dm.data_ptr(), G * N, 4, dd.data_ptr(), 0, 0, cnt.data_ptr(),
-                             torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.stream(stream):
+            gpu.run_ticks_device(dm.data_ptr(), G * N, 4, dd.data_ptr(), dr.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize()
+        # the rpc slots hold the LAST tick's pipelined rpcs
+        last = decs[-1]
+        slots = dr.cpu().numpy().view(abi.RPC_DTYPE).reshape(G * N, N - 1)
+        got_r = np.concatenate([slots[i, :int(last["n_rpcs"][i])] for i in range(G * N)]
+                               + [np.zeros(0, dtype=abi.RPC_DTYPE)])
+        assert int(last["n_rpcs"].sum()) == len(got_r)
+        assert np.all(got_r["msg_index"] >= 3 * G * N)
         got = dd.cpu().numpy().view(abi.DECISION_DTYPE)
         want = np.concatenate(decs)
         assert got.tobytes() == want.tobytes()
