@@ -66,8 +66,13 @@ enum {
   RGB_MSG_WRITTEN       = 5,  /* {ra_log_event,{written,Term,Seq}} (contiguous Seq = [from..to])    */
   RGB_MSG_PIPELINE_RPCS = 6,  /* info event pipeline_rpcs    src/ra_server.erl:793-801             */
   RGB_MSG_APPEND        = 7,  /* {command,_} / {commands,_}: leader appended n entries in its term */
-  RGB_MSG_AWAIT_TIMEOUT = 8   /* await_condition_timeout     src/ra_server.erl:1932-1945           */
+  RGB_MSG_AWAIT_TIMEOUT = 8,  /* await_condition_timeout     src/ra_server.erl:1932-1945           */
+  RGB_MSG_ELECTION_TIMEOUT = 9,  /* election_timeout -> call_for_election/2 src/ra_server.erl:2877-2924 */
+  RGB_MSG_PRE_VOTE_RPC     = 10, /* #pre_vote_rpc{}          src/ra.hrl:157-166                    */
+  RGB_MSG_PRE_VOTE_RESULT  = 11  /* #pre_vote_result{}       src/ra.hrl:168-171                    */
 };
+#define RGB_MSG_KIND_MAX RGB_MSG_PRE_VOTE_RESULT
+#define RGB_PROTO_VERSION 1u    /* ?RA_PROTO_VERSION src/ra.hrl:107 */
 
 /* rgb_msg.flags */
 #define RGB_MF_SUCCESS  0x01u  /* AER_REPLY: success=true; VOTE_RESULT: vote_granted=true */
@@ -83,6 +88,10 @@ enum {
  *   VOTE_RESULT   term, from=voter, flags&SUCCESS=vote_granted
  *   WRITTEN       term, a=first index of the written range, b=last index of the written range
  *   APPEND        n_entries = number of commands appended by the leader (flags&FORCE for noop)
+ *   ELECTION_TIMEOUT  c = fresh pre-vote token (the host's make_ref())
+ *   PRE_VOTE_RPC  term, from=candidate_id, a=last_log_index, b=last_log_term, c=token,
+ *                 n_entries=candidate machine_version, gap=protocol version
+ *   PRE_VOTE_RESULT term, from=voter, flags&SUCCESS=vote_granted, c=token
  */
 typedef struct rgb_msg {
   uint32_t server;      /* target server id = group * n_members + member slot */
@@ -119,6 +128,12 @@ typedef struct rgb_msg {
 #define RGB_F_INVARIANT      (1u << 15) /* the reference would exit/assert; code in .invariant; state unchanged       */
 #define RGB_F_RUNS_OVERFLOW  (1u << 16) /* term-run table overflowed: oldest run dropped, first_index raised          */
 #define RGB_F_SEND_SNAPSHOT  (1u << 17) /* a pipelined peer needs {send_snapshot,..} (rgb_rpc kind RGB_RPC_SNAPSHOT)  */
+#define RGB_F_REPLY_PRE_VOTE (1u << 18) /* the reply is a #pre_vote_result{}: reply_term, token in reply_next_index   */
+#define RGB_F_START_ELECTION_TIMEOUT (1u << 19) /* effect start_election_timeout                                      */
+#define RGB_F_SEND_VOTE_REQUESTS (1u << 20) /* {send_vote_requests,Reqs} to every peer: term=reply_term,
+                                             last_log_index=reply_last_index, last_log_term=reply_last_term;
+                                             #request_vote_rpc{} unless RGB_F_PRE_VOTE_REQS                           */
+#define RGB_F_PRE_VOTE_REQS  (1u << 21) /* the requests are #pre_vote_rpc{} with token=reply_next_index               */
 
 /* rgb_decision.invariant: exit reasons / failed assertions of the reference */
 enum {
@@ -223,6 +238,9 @@ typedef struct rgb_server_state {
   uint8_t  self_nonvoter;       /* own `membership` =/= voter                             */
   uint8_t  cond_leader;         /* await_condition: who the stored reply is cast to       */
   uint8_t  _pad[3];
+  uint64_t pre_vote_token;      /* pre_vote_token (an Erlang reference, opaque 64 bits)   */
+  uint32_t machine_version;     /* cfg.machine_version                                    */
+  uint32_t effective_machine_version; /* cfg.effective_machine_version                    */
 } rgb_server_state;
 
 /* ra_leaderboard row + key_metrics gauges per group (src/ra_leaderboard.erl:18-26, src/ra.erl:1242-1250) */

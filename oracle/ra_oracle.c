@@ -48,6 +48,8 @@ typedef struct {
            commit_index_sent[RGB_MAX_MEMBERS];
   uint8_t  role, cond_reason, self, n_members, voted_for, leader_id, votes;
   uint8_t  present_mask, voter_mask, status_mask, self_nonvoter, cond_leader;
+  uint64_t pre_vote_token;
+  uint32_t machine_version, effective_machine_version;
 } oscal;
 
 typedef struct {
@@ -243,6 +245,7 @@ typedef struct {
   uint64_t w_first, w_last;
   rgb_rpc *rpcs; uint32_t rpc_cap, n_rpcs_total; uint8_t n_rpcs;
   uint32_t msg_index;
+  int      vote_reqs;              /* {send_vote_requests,..}: request fields ride in r_* */
 } ofx;
 
 static int is_present(const oscal *s, unsigned i) {
@@ -413,6 +416,147 @@ static int make_pipelined_rpc_effects(struct ora_ctx *c, oserver *sv, uint32_t s
   return 0;
 }
 
+/* required_quorum/1 :3996-3999, count_voters/1 :4001-4009 */
+static unsigned required_quorum(const oscal *s) {
+  unsigned voters = 0;
+  for (unsigned i = 0; i < s->n_members; i++)
+    if (is_present(s, i) && ((s->voter_mask >> i) & 1u)) voters++;
+  return voters / 2 + 1;
+}
+
+/* the leader branch of handle_candidate(#request_vote_result{vote_granted = true}) :1055-1058 */
+static void become_leader(oserver *sv, ofx *fx) {
+  oscal *s = &sv->s;
+  /* initialise_peers/1 :3234-3242: every member next_index = ra_log:next_index,
+   * match_index 0, commit_index_sent 0, status normal */
+  uint64_t ni = log_next_index(&sv->log);
+  for (unsigned i = 0; i < s->n_members; i++) {
+    if (!is_present(s, i)) continue;
+    s->next_index[i] = ni; s->match_index[i] = 0; s->commit_index_sent[i] = 0;
+  }
+  s->status_mask = 0xFF;
+  set_leader_id(s, s->self, fx);
+  s->votes = 0;
+  set_role(s, RGB_ROLE_LEADER, fx);
+  fx->flags |= RGB_F_BECAME_LEADER;
+}
+
+/* one granted vote for a candidate in its own term, :1045-1061 */
+static void candidate_vote_granted(oserver *sv, ofx *fx) {
+  oscal *s = &sv->s;
+  unsigned nv = (unsigned)s->votes + 1;
+  if (nv == required_quorum(s)) become_leader(sv, fx);
+  else s->votes = (uint8_t)nv;
+}
+
+static void vote_requests(oserver *sv, uint64_t term, int pre, ofx *fx) {
+  uint64_t li, lt;
+  log_last_index_term(&sv->log, &li, &lt);
+  fx->flags &= ~(uint32_t)RGB_F_PRE_VOTE_REQS;   /* a single-member pre-vote goes straight on to the real vote */
+  fx->flags |= RGB_F_SEND_VOTE_REQUESTS | (pre ? RGB_F_PRE_VOTE_REQS : 0);
+  fx->has_reply = 0;
+  fx->r_term = term; fx->r_next = pre ? sv->s.pre_vote_token : 0; fx->r_last = li; fx->r_lterm = lt;
+  fx->vote_reqs = 1;
+}
+
+/* call_for_election(candidate, State) :2880-2899; the {next_event, cast, VoteForSelf} it emits
+ * is the next message the reference processes, so it is applied here */
+static void call_for_election_candidate(oserver *sv, ofx *fx) {
+  oscal *s = &sv->s;
+  uint64_t new_term = s->current_term + 1;
+  update_term_and_voted_for(s, new_term, s->self, fx);
+  set_leader_id(s, RGB_NONE, fx);
+  s->votes = 0;
+  set_role(s, RGB_ROLE_CANDIDATE, fx);
+  vote_requests(sv, new_term, 0, fx);
+  candidate_vote_granted(sv, fx);                         /* vote for self */
+}
+
+/* call_for_election(pre_vote, State) :2900-2924 (+ the self pre-vote, :1229-1246) */
+static void call_for_election_pre_vote(oserver *sv, uint64_t token, ofx *fx) {
+  oscal *s = &sv->s;
+  update_term_and_voted_for(s, s->current_term, s->self, fx);
+  set_leader_id(s, RGB_NONE, fx);
+  s->votes = 0;
+  s->pre_vote_token = token;
+  set_role(s, RGB_ROLE_PRE_VOTE, fx);
+  vote_requests(sv, s->current_term, 1, fx);
+  /* self #pre_vote_result{vote_granted = true}: only counted when membership is voter */
+  if (!s->self_nonvoter) {
+    unsigned nv = (unsigned)s->votes + 1;
+    if (nv == required_quorum(s)) call_for_election_candidate(sv, fx);
+    else s->votes = (uint8_t)nv;
+  }
+}
+
+static void pre_vote_reply(uint64_t term, uint64_t token, int granted, uint8_t to, ofx *fx) {
+  fx->has_reply = 1;
+  fx->flags |= RGB_F_REPLY | RGB_F_REPLY_PRE_VOTE | (granted ? RGB_F_REPLY_SUCCESS : 0);
+  fx->r_term = term; fx->r_next = token; fx->r_last = 0; fx->r_lterm = 0;
+  fx->reply_to = to;
+}
+
+/* process_pre_vote/3 :2926-2983 (the server stays in FsmState) */
+static int process_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx) {
+  oscal *s = &sv->s;
+  uint64_t token = m->c;
+  if (m->term >= s->current_term) {
+    update_term(s, m->term, fx);              /* pre-vote never sets voted_for */
+    uint64_t li, lt;
+    log_last_index_term(&sv->log, &li, &lt);
+    int up = (m->b > lt) || (m->b == lt && m->a >= li);
+    uint32_t theirs = m->n_entries, eff = s->effective_machine_version, ours = s->machine_version;
+    if (up && (uint32_t)m->gap > RGB_PROTO_VERSION) {
+      pre_vote_reply(m->term, token, 0, m->from, fx);
+    } else if (up && (theirs == eff || (theirs >= eff && theirs <= ours))) {
+      pre_vote_reply(m->term, token, 1, m->from, fx);
+    } else if (up) {
+      pre_vote_reply(m->term, token, 0, m->from, fx);
+      fx->flags |= RGB_F_START_ELECTION_TIMEOUT;
+    } else if (s->role == RGB_ROLE_FOLLOWER) {
+      fx->flags |= RGB_F_START_ELECTION_TIMEOUT;          /* no reply, :2968-2969 */
+    } else {
+      pre_vote_reply(m->term, token, 0, m->from, fx);
+    }
+    return 0;
+  }
+  pre_vote_reply(s->current_term, token, 0, m->from, fx);
+  return 0;
+}
+
+/* make_all_rpcs/1 :2353-2367 -> make_rpcs_for/2 :2369-2377: one append_entries_rpc (batch size 1)
+ * to every peer with status normal; next_index is NOT advanced.  (heartbeat effects and
+ * snapshot_backoff peers are outside the device model.) */
+static int make_all_rpcs(oserver *sv, uint32_t srv_id, ofx *fx) {
+  oscal *s = &sv->s;
+  for (unsigned i = 0; i < s->n_members; i++) {
+    if (i == s->self || !is_present(s, i)) continue;
+    if (!((s->status_mask >> i) & 1u)) continue;
+    uint64_t prev = s->next_index[i] - 1;
+    uint64_t prev_term = log_fetch_term(&sv->log, prev);
+    rgb_rpc r;
+    memset(&r, 0, sizeof r);
+    r.msg_index = fx->msg_index; r.server = srv_id; r.peer = (uint8_t)i;
+    r.term = s->current_term; r.leader_commit = s->commit_index;
+    if (prev_term == UNDEF && !(sv->log.snap_idx != UNDEF && sv->log.snap_idx == prev)) {
+      if (sv->log.snap_idx == UNDEF || !(prev < sv->log.snap_idx)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
+      r.kind = RGB_RPC_SNAPSHOT; r.prev_log_index = sv->log.snap_idx; r.prev_log_term = sv->log.snap_term;
+      r.next_index = sv->log.snap_idx;
+      fx->flags |= RGB_F_SEND_SNAPSHOT;
+    } else {
+      if (prev_term == UNDEF) prev_term = sv->log.snap_term;
+      uint64_t li, lt;
+      log_last_index_term(&sv->log, &li, &lt);
+      uint64_t to = prev + 1 < li ? prev + 1 : li;
+      r.kind = RGB_RPC_AER; r.prev_log_index = prev; r.prev_log_term = prev_term;
+      r.n_entries = (uint16_t)(to >= prev + 1 ? to - prev : 0);
+      r.next_index = to + 1;
+    }
+    emit_rpc(fx, &r);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------- follower clauses -- */
 static int follower_aer(oserver *sv, const rgb_msg *m, ofx *fx);
 
@@ -555,6 +699,14 @@ static int handle_follower(oserver *sv, const rgb_msg *m, ofx *fx) {
       return 0;
     }
     case RGB_MSG_VOTE_RESULT:  return 0;                   /* :1609-1611 ignored */
+    case RGB_MSG_PRE_VOTE_RESULT: return 0;                /* :1612-1614 ignored */
+    case RGB_MSG_PRE_VOTE_RPC:
+      if (sv->s.self_nonvoter) return 0;                   /* :1475-1480 ignored, no reply */
+      return process_pre_vote(sv, m, fx);                  /* :1481-1482 */
+    case RGB_MSG_ELECTION_TIMEOUT:
+      if (sv->s.self_nonvoter) return 0;                   /* :1619-1624 */
+      call_for_election_pre_vote(sv, m->c, fx);            /* :1625-1626 */
+      return 0;
     default:
       fx->flags |= RGB_F_UNHANDLED;                        /* :1655 catch-all */
       return 0;
@@ -664,6 +816,21 @@ static int handle_leader(struct ora_ctx *c, oserver *sv, uint32_t srv_id, const 
       int more;
       return make_pipelined_rpc_effects(c, sv, srv_id, (m->flags & RGB_MF_FORCE) != 0, &more, fx);
     }
+    case RGB_MSG_PRE_VOTE_RPC: {
+      if (m->term > s->current_term) {
+        /* :946-960 */
+        if (!is_present(s, m->from)) return 0;
+        set_leader_id(s, RGB_NONE, fx);
+        update_term(s, m->term, fx);
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      return make_all_rpcs(sv, srv_id, fx);                /* :961-966 enforce leadership */
+    }
+    case RGB_MSG_VOTE_RESULT:                              /* :967-969 */
+    case RGB_MSG_PRE_VOTE_RESULT:                          /* :970-972 */
+      return 0;
     default:
       fx->flags |= RGB_F_UNHANDLED;
       return 0;
@@ -677,28 +844,7 @@ static int handle_candidate(oserver *sv, const rgb_msg *m, ofx *fx, int *reproce
     case RGB_MSG_VOTE_RESULT: {
       int granted = (m->flags & RGB_MF_SUCCESS) != 0;
       if (granted && m->term == s->current_term) {
-        /* :1045-1061, required_quorum/1 :3996-3999, count_voters/1 :4001-4009 */
-        unsigned voters = 0;
-        for (unsigned i = 0; i < s->n_members; i++)
-          if (is_present(s, i) && ((s->voter_mask >> i) & 1u)) voters++;
-        unsigned quorum = voters / 2 + 1;
-        unsigned nv = (unsigned)s->votes + 1;
-        if (nv == quorum) {
-          /* initialise_peers/1 :3234-3242: every member next_index = ra_log:next_index,
-           * match_index 0, commit_index_sent 0, status normal */
-          uint64_t ni = log_next_index(&sv->log);
-          for (unsigned i = 0; i < s->n_members; i++) {
-            if (!is_present(s, i)) continue;
-            s->next_index[i] = ni; s->match_index[i] = 0; s->commit_index_sent[i] = 0;
-          }
-          s->status_mask = 0xFF;
-          set_leader_id(s, s->self, fx);
-          s->votes = 0;
-          set_role(s, RGB_ROLE_LEADER, fx);
-          fx->flags |= RGB_F_BECAME_LEADER;
-        } else {
-          s->votes = (uint8_t)nv;
-        }
+        candidate_vote_granted(sv, fx);                     /* :1045-1061 */
         return 0;
       }
       if (m->term > s->current_term) {
@@ -740,6 +886,18 @@ static int handle_candidate(oserver *sv, const rgb_msg *m, ofx *fx, int *reproce
     case RGB_MSG_WRITTEN:
       log_written(&sv->log, m->term, m->a, m->b);           /* :1157-1160 */
       return 0;
+    case RGB_MSG_PRE_VOTE_RPC:
+      if (m->term > s->current_term) {
+        update_term_and_voted_for(s, m->term, RGB_NONE, fx); /* :1116-1122 */
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      return process_pre_vote(sv, m, fx);                   /* :1127-1131 */
+    case RGB_MSG_PRE_VOTE_RESULT: return 0;                 /* :1135-1137 */
+    case RGB_MSG_ELECTION_TIMEOUT:
+      call_for_election_candidate(sv, fx);                  /* :1161-1162 */
+      return 0;
     default:
       fx->flags |= RGB_F_UNHANDLED;
       return 0;
@@ -775,6 +933,28 @@ static int handle_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx, int *reproces
     case RGB_MSG_WRITTEN:
       log_written(&sv->log, m->term, m->a, m->b);           /* :1257-1260 */
       return 0;
+    case RGB_MSG_PRE_VOTE_RESULT: {
+      int granted = (m->flags & RGB_MF_SUCCESS) != 0;
+      if (m->term > s->current_term) {
+        update_term(s, m->term, fx);                        /* :1219-1228 */
+        s->votes = 0;
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        return 0;
+      }
+      if (granted && m->term == s->current_term && m->c == s->pre_vote_token && !s->self_nonvoter) {
+        /* :1229-1246 */
+        unsigned nv = (unsigned)s->votes + 1;
+        if (nv == required_quorum(s)) call_for_election_candidate(sv, fx);
+        else s->votes = (uint8_t)nv;
+        return 0;
+      }
+      return 0;                                             /* :1247-1249 */
+    }
+    case RGB_MSG_PRE_VOTE_RPC:
+      return process_pre_vote(sv, m, fx);                   /* :1250-1251 */
+    case RGB_MSG_ELECTION_TIMEOUT:
+      call_for_election_pre_vote(sv, m->c, fx);             /* :1255-1256 */
+      return 0;
     default:
       fx->flags |= RGB_F_UNHANDLED;
       return 0;
@@ -802,6 +982,12 @@ static int handle_await_condition(oserver *sv, const rgb_msg *m, ofx *fx, int *r
     }
     case RGB_MSG_WRITTEN:
       log_written(&sv->log, m->term, m->a, m->b);           /* :1946-1949, no reply */
+      return 0;
+    case RGB_MSG_PRE_VOTE_RPC:
+      return process_pre_vote(sv, m, fx);                   /* :1920-1921 */
+    case RGB_MSG_ELECTION_TIMEOUT:
+      if (s->self_nonvoter) return 0;                       /* :1922-1929 */
+      call_for_election_pre_vote(sv, m->c, fx);             /* :1930-1931 */
       return 0;
     case RGB_MSG_AER: {
       /* follower_catchup_cond/3 :2201-2218 */
@@ -871,8 +1057,8 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
   d->role = sv->s.role;
   d->flags = fx.flags;
   d->n_rpcs = fx.n_rpcs;
-  if (fx.has_reply) {
-    d->reply_to = fx.reply_to;
+  if (fx.has_reply || fx.vote_reqs) {
+    d->reply_to = fx.has_reply ? fx.reply_to : RGB_NONE;
     d->reply_term = fx.r_term; d->reply_next_index = fx.r_next;
     d->reply_last_index = fx.r_last; d->reply_last_term = fx.r_lterm;
   } else if (fx.flags & RGB_F_WROTE) {
@@ -945,6 +1131,9 @@ int ora_set_state(ora_ctx *c, uint32_t first, uint32_t n, const rgb_server_state
     s->votes = h->votes; s->present_mask = h->present_mask; s->voter_mask = h->voter_mask;
     s->status_mask = h->status_mask; s->self_nonvoter = h->self_nonvoter;
     s->cond_leader = h->cond_leader;
+    s->pre_vote_token = h->pre_vote_token;
+    s->machine_version = h->machine_version;
+    s->effective_machine_version = h->effective_machine_version;
     olog *l = &sv->log;
     free(l->terms);
     memset(l, 0, sizeof *l);
@@ -990,6 +1179,9 @@ int ora_get_state(const ora_ctx *c, uint32_t first, uint32_t n, rgb_server_state
     h->votes = s->votes; h->present_mask = s->present_mask; h->voter_mask = s->voter_mask;
     h->status_mask = s->status_mask; h->self_nonvoter = s->self_nonvoter;
     h->cond_leader = s->cond_leader;
+    h->pre_vote_token = s->pre_vote_token;
+    h->machine_version = s->machine_version;
+    h->effective_machine_version = s->effective_machine_version;
     if (l->has_range) {
       h->first_index = l->first;
       unsigned nr = 0;
@@ -1073,6 +1265,8 @@ uint64_t ora_server_checksum(const rgb_server_state *h) {
   uint64_t masks = (uint64_t)h->present_mask | ((uint64_t)h->voter_mask << 8) |
                    ((uint64_t)h->status_mask << 16) | ((uint64_t)h->self_nonvoter << 24);
   x = fnv_word(x, masks);
+  x = fnv_word(x, h->pre_vote_token);
+  x = fnv_word(x, (uint64_t)h->machine_version | ((uint64_t)h->effective_machine_version << 32));
   for (unsigned i = 0; i < h->n_members && i < RGB_MAX_MEMBERS; i++) {
     x = fnv_word(x, h->match_index[i]); x = fnv_word(x, h->next_index[i]);
     x = fnv_word(x, h->commit_index_sent[i]);

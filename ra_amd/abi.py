@@ -23,7 +23,9 @@ ROLE_NAMES = ["follower", "candidate", "leader", "pre_vote", "await_condition"]
 COND_NONE, COND_MISSING, COND_TERM_MISMATCH = range(3)
 
 (MSG_NOP, MSG_AER, MSG_AER_REPLY, MSG_REQUEST_VOTE, MSG_VOTE_RESULT, MSG_WRITTEN,
- MSG_PIPELINE_RPCS, MSG_APPEND, MSG_AWAIT_TIMEOUT) = range(9)
+ MSG_PIPELINE_RPCS, MSG_APPEND, MSG_AWAIT_TIMEOUT, MSG_ELECTION_TIMEOUT, MSG_PRE_VOTE_RPC,
+ MSG_PRE_VOTE_RESULT) = range(12)
+PROTO_VERSION = 1
 MF_SUCCESS = 0x01
 MF_FORCE = 0x02
 
@@ -45,6 +47,10 @@ F_UNHANDLED = 1 << 14
 F_INVARIANT = 1 << 15
 F_RUNS_OVERFLOW = 1 << 16
 F_SEND_SNAPSHOT = 1 << 17
+F_REPLY_PRE_VOTE = 1 << 18
+F_START_ELECTION_TIMEOUT = 1 << 19
+F_SEND_VOTE_REQUESTS = 1 << 20
+F_PRE_VOTE_REQS = 1 << 21
 
 (INV_NONE, INV_LEADER_SAW_AER_SAME_TERM, INV_TRUNCATE_BELOW_APPLIED, INV_WRITE_BELOW_APPLIED,
  INV_MISMATCH_TERM_UNDEFINED, INV_WRITE_INTEGRITY, INV_SET_LAST_INDEX_NOT_FOUND,
@@ -90,6 +96,7 @@ SERVER_STATE_DTYPE = np.dtype([
     ("voted_for", u8), ("leader_id", u8), ("votes", u8), ("n_runs", u8),
     ("present_mask", u8), ("voter_mask", u8), ("status_mask", u8), ("self_nonvoter", u8),
     ("cond_leader", u8), ("_pad", u8, (3,)),
+    ("pre_vote_token", u64), ("machine_version", u32), ("effective_machine_version", u32),
 ])
 
 LEADERBOARD_DTYPE = np.dtype([
@@ -104,7 +111,7 @@ CONFIG_DTYPE = np.dtype([
 
 STRUCT_DTYPES = [MSG_DTYPE, DECISION_DTYPE, RPC_DTYPE, SERVER_STATE_DTYPE, LEADERBOARD_DTYPE,
                  CONFIG_DTYPE]
-EXPECTED_SIZES = [64, 64, 56, 576, 32, 32]
+EXPECTED_SIZES = [64, 64, 56, 592, 32, 32]
 for _dt, _sz in zip(STRUCT_DTYPES, EXPECTED_SIZES):
     assert _dt.itemsize == _sz, (_dt, _dt.itemsize, _sz)
 

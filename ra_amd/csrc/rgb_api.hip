@@ -289,7 +289,7 @@ int rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_stat
 }
 
 static int validate_msg(const rgb_ctx *ctx, const rgb_msg &m) {
-  if (m.kind > RGB_MSG_AWAIT_TIMEOUT) return RGB_E_INVAL;
+  if (m.kind > RGB_MSG_KIND_MAX) return RGB_E_INVAL;
   if (m.kind == RGB_MSG_NOP) return RGB_OK;
   if (m.server >= ctx->dev.n_servers) return RGB_E_INVAL;
   if (m.from != RGB_NONE && m.from >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
@@ -326,17 +326,24 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     if (r + 1 > n_rounds) n_rounds = r + 1;
   }
   for (u32 t : ctx->touched) ctx->seen[t] = 0;
+  /* device order: by round, then by clause family = (message kind, success flag) (a round holds
+   * at most one message per server, so its order is free; family-homogeneous wavefronts do not
+   * diverge across clause families), stable inside a bucket */
+  const u32 NK = 2 * (RGB_MSG_KIND_MAX + 1);
+  auto family = [](const rgb_msg &m) -> u32 { return 2u * m.kind + (m.flags & RGB_MF_SUCCESS ? 1u : 0u); };
   std::vector<u32> start(n_rounds + 1, 0);
-  for (u32 i = 0; i < n; ++i) start[ctx->round_of[i] + 1]++;
+  std::vector<u32> bucket((size_t)n_rounds * NK + 1, 0);
+  for (u32 i = 0; i < n; ++i) {
+    start[ctx->round_of[i] + 1]++;
+    bucket[(size_t)ctx->round_of[i] * NK + family(msgs[i]) + 1]++;
+  }
   for (u32 r = 0; r < n_rounds; ++r) start[r + 1] += start[r];
+  for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) bucket[b + 1] += bucket[b];
   s.perm.resize(n);
-  {
-    std::vector<u32> pos(start.begin(), start.end() - (n_rounds ? 1 : 0));
-    for (u32 i = 0; i < n; ++i) {
-      u32 p = pos[ctx->round_of[i]]++;
-      s.perm[p] = i;
-      s.h_msgs[p] = msgs[i];
-    }
+  for (u32 i = 0; i < n; ++i) {
+    u32 p = bucket[(size_t)ctx->round_of[i] * NK + family(msgs[i])]++;
+    s.perm[p] = i;
+    s.h_msgs[p] = msgs[i];
   }
   s.n = n; s.tick = tick;
   if (n) {

@@ -20,6 +20,11 @@
 #define UNDEF 0xFFFFFFFFFFFFFFFFull
 #define SLOT_NONE4 0xFu
 
+#define RGB_TICK_BLOCK 64
+#ifndef RGB_MIN_WAVES
+#define RGB_MIN_WAVES(N) 2   /* waves per SIMD the register allocator must leave room for */
+#endif
+
 namespace {
 
 __device__ __forceinline__ u64 pk_get(u64 pk, int sh, int w) { return (pk >> sh) & ((1ull << w) - 1ull); }
@@ -34,7 +39,7 @@ __device__ __forceinline__ unsigned slot4to8(unsigned s) { return s >= 8u ? (uns
  * the effects being accumulated and the pending (uncommitted) log-table edits. */
 struct Lane {
   /* hot line */
-  u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt;
+  u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt, token, macver;
   /* message */
   u32 server, n_entries, n_run0;
   unsigned kind, from, mflags, gap;
@@ -50,6 +55,7 @@ struct Lane {
   unsigned reply_to;
   u64 r_term, r_next, r_last, r_lterm;
   u64 w_first, w_last;
+  bool vote_reqs;        /* {send_vote_requests,..}: the request fields ride in r_* */
   /* pending run-table edits: n_runs is the NEW count; the last `push_cnt` runs are not in
    * memory yet: (ps0,pt0) then (lrs,lrt) */
   unsigned n_runs;
@@ -57,14 +63,48 @@ struct Lane {
   u64 ps0, pt0;
   bool cond_dirty;
   u64 cr0, cr1, cr2, cr3;
-  /* pending peer edit (leader): one peer slot may have new match/next before commit */
+  /* the server's peers row in registers (leader-side messages): match_index / next_index /
+   * commit_index_sent per member, loaded with the hot line (one round trip), written back
+   * word by word where the dirty masks say so.  Only indexes < N are ever touched (loops are
+   * fully unrolled on the template parameter, so these arrays live in VGPRs). */
+  u64 pmi[8], pni[8], pcs[8];
+  unsigned dmi, dni, dcs;
   bool peers_loaded;
 };
+
+template <int N>
+__device__ __forceinline__ void load_peers(Lane &L) {
+  if (L.peers_loaded) return;
+  constexpr int PS = (3 * N + 7) & ~7;
+  u64 w[PS];
+  const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(L.peers);
+#pragma unroll
+  for (int k = 0; k < PS / 2; ++k) {
+    if (2 * k < 3 * N) { ulonglong2 v = pp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { L.pmi[i] = w[i]; L.pni[i] = w[N + i]; L.pcs[i] = w[2 * N + i]; }
+  L.peers_loaded = true;
+}
+
+template <int N>
+__device__ __forceinline__ u64 peer_get(const u64 (&a)[8], unsigned p) {
+  u64 r = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r = ((unsigned)i == p) ? a[i] : r;
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void peer_set(u64 (&a)[8], unsigned &dirty, unsigned p, u64 v) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if ((unsigned)i == p) { a[i] = v; dirty |= 1u << i; }
+}
 
 __device__ __forceinline__ bool range_nonempty(const Lane &L) { return L.first <= L.li; }
 
 /* ra_log:fetch_term/2 (src/ra_log.erl:1186-1200): defined only inside the range */
-__device__ u64 fetch_term(const Lane &L, u64 idx) {
+__device__ __forceinline__ u64 fetch_term(const Lane &L, u64 idx) {
   if (!(range_nonempty(L) && idx >= L.first && idx <= L.li)) return UNDEF;
   if (idx >= L.lrs) return L.lrt;
   /* older runs are all in memory (only the newest may be pending) */
@@ -89,7 +129,7 @@ __device__ __forceinline__ u64 srv_fetch_term(const Lane &L, u64 idx) {
 
 /* index of the run holding idx (largest k with start_k <= idx), -1 if none.  Only called
  * before any edit of this message is pending. */
-__device__ int find_run(const Lane &L, u64 idx) {
+__device__ __forceinline__ int find_run(const Lane &L, u64 idx) {
   if (L.n_runs == 0) return -1;
   if (idx >= L.lrs) return (int)L.n_runs - 1;
   for (int k = (int)L.n_runs - 2; k >= 0; --k)
@@ -109,7 +149,7 @@ __device__ __forceinline__ u64 next_log_index(const Lane &L) {
 
 enum { HLE_OK = 0, HLE_MISMATCH = 1, HLE_MISSING = 2 };
 /* has_log_entry_or_snapshot/3 (src/ra_server.erl:3168-3183) */
-__device__ int has_log_entry_or_snapshot(const Lane &L, u64 idx, u64 term) {
+__device__ __forceinline__ int has_log_entry_or_snapshot(const Lane &L, u64 idx, u64 term) {
   u64 t = fetch_term(L, idx);
   if (t == UNDEF) {
     if (L.si != UNDEF && L.si == idx) return L.st == term ? HLE_OK : HLE_MISMATCH;
@@ -129,7 +169,7 @@ __device__ __forceinline__ bool status_normal(const Lane &L, unsigned i) { retur
 
 /* role change; become(follower,..) resets every peer status to normal
  * (src/ra_server.erl:2183-2192) */
-__device__ void set_role(Lane &L, unsigned role) {
+__device__ __forceinline__ void set_role(Lane &L, unsigned role) {
   unsigned old = role_of(L);
   if (old != role) L.flags |= RGB_F_ROLE_CHANGED;
   if (role == RGB_ROLE_FOLLOWER && old != RGB_ROLE_FOLLOWER)
@@ -139,7 +179,7 @@ __device__ void set_role(Lane &L, unsigned role) {
 }
 
 /* update_term_and_voted_for/3 (src/ra_server.erl:3041-3058); voted4 is a 4-bit slot */
-__device__ void update_term_and_voted_for(Lane &L, u64 term, unsigned voted4) {
+__device__ __forceinline__ void update_term_and_voted_for(Lane &L, u64 term, unsigned voted4) {
   unsigned cur = (unsigned)pk_get(L.pk, PK_VOTED_SH, 4);
   if (term == L.ct && voted4 == cur) return;
   L.flags |= RGB_F_PERSIST;
@@ -156,17 +196,30 @@ __device__ __forceinline__ void set_leader_id(Lane &L, unsigned l4) {
 }
 
 /* append_entries_reply/3 (src/ra_server.erl:3624-3631) */
-__device__ void aer_reply(Lane &L, u64 term, bool success, unsigned to8) {
+__device__ __forceinline__ void aer_reply(Lane &L, u64 term, bool success, unsigned to8) {
   L.has_reply = true;
   L.flags |= RGB_F_REPLY | (success ? RGB_F_REPLY_SUCCESS : 0u);
   L.r_term = term; L.r_next = L.li + 1; L.r_last = L.lwi; L.r_lterm = L.lwt;
   L.reply_to = to8;
 }
-__device__ void vote_reply(Lane &L, u64 term, bool granted, unsigned to8) {
+__device__ __forceinline__ void vote_reply(Lane &L, u64 term, bool granted, unsigned to8) {
   L.has_reply = true;
   L.flags |= RGB_F_REPLY | RGB_F_REPLY_VOTE | (granted ? RGB_F_REPLY_SUCCESS : 0u);
   L.r_term = term; L.r_next = 0; L.r_last = 0; L.r_lterm = 0;
   L.reply_to = to8;
+}
+
+__device__ __forceinline__ void pre_vote_reply(Lane &L, u64 term, u64 token, bool granted, unsigned to8) {
+  L.has_reply = true;
+  L.flags |= RGB_F_REPLY | RGB_F_REPLY_PRE_VOTE | (granted ? RGB_F_REPLY_SUCCESS : 0u);
+  L.r_term = term; L.r_next = token; L.r_last = 0; L.r_lterm = 0;
+  L.reply_to = to8;
+}
+
+/* required_quorum/1 (src/ra_server.erl:3996-3999), count_voters/1 :4001-4009 */
+__device__ __forceinline__ unsigned required_quorum(const Lane &L) {
+  unsigned voters = __popc((unsigned)(pk_get(L.pk, PK_PRESENT_SH, 8) & pk_get(L.pk, PK_VOTER_SH, 8)));
+  return voters / 2 + 1;
 }
 
 /* apply_to/5 (src/ra_server.erl:3250-3282): only the cursor moves on the device */
@@ -188,7 +241,7 @@ __device__ __forceinline__ void evaluate_commit_index_follower(Lane &L) {
 /* ---- log edits (register side; memory is touched at commit) ---- */
 
 /* append one segment [s..e] of term t after the current last run */
-__device__ void push_segment(Lane &L, u64 s, u64 t) {
+__device__ __forceinline__ void push_segment(Lane &L, u64 s, u64 t) {
   if (L.n_runs > 0 && L.lrt == t) return;            /* extends the last run */
   if (L.push_cnt == 1) { L.ps0 = L.lrs; L.pt0 = L.lrt; }
   L.push_cnt += 1;
@@ -198,7 +251,7 @@ __device__ void push_segment(Lane &L, u64 s, u64 t) {
 
 /* cut the table so that its last run is the one holding `keep_idx` (largest start <=
  * keep_idx); runs starting above it disappear.  keep_term = term_at(keep_idx) if known. */
-__device__ void truncate_runs_to(Lane &L, u64 keep_idx) {
+__device__ __forceinline__ void truncate_runs_to(Lane &L, u64 keep_idx) {
   int k = find_run(L, keep_idx);
   if (k < 0) { L.n_runs = 0; return; }
   if ((unsigned)k != L.n_runs - 1) {
@@ -210,7 +263,7 @@ __device__ void truncate_runs_to(Lane &L, u64 keep_idx) {
 
 /* ra_log:write/2 (src/ra_log.erl:547-599, range update :1618-1623) of entries k0..n-1.
  * Returns an RGB_INV_* code, 0 on success.  Validates before editing. */
-__device__ int log_write(Lane &L, u32 k0) {
+__device__ __forceinline__ int log_write(Lane &L, u32 k0) {
   const u64 base = L.a + 1 + (u64)L.gap;
   const u64 fst = base + k0;
   const u64 lst = base + (L.n_entries - 1);
@@ -247,7 +300,7 @@ __device__ int log_write(Lane &L, u32 k0) {
 }
 
 /* ra_log:set_last_index/2 (src/ra_log.erl:842-893) */
-__device__ int log_set_last_index(Lane &L, u64 idx) {
+__device__ __forceinline__ int log_set_last_index(Lane &L, u64 idx) {
   u64 t = fetch_term(L, idx);
   bool snap_is_idx = (L.si != UNDEF && L.si == idx);
   if (t == UNDEF && !snap_is_idx) return RGB_INV_SET_LAST_INDEX_NOT_FOUND;
@@ -277,7 +330,7 @@ __device__ int log_set_last_index(Lane &L, u64 idx) {
  * of [from..to] inside the range whose term is Term becomes last_written.  Walking down one
  * index at a time (as the reference does through ra_seq:limit) stops without change only on
  * indexes at/below the snapshot, below which nothing can match either. */
-__device__ bool log_written(Lane &L, u64 term, u64 from, u64 to) {
+__device__ __forceinline__ bool log_written(Lane &L, u64 term, u64 from, u64 to) {
   if (!range_nonempty(L)) return false;
   u64 hi = to < L.li ? to : L.li;
   u64 lo = from > L.first ? from : L.first;
@@ -308,7 +361,7 @@ __device__ bool log_written(Lane &L, u64 term, u64 from, u64 to) {
 /* agreed_commit/1 (src/ra_server.erl:3684-3688) over up to 8 values held in registers:
  * descending order statistic nth = n/2+1 by rank counting (branch-free, no memory) */
 template <int N>
-__device__ u64 agreed_commit(const u64 (&v)[N], const bool (&use)[N], int n) {
+__device__ __forceinline__ u64 agreed_commit(const u64 (&v)[N], const bool (&use)[N], int n) {
   const int nth = n / 2 + 1;
   u64 res = UNDEF;
 #pragma unroll
@@ -329,7 +382,7 @@ __device__ u64 agreed_commit(const u64 (&v)[N], const bool (&use)[N], int n) {
 
 /* match_indexes/1 :3671-3682, increment_commit_index/1 :3648-3657, evaluate_quorum/2 :3633-3646 */
 template <int N>
-__device__ void evaluate_quorum(Lane &L, unsigned ov_peer, u64 ov_mi) {
+__device__ __forceinline__ void evaluate_quorum(Lane &L) {
   u64 v[N + 1];
   bool use[N + 1];
   const unsigned self = self_of(L);
@@ -338,9 +391,7 @@ __device__ void evaluate_quorum(Lane &L, unsigned ov_peer, u64 ov_mi) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     bool u = ((unsigned)i != self) && present(L, i) && voter(L, i);
-    u64 mi = L.peers[i];
-    if ((unsigned)i == ov_peer) mi = ov_mi;
-    v[i] = mi; use[i] = u;
+    v[i] = L.pmi[i]; use[i] = u;
     n += u ? 1 : 0;
   }
   const u64 ci0 = L.ci;
@@ -352,12 +403,12 @@ __device__ void evaluate_quorum(Lane &L, unsigned ov_peer, u64 ov_mi) {
 }
 
 /* make_pipelined_rpc_effects/3 :2285-2346 + make_rpc_effect/5 :2382-2416 +
- * make_append_entries_rpc/6 :2418-2435.  Two passes: EMIT=false validates (assertions of the
- * reference) without side effects, EMIT=true stores peers and emits rpc records. */
+ * make_append_entries_rpc/6 :2418-2435.  One pass: peer cursors change in registers and rpc
+ * records go to this message's private slots, so when an assertion of the reference fails
+ * (non-zero return) nothing has been committed: the decision reports n_rpcs = 0. */
 template <int N, bool EMIT>
-__device__ int pipeline_rpcs(Lane &L, bool force, unsigned ov_peer, u64 ov_mi, u64 ov_ni,
-                             u32 max_pipe, u32 max_batch, bool &more, unsigned &n_out,
-                             rgb_rpc *rpcs, u32 slot_base, u32 msg_index) {
+__device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, u32 max_batch, bool &more,
+                             unsigned &n_out, rgb_rpc *rpcs, u32 slot_base, u32 msg_index) {
   const unsigned self = self_of(L);
   const u64 next_log = next_log_index(L);
   more = false;
@@ -365,17 +416,10 @@ __device__ int pipeline_rpcs(Lane &L, bool force, unsigned ov_peer, u64 ov_mi, u
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if ((unsigned)i == self || !present(L, i) || !status_normal(L, i)) continue;
-    u64 mi = L.peers[i], ni = L.peers[N + i], cis = L.peers[2 * N + i];
-    if ((unsigned)i == ov_peer) { mi = ov_mi; ni = ov_ni; }
-    if (!(ni < next_log || cis < L.ci)) {
-      if (EMIT && (unsigned)i == ov_peer) { L.peers[i] = mi; L.peers[N + i] = ni; }
-      continue;
-    }
+    const u64 mi = L.pmi[i], ni = L.pni[i], cis = L.pcs[i];
+    if (!(ni < next_log || cis < L.ci)) continue;
     long long inflight = (long long)(ni - mi) - 1;
-    if (!(inflight < (long long)max_pipe || force)) {
-      if (EMIT && (unsigned)i == ov_peer) { L.peers[i] = mi; L.peers[N + i] = ni; }
-      continue;
-    }
+    if (!(inflight < (long long)max_pipe || force)) continue;
     long long room = (long long)max_pipe - inflight;
     long long bs = (long long)max_batch < room ? (long long)max_batch : room;
     if (bs < 1) bs = 1;
@@ -399,9 +443,8 @@ __device__ int pipeline_rpcs(Lane &L, bool force, unsigned ov_peer, u64 ov_mi, u
     long long new_inflight = (long long)(new_ni - mi) - 1;
     if (new_ni < next_log && new_inflight < (long long)max_pipe) more = true;
     if (EMIT) {
-      L.peers[i] = mi;
-      L.peers[N + i] = new_ni;
-      L.peers[2 * N + i] = L.ci;
+      L.pni[i] = new_ni; L.dni |= 1u << i;
+      L.pcs[i] = L.ci;   L.dcs |= 1u << i;
       if (rpcs != nullptr) {
         /* fixed slot: this message's (n_out-1)-th record; 56 B = 7 x 8-B stores */
         u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
@@ -414,12 +457,139 @@ __device__ int pipeline_rpcs(Lane &L, bool force, unsigned ov_peer, u64 ov_mi, u
   return 0;
 }
 
+/* ------------------------------------------------------------------ elections ---- */
+
+/* the leader branch of handle_candidate(#request_vote_result{vote_granted=true}) :1055-1058 with
+ * initialise_peers/1 :3234-3242 */
+template <int N>
+__device__ __forceinline__ void become_leader(Lane &L) {
+  const u64 ni = next_log_index(L);
+  load_peers<N>(L);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (!present(L, i)) continue;
+    L.pmi[i] = 0; L.pni[i] = ni; L.pcs[i] = 0;
+    L.dmi |= 1u << i; L.dni |= 1u << i; L.dcs |= 1u << i;
+  }
+  L.pk = pk_set(L.pk, PK_STATUS_SH, 8, 0xFF);
+  set_leader_id(L, self_of(L));
+  L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+  set_role(L, RGB_ROLE_LEADER);
+  L.flags |= RGB_F_BECAME_LEADER;
+}
+
+/* one granted vote for a candidate in its own term (src/ra_server.erl:1045-1061) */
+template <int N>
+__device__ __forceinline__ void candidate_vote_granted(Lane &L) {
+  unsigned nv = (unsigned)pk_get(L.pk, PK_VOTES_SH, 4) + 1;
+  if (nv == required_quorum(L)) become_leader<N>(L);
+  else L.pk = pk_set(L.pk, PK_VOTES_SH, 4, nv);
+}
+
+__device__ __forceinline__ void vote_requests(Lane &L, u64 term, bool pre) {
+  L.flags &= ~(u32)RGB_F_PRE_VOTE_REQS;
+  L.flags |= RGB_F_SEND_VOTE_REQUESTS | (pre ? RGB_F_PRE_VOTE_REQS : 0u);
+  L.has_reply = false;
+  L.r_term = term; L.r_next = pre ? L.token : 0; L.r_last = L.li; L.r_lterm = L.lt;
+  L.vote_reqs = true;
+}
+
+/* call_for_election(candidate,_) (src/ra_server.erl:2880-2899) + the self vote it casts */
+template <int N>
+__device__ __forceinline__ void call_for_election_candidate(Lane &L) {
+  const u64 new_term = L.ct + 1;
+  update_term_and_voted_for(L, new_term, self_of(L));
+  set_leader_id(L, SLOT_NONE4);
+  L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+  set_role(L, RGB_ROLE_CANDIDATE);
+  vote_requests(L, new_term, false);
+  candidate_vote_granted<N>(L);
+}
+
+/* call_for_election(pre_vote,_) (src/ra_server.erl:2900-2924) + the self pre-vote (:1229-1246) */
+template <int N>
+__device__ __forceinline__ void call_for_election_pre_vote(Lane &L, u64 token) {
+  update_term_and_voted_for(L, L.ct, self_of(L));
+  set_leader_id(L, SLOT_NONE4);
+  L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+  L.token = token;
+  set_role(L, RGB_ROLE_PRE_VOTE);
+  vote_requests(L, L.ct, true);
+  if (!pk_get(L.pk, PK_NONVOTER_SH, 1)) {
+    unsigned nv = (unsigned)pk_get(L.pk, PK_VOTES_SH, 4) + 1;
+    if (nv == required_quorum(L)) call_for_election_candidate<N>(L);
+    else L.pk = pk_set(L.pk, PK_VOTES_SH, 4, nv);
+  }
+}
+
+/* process_pre_vote/3 (src/ra_server.erl:2926-2983); the server stays in its role */
+__device__ __forceinline__ int process_pre_vote(Lane &L) {
+  const u64 token = L.c;
+  if (L.term >= L.ct) {
+    update_term(L, L.term);                 /* a pre-vote never sets voted_for */
+    const bool up = (L.b > L.lt) || (L.b == L.lt && L.a >= L.li);
+    const u32 theirs = L.n_entries, ours = (u32)(L.macver & 0xFFFFFFFFull), eff = (u32)(L.macver >> 32);
+    if (up && L.gap > RGB_PROTO_VERSION) {
+      pre_vote_reply(L, L.term, token, false, L.from);
+    } else if (up && (theirs == eff || (theirs >= eff && theirs <= ours))) {
+      pre_vote_reply(L, L.term, token, true, L.from);
+    } else if (up) {
+      pre_vote_reply(L, L.term, token, false, L.from);
+      L.flags |= RGB_F_START_ELECTION_TIMEOUT;
+    } else if (role_of(L) == RGB_ROLE_FOLLOWER) {
+      L.flags |= RGB_F_START_ELECTION_TIMEOUT;             /* no reply, :2968-2969 */
+    } else {
+      pre_vote_reply(L, L.term, token, false, L.from);
+    }
+    return 0;
+  }
+  pre_vote_reply(L, L.ct, token, false, L.from);
+  return 0;
+}
+
+/* make_all_rpcs/1 :2353-2367 -> make_rpcs_for/2 :2369-2377: one rpc (batch 1) per normal peer,
+ * next_index NOT advanced */
+template <int N>
+__device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *rpcs, u32 slot_base,
+                                             u32 msg_index) {
+  const unsigned self = self_of(L);
+  load_peers<N>(L);
+  n_out = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if ((unsigned)i == self || !present(L, i) || !status_normal(L, i)) continue;
+    const u64 prev = L.pni[i] - 1;
+    u64 prev_term = fetch_term(L, prev);
+    u64 rp_idx, rp_term, new_ni;
+    unsigned kind, n_ent = 0;
+    if (prev_term == UNDEF && !(L.si != UNDEF && L.si == prev)) {
+      if (L.si == UNDEF || !(prev < L.si)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
+      kind = RGB_RPC_SNAPSHOT; rp_idx = L.si; rp_term = L.st; new_ni = L.si;
+      L.flags |= RGB_F_SEND_SNAPSHOT;
+    } else {
+      if (prev_term == UNDEF) prev_term = L.st;
+      u64 to = prev + 1 < L.li ? prev + 1 : L.li;
+      kind = RGB_RPC_AER; rp_idx = prev; rp_term = prev_term;
+      n_ent = (unsigned)(to >= prev + 1 ? to - prev : 0);
+      new_ni = to + 1;
+    }
+    n_out += 1;
+    if (rpcs != nullptr) {
+      u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
+      o[0] = (u64)msg_index | ((u64)L.server << 32);
+      o[1] = (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16);
+      o[2] = L.ct; o[3] = rp_idx; o[4] = rp_term; o[5] = L.ci; o[6] = new_ni;
+    }
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ follower ---- */
 
 /* drop_existing/3 (src/ra_server.erl:3700-3708) run-wise: number of leading entries of the
  * message that already exist with the same term.  Equivalent to the per-entry
  * ra_log:exists loop because run tables are canonical (adjacent runs differ in term). */
-__device__ u32 drop_existing(const Lane &L) {
+__device__ __forceinline__ u32 drop_existing(const Lane &L) {
   if (L.n_entries == 0) return 0;
   const u64 base = L.a + 1 + (u64)L.gap;
   if (!range_nonempty(L) || base > L.li || base < L.first) return 0;
@@ -445,7 +615,7 @@ __device__ u32 drop_existing(const Lane &L) {
 }
 
 /* handle_follower(#append_entries_rpc{}) (src/ra_server.erl:1283-1440) */
-__device__ int follower_aer(Lane &L) {
+__device__ __forceinline__ int follower_aer(Lane &L) {
   const u64 cur_term = L.ct;
   if (!(L.term >= cur_term)) {
     aer_reply(L, cur_term, false, L.from);                          /* :1431-1440 */
@@ -522,7 +692,7 @@ __device__ int follower_aer(Lane &L) {
 }
 
 /* handle_follower(#request_vote_rpc{}) (src/ra_server.erl:1483-1529) */
-__device__ int follower_request_vote(Lane &L) {
+__device__ __forceinline__ int follower_request_vote(Lane &L) {
   if (pk_get(L.pk, PK_NONVOTER_SH, 1)) return 0;
   const unsigned cand4 = slot8to4(L.from);
   const unsigned voted = (unsigned)pk_get(L.pk, PK_VOTED_SH, 4);
@@ -546,7 +716,8 @@ __device__ int follower_request_vote(Lane &L) {
   return 0;
 }
 
-__device__ int handle_follower(Lane &L) {
+template <int N>
+__device__ __forceinline__ int handle_follower(Lane &L) {
   switch (L.kind) {
     case RGB_MSG_AER:          return follower_aer(L);
     case RGB_MSG_REQUEST_VOTE: return follower_request_vote(L);
@@ -559,13 +730,21 @@ __device__ int handle_follower(Lane &L) {
     }
     case RGB_MSG_AER_REPLY:    update_term(L, L.term); return 0;     /* :1530-1533 */
     case RGB_MSG_VOTE_RESULT:  return 0;                             /* :1609-1611 */
+    case RGB_MSG_PRE_VOTE_RESULT: return 0;                          /* :1612-1614 */
+    case RGB_MSG_PRE_VOTE_RPC:
+      if (pk_get(L.pk, PK_NONVOTER_SH, 1)) return 0;                 /* :1475-1480 */
+      return process_pre_vote(L);                                    /* :1481-1482 */
+    case RGB_MSG_ELECTION_TIMEOUT:
+      if (pk_get(L.pk, PK_NONVOTER_SH, 1)) return 0;                 /* :1619-1624 */
+      call_for_election_pre_vote<N>(L, L.c);                         /* :1625-1626 */
+      return 0;
     default: L.flags |= RGB_F_UNHANDLED; return 0;
   }
 }
 
 /* -------------------------------------------------------------------- leader ---- */
 template <int N>
-__device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_rpc *rpcs,
+__device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_rpc *rpcs,
                              u32 slot_base, u32 msg_index, unsigned &n_rpcs) {
   switch (L.kind) {
     case RGB_MSG_AER_REPLY: {
@@ -574,10 +753,10 @@ __device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_r
       if (success && L.term == L.ct) {
         /* :532-571 */
         if (!present(L, peer)) return 0;
-        u64 mi = L.peers[peer], ni = L.peers[N + peer];
-        if (L.b > mi) { mi = L.b; L.peers[peer] = mi; }
-        if (L.a > ni) { L.peers[N + peer] = L.a; }
-        evaluate_quorum<N>(L, peer, mi);
+        load_peers<N>(L);
+        if (L.b > peer_get<N>(L.pmi, peer)) peer_set<N>(L.pmi, L.dmi, peer, L.b);
+        if (L.a > peer_get<N>(L.pni, peer)) peer_set<N>(L.pni, L.dni, peer, L.a);
+        evaluate_quorum<N>(L);
         L.flags |= RGB_F_PIPELINE;
         return 0;
       }
@@ -592,7 +771,8 @@ __device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_r
       if (!success) {
         /* :587-652 */
         if (!present(L, peer)) return 0;
-        u64 mi = L.peers[peer], ni = L.peers[N + peer];
+        load_peers<N>(L);
+        u64 mi = peer_get<N>(L.pmi, peer), ni = peer_get<N>(L.pni, peer);
         const u64 peer_next = L.a, peer_last = L.b, peer_last_term = L.c;
         u64 t = fetch_term(L, peer_last);
         if (t == UNDEF) {
@@ -607,16 +787,13 @@ __device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_r
           long long lo = (long long)mi + 1;
           ni = (u64)(mn > lo ? mn : lo);
         }
+        /* registers only: nothing reaches memory unless the message commits */
+        peer_set<N>(L.pmi, L.dmi, peer, mi);
+        peer_set<N>(L.pni, L.dni, peer, ni);
         bool more; unsigned cnt;
-        int rc = pipeline_rpcs<N, false>(L, false, peer, mi, ni, dev.max_pipeline_count,
-                                         dev.max_aer_batch, more, cnt, nullptr, 0, 0);
+        int rc = pipeline_rpcs<N, true>(L, false, dev.max_pipeline_count, dev.max_aer_batch, more, cnt,
+                                        rpcs, slot_base, msg_index);
         if (rc) return rc;
-        pipeline_rpcs<N, true>(L, false, peer, mi, ni, dev.max_pipeline_count, dev.max_aer_batch,
-                               more, cnt, rpcs, slot_base, msg_index);
-        /* the peer edit must land even when the peer itself got no rpc */
-        if (!(status_normal(L, peer) && peer != self_of(L))) {
-          L.peers[peer] = mi; L.peers[N + peer] = ni;
-        }
         n_rpcs = cnt;
         return 0;
       }
@@ -649,19 +826,18 @@ __device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_r
     }
     case RGB_MSG_WRITTEN: {
       log_written(L, L.term, L.a, L.b);                              /* :739-744 */
-      evaluate_quorum<N>(L, 0xFFu, 0);
+      load_peers<N>(L);
+      evaluate_quorum<N>(L);
       L.flags |= RGB_F_PIPELINE;
       return 0;
     }
     case RGB_MSG_PIPELINE_RPCS:
     case RGB_MSG_APPEND: {
       bool force = false;
-      /* saved cursors for rollback if the pipelining assertion fails */
-      const u64 s_li = L.li, s_lt = L.lt, s_lrs = L.lrs, s_lrt = L.lrt, s_first = L.first;
-      const unsigned s_nr = L.n_runs, s_pc = L.push_cnt;
+      load_peers<N>(L);
       if (L.kind == RGB_MSG_APPEND) {
         /* {command,_} :653-693 / {commands,_} :695-738: ra_log:append of n entries at
-         * next_index in the current term */
+         * next_index in the current term (registers only until commit) */
         force = (L.mflags & RGB_MF_FORCE) != 0;
         if (L.n_entries > 0) {
           u64 nidx = next_log_index(L);
@@ -672,50 +848,43 @@ __device__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_r
         }
       }
       bool more; unsigned cnt;
-      int rc = pipeline_rpcs<N, false>(L, force, 0xFFu, 0, 0, dev.max_pipeline_count,
-                                       dev.max_aer_batch, more, cnt, nullptr, 0, 0);
-      if (rc) {
-        L.li = s_li; L.lt = s_lt; L.lrs = s_lrs; L.lrt = s_lrt; L.first = s_first;
-        L.n_runs = s_nr; L.push_cnt = s_pc;
-        return rc;
-      }
-      pipeline_rpcs<N, true>(L, force, 0xFFu, 0, 0, dev.max_pipeline_count, dev.max_aer_batch,
-                             more, cnt, rpcs, slot_base, msg_index);
+      int rc = pipeline_rpcs<N, true>(L, force, dev.max_pipeline_count, dev.max_aer_batch, more, cnt,
+                                      rpcs, slot_base, msg_index);
+      if (rc) return rc;
       n_rpcs = cnt;
       if (L.kind == RGB_MSG_PIPELINE_RPCS && more) L.flags |= RGB_F_PIPELINE;   /* :793-801 */
       return 0;
     }
+    case RGB_MSG_PRE_VOTE_RPC: {
+      if (L.term > L.ct) {
+        if (!present(L, L.from)) return 0;                           /* :946-960 */
+        set_leader_id(L, SLOT_NONE4);
+        update_term(L, L.term);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      unsigned cnt;
+      int rc = make_all_rpcs<N>(L, cnt, rpcs, slot_base, msg_index);  /* :961-966 */
+      if (rc) return rc;
+      n_rpcs = cnt;
+      return 0;
+    }
+    case RGB_MSG_VOTE_RESULT:                                        /* :967-969 */
+    case RGB_MSG_PRE_VOTE_RESULT:                                    /* :970-972 */
+      return 0;
     default: L.flags |= RGB_F_UNHANDLED; return 0;
   }
 }
 
 /* ----------------------------------------------------------------- candidate ---- */
 template <int N>
-__device__ int handle_candidate(Lane &L, bool &reprocess) {
+__device__ __forceinline__ int handle_candidate(Lane &L, bool &reprocess) {
   switch (L.kind) {
     case RGB_MSG_VOTE_RESULT: {
       const bool granted = (L.mflags & RGB_MF_SUCCESS) != 0;
       if (granted && L.term == L.ct) {
-        /* :1045-1061, required_quorum/1 :3996-3999 */
-        unsigned voters = __popc((unsigned)(pk_get(L.pk, PK_PRESENT_SH, 8) & pk_get(L.pk, PK_VOTER_SH, 8)));
-        unsigned quorum = voters / 2 + 1;
-        unsigned nv = (unsigned)pk_get(L.pk, PK_VOTES_SH, 4) + 1;
-        if (nv == quorum) {
-          /* initialise_peers/1 :3234-3242 */
-          const u64 ni = next_log_index(L);
-#pragma unroll
-          for (int i = 0; i < N; ++i) {
-            if (!present(L, i)) continue;
-            L.peers[i] = 0; L.peers[N + i] = ni; L.peers[2 * N + i] = 0;
-          }
-          L.pk = pk_set(L.pk, PK_STATUS_SH, 8, 0xFF);
-          set_leader_id(L, self_of(L));
-          L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
-          set_role(L, RGB_ROLE_LEADER);
-          L.flags |= RGB_F_BECAME_LEADER;
-        } else {
-          L.pk = pk_set(L.pk, PK_VOTES_SH, 4, nv);
-        }
+        candidate_vote_granted<N>(L);                                /* :1045-1061 */
         return 0;
       }
       if (L.term > L.ct) {
@@ -753,12 +922,25 @@ __device__ int handle_candidate(Lane &L, bool &reprocess) {
     case RGB_MSG_WRITTEN:
       log_written(L, L.term, L.a, L.b);                              /* :1157-1160 */
       return 0;
+    case RGB_MSG_PRE_VOTE_RPC:
+      if (L.term > L.ct) {
+        update_term_and_voted_for(L, L.term, SLOT_NONE4);            /* :1116-1122 */
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      return process_pre_vote(L);                                    /* :1127-1131 */
+    case RGB_MSG_PRE_VOTE_RESULT: return 0;                          /* :1135-1137 */
+    case RGB_MSG_ELECTION_TIMEOUT:
+      call_for_election_candidate<N>(L);                             /* :1161-1162 */
+      return 0;
     default: L.flags |= RGB_F_UNHANDLED; return 0;
   }
 }
 
 /* ------------------------------------------------------------------ pre_vote ---- */
-__device__ int handle_pre_vote(Lane &L, bool &reprocess) {
+template <int N>
+__device__ __forceinline__ int handle_pre_vote(Lane &L, bool &reprocess) {
   switch (L.kind) {
     case RGB_MSG_AER:
       if (L.term >= L.ct) {
@@ -784,12 +966,32 @@ __device__ int handle_pre_vote(Lane &L, bool &reprocess) {
     case RGB_MSG_WRITTEN:
       log_written(L, L.term, L.a, L.b);                              /* :1257-1260 */
       return 0;
+    case RGB_MSG_PRE_VOTE_RESULT: {
+      const bool granted = (L.mflags & RGB_MF_SUCCESS) != 0;
+      if (L.term > L.ct) {
+        update_term(L, L.term);                                      /* :1219-1228 */
+        L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        return 0;
+      }
+      if (granted && L.term == L.ct && L.c == L.token && !pk_get(L.pk, PK_NONVOTER_SH, 1)) {
+        unsigned nv = (unsigned)pk_get(L.pk, PK_VOTES_SH, 4) + 1;    /* :1229-1246 */
+        if (nv == required_quorum(L)) call_for_election_candidate<N>(L);
+        else L.pk = pk_set(L.pk, PK_VOTES_SH, 4, nv);
+      }
+      return 0;
+    }
+    case RGB_MSG_PRE_VOTE_RPC: return process_pre_vote(L);           /* :1250-1251 */
+    case RGB_MSG_ELECTION_TIMEOUT:
+      call_for_election_pre_vote<N>(L, L.c);                         /* :1255-1256 */
+      return 0;
     default: L.flags |= RGB_F_UNHANDLED; return 0;
   }
 }
 
 /* ----------------------------------------------------------- await_condition ---- */
-__device__ int handle_await_condition(Lane &L, bool &reprocess, const u64 *cond_row) {
+template <int N>
+__device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, const u64 *cond_row) {
   switch (L.kind) {
     case RGB_MSG_REQUEST_VOTE:
       set_role(L, RGB_ROLE_FOLLOWER);                                /* :1918-1919 */
@@ -807,6 +1009,11 @@ __device__ int handle_await_condition(Lane &L, bool &reprocess, const u64 *cond_
     case RGB_MSG_WRITTEN:
       log_written(L, L.term, L.a, L.b);                              /* :1946-1949 */
       return 0;
+    case RGB_MSG_PRE_VOTE_RPC: return process_pre_vote(L);           /* :1920-1921 */
+    case RGB_MSG_ELECTION_TIMEOUT:
+      if (pk_get(L.pk, PK_NONVOTER_SH, 1)) return 0;                 /* :1922-1929 */
+      call_for_election_pre_vote<N>(L, L.c);                         /* :1930-1931 */
+      return 0;
     case RGB_MSG_AER: {
       /* follower_catchup_cond/3 :2201-2218 */
       bool pred = false;
@@ -822,29 +1029,24 @@ __device__ int handle_await_condition(Lane &L, bool &reprocess, const u64 *cond_
   }
 }
 
-__device__ __forceinline__ void store_decision(rgb_decision *out, u32 server, unsigned role,
-                                               unsigned reply_to, unsigned n_rpcs, unsigned kind,
-                                               u32 flags, u32 inv, u64 w2, u64 w3, u64 w4, u64 w5,
-                                               u64 ci, u64 la) {
-  u64 w0 = (u64)server | ((u64)(role & 0xFF) << 32) | ((u64)(reply_to & 0xFF) << 40) |
+/* the 64-byte decision as 8 words (layout of rgb_decision) */
+struct Dec { u64 w[8]; };
+
+__device__ __forceinline__ void make_decision(Dec &d, u32 server, unsigned role, unsigned reply_to,
+                                              unsigned n_rpcs, unsigned kind, u32 flags, u32 inv, u64 w2,
+                                              u64 w3, u64 w4, u64 w5, u64 ci, u64 la) {
+  d.w[0] = (u64)server | ((u64)(role & 0xFF) << 32) | ((u64)(reply_to & 0xFF) << 40) |
            ((u64)(n_rpcs & 0xFF) << 48) | ((u64)(kind & 0xFF) << 56);
-  u64 w1 = (u64)flags | ((u64)inv << 32);
-  ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out);
-  o[0] = make_ulonglong2(w0, w1);
-  o[1] = make_ulonglong2(w2, w3);
-  o[2] = make_ulonglong2(w4, w5);
-  o[3] = make_ulonglong2(ci, la);
+  d.w[1] = (u64)flags | ((u64)inv << 32);
+  d.w[2] = w2; d.w[3] = w3; d.w[4] = w4; d.w[5] = w5; d.w[6] = ci; d.w[7] = la;
 }
 
+/* One message against one server: everything between "message words in registers" and
+ * "decision words in registers".  State loads/stores go straight to the server's lines. */
 template <int N>
-__global__ __launch_bounds__(256) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
-                                                       u32 n, rgb_decision *__restrict__ dec,
-                                                       rgb_rpc *__restrict__ rpcs, u32 msg_index_base) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  /* message: 4 x 16 B */
-  const ulonglong2 *mp = reinterpret_cast<const ulonglong2 *>(msgs + i);
-  const ulonglong2 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
+__device__ __forceinline__ void process_message(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
+                                                const ulonglong2 m2, const ulonglong2 m3, u32 i,
+                                                rgb_rpc *__restrict__ rpcs, u32 msg_index_base, Dec &out) {
   Lane L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   L.kind = (unsigned)((m0.x >> 32) & 0xFF);
@@ -858,53 +1060,59 @@ __global__ __launch_bounds__(256) void rgb_tick_kernel(rgb_dev dev, const rgb_ms
   if (L.n_run0 > L.n_entries) L.n_run0 = L.n_entries;
 
   if (L.kind == RGB_MSG_NOP) {
-    store_decision(dec + i, L.server, 0, RGB_NONE, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    make_decision(out, L.server, 0, RGB_NONE, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
     return;
   }
   if (L.server >= dev.n_servers) {
-    store_decision(dec + i, L.server, 0xFF, RGB_NONE, 0, L.kind, RGB_F_UNHANDLED, 0, 0, 0, 0, 0, 0, 0);
+    make_decision(out, L.server, 0xFF, RGB_NONE, 0, L.kind, RGB_F_UNHANDLED, 0, 0, 0, 0, 0, 0, 0);
     return;
   }
-  /* hot line: 7 x 16 B (13 live words) */
+  /* hot line: 8 x 16 B (15 live words) */
   u64 *hot = dev.hot + (size_t)L.server * RGB_HOT_WORDS;
   const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(hot);
   const ulonglong2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4], h5 = hp[5], h6 = hp[6];
-  L.ct = h0.x; L.ci = h0.y; L.la = h1.x; L.li = h1.y; L.lt = h2.x; L.lwi = h2.y; L.lwt = h3.x;
-  L.pk = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
   L.runs = dev.runs + (size_t)L.server * dev.max_runs * 2;
   L.peers = dev.peers + (size_t)L.server * dev.peer_stride;
   L.max_runs = dev.max_runs;
+  L.peers_loaded = false; L.dmi = L.dni = L.dcs = 0;
+  /* leader-side kinds: fetch the peers row in the same round trip as the hot line (the address
+   * only depends on the message); kinds that need it rarely load it lazily */
+  if (L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS)
+    load_peers<N>(L);
+  L.ct = h0.x; L.ci = h0.y; L.la = h1.x; L.li = h1.y; L.lt = h2.x; L.lwi = h2.y; L.lwt = h3.x;
+  L.pk = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
+  L.token = h6.y; L.macver = hp[7].x; L.vote_reqs = false;
   L.flags = 0; L.inv = 0; L.has_reply = false; L.reply_to = RGB_NONE;
   L.r_term = L.r_next = L.r_last = L.r_lterm = 0; L.w_first = L.w_last = 0;
   L.n_runs = (unsigned)pk_get(L.pk, PK_NRUNS_SH, 5);
   L.push_cnt = 0; L.ps0 = L.pt0 = 0;
   L.cond_dirty = false; L.cr0 = L.cr1 = L.cr2 = L.cr3 = 0;
-  L.peers_loaded = false;
 
-  /* saved copy for invariant roll-back (registers only; memory is written at commit, except
-   * peers rows which are only written after validation) */
-  const Lane S = L;
+  const unsigned role0 = role_of(L);
+  const u64 ci0 = L.ci, la0 = L.la;
   const unsigned n_runs0 = L.n_runs;
   unsigned n_rpcs = 0;
   int rc = 0;
-  for (int pass = 0; pass < 2; ++pass) {
+  /* every {next_event, Msg} re-processing of the reference lands in follower, so: non-follower
+   * roles first, then handle_follower once for servers that are (or just became) followers */
+  bool to_follower = role0 == RGB_ROLE_FOLLOWER;
+  if (!to_follower) {
     bool reprocess = false;
-    switch (role_of(L)) {
-      case RGB_ROLE_FOLLOWER:        rc = handle_follower(L); break;
+    switch (role0) {
       case RGB_ROLE_LEADER:          rc = handle_leader<N>(L, reprocess, dev, rpcs, i * (N > 1 ? N - 1 : 1),
                                                            msg_index_base + i, n_rpcs); break;
       case RGB_ROLE_CANDIDATE:       rc = handle_candidate<N>(L, reprocess); break;
-      case RGB_ROLE_PRE_VOTE:        rc = handle_pre_vote(L, reprocess); break;
-      case RGB_ROLE_AWAIT_CONDITION: rc = handle_await_condition(L, reprocess,
+      case RGB_ROLE_PRE_VOTE:        rc = handle_pre_vote<N>(L, reprocess); break;
+      case RGB_ROLE_AWAIT_CONDITION: rc = handle_await_condition<N>(L, reprocess,
                                                 dev.cond + (size_t)L.server * 4); break;
       default: L.flags |= RGB_F_UNHANDLED; break;
     }
-    if (rc || !reprocess) break;
-    L.flags |= RGB_F_REPROCESSED;
+    if (!rc && reprocess) { L.flags |= RGB_F_REPROCESSED; to_follower = true; }
   }
+  if (!rc && to_follower) rc = handle_follower<N>(L);
   if (rc) {
-    store_decision(dec + i, S.server, role_of(S), RGB_NONE, 0, S.kind, RGB_F_INVARIANT, (u32)rc,
-                   0, 0, 0, 0, S.ci, S.la);
+    /* the reference would exit/assert: nothing is committed */
+    make_decision(out, L.server, role0, RGB_NONE, 0, L.kind, RGB_F_INVARIANT, (u32)rc, 0, 0, 0, 0, ci0, la0);
     return;
   }
 
@@ -938,6 +1146,15 @@ __global__ __launch_bounds__(256) void rgb_tick_kernel(rgb_dev dev, const rgb_ms
     cp[0] = make_ulonglong2(L.cr0, L.cr1);
     cp[1] = make_ulonglong2(L.cr2, L.cr3);
   }
+  /* ---- commit: peers row (dirty words only) ---- */
+  if (L.dmi | L.dni | L.dcs) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (L.dmi & (1u << k)) L.peers[k] = L.pmi[k];
+      if (L.dni & (1u << k)) L.peers[N + k] = L.pni[k];
+      if (L.dcs & (1u << k)) L.peers[2 * N + k] = L.pcs[k];
+    }
+  }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
   if (L.ct != h0.x || L.ci != h0.y) ho[0] = make_ulonglong2(L.ct, L.ci);
@@ -945,13 +1162,56 @@ __global__ __launch_bounds__(256) void rgb_tick_kernel(rgb_dev dev, const rgb_ms
   if (L.lt != h2.x || L.lwi != h2.y) ho[2] = make_ulonglong2(L.lt, L.lwi);
   if (L.lwt != h3.x || L.pk != h3.y) ho[3] = make_ulonglong2(L.lwt, L.pk);
   if (L.first != h5.x || L.lrs != h5.y) ho[5] = make_ulonglong2(L.first, L.lrs);
-  if (L.lrt != h6.x) ho[6] = make_ulonglong2(L.lrt, h6.y);
+  if (L.lrt != h6.x || L.token != h6.y) ho[6] = make_ulonglong2(L.lrt, L.token);
 
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
-  if (L.has_reply) { w2 = L.r_term; w3 = L.r_next; w4 = L.r_last; w5 = L.r_lterm; }
+  if (L.has_reply || L.vote_reqs) { w2 = L.r_term; w3 = L.r_next; w4 = L.r_last; w5 = L.r_lterm; }
   else if (L.flags & RGB_F_WROTE) { w3 = L.w_first; w4 = L.w_last; }
-  store_decision(dec + i, L.server, role_of(L), L.has_reply ? L.reply_to : (unsigned)RGB_NONE, n_rpcs,
-                 L.kind, L.flags, 0, w2, w3, w4, w5, L.ci, L.la);
+  make_decision(out, L.server, role_of(L), L.has_reply ? L.reply_to : (unsigned)RGB_NONE, n_rpcs, L.kind,
+                L.flags, 0, w2, w3, w4, w5, L.ci, L.la);
+}
+
+/* The tick kernel: one lane per message, one wavefront per 64 consecutive messages.  Messages
+ * come in and decisions go out through LDS so that every global access of the 64-byte records
+ * is a fully coalesced 1 KiB wave transaction (lane stride 16 B) instead of 64 strided 16-byte
+ * pieces; LDS slots are padded to 80 B so the per-lane 16-byte reads/writes are conflict-free. */
+#define RGB_IO_SLOT 5   /* 16-byte units per LDS record slot: 64 B payload + 16 B pad */
+
+template <int N>
+__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
+                                                                  u32 n, rgb_decision *__restrict__ dec,
+                                                                  rgb_rpc *__restrict__ rpcs, u32 msg_index_base) {
+  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_IO_SLOT];
+  const u32 lane = threadIdx.x;
+  const u32 base = blockIdx.x * RGB_TICK_BLOCK;           /* first message of this wavefront */
+  const u32 cnt = n - base < RGB_TICK_BLOCK ? n - base : RGB_TICK_BLOCK;
+  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u32 piece = k * RGB_TICK_BLOCK + lane;          /* 16-byte piece of the 64-message block */
+    const u32 j = piece >> 2, part = piece & 3u;
+    if (j < cnt) io[j * RGB_IO_SLOT + part] = src[piece];
+  }
+  __syncthreads();
+  const bool active = lane < cnt;
+  Dec d;
+  if (active) {
+    const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
+                     m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
+    process_message<N>(dev, m0, m1, m2, m3, base + lane, rpcs, msg_index_base, d);
+    io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
+    io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
+    io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
+    io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
+  }
+  __syncthreads();
+  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u32 piece = k * RGB_TICK_BLOCK + lane;
+    const u32 j = piece >> 2, part = piece & 3u;
+    if (j < cnt) dst[piece] = io[j * RGB_IO_SLOT + part];
+  }
 }
 
 /* ------------------------------------------------------------- support kernels -- */
@@ -1005,7 +1265,9 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
   hot[HOT_LWI] = h.last_written_index; hot[HOT_LWT] = h.last_written_term;
   hot[HOT_PK] = pk; hot[HOT_SI] = h.snapshot_index; hot[HOT_ST] = h.snapshot_term;
   hot[HOT_FIRST] = first_index; hot[HOT_LRS] = lrs; hot[HOT_LRT] = lrt;
-  hot[13] = 0; hot[14] = 0; hot[15] = 0;
+  hot[HOT_TOKEN] = h.pre_vote_token;
+  hot[HOT_MACVER] = (u64)h.machine_version | ((u64)h.effective_machine_version << 32);
+  hot[15] = 0;
   u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < dev.peer_stride; ++i) pr[i] = 0;
   for (unsigned i = 0; i < N; ++i) {
@@ -1052,6 +1314,9 @@ __global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ ou
   h.status_mask = (uint8_t)pk_get(pk, PK_STATUS_SH, 8);
   h.self_nonvoter = (uint8_t)pk_get(pk, PK_NONVOTER_SH, 1);
   h.cond_leader = (uint8_t)slot4to8((unsigned)pk_get(pk, PK_CONDLDR_SH, 4));
+  h.pre_vote_token = hot[HOT_TOKEN];
+  h.machine_version = (uint32_t)(hot[HOT_MACVER] & 0xFFFFFFFFull);
+  h.effective_machine_version = (uint32_t)(hot[HOT_MACVER] >> 32);
   out[k] = h;
 }
 
@@ -1114,6 +1379,8 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   u64 masks = pk_get(pk, PK_PRESENT_SH, 8) | (pk_get(pk, PK_VOTER_SH, 8) << 8) |
               (pk_get(pk, PK_STATUS_SH, 8) << 16) | (pk_get(pk, PK_NONVOTER_SH, 1) << 24);
   x = fnv_word(x, masks);
+  x = fnv_word(x, hot[HOT_TOKEN]);
+  x = fnv_word(x, hot[HOT_MACVER]);
   const u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < N; ++i) {
     x = fnv_word(x, pr[i]); x = fnv_word(x, pr[N + i]); x = fnv_word(x, pr[2 * N + i]);
@@ -1131,7 +1398,7 @@ int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, rgb_decisi
                     rgb_rpc *d_rpcs, u32 msg_index_base, void *stream) {
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((n + RGB_BLOCK - 1) / RGB_BLOCK), block(RGB_BLOCK);
+  dim3 grid((n + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                               \
   case NN:                                                                                       \
     hipLaunchKernelGGL(rgb_tick_kernel<NN>, grid, block, 0, st, dev, d_msgs, n, d_dec, d_rpcs,   \

@@ -15,7 +15,7 @@ import numpy as np
 from . import abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libra_gpu_batch.so")
+LIB_PATH = os.environ.get("RGB_LIB") or os.path.join(_CSRC, "libra_gpu_batch.so")
 
 EXPORTS = [
     "rgb_abi_version", "rgb_struct_size", "rgb_strerror", "rgb_default_config", "rgb_open",

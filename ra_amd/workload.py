@@ -412,7 +412,10 @@ def gen_tick(st: np.ndarray, n_members: int, tick: int, seed: int, mix: dict = M
         w["b"] = st["last_index"][ws]
         out.append(w)
     msgs = np.concatenate(out)
-    return msgs
+    # a tick holds at most one message per server, so its order is free: group by kind so that
+    # wavefronts run one clause family = (kind, success flag), as rgb_submit does for host batches
+    key = msgs["kind"].astype(np.int64) * 2 + (msgs["flags"] & abi.MF_SUCCESS)
+    return msgs[np.argsort(key, kind="stable")]
 
 
 def pad_tick(msgs: np.ndarray, width: int) -> np.ndarray:

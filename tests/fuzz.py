@@ -71,6 +71,9 @@ def random_states(rng: np.random.Generator, n_groups: int, n_members: int, max_r
         st["voter_mask"][s] = full if rng.random() < 0.85 else (int(rng.integers(0, full + 1)) | (1 << (s % n_members)))
         st["status_mask"][s] = 0xFF if rng.random() < 0.85 else int(rng.integers(0, 256))
         st["self_nonvoter"][s] = 1 if rng.random() < 0.05 else 0
+        st["pre_vote_token"][s] = int(rng.integers(0, 3))
+        st["machine_version"][s] = int(rng.integers(0, 3))
+        st["effective_machine_version"][s] = int(rng.integers(0, 3))
         for j in range(n_members):
             mi = max(0, li - int(rng.integers(0, 12)))
             if rng.random() < 0.1:
@@ -115,15 +118,17 @@ def random_msgs(rng: np.random.Generator, st: np.ndarray, n_members: int, frac: 
         role = int(row["role"])
         kinds = [abi.MSG_AER, abi.MSG_AER_REPLY, abi.MSG_REQUEST_VOTE, abi.MSG_VOTE_RESULT,
                  abi.MSG_WRITTEN, abi.MSG_PIPELINE_RPCS, abi.MSG_APPEND, abi.MSG_AWAIT_TIMEOUT,
-                 abi.MSG_NOP]
+                 abi.MSG_NOP, abi.MSG_ELECTION_TIMEOUT, abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT]
         if role == abi.ROLE_LEADER:
-            p = [0.1, 0.45, 0.08, 0.02, 0.1, 0.1, 0.12, 0.01, 0.02]
+            p = [0.1, 0.41, 0.08, 0.02, 0.1, 0.1, 0.12, 0.01, 0.02, 0.01, 0.02, 0.01]
         elif role == abi.ROLE_CANDIDATE:
-            p = [0.2, 0.1, 0.15, 0.4, 0.1, 0.01, 0.01, 0.01, 0.02]
+            p = [0.18, 0.08, 0.13, 0.36, 0.1, 0.01, 0.01, 0.01, 0.02, 0.04, 0.04, 0.02]
         elif role == abi.ROLE_AWAIT_CONDITION:
-            p = [0.55, 0.05, 0.1, 0.02, 0.1, 0.01, 0.01, 0.14, 0.02]
+            p = [0.5, 0.05, 0.1, 0.02, 0.1, 0.01, 0.01, 0.12, 0.02, 0.03, 0.03, 0.01]
+        elif role == abi.ROLE_PRE_VOTE:
+            p = [0.25, 0.04, 0.1, 0.02, 0.1, 0.01, 0.01, 0.01, 0.02, 0.06, 0.08, 0.3]
         else:
-            p = [0.5, 0.06, 0.2, 0.03, 0.15, 0.01, 0.02, 0.01, 0.02]
+            p = [0.46, 0.06, 0.18, 0.03, 0.13, 0.01, 0.02, 0.01, 0.02, 0.04, 0.03, 0.01]
         kind = int(rng.choice(kinds, p=p))
         m["kind"][q] = kind
         term = ct + int(rng.choice([-1, 0, 0, 0, 0, 1, 2], p=[0.1, 0.2, 0.2, 0.2, 0.1, 0.15, 0.05]))
@@ -186,6 +191,17 @@ def random_msgs(rng: np.random.Generator, st: np.ndarray, n_members: int, frac: 
             if tw is None or rng.random() < 0.3:
                 tw = max(0, lt + int(rng.integers(-2, 1)))
             m["term"][q] = tw
+        elif kind == abi.MSG_ELECTION_TIMEOUT:
+            m["c"][q] = int(rng.integers(0, 3))
+        elif kind == abi.MSG_PRE_VOTE_RPC:
+            m["a"][q] = max(0, li + int(rng.integers(-2, 3)))
+            m["b"][q] = max(0, lt + int(rng.integers(-1, 2)))
+            m["c"][q] = int(rng.integers(0, 1000))
+            m["n_entries"][q] = int(rng.integers(0, 4))
+            m["gap"][q] = int(rng.choice([0, 1, 1, 1, 2]))
+        elif kind == abi.MSG_PRE_VOTE_RESULT:
+            m["flags"][q] = abi.MF_SUCCESS if rng.random() < 0.75 else 0
+            m["c"][q] = int(rng.integers(0, 3))
         elif kind == abi.MSG_APPEND:
             m["n_entries"][q] = int(rng.integers(0, 5))
             m["flags"][q] = abi.MF_FORCE if rng.random() < 0.2 else 0

@@ -67,6 +67,15 @@ def vote_result(term, granted, voter="n2"):
     return dict(kind="vote_result", term=term, granted=granted, **{"from": voter})
 
 
+def pre_vote(term, cand, last, token=77, machine_version=0, version=1):
+    return dict(kind="pre_vote_rpc", term=term, **{"from": cand}, last=list(last), token=token,
+                machine_version=machine_version, version=version)
+
+
+def pre_vote_result(term, granted, token, voter="n2"):
+    return dict(kind="pre_vote_result", term=term, granted=granted, token=token, **{"from": voter})
+
+
 def step(as_, msg, **expect):
     return {"as": as_, "msg": msg, "expect": expect}
 
@@ -424,6 +433,98 @@ vec("V10", "test/ra_server_SUITE.erl:2503-2548 candidate_election", 5, "n1", "ba
          flags_set=["BECAME_LEADER"]),
 ], tweak=dict(current_term=6, votes=1),
     note="5 members: quorum 3; a fork step does not carry its state forward")
+
+# ------------------------------------------------ elections: pre-vote, timeouts ----
+PV = dict(vote=False, pre_vote=True)
+vec("E1", "test/ra_server_SUITE.erl:1514-1620 follower_pre_vote", 3, "n1", "base", [
+    dict(reset=True, **step("follower", pre_vote(5, "n2", (3, 5)), role="follower",
+                             state=dict(current_term=5),
+                             reply=dict(pre_vote=True, term=5, token=77, success=True),
+                             effects_only_reply=True)),
+    dict(reset=True, **step("follower", pre_vote(5, "n2", (3, 5), version=2), role="follower",
+                             reply=dict(pre_vote=True, term=5, token=77, success=False))),
+    dict(reset=True, **step("follower", pre_vote(5, "n2", (3, 5), version=0), role="follower",
+                             reply=dict(pre_vote=True, term=5, token=77, success=True))),
+    dict(reset=True, **step("follower", pre_vote(5, "n2", (3, 5), machine_version=99), role="follower",
+                             reply=dict(pre_vote=True, term=5, token=77, success=False),
+                             flags_set=["START_ELECTION_TIMEOUT"])),
+    dict(reset=True, **step("follower", pre_vote(4, "n2", (3, 5)), role="follower",
+                             state=dict(current_term=5),
+                             reply=dict(pre_vote=True, term=5, token=77, success=False),
+                             effects_only_reply=True)),
+    dict(reset=True, **step("follower", pre_vote(6, "n2", (3, 4)), role="follower",
+                             state=dict(current_term=6), no_reply=True,
+                             flags_set=["START_ELECTION_TIMEOUT"])),
+    dict(reset=True, **step("follower", pre_vote(5, "n2", (4, 5)), role="follower",
+                             state=dict(current_term=5),
+                             reply=dict(pre_vote=True, term=5, token=77, success=True))),
+    dict(reset=True, **step("pre_vote", pre_vote(5, "n2", (3, 5)), role="pre_vote",
+                             state=dict(current_term=5),
+                             reply=dict(pre_vote=True, term=5, token=77, success=True))),
+    dict(reset=True, **step("await_condition", pre_vote(5, "n2", (3, 5)), role="await_condition",
+                             state=dict(current_term=5),
+                             reply=dict(pre_vote=True, term=5, token=77, success=True))),
+], note="also pre_vote_receives_pre_vote :1665-1680, await_condition_receives_pre_vote :1682-1698")
+
+for _i, (_eff, _ours, _theirs, _ok) in enumerate([(1, 0, 1, True), (1, 1, 0, False), (3, 2, 2, False),
+                                                   (1, 3, 2, True), (0, 1, 0, True), (2, 2, 2, True)]):
+    vec(f"E2.{_i}", "test/ra_server_SUITE.erl:1548-1596 follower_pre_vote (machine versions)", 3, "n1",
+        "base", [step("follower", pre_vote(5, "n2", (3, 5), machine_version=_theirs), role="follower",
+                      reply=dict(pre_vote=True, term=5, token=77, success=_ok))],
+        tweak=dict(effective_machine_version=_eff, machine_version=_ours))
+
+vec("E3", "test/ra_server_SUITE.erl:1618-1620 follower_pre_vote (non-voter)", 3, "n1", "base", [
+    step("follower", pre_vote(5, "n2", (3, 5)), role="follower", state_unchanged=True, no_reply=True),
+], tweak=dict(self_nonvoter=True))
+
+vec("E4", "test/ra_server_SUITE.erl:1634-1663 pre_vote_does_not_set_voted_for", 3, "n1", "base", [
+    step("follower", pre_vote(5, "n2", (3, 5)), role="follower", state=dict(voted_for=None),
+         reply=dict(pre_vote=True, term=5, token=77, success=True)),
+    step("follower", req_vote(5, "n3", (3, 5)), role="follower", state=dict(voted_for="n3"),
+         reply=dict(vote=True, term=5, success=True)),
+])
+
+vec("E5", "test/ra_server_SUITE.erl:2550-2577 pre_vote_election", 5, "n1", "base", [
+    step("pre_vote", pre_vote_result(5, True, 1234), role="pre_vote", state=dict(votes=2), no_reply=True),
+    dict(fork=True, **step("pre_vote", pre_vote_result(5, True, 999), role="pre_vote",
+                            state=dict(votes=2), no_reply=True)),
+    step("pre_vote", pre_vote_result(5, False, 1234), role="pre_vote", state=dict(votes=2)),
+    dict(fork=True, **step("pre_vote", pre_vote_result(6, False, 1234), role="follower",
+                            state=dict(current_term=6, votes=0), no_reply=True)),
+    step("pre_vote", pre_vote_result(5, True, 1234), role="candidate", state=dict(current_term=6),
+         flags_set=["SEND_VOTE_REQUESTS", "PERSIST"], flags_clear=["PRE_VOTE_REQS"]),
+], tweak=dict(votes=1, pre_vote_token=1234, role="pre_vote"))
+
+vec("E6", "test/ra_server_SUITE.erl:2579-2587 pre_vote_election_non_voter", 5, "n1", "base", [
+    step("pre_vote", pre_vote_result(5, True, 1234), role="pre_vote", state=dict(votes=1), no_reply=True),
+], tweak=dict(votes=1, pre_vote_token=1234, role="pre_vote", self_nonvoter=True))
+
+vec("E7", "test/ra_server_SUITE.erl:2589-2606 pre_vote_election_reverts", 5, "n1", "base", [
+    dict(reset=True, **step("pre_vote", req_vote(6, "n2", (3, 5)), role="follower",
+                             state=dict(current_term=6), flags_set=["REPROCESSED"])),
+    dict(reset=True, **step("pre_vote", aer(5, "n2", (3, 5), 3, []), role="follower",
+                             state=dict(current_term=5), flags_set=["REPROCESSED"])),
+], tweak=dict(votes=1, pre_vote_token=1234, role="pre_vote"))
+
+vec("E8", "test/ra_server_SUITE.erl:335-381 election_timeout", 3, "n1", "base", [
+    dict(reset=True, **step("follower", dict(kind="election_timeout", token=4242), role="pre_vote",
+                             state=dict(current_term=5, votes=1, pre_vote_token=4242),
+                             vote_requests=dict(pre_vote=True, term=5, token=4242, last=[3, 5]))),
+    dict(reset=True, **step("pre_vote", dict(kind="election_timeout", token=4343), role="pre_vote",
+                             state=dict(current_term=5, votes=1, pre_vote_token=4343),
+                             vote_requests=dict(pre_vote=True, term=5, token=4343, last=[3, 5]))),
+    dict(reset=True, **step("candidate", dict(kind="election_timeout", token=1), role="candidate",
+                             state=dict(current_term=6, votes=1, voted_for="n1"),
+                             vote_requests=dict(pre_vote=False, term=6, last=[3, 5]))),
+], note="the reference returns votes=0 plus a {next_event, cast, VoteForSelf}; the engine applies "
+        "that self vote in the same decision, hence votes=1")
+
+vec("E9", "test/ra_server_SUITE.erl:350-353 election_timeout (non-voters ignore it)", 3, "n1", "base", [
+    dict(reset=True, **step("follower", dict(kind="election_timeout", token=5), role="follower",
+                             state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("await_condition", dict(kind="election_timeout", token=5),
+                             role="await_condition", state_unchanged=True, no_reply=True)),
+], tweak=dict(self_nonvoter=True))
 
 # -------------------------------------------- A.7 real-log last_written cursor ----
 vec("R1", "test/ra_log_2_SUITE.erl:189-211 (driven through follower AERs)", 3, "n2", "empty", [

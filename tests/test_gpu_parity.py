@@ -70,7 +70,8 @@ def test_hip_equals_oracle_on_random_ticks(engine_mod, oracle_lib, n_members, se
             assert gpu.state_checksum() == want
         if n_members >= 3:
             for f in ("REPLY", "PERSIST", "LEADER_MSG", "APPLIED", "WROTE", "TRUNCATED", "PIPELINE",
-                      "REPROCESSED", "ROLE_CHANGED", "UNHANDLED", "INVARIANT"):
+                      "REPROCESSED", "ROLE_CHANGED", "UNHANDLED", "INVARIANT", "REPLY_PRE_VOTE",
+                      "SEND_VOTE_REQUESTS", "PRE_VOTE_REQS", "BECAME_LEADER", "START_ELECTION_TIMEOUT"):
                 assert seen_flags & VR.FLAG[f], f"fuzz never produced {f}"
 
 

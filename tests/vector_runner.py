@@ -45,7 +45,8 @@ def initial_state(v) -> np.ndarray:
         st["next_index"][i, :n] = 4
         st["match_index"][i, :n] = 3
     tw = v.get("tweak") or {}
-    for k in ("commit_index", "last_applied", "current_term", "votes"):
+    for k in ("commit_index", "last_applied", "current_term", "votes", "pre_vote_token", "machine_version",
+              "effective_machine_version"):
         if k in tw:
             st[k][i] = tw[k]
     if "voted_for" in tw:
@@ -140,6 +141,21 @@ def make_msg(v, m) -> np.ndarray:
         out["flags"] = abi.MF_FORCE if m.get("force") else 0
     elif k == "await_timeout":
         out["kind"] = abi.MSG_AWAIT_TIMEOUT
+    elif k == "election_timeout":
+        out["kind"] = abi.MSG_ELECTION_TIMEOUT
+        out["c"] = m["token"]
+    elif k == "pre_vote_rpc":
+        out["kind"] = abi.MSG_PRE_VOTE_RPC
+        out["term"] = m["term"]
+        out["a"], out["b"] = m["last"]
+        out["c"] = m["token"]
+        out["n_entries"] = m["machine_version"]
+        out["gap"] = m["version"]
+    elif k == "pre_vote_result":
+        out["kind"] = abi.MSG_PRE_VOTE_RESULT
+        out["term"] = m["term"]
+        out["flags"] = abi.MF_SUCCESS if m["granted"] else 0
+        out["c"] = m["token"]
     else:
         raise ValueError(k)
     return out
@@ -222,6 +238,9 @@ def run_vector(engine_factory, v):
             r = exp["reply"]
             assert flags & abi.F_REPLY, f"{where}: no reply"
             assert bool(flags & abi.F_REPLY_VOTE) == bool(r.get("vote", False)), f"{where}: reply kind"
+            assert bool(flags & abi.F_REPLY_PRE_VOTE) == bool(r.get("pre_vote", False)), f"{where}: reply kind"
+            if "token" in r:
+                assert int(d["reply_next_index"]) == r["token"], f"{where}: reply token"
             if "to" in r:
                 assert int(d["reply_to"]) == slot(r["to"]), f"{where}: reply_to={int(d['reply_to'])}"
             if "success" in r:
@@ -230,8 +249,17 @@ def run_vector(engine_factory, v):
                 if k in r:
                     got = int(d["reply_" + k])
                     assert got == r[k], f"{where}: reply.{k}={got} expected {r[k]}"
+        if "vote_requests" in exp:
+            q = exp["vote_requests"]
+            assert flags & abi.F_SEND_VOTE_REQUESTS, f"{where}: no send_vote_requests"
+            assert bool(flags & abi.F_PRE_VOTE_REQS) == q["pre_vote"], f"{where}: request kind"
+            assert int(d["reply_term"]) == q["term"], f"{where}: request term {int(d['reply_term'])}"
+            assert [int(d["reply_last_index"]), int(d["reply_last_term"])] == q["last"], f"{where}: last log"
+            if "token" in q:
+                assert int(d["reply_next_index"]) == q["token"], f"{where}: request token"
         if exp.get("effects_only_reply"):
-            other = flags & ~(abi.F_REPLY | abi.F_REPLY_SUCCESS | abi.F_REPLY_VOTE | abi.F_PERSIST |
+            other = flags & ~(abi.F_REPLY | abi.F_REPLY_SUCCESS | abi.F_REPLY_VOTE | abi.F_REPLY_PRE_VOTE |
+                              abi.F_PERSIST |
                               abi.F_LEADER_CHANGED | abi.F_ROLE_CHANGED | abi.F_REPROCESSED)
             assert other == 0, f"{where}: extra effects flags {other:#x}"
         for fn in exp.get("flags_set", []):
