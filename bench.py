@@ -2,10 +2,15 @@
 """bench.py -- append_entries decisions/sec across N Raft groups on MI355X (BASELINE.json).
 
 Workload (config.workload): BASELINE.json configs[2] -- 65 536 five-member Raft groups per GPU,
-mixed append_entries / append_entries_reply / request_vote (5 % term churn) plus the
-housekeeping events ({commands,_} appends, {written,..} log events) that keep the logs moving.
-A "step" is one tick = one pass of the hot path (one kernel launch) over one batch of synthetic
-messages, at most one message per server, messages already resident in HBM.
+mixed append_entries_rpc / append_entries_reply / request_vote_rpc with 5 % term churn (5 % of
+the groups per tick see a request_vote with term+1; deposed groups re-elect through
+election_timeout / pre_vote / request_vote_result on the device), plus the {commands,_} appends
+and {written,..} log events that keep the logs moving.  The stream is produced by the
+device-side load generator (include/ra_gpu_batch_synth.h) from the evolving device state.
+
+A "step" is one tick: one pass of the hot path (ONE launch of rgb_tick_kernel) over one batch
+holding at most one message per server, messages already resident in HBM.  `value` counts real
+decisions only (empty NOP slots of the dense tick layout are not decisions).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -34,15 +39,15 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=480)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--groups", type=int, default=65536, help="Raft groups per GPU")
     ap.add_argument("--members", type=int, default=5)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0003)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--check-ticks", type=int, default=2,
+    ap.add_argument("--check-ticks", type=int, default=3,
                     help="ticks compared bit-for-bit with the oracle before timing (rank 0)")
     args = ap.parse_args()
 
@@ -62,9 +67,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     G, N = args.groups, args.members
+    S = G * N
     K, Wm = args.steps, args.warmup
     T = Wm + K
-    # this rank's shard of the global group id space (hash partition)
+    NK = abi.MSG_PRE_VOTE_RESULT + 1
+    # this rank's shard of the global group-id space (hash partition)
     my_groups = shard.local_group_ids(G * world, world, rank, per_rank=G)
     seed = (args.seed ^ (rank * 0x9E3779B97F4A7C15)) & ((1 << 64) - 1)
 
@@ -77,43 +84,63 @@ def main():
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
     assert sptr != 0
-
-    # ---- pass 1 (untimed): synthesise the tick stream from the evolving device state ----
-    t_gen = time.time()
-    ticks = []
-    scratch_dec = None
-    for t in range(T):
-        cur = eng.get_state()
-        m = W.gen_tick(cur, N, t, seed, W.MIX_CONFIG3)
-        ticks.append(m)
-        dm = torch.from_numpy(m.view(np.uint8).reshape(-1)).to(dev)
-        if scratch_dec is None or scratch_dec.numel() < len(m) * 64:
-            scratch_dec = torch.empty(len(m) * 64 + 4096, dtype=torch.uint8, device=dev)
-        eng.run_ticks_device(dm.data_ptr(), len(m), 1, scratch_dec.data_ptr(), stream=sptr)
-        torch.cuda.synchronize()
-        del dm
-    gen_s = time.time() - t_gen
-    width = max(len(m) for m in ticks)
-    width = (width + 255) // 256 * 256
-    host = np.zeros((T, width), dtype=abi.MSG_DTYPE)
-    for t, m in enumerate(ticks):
-        host[t, :len(m)] = m
-    n_dec = np.array([len(m) for m in ticks], dtype=np.int64)     # non-NOP decisions per tick
-    alg_bytes = np.array([W.algorithmic_bytes(m, N) for m in ticks], dtype=np.int64)
-    d_msgs = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(dev)
-    d_dec = torch.empty(T * width * 64, dtype=torch.uint8, device=dev)
-    d_rpcs = torch.empty(width * max(N - 1, 1) * 56, dtype=torch.uint8, device=dev)  # rewritten every tick
-    counts = n_dec.astype(np.uint32)
+    tick_bytes = S * 64
+    d_msgs = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)
+    d_dec = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)
+    d_rpcs = torch.empty(S * max(N - 1, 1) * 56, dtype=torch.uint8, device=dev)   # rewritten every tick
+    d_kc = torch.zeros(T * NK, dtype=torch.int32, device=dev)
+    d_n = torch.zeros(T, dtype=torch.int32, device=dev)           # real size of every tick
     lb_local = torch.empty(G * 32, dtype=torch.uint8, device=dev)
     lb_all = torch.empty(world * G * 32, dtype=torch.uint8, device=dev) if world > 1 else None
-    tick_bytes = width * 64
+
+    # ---- pass 1 (untimed): generate tick t from the device state, then apply it ----
+    t_gen = time.time()
+    for t in range(T):
+        eng.synth_tick_device(seed, t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
+                              d_n.data_ptr() + t * 4, sptr)
+        eng.run_ticks_device(d_msgs.data_ptr() + t * tick_bytes, S, 1, d_dec.data_ptr() + t * tick_bytes,
+                             d_rpcs.data_ptr(), sptr, d_tick_counts=d_n.data_ptr() + t * 4)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t_gen
+    checksum_pass1 = eng.state_checksum()
+    kc = d_kc.cpu().numpy().reshape(T, NK).astype(np.int64)
+    n_dec = kc[:, 1:].sum(axis=1)                                  # decisions per tick
+    assert np.array_equal(n_dec, d_n.cpu().numpy().astype(np.int64))
+    counts = n_dec.astype(np.uint32)
+    alg_bytes = W.algorithmic_bytes_from_counts(kc, N)
+
+    def tick_msgs(t):
+        nt = int(n_dec[t])
+        return d_msgs[t * tick_bytes:t * tick_bytes + nt * 64].cpu().numpy().view(abi.MSG_DTYPE)
+
+    # ---- correctness gate (rank 0): the first ticks bit-for-bit against the oracle ----
+    checked = 0
+    first_ticks = []
+    if rank == 0 and (args.check_ticks > 0 or not args.no_cpu_baseline):
+        from oracle import oracle as O
+        n_keep = max(args.check_ticks, 0 if args.no_cpu_baseline else 16)
+        first_ticks = [tick_msgs(t) for t in range(min(n_keep, T))]
+        if args.check_ticks > 0:
+            cpu = O.Oracle(G, N)
+            cpu.set_state(0, st0)
+            for t in range(min(args.check_ticks, T)):
+                want, _ = cpu.step_parallel(first_ticks[t])
+                nt = int(n_dec[t])
+                got = d_dec[t * tick_bytes:t * tick_bytes + nt * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+                if got.tobytes() != want.tobytes():
+                    bad = int(np.flatnonzero((got.view(np.uint8).reshape(nt, 64) !=
+                                              want.view(np.uint8).reshape(nt, 64)).any(axis=1))[0])
+                    raise SystemExit(f"PARITY FAILURE tick {t} slot {bad}: msg={first_ticks[t][bad]} "
+                                     f"gpu={got[bad]} cpu={want[bad]}")
+                checked += 1
+            cpu.close()
 
     def run(t0, t1, with_snapshots=True):
-        """Enqueue ticks [t0, t1) on the current torch stream."""
+        """Enqueue ticks [t0, t1) on the stream: one kernel launch per tick."""
         t = t0
         while t < t1:
             nxt = min(t1, (t // SNAPSHOT_EVERY + 1) * SNAPSHOT_EVERY)
-            eng.run_ticks_device(d_msgs.data_ptr() + t * tick_bytes, width, nxt - t,
+            eng.run_ticks_device(d_msgs.data_ptr() + t * tick_bytes, S, nxt - t,
                                  d_dec.data_ptr() + t * tick_bytes, d_rpcs.data_ptr(), sptr,
                                  tick_counts=counts[t:nxt])
             if with_snapshots and nxt % SNAPSHOT_EVERY == 0:
@@ -122,44 +149,21 @@ def main():
                     dist.all_gather_into_tensor(lb_all, lb_local)
             t = nxt
 
-    # ---- correctness gate before timing (rank 0): first ticks bit-exact vs the oracle ----
-    checked = 0
-    if rank == 0 and args.check_ticks > 0:
-        from oracle import oracle as O
-        cpu = O.Oracle(G, N)
-        cpu.set_state(0, st0)
-        eng.set_state(0, st0)
-        nchk = min(args.check_ticks, T)
-        run(0, nchk, with_snapshots=False)
-        torch.cuda.synchronize()
-        got = d_dec[:nchk * tick_bytes].cpu().numpy().view(abi.DECISION_DTYPE).reshape(nchk, width)
-        for t in range(nchk):
-            nt = int(n_dec[t])
-            want, _ = cpu.step_parallel(host[t, :nt])
-            g = got[t, :nt]
-            if g.tobytes() != want.tobytes():
-                bad = int(np.flatnonzero((g.view(np.uint8).reshape(nt, 64) !=
-                                          want.view(np.uint8).reshape(nt, 64)).any(axis=1))[0])
-                raise SystemExit(f"PARITY FAILURE tick {t} decision {bad}: gpu={g[bad]} cpu={want[bad]}")
-        assert eng.get_state().tobytes() == cpu.get_state().tobytes(), "state differs from the oracle"
-        checked = nchk
-        cpu.close()
-
     # ---- pass 2: reset, warm up, time exactly K ticks ----
     eng.set_state(0, st0)
     run(0, Wm)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     # the K timed ticks are captured once into a hipGraph (launch-bound inner loop: the eager host
-    # launch rate is ~3.7 us per kernel on this box, the kernels themselves are shorter)
+    # launch rate is ~3.7 us per kernel on this box)
     graph = None
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
             run(Wm, T)
         torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wall0 = time.perf_counter()
     ev0.record(stream)
@@ -175,16 +179,17 @@ def main():
     wall = time.perf_counter() - wall0
     ev_ms = ev0.elapsed_time(ev1)
     elapsed = max(wall, ev_ms / 1e3)
+    checksum_pass2 = eng.state_checksum()
+    assert checksum_pass2 == checksum_pass1, "replay diverged from the generation pass"
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         tot = torch.tensor([int(n_dec[Wm:].sum()), int(alg_bytes[Wm:].sum())], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_dec, total_bytes = int(tot[0].item()), int(tot[1].item())
+        total_dec = int(tot[0].item())
     else:
-        total_dec, total_bytes = int(n_dec[Wm:].sum()), int(alg_bytes[Wm:].sum())
-    final_checksum = eng.state_checksum()
+        total_dec = int(n_dec[Wm:].sum())
 
     # ---- cpu baseline (rank 0, N=1 only): the oracle on this box's host cores ----
     cpu_baseline = None
@@ -192,8 +197,7 @@ def main():
         from oracle import oracle as O
         cpu = O.Oracle(G, N)
         ncpu = os.cpu_count() or 1
-        sample = min(T, 16)
-        # pick the thread count that is fastest on this box (OpenMP fork/join dominates small ticks)
+        sample = first_ticks[:16]
         best_thr, best_rate = 1, 0.0
         for thr in sorted({1, 8, 16, 32, 64, ncpu}):
             if thr > ncpu:
@@ -201,9 +205,9 @@ def main():
             cpu.set_state(0, st0)
             t0 = time.perf_counter()
             nd = 0
-            for t in range(min(sample, 4)):
-                cpu.step_parallel(ticks[t], thr)
-                nd += len(ticks[t])
+            for m in sample[:4]:
+                cpu.step_parallel(m, thr)
+                nd += len(m)
             rate = nd / (time.perf_counter() - t0)
             if rate > best_rate:
                 best_thr, best_rate = thr, rate
@@ -211,15 +215,15 @@ def main():
         spent, done_dec, reps = 0.0, 0, 0
         while spent < args.cpu_seconds and reps < 256:
             cpu.set_state(0, st0)
-            for t in range(sample):
+            for m in sample:
                 t0 = time.perf_counter()
-                cpu.step_parallel(ticks[t], threads)
+                cpu.step_parallel(m, threads)
                 spent += time.perf_counter() - t0
-                done_dec += len(ticks[t])
+                done_dec += len(m)
             reps += 1
         cpu_baseline = {
             "value": done_dec / spent, "unit": "decisions/s", "cores": threads, "kind": "port",
-            "sample": f"first {sample} ticks of the same stream x {reps} repetitions "
+            "sample": f"first {len(sample)} ticks of the same stream x {reps} repetitions "
                       f"({done_dec} decisions, {spent:.1f} s of oracle time, OpenMP over messages, "
                       f"best of 1/8/16/32/64/{ncpu} threads on {ncpu} host cores)",
         }
@@ -229,12 +233,10 @@ def main():
         per_launch_s = (ev_ms / 1e3) / K
         launch_bytes = float(alg_bytes[Wm:].mean())
         achieved = launch_bytes / per_launch_s / 1e9
-        kinds = {}
-        allm = np.concatenate(ticks[Wm:])
-        for name, code in (("aer", abi.MSG_AER), ("aer_reply", abi.MSG_AER_REPLY),
-                           ("request_vote", abi.MSG_REQUEST_VOTE), ("append", abi.MSG_APPEND),
-                           ("written", abi.MSG_WRITTEN)):
-            kinds[name] = round(float((allm["kind"] == code).mean()), 4)
+        names = ["nop", "aer", "aer_reply", "request_vote", "vote_result", "written", "pipeline_rpcs",
+                 "append", "await_timeout", "election_timeout", "pre_vote_rpc", "pre_vote_result"]
+        tk = kc[Wm:].sum(axis=0)
+        mix = {names[i]: round(float(tk[i]) / float(tk[1:].sum()), 4) for i in range(1, NK) if tk[i]}
         out = {
             "metric": "append_entries decisions/sec across N Raft groups; achieved HBM GB/s vs peak",
             "value": total_dec / elapsed,
@@ -245,18 +247,19 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {
                 "workload": "configs[2]: 65536 groups x 5 members per GPU, mixed append_entries + "
-                            "request_vote (5% term churn), device-resident message batches",
+                            "request_vote (5% term churn), device-resident message batches, "
+                            "one kernel launch per tick",
                 "groups_per_gpu": G, "members": N, "decisions_per_tick": float(n_dec[Wm:].mean()),
-                "tick_width": width, "message_mix": kinds,
+                "message_mix": mix,
                 "leaderboard_allgather_every": SNAPSHOT_EVERY,
                 "parallelism": f"hash-sharded groups x{world}, no data-path collective",
-                "oracle_checked_ticks": checked, "state_checksum": f"{final_checksum:#018x}",
-                "stream_generation_s": round(gen_s, 1),
+                "oracle_checked_ticks": checked, "state_checksum": f"{checksum_pass2:#018x}",
+                "stream_generation_s": round(gen_s, 2), "hip_graph": graph is not None,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "rgb_tick_kernel<5>",
+                "kernel": f"rgb_tick_kernel<{N}>",
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "avg_launch_us": per_launch_s * 1e6,
             },

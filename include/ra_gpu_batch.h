@@ -308,15 +308,16 @@ int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
 
 /* Device-resident path (benchmarks, device-side producers): d_msgs holds n_ticks ticks laid out
  * tick_stride messages apart; tick t carries tick_counts[t] messages (host array; NULL = every
- * tick carries tick_stride messages), at most ONE message per server per tick (caller's
- * guarantee).  d_decisions has the same layout.  d_rpcs, when not NULL, receives the pipelined
- * rpcs of the CURRENT tick in fixed slots: message i owns records [i*(n_members-1),
- * (i+1)*(n_members-1)) of which the first rgb_decision.n_rpcs are valid; the buffer
- * (tick_stride*(n_members-1) records) is rewritten every tick.  Enqueued on `stream` (a
+ * tick carries tick_stride messages) further clamped by d_tick_counts[t] when that device array
+ * (uint32, written by a device-side producer) is not NULL; at most ONE message per server per
+ * tick (caller's guarantee).  d_decisions has the same layout.  d_rpcs, when not NULL, receives
+ * the pipelined rpcs of the CURRENT tick in fixed slots: message i owns records
+ * [i*(n_members-1), (i+1)*(n_members-1)) of which the first rgb_decision.n_rpcs are valid; the
+ * buffer (tick_stride*(n_members-1) records) is rewritten every tick.  Enqueued on `stream` (a
  * hipStream_t, NULL = the context's stream); returns without synchronising. */
 int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
-                          const uint32_t *tick_counts, uint32_t n_ticks, void *d_decisions,
-                          void *d_rpcs, void *stream);
+                          const uint32_t *tick_counts, const void *d_tick_counts, uint32_t n_ticks,
+                          void *d_decisions, void *d_rpcs, void *stream);
 
 /* leaderboard / metrics snapshot: one row per group */
 int  rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out);

@@ -1,0 +1,40 @@
+/*
+ * ra_gpu_batch_synth.h -- device-side synthetic load generator for libra_gpu_batch: what
+ * ra_bench (reference src/ra_bench.erl) is to Ra.  Benchmark tooling, not part of the drop-in
+ * boundary: it reads the CURRENT device state of every group and writes one dense tick of
+ * messages (at most one per server) straight into HBM, so long message streams can be produced
+ * without a host round trip per tick.
+ *
+ * The tick is written COMPACTED (no empty slots) and ordered by clause family (message kind,
+ * success flag) -- the order rgb_submit gives host batches; its message count goes to *d_n.
+ *
+ * Per group and tick (a fully loaded node):
+ *   leader      append_entries_reply ok 75 % / failed 5 % / {commands,_} append of 1..4 entries
+ *               20 %; a {written,..} event instead with probability 1/4 while it has unwritten
+ *               entries; a noop append (Force) right after winning an election
+ *   follower    append_entries_rpc with probability 1/2 (80 % append at the tail, 5 % empty
+ *               heartbeat, 5 % gap -> missing, 5 % wrong prev_log_term -> term_mismatch,
+ *               5 % overlapping resend), else {written,..} for its unwritten entries (80 %)
+ *   term churn  5 % of the groups: one member gets a request_vote_rpc with term+1
+ *   elections   a leader that is behind a member's term receives that member's failed reply
+ *               (steps down); a leaderless group runs election_timeout -> pre_vote_result x
+ *               quorum -> request_vote_result x quorum on its most advanced member
+ */
+#ifndef RA_GPU_BATCH_SYNTH_H
+#define RA_GPU_BATCH_SYNTH_H
+#include "ra_gpu_batch.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Write tick `tick` (at most n_groups*n_members rgb_msg) to d_msgs from the current device state.
+ * d_kind_counts (may be NULL): uint32[RGB_MSG_KIND_MAX+1], incremented per generated message
+ * kind; d_n (may be NULL): uint32 message count of the tick.  Enqueued on `stream` (NULL = the
+ * context's stream); no synchronisation. */
+int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs,
+                          void *d_kind_counts, void *d_n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

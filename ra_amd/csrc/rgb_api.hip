@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rgb_internal.h"
+#include "../../include/ra_gpu_batch_synth.h"
 
 struct rgb_slot {
   rgb_msg *h_msgs = nullptr;        /* pinned */
@@ -54,6 +55,7 @@ struct rgb_ctx {
   /* snapshot / checksum scratch */
   rgb_leaderboard_row *d_rows = nullptr;
   u64 *d_sums = nullptr;
+  u32 *d_synth = nullptr;     /* load-generator scratch (family counters) */
 };
 
 #define HIPCHK(ctx, expr)                          \
@@ -133,6 +135,7 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+  if (ctx->d_synth) (void)hipFree(ctx->d_synth);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -351,7 +354,7 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
                                ctx->stream));
     for (u32 r = 0; r < n_rounds; ++r) {
       u32 off = start[r], cnt = start[r + 1] - start[r];
-      int rc = rgb_launch_tick(ctx->dev, s.d_msgs + off, cnt, s.d_dec + off,
+      int rc = rgb_launch_tick(ctx->dev, s.d_msgs + off, cnt, nullptr, s.d_dec + off,
                                s.d_rpcs + (size_t)off * ctx->rpc_stride, off, ctx->stream);
       if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
     }
@@ -409,20 +412,34 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
 }
 
 int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
-                         const uint32_t *tick_counts, uint32_t n_ticks, void *d_decisions,
-                         void *d_rpcs, void *stream) {
+                         const uint32_t *tick_counts, const void *d_tick_counts, uint32_t n_ticks,
+                         void *d_decisions, void *d_rpcs, void *stream) {
   if (!ctx || !d_msgs || !d_decisions) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   void *st = stream ? stream : (void *)ctx->stream;
   const rgb_msg *m = (const rgb_msg *)d_msgs;
   rgb_decision *d = (rgb_decision *)d_decisions;
+  const u32 *dn = (const u32 *)d_tick_counts;
   for (u32 t = 0; t < n_ticks; ++t) {
     size_t off = (size_t)t * tick_stride;
     u32 cnt = tick_counts ? tick_counts[t] : tick_stride;
     if (cnt > tick_stride) return RGB_E_INVAL;
-    int rc = rgb_launch_tick(ctx->dev, m + off, cnt, d + off, (rgb_rpc *)d_rpcs, (u32)off, st);
+    int rc = rgb_launch_tick(ctx->dev, m + off, cnt, dn ? dn + t : nullptr, d + off, (rgb_rpc *)d_rpcs,
+                             (u32)off, st);
     if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
   }
+  return RGB_OK;
+}
+
+int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
+                          void *d_n, void *stream) {
+  if (!ctx || !d_msgs) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  void *st = stream ? stream : (void *)ctx->stream;
+  if (!ctx->d_synth) HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth, 4 * (RGB_MSG_KIND_MAX + 1) * sizeof(u32)));
+  int rc = rgb_launch_synth(ctx->dev, seed, tick, (rgb_msg *)d_msgs, ctx->d_synth, (u32 *)d_kind_counts,
+                            (u32 *)d_n, st);
+  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
   return RGB_OK;
 }
 

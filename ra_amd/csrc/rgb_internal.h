@@ -77,8 +77,12 @@ struct rgb_dev {
 
 /* kernel launchers (rgb_kernels.hip) */
 /* d_rpcs: n * max(N-1,1) fixed slots (message i owns slots [i*(N-1), (i+1)*(N-1))), or NULL */
-int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, rgb_decision *d_dec,
+/* d_n: optional device-resident message count (min(n, *d_n) messages are processed) */
+int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, const u32 *d_n, rgb_decision *d_dec,
                     rgb_rpc *d_rpcs, u32 msg_index_base, void *stream);
+/* d_scratch: 2*2*(RGB_MSG_KIND_MAX+1) u32 of device scratch */
+int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
+                     u32 *d_kind_counts, u32 *d_n, void *stream);
 int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream);
 int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u32 n, void *stream);
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream);

@@ -1179,11 +1179,17 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 
 template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
-                                                                  u32 n, rgb_decision *__restrict__ dec,
+                                                                  u32 n, const u32 *__restrict__ n_dev,
+                                                                  rgb_decision *__restrict__ dec,
                                                                   rgb_rpc *__restrict__ rpcs, u32 msg_index_base) {
   __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_IO_SLOT];
   const u32 lane = threadIdx.x;
   const u32 base = blockIdx.x * RGB_TICK_BLOCK;           /* first message of this wavefront */
+  if (n_dev != nullptr) {                                 /* the tick's real size lives on the device */
+    const u32 nd = *n_dev;
+    n = nd < n ? nd : n;
+    if (base >= n) return;                                /* uniform per block */
+  }
   const u32 cnt = n - base < RGB_TICK_BLOCK ? n - base : RGB_TICK_BLOCK;
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
 #pragma unroll
@@ -1212,6 +1218,224 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
     const u32 j = piece >> 2, part = piece & 3u;
     if (j < cnt) dst[piece] = io[j * RGB_IO_SLOT + part];
   }
+}
+
+
+/* ------------------------------------------------------------ synthetic load ---- */
+/* Device-side load generator (include/ra_gpu_batch_synth.h).  One lane per GROUP reads the hot
+ * lines of its N members (and the leader's peers row) and synthesises this tick's messages.  The
+ * tick comes out COMPACTED and ordered by clause family (kind, success flag), the order
+ * rgb_submit gives host batches:  pass 1 (rgb_synth_kernel<N,false>) counts messages per family,
+ * pass 2 (<N,true>) recomputes them (same counter-based PRNG) and writes each one at
+ * family_base + block reservation + rank. */
+
+#define SYN_FAMILIES (2 * (RGB_MSG_KIND_MAX + 1))
+
+__device__ __forceinline__ u64 sm64(u64 &x) {
+  x += 0x9E3779B97F4A7C15ull;
+  u64 z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct SynMember { u64 ct, ci, la, li, lt, lwi, lwt, pk, first, lrs, lrt, token; };
+
+struct SynMsg {
+  u32 server; unsigned kind, from, flags, gap; u64 term, a, b, c; u32 n_entries, n_run0; u64 run0, run1;
+};
+
+__device__ __forceinline__ void syn_store(rgb_msg *slot, const SynMsg &m) {
+  ulonglong2 *o = reinterpret_cast<ulonglong2 *>(slot);
+  u64 w0 = (u64)m.server | ((u64)(m.kind & 0xFF) << 32) | ((u64)(m.from & 0xFF) << 40) |
+           ((u64)(m.flags & 0xFF) << 48) | ((u64)(m.gap & 0xFF) << 56);
+  o[0] = make_ulonglong2(w0, m.term);
+  o[1] = make_ulonglong2(m.a, m.b);
+  o[2] = make_ulonglong2(m.c, (u64)m.n_entries | ((u64)m.n_run0 << 32));
+  o[3] = make_ulonglong2(m.run0, m.run1);
+}
+
+__device__ __forceinline__ SynMsg syn_msg(u32 server, unsigned kind, unsigned from, unsigned flags, u64 term,
+                                          u64 a, u64 b, u64 c, u32 n_entries = 0, u32 n_run0 = 0, u64 run0 = 0) {
+  SynMsg m;
+  m.server = server; m.kind = kind; m.from = from; m.flags = flags; m.gap = 0; m.term = term;
+  m.a = a; m.b = b; m.c = c; m.n_entries = n_entries; m.n_run0 = n_run0; m.run0 = run0; m.run1 = 0;
+  return m;
+}
+
+/* the messages of group g for this tick; emit(msg) is called once per message */
+template <int N, class Emit>
+__device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 tick, u32 g, Emit &&emit) {
+  u64 rs = seed ^ (tick * 0xD1B54A32D192ED03ull) ^ ((u64)g * 0x9E3779B97F4A7C15ull);
+  SynMember mb[N];
+  int leader = -1, cand = -1, prev = -1, hi = 0;
+  u64 lead_ct = 0, maxct = 0;
+#pragma unroll
+  for (int m = 0; m < N; ++m) {
+    const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(dev.hot + ((size_t)g * N + m) * RGB_HOT_WORDS);
+    const ulonglong2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h5 = hp[5], h6 = hp[6];
+    mb[m].ct = h0.x; mb[m].ci = h0.y; mb[m].la = h1.x; mb[m].li = h1.y; mb[m].lt = h2.x;
+    mb[m].lwi = h2.y; mb[m].lwt = h3.x; mb[m].pk = h3.y; mb[m].first = h5.x; mb[m].lrs = h5.y;
+    mb[m].lrt = h6.x; mb[m].token = h6.y;
+  }
+#pragma unroll
+  for (int m = 0; m < N; ++m) {
+    const unsigned role = (unsigned)pk_get(mb[m].pk, PK_ROLE_SH, 3);
+    if (mb[m].ct > maxct) maxct = mb[m].ct;
+    if (role == RGB_ROLE_LEADER && (leader < 0 || mb[m].ct > lead_ct)) { leader = m; lead_ct = mb[m].ct; }
+  }
+#pragma unroll
+  for (int m = 0; m < N; ++m) {
+    const unsigned role = (unsigned)pk_get(mb[m].pk, PK_ROLE_SH, 3);
+    if (role == RGB_ROLE_CANDIDATE && mb[m].ct == maxct && cand < 0) cand = m;
+    if (role == RGB_ROLE_PRE_VOTE && mb[m].ct == maxct && prev < 0) prev = m;
+    /* most advanced member: highest term, then most up-to-date log */
+    const bool better = mb[m].ct > mb[hi].ct ||
+                        (mb[m].ct == mb[hi].ct && (mb[m].lt > mb[hi].lt ||
+                                                   (mb[m].lt == mb[hi].lt && mb[m].li > mb[hi].li)));
+    if (better) hi = m;
+  }
+  auto sid = [&](int m) -> u32 { return g * N + (u32)m; };
+  auto other = [&](int m, u64 r) -> int { return N > 1 ? (int)((m + 1 + r % (N - 1)) % N) : m; };
+
+  const bool healthy = leader >= 0 && lead_ct == maxct;
+  if (!healthy) {
+    /* election traffic only */
+    const u64 r = sm64(rs);
+    if (leader >= 0) {
+      /* a member is ahead of the leader: its failed reply deposes the leader (a7) */
+      int mh = hi == leader ? other(leader, r) : hi;
+      emit(syn_msg(sid(leader), RGB_MSG_AER_REPLY, mh, 0, mb[mh].ct, mb[mh].li + 1, mb[mh].lwi, mb[mh].lwt));
+    } else if (cand >= 0) {
+      emit(syn_msg(sid(cand), RGB_MSG_VOTE_RESULT, other(cand, r), RGB_MF_SUCCESS, mb[cand].ct, 0, 0, 0));
+    } else if (prev >= 0) {
+      emit(syn_msg(sid(prev), RGB_MSG_PRE_VOTE_RESULT, other(prev, r), RGB_MF_SUCCESS, mb[prev].ct, 0, 0,
+                   mb[prev].token));
+    } else {
+      emit(syn_msg(sid(hi), RGB_MSG_ELECTION_TIMEOUT, RGB_NONE, 0, 0, 0, 0, (r | 1ull) & 0xFFFFFFFFFFFFull));
+    }
+    return;
+  }
+  const int l = leader;
+  const SynMember &ld = mb[l];
+  bool used[N];
+#pragma unroll
+  for (int m = 0; m < N; ++m) used[m] = false;
+  /* term churn: 5 % of the groups, one member gets request_vote term+1 */
+  const u64 rc = sm64(rs);
+  if (rc % 100 < 5) {
+    const int churn = (int)((rc >> 8) % N);
+    const u64 r2 = sm64(rs);
+    const u64 lli = mb[churn].li + (r2 % 3) > 0 ? mb[churn].li + (r2 % 3) - 1 : 0;
+    emit(syn_msg(sid(churn), RGB_MSG_REQUEST_VOTE, other(churn, r2 >> 8), 0, mb[churn].ct + 1, lli,
+                 mb[churn].lt, 0));
+    used[churn] = true;
+  }
+  /* ---- leader-side message ---- */
+  if (!used[l]) {
+    const u64 r = sm64(rs), r2 = sm64(rs);
+    const bool nonempty = ld.first <= ld.li;
+    if (ld.lt != ld.ct || !nonempty) {
+      /* just elected: the noop of the new term, pipelined with Force */
+      emit(syn_msg(sid(l), RGB_MSG_APPEND, RGB_NONE, RGB_MF_FORCE, 0, 0, 0, 0, 1));
+    } else if (ld.lwi < ld.li && (r & 3) == 0) {
+      const u64 a = ld.lwi + 1 > ld.first ? ld.lwi + 1 : ld.first;
+      emit(syn_msg(sid(l), RGB_MSG_WRITTEN, RGB_NONE, 0, ld.lt, a, ld.li, 0));
+    } else {
+      const unsigned v = (unsigned)((r >> 8) % 100);
+      const int j = other(l, r >> 16);
+      const u64 *pr = dev.peers + (size_t)sid(l) * dev.peer_stride;
+      const u64 mi = pr[j];
+      Lane T;                                   /* term lookups against the leader's log */
+      T.first = ld.first; T.li = ld.li; T.lrs = ld.lrs; T.lrt = ld.lrt; T.push_cnt = 0;
+      T.n_runs = (unsigned)pk_get(ld.pk, PK_NRUNS_SH, 5);
+      T.runs = dev.runs + (size_t)sid(l) * dev.max_runs * 2;
+      if (v < 75) {
+        u64 last = mi + r2 % 5; if (last > ld.li) last = ld.li;
+        u64 nxt = last + 1 + (r2 >> 8) % 3; if (nxt > ld.li + 1) nxt = ld.li + 1;
+        u64 t = fetch_term(T, last); if (t == UNDEF) t = 0;
+        emit(syn_msg(sid(l), RGB_MSG_AER_REPLY, j, RGB_MF_SUCCESS, ld.ct, nxt, last, t));
+      } else if (v < 80) {
+        u64 lo = ld.first > 0 ? ld.first - 1 : 0;
+        u64 last = mi > r2 % 4 ? mi - r2 % 4 : 0; if (last < lo) last = lo;
+        u64 t = fetch_term(T, last); if (t == UNDEF) t = 0;
+        if ((r2 >> 8) & 1) t += 1;                         /* half of them with a wrong term */
+        emit(syn_msg(sid(l), RGB_MSG_AER_REPLY, j, 0, ld.ct, last + 1, last, t));
+      } else {
+        emit(syn_msg(sid(l), RGB_MSG_APPEND, RGB_NONE, 0, 0, 0, 0, 0, 1 + (u32)(r2 % 4)));
+      }
+    }
+  }
+  /* ---- follower-side messages ---- */
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (j == l || used[j]) continue;
+    const SynMember &f = mb[j];
+    const u64 r = sm64(rs), r2 = sm64(rs);
+    if ((r & 1) == 0) {
+      const unsigned v = (unsigned)((r >> 8) % 100);
+      const u64 eterm = ld.ct > f.lt ? ld.ct : f.lt;
+      u64 prev_i = f.li, prev_t = f.lt, run0 = eterm;
+      u32 n_ent = 1 + (u32)(r2 % 8);
+      if (v >= 80 && v < 85) { n_ent = 0; }                                   /* heartbeat */
+      else if (v >= 85 && v < 90) { prev_i = f.li + 1 + (r2 >> 8) % 3; prev_t = ld.ct; n_ent = (u32)((r2 >> 16) % 3); }
+      else if (v >= 90 && v < 95) { prev_t = f.lt + 1; n_ent = 0; }           /* term mismatch */
+      else if (v >= 95) {
+        const u64 back = 1 + (r2 >> 8) % 4;                                   /* overlapping resend */
+        u64 floor_i = f.lrs > f.la ? f.lrs : f.la; if (f.first > floor_i) floor_i = f.first;
+        if (f.first <= f.li && f.li >= back && f.li - back >= floor_i) {
+          prev_i = f.li - back; prev_t = f.lt; n_ent = (u32)back; run0 = f.lt;
+        }
+      }
+      emit(syn_msg(sid(j), RGB_MSG_AER, l, 0, ld.ct, prev_i, prev_t, ld.ci, n_ent, n_ent, run0));
+    } else if (f.lwi < f.li && f.first <= f.li && (r >> 8) % 10 < 8) {
+      const u64 a = f.lwi + 1 > f.first ? f.lwi + 1 : f.first;
+      emit(syn_msg(sid(j), RGB_MSG_WRITTEN, RGB_NONE, 0, f.lt, a, f.li, 0));
+    }
+  }
+}
+
+/* fam_total[f]: messages of family f in this tick (pass 1 output, pass 2 input);
+ * fam_fill[f]: running reservation inside family f (pass 2);  both zeroed by the host per tick.
+ * d_n: total messages of the tick (written by pass 1's last step on the host side: the sum). */
+template <int N, bool WRITE>
+__global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u64 tick, rgb_msg *__restrict__ out,
+                                                       u32 *__restrict__ fam_total, u32 *__restrict__ fam_fill,
+                                                       u32 *__restrict__ kind_counts, u32 *__restrict__ d_n) {
+  __shared__ u32 cnt[SYN_FAMILIES], base[SYN_FAMILIES], rank[SYN_FAMILIES];
+  if (threadIdx.x < SYN_FAMILIES) { cnt[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
+  __syncthreads();
+  const u32 G = dev.n_servers / N;
+  const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+  auto family = [](const SynMsg &m) -> unsigned { return 2u * m.kind + ((m.flags & RGB_MF_SUCCESS) ? 1u : 0u); };
+  if (g < G) synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) { atomicAdd(&cnt[family(m)], 1u); });
+  __syncthreads();
+  if (!WRITE) {
+    if (threadIdx.x < SYN_FAMILIES && cnt[threadIdx.x]) atomicAdd(&fam_total[threadIdx.x], cnt[threadIdx.x]);
+    return;
+  }
+  if (threadIdx.x < SYN_FAMILIES) {
+    /* family base = exclusive scan of the totals; block reservation inside the family */
+    u32 b = 0;
+    for (unsigned f = 0; f < threadIdx.x; ++f) b += fam_total[f];
+    u32 mine = cnt[threadIdx.x];
+    base[threadIdx.x] = b + (mine ? atomicAdd(&fam_fill[threadIdx.x], mine) : 0u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    u32 total = 0;
+    for (unsigned f = 0; f < SYN_FAMILIES; ++f) {
+      total += fam_total[f];
+      if (kind_counts != nullptr && fam_total[f]) kind_counts[f >> 1] += fam_total[f];
+    }
+    if (d_n != nullptr) *d_n = total;
+  }
+  __syncthreads();
+  if (g < G)
+    synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) {
+      const unsigned f = family(m);
+      const u32 slot = base[f] + atomicAdd(&rank[f], 1u);
+      syn_store(out + slot, m);
+    });
 }
 
 /* ------------------------------------------------------------- support kernels -- */
@@ -1394,15 +1618,38 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
 
 #define RGB_BLOCK 256
 
-int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, rgb_decision *d_dec,
+int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, const u32 *d_n, rgb_decision *d_dec,
                     rgb_rpc *d_rpcs, u32 msg_index_base, void *stream) {
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((n + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                               \
   case NN:                                                                                       \
-    hipLaunchKernelGGL(rgb_tick_kernel<NN>, grid, block, 0, st, dev, d_msgs, n, d_dec, d_rpcs,   \
-                       msg_index_base);                                                          \
+    hipLaunchKernelGGL(rgb_tick_kernel<NN>, grid, block, 0, st, dev, d_msgs, n, d_n, d_dec,      \
+                       d_rpcs, msg_index_base);                                                  \
+    break;
+  switch (dev.n_members) {
+    LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
+    default: return -1;
+  }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
+                     u32 *d_kind_counts, u32 *d_n, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const u32 G = dev.n_servers / dev.n_members;
+  dim3 grid((G + 63) / 64), block(64);
+  u32 *fam_total = d_scratch, *fam_fill = d_scratch + SYN_FAMILIES;
+  hipError_t e = hipMemsetAsync(d_scratch, 0, 2 * SYN_FAMILIES * sizeof(u32), st);
+  if (e != hipSuccess) return (int)e;
+#define LAUNCH(NN)                                                                                     \
+  case NN:                                                                                             \
+    hipLaunchKernelGGL((rgb_synth_kernel<NN, false>), grid, block, 0, st, dev, seed, tick, d_msgs,      \
+                       fam_total, fam_fill, d_kind_counts, d_n);                                       \
+    hipLaunchKernelGGL((rgb_synth_kernel<NN, true>), grid, block, 0, st, dev, seed, tick, d_msgs,       \
+                       fam_total, fam_fill, d_kind_counts, d_n);                                       \
     break;
   switch (dev.n_members) {
     LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)

@@ -23,6 +23,7 @@ EXPORTS = [
     "rgb_download_state", "rgb_submit", "rgb_collect", "rgb_run_ticks_device", "rgb_snapshot",
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize",
 ]
+SYNTH_EXPORTS = ["rgb_synth_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
 
 
 class RgbError(RuntimeError):
@@ -83,11 +84,12 @@ def lib():
     L.rgb_download_state.argtypes = [vp, u32, u32, vp]
     L.rgb_submit.argtypes = [vp, vp, u32, C.c_uint64]
     L.rgb_collect.argtypes = [vp, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), u64p]
-    L.rgb_run_ticks_device.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp]
+    L.rgb_run_ticks_device.argtypes = [vp, vp, u32, vp, vp, u32, vp, vp, vp]
     L.rgb_snapshot.argtypes = [vp, vp]
     L.rgb_snapshot_device.argtypes = [vp, vp, vp]
     L.rgb_state_checksum.argtypes = [vp, u32, u32, u64p]
     L.rgb_synchronize.argtypes = [vp]
+    L.rgb_synth_tick_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
     if L.rgb_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("ABI version mismatch")
     for i, dt in enumerate(abi.STRUCT_DTYPES):
@@ -202,16 +204,26 @@ class RaGpuBatch:
 
     # -- device-resident path ------------------------------------------------------------
     def run_ticks_device(self, d_msgs: int, tick_stride: int, n_ticks: int, d_decisions: int,
-                         d_rpcs: int = 0, stream: int = 0, tick_counts: np.ndarray | None = None):
+                         d_rpcs: int = 0, stream: int = 0, tick_counts: np.ndarray | None = None,
+                         d_tick_counts: int = 0):
         """Raw device pointers (e.g. torch tensors' data_ptr()); enqueues and returns.
-        tick_counts: messages per tick (uint32, host) or None for tick_stride each."""
+        tick_counts: messages per tick (uint32, host) or None for tick_stride each;
+        d_tick_counts: device uint32 array with the real size of each tick (device producers)."""
         cp = None
         if tick_counts is not None:
             tc = np.ascontiguousarray(tick_counts, dtype=np.uint32)
             assert len(tc) >= n_ticks
             cp = tc.ctypes.data
-        self._check(self._L.rgb_run_ticks_device(self._h, d_msgs, tick_stride, cp, n_ticks, d_decisions,
-                                                 d_rpcs or None, stream or None), "rgb_run_ticks_device")
+        self._check(self._L.rgb_run_ticks_device(self._h, d_msgs, tick_stride, cp, d_tick_counts or None,
+                                                 n_ticks, d_decisions, d_rpcs or None, stream or None),
+                    "rgb_run_ticks_device")
+
+    def synth_tick_device(self, seed: int, tick: int, d_msgs: int, d_kind_counts: int = 0, d_n: int = 0,
+                          stream: int = 0):
+        """Device-side load generator (include/ra_gpu_batch_synth.h): one compacted, family-ordered
+        tick from the current device state into d_msgs (room for n_servers messages)."""
+        self._check(self._L.rgb_synth_tick_device(self._h, seed, tick, d_msgs, d_kind_counts or None,
+                                                  d_n or None, stream or None), "rgb_synth_tick_device")
 
     # -- observability -----------------------------------------------------------------
     def snapshot(self) -> np.ndarray:

@@ -431,9 +431,24 @@ def algorithmic_bytes(msgs: np.ndarray, n_members: int) -> int:
     k = msgs["kind"]
     n_aer = int((k == abi.MSG_AER).sum())
     n_rep = int((k == abi.MSG_AER_REPLY).sum())
-    n_vote = int((k == abi.MSG_REQUEST_VOTE).sum()) + int((k == abi.MSG_VOTE_RESULT).sum())
+    n_vote = int(np.isin(k, [abi.MSG_REQUEST_VOTE, abi.MSG_VOTE_RESULT, abi.MSG_ELECTION_TIMEOUT,
+                             abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT]).sum())
     # housekeeping kinds are priced like the class they resemble: written/await_timeout touch the
     # follower cursor like a vote (112 B); append/pipeline_rpcs walk the peer arrays like a reply
     n_small = int(np.isin(k, [abi.MSG_WRITTEN, abi.MSG_AWAIT_TIMEOUT]).sum())
     n_peer = int(np.isin(k, [abi.MSG_APPEND, abi.MSG_PIPELINE_RPCS]).sum())
     return 256 * n_aer + (168 + 16 * n_members) * (n_rep + n_peer) + 112 * (n_vote + n_small)
+
+
+def algorithmic_bytes_from_counts(kind_counts: np.ndarray, n_members: int) -> np.ndarray:
+    """Same pricing as algorithmic_bytes() from per-kind message counts [..., n_kinds]."""
+    kc = np.asarray(kind_counts, dtype=np.int64)
+    rep = 168 + 16 * n_members
+    price = np.zeros(kc.shape[-1], dtype=np.int64)
+    price[abi.MSG_AER] = 256
+    for k in (abi.MSG_AER_REPLY, abi.MSG_APPEND, abi.MSG_PIPELINE_RPCS):
+        price[k] = rep
+    for k in (abi.MSG_REQUEST_VOTE, abi.MSG_VOTE_RESULT, abi.MSG_WRITTEN, abi.MSG_AWAIT_TIMEOUT,
+              abi.MSG_ELECTION_TIMEOUT, abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT):
+        price[k] = 112
+    return (kc * price).sum(axis=-1)

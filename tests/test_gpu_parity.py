@@ -202,3 +202,61 @@ def test_run_table_overflow_is_flagged(engine_mod):
         assert flags & abi.F_RUNS_OVERFLOW
         assert int(st["n_runs"]) == 3 and int(st["last_index"]) == 5 and int(st["last_term"]) == 5
         assert int(st["first_index"]) == int(st["run_start"][0]) == 3
+
+
+@pytest.mark.parametrize("n_members,groups,ticks", [(5, 2048, 48), (7, 1024, 32), (3, 1024, 32)])
+def test_device_generated_stream_matches_oracle(engine_mod, oracle_lib, n_members, groups, ticks):
+    """The bench's tick stream (device-side load generator incl. term churn and on-device
+    elections) replayed through the oracle: every decision and the final state are identical."""
+    import torch
+    from ra_amd import workload as W
+    G, N = groups, n_members
+    S = G * N
+    st0 = W.initial_states(G, N, 0x5EED0003)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st0)
+    stream = torch.cuda.Stream()
+    with engine_mod.RaGpuBatch(G, N, max_runs=16) as gpu:
+        gpu.set_state(0, st0)
+        dm = torch.zeros(ticks * S * 64, dtype=torch.uint8, device="cuda")
+        dd = torch.zeros(ticks * S * 64, dtype=torch.uint8, device="cuda")
+        dr = torch.zeros(S * max(N - 1, 1) * 56, dtype=torch.uint8, device="cuda")
+        kc = torch.zeros(ticks * 12, dtype=torch.int32, device="cuda")
+        dn = torch.zeros(ticks, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for t in range(ticks):
+                gpu.synth_tick_device(0x5EED0003, t, dm.data_ptr() + t * S * 64, kc.data_ptr() + t * 48,
+                                      dn.data_ptr() + t * 4, stream.cuda_stream)
+                gpu.run_ticks_device(dm.data_ptr() + t * S * 64, S, 1, dd.data_ptr() + t * S * 64,
+                                     dr.data_ptr(), stream.cuda_stream, d_tick_counts=dn.data_ptr() + t * 4)
+        torch.cuda.synchronize()
+        msgs = dm.cpu().numpy().view(abi.MSG_DTYPE).reshape(ticks, S)
+        decs = dd.cpu().numpy().view(abi.DECISION_DTYPE).reshape(ticks, S)
+        counts = kc.cpu().numpy().reshape(ticks, 12)
+        ns = dn.cpu().numpy()
+        flags_seen = 0
+        for t in range(ticks):
+            nt = int(ns[t])
+            m = msgs[t, :nt]
+            assert nt > G and not np.any(m["kind"] == abi.MSG_NOP)
+            assert len(np.unique(m["server"])) == nt, "two messages for one server in a tick"
+            assert np.array_equal(np.bincount(m["kind"], minlength=12), counts[t])
+            fam = m["kind"].astype(np.int64) * 2 + (m["flags"] & abi.MF_SUCCESS)
+            assert np.all(np.diff(fam) >= 0), "tick is not ordered by clause family"
+            want, _ = cpu.step(m)
+            got = decs[t, :nt]
+            if got.tobytes() != want.tobytes():
+                bad = int(np.flatnonzero((got.view(np.uint8).reshape(nt, 64) !=
+                                          want.view(np.uint8).reshape(nt, 64)).any(axis=1))[0])
+                raise AssertionError(f"tick {t} slot {bad}: msg={m[bad]}\n gpu={got[bad]}\n cpu={want[bad]}")
+            flags_seen |= int(np.bitwise_or.reduce(want["flags"]))
+            assert not np.any(want["flags"] & abi.F_INVARIANT), "the generator produced an invariant breach"
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes()
+        # term churn really exercises the election path on the device
+        for f in ("BECAME_LEADER", "SEND_VOTE_REQUESTS", "PRE_VOTE_REQS", "ROLE_CHANGED", "WROTE", "APPLIED",
+                  "PIPELINE", "PERSIST", "REPROCESSED") if ticks >= 32 else ():
+            assert flags_seen & VR.FLAG[f], f"stream never produced {f}"
+        # and the groups stay healthy: most of them have exactly one leader at the end
+        rows = gpu.snapshot()
+        assert (rows["n_leaders"] == 1).mean() > 0.6
