@@ -313,11 +313,18 @@ int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
  * tick (caller's guarantee).  d_decisions has the same layout.  d_rpcs, when not NULL, receives
  * the pipelined rpcs of the CURRENT tick in fixed slots: message i owns records
  * [i*(n_members-1), (i+1)*(n_members-1)) of which the first rgb_decision.n_rpcs are valid; the
- * buffer (tick_stride*(n_members-1) records) is rewritten every tick.  Enqueued on `stream` (a
- * hipStream_t, NULL = the context's stream); returns without synchronising. */
+ * buffer (tick_stride*(n_members-1) records) is rewritten every tick.
+ * kind_counts (host, may be NULL): uint32[n_ticks][RGB_MSG_KIND_MAX+1] message counts per kind for
+ * ticks whose messages are ordered by clause family (the order rgb_submit and the load generator
+ * produce: append_entries_rpc, append_entries_reply, written, append, then the rest); the library
+ * then launches the class-dispatch kernel (each wavefront runs the code path specialised for its
+ * slice's message kind) instead of the kind-generic kernel.
+ * Enqueued on `stream` (a hipStream_t, NULL = the context's stream); returns without
+ * synchronising. */
 int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
-                          const uint32_t *tick_counts, const void *d_tick_counts, uint32_t n_ticks,
-                          void *d_decisions, void *d_rpcs, void *stream);
+                          const uint32_t *tick_counts, const void *d_tick_counts,
+                          const uint32_t *kind_counts, uint32_t n_ticks, void *d_decisions,
+                          void *d_rpcs, void *stream);
 
 /* leaderboard / metrics snapshot: one row per group */
 int  rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out);

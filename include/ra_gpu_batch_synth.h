@@ -34,6 +34,12 @@ extern "C" {
 int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs,
                           void *d_kind_counts, void *d_n, void *stream);
 
+/* Apply the tick that rgb_synth_tick_device just wrote (same stream): one launch of the
+ * class-dispatch kernel sized from the family totals the generator left in device memory, so no
+ * host round trip is needed between generating a tick and applying it. */
+int rgb_synth_apply_tick_device(rgb_ctx *ctx, const void *d_msgs, uint32_t max_msgs, void *d_decisions,
+                                void *d_rpcs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,9 @@ COND_NONE, COND_MISSING, COND_TERM_MISMATCH = range(3)
  MSG_PIPELINE_RPCS, MSG_APPEND, MSG_AWAIT_TIMEOUT, MSG_ELECTION_TIMEOUT, MSG_PRE_VOTE_RPC,
  MSG_PRE_VOTE_RESULT) = range(12)
 PROTO_VERSION = 1
+# device order of a tick: clause family = (class rank of the kind, success flag); the four hot
+# kinds first (each has a specialised kernel), the rest after (ra_amd/csrc/rgb_internal.h)
+KIND_RANK = np.array([11, 0, 1, 5, 6, 2, 4, 3, 7, 8, 9, 10], dtype=np.int64)
 MF_SUCCESS = 0x01
 MF_FORCE = 0x02
 
@@ -114,6 +117,10 @@ STRUCT_DTYPES = [MSG_DTYPE, DECISION_DTYPE, RPC_DTYPE, SERVER_STATE_DTYPE, LEADE
 EXPECTED_SIZES = [64, 64, 56, 592, 32, 32]
 for _dt, _sz in zip(STRUCT_DTYPES, EXPECTED_SIZES):
     assert _dt.itemsize == _sz, (_dt, _dt.itemsize, _sz)
+
+
+def family(msgs: np.ndarray) -> np.ndarray:
+    return KIND_RANK[msgs["kind"]] * 2 + (msgs["flags"] & MF_SUCCESS)
 
 
 def empty_server_states(n_groups: int, n_members: int) -> np.ndarray:

@@ -19,6 +19,15 @@
 #include "rgb_internal.h"
 #include "../../include/ra_gpu_batch_synth.h"
 
+#define HIPCHK(ctx, expr)                          \
+  do {                                             \
+    hipError_t e__ = (expr);                       \
+    if (e__ != hipSuccess) {                       \
+      (ctx)->last_hip = (int)e__;                  \
+      return RGB_E_HIP;                            \
+    }                                              \
+  } while (0)
+
 struct rgb_slot {
   rgb_msg *h_msgs = nullptr;        /* pinned */
   rgb_decision *h_dec = nullptr;    /* pinned */
@@ -58,14 +67,14 @@ struct rgb_ctx {
   u32 *d_synth = nullptr;     /* load-generator scratch (family counters) */
 };
 
-#define HIPCHK(ctx, expr)                          \
-  do {                                             \
-    hipError_t e__ = (expr);                       \
-    if (e__ != hipSuccess) {                       \
-      (ctx)->last_hip = (int)e__;                  \
-      return RGB_E_HIP;                            \
-    }                                              \
-  } while (0)
+/* A tick ordered by clause family: ONE launch of the class-dispatch kernel. */
+static int launch_tick_classes(rgb_ctx *ctx, const rgb_msg *m, rgb_decision *d, rgb_rpc *rpcs,
+                               const u32 counts[RGB_N_CLASSES], u32 rpc_slot_base, u32 msg_index_base,
+                               hipStream_t main) {
+  int rc = rgb_launch_tick_classes(ctx->dev, m, counts, nullptr, 0, d, rpcs, rpc_slot_base, msg_index_base, main);
+  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  return RGB_OK;
+}
 
 extern "C" {
 
@@ -136,6 +145,7 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->d_synth) (void)hipFree(ctx->d_synth);
+
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -161,6 +171,7 @@ int rgb_open(const rgb_config *cfg_in, rgb_ctx **out) {
   memset(&ctx->dev, 0, sizeof ctx->dev);
   e = hipSetDevice(cfg.device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+
   if (e != hipSuccess) { ctx->last_hip = (int)e; delete ctx; return RGB_E_HIP; }
   *out = ctx;
   return RGB_OK;
@@ -194,6 +205,11 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   d.peer_stride = rgb_peer_stride(n_members);
   d.max_pipeline_count = ctx->cfg.max_pipeline_count;
   d.max_aer_batch = ctx->cfg.max_aer_batch;
+  { const char *e = getenv("RGB_DEBUG"); d.dbg = e ? (u32)atoi(e) : 0u; d.dbg_buf = nullptr; }
+  if (d.dbg & 16u) {
+    HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(S / 64 + 16) * 4 * sizeof(u64)));
+    HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 4 * sizeof(u64)));
+  }
   HIPCHK(ctx, hipMalloc((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.runs, (size_t)S * d.max_runs * 2 * sizeof(u64)));
@@ -332,8 +348,8 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   /* device order: by round, then by clause family = (message kind, success flag) (a round holds
    * at most one message per server, so its order is free; family-homogeneous wavefronts do not
    * diverge across clause families), stable inside a bucket */
-  const u32 NK = 2 * (RGB_MSG_KIND_MAX + 1);
-  auto family = [](const rgb_msg &m) -> u32 { return 2u * m.kind + (m.flags & RGB_MF_SUCCESS ? 1u : 0u); };
+  const u32 NK = RGB_N_FAMILIES;
+  auto family = [](const rgb_msg &m) -> u32 { return rgb_family(m.kind, m.flags); };
   std::vector<u32> start(n_rounds + 1, 0);
   std::vector<u32> bucket((size_t)n_rounds * NK + 1, 0);
   for (u32 i = 0; i < n; ++i) {
@@ -354,9 +370,26 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
                                ctx->stream));
     for (u32 r = 0; r < n_rounds; ++r) {
       u32 off = start[r], cnt = start[r + 1] - start[r];
-      int rc = rgb_launch_tick(ctx->dev, s.d_msgs + off, cnt, nullptr, s.d_dec + off,
-                               s.d_rpcs + (size_t)off * ctx->rpc_stride, off, ctx->stream);
-      if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+      int rc;
+      if (cnt >= 4096) {
+        /* big round: the class-dispatch kernel (specialised path per message kind) */
+        u32 cc[RGB_N_CLASSES] = {0};
+        for (u32 p = off; p < off + cnt; ++p)
+          if (s.h_msgs[p].kind != RGB_MSG_NOP) cc[rgb_class_of_kind(s.h_msgs[p].kind)]++;
+        rc = launch_tick_classes(ctx, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
+        if (rc) return rc;
+        u32 real = 0;
+        for (int c = 0; c < RGB_N_CLASSES; ++c) real += cc[c];
+        if (real < cnt) {      /* NOP slots sort last: the generic kernel writes their empty decisions */
+          rc = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
+                               s.d_rpcs, off + real, off + real, ctx->stream);
+          if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+        }
+      } else {
+        rc = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off,
+                             ctx->stream);
+        if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+      }
     }
     HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost,
                                ctx->stream));
@@ -412,19 +445,31 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
 }
 
 int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
-                         const uint32_t *tick_counts, const void *d_tick_counts, uint32_t n_ticks,
-                         void *d_decisions, void *d_rpcs, void *stream) {
+                         const uint32_t *tick_counts, const void *d_tick_counts,
+                         const uint32_t *kind_counts, uint32_t n_ticks, void *d_decisions, void *d_rpcs,
+                         void *stream) {
   if (!ctx || !d_msgs || !d_decisions) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
-  void *st = stream ? stream : (void *)ctx->stream;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   const rgb_msg *m = (const rgb_msg *)d_msgs;
   rgb_decision *d = (rgb_decision *)d_decisions;
   const u32 *dn = (const u32 *)d_tick_counts;
+  const u32 NKIND = RGB_MSG_KIND_MAX + 1;
   for (u32 t = 0; t < n_ticks; ++t) {
     size_t off = (size_t)t * tick_stride;
+    if (kind_counts) {
+      /* family-ordered tick with host-known per-kind counts: the class-dispatch kernel */
+      u32 cc[RGB_N_CLASSES] = {0};
+      u64 total = 0;
+      for (u32 k = 1; k < NKIND; ++k) { cc[rgb_class_of_kind(k)] += kind_counts[t * NKIND + k]; total += kind_counts[t * NKIND + k]; }
+      if (total > tick_stride || kind_counts[t * NKIND + RGB_MSG_NOP]) return RGB_E_INVAL;
+      int rc = launch_tick_classes(ctx, m + off, d + off, (rgb_rpc *)d_rpcs, cc, 0, (u32)off, st);
+      if (rc) return rc;
+      continue;
+    }
     u32 cnt = tick_counts ? tick_counts[t] : tick_stride;
     if (cnt > tick_stride) return RGB_E_INVAL;
-    int rc = rgb_launch_tick(ctx->dev, m + off, cnt, dn ? dn + t : nullptr, d + off, (rgb_rpc *)d_rpcs,
+    int rc = rgb_launch_tick(ctx->dev, -1, m + off, cnt, dn ? dn + t : nullptr, d + off, (rgb_rpc *)d_rpcs, 0,
                              (u32)off, st);
     if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
   }
@@ -439,6 +484,17 @@ int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_ms
   if (!ctx->d_synth) HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth, 4 * (RGB_MSG_KIND_MAX + 1) * sizeof(u32)));
   int rc = rgb_launch_synth(ctx->dev, seed, tick, (rgb_msg *)d_msgs, ctx->d_synth, (u32 *)d_kind_counts,
                             (u32 *)d_n, st);
+  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  return RGB_OK;
+}
+
+int rgb_synth_apply_tick_device(rgb_ctx *ctx, const void *d_msgs, uint32_t max_msgs, void *d_decisions,
+                                void *d_rpcs, void *stream) {
+  if (!ctx || !d_msgs || !d_decisions) return RGB_E_INVAL;
+  if (!ctx->registered || !ctx->d_synth) return RGB_E_STATE;
+  void *st = stream ? stream : (void *)ctx->stream;
+  int rc = rgb_launch_tick_classes(ctx->dev, (const rgb_msg *)d_msgs, nullptr, ctx->d_synth, max_msgs,
+                                   (rgb_decision *)d_decisions, (rgb_rpc *)d_rpcs, 0, 0, st);
   if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
   return RGB_OK;
 }
@@ -480,6 +536,13 @@ int rgb_state_checksum(rgb_ctx *ctx, uint32_t first, uint32_t n, uint64_t *out) 
   u64 acc = 0;
   for (u32 k = 0; k < n; ++k) acc += sums[k] * (2ull * (u64)(first + k) + 1ull);
   *out = acc;
+  return RGB_OK;
+}
+
+/* profiling aid (RGB_DEBUG & 16): per-wave timestamps of the last class-dispatch launch */
+int rgb_debug_read(rgb_ctx *ctx, uint64_t *out, uint32_t n_words) {
+  if (!ctx || !out || !ctx->dev.dbg_buf) return RGB_E_INVAL;
+  HIPCHK(ctx, hipMemcpy(out, ctx->dev.dbg_buf, (size_t)n_words * sizeof(u64), hipMemcpyDeviceToHost));
   return RGB_OK;
 }
 

@@ -58,6 +58,32 @@ typedef uint32_t u32;
 #define PK_VOTER_SH     40  /* 8 */
 #define PK_STATUS_SH    48  /* 8 */
 
+/* Device order of a tick: clause family = (class rank of the message kind, success flag).  Every
+ * kind is its own kernel class: a wavefront of the class-dispatch kernel runs the code path
+ * specialised (compile-time kind) for its 64-message slice. */
+#define RGB_N_CLASSES 11
+static inline __host__ __device__ unsigned rgb_kind_rank(unsigned kind) {
+  switch (kind) {
+    case RGB_MSG_AER: return 0;
+    case RGB_MSG_AER_REPLY: return 1;
+    case RGB_MSG_WRITTEN: return 2;
+    case RGB_MSG_APPEND: return 3;
+    case RGB_MSG_PIPELINE_RPCS: return 4;
+    case RGB_MSG_REQUEST_VOTE: return 5;
+    case RGB_MSG_VOTE_RESULT: return 6;
+    case RGB_MSG_AWAIT_TIMEOUT: return 7;
+    case RGB_MSG_ELECTION_TIMEOUT: return 8;
+    case RGB_MSG_PRE_VOTE_RPC: return 9;
+    case RGB_MSG_PRE_VOTE_RESULT: return 10;
+    default: return 11;   /* NOP */
+  }
+}
+#define RGB_N_FAMILIES 24
+static inline __host__ __device__ unsigned rgb_family(unsigned kind, unsigned flags) {
+  return 2u * rgb_kind_rank(kind) + ((flags & RGB_MF_SUCCESS) ? 1u : 0u);
+}
+static inline unsigned rgb_class_of_kind(unsigned kind) { return rgb_kind_rank(kind); }   /* NOP has no class */
+
 static inline __host__ __device__ unsigned rgb_peer_stride(unsigned n_members) {
   return (3u * n_members + 7u) & ~7u;
 }
@@ -73,14 +99,25 @@ struct rgb_dev {
   u32 peer_stride;
   u32 max_pipeline_count;
   u32 max_aer_batch;
+  u32 dbg;   /* profiling knobs (env RGB_DEBUG, 0 in production): 1 = no state write-back, 2 = no
+                decision store, 4 = no peers prefetch, 8 = no hot-line load (zero state),
+                16 = per-wave timestamps into dbg_buf */
+  u64 *dbg_buf;
 };
 
 /* kernel launchers (rgb_kernels.hip) */
 /* d_rpcs: n * max(N-1,1) fixed slots (message i owns slots [i*(N-1), (i+1)*(N-1))), or NULL */
-/* d_n: optional device-resident message count (min(n, *d_n) messages are processed) */
-int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, const u32 *d_n, rgb_decision *d_dec,
-                    rgb_rpc *d_rpcs, u32 msg_index_base, void *stream);
-/* d_scratch: 2*2*(RGB_MSG_KIND_MAX+1) u32 of device scratch */
+/* d_n: optional device-resident message count (min(n, *d_n) messages are processed).
+ * cls: -1 = generic kernel (any kinds), 0..3 = the kernel specialised for that class's kind (every
+ * message of the slice must have it).  rpc_slot_base: fixed-slot index of the slice's message 0. */
+int rgb_launch_tick(const rgb_dev &dev, int cls, const rgb_msg *d_msgs, u32 n, const u32 *d_n,
+                    rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_slot_base, u32 msg_index_base, void *stream);
+/* family-ordered tick, ONE launch: counts[] (host) or d_family_totals (device, RGB_N_FAMILIES u32,
+ * with max_msgs bounding the grid) give the class sizes */
+int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32 counts[RGB_N_CLASSES],
+                            const u32 *d_family_totals, u32 max_msgs, rgb_decision *d_dec, rgb_rpc *d_rpcs,
+                            u32 rpc_slot_base, u32 msg_index_base, void *stream);
+/* d_scratch: 2*RGB_N_FAMILIES u32 of device scratch */
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
                      u32 *d_kind_counts, u32 *d_n, void *stream);
 int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream);

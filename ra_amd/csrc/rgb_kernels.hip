@@ -21,6 +21,9 @@
 #define SLOT_NONE4 0xFu
 
 #define RGB_TICK_BLOCK 64
+#ifndef RGB_CLASS_MIN_WAVES
+#define RGB_CLASS_MIN_WAVES(N) ((N) <= 5 ? 4 : 3)   /* the class-dispatch kernel: hot paths fit 128 VGPRs */
+#endif
 #ifndef RGB_MIN_WAVES
 #define RGB_MIN_WAVES(N) 2   /* waves per SIMD the register allocator must leave room for */
 #endif
@@ -1043,13 +1046,17 @@ __device__ __forceinline__ void make_decision(Dec &d, u32 server, unsigned role,
 
 /* One message against one server: everything between "message words in registers" and
  * "decision words in registers".  State loads/stores go straight to the server's lines. */
-template <int N>
+template <int N, int KIND>
 __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
-                                                rgb_rpc *__restrict__ rpcs, u32 msg_index_base, Dec &out) {
+                                                rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
+                                                u32 msg_index_base, Dec &out) {
   Lane L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
-  L.kind = (unsigned)((m0.x >> 32) & 0xFF);
+  /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
+   * (and its registers) remain */
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF);
+  L.kind = KIND >= 0 ? (unsigned)KIND : wire_kind;
   L.from = (unsigned)((m0.x >> 40) & 0xFF);
   L.mflags = (unsigned)((m0.x >> 48) & 0xFF);
   L.gap = (unsigned)((m0.x >> 56) & 0xFF);
@@ -1063,25 +1070,28 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     make_decision(out, L.server, 0, RGB_NONE, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
     return;
   }
-  if (L.server >= dev.n_servers) {
-    make_decision(out, L.server, 0xFF, RGB_NONE, 0, L.kind, RGB_F_UNHANDLED, 0, 0, 0, 0, 0, 0, 0);
+  if (L.server >= dev.n_servers || wire_kind != L.kind) {
+    make_decision(out, L.server, 0xFF, RGB_NONE, 0, wire_kind, RGB_F_UNHANDLED, 0, 0, 0, 0, 0, 0, 0);
     return;
   }
   /* hot line: 8 x 16 B (15 live words) */
   u64 *hot = dev.hot + (size_t)L.server * RGB_HOT_WORDS;
   const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(hot);
-  const ulonglong2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4], h5 = hp[5], h6 = hp[6];
+  ulonglong2 h0, h1, h2, h3, h4, h5, h6;
+  if (dev.dbg & 8u) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = make_ulonglong2(0, 0); h3.y = 0x1Full << PK_PRESENT_SH; }
+  else { h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; }
   L.runs = dev.runs + (size_t)L.server * dev.max_runs * 2;
   L.peers = dev.peers + (size_t)L.server * dev.peer_stride;
   L.max_runs = dev.max_runs;
   L.peers_loaded = false; L.dmi = L.dni = L.dcs = 0;
   /* leader-side kinds: fetch the peers row in the same round trip as the hot line (the address
    * only depends on the message); kinds that need it rarely load it lazily */
-  if (L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS)
+  if ((L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS) &&
+      !(dev.dbg & 4u))
     load_peers<N>(L);
   L.ct = h0.x; L.ci = h0.y; L.la = h1.x; L.li = h1.y; L.lt = h2.x; L.lwi = h2.y; L.lwt = h3.x;
   L.pk = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
-  L.token = h6.y; L.macver = hp[7].x; L.vote_reqs = false;
+  L.token = h6.y; L.macver = (dev.dbg & 8u) ? 0 : hp[7].x; L.vote_reqs = false;
   L.flags = 0; L.inv = 0; L.has_reply = false; L.reply_to = RGB_NONE;
   L.r_term = L.r_next = L.r_last = L.r_lterm = 0; L.w_first = L.w_last = 0;
   L.n_runs = (unsigned)pk_get(L.pk, PK_NRUNS_SH, 5);
@@ -1099,7 +1109,8 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (!to_follower) {
     bool reprocess = false;
     switch (role0) {
-      case RGB_ROLE_LEADER:          rc = handle_leader<N>(L, reprocess, dev, rpcs, i * (N > 1 ? N - 1 : 1),
+      case RGB_ROLE_LEADER:          rc = handle_leader<N>(L, reprocess, dev, rpcs,
+                                                           (rpc_slot_base + i) * (N > 1 ? N - 1 : 1),
                                                            msg_index_base + i, n_rpcs); break;
       case RGB_ROLE_CANDIDATE:       rc = handle_candidate<N>(L, reprocess); break;
       case RGB_ROLE_PRE_VOTE:        rc = handle_pre_vote<N>(L, reprocess); break;
@@ -1117,6 +1128,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   }
 
   /* ---- commit: run table ---- */
+  if (dev.dbg & 1u) { L.n_runs = n_runs0; L.push_cnt = 0; L.cond_dirty = false; L.dmi = L.dni = L.dcs = 0; }
   if (L.n_runs != n_runs0 || L.push_cnt) {
     u64 *runs = const_cast<u64 *>(L.runs);
     unsigned nr = L.n_runs;
@@ -1157,12 +1169,14 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
+  if (!(dev.dbg & 1u)) {
   if (L.ct != h0.x || L.ci != h0.y) ho[0] = make_ulonglong2(L.ct, L.ci);
   if (L.la != h1.x || L.li != h1.y) ho[1] = make_ulonglong2(L.la, L.li);
   if (L.lt != h2.x || L.lwi != h2.y) ho[2] = make_ulonglong2(L.lt, L.lwi);
   if (L.lwt != h3.x || L.pk != h3.y) ho[3] = make_ulonglong2(L.lwt, L.pk);
   if (L.first != h5.x || L.lrs != h5.y) ho[5] = make_ulonglong2(L.first, L.lrs);
   if (L.lrt != h6.x || L.token != h6.y) ho[6] = make_ulonglong2(L.lrt, L.token);
+  }
 
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
   if (L.has_reply || L.vote_reqs) { w2 = L.r_term; w3 = L.r_next; w4 = L.r_last; w5 = L.r_lterm; }
@@ -1177,11 +1191,12 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
  * pieces; LDS slots are padded to 80 B so the per-lane 16-byte reads/writes are conflict-free. */
 #define RGB_IO_SLOT 5   /* 16-byte units per LDS record slot: 64 B payload + 16 B pad */
 
-template <int N>
+template <int N, int KIND>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
                                                                   u32 n, const u32 *__restrict__ n_dev,
                                                                   rgb_decision *__restrict__ dec,
-                                                                  rgb_rpc *__restrict__ rpcs, u32 msg_index_base) {
+                                                                  rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
+                                                                  u32 msg_index_base) {
   __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_IO_SLOT];
   const u32 lane = threadIdx.x;
   const u32 base = blockIdx.x * RGB_TICK_BLOCK;           /* first message of this wavefront */
@@ -1204,13 +1219,14 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
   if (active) {
     const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
                      m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
-    process_message<N>(dev, m0, m1, m2, m3, base + lane, rpcs, msg_index_base, d);
+    process_message<N, KIND>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d);
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
     io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
     io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
   }
   __syncthreads();
+  if (dev.dbg & 2u) return;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -1221,6 +1237,102 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
 }
 
 
+/* The per-tick kernel for family-ordered ticks: ONE launch, each wavefront (= block) serves one
+ * 64-message slice of one kernel class and runs the code path specialised for that class's
+ * message kind (compile-time kind => the clause switches fold; every path needs <= 128 VGPRs, so
+ * four wavefronts per SIMD stay resident, against two for the kind-generic kernel).  One class per
+ * message kind, in family order.  Blocks are handed to classes heaviest-first (pipelining kinds,
+ * elections, replies, then the cheap append_entries_rpc / written bulk) so the long paths start
+ * on an idle memory system and finish under the cover of the bulk.  Class sizes come by value
+ * (host-known) or from device memory (device-side producers). */
+struct rgb_class_counts { u32 n[RGB_N_CLASSES]; };
+
+template <int N>
+__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_tick_classes_kernel(
+    rgb_dev dev, const rgb_msg *__restrict__ msgs, rgb_class_counts cc, const u32 *__restrict__ fam_dev,
+    rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base, u32 msg_index_base) {
+  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_IO_SLOT];
+  if (fam_dev != nullptr) {
+    /* per-family totals written by a device-side producer (2 families per class) */
+#pragma unroll
+    for (int c = 0; c < RGB_N_CLASSES; ++c) cc.n[c] = fam_dev[2 * c] + fam_dev[2 * c + 1];
+  }
+  /* block -> class, heaviest classes first (ranks: 3 append, 4 pipeline_rpcs, 9 pre_vote_rpc,
+   * 8 election_timeout, 10 pre_vote_result, 6 vote_result, 5 request_vote, 7 await_timeout,
+   * 1 append_entries_reply, 0 append_entries_rpc, 2 written) */
+  constexpr int order[RGB_N_CLASSES] = {3, 4, 9, 8, 10, 6, 5, 7, 1, 0, 2};
+  u32 blk = blockIdx.x;
+  int cls = -1;
+#pragma unroll
+  for (int q = 0; q < RGB_N_CLASSES; ++q) {
+    const int c = order[q];
+    const u32 nb = (cc.n[c] + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
+    if (cls < 0) {
+      if (blk < nb) cls = c;
+      else blk -= nb;
+    }
+  }
+  if (cls < 0) return;
+  u32 off = 0;                                            /* memory offset of the class: family order */
+#pragma unroll
+  for (int c = 0; c < RGB_N_CLASSES; ++c) off += c < cls ? cc.n[c] : 0u;
+  u32 ncls = 0;
+#pragma unroll
+  for (int c = 0; c < RGB_N_CLASSES; ++c) ncls = c == cls ? cc.n[c] : ncls;
+  const u32 lane = threadIdx.x;
+  u64 t0 = 0, t1 = 0, t2 = 0;
+  if (dev.dbg & 16u) t0 = wall_clock64();
+  const u32 base = off + blk * RGB_TICK_BLOCK;            /* first message of this wavefront */
+  const u32 end = off + ncls;
+  const u32 cnt = end - base < RGB_TICK_BLOCK ? end - base : RGB_TICK_BLOCK;
+  const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u32 piece = k * RGB_TICK_BLOCK + lane;
+    const u32 j = piece >> 2, part = piece & 3u;
+    if (j < cnt) io[j * RGB_IO_SLOT + part] = src[piece];
+  }
+  __syncthreads();
+  if (dev.dbg & 16u) t1 = wall_clock64();
+  const bool active = lane < cnt;
+  if (active) {
+    const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
+                     m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
+    Dec d;
+#define RGB_CASE(RANK, KIND)                                                                            \
+  case RANK:                                                                                            \
+    process_message<N, KIND>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d); \
+    break;
+    switch (cls) {
+      RGB_CASE(0, RGB_MSG_AER) RGB_CASE(1, RGB_MSG_AER_REPLY) RGB_CASE(2, RGB_MSG_WRITTEN)
+      RGB_CASE(3, RGB_MSG_APPEND) RGB_CASE(4, RGB_MSG_PIPELINE_RPCS) RGB_CASE(5, RGB_MSG_REQUEST_VOTE)
+      RGB_CASE(6, RGB_MSG_VOTE_RESULT) RGB_CASE(7, RGB_MSG_AWAIT_TIMEOUT)
+      RGB_CASE(8, RGB_MSG_ELECTION_TIMEOUT) RGB_CASE(9, RGB_MSG_PRE_VOTE_RPC)
+      default: process_message<N, RGB_MSG_PRE_VOTE_RESULT>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
+                                                           msg_index_base, d); break;
+    }
+#undef RGB_CASE
+    if (dev.dbg & 16u) t2 = wall_clock64();
+    io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
+    io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
+    io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
+    io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
+  }
+  __syncthreads();
+  if (dev.dbg & 2u) return;
+  ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u32 piece = k * RGB_TICK_BLOCK + lane;
+    const u32 j = piece >> 2, part = piece & 3u;
+    if (j < cnt) dst[piece] = io[j * RGB_IO_SLOT + part];
+  }
+  if ((dev.dbg & 16u) && lane == 0) {
+    u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 4;
+    o[0] = t0; o[1] = t1; o[2] = t2 | ((u64)cls << 60); o[3] = wall_clock64();
+  }
+}
+
 /* ------------------------------------------------------------ synthetic load ---- */
 /* Device-side load generator (include/ra_gpu_batch_synth.h).  One lane per GROUP reads the hot
  * lines of its N members (and the leader's peers row) and synthesises this tick's messages.  The
@@ -1229,7 +1341,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
  * pass 2 (<N,true>) recomputes them (same counter-based PRNG) and writes each one at
  * family_base + block reservation + rank. */
 
-#define SYN_FAMILIES (2 * (RGB_MSG_KIND_MAX + 1))
+#define SYN_FAMILIES RGB_N_FAMILIES
 
 __device__ __forceinline__ u64 sm64(u64 &x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -1407,7 +1519,7 @@ __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u6
   __syncthreads();
   const u32 G = dev.n_servers / N;
   const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-  auto family = [](const SynMsg &m) -> unsigned { return 2u * m.kind + ((m.flags & RGB_MF_SUCCESS) ? 1u : 0u); };
+  auto family = [](const SynMsg &m) -> unsigned { return rgb_family(m.kind, m.flags); };
   if (g < G) synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) { atomicAdd(&cnt[family(m)], 1u); });
   __syncthreads();
   if (!WRITE) {
@@ -1423,9 +1535,13 @@ __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u6
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     u32 total = 0;
+    const unsigned kind_of_rank[12] = {RGB_MSG_AER, RGB_MSG_AER_REPLY, RGB_MSG_WRITTEN, RGB_MSG_APPEND,
+                                       RGB_MSG_PIPELINE_RPCS, RGB_MSG_REQUEST_VOTE, RGB_MSG_VOTE_RESULT,
+                                       RGB_MSG_AWAIT_TIMEOUT, RGB_MSG_ELECTION_TIMEOUT, RGB_MSG_PRE_VOTE_RPC,
+                                       RGB_MSG_PRE_VOTE_RESULT, RGB_MSG_NOP};
     for (unsigned f = 0; f < SYN_FAMILIES; ++f) {
       total += fam_total[f];
-      if (kind_counts != nullptr && fam_total[f]) kind_counts[f >> 1] += fam_total[f];
+      if (kind_counts != nullptr && fam_total[f]) kind_counts[kind_of_rank[f >> 1]] += fam_total[f];
     }
     if (d_n != nullptr) *d_n = total;
   }
@@ -1618,15 +1734,53 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
 
 #define RGB_BLOCK 256
 
-int rgb_launch_tick(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, const u32 *d_n, rgb_decision *d_dec,
-                    rgb_rpc *d_rpcs, u32 msg_index_base, void *stream) {
+template <int KIND>
+static int launch_tick_kind(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, const u32 *d_n, rgb_decision *d_dec,
+                            rgb_rpc *d_rpcs, u32 rpc_slot_base, u32 msg_index_base, hipStream_t st) {
+  dim3 grid((n + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK), block(RGB_TICK_BLOCK);
+#define LAUNCH(NN)                                                                                   \
+  case NN:                                                                                           \
+    hipLaunchKernelGGL((rgb_tick_kernel<NN, KIND>), grid, block, 0, st, dev, d_msgs, n, d_n, d_dec,   \
+                       d_rpcs, rpc_slot_base, msg_index_base);                                       \
+    break;
+  switch (dev.n_members) {
+    LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
+    default: return -1;
+  }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_tick(const rgb_dev &dev, int cls, const rgb_msg *d_msgs, u32 n, const u32 *d_n,
+                    rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_slot_base, u32 msg_index_base, void *stream) {
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((n + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK), block(RGB_TICK_BLOCK);
-#define LAUNCH(NN)                                                                               \
-  case NN:                                                                                       \
-    hipLaunchKernelGGL(rgb_tick_kernel<NN>, grid, block, 0, st, dev, d_msgs, n, d_n, d_dec,      \
-                       d_rpcs, msg_index_base);                                                  \
+  switch (cls) {
+    case 0: return launch_tick_kind<RGB_MSG_AER>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
+    case 1: return launch_tick_kind<RGB_MSG_AER_REPLY>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
+    case 2: return launch_tick_kind<RGB_MSG_WRITTEN>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
+    case 3: return launch_tick_kind<RGB_MSG_APPEND>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
+    default: return launch_tick_kind<-1>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
+  }
+}
+
+int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32 counts[RGB_N_CLASSES],
+                            const u32 *d_family_totals, u32 max_msgs, rgb_decision *d_dec, rgb_rpc *d_rpcs,
+                            u32 rpc_slot_base, u32 msg_index_base, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  rgb_class_counts cc;
+  u32 blocks = 0;
+  for (int c = 0; c < RGB_N_CLASSES; ++c) {
+    cc.n[c] = counts ? counts[c] : 0;
+    blocks += (cc.n[c] + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
+  }
+  if (d_family_totals) blocks = (max_msgs + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK + RGB_N_CLASSES;
+  if (blocks == 0) return 0;
+  dim3 grid(blocks), block(RGB_TICK_BLOCK);
+#define LAUNCH(NN)                                                                                     \
+  case NN:                                                                                             \
+    hipLaunchKernelGGL(rgb_tick_classes_kernel<NN>, grid, block, 0, st, dev, d_msgs, cc, d_family_totals, \
+                       d_dec, d_rpcs, rpc_slot_base, msg_index_base);                                  \
     break;
   switch (dev.n_members) {
     LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)

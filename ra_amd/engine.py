@@ -23,7 +23,7 @@ EXPORTS = [
     "rgb_download_state", "rgb_submit", "rgb_collect", "rgb_run_ticks_device", "rgb_snapshot",
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize",
 ]
-SYNTH_EXPORTS = ["rgb_synth_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
+SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_apply_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
 
 
 class RgbError(RuntimeError):
@@ -84,12 +84,13 @@ def lib():
     L.rgb_download_state.argtypes = [vp, u32, u32, vp]
     L.rgb_submit.argtypes = [vp, vp, u32, C.c_uint64]
     L.rgb_collect.argtypes = [vp, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), u64p]
-    L.rgb_run_ticks_device.argtypes = [vp, vp, u32, vp, vp, u32, vp, vp, vp]
+    L.rgb_run_ticks_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp]
     L.rgb_snapshot.argtypes = [vp, vp]
     L.rgb_snapshot_device.argtypes = [vp, vp, vp]
     L.rgb_state_checksum.argtypes = [vp, u32, u32, u64p]
     L.rgb_synchronize.argtypes = [vp]
     L.rgb_synth_tick_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
+    L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     if L.rgb_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("ABI version mismatch")
     for i, dt in enumerate(abi.STRUCT_DTYPES):
@@ -205,16 +206,23 @@ class RaGpuBatch:
     # -- device-resident path ------------------------------------------------------------
     def run_ticks_device(self, d_msgs: int, tick_stride: int, n_ticks: int, d_decisions: int,
                          d_rpcs: int = 0, stream: int = 0, tick_counts: np.ndarray | None = None,
-                         d_tick_counts: int = 0):
+                         d_tick_counts: int = 0, kind_counts: np.ndarray | None = None):
         """Raw device pointers (e.g. torch tensors' data_ptr()); enqueues and returns.
         tick_counts: messages per tick (uint32, host) or None for tick_stride each;
-        d_tick_counts: device uint32 array with the real size of each tick (device producers)."""
+        d_tick_counts: device uint32 array with the real size of each tick (device producers);
+        kind_counts: uint32 [n_ticks, n_kinds] (host) for family-ordered ticks -> specialised,
+        concurrent per-kind kernels."""
         cp = None
         if tick_counts is not None:
             tc = np.ascontiguousarray(tick_counts, dtype=np.uint32)
             assert len(tc) >= n_ticks
             cp = tc.ctypes.data
-        self._check(self._L.rgb_run_ticks_device(self._h, d_msgs, tick_stride, cp, d_tick_counts or None,
+        kp = None
+        if kind_counts is not None:
+            kcs = np.ascontiguousarray(kind_counts, dtype=np.uint32)
+            assert kcs.shape == (n_ticks, abi.MSG_PRE_VOTE_RESULT + 1), kcs.shape
+            kp = kcs.ctypes.data
+        self._check(self._L.rgb_run_ticks_device(self._h, d_msgs, tick_stride, cp, d_tick_counts or None, kp,
                                                  n_ticks, d_decisions, d_rpcs or None, stream or None),
                     "rgb_run_ticks_device")
 
@@ -224,6 +232,12 @@ class RaGpuBatch:
         tick from the current device state into d_msgs (room for n_servers messages)."""
         self._check(self._L.rgb_synth_tick_device(self._h, seed, tick, d_msgs, d_kind_counts or None,
                                                   d_n or None, stream or None), "rgb_synth_tick_device")
+
+    def synth_apply_tick_device(self, d_msgs: int, max_msgs: int, d_decisions: int, d_rpcs: int = 0,
+                                stream: int = 0):
+        """Apply the tick just generated by synth_tick_device (class-dispatch kernel sized on-device)."""
+        self._check(self._L.rgb_synth_apply_tick_device(self._h, d_msgs, max_msgs, d_decisions, d_rpcs or None,
+                                                        stream or None), "rgb_synth_apply_tick_device")
 
     # -- observability -----------------------------------------------------------------
     def snapshot(self) -> np.ndarray:

@@ -414,8 +414,7 @@ def gen_tick(st: np.ndarray, n_members: int, tick: int, seed: int, mix: dict = M
     msgs = np.concatenate(out)
     # a tick holds at most one message per server, so its order is free: group by kind so that
     # wavefronts run one clause family = (kind, success flag), as rgb_submit does for host batches
-    key = msgs["kind"].astype(np.int64) * 2 + (msgs["flags"] & abi.MF_SUCCESS)
-    return msgs[np.argsort(key, kind="stable")]
+    return msgs[np.argsort(abi.family(msgs), kind="stable")]
 
 
 def pad_tick(msgs: np.ndarray, width: int) -> np.ndarray:

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""RGB_DEBUG=16: per-wave timestamps of one class-dispatch tick -> concurrency picture."""
+import os, sys, ctypes as C
+os.environ["RGB_DEBUG"] = "16"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ra_amd import abi, engine, workload as W
+G, N = 65536, 5
+S = G * N
+eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
+eng.set_state(0, W.initial_states(G, N, 0x5EED0003))
+stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); sp = stream.cuda_stream
+dm = torch.empty(S * 64, dtype=torch.uint8, device="cuda"); dd = torch.empty(S * 64, dtype=torch.uint8, device="cuda")
+dr = torch.empty(S * 4 * 56, dtype=torch.uint8, device="cuda")
+kc = torch.zeros(12, dtype=torch.int32, device="cuda"); dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+for t in range(24):
+    eng.synth_tick_device(0x5EED0003, t, dm.data_ptr(), kc.data_ptr(), dn.data_ptr(), sp)
+    torch.cuda.synchronize()
+    eng.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), sp)
+    torch.cuda.synchronize()
+nblk = S // 64 + 16
+buf = np.zeros(nblk * 4, dtype=np.uint64)
+L = engine.lib(); L.rgb_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+assert L.rgb_debug_read(eng._h, buf.ctypes.data, len(buf)) == 0
+b = buf.reshape(nblk, 4)
+b = b[b[:, 0] > 0]
+b = b[b[:, 0].astype(np.int64) > b[:, 0].astype(np.int64).max() - 20000]   # the last launch only (200 us window)
+cls = (b[:, 2] >> np.uint64(60)).astype(int)
+t0 = b[:, 0].astype(np.int64); t1 = b[:, 1].astype(np.int64); t2 = (b[:, 2] & np.uint64((1 << 60) - 1)).astype(np.int64); t3 = b[:, 3].astype(np.int64)
+z = t0.min()
+tick = 10.0  # ns per wall_clock64 tick (100 MHz)
+print("waves", len(b), "msgs", int(dn.item()), "kernel span %.1f us" % ((t3.max() - z) * tick / 1e3))
+for c in range(5):
+    m = cls == c
+    if not m.any(): continue
+    print(f"class {c}: waves {m.sum():5d} start {((t0[m]-z).min()*tick/1e3):6.1f}..{((t0[m]-z).max()*tick/1e3):6.1f} us | "
+          f"msg-load {np.median(t1[m]-t0[m])*tick/1e3:5.2f} | process {np.median(t2[m]-t1[m])*tick/1e3:5.2f} (p90 {np.percentile(t2[m]-t1[m],90)*tick/1e3:5.2f}) | "
+          f"dec-store {np.median(t3[m]-t2[m])*tick/1e3:5.2f} | wave life {np.median(t3[m]-t0[m])*tick/1e3:5.2f} us")
+# concurrency over time
+ev = np.concatenate([np.stack([t0 - z, np.ones_like(t0)], 1), np.stack([t3 - z, -np.ones_like(t3)], 1)])
+ev = ev[np.argsort(ev[:, 0], kind="stable")]
+conc = np.cumsum(ev[:, 1])
+for us in range(0, min(int((t3.max() - z) * tick / 1e3) + 1, 60), 2):
+    i = np.searchsorted(ev[:, 0], us * 1e3 / tick)
+    print(f"  t={us:3d} us  waves in flight {int(conc[min(i, len(conc)-1)]):5d}  started {int((t0 - z <= us*1e3/tick).sum()):5d}")
