@@ -101,7 +101,7 @@ struct rgb_dev {
   u32 max_aer_batch;
   u32 dbg;   /* profiling knobs (env RGB_DEBUG, 0 in production): 1 = no state write-back, 2 = no
                 decision store, 4 = no peers prefetch, 8 = no hot-line load (zero state),
-                16 = per-wave timestamps into dbg_buf */
+                16 = per-wave timestamps into dbg_buf, 32 = write-through (sc1) stores */
   u64 *dbg_buf;
 };
 

@@ -30,6 +30,20 @@
 
 namespace {
 
+/* write-through (sc1) stores: the bytes leave the XCD's L2 at once instead of sitting dirty until
+ * the kernel-end write-back (which the next dependent launch has to wait for) */
+__device__ __forceinline__ void store16_wt(void *p, ulonglong2 v) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u d;
+  d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+}
+__device__ __forceinline__ void store8_wt(u64 *p, u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define ST16(ptr, val, wt) do { if (wt) store16_wt((void *)(ptr), (val)); else *(ptr) = (val); } while (0)
+#define ST8(ptr, val, wt) do { if (wt) store8_wt((u64 *)(ptr), (val)); else *(ptr) = (val); } while (0)
+
 __device__ __forceinline__ u64 pk_get(u64 pk, int sh, int w) { return (pk >> sh) & ((1ull << w) - 1ull); }
 __device__ __forceinline__ u64 pk_set(u64 pk, int sh, int w, u64 v) {
   const u64 m = ((1ull << w) - 1ull) << sh;
@@ -1153,29 +1167,30 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     if (L.push_cnt >= 1) { runs[2 * (nr - 1)] = L.lrs; runs[2 * (nr - 1) + 1] = L.lrt; }
   }
   L.pk = pk_set(L.pk, PK_NRUNS_SH, 5, L.n_runs);
+  const bool wt = (dev.dbg & 32u) != 0;
   if (L.cond_dirty) {
     ulonglong2 *cp = reinterpret_cast<ulonglong2 *>(dev.cond + (size_t)L.server * 4);
-    cp[0] = make_ulonglong2(L.cr0, L.cr1);
-    cp[1] = make_ulonglong2(L.cr2, L.cr3);
+    ST16(cp, make_ulonglong2(L.cr0, L.cr1), wt);
+    ST16(cp + 1, make_ulonglong2(L.cr2, L.cr3), wt);
   }
   /* ---- commit: peers row (dirty words only) ---- */
   if (L.dmi | L.dni | L.dcs) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      if (L.dmi & (1u << k)) L.peers[k] = L.pmi[k];
-      if (L.dni & (1u << k)) L.peers[N + k] = L.pni[k];
-      if (L.dcs & (1u << k)) L.peers[2 * N + k] = L.pcs[k];
+      if (L.dmi & (1u << k)) ST8(L.peers + k, L.pmi[k], wt);
+      if (L.dni & (1u << k)) ST8(L.peers + N + k, L.pni[k], wt);
+      if (L.dcs & (1u << k)) ST8(L.peers + 2 * N + k, L.pcs[k], wt);
     }
   }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
   if (!(dev.dbg & 1u)) {
-  if (L.ct != h0.x || L.ci != h0.y) ho[0] = make_ulonglong2(L.ct, L.ci);
-  if (L.la != h1.x || L.li != h1.y) ho[1] = make_ulonglong2(L.la, L.li);
-  if (L.lt != h2.x || L.lwi != h2.y) ho[2] = make_ulonglong2(L.lt, L.lwi);
-  if (L.lwt != h3.x || L.pk != h3.y) ho[3] = make_ulonglong2(L.lwt, L.pk);
-  if (L.first != h5.x || L.lrs != h5.y) ho[5] = make_ulonglong2(L.first, L.lrs);
-  if (L.lrt != h6.x || L.token != h6.y) ho[6] = make_ulonglong2(L.lrt, L.token);
+  if (L.ct != h0.x || L.ci != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.ci), wt);
+  if (L.la != h1.x || L.li != h1.y) ST16(ho + 1, make_ulonglong2(L.la, L.li), wt);
+  if (L.lt != h2.x || L.lwi != h2.y) ST16(ho + 2, make_ulonglong2(L.lt, L.lwi), wt);
+  if (L.lwt != h3.x || L.pk != h3.y) ST16(ho + 3, make_ulonglong2(L.lwt, L.pk), wt);
+  if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs), wt);
+  if (L.lrt != h6.x || L.token != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.token), wt);
   }
 
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
@@ -1321,11 +1336,12 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   __syncthreads();
   if (dev.dbg & 2u) return;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
+  const bool wt = (dev.dbg & 32u) != 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) dst[piece] = io[j * RGB_IO_SLOT + part];
+    if (j < cnt) ST16(dst + piece, io[j * RGB_IO_SLOT + part], wt);
   }
   if ((dev.dbg & 16u) && lane == 0) {
     u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 4;

@@ -1,0 +1,112 @@
+"""The N>1 path on CPU: hash sharding of groups over ranks (no data-path collective) and the
+leaderboard all-gather, with torch.distributed 'gloo', world_size 2.  Each rank runs the CPU
+checker on its shard (tests may use the oracle); the gathered result must equal a single
+process that owns every group."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ra_amd import abi, shard, workload as W
+
+N = 5
+G_GLOBAL = 512
+TICKS = 4
+SEED = 0x5EED0004
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_shard(gids):
+    """States after TICKS ticks for the groups `gids` (each group seeded by its global uid)."""
+    from oracle import oracle as O
+    G = len(gids)
+    st = np.concatenate([W.initial_states(1, N, SEED ^ int(g)) for g in gids]) if G else \
+        np.zeros(0, dtype=abi.SERVER_STATE_DTYPE)
+    st["self"] = np.arange(G * N) % N
+    cpu = O.Oracle(max(G, 1), N)
+    if G:
+        cpu.set_state(0, st)
+    for t in range(TICKS):
+        if not G:
+            break
+        cur = cpu.get_state()
+        if W.heal(cur, N, max_runs=16):
+            cpu.set_state(0, cur)
+        # group-local randomness: generate per group so that the stream does not depend on the shard
+        msgs = []
+        for k, g in enumerate(gids):
+            m = W.gen_tick(cur[k * N:(k + 1) * N], N, t, SEED ^ int(g))
+            m["server"] += k * N
+            msgs.append(m)
+        cpu.step(np.concatenate(msgs))
+    return cpu.get_state() if G else st
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gids = shard.local_group_ids(G_GLOBAL, world, rank)
+    st = _run_shard(gids)
+    rows = shard.leaderboard_rows_from_states(st, N)
+    uids, allrows = shard.all_gather_leaderboard(rows, gids, dist)
+    # a scalar metric all-reduced the same way bench.py aggregates decisions
+    tot = torch.tensor([len(gids)], dtype=torch.int64)
+    dist.all_reduce(tot)
+    assert int(tot.item()) == G_GLOBAL
+    np.save(os.path.join(out_dir, f"uids_{rank}.npy"), uids)
+    np.save(os.path.join(out_dir, f"rows_{rank}.npy"), allrows.view(np.uint8))
+    dist.destroy_process_group()
+
+
+def test_owner_is_a_partition_and_roughly_balanced():
+    ids = np.arange(200000, dtype=np.uint64)
+    for world in (2, 4, 8):
+        own = shard.owner(ids, world)
+        assert own.min() == 0 and own.max() == world - 1
+        counts = np.bincount(own, minlength=world)
+        assert counts.sum() == len(ids)
+        assert counts.max() / counts.min() < 1.05
+        parts = [shard.local_group_ids(len(ids), world, r) for r in range(world)]
+        assert sum(len(p) for p in parts) == len(ids)
+        assert len(np.unique(np.concatenate(parts))) == len(ids)
+    # weak-scaling helper: exactly per_rank groups, all owned by the rank
+    g = shard.local_group_ids(0, 8, 3, per_rank=1000)
+    assert len(g) == 1000 and np.all(shard.owner(g, 8) == 3)
+
+
+def test_route_splits_a_batch_by_owner():
+    rng = np.random.default_rng(0)
+    guid = rng.integers(0, 10000, size=5000).astype(np.uint64)
+    msgs = np.zeros(len(guid), dtype=abi.MSG_DTYPE)
+    parts = shard.route(msgs, guid, 4, N)
+    assert sum(len(p) for p in parts) == len(guid)
+    for s, p in enumerate(parts):
+        assert np.all(shard.owner(guid[p], 4) == s)
+        assert np.all(np.diff(p) > 0)          # order inside a shard is submission order
+
+
+def test_two_rank_gloo_leaderboard_equals_single_process(tmp_path, oracle_lib):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    # single-process reference over every group
+    all_g = np.arange(G_GLOBAL, dtype=np.uint64)
+    ref_rows = shard.leaderboard_rows_from_states(_run_shard(all_g), N)
+    for r in range(world):
+        uids = np.load(tmp_path / f"uids_{r}.npy")
+        rows = np.load(tmp_path / f"rows_{r}.npy").view(abi.LEADERBOARD_DTYPE)
+        assert np.array_equal(uids, all_g)
+        assert rows.tobytes() == ref_rows.tobytes(), f"rank {r}: gathered leaderboard differs"
+    assert (ref_rows["n_leaders"] == 1).mean() > 0.8
