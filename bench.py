@@ -72,7 +72,7 @@ def main():
     S = G * N
     K, Wm = args.steps, args.warmup
     T = Wm + K
-    NK = abi.MSG_PRE_VOTE_RESULT + 1
+    NK = abi.N_KINDS
     # this rank's shard of the global group-id space (hash partition)
     my_groups = shard.local_group_ids(G * world, world, rank, per_rank=G)
     seed = (args.seed ^ (rank * 0x9E3779B97F4A7C15)) & ((1 << 64) - 1)
@@ -237,7 +237,8 @@ def main():
         launch_bytes = float(alg_bytes[Wm:].mean())
         achieved = launch_bytes / per_launch_s / 1e9
         names = ["nop", "aer", "aer_reply", "request_vote", "vote_result", "written", "pipeline_rpcs",
-                 "append", "await_timeout", "election_timeout", "pre_vote_rpc", "pre_vote_result"]
+                 "append", "await_timeout", "election_timeout", "pre_vote_rpc", "pre_vote_result",
+                 "snapshot_written"]
         tk = kc[Wm:].sum(axis=0)
         mix = {names[i]: round(float(tk[i]) / float(tk[1:].sum()), 4) for i in range(1, NK) if tk[i]}
         out = {

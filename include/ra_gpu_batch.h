@@ -69,9 +69,11 @@ enum {
   RGB_MSG_AWAIT_TIMEOUT = 8,  /* await_condition_timeout     src/ra_server.erl:1932-1945           */
   RGB_MSG_ELECTION_TIMEOUT = 9,  /* election_timeout -> call_for_election/2 src/ra_server.erl:2877-2924 */
   RGB_MSG_PRE_VOTE_RPC     = 10, /* #pre_vote_rpc{}          src/ra.hrl:157-166                    */
-  RGB_MSG_PRE_VOTE_RESULT  = 11  /* #pre_vote_result{}       src/ra.hrl:168-171                    */
+  RGB_MSG_PRE_VOTE_RESULT  = 11, /* #pre_vote_result{}       src/ra.hrl:168-171                    */
+  RGB_MSG_SNAPSHOT_WRITTEN = 12  /* {ra_log_event,{snapshot_written,{Idx,Term},_,snapshot,_,_}}
+                                    src/ra_log.erl:1054-1150: the log prefix up to Idx is released */
 };
-#define RGB_MSG_KIND_MAX RGB_MSG_PRE_VOTE_RESULT
+#define RGB_MSG_KIND_MAX RGB_MSG_SNAPSHOT_WRITTEN
 #define RGB_PROTO_VERSION 1u    /* ?RA_PROTO_VERSION src/ra.hrl:107 */
 
 /* rgb_msg.flags */
@@ -92,6 +94,7 @@ enum {
  *   PRE_VOTE_RPC  term, from=candidate_id, a=last_log_index, b=last_log_term, c=token,
  *                 n_entries=candidate machine_version, gap=protocol version
  *   PRE_VOTE_RESULT term, from=voter, flags&SUCCESS=vote_granted, c=token
+ *   SNAPSHOT_WRITTEN a=snapshot index, b=snapshot term (kind `snapshot`, not `checkpoint`)
  */
 typedef struct rgb_msg {
   uint32_t server;      /* target server id = group * n_members + member slot */

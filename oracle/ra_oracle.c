@@ -235,6 +235,23 @@ static int log_written(olog *l, uint64_t term, uint64_t from, uint64_t to) {
   }
 }
 
+/* ra_log:handle_event({snapshot_written, {SnapIdx, SnapTerm}, _, snapshot, _, _}),
+ * src/ra_log.erl:1054-1150: only when the range is defined and SnapIdx >= its first index;
+ * last_written follows the snapshot when it is not above it; the range is truncated
+ * (ra_range:truncate/2, src/ra_range.erl:93-106).  Returns 1 if last_written changed. */
+static int log_snapshot_written(olog *l, uint64_t snap_idx, uint64_t snap_term) {
+  if (!(l->has_range && snap_idx >= l->first)) return 0;   /* stale: second clause, no change */
+  int changed = 0;
+  if (!(l->lw_idx > snap_idx)) {
+    changed = !(l->lw_idx == snap_idx && l->lw_term == snap_term);
+    l->lw_idx = snap_idx; l->lw_term = snap_term;
+  }
+  if (snap_idx >= l->last) l->has_range = 0;               /* truncate: nothing left */
+  else l->first = snap_idx + 1;
+  l->snap_idx = snap_idx; l->snap_term = snap_term;
+  return changed;
+}
+
 /* --------------------------------------------------------------- server helpers -- */
 typedef struct {
   uint32_t flags;
@@ -688,8 +705,17 @@ static int follower_written(oserver *sv, const rgb_msg *m, ofx *fx) {
   return 0;
 }
 
+/* handle_follower({ra_log_event, Evt}) for a snapshot_written event: same clause as written */
+static int follower_snapshot_written(oserver *sv, const rgb_msg *m, ofx *fx) {
+  int changed = log_snapshot_written(&sv->log, m->a, m->b);
+  if (changed && sv->s.leader_id != RGB_NONE)
+    aer_reply(sv, sv->s.current_term, 1, sv->s.leader_id, fx);
+  return 0;
+}
+
 static int handle_follower(oserver *sv, const rgb_msg *m, ofx *fx) {
   switch (m->kind) {
+    case RGB_MSG_SNAPSHOT_WRITTEN: return follower_snapshot_written(sv, m, fx);
     case RGB_MSG_AER:          return follower_aer(sv, m, fx);
     case RGB_MSG_REQUEST_VOTE: return follower_request_vote(sv, m, fx);
     case RGB_MSG_WRITTEN:      return follower_written(sv, m, fx);
@@ -831,6 +857,9 @@ static int handle_leader(struct ora_ctx *c, oserver *sv, uint32_t srv_id, const 
     case RGB_MSG_VOTE_RESULT:                              /* :967-969 */
     case RGB_MSG_PRE_VOTE_RESULT:                          /* :970-972 */
       return 0;
+    case RGB_MSG_SNAPSHOT_WRITTEN:                         /* :745-747 other ra_log_events */
+      log_snapshot_written(l, m->a, m->b);
+      return 0;
     default:
       fx->flags |= RGB_F_UNHANDLED;
       return 0;
@@ -895,6 +924,9 @@ static int handle_candidate(oserver *sv, const rgb_msg *m, ofx *fx, int *reproce
       }
       return process_pre_vote(sv, m, fx);                   /* :1127-1131 */
     case RGB_MSG_PRE_VOTE_RESULT: return 0;                 /* :1135-1137 */
+    case RGB_MSG_SNAPSHOT_WRITTEN:
+      log_snapshot_written(&sv->log, m->a, m->b);           /* :1157-1160 */
+      return 0;
     case RGB_MSG_ELECTION_TIMEOUT:
       call_for_election_candidate(sv, fx);                  /* :1161-1162 */
       return 0;
@@ -950,6 +982,9 @@ static int handle_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx, int *reproces
       }
       return 0;                                             /* :1247-1249 */
     }
+    case RGB_MSG_SNAPSHOT_WRITTEN:
+      log_snapshot_written(&sv->log, m->a, m->b);           /* :1257-1260 */
+      return 0;
     case RGB_MSG_PRE_VOTE_RPC:
       return process_pre_vote(sv, m, fx);                   /* :1250-1251 */
     case RGB_MSG_ELECTION_TIMEOUT:
@@ -982,6 +1017,9 @@ static int handle_await_condition(oserver *sv, const rgb_msg *m, ofx *fx, int *r
     }
     case RGB_MSG_WRITTEN:
       log_written(&sv->log, m->term, m->a, m->b);           /* :1946-1949, no reply */
+      return 0;
+    case RGB_MSG_SNAPSHOT_WRITTEN:
+      log_snapshot_written(&sv->log, m->a, m->b);           /* :1946-1949 */
       return 0;
     case RGB_MSG_PRE_VOTE_RPC:
       return process_pre_vote(sv, m, fx);                   /* :1920-1921 */

@@ -24,11 +24,12 @@ COND_NONE, COND_MISSING, COND_TERM_MISMATCH = range(3)
 
 (MSG_NOP, MSG_AER, MSG_AER_REPLY, MSG_REQUEST_VOTE, MSG_VOTE_RESULT, MSG_WRITTEN,
  MSG_PIPELINE_RPCS, MSG_APPEND, MSG_AWAIT_TIMEOUT, MSG_ELECTION_TIMEOUT, MSG_PRE_VOTE_RPC,
- MSG_PRE_VOTE_RESULT) = range(12)
+ MSG_PRE_VOTE_RESULT, MSG_SNAPSHOT_WRITTEN) = range(13)
+N_KINDS = 13
 PROTO_VERSION = 1
 # device order of a tick: clause family = (class rank of the kind, success flag); the four hot
 # kinds first (each has a specialised kernel), the rest after (ra_amd/csrc/rgb_internal.h)
-KIND_RANK = np.array([11, 0, 1, 5, 6, 2, 4, 3, 7, 8, 9, 10], dtype=np.int64)
+KIND_RANK = np.array([12, 0, 1, 5, 6, 2, 4, 3, 7, 8, 9, 10, 11], dtype=np.int64)
 MF_SUCCESS = 0x01
 MF_FORCE = 0x02
 

@@ -61,7 +61,7 @@ typedef uint32_t u32;
 /* Device order of a tick: clause family = (class rank of the message kind, success flag).  Every
  * kind is its own kernel class: a wavefront of the class-dispatch kernel runs the code path
  * specialised (compile-time kind) for its 64-message slice. */
-#define RGB_N_CLASSES 11
+#define RGB_N_CLASSES 12
 static inline __host__ __device__ unsigned rgb_kind_rank(unsigned kind) {
   switch (kind) {
     case RGB_MSG_AER: return 0;
@@ -75,10 +75,11 @@ static inline __host__ __device__ unsigned rgb_kind_rank(unsigned kind) {
     case RGB_MSG_ELECTION_TIMEOUT: return 8;
     case RGB_MSG_PRE_VOTE_RPC: return 9;
     case RGB_MSG_PRE_VOTE_RESULT: return 10;
-    default: return 11;   /* NOP */
+    case RGB_MSG_SNAPSHOT_WRITTEN: return 11;
+    default: return 12;   /* NOP */
   }
 }
-#define RGB_N_FAMILIES 24
+#define RGB_N_FAMILIES 26
 static inline __host__ __device__ unsigned rgb_family(unsigned kind, unsigned flags) {
   return 2u * rgb_kind_rank(kind) + ((flags & RGB_MF_SUCCESS) ? 1u : 0u);
 }

@@ -373,6 +373,38 @@ __device__ __forceinline__ bool log_written(Lane &L, u64 term, u64 from, u64 to)
   return false;
 }
 
+/* ra_log:handle_event({snapshot_written,{Idx,Term},_,snapshot,_,_}) (src/ra_log.erl:1054-1150):
+ * only when the range is defined and Idx >= its first index; last_written follows the snapshot
+ * when it is not above it; the range is truncated behind the snapshot (ra_range:truncate/2).
+ * The run table loses its leading runs right here (no other log edit can share the message). */
+__device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term) {
+  if (!(range_nonempty(L) && idx >= L.first)) return false;
+  bool changed = false;
+  if (!(L.lwi > idx)) {
+    changed = !(L.lwi == idx && L.lwt == term);
+    L.lwi = idx; L.lwt = term;
+  }
+  if (idx >= L.li) {
+    L.li = idx; L.lt = term; L.first = idx + 1; L.n_runs = 0;       /* range undefined */
+  } else {
+    const u64 nf = idx + 1;
+    const int k = find_run(L, nf);
+    u64 *runs = const_cast<u64 *>(L.runs);
+    if (k > 0) {
+      for (unsigned j = (unsigned)k; j < L.n_runs; ++j) {
+        runs[2 * (j - k)] = runs[2 * j];
+        runs[2 * (j - k) + 1] = runs[2 * j + 1];
+      }
+      L.n_runs -= (unsigned)k;
+    }
+    if (L.n_runs > 0) runs[0] = nf;
+    if (L.lrs < nf) L.lrs = nf;
+    L.first = nf;
+  }
+  L.si = idx; L.st = term;
+  return changed;
+}
+
 /* ---- quorum ---- */
 
 /* agreed_commit/1 (src/ra_server.erl:3684-3688) over up to 8 values held in registers:
@@ -745,6 +777,12 @@ __device__ __forceinline__ int handle_follower(Lane &L) {
       if (changed && l4 != SLOT_NONE4) aer_reply(L, L.ct, true, slot4to8(l4));
       return 0;
     }
+    case RGB_MSG_SNAPSHOT_WRITTEN: {
+      bool changed = log_snapshot_written(L, L.a, L.b);
+      unsigned l4 = (unsigned)pk_get(L.pk, PK_LEADER_SH, 4);
+      if (changed && l4 != SLOT_NONE4) aer_reply(L, L.ct, true, slot4to8(l4));
+      return 0;
+    }
     case RGB_MSG_AER_REPLY:    update_term(L, L.term); return 0;     /* :1530-1533 */
     case RGB_MSG_VOTE_RESULT:  return 0;                             /* :1609-1611 */
     case RGB_MSG_PRE_VOTE_RESULT: return 0;                          /* :1612-1614 */
@@ -890,6 +928,9 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
     case RGB_MSG_VOTE_RESULT:                                        /* :967-969 */
     case RGB_MSG_PRE_VOTE_RESULT:                                    /* :970-972 */
       return 0;
+    case RGB_MSG_SNAPSHOT_WRITTEN:                                   /* :745-747 */
+      log_snapshot_written(L, L.a, L.b);
+      return 0;
     default: L.flags |= RGB_F_UNHANDLED; return 0;
   }
 }
@@ -948,6 +989,9 @@ __device__ __forceinline__ int handle_candidate(Lane &L, bool &reprocess) {
       }
       return process_pre_vote(L);                                    /* :1127-1131 */
     case RGB_MSG_PRE_VOTE_RESULT: return 0;                          /* :1135-1137 */
+    case RGB_MSG_SNAPSHOT_WRITTEN:
+      log_snapshot_written(L, L.a, L.b);                             /* :1157-1160 */
+      return 0;
     case RGB_MSG_ELECTION_TIMEOUT:
       call_for_election_candidate<N>(L);                             /* :1161-1162 */
       return 0;
@@ -998,6 +1042,9 @@ __device__ __forceinline__ int handle_pre_vote(Lane &L, bool &reprocess) {
       }
       return 0;
     }
+    case RGB_MSG_SNAPSHOT_WRITTEN:
+      log_snapshot_written(L, L.a, L.b);                             /* :1257-1260 */
+      return 0;
     case RGB_MSG_PRE_VOTE_RPC: return process_pre_vote(L);           /* :1250-1251 */
     case RGB_MSG_ELECTION_TIMEOUT:
       call_for_election_pre_vote<N>(L, L.c);                         /* :1255-1256 */
@@ -1025,6 +1072,9 @@ __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, 
     }
     case RGB_MSG_WRITTEN:
       log_written(L, L.term, L.a, L.b);                              /* :1946-1949 */
+      return 0;
+    case RGB_MSG_SNAPSHOT_WRITTEN:
+      log_snapshot_written(L, L.a, L.b);                             /* :1946-1949 */
       return 0;
     case RGB_MSG_PRE_VOTE_RPC: return process_pre_vote(L);           /* :1920-1921 */
     case RGB_MSG_ELECTION_TIMEOUT:
@@ -1189,6 +1239,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (L.la != h1.x || L.li != h1.y) ST16(ho + 1, make_ulonglong2(L.la, L.li), wt);
   if (L.lt != h2.x || L.lwi != h2.y) ST16(ho + 2, make_ulonglong2(L.lt, L.lwi), wt);
   if (L.lwt != h3.x || L.pk != h3.y) ST16(ho + 3, make_ulonglong2(L.lwt, L.pk), wt);
+  if (L.si != h4.x || L.st != h4.y) ST16(ho + 4, make_ulonglong2(L.si, L.st), wt);
   if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs), wt);
   if (L.lrt != h6.x || L.token != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.token), wt);
   }
@@ -1274,8 +1325,8 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   }
   /* block -> class, heaviest classes first (ranks: 3 append, 4 pipeline_rpcs, 9 pre_vote_rpc,
    * 8 election_timeout, 10 pre_vote_result, 6 vote_result, 5 request_vote, 7 await_timeout,
-   * 1 append_entries_reply, 0 append_entries_rpc, 2 written) */
-  constexpr int order[RGB_N_CLASSES] = {3, 4, 9, 8, 10, 6, 5, 7, 1, 0, 2};
+   * 11 snapshot_written, 1 append_entries_reply, 0 append_entries_rpc, 2 written) */
+  constexpr int order[RGB_N_CLASSES] = {3, 4, 9, 8, 10, 6, 5, 7, 11, 1, 0, 2};
   u32 blk = blockIdx.x;
   int cls = -1;
 #pragma unroll
@@ -1323,8 +1374,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(3, RGB_MSG_APPEND) RGB_CASE(4, RGB_MSG_PIPELINE_RPCS) RGB_CASE(5, RGB_MSG_REQUEST_VOTE)
       RGB_CASE(6, RGB_MSG_VOTE_RESULT) RGB_CASE(7, RGB_MSG_AWAIT_TIMEOUT)
       RGB_CASE(8, RGB_MSG_ELECTION_TIMEOUT) RGB_CASE(9, RGB_MSG_PRE_VOTE_RPC)
-      default: process_message<N, RGB_MSG_PRE_VOTE_RESULT>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                           msg_index_base, d); break;
+      RGB_CASE(10, RGB_MSG_PRE_VOTE_RESULT)
+      default: process_message<N, RGB_MSG_SNAPSHOT_WRITTEN>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
+                                                            msg_index_base, d); break;
     }
 #undef RGB_CASE
     if (dev.dbg & 16u) t2 = wall_clock64();
@@ -1459,6 +1511,22 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
                  mb[churn].lt, 0));
     used[churn] = true;
   }
+  /* ---- log compaction: a member whose log spans many terms gets the snapshot_written event of a
+   * snapshot taken at its last_applied index (release_cursor), which releases the old term runs ---- */
+#pragma unroll
+  for (int m = 0; m < N; ++m) {
+    if (used[m]) continue;
+    const SynMember &x = mb[m];
+    const unsigned nr = (unsigned)pk_get(x.pk, PK_NRUNS_SH, 5);
+    if (nr < 4 || !(x.first <= x.li) || x.la < x.first || x.la > x.li) continue;
+    Lane T;
+    T.first = x.first; T.li = x.li; T.lrs = x.lrs; T.lrt = x.lrt; T.push_cnt = 0; T.n_runs = nr;
+    T.runs = dev.runs + (size_t)sid(m) * dev.max_runs * 2;
+    const u64 t = fetch_term(T, x.la);
+    if (t == UNDEF) continue;
+    emit(syn_msg(sid(m), RGB_MSG_SNAPSHOT_WRITTEN, RGB_NONE, 0, 0, x.la, t, 0));
+    used[m] = true;
+  }
   /* ---- leader-side message ---- */
   if (!used[l]) {
     const u64 r = sm64(rs), r2 = sm64(rs);
@@ -1479,7 +1547,11 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
       T.n_runs = (unsigned)pk_get(ld.pk, PK_NRUNS_SH, 5);
       T.runs = dev.runs + (size_t)sid(l) * dev.max_runs * 2;
       if (v < 75) {
-        u64 last = mi + r2 % 5; if (last > ld.li) last = ld.li;
+        /* what follower j has durably written (its first reply after an election jumps the
+         * leader's match_index from 0 to there), else a small step past the known match */
+        u64 last = mi + r2 % 5;
+        if (mb[j].lwi > last) last = mb[j].lwi;
+        if (last > ld.li) last = ld.li;
         u64 nxt = last + 1 + (r2 >> 8) % 3; if (nxt > ld.li + 1) nxt = ld.li + 1;
         u64 t = fetch_term(T, last); if (t == UNDEF) t = 0;
         emit(syn_msg(sid(l), RGB_MSG_AER_REPLY, j, RGB_MF_SUCCESS, ld.ct, nxt, last, t));
@@ -1551,10 +1623,10 @@ __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u6
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     u32 total = 0;
-    const unsigned kind_of_rank[12] = {RGB_MSG_AER, RGB_MSG_AER_REPLY, RGB_MSG_WRITTEN, RGB_MSG_APPEND,
+    const unsigned kind_of_rank[13] = {RGB_MSG_AER, RGB_MSG_AER_REPLY, RGB_MSG_WRITTEN, RGB_MSG_APPEND,
                                        RGB_MSG_PIPELINE_RPCS, RGB_MSG_REQUEST_VOTE, RGB_MSG_VOTE_RESULT,
                                        RGB_MSG_AWAIT_TIMEOUT, RGB_MSG_ELECTION_TIMEOUT, RGB_MSG_PRE_VOTE_RPC,
-                                       RGB_MSG_PRE_VOTE_RESULT, RGB_MSG_NOP};
+                                       RGB_MSG_PRE_VOTE_RESULT, RGB_MSG_SNAPSHOT_WRITTEN, RGB_MSG_NOP};
     for (unsigned f = 0; f < SYN_FAMILIES; ++f) {
       total += fam_total[f];
       if (kind_counts != nullptr && fam_total[f]) kind_counts[kind_of_rank[f >> 1]] += fam_total[f];

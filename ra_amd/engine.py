@@ -220,7 +220,7 @@ class RaGpuBatch:
         kp = None
         if kind_counts is not None:
             kcs = np.ascontiguousarray(kind_counts, dtype=np.uint32)
-            assert kcs.shape == (n_ticks, abi.MSG_PRE_VOTE_RESULT + 1), kcs.shape
+            assert kcs.shape == (n_ticks, abi.N_KINDS), kcs.shape
             kp = kcs.ctypes.data
         self._check(self._L.rgb_run_ticks_device(self._h, d_msgs, tick_stride, cp, d_tick_counts or None, kp,
                                                  n_ticks, d_decisions, d_rpcs or None, stream or None),

@@ -434,7 +434,7 @@ def algorithmic_bytes(msgs: np.ndarray, n_members: int) -> int:
                              abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT]).sum())
     # housekeeping kinds are priced like the class they resemble: written/await_timeout touch the
     # follower cursor like a vote (112 B); append/pipeline_rpcs walk the peer arrays like a reply
-    n_small = int(np.isin(k, [abi.MSG_WRITTEN, abi.MSG_AWAIT_TIMEOUT]).sum())
+    n_small = int(np.isin(k, [abi.MSG_WRITTEN, abi.MSG_AWAIT_TIMEOUT, abi.MSG_SNAPSHOT_WRITTEN]).sum())
     n_peer = int(np.isin(k, [abi.MSG_APPEND, abi.MSG_PIPELINE_RPCS]).sum())
     return 256 * n_aer + (168 + 16 * n_members) * (n_rep + n_peer) + 112 * (n_vote + n_small)
 
@@ -448,6 +448,7 @@ def algorithmic_bytes_from_counts(kind_counts: np.ndarray, n_members: int) -> np
     for k in (abi.MSG_AER_REPLY, abi.MSG_APPEND, abi.MSG_PIPELINE_RPCS):
         price[k] = rep
     for k in (abi.MSG_REQUEST_VOTE, abi.MSG_VOTE_RESULT, abi.MSG_WRITTEN, abi.MSG_AWAIT_TIMEOUT,
-              abi.MSG_ELECTION_TIMEOUT, abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT):
+              abi.MSG_ELECTION_TIMEOUT, abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT,
+              abi.MSG_SNAPSHOT_WRITTEN):
         price[k] = 112
     return (kc * price).sum(axis=-1)

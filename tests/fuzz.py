@@ -118,17 +118,18 @@ def random_msgs(rng: np.random.Generator, st: np.ndarray, n_members: int, frac: 
         role = int(row["role"])
         kinds = [abi.MSG_AER, abi.MSG_AER_REPLY, abi.MSG_REQUEST_VOTE, abi.MSG_VOTE_RESULT,
                  abi.MSG_WRITTEN, abi.MSG_PIPELINE_RPCS, abi.MSG_APPEND, abi.MSG_AWAIT_TIMEOUT,
-                 abi.MSG_NOP, abi.MSG_ELECTION_TIMEOUT, abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT]
+                 abi.MSG_NOP, abi.MSG_ELECTION_TIMEOUT, abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT,
+                 abi.MSG_SNAPSHOT_WRITTEN]
         if role == abi.ROLE_LEADER:
-            p = [0.1, 0.41, 0.08, 0.02, 0.1, 0.1, 0.12, 0.01, 0.02, 0.01, 0.02, 0.01]
+            p = [0.1, 0.38, 0.08, 0.02, 0.1, 0.1, 0.12, 0.01, 0.02, 0.01, 0.02, 0.01, 0.03]
         elif role == abi.ROLE_CANDIDATE:
-            p = [0.18, 0.08, 0.13, 0.36, 0.1, 0.01, 0.01, 0.01, 0.02, 0.04, 0.04, 0.02]
+            p = [0.18, 0.08, 0.13, 0.33, 0.1, 0.01, 0.01, 0.01, 0.02, 0.04, 0.04, 0.02, 0.03]
         elif role == abi.ROLE_AWAIT_CONDITION:
-            p = [0.5, 0.05, 0.1, 0.02, 0.1, 0.01, 0.01, 0.12, 0.02, 0.03, 0.03, 0.01]
+            p = [0.47, 0.05, 0.1, 0.02, 0.1, 0.01, 0.01, 0.12, 0.02, 0.03, 0.03, 0.01, 0.03]
         elif role == abi.ROLE_PRE_VOTE:
-            p = [0.25, 0.04, 0.1, 0.02, 0.1, 0.01, 0.01, 0.01, 0.02, 0.06, 0.08, 0.3]
+            p = [0.25, 0.04, 0.1, 0.02, 0.1, 0.01, 0.01, 0.01, 0.02, 0.06, 0.08, 0.27, 0.03]
         else:
-            p = [0.46, 0.06, 0.18, 0.03, 0.13, 0.01, 0.02, 0.01, 0.02, 0.04, 0.03, 0.01]
+            p = [0.42, 0.06, 0.18, 0.03, 0.13, 0.01, 0.02, 0.01, 0.02, 0.04, 0.03, 0.01, 0.04]
         kind = int(rng.choice(kinds, p=p))
         m["kind"][q] = kind
         term = ct + int(rng.choice([-1, 0, 0, 0, 0, 1, 2], p=[0.1, 0.2, 0.2, 0.2, 0.1, 0.15, 0.05]))
@@ -191,6 +192,16 @@ def random_msgs(rng: np.random.Generator, st: np.ndarray, n_members: int, frac: 
             if tw is None or rng.random() < 0.3:
                 tw = max(0, lt + int(rng.integers(-2, 1)))
             m["term"][q] = tw
+        elif kind == abi.MSG_SNAPSHOT_WRITTEN:
+            # around last_applied / the range start / past the end of the log
+            si = max(0, int(row["last_applied"]) + int(rng.integers(-3, 3)))
+            if rng.random() < 0.15:
+                si = li + int(rng.integers(0, 3))
+            if rng.random() < 0.1:
+                si = max(0, first - int(rng.integers(0, 3)))
+            m["a"][q] = si
+            tt = _term_at(row, si)
+            m["b"][q] = tt if tt is not None else max(0, lt - int(rng.integers(0, 2)))
         elif kind == abi.MSG_ELECTION_TIMEOUT:
             m["c"][q] = int(rng.integers(0, 3))
         elif kind == abi.MSG_PRE_VOTE_RPC:

@@ -23,7 +23,8 @@ Vector format
   steps      list of {as: ra_state the reference test calls handle_<as>/2 in,
                       msg: message, expect: asserted facts}
   msg kinds  aer / aer_reply / request_vote / vote_result / written / pipeline_rpcs /
-             append / await_timeout
+             append / await_timeout / election_timeout / pre_vote_rpc / pre_vote_result /
+             snapshot_written
   expect     role; state{field: value}; peers{name:{next_index,match_index}};
              reply{...} (only the asserted fields) or no_reply; flags_set / flags_clear
              (names of RGB_F_*); rpcs (exact set when rpcs_exact) each {peer, prev:[i,t],
@@ -562,6 +563,15 @@ vec("R4", "test/ra_log_2_SUITE.erl:295-327 (driven through follower AERs)", 3, "
     step("follower", written(1, 1, 2), role="follower", state=dict(last_written=[1, 1])),
     step("follower", written(3, 2, 3), role="follower", state=dict(last_written=[3, 3])),
 ], log_model="real")
+
+vec("R5", "test/ra_log_2_SUITE.erl:157-186 snapshot_before_written (driven as follower log events)",
+    3, "n2", "empty", [
+        step("follower", dict(kind="snapshot_written", index=10, term=1), role="follower",
+             state=dict(last_written=[10, 1], snapshot=[10, 1], first_index=11, last_index=19)),
+        step("follower", written(1, 6, 19), role="follower", state=dict(last_written=[19, 1])),
+    ], tweak=dict(current_term=1, leader_id="n1", log=[[0, 0]] + [[i, 1] for i in range(1, 20)],
+                  last_written=[5, 1], commit_index=10, last_applied=10),
+    log_model="real", note="snapshot_written overtakes the written events of lower entries")
 
 AGREED_COMMIT = [([4], 4), ([4, 3], 3), ([4, 4, 4], 4), ([4, 4, 3], 4), ([3, 4, 4], 4),
                  ([4, 2, 3], 3)]

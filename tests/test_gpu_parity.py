@@ -221,12 +221,12 @@ def test_device_generated_stream_matches_oracle(engine_mod, oracle_lib, n_member
         dm = torch.zeros(ticks * S * 64, dtype=torch.uint8, device="cuda")
         dd = torch.zeros(ticks * S * 64, dtype=torch.uint8, device="cuda")
         dr = torch.zeros(S * max(N - 1, 1) * 56, dtype=torch.uint8, device="cuda")
-        kc = torch.zeros(ticks * 12, dtype=torch.int32, device="cuda")
+        kc = torch.zeros(ticks * abi.N_KINDS, dtype=torch.int32, device="cuda")
         dn = torch.zeros(ticks, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         with torch.cuda.stream(stream):
             for t in range(ticks):
-                gpu.synth_tick_device(0x5EED0003, t, dm.data_ptr() + t * S * 64, kc.data_ptr() + t * 48,
+                gpu.synth_tick_device(0x5EED0003, t, dm.data_ptr() + t * S * 64, kc.data_ptr() + t * 4 * abi.N_KINDS,
                                       dn.data_ptr() + t * 4, stream.cuda_stream)
                 if t % 2 == 0:      # both ways of applying a device-generated tick
                     gpu.synth_apply_tick_device(dm.data_ptr() + t * S * 64, S, dd.data_ptr() + t * S * 64,
@@ -237,7 +237,7 @@ def test_device_generated_stream_matches_oracle(engine_mod, oracle_lib, n_member
         torch.cuda.synchronize()
         msgs = dm.cpu().numpy().view(abi.MSG_DTYPE).reshape(ticks, S)
         decs = dd.cpu().numpy().view(abi.DECISION_DTYPE).reshape(ticks, S)
-        counts = kc.cpu().numpy().reshape(ticks, 12)
+        counts = kc.cpu().numpy().reshape(ticks, abi.N_KINDS)
         ns = dn.cpu().numpy()
         flags_seen = 0
         for t in range(ticks):
@@ -245,7 +245,7 @@ def test_device_generated_stream_matches_oracle(engine_mod, oracle_lib, n_member
             m = msgs[t, :nt]
             assert nt > G and not np.any(m["kind"] == abi.MSG_NOP)
             assert len(np.unique(m["server"])) == nt, "two messages for one server in a tick"
-            assert np.array_equal(np.bincount(m["kind"], minlength=12), counts[t])
+            assert np.array_equal(np.bincount(m["kind"], minlength=abi.N_KINDS), counts[t])
             assert np.all(np.diff(abi.family(m)) >= 0), "tick is not ordered by clause family"
             want, _ = cpu.step(m)
             got = decs[t, :nt]

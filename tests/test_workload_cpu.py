@@ -35,7 +35,7 @@ def test_workload_is_consistent_and_healthy(oracle_lib, name, G, N, kw, mix, bm)
         assert not np.any(d["flags"] & abi.F_INVARIANT)
         seen |= int(np.bitwise_or.reduce(d["flags"]))
         assert W.algorithmic_bytes(m, N) == int(W.algorithmic_bytes_from_counts(
-            np.bincount(m["kind"], minlength=12), N))
+            np.bincount(m["kind"], minlength=abi.N_KINDS), N))
     assert seen & abi.F_REPLY and seen & abi.F_APPLIED
     if bm:
         assert (cpu.get_state()["role"] == abi.ROLE_AWAIT_CONDITION).sum() > 0   # the repair path ran

@@ -141,6 +141,9 @@ def make_msg(v, m) -> np.ndarray:
         out["flags"] = abi.MF_FORCE if m.get("force") else 0
     elif k == "await_timeout":
         out["kind"] = abi.MSG_AWAIT_TIMEOUT
+    elif k == "snapshot_written":
+        out["kind"] = abi.MSG_SNAPSHOT_WRITTEN
+        out["a"], out["b"] = m["index"], m["term"]
     elif k == "election_timeout":
         out["kind"] = abi.MSG_ELECTION_TIMEOUT
         out["c"] = m["token"]
@@ -168,6 +171,9 @@ def _check_state(row, exp, where):
         elif k == "last_written":
             got = [int(row["last_written_index"]), int(row["last_written_term"])]
             assert got == list(val), f"{where}: last_written={got} expected {val}"
+        elif k == "snapshot":
+            got = [int(row["snapshot_index"]), int(row["snapshot_term"])]
+            assert got == list(val), f"{where}: snapshot={got} expected {val}"
         elif k == "log":
             got = [list(e) for e in abi.log_entries(row)]
             assert got == [list(e) for e in val], f"{where}: log={got} expected {val}"

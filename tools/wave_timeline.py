@@ -12,8 +12,8 @@ eng.set_state(0, W.initial_states(G, N, 0x5EED0003))
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); sp = stream.cuda_stream
 dm = torch.empty(S * 64, dtype=torch.uint8, device="cuda"); dd = torch.empty(S * 64, dtype=torch.uint8, device="cuda")
 dr = torch.empty(S * 4 * 56, dtype=torch.uint8, device="cuda")
-kc = torch.zeros(12, dtype=torch.int32, device="cuda"); dn = torch.zeros(1, dtype=torch.int32, device="cuda")
-for t in range(24):
+kc = torch.zeros(abi.N_KINDS, dtype=torch.int32, device="cuda"); dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+for t in range(int(os.environ.get("TL_TICKS", "24"))):
     eng.synth_tick_device(0x5EED0003, t, dm.data_ptr(), kc.data_ptr(), dn.data_ptr(), sp)
     torch.cuda.synchronize()
     eng.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), sp)
@@ -43,3 +43,10 @@ conc = np.cumsum(ev[:, 1])
 for us in range(0, min(int((t3.max() - z) * tick / 1e3) + 1, 60), 2):
     i = np.searchsorted(ev[:, 0], us * 1e3 / tick)
     print(f"  t={us:3d} us  waves in flight {int(conc[min(i, len(conc)-1)]):5d}  started {int((t0 - z <= us*1e3/tick).sum()):5d}")
+st = eng.get_state()
+import collections
+print("n_runs hist", np.bincount(st["n_runs"], minlength=17).tolist())
+print("roles", np.bincount(st["role"], minlength=5).tolist())
+print("log span (LI-first) p50/p99", np.percentile((st["last_index"] - st["first_index"]).astype(np.int64), [50, 99]).tolist())
+print("LI-LWI p50/p99", np.percentile((st["last_index"] - st["last_written_index"]).astype(np.int64), [50, 99]).tolist())
+print("kind counts", kc.cpu().numpy().tolist())
