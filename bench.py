@@ -241,6 +241,12 @@ def main():
                  "snapshot_written"]
         tk = kc[Wm:].sum(axis=0)
         mix = {names[i]: round(float(tk[i]) / float(tk[1:].sum()), 4) for i in range(1, NK) if tk[i]}
+        traffic = None
+        try:   # PMC passes cannot run inside this process: the committed per-launch figure, if any
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = float(json.load(f)["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
         out = {
             "metric": "append_entries decisions/sec across N Raft groups; achieved HBM GB/s vs peak",
             "value": total_dec / elapsed,
@@ -262,7 +268,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from profiles/r01_traffic.json (rocprofv3 PMC passes of "
+                                "tools/profile_round.sh, gfx950 x2 fetch correction); not re-measured in this run",
                 "kernel": f"rgb_tick_classes_kernel<{N}>" if not args.generic_kernel
                           else f"rgb_tick_kernel<{N},generic>",
                 "algorithmic_bytes_per_launch": launch_bytes,
