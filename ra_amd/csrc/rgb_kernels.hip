@@ -20,7 +20,9 @@
 #define UNDEF 0xFFFFFFFFFFFFFFFFull
 #define SLOT_NONE4 0xFu
 
+#ifndef RGB_TICK_BLOCK
 #define RGB_TICK_BLOCK 64
+#endif
 #ifndef RGB_CLASS_MIN_WAVES
 #define RGB_CLASS_MIN_WAVES(N) ((N) <= 5 ? 4 : 3)   /* the class-dispatch kernel: hot paths fit 128 VGPRs */
 #endif
@@ -1234,6 +1236,16 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
+  const bool hot_dirty = L.ct != h0.x || L.ci != h0.y || L.la != h1.x || L.li != h1.y || L.lt != h2.x ||
+                         L.lwi != h2.y || L.lwt != h3.x || L.pk != h3.y || L.si != h4.x || L.st != h4.y ||
+                         L.first != h5.x || L.lrs != h5.y || L.lrt != h6.x || L.token != h6.y;
+  if ((dev.dbg & 64u) && hot_dirty && !(dev.dbg & 1u)) {
+    /* experiment: rewrite the whole 128-byte line (no partial-line read-modify-write at memory) */
+    ho[0] = make_ulonglong2(L.ct, L.ci); ho[1] = make_ulonglong2(L.la, L.li);
+    ho[2] = make_ulonglong2(L.lt, L.lwi); ho[3] = make_ulonglong2(L.lwt, L.pk);
+    ho[4] = make_ulonglong2(L.si, L.st); ho[5] = make_ulonglong2(L.first, L.lrs);
+    ho[6] = make_ulonglong2(L.lrt, L.token); ho[7] = make_ulonglong2(L.macver, 0);
+  } else
   if (!(dev.dbg & 1u)) {
   if (L.ct != h0.x || L.ci != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.ci), wt);
   if (L.la != h1.x || L.li != h1.y) ST16(ho + 1, make_ulonglong2(L.la, L.li), wt);

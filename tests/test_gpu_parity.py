@@ -263,3 +263,66 @@ def test_device_generated_stream_matches_oracle(engine_mod, oracle_lib, n_member
         # and the groups stay healthy: most of them have exactly one leader at the end
         rows = gpu.snapshot()
         assert (rows["n_leaders"] == 1).mean() > 0.6
+
+
+def test_config5_log_matching_repair_matches_oracle(engine_mod, oracle_lib):
+    """BASELINE config 5 shape at a size the oracle handles in seconds: 7 members, 1024-entry
+    uncommitted backlogs crossing 3-6 term boundaries, AERs with prev_log_index inside the backlog
+    and a wrong prev_log_term half of the time, failed replies driving the leader's a8 repair."""
+    from ra_amd import workload as W
+    G, N, seed = 1024, 7, 0x5EED0005
+    st = W.initial_states(G, N, seed, backlog=1024, boundaries=(3, 6))
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(G, N, max_runs=16, ring_capacity=G * N, ring_slots=2) as gpu:
+        gpu.set_state(0, st)
+        seen = 0
+        for t in range(10):
+            cur = cpu.get_state()
+            m = W.gen_tick(cur, N, t, seed, W.MIX_CONFIG5, backlog_mode=True)
+            do, ro = cpu.step(m)
+            dg, rg = gpu.step(m)
+            assert_same(f"config5 tick {t}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+            seen |= int(np.bitwise_or.reduce(do["flags"]))
+        assert (cpu.get_state()["role"] == abi.ROLE_AWAIT_CONDITION).sum() > G // 4   # mismatches happened
+        assert seen & abi.F_REPLY and seen & abi.F_PIPELINE
+
+
+def test_full_size_properties_config3(engine_mod):
+    """BASELINE config 3 at full size (65 536 groups x 5 members), no oracle in the loop:
+    (1) determinism: two engines fed the same device-generated stream end on the same checksum of
+    checksums; (2) batch-split invariance: a tick applied as ONE batch (class kernel) and the same
+    tick applied through the host path in four chunks (sub-batches, generic/class kernels, different
+    order of servers) give the same state; (3) every decision of a tick names a distinct server."""
+    import torch
+    from ra_amd import workload as W
+    G, N, seed, ticks = 65536, 5, 0x5EED0003, 6
+    S = G * N
+    st0 = W.initial_states(G, N, seed)
+    stream = torch.cuda.Stream()
+    a = engine_mod.RaGpuBatch(G, N, max_runs=16)
+    b = engine_mod.RaGpuBatch(G, N, max_runs=16, ring_capacity=65536, ring_slots=2)
+    try:
+        a.set_state(0, st0)
+        b.set_state(0, st0)
+        dm = torch.zeros(S * 64, dtype=torch.uint8, device="cuda")
+        dd = torch.zeros(S * 64, dtype=torch.uint8, device="cuda")
+        dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for t in range(ticks):
+            with torch.cuda.stream(stream):
+                a.synth_tick_device(seed, t, dm.data_ptr(), 0, dn.data_ptr(), stream.cuda_stream)
+                a.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), 0, stream.cuda_stream)
+            torch.cuda.synchronize()
+            n = int(dn.item())
+            msgs = dm[:n * 64].cpu().numpy().view(abi.MSG_DTYPE)
+            dec_a = dd[:n * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+            assert len(np.unique(msgs["server"])) == n
+            assert not np.any(dec_a["flags"] & abi.F_INVARIANT)
+            # the same messages, shuffled, through the host path in 65536-message chunks
+            perm = np.random.default_rng(t).permutation(n)
+            dec_b, _ = b.step(msgs[perm])
+            assert dec_b.tobytes() == dec_a[perm].tobytes(), f"tick {t}: host path decisions differ"
+            assert a.state_checksum() == b.state_checksum(), f"tick {t}: states differ"
+    finally:
+        a.close()
+        b.close()
