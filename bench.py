@@ -60,8 +60,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # RGB_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU boxes)
+    use_dist = world > 1 or bool(os.environ.get("RGB_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -93,7 +98,7 @@ def main():
     d_kc = torch.zeros(T * NK, dtype=torch.int32, device=dev)
     d_n = torch.zeros(T, dtype=torch.int32, device=dev)           # real size of every tick
     lb_local = torch.empty(G * 32, dtype=torch.uint8, device=dev)
-    lb_all = torch.empty(world * G * 32, dtype=torch.uint8, device=dev) if world > 1 else None
+    lb_all = torch.empty(world * G * 32, dtype=torch.uint8, device=dev) if use_dist else None
 
     # ---- pass 1 (untimed): generate tick t from the device state, then apply it ----
     t_gen = time.time()
@@ -148,7 +153,7 @@ def main():
                                  kind_counts=None if args.generic_kernel else kc[t:nxt].astype(np.uint32))
             if with_snapshots and nxt % SNAPSHOT_EVERY == 0:
                 eng.snapshot_device(lb_local.data_ptr(), sptr)
-                if world > 1:
+                if use_dist:
                     dist.all_gather_into_tensor(lb_all, lb_local)
             t = nxt
 
@@ -156,27 +161,61 @@ def main():
     eng.set_state(0, st0)
     run(0, Wm)
     torch.cuda.synchronize()
-    # the K timed ticks are captured once into a hipGraph (launch-bound inner loop: the eager host
-    # launch rate is ~3.7 us per kernel on this box)
-    graph = None
+
+    # The timed ticks are captured into hipGraphs, one per leaderboard period (16 ticks + the
+    # snapshot kernel): the inner loop is launch-bound (the eager host launch rate is ~3.7 us per
+    # kernel on this box).  The RCCL all-gather stays outside the graphs, on the same stream.
+    def segments(t0, t1):
+        t = t0
+        while t < t1:
+            nxt = min(t1, (t // SNAPSHOT_EVERY + 1) * SNAPSHOT_EVERY)
+            yield t, nxt
+            t = nxt
+
+    def run_segment(t, nxt):
+        eng.run_ticks_device(d_msgs.data_ptr() + t * tick_bytes, S, nxt - t,
+                             d_dec.data_ptr() + t * tick_bytes, d_rpcs.data_ptr(), sptr,
+                             tick_counts=counts[t:nxt],
+                             kind_counts=None if args.generic_kernel else kc[t:nxt].astype(np.uint32))
+        if nxt % SNAPSHOT_EVERY == 0:
+            eng.snapshot_device(lb_local.data_ptr(), sptr)
+
+    graphs = None
     if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
-            run(Wm, T)
-        torch.cuda.synchronize()
-    if world > 1:
+        try:
+            graphs = []
+            for t, nxt in segments(Wm, T):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    run_segment(t, nxt)
+                graphs.append((g, nxt))
+            torch.cuda.synchronize()
+        except Exception as e:                      # pragma: no cover - fall back to eager launches
+            print(f"[bench] hipGraph capture failed ({e!r}); eager launches", file=sys.stderr)
+            graphs = None
+
+    def timed():
+        if graphs is not None:
+            for g, nxt in graphs:
+                g.replay()
+                if use_dist and nxt % SNAPSHOT_EVERY == 0:
+                    dist.all_gather_into_tensor(lb_all, lb_local)
+        else:
+            for t, nxt in segments(Wm, T):
+                run_segment(t, nxt)
+                if use_dist and nxt % SNAPSHOT_EVERY == 0:
+                    dist.all_gather_into_tensor(lb_all, lb_local)
+
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wall0 = time.perf_counter()
     ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        run(Wm, T)
+    timed()
     ev1.record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - wall0
@@ -184,7 +223,7 @@ def main():
     elapsed = max(wall, ev_ms / 1e3)
     checksum_pass2 = eng.state_checksum()
     assert checksum_pass2 == checksum_pass1 or os.environ.get("RGB_DEBUG"), "replay diverged from the generation pass"
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -264,7 +303,7 @@ def main():
                 "leaderboard_allgather_every": SNAPSHOT_EVERY,
                 "parallelism": f"hash-sharded groups x{world}, no data-path collective",
                 "oracle_checked_ticks": checked, "state_checksum": f"{checksum_pass2:#018x}",
-                "stream_generation_s": round(gen_s, 2), "hip_graph": graph is not None,
+                "stream_generation_s": round(gen_s, 2), "hip_graph": graphs is not None,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -280,7 +319,7 @@ def main():
         }
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     _ = my_groups
 

@@ -177,11 +177,17 @@ class RaGpuBatch:
         m = np.ascontiguousarray(msgs, dtype=abi.MSG_DTYPE)
         self._check(self._L.rgb_submit(self._h, m.ctypes.data, len(m), tick), "rgb_submit")
 
-    def collect(self, cap: int | None = None, rpc_cap: int | None = None):
-        cap = self.ring_capacity if cap is None else cap
-        rpc_cap = cap * max(self.n_members - 1, 1) if rpc_cap is None else rpc_cap
-        dec = np.zeros(cap, dtype=abi.DECISION_DTYPE)
-        rpcs = np.zeros(max(rpc_cap, 1), dtype=abi.RPC_DTYPE)
+    def collect(self, cap: int | None = None, rpc_cap: int | None = None, out=None):
+        """Wait for the oldest submitted batch.  `out` = (decisions, rpcs) preallocated arrays to
+        reuse (the NIF hands BEAM binaries instead); returns views of the filled parts."""
+        if out is not None:
+            dec, rpcs = out
+            cap, rpc_cap = len(dec), len(rpcs)
+        else:
+            cap = self.ring_capacity if cap is None else cap
+            rpc_cap = cap * max(self.n_members - 1, 1) if rpc_cap is None else rpc_cap
+            dec = np.empty(cap, dtype=abi.DECISION_DTYPE)
+            rpcs = np.empty(max(rpc_cap, 1), dtype=abi.RPC_DTYPE)
         n, nr, tick = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
         self._check(self._L.rgb_collect(self._h, dec.ctypes.data, cap, C.byref(n), rpcs.ctypes.data,
                                         rpc_cap, C.byref(nr), C.byref(tick)), "rgb_collect")

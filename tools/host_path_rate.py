@@ -20,6 +20,7 @@ for t in range(12):
         eng.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), 0, sp)
     torch.cuda.synchronize()
     ticks.append(dm[:int(dn.item()) * 64].cpu().numpy().view(abi.MSG_DTYPE).copy())
+bufs = (np.empty(262144, dtype=abi.DECISION_DTYPE), np.empty(262144 * 4, dtype=abi.RPC_DTYPE))
 for size in (256, 4096, 65536, None):
     eng.set_state(0, st0)
     t0 = time.perf_counter(); nd = 0
@@ -31,9 +32,14 @@ for size in (256, 4096, 65536, None):
             chunks = chunks[:64]
         for c in chunks:
             while pending >= 3:
-                d, r, _ = eng.collect(cap=262144, rpc_cap=262144); pending -= 1
-            eng.submit(c); pending += 1; nd += len(c)
+                d, r, _ = eng.collect(out=bufs); pending -= 1
+            try:
+                eng.submit(c)
+            except Exception as e:
+                k = c["kind"]; bad = (c["server"] >= S) | (k > 12) | ((c["from"] != 255) & (c["from"] >= 8)) | ((k == 1) & (c["n_run0"] > c["n_entries"])) | ((k == 5) & (c["a"] > c["b"]))
+                print("submit failed", e, "len", len(c), "bad msgs", int(bad.sum()), c[bad][:3]); raise
+            pending += 1; nd += len(c)
     while pending:
-        eng.collect(cap=262144, rpc_cap=262144); pending -= 1
+        eng.collect(out=bufs); pending -= 1
     dt = time.perf_counter() - t0
     print(f"batch {size or 'full tick (~212k)'}: {nd / dt / 1e6:8.1f} M decisions/s through submit/collect ({nd} decisions, {dt*1e3:.1f} ms)")
