@@ -40,11 +40,29 @@ __device__ __forceinline__ void store16_wt(void *p, ulonglong2 v) {
   d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 }
+__device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u d;
+  d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+}
 __device__ __forceinline__ void store8_wt(u64 *p, u64 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#define ST16(ptr, val, wt) do { if (wt) store16_wt((void *)(ptr), (val)); else *(ptr) = (val); } while (0)
-#define ST8(ptr, val, wt) do { if (wt) store8_wt((u64 *)(ptr), (val)); else *(ptr) = (val); } while (0)
+/* store mode: 0 plain, 1 write-through (sc1), 2 non-temporal */
+#define ST16(ptr, val, wt) do { if ((wt) == 1) store16_wt((void *)(ptr), (val)); else if ((wt) == 2) store16_nt((void *)(ptr), (val)); else *(ptr) = (val); } while (0)
+#define ST8(ptr, val, wt) do { if ((wt) == 1) store8_wt((u64 *)(ptr), (val)); else if ((wt) == 2) __builtin_nontemporal_store((u64)(val), (u64 *)(ptr)); else *(ptr) = (val); } while (0)
+
+/* non-temporal 16-byte load: message records are read exactly once */
+typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ ulonglong2 ld16(const ulonglong2 *p) {
+  if (NT) {
+    v2u64 v = __builtin_nontemporal_load(reinterpret_cast<const v2u64 *>(p));
+    return make_ulonglong2(v.x, v.y);
+  }
+  return *p;
+}
 
 __device__ __forceinline__ u64 pk_get(u64 pk, int sh, int w) { return (pk >> sh) & ((1ull << w) - 1ull); }
 __device__ __forceinline__ u64 pk_set(u64 pk, int sh, int w, u64 v) {
@@ -89,6 +107,7 @@ struct Lane {
   u64 pmi[8], pni[8], pcs[8];
   unsigned dmi, dni, dcs;
   bool peers_loaded;
+  bool rpc_nt;            /* profiling knob: non-temporal rpc record stores */
 };
 
 template <int N>
@@ -499,9 +518,10 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
       if (rpcs != nullptr) {
         /* fixed slot: this message's (n_out-1)-th record; 56 B = 7 x 8-B stores */
         u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
-        o[0] = (u64)msg_index | ((u64)L.server << 32);
-        o[1] = (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16);
-        o[2] = L.ct; o[3] = rp_idx; o[4] = rp_term; o[5] = L.ci; o[6] = new_ni;
+        const int rm = L.rpc_nt ? 2 : 0;
+        ST8(o + 0, (u64)msg_index | ((u64)L.server << 32), rm);
+        ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16), rm);
+        ST8(o + 2, L.ct, rm); ST8(o + 3, rp_idx, rm); ST8(o + 4, rp_term, rm); ST8(o + 5, L.ci, rm); ST8(o + 6, new_ni, rm);
       }
     }
   }
@@ -627,9 +647,10 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
     n_out += 1;
     if (rpcs != nullptr) {
       u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
-      o[0] = (u64)msg_index | ((u64)L.server << 32);
-      o[1] = (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16);
-      o[2] = L.ct; o[3] = rp_idx; o[4] = rp_term; o[5] = L.ci; o[6] = new_ni;
+      const int rm = L.rpc_nt ? 2 : 0;
+      ST8(o + 0, (u64)msg_index | ((u64)L.server << 32), rm);
+      ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16), rm);
+      ST8(o + 2, L.ct, rm); ST8(o + 3, rp_idx, rm); ST8(o + 4, rp_term, rm); ST8(o + 5, L.ci, rm); ST8(o + 6, new_ni, rm);
     }
   }
   return 0;
@@ -1116,7 +1137,7 @@ template <int N, int KIND>
 __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
-                                                u32 msg_index_base, Dec &out) {
+                                                u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr) {
   Lane L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -1145,7 +1166,10 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(hot);
   ulonglong2 h0, h1, h2, h3, h4, h5, h6;
   if (dev.dbg & 8u) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = make_ulonglong2(0, 0); h3.y = 0x1Full << PK_PRESENT_SH; }
-  else { h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; }
+  else {
+    h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6];
+  }
+  L.rpc_nt = (dev.dbg & 4096u) != 0;
   L.runs = dev.runs + (size_t)L.server * dev.max_runs * 2;
   L.peers = dev.peers + (size_t)L.server * dev.peer_stride;
   L.max_runs = dev.max_runs;
@@ -1155,6 +1179,11 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if ((L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS) &&
       !(dev.dbg & 4u))
     load_peers<N>(L);
+  if (t_loaded && (dev.dbg & 16u)) {
+    /* profiling: force the state round trip to complete here */
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(h0.x), "v"(h6.y) : "memory");
+    *t_loaded = wall_clock64();
+  }
   L.ct = h0.x; L.ci = h0.y; L.la = h1.x; L.li = h1.y; L.lt = h2.x; L.lwi = h2.y; L.lwt = h3.x;
   L.pk = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
   L.token = h6.y; L.macver = (dev.dbg & 8u) ? 0 : hp[7].x; L.vote_reqs = false;
@@ -1219,7 +1248,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     if (L.push_cnt >= 1) { runs[2 * (nr - 1)] = L.lrs; runs[2 * (nr - 1) + 1] = L.lrt; }
   }
   L.pk = pk_set(L.pk, PK_NRUNS_SH, 5, L.n_runs);
-  const bool wt = (dev.dbg & 32u) != 0;
+  const int wt = (dev.dbg & 32u) ? 1 : (dev.dbg & 1024u) ? 2 : 0;
   if (L.cond_dirty) {
     ulonglong2 *cp = reinterpret_cast<ulonglong2 *>(dev.cond + (size_t)L.server * 4);
     ST16(cp, make_ulonglong2(L.cr0, L.cr1), wt);
@@ -1289,7 +1318,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;          /* 16-byte piece of the 64-message block */
     const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) io[j * RGB_IO_SLOT + part] = src[piece];
+    if (j < cnt) io[j * RGB_IO_SLOT + part] = ld16<true>(src + piece);
   }
   __syncthreads();
   const bool active = lane < cnt;
@@ -1310,7 +1339,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) dst[piece] = io[j * RGB_IO_SLOT + part];
+    if (j < cnt) store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
   }
 }
 
@@ -1358,7 +1387,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #pragma unroll
   for (int c = 0; c < RGB_N_CLASSES; ++c) ncls = c == cls ? cc.n[c] : ncls;
   const u32 lane = threadIdx.x;
-  u64 t0 = 0, t1 = 0, t2 = 0;
+  u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl = 0;
   if (dev.dbg & 16u) t0 = wall_clock64();
   const u32 base = off + blk * RGB_TICK_BLOCK;            /* first message of this wavefront */
   const u32 end = off + ncls;
@@ -1368,7 +1397,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) io[j * RGB_IO_SLOT + part] = src[piece];
+    if (j < cnt) io[j * RGB_IO_SLOT + part] = (dev.dbg & 2048u) ? src[piece] : ld16<true>(src + piece);   /* read once */
   }
   __syncthreads();
   if (dev.dbg & 16u) t1 = wall_clock64();
@@ -1379,7 +1408,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     Dec d;
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
-    process_message<N, KIND>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d); \
+    process_message<N, KIND>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, &tl); \
     break;
     switch (cls) {
       RGB_CASE(0, RGB_MSG_AER) RGB_CASE(1, RGB_MSG_AER_REPLY) RGB_CASE(2, RGB_MSG_WRITTEN)
@@ -1388,10 +1417,10 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(8, RGB_MSG_ELECTION_TIMEOUT) RGB_CASE(9, RGB_MSG_PRE_VOTE_RPC)
       RGB_CASE(10, RGB_MSG_PRE_VOTE_RESULT)
       default: process_message<N, RGB_MSG_SNAPSHOT_WRITTEN>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                            msg_index_base, d); break;
+                                                            msg_index_base, d, &tl); break;
     }
 #undef RGB_CASE
-    if (dev.dbg & 16u) t2 = wall_clock64();
+    if (dev.dbg & 16u) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
     io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
@@ -1400,16 +1429,20 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   __syncthreads();
   if (dev.dbg & 2u) return;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
-  const bool wt = (dev.dbg & 32u) != 0;
+  const int wt = (dev.dbg & 32u) ? 1 : 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) ST16(dst + piece, io[j * RGB_IO_SLOT + part], wt);
+    if (j < cnt) {
+      /* decisions are never re-read on the device: non-temporal (measured -5 % per tick) */
+      if (dev.dbg & 128u) ST16(dst + piece, io[j * RGB_IO_SLOT + part], wt);
+      else store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+    }
   }
   if ((dev.dbg & 16u) && lane == 0) {
     u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 4;
-    o[0] = t0; o[1] = t1; o[2] = t2 | ((u64)cls << 60); o[3] = wall_clock64();
+    o[0] = t0; o[1] = t1 | ((tl - t1) << 40); o[2] = t2 | ((t2b - t2) << 40) | ((u64)cls << 60); o[3] = wall_clock64();
   }
 }
 

@@ -26,15 +26,18 @@ b = buf.reshape(nblk, 4)
 b = b[b[:, 0] > 0]
 b = b[b[:, 0].astype(np.int64) > b[:, 0].astype(np.int64).max() - 20000]   # the last launch only (200 us window)
 cls = (b[:, 2] >> np.uint64(60)).astype(int)
-t0 = b[:, 0].astype(np.int64); t1 = b[:, 1].astype(np.int64); t2 = (b[:, 2] & np.uint64((1 << 60) - 1)).astype(np.int64); t3 = b[:, 3].astype(np.int64)
+M40 = np.uint64((1 << 40) - 1)
+t0 = b[:, 0].astype(np.int64); t1 = (b[:, 1] & M40).astype(np.int64); dl = (b[:, 1] >> np.uint64(40)).astype(np.int64)
+t2 = (b[:, 2] & M40).astype(np.int64); dst = ((b[:, 2] >> np.uint64(40)) & np.uint64(0xFFFFF)).astype(np.int64); t3 = (b[:, 3] & M40).astype(np.int64)
+t0 = t0 & ((1 << 40) - 1)
 z = t0.min()
 tick = 10.0  # ns per wall_clock64 tick (100 MHz)
 print("waves", len(b), "msgs", int(dn.item()), "kernel span %.1f us" % ((t3.max() - z) * tick / 1e3))
-for c in range(5):
+for c in range(12):
     m = cls == c
     if not m.any(): continue
     print(f"class {c}: waves {m.sum():5d} start {((t0[m]-z).min()*tick/1e3):6.1f}..{((t0[m]-z).max()*tick/1e3):6.1f} us | "
-          f"msg-load {np.median(t1[m]-t0[m])*tick/1e3:5.2f} | process {np.median(t2[m]-t1[m])*tick/1e3:5.2f} (p90 {np.percentile(t2[m]-t1[m],90)*tick/1e3:5.2f}) | "
+          f"msg-load {np.median(t1[m]-t0[m])*tick/1e3:5.2f} | state-load {np.median(dl[m])*tick/1e3:5.2f} | store-drain {np.median(dst[m])*tick/1e3:5.2f} | process {np.median(t2[m]-t1[m])*tick/1e3:5.2f} (p90 {np.percentile(t2[m]-t1[m],90)*tick/1e3:5.2f}) | "
           f"dec-store {np.median(t3[m]-t2[m])*tick/1e3:5.2f} | wave life {np.median(t3[m]-t0[m])*tick/1e3:5.2f} us")
 # concurrency over time
 ev = np.concatenate([np.stack([t0 - z, np.ones_like(t0)], 1), np.stack([t3 - z, -np.ones_like(t3)], 1)])
