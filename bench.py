@@ -39,12 +39,14 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=480)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--groups", type=int, default=65536, help="Raft groups per GPU")
     ap.add_argument("--members", type=int, default=5)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0003)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the PCIe-inclusive rgb_submit/rgb_collect measurement (rank 0, N=1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph")
     ap.add_argument("--generic-kernel", action="store_true",
                     help="the kind-generic kernel instead of the class-dispatch kernel")
@@ -123,11 +125,11 @@ def main():
     # ---- correctness gate (rank 0): the first ticks bit-for-bit against the oracle ----
     checked = 0
     first_ticks = []
-    if rank == 0 and (args.check_ticks > 0 or not args.no_cpu_baseline):
-        from oracle import oracle as O
-        n_keep = max(args.check_ticks, 0 if args.no_cpu_baseline else 16)
+    if rank == 0 and (args.check_ticks > 0 or not args.no_cpu_baseline or not args.no_host_path):
+        n_keep = max(args.check_ticks, 0 if args.no_cpu_baseline else 16, 0 if args.no_host_path else 12)
         first_ticks = [tick_msgs(t) for t in range(min(n_keep, T))]
         if args.check_ticks > 0:
+            from oracle import oracle as O
             cpu = O.Oracle(G, N)
             cpu.set_state(0, st0)
             for t in range(min(args.check_ticks, T)):
@@ -271,6 +273,32 @@ def main():
         }
         cpu.close()
 
+    # ---- host path (rank 0, N=1 only): the same ticks through rgb_submit -> kernel -> rgb_collect,
+    # host buffers in, host buffers out (pinned ring, PCIe both ways).  Reported beside `value`,
+    # never as `value`. ----
+    host_path = None
+    if rank == 0 and world == 1 and not args.no_host_path and first_ticks:
+        BATCH = 131072
+        eng_h = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=4, ring_capacity=BATCH)
+        bufs = (np.empty(BATCH, dtype=abi.DECISION_DTYPE), np.empty(BATCH * max(N - 1, 1), dtype=abi.RPC_DTYPE))
+        best = 0.0
+        for rep in range(3):
+            eng_h.set_state(0, st0)
+            pending, nd = 0, 0
+            t0 = time.perf_counter()
+            for m in first_ticks[:12]:
+                for i in range(0, len(m), BATCH):
+                    while pending >= 3:
+                        eng_h.collect(out=bufs); pending -= 1
+                    eng_h.submit(m[i:i + BATCH]); pending += 1; nd += len(m[i:i + BATCH])
+            while pending:
+                eng_h.collect(out=bufs); pending -= 1
+            best = max(best, nd / (time.perf_counter() - t0))
+        eng_h.close()
+        host_path = {"value": best, "unit": "decisions/s", "batch": BATCH,
+                     "note": "first 12 ticks through rgb_submit/rgb_collect (ctypes caller, pinned ring, "
+                             "PCIe both ways, 64-B message in / 64-B decision + rpc records out), best of 3"}
+
     if rank == 0:
         per_launch_s = (ev_ms / 1e3) / K
         launch_bytes = float(alg_bytes[Wm:].mean())
@@ -316,6 +344,7 @@ def main():
                 "avg_launch_us": per_launch_s * 1e6,
             },
             "cpu_baseline": cpu_baseline,
+            "host_path": host_path,
         }
         print(json.dumps(out))
     eng.close()

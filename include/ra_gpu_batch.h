@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGB_ABI_VERSION   1u
+#define RGB_ABI_VERSION   2u
 #define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
 #define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
 #define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
@@ -137,6 +137,9 @@ typedef struct rgb_msg {
                                              last_log_index=reply_last_index, last_log_term=reply_last_term;
                                              #request_vote_rpc{} unless RGB_F_PRE_VOTE_REQS                           */
 #define RGB_F_PRE_VOTE_REQS  (1u << 21) /* the requests are #pre_vote_rpc{} with token=reply_next_index               */
+#define RGB_F_RESEND_PENDING (1u << 22) /* the written event is not a prefix of `pending` (a WAL gap): the host runs
+                                           ra_log:resend_pending/2 (src/ra_log.erl:917-919, 1663-1700); the log
+                                           cursors are unchanged                                                 */
 
 /* rgb_decision.invariant: exit reasons / failed assertions of the reference */
 enum {
@@ -149,8 +152,9 @@ enum {
   RGB_INV_SET_LAST_INDEX_NOT_FOUND  = 6, /* {ok,L} = ra_log:set_last_index badmatch  src/ra_log.erl:857-859 */
   RGB_INV_LAST_WRITTEN_TERM         = 7, /* true = Term =/= undefined        src/ra_log.erl:576, 878 */
   RGB_INV_NEXT_INDEX_REGRESSED      = 8, /* ?assert(NewNextIdx >= NextIdx)   src/ra_server.erl:2333 */
-  RGB_INV_PIPELINE_PREV_UNDEFINED   = 9  /* make_rpc_effect: no term for NextIdx-1 and no snapshot above it
+  RGB_INV_PIPELINE_PREV_UNDEFINED   = 9, /* make_rpc_effect: no term for NextIdx-1 and no snapshot above it
                                             (case_clause / ?assert(PrevIdx < SnapIdx)) src/ra_server.erl:2392-2408 */
+  RGB_INV_WRITTEN_NOT_PREFIX        = 10 /* {ok, Pend} = ra_seq:remove_prefix(..) badmatch  src/ra_log.erl:929 */
 };
 
 /*
@@ -242,6 +246,9 @@ typedef struct rgb_server_state {
   uint8_t  cond_leader;         /* await_condition: who the stored reply is cast to       */
   uint8_t  _pad[3];
   uint64_t pre_vote_token;      /* pre_vote_token (an Erlang reference, opaque 64 bits)   */
+  uint64_t pending_first;       /* ra_log `pending` (src/ra_log.erl:126): the indexes handed to the WAL
+                                   and not yet confirmed are [pending_first .. last_index]; empty is
+                                   stored as last_index + 1 (set it so on upload)            */
   uint32_t machine_version;     /* cfg.machine_version                                    */
   uint32_t effective_machine_version; /* cfg.effective_machine_version                    */
 } rgb_server_state;

@@ -36,6 +36,9 @@ typedef struct {
   uint64_t last_term;
   uint64_t lw_idx, lw_term;
   uint64_t snap_idx, snap_term;   /* UNDEF = no snapshot */
+  uint64_t pend_first;            /* pending (src/ra_log.erl:126): indexes handed to the WAL and not yet
+                                     confirmed, always the contiguous tail [pend_first .. last] on this
+                                     path; empty is held canonically as last_index + 1 */
   uint64_t base;                  /* index stored at terms[0] */
   uint64_t *terms;
   size_t   cap;
@@ -102,6 +105,16 @@ static uint64_t log_fetch_term(const olog *l, uint64_t idx) {
 static void log_last_index_term(const olog *l, uint64_t *idx, uint64_t *term) {
   if (l->has_range) { *idx = l->last; *term = l->last_term; }
   else { *idx = l->snap_idx; *term = l->snap_term; }
+}
+
+/* pending = ra_seq of [pend_first .. range last]; canonical empty form */
+static int log_pend_nonempty(const olog *l) { return l->has_range && l->pend_first <= l->last; }
+static void log_pend_canon(olog *l) {
+  if (!log_pend_nonempty(l)) {
+    uint64_t li, lt;
+    log_last_index_term(l, &li, &lt);
+    l->pend_first = li + 1;
+  }
 }
 
 /* ra_log:next_index/1, src/ra_log.erl:1166-1174 */
@@ -174,6 +187,8 @@ static int log_write(olog *l, const rgb_msg *m, uint32_t k0) {
   l->last = lst;
   l->last_term = msg_entry_term(m, m->n_entries - 1);
   l->lw_idx = lwi; l->lw_term = lwt;
+  /* Pend = ra_seq:limit(FstIdx - 1, Pend0) :583, then ra_seq:append per entry :1610 */
+  if (fst < l->pend_first) l->pend_first = fst;
   return 0;
 }
 
@@ -183,6 +198,7 @@ static int log_append(olog *l, uint64_t idx, uint64_t term) {
   l->terms[idx - l->base] = term;
   if (!l->has_range) { l->has_range = 1; l->first = idx; }
   l->last = idx; l->last_term = term;
+  if (idx < l->pend_first) l->pend_first = idx;           /* limit(Idx-1) + append(Idx) :503-505 */
   return 0;
 }
 
@@ -199,6 +215,8 @@ static int log_set_last_index(olog *l, uint64_t idx) {
     }
     l->last_term = l->snap_term;
     l->lw_idx = l->snap_idx; l->lw_term = l->snap_term;
+    if (idx + 1 < l->pend_first) l->pend_first = idx + 1;  /* pending = ra_seq:limit(Idx, Pend0) :868 */
+    log_pend_canon(l);
     return 0;
   }
   uint64_t lwi = idx < l->lw_idx ? idx : l->lw_idx;
@@ -212,23 +230,41 @@ static int log_set_last_index(olog *l, uint64_t idx) {
   }
   l->last_term = t;
   l->lw_idx = lwi; l->lw_term = lwt;
+  if (idx + 1 < l->pend_first) l->pend_first = idx + 1;    /* pending = ra_seq:limit(Idx, Pend0) :891 */
+  log_pend_canon(l);
   return 0;
 }
 
 /* ra_log:handle_event({written, Term, Seq}), src/ra_log.erl:897-944, for a contiguous
- * Seq = [from..to] (pending/resend bookkeeping stays on the host).  Returns 1 if
- * last_written changed. */
-static int log_written(olog *l, uint64_t term, uint64_t from, uint64_t to) {
+ * Seq = [from..to].  ra_seq:remove_prefix/2 (src/ra_seq.erl:144-147, drop_prefix :278-291) on a
+ * contiguous pending tail: prefix elements below the tail are skipped; a prefix that starts
+ * above the tail's first index is {error, not_prefix}.  Returns 1 if last_written changed;
+ * *resend is set when the reference calls resend_pending/2 (:917-919, State0 otherwise
+ * unchanged: the re-send itself is WAL I/O and stays on the host); *inv when the
+ * {ok, Pend} = ... match of the snapshot clause (:929) would fail. */
+static int log_written(olog *l, uint64_t term, uint64_t from, uint64_t to, int *resend, int *inv) {
   uint64_t idx = to;
   for (;;) {
     uint64_t t = log_fetch_term(l, idx);
     if (t != UNDEF && t == term) {
+      if (log_pend_nonempty(l)) {
+        if (from > l->pend_first) { *resend = 1; return 0; }
+        if (idx + 1 > l->pend_first) l->pend_first = idx + 1;
+        log_pend_canon(l);
+      }
       int changed = !(l->lw_idx == idx && l->lw_term == term);
       l->lw_idx = idx; l->lw_term = term;
       return changed;
     }
-    if (t == UNDEF && l->snap_idx != UNDEF && idx <= l->snap_idx)
-      return 0;                                            /* snapshot overtook the write */
+    if (t == UNDEF && l->snap_idx != UNDEF && idx <= l->snap_idx) {
+      /* snapshot overtook the write: only pending is trimmed */
+      if (log_pend_nonempty(l)) {
+        if (from > l->pend_first) { *inv = RGB_INV_WRITTEN_NOT_PREFIX; return 0; }
+        if (idx + 1 > l->pend_first) l->pend_first = idx + 1;
+        log_pend_canon(l);
+      }
+      return 0;
+    }
     /* term mismatch (or undefined above the snapshot): ra_seq:limit(Idx-1, Seq) and retry */
     if (idx == 0 || idx - 1 < from) return 0;
     idx -= 1;
@@ -249,6 +285,10 @@ static int log_snapshot_written(olog *l, uint64_t snap_idx, uint64_t snap_term) 
   if (snap_idx >= l->last) l->has_range = 0;               /* truncate: nothing left */
   else l->first = snap_idx + 1;
   l->snap_idx = snap_idx; l->snap_term = snap_term;
+  /* Pend = ra_seq:floor(SmallestLiveIdx, Pend0) :1100-1107 with no live indexes below the
+   * snapshot (live-index tracking is machine state and stays on the host) */
+  if (snap_idx + 1 > l->pend_first) l->pend_first = snap_idx + 1;
+  log_pend_canon(l);
   return changed;
 }
 
@@ -697,9 +737,21 @@ static int follower_request_vote(oserver *sv, const rgb_msg *m, ofx *fx) {
   return 0;
 }
 
+/* ra_log:handle_event({written,..}) in any role: *changed = last_written moved; the resend
+ * request of a not_prefix written event is an effect flag (host I/O); returns an RGB_INV_* */
+static int srv_written(oserver *sv, const rgb_msg *m, ofx *fx, int *changed) {
+  int resend = 0, inv = 0;
+  *changed = log_written(&sv->log, m->term, m->a, m->b, &resend, &inv);
+  if (inv) return inv;
+  if (resend) fx->flags |= RGB_F_RESEND_PENDING;
+  return 0;
+}
+
 /* handle_follower({ra_log_event,{written,..}}), src/ra_server.erl:1457-1474 */
 static int follower_written(oserver *sv, const rgb_msg *m, ofx *fx) {
-  int changed = log_written(&sv->log, m->term, m->a, m->b);
+  int changed;
+  int rc = srv_written(sv, m, fx, &changed);
+  if (rc) return rc;
   if (changed && sv->s.leader_id != RGB_NONE)
     aer_reply(sv, sv->s.current_term, 1, sv->s.leader_id, fx);
   return 0;
@@ -821,7 +873,9 @@ static int handle_leader(struct ora_ctx *c, oserver *sv, uint32_t srv_id, const 
     }
     case RGB_MSG_WRITTEN: {
       /* :739-744 */
-      log_written(l, m->term, m->a, m->b);
+      int changed;
+      int rc = srv_written(sv, m, fx, &changed);
+      if (rc) return rc;
       evaluate_quorum(sv, fx);
       fx->flags |= RGB_F_PIPELINE;
       return 0;
@@ -913,8 +967,7 @@ static int handle_candidate(oserver *sv, const rgb_msg *m, ofx *fx, int *reproce
       return 0;
     }
     case RGB_MSG_WRITTEN:
-      log_written(&sv->log, m->term, m->a, m->b);           /* :1157-1160 */
-      return 0;
+      { int changed; return srv_written(sv, m, fx, &changed); }   /* :1157-1160 */
     case RGB_MSG_PRE_VOTE_RPC:
       if (m->term > s->current_term) {
         update_term_and_voted_for(s, m->term, RGB_NONE, fx); /* :1116-1122 */
@@ -963,8 +1016,7 @@ static int handle_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx, int *reproces
     case RGB_MSG_VOTE_RESULT:
       return 0;                                             /* :1249-1251 */
     case RGB_MSG_WRITTEN:
-      log_written(&sv->log, m->term, m->a, m->b);           /* :1257-1260 */
-      return 0;
+      { int changed; return srv_written(sv, m, fx, &changed); }   /* :1257-1260 */
     case RGB_MSG_PRE_VOTE_RESULT: {
       int granted = (m->flags & RGB_MF_SUCCESS) != 0;
       if (m->term > s->current_term) {
@@ -1016,8 +1068,7 @@ static int handle_await_condition(oserver *sv, const rgb_msg *m, ofx *fx, int *r
       return 0;
     }
     case RGB_MSG_WRITTEN:
-      log_written(&sv->log, m->term, m->a, m->b);           /* :1946-1949, no reply */
-      return 0;
+      { int changed; return srv_written(sv, m, fx, &changed); }   /* :1946-1949, no reply */
     case RGB_MSG_SNAPSHOT_WRITTEN:
       log_snapshot_written(&sv->log, m->a, m->b);           /* :1946-1949 */
       return 0;
@@ -1125,6 +1176,7 @@ static void server_init_empty(oserver *sv, uint32_t n_members, uint32_t self) {
   l->snap_idx = UNDEF; l->snap_term = UNDEF;
   log_append(l, 0, 0);                                      /* src/ra_log.erl:1637-1647 */
   l->lw_idx = 0; l->lw_term = 0;
+  l->pend_first = 1;                                        /* ...and its written event: nothing pending */
 }
 
 ora_ctx *ora_new(uint32_t n_groups, uint32_t n_members, uint32_t max_pipeline_count,
@@ -1178,6 +1230,7 @@ int ora_set_state(ora_ctx *c, uint32_t first, uint32_t n, const rgb_server_state
     l->snap_idx = h->snapshot_index; l->snap_term = h->snapshot_term;
     l->lw_idx = h->last_written_index; l->lw_term = h->last_written_term;
     l->last_term = h->last_term;
+    l->pend_first = h->pending_first;
     if (h->first_index <= h->last_index) {
       if (h->n_runs == 0 || h->run_start[0] != h->first_index) return RGB_E_INVAL;
       l->has_range = 1; l->first = h->first_index; l->last = h->last_index;
@@ -1207,6 +1260,7 @@ int ora_get_state(const ora_ctx *c, uint32_t first, uint32_t n, rgb_server_state
     h->last_applied = s->last_applied;
     log_last_index_term(l, &h->last_index, &h->last_term);
     h->last_written_index = l->lw_idx; h->last_written_term = l->lw_term;
+    h->pending_first = l->pend_first;
     h->snapshot_index = l->snap_idx; h->snapshot_term = l->snap_term;
     memcpy(h->cond_reply, s->cond_reply, sizeof s->cond_reply);
     memcpy(h->match_index, s->match_index, sizeof s->match_index);
@@ -1304,6 +1358,7 @@ uint64_t ora_server_checksum(const rgb_server_state *h) {
                    ((uint64_t)h->status_mask << 16) | ((uint64_t)h->self_nonvoter << 24);
   x = fnv_word(x, masks);
   x = fnv_word(x, h->pre_vote_token);
+  x = fnv_word(x, h->pending_first);
   x = fnv_word(x, (uint64_t)h->machine_version | ((uint64_t)h->effective_machine_version << 32));
   for (unsigned i = 0; i < h->n_members && i < RGB_MAX_MEMBERS; i++) {
     x = fnv_word(x, h->match_index[i]); x = fnv_word(x, h->next_index[i]);

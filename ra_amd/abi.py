@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 UNDEF = np.uint64(0xFFFFFFFFFFFFFFFF)  # Erlang 'undefined'
 UNDEF_INT = 0xFFFFFFFFFFFFFFFF
 NONE = 0xFF                            # undefined member slot
@@ -55,10 +55,12 @@ F_REPLY_PRE_VOTE = 1 << 18
 F_START_ELECTION_TIMEOUT = 1 << 19
 F_SEND_VOTE_REQUESTS = 1 << 20
 F_PRE_VOTE_REQS = 1 << 21
+F_RESEND_PENDING = 1 << 22
 
 (INV_NONE, INV_LEADER_SAW_AER_SAME_TERM, INV_TRUNCATE_BELOW_APPLIED, INV_WRITE_BELOW_APPLIED,
  INV_MISMATCH_TERM_UNDEFINED, INV_WRITE_INTEGRITY, INV_SET_LAST_INDEX_NOT_FOUND,
- INV_LAST_WRITTEN_TERM, INV_NEXT_INDEX_REGRESSED, INV_PIPELINE_PREV_UNDEFINED) = range(10)
+ INV_LAST_WRITTEN_TERM, INV_NEXT_INDEX_REGRESSED, INV_PIPELINE_PREV_UNDEFINED,
+ INV_WRITTEN_NOT_PREFIX) = range(11)
 
 RPC_AER, RPC_SNAPSHOT = 1, 2
 
@@ -100,7 +102,8 @@ SERVER_STATE_DTYPE = np.dtype([
     ("voted_for", u8), ("leader_id", u8), ("votes", u8), ("n_runs", u8),
     ("present_mask", u8), ("voter_mask", u8), ("status_mask", u8), ("self_nonvoter", u8),
     ("cond_leader", u8), ("_pad", u8, (3,)),
-    ("pre_vote_token", u64), ("machine_version", u32), ("effective_machine_version", u32),
+    ("pre_vote_token", u64), ("pending_first", u64),
+    ("machine_version", u32), ("effective_machine_version", u32),
 ])
 
 LEADERBOARD_DTYPE = np.dtype([
@@ -115,7 +118,7 @@ CONFIG_DTYPE = np.dtype([
 
 STRUCT_DTYPES = [MSG_DTYPE, DECISION_DTYPE, RPC_DTYPE, SERVER_STATE_DTYPE, LEADERBOARD_DTYPE,
                  CONFIG_DTYPE]
-EXPECTED_SIZES = [64, 64, 56, 592, 32, 32]
+EXPECTED_SIZES = [64, 64, 56, 600, 32, 32]
 for _dt, _sz in zip(STRUCT_DTYPES, EXPECTED_SIZES):
     assert _dt.itemsize == _sz, (_dt, _dt.itemsize, _sz)
 
@@ -133,6 +136,7 @@ def empty_server_states(n_groups: int, n_members: int) -> np.ndarray:
     st["snapshot_index"] = UNDEF
     st["snapshot_term"] = UNDEF
     st["next_index"][:, :n_members] = 1   # slots beyond n_members stay 0 (canonical form)
+    st["pending_first"] = 1               # nothing pending: last_index + 1
     st["role"] = ROLE_FOLLOWER
     st["self"] = np.arange(n, dtype=np.uint32) % n_members
     st["n_members"] = n_members
@@ -179,6 +183,8 @@ def set_log(st: np.ndarray, i: int, entries, last_written=None, snapshot=None, f
     if last_written is None:
         last_written = (int(s["last_index"][0]), int(s["last_term"][0]))
     s["last_written_index"], s["last_written_term"] = last_written
+    # ra_log `pending`: the unwritten tail is what the WAL still owes (empty = last_index + 1)
+    s["pending_first"] = min(int(last_written[0]), int(s["last_index"][0])) + 1
 
 
 def log_entries(st_row) -> list:

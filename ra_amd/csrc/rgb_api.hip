@@ -239,6 +239,7 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
       rgb_server_state &h = init[k];
       memset(&h, 0, sizeof h);
       h.snapshot_index = RGB_UNDEF; h.snapshot_term = RGB_UNDEF;
+      h.pending_first = 1;   /* [0:0] is written: nothing pending (last_index + 1) */
       for (unsigned i = 0; i < n_members; ++i) h.next_index[i] = 1;
       h.role = RGB_ROLE_FOLLOWER; h.self = (uint8_t)((base + k) % n_members);
       h.n_members = (uint8_t)n_members; h.voted_for = RGB_NONE; h.leader_id = RGB_NONE;

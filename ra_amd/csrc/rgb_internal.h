@@ -10,7 +10,8 @@
  *        7 packed (role, condition, slots, masks -- see PK_*)
  *        8 snapshot_index 9 snapshot_term  10 first_index
  *        11 last-run start index           12 last-run term
- *        13 pre_vote_token   14 machine_version | effective_machine_version << 32   15 spare
+ *        13 pre_vote_token   14 machine_version | effective_machine_version << 32
+ *        15 first pending index (ra_log `pending` = [this .. last_index])
  *   peers[S][PS] u64   PS = roundup(3*N, 8): match_index[N] | next_index[N] | commit_index_sent[N]
  *        only leader-side messages touch it
  *   runs [S][K][2] u64 (start, term) of each term run of the ra_log range; only probed when an
@@ -43,6 +44,7 @@ typedef uint32_t u32;
 #define HOT_LRT   12
 #define HOT_TOKEN 13
 #define HOT_MACVER 14
+#define HOT_PEND  15
 
 /* packed word: bit offset / width */
 #define PK_ROLE_SH      0   /* 3 */

@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned slot4to8(unsigned s) { return s >= 8u ? (uns
  * the effects being accumulated and the pending (uncommitted) log-table edits. */
 struct Lane {
   /* hot line */
-  u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt, token, macver;
+  u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt, token, macver, pend;
   /* message */
   u32 server, n_entries, n_run0;
   unsigned kind, from, mflags, gap;
@@ -299,6 +299,12 @@ __device__ __forceinline__ void truncate_runs_to(Lane &L, u64 keep_idx) {
   }
 }
 
+/* ra_log `pending` (src/ra_log.erl:126): on this path always the contiguous tail
+ * [pend .. last_index] of indexes handed to the WAL and not yet confirmed; empty is held as
+ * last_index + 1. */
+__device__ __forceinline__ bool pend_nonempty(const Lane &L) { return range_nonempty(L) && L.pend <= L.li; }
+__device__ __forceinline__ void pend_canon(Lane &L) { if (!pend_nonempty(L)) L.pend = L.li + 1; }
+
 /* ra_log:write/2 (src/ra_log.erl:547-599, range update :1618-1623) of entries k0..n-1.
  * Returns an RGB_INV_* code, 0 on success.  Validates before editing. */
 __device__ __forceinline__ int log_write(Lane &L, u32 k0) {
@@ -334,6 +340,7 @@ __device__ __forceinline__ int log_write(Lane &L, u32 k0) {
   L.li = lst;
   L.lt = (L.n_entries - 1) < L.n_run0 ? L.run0_term : L.run1_term;
   L.lwi = lwi; L.lwt = lwt;
+  if (fst < L.pend) L.pend = fst;      /* ra_seq:limit(FstIdx-1, Pend0) :583 + ra_seq:append per entry :1610 */
   return 0;
 }
 
@@ -351,6 +358,8 @@ __device__ __forceinline__ int log_set_last_index(Lane &L, u64 idx) {
     if (!range_nonempty(L)) L.li = L.si;
     L.lt = L.st;
     L.lwi = L.si; L.lwt = L.st;
+    if (idx + 1 < L.pend) L.pend = idx + 1;   /* pending = ra_seq:limit(Idx, Pend0) :868 */
+    pend_canon(L);
     return 0;
   }
   u64 lwi = idx < L.lwi ? idx : L.lwi;
@@ -361,37 +370,72 @@ __device__ __forceinline__ int log_set_last_index(Lane &L, u64 idx) {
   if (idx + 1 <= L.li) { truncate_runs_to(L, idx); L.li = idx; }
   L.lt = t;
   L.lwi = lwi; L.lwt = lwt;
+  if (idx + 1 < L.pend) L.pend = idx + 1;     /* pending = ra_seq:limit(Idx, Pend0) :891 */
+  pend_canon(L);
   return 0;
 }
 
-/* ra_log:handle_event({written,Term,[from..to]}) (src/ra_log.erl:897-944): the highest index
- * of [from..to] inside the range whose term is Term becomes last_written.  Walking down one
- * index at a time (as the reference does through ra_seq:limit) stops without change only on
- * indexes at/below the snapshot, below which nothing can match either. */
-__device__ __forceinline__ bool log_written(Lane &L, u64 term, u64 from, u64 to) {
-  if (!range_nonempty(L)) return false;
-  u64 hi = to < L.li ? to : L.li;
-  u64 lo = from > L.first ? from : L.first;
-  if (hi < lo) return false;
-  /* walk runs from the newest: run k covers [start_k, end_k] */
-  u64 end = L.li;
-  for (int k = (int)L.n_runs - 1; k >= 0; --k) {
-    u64 s, t;
-    if ((unsigned)k == L.n_runs - 1) { s = L.lrs; t = L.lrt; }
-    else { s = L.runs[2 * k]; t = L.runs[2 * k + 1]; }
-    u64 rs = s < L.first ? L.first : s;
-    if (rs <= hi && end >= lo && t == term) {
-      u64 idx = end < hi ? end : hi;
-      if (idx >= lo && idx >= rs) {
-        bool changed = !(L.lwi == idx && L.lwt == term);
-        L.lwi = idx; L.lwt = term;
-        return changed;
+/* ra_log:handle_event({written,Term,[from..to]}) (src/ra_log.erl:897-944).  The reference walks
+ * the sequence down one index at a time (ra_seq:limit(Last-1)) until either the index's term is
+ * Term (first clause: last_written moves there) or the index is undefined and at/below the
+ * snapshot (second clause: only `pending` is trimmed).  Run-wise here: c1 = the highest index of
+ * [from..to] inside the range whose run has term Term, c2 = the highest index of [from..to]
+ * outside the range and at/below the snapshot; the higher one decides.  `pending` loses the
+ * written prefix (ra_seq:remove_prefix/2); a written range that starts above the first pending
+ * index is not a prefix: resend request (first clause, :917-919, cursors unchanged) or a failed
+ * match (second clause, :929).  Returns an RGB_INV_* code; `changed` = last_written moved. */
+__device__ __forceinline__ int log_written(Lane &L, u64 term, u64 from, u64 to, bool &changed) {
+  changed = false;
+  const bool in_range = range_nonempty(L);
+  bool have1 = false; u64 c1 = 0;
+  if (in_range) {
+    const u64 hi = to < L.li ? to : L.li;
+    const u64 lo = from > L.first ? from : L.first;
+    if (hi >= lo) {
+      /* walk runs from the newest: run k covers [start_k, end_k] */
+      u64 end = L.li;
+      for (int k = (int)L.n_runs - 1; k >= 0; --k) {
+        u64 s, t;
+        if ((unsigned)k == L.n_runs - 1) { s = L.lrs; t = L.lrt; }
+        else { s = L.runs[2 * k]; t = L.runs[2 * k + 1]; }
+        const u64 rs = s < L.first ? L.first : s;
+        if (rs <= hi && end >= lo && t == term) {
+          const u64 idx = end < hi ? end : hi;
+          if (idx >= lo && idx >= rs) { have1 = true; c1 = idx; break; }
+        }
+        if (s <= lo) break;
+        end = s - 1;
       }
     }
-    if (s <= lo) break;
-    end = s - 1;
   }
-  return false;
+  bool have2 = false; u64 c2 = 0;
+  if (L.si != UNDEF) {
+    u64 u = to < L.si ? to : L.si;
+    bool ok = u >= from;
+    if (ok && in_range && u >= L.first && u <= L.li) {      /* inside the range: next one below it */
+      ok = L.first > 0 && L.first - 1 >= from;
+      u = L.first - 1;
+    }
+    if (ok) { have2 = true; c2 = u; }
+  }
+  if (have1 && (!have2 || c1 > c2)) {
+    if (pend_nonempty(L)) {
+      if (from > L.pend) { L.flags |= RGB_F_RESEND_PENDING; return 0; }
+      if (c1 + 1 > L.pend) L.pend = c1 + 1;
+      pend_canon(L);
+    }
+    changed = !(L.lwi == c1 && L.lwt == term);
+    L.lwi = c1; L.lwt = term;
+    return 0;
+  }
+  if (have2) {
+    if (pend_nonempty(L)) {
+      if (from > L.pend) return RGB_INV_WRITTEN_NOT_PREFIX;
+      if (c2 + 1 > L.pend) L.pend = c2 + 1;
+      pend_canon(L);
+    }
+  }
+  return 0;
 }
 
 /* ra_log:handle_event({snapshot_written,{Idx,Term},_,snapshot,_,_}) (src/ra_log.erl:1054-1150):
@@ -423,6 +467,8 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
     L.first = nf;
   }
   L.si = idx; L.st = term;
+  if (idx + 1 > L.pend) L.pend = idx + 1;     /* ra_seq:floor(SnapIdx+1, Pend0) :1100-1107, no live indexes */
+  pend_canon(L);
   return changed;
 }
 
@@ -795,7 +841,9 @@ __device__ __forceinline__ int handle_follower(Lane &L) {
     case RGB_MSG_REQUEST_VOTE: return follower_request_vote(L);
     case RGB_MSG_WRITTEN: {
       /* :1457-1474 */
-      bool changed = log_written(L, L.term, L.a, L.b);
+      bool changed;
+      int rc = log_written(L, L.term, L.a, L.b, changed);
+      if (rc) return rc;
       unsigned l4 = (unsigned)pk_get(L.pk, PK_LEADER_SH, 4);
       if (changed && l4 != SLOT_NONE4) aer_reply(L, L.ct, true, slot4to8(l4));
       return 0;
@@ -903,7 +951,9 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
       return 0;
     }
     case RGB_MSG_WRITTEN: {
-      log_written(L, L.term, L.a, L.b);                              /* :739-744 */
+      bool changed;
+      int rc = log_written(L, L.term, L.a, L.b, changed);            /* :739-744 */
+      if (rc) return rc;
       load_peers<N>(L);
       evaluate_quorum<N>(L);
       L.flags |= RGB_F_PIPELINE;
@@ -923,6 +973,7 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
           push_segment(L, nidx, L.ct);
           L.li = nidx + (L.n_entries - 1);
           L.lt = L.ct;
+          if (nidx < L.pend) L.pend = nidx;   /* ra_seq:limit(Idx-1) + append(Idx) :503-505 */
         }
       }
       bool more; unsigned cnt;
@@ -1001,8 +1052,7 @@ __device__ __forceinline__ int handle_candidate(Lane &L, bool &reprocess) {
       vote_reply(L, L.ct, false, L.from);                            /* :1123-1125 */
       return 0;
     case RGB_MSG_WRITTEN:
-      log_written(L, L.term, L.a, L.b);                              /* :1157-1160 */
-      return 0;
+      { bool changed; return log_written(L, L.term, L.a, L.b, changed); }   /* :1157-1160 */
     case RGB_MSG_PRE_VOTE_RPC:
       if (L.term > L.ct) {
         update_term_and_voted_for(L, L.term, SLOT_NONE4);            /* :1116-1122 */
@@ -1048,8 +1098,7 @@ __device__ __forceinline__ int handle_pre_vote(Lane &L, bool &reprocess) {
       return 0;
     case RGB_MSG_VOTE_RESULT: return 0;                              /* :1249-1251 */
     case RGB_MSG_WRITTEN:
-      log_written(L, L.term, L.a, L.b);                              /* :1257-1260 */
-      return 0;
+      { bool changed; return log_written(L, L.term, L.a, L.b, changed); }   /* :1257-1260 */
     case RGB_MSG_PRE_VOTE_RESULT: {
       const bool granted = (L.mflags & RGB_MF_SUCCESS) != 0;
       if (L.term > L.ct) {
@@ -1094,8 +1143,7 @@ __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, 
       return 0;
     }
     case RGB_MSG_WRITTEN:
-      log_written(L, L.term, L.a, L.b);                              /* :1946-1949 */
-      return 0;
+      { bool changed; return log_written(L, L.term, L.a, L.b, changed); }   /* :1946-1949 */
     case RGB_MSG_SNAPSHOT_WRITTEN:
       log_snapshot_written(L, L.a, L.b);                             /* :1946-1949 */
       return 0;
@@ -1164,10 +1212,10 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   /* hot line: 8 x 16 B (15 live words) */
   u64 *hot = dev.hot + (size_t)L.server * RGB_HOT_WORDS;
   const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(hot);
-  ulonglong2 h0, h1, h2, h3, h4, h5, h6;
-  if (dev.dbg & 8u) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = make_ulonglong2(0, 0); h3.y = 0x1Full << PK_PRESENT_SH; }
+  ulonglong2 h0, h1, h2, h3, h4, h5, h6, h7;
+  if (dev.dbg & 8u) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_ulonglong2(0, 0); h3.y = 0x1Full << PK_PRESENT_SH; }
   else {
-    h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6];
+    h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; h7 = hp[7];
   }
   L.rpc_nt = (dev.dbg & 4096u) != 0;
   L.runs = dev.runs + (size_t)L.server * dev.max_runs * 2;
@@ -1186,7 +1234,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   }
   L.ct = h0.x; L.ci = h0.y; L.la = h1.x; L.li = h1.y; L.lt = h2.x; L.lwi = h2.y; L.lwt = h3.x;
   L.pk = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
-  L.token = h6.y; L.macver = (dev.dbg & 8u) ? 0 : hp[7].x; L.vote_reqs = false;
+  L.token = h6.y; L.macver = h7.x; L.pend = h7.y; L.vote_reqs = false;
   L.flags = 0; L.inv = 0; L.has_reply = false; L.reply_to = RGB_NONE;
   L.r_term = L.r_next = L.r_last = L.r_lterm = 0; L.w_first = L.w_last = 0;
   L.n_runs = (unsigned)pk_get(L.pk, PK_NRUNS_SH, 5);
@@ -1267,13 +1315,14 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
   const bool hot_dirty = L.ct != h0.x || L.ci != h0.y || L.la != h1.x || L.li != h1.y || L.lt != h2.x ||
                          L.lwi != h2.y || L.lwt != h3.x || L.pk != h3.y || L.si != h4.x || L.st != h4.y ||
-                         L.first != h5.x || L.lrs != h5.y || L.lrt != h6.x || L.token != h6.y;
+                         L.first != h5.x || L.lrs != h5.y || L.lrt != h6.x || L.token != h6.y ||
+                         L.pend != h7.y;
   if ((dev.dbg & 64u) && hot_dirty && !(dev.dbg & 1u)) {
     /* experiment: rewrite the whole 128-byte line (no partial-line read-modify-write at memory) */
     ho[0] = make_ulonglong2(L.ct, L.ci); ho[1] = make_ulonglong2(L.la, L.li);
     ho[2] = make_ulonglong2(L.lt, L.lwi); ho[3] = make_ulonglong2(L.lwt, L.pk);
     ho[4] = make_ulonglong2(L.si, L.st); ho[5] = make_ulonglong2(L.first, L.lrs);
-    ho[6] = make_ulonglong2(L.lrt, L.token); ho[7] = make_ulonglong2(L.macver, 0);
+    ho[6] = make_ulonglong2(L.lrt, L.token); ho[7] = make_ulonglong2(L.macver, L.pend);
   } else
   if (!(dev.dbg & 1u)) {
   if (L.ct != h0.x || L.ci != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.ci), wt);
@@ -1283,6 +1332,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (L.si != h4.x || L.st != h4.y) ST16(ho + 4, make_ulonglong2(L.si, L.st), wt);
   if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs), wt);
   if (L.lrt != h6.x || L.token != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.token), wt);
+  if (L.pend != h7.y) ST16(ho + 7, make_ulonglong2(L.macver, L.pend), wt);
   }
 
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
@@ -1740,7 +1790,7 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
   hot[HOT_FIRST] = first_index; hot[HOT_LRS] = lrs; hot[HOT_LRT] = lrt;
   hot[HOT_TOKEN] = h.pre_vote_token;
   hot[HOT_MACVER] = (u64)h.machine_version | ((u64)h.effective_machine_version << 32);
-  hot[15] = 0;
+  hot[HOT_PEND] = h.pending_first;
   u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < dev.peer_stride; ++i) pr[i] = 0;
   for (unsigned i = 0; i < N; ++i) {
@@ -1790,6 +1840,7 @@ __global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ ou
   h.pre_vote_token = hot[HOT_TOKEN];
   h.machine_version = (uint32_t)(hot[HOT_MACVER] & 0xFFFFFFFFull);
   h.effective_machine_version = (uint32_t)(hot[HOT_MACVER] >> 32);
+  h.pending_first = hot[HOT_PEND];
   out[k] = h;
 }
 
@@ -1853,6 +1904,7 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
               (pk_get(pk, PK_STATUS_SH, 8) << 16) | (pk_get(pk, PK_NONVOTER_SH, 1) << 24);
   x = fnv_word(x, masks);
   x = fnv_word(x, hot[HOT_TOKEN]);
+  x = fnv_word(x, hot[HOT_PEND]);
   x = fnv_word(x, hot[HOT_MACVER]);
   const u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < N; ++i) {

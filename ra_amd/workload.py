@@ -132,6 +132,7 @@ def initial_states(n_groups: int, n_members: int, seed: int, backlog: int = 0,
     st["last_index"] = li.reshape(S)
     st["last_term"] = rep(term)
     st["last_written_index"] = lwi.reshape(S)
+    st["pending_first"] = lwi.reshape(S) + 1      # the unwritten tail is what the WAL still owes
     st["snapshot_index"] = rep(si)
     st["snapshot_term"] = rep(snap_term)
     st["first_index"] = rep(first)
@@ -191,6 +192,7 @@ def _compact(st: np.ndarray, mask: np.ndarray):
     low = s["last_written_index"].astype(np.int64) < la
     s["last_written_index"] = np.where(low, la, s["last_written_index"].astype(np.int64))
     s["last_written_term"] = np.where(low, lat, s["last_written_term"].astype(np.int64))
+    s["pending_first"] = np.maximum(s["pending_first"].astype(np.int64), la + 1)   # ra_seq:floor(SnapIdx+1, Pend)
     st[idx] = s
 
 
@@ -237,6 +239,7 @@ def heal(st: np.ndarray, n_members: int, max_runs: int = 8) -> int:
         st["last_term"][ws] = T
         st["last_written_index"][ws] = nli
         st["last_written_term"][ws] = T
+        st["pending_first"][ws] = nli + 1
         st["match_index"][ws, :N] = 0
         st["next_index"][ws, :N] = (nli + 1)[:, None]
         st["commit_index_sent"][ws, :N] = st["commit_index"][ws][:, None]

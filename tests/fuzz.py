@@ -51,6 +51,9 @@ def random_states(rng: np.random.Generator, n_groups: int, n_members: int, max_r
                         snapshot=(si, stm) if has_snap else None)
         li, lt = int(st["last_index"][s]), int(st["last_term"][s])
         first = int(st["first_index"][s])
+        if first <= li and rng.random() < 0.4:
+            # `pending` need not start right after last_written (resends, segment flushes)
+            st["pending_first"][s] = int(rng.integers(first, li + 2))
         st["current_term"][s] = lt + int(rng.integers(0, 3))
         lo = max(first - 1, 0) if first > 0 else 0
         la = int(rng.integers(lo, li + 1))
@@ -187,6 +190,8 @@ def random_msgs(rng: np.random.Generator, st: np.ndarray, n_members: int, frac: 
         elif kind == abi.MSG_WRITTEN:
             hi = max(0, li + int(rng.integers(-3, 3)))
             lo = max(0, hi - int(rng.integers(0, 6)))
+            if rng.random() < 0.5:
+                lo = min(int(row["pending_first"]), hi)          # the in-order case: a prefix of pending
             m["a"][q], m["b"][q] = lo, hi
             tw = _term_at(row, hi)
             if tw is None or rng.random() < 0.3:

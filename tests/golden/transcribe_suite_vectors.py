@@ -573,6 +573,52 @@ vec("R5", "test/ra_log_2_SUITE.erl:157-186 snapshot_before_written (driven as fo
                   last_written=[5, 1], commit_index=10, last_applied=10),
     log_model="real", note="snapshot_written overtakes the written events of lower entries")
 
+# -------------------------------------------- A.8 real-log `pending` / written-event gaps ----
+# The reference pins the END state of these WAL scenarios (ra_log:last_written/1); the
+# intermediate expectations (resend request, cursors untouched) follow
+# src/ra_log.erl:897-944 + ra_seq:remove_prefix/2 (src/ra_seq.erl:144-147, 278-291).
+vec("P1", "test/ra_log_2_SUITE.erl:1556-1573 missed_written_then_write (driven as leader appends + log events)",
+    3, "n1", "empty", [
+        step("leader", dict(kind="append", n=9), role="leader",
+             state=dict(last_index=9, last_term=2, last_written=[0, 0], pending_first=1)),
+        step("leader", dict(kind="append", n=5), role="leader",
+             state=dict(last_index=14, last_term=2, last_written=[0, 0], pending_first=1)),
+        # the written event of 1..9 was lost; the one for 10..14 is not a prefix of pending
+        step("leader", written(2, 10, 14), role="leader",
+             state=dict(last_written=[0, 0], pending_first=1), flags_set=["RESEND_PENDING"]),
+        # after the resend the WAL confirms everything
+        step("leader", written(2, 1, 14), role="leader",
+             state=dict(last_written=[14, 2], pending_first=15), flags_clear=["RESEND_PENDING"]),
+    ], tweak=dict(current_term=2, role="leader", leader_id="n1"),
+    log_model="real", note="{14,2} == last_written is the reference's assertion")
+
+vec("P2", "test/ra_log_2_SUITE.erl:1031-1085 set_last_index_limits_pending_before_new_write "
+          "(driven through follower AERs)", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(i, 1) for i in range(1, 11)]), role="follower",
+         state=dict(last_index=10, pending_first=1)),
+    # set_last_index(5) while 6..10 are still pending: pending is limited to the new last index
+    step("follower", aer(1, "n1", (5, 1), 0, []), role="follower",
+         state=dict(last_index=5, last_term=1, pending_first=1), flags_set=["TRUNCATED"]),
+    step("follower", written(1, 1, 10), role="follower",
+         state=dict(last_written=[5, 1], pending_first=6)),
+], log_model="real", note="{5,1} == last_written and nothing left to resend are the reference's assertions")
+
+vec("P3", "test/ra_log_2_SUITE.erl:710-760 written_event_after_snapshot (driven as leader appends + log events)",
+    3, "n1", "empty", [
+        step("leader", dict(kind="append", n=2), role="leader",
+             state=dict(last_index=2, pending_first=1)),
+        step("leader", dict(kind="snapshot_written", index=2, term=1), role="leader",
+             state=dict(last_written=[2, 1], snapshot=[2, 1], pending_first=3)),
+        # the written event for [1,2] arrives after the snapshot: nothing to do
+        step("leader", written(1, 1, 2), role="leader",
+             state=dict(last_written=[2, 1], pending_first=3), flags_clear=["RESEND_PENDING"]),
+        step("leader", dict(kind="append", n=2), role="leader",
+             state=dict(last_index=4, pending_first=3)),
+        step("leader", written(1, 3, 4), role="leader",
+             state=dict(last_written=[4, 1], pending_first=5)),
+    ], tweak=dict(current_term=1, role="leader", leader_id="n1", commit_index=2, last_applied=2),
+    log_model="real")
+
 AGREED_COMMIT = [([4], 4), ([4, 3], 3), ([4, 4, 4], 4), ([4, 4, 3], 4), ([3, 4, 4], 4),
                  ([4, 2, 3], 3)]
 

@@ -211,9 +211,19 @@ def run_vector(engine_factory, v):
         before = eng.get_state(0, n)
         cur = before.copy()
         want_role = ROLE[s["as"]]
+        patched = False
         if int(cur["role"][i]) != want_role:
             # the reference test calls handle_<as>/2 directly on this state
             cur["role"][i] = want_role
+            patched = True
+        if v.get("log_model") == "mem" and s["msg"].get("kind") == "written":
+            # vectors authored against the reference's fake log (test/ra_log_memory.erl): it keeps no
+            # `pending` seq, every written event applies -> nothing pending before the event
+            empty = int(cur["last_index"][i]) + 1
+            if int(cur["pending_first"][i]) != empty:
+                cur["pending_first"][i] = empty
+                patched = True
+        if patched:
             eng.set_state(0, cur)
         dec, rpcs = eng.step(make_msg(v, s["msg"]))
         d = dec[0]
