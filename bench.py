@@ -305,7 +305,7 @@ def main():
         achieved = launch_bytes / per_launch_s / 1e9
         names = ["nop", "aer", "aer_reply", "request_vote", "vote_result", "written", "pipeline_rpcs",
                  "append", "await_timeout", "election_timeout", "pre_vote_rpc", "pre_vote_result",
-                 "snapshot_written"]
+                 "snapshot_written", "heartbeat_rpc", "heartbeat_reply", "consistent_query"]
         tk = kc[Wm:].sum(axis=0)
         mix = {names[i]: round(float(tk[i]) / float(tk[1:].sum()), 4) for i in range(1, NK) if tk[i]}
         traffic = None

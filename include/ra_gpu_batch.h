@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGB_ABI_VERSION   2u
+#define RGB_ABI_VERSION   3u
 #define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
 #define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
 #define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
@@ -70,10 +70,16 @@ enum {
   RGB_MSG_ELECTION_TIMEOUT = 9,  /* election_timeout -> call_for_election/2 src/ra_server.erl:2877-2924 */
   RGB_MSG_PRE_VOTE_RPC     = 10, /* #pre_vote_rpc{}          src/ra.hrl:157-166                    */
   RGB_MSG_PRE_VOTE_RESULT  = 11, /* #pre_vote_result{}       src/ra.hrl:168-171                    */
-  RGB_MSG_SNAPSHOT_WRITTEN = 12  /* {ra_log_event,{snapshot_written,{Idx,Term},_,snapshot,_,_}}
+  RGB_MSG_SNAPSHOT_WRITTEN = 12, /* {ra_log_event,{snapshot_written,{Idx,Term},_,snapshot,_,_}}
                                     src/ra_log.erl:1054-1150: the log prefix up to Idx is released */
+  RGB_MSG_HEARTBEAT_RPC    = 13, /* #heartbeat_rpc{}         src/ra.hrl:193-196                    */
+  RGB_MSG_HEARTBEAT_REPLY  = 14, /* {Peer,#heartbeat_reply{}} src/ra.hrl:198-200                   */
+  RGB_MSG_CONSISTENT_QUERY = 15  /* {consistent_query,_,_} / {consistent_aux,_,_} with
+                                    cluster_change_permitted = true  src/ra_server.erl:855-860, 868-873:
+                                    the query itself (a fun) stays queued on the host under the
+                                    query_index the decision returns                               */
 };
-#define RGB_MSG_KIND_MAX RGB_MSG_SNAPSHOT_WRITTEN
+#define RGB_MSG_KIND_MAX RGB_MSG_CONSISTENT_QUERY
 #define RGB_PROTO_VERSION 1u    /* ?RA_PROTO_VERSION src/ra.hrl:107 */
 
 /* rgb_msg.flags */
@@ -95,6 +101,9 @@ enum {
  *                 n_entries=candidate machine_version, gap=protocol version
  *   PRE_VOTE_RESULT term, from=voter, flags&SUCCESS=vote_granted, c=token
  *   SNAPSHOT_WRITTEN a=snapshot index, b=snapshot term (kind `snapshot`, not `checkpoint`)
+ *   HEARTBEAT_RPC term, from=leader_id, a=query_index
+ *   HEARTBEAT_REPLY term, from=peer, a=query_index
+ *   CONSISTENT_QUERY (no fields)
  */
 typedef struct rgb_msg {
   uint32_t server;      /* target server id = group * n_members + member slot */
@@ -137,6 +146,15 @@ typedef struct rgb_msg {
                                              last_log_index=reply_last_index, last_log_term=reply_last_term;
                                              #request_vote_rpc{} unless RGB_F_PRE_VOTE_REQS                           */
 #define RGB_F_PRE_VOTE_REQS  (1u << 21) /* the requests are #pre_vote_rpc{} with token=reply_next_index               */
+#define RGB_F_REPLY_HEARTBEAT (1u << 23) /* the reply is a #heartbeat_reply{term=reply_term, query_index=reply_next_index} */
+#define RGB_F_SEND_HEARTBEATS (1u << 24) /* {send_rpc,Peer,#heartbeat_rpc{}} to every member slot set in
+                                            rgb_decision.heartbeat_to: term=reply_term, query_index=reply_last_term
+                                            (heartbeat_rpc_effects/4 src/ra_server.erl:3775-3795)                  */
+#define RGB_F_QUERY_QUORUM   (1u << 25) /* a same-term #heartbeat_reply{} was counted: reply_next_index is the
+                                           consensus query index (get_current_query_quorum/1 :3831-3832); the host
+                                           releases its queued queries up to it (heartbeat_rpc_quorum/3 :3797-3814) */
+#define RGB_F_QUERY_APPLY    (1u << 26) /* no peers: the consistent query (or every waiting one) applies now
+                                           (src/ra_server.erl:3738-3743, 3757-3760)                                */
 #define RGB_F_RESEND_PENDING (1u << 22) /* the written event is not a prefix of `pending` (a WAL gap): the host runs
                                            ra_log:resend_pending/2 (src/ra_log.erl:917-919, 1663-1700); the log
                                            cursors are unchanged                                                 */
@@ -154,7 +172,8 @@ enum {
   RGB_INV_NEXT_INDEX_REGRESSED      = 8, /* ?assert(NewNextIdx >= NextIdx)   src/ra_server.erl:2333 */
   RGB_INV_PIPELINE_PREV_UNDEFINED   = 9, /* make_rpc_effect: no term for NextIdx-1 and no snapshot above it
                                             (case_clause / ?assert(PrevIdx < SnapIdx)) src/ra_server.erl:2392-2408 */
-  RGB_INV_WRITTEN_NOT_PREFIX        = 10 /* {ok, Pend} = ra_seq:remove_prefix(..) badmatch  src/ra_log.erl:929 */
+  RGB_INV_WRITTEN_NOT_PREFIX        = 10, /* {ok, Pend} = ra_seq:remove_prefix(..) badmatch  src/ra_log.erl:929 */
+  RGB_INV_LEADER_SAW_HEARTBEAT_SAME_TERM = 11 /* exit(leader_saw_heartbeat_rpc_in_same_term) src/ra_server.erl:898-903 */
 };
 
 /*
@@ -171,7 +190,9 @@ typedef struct rgb_decision {
   uint8_t  n_rpcs;     /* rgb_rpc records emitted for this message */
   uint8_t  kind;       /* echo of rgb_msg.kind                     */
   uint32_t flags;      /* RGB_F_*                                  */
-  uint32_t invariant;  /* RGB_INV_*                                */
+  uint16_t invariant;  /* RGB_INV_*                                */
+  uint8_t  heartbeat_to; /* RGB_F_SEND_HEARTBEATS: bit i = member slot i gets a #heartbeat_rpc{} */
+  uint8_t  _rsv;
   uint64_t reply_term;
   uint64_t reply_next_index;
   uint64_t reply_last_index;
@@ -246,6 +267,8 @@ typedef struct rgb_server_state {
   uint8_t  cond_leader;         /* await_condition: who the stored reply is cast to       */
   uint8_t  _pad[3];
   uint64_t pre_vote_token;      /* pre_vote_token (an Erlang reference, opaque 64 bits)   */
+  uint64_t query_index;         /* query_index (src/ra_server.erl:96): consistent-query heartbeat counter */
+  uint64_t peer_query_index[RGB_MAX_MEMBERS]; /* #{query_index} of every peer (src/ra.hrl:61-73); own slot unused (0) */
   uint64_t pending_first;       /* ra_log `pending` (src/ra_log.erl:126): the indexes handed to the WAL
                                    and not yet confirmed are [pending_first .. last_index]; empty is
                                    stored as last_index + 1 (set it so on upload)            */

@@ -53,6 +53,8 @@ typedef struct {
   uint8_t  present_mask, voter_mask, status_mask, self_nonvoter, cond_leader;
   uint64_t pre_vote_token;
   uint32_t machine_version, effective_machine_version;
+  uint64_t query_index;                       /* src/ra_server.erl:96 */
+  uint64_t peer_query_index[RGB_MAX_MEMBERS]; /* ra_peer_state().query_index src/ra.hrl:61-73 */
 } oscal;
 
 typedef struct {
@@ -303,6 +305,9 @@ typedef struct {
   rgb_rpc *rpcs; uint32_t rpc_cap, n_rpcs_total; uint8_t n_rpcs;
   uint32_t msg_index;
   int      vote_reqs;              /* {send_vote_requests,..}: request fields ride in r_* */
+  uint8_t  hb_mask;                /* heartbeat_rpc_effects/4: peers that get a #heartbeat_rpc{} */
+  uint64_t hb_term, hb_query_index;
+  uint64_t q_consensus;            /* RGB_F_QUERY_QUORUM */
 } ofx;
 
 static int is_present(const oscal *s, unsigned i) {
@@ -324,6 +329,8 @@ static void update_term_and_voted_for(oscal *s, uint64_t term, uint8_t voted_for
   fx->flags |= RGB_F_PERSIST;
   s->current_term = term;
   s->voted_for = voted_for;
+  /* reset_query_index/1 :3769-3773: every cluster entry's query_index := 0 */
+  memset(s->peer_query_index, 0, sizeof s->peer_query_index);
 }
 /* update_term/2, src/ra_server.erl:3060-3064 */
 static void update_term(oscal *s, uint64_t term, ofx *fx) {
@@ -408,6 +415,70 @@ static void evaluate_quorum(oserver *sv, ofx *fx) {
     s->commit_index = p;
   if (s->commit_index > ci0) fx->flags |= RGB_F_AUX_EVAL;
   if (apply_to(sv, s->commit_index)) fx->flags |= RGB_F_APPLIED;
+}
+
+/* heartbeat_reply/2 :3727-3729 cast to the sender of the #heartbeat_rpc{} */
+static void heartbeat_reply(uint64_t term, uint64_t query_index, uint8_t to, ofx *fx) {
+  fx->has_reply = 1;
+  fx->flags |= RGB_F_REPLY | RGB_F_REPLY_HEARTBEAT;
+  fx->r_term = term; fx->r_next = query_index; fx->r_last = 0; fx->r_lterm = 0;
+  fx->reply_to = to;
+}
+
+static unsigned n_peers(const oscal *s) {                  /* maps:size(peers(State)) */
+  unsigned n = 0;
+  for (unsigned i = 0; i < s->n_members; i++)
+    if (i != s->self && is_present(s, i)) n++;
+  return n;
+}
+
+/* heartbeat_rpc_effects/4 + heartbeat_rpc_effect_for_peer/5 :3775-3795: peers with status normal
+ * whose query_index is below QueryIndex */
+static void heartbeat_rpc_effects(const oscal *s, uint64_t query_index, ofx *fx) {
+  uint8_t mask = 0;
+  for (unsigned i = 0; i < s->n_members; i++) {
+    if (i == s->self || !is_present(s, i)) continue;
+    if (!((s->status_mask >> i) & 1u)) continue;
+    if (s->peer_query_index[i] < query_index) mask |= (uint8_t)(1u << i);
+  }
+  if (mask) {
+    fx->flags |= RGB_F_SEND_HEARTBEATS;
+    fx->hb_mask |= mask;
+    fx->hb_term = s->current_term; fx->hb_query_index = query_index;
+  }
+}
+
+/* update_heartbeat_rpc_effects/1 :3731-3747 (the waiting queue lives on the host: with no
+ * peers every waiting query applies now) */
+static void update_heartbeat_rpc_effects(const oscal *s, ofx *fx) {
+  if (n_peers(s) == 0) { fx->flags |= RGB_F_QUERY_APPLY; return; }
+  heartbeat_rpc_effects(s, s->query_index, fx);
+}
+
+/* make_heartbeat_rpc_effects/2 :3749-3767 */
+static void make_heartbeat_rpc_effects(oscal *s, ofx *fx) {
+  if (n_peers(s) == 0) { fx->flags |= RGB_F_QUERY_APPLY; return; }
+  s->query_index += 1;
+  heartbeat_rpc_effects(s, s->query_index, fx);
+  /* queue:in({NewQueryIndex, QueryRef}, Waiting): the host queues it under this index */
+  fx->hb_term = s->current_term; fx->hb_query_index = s->query_index;
+}
+
+/* heartbeat_rpc_quorum/3 :3797-3814 -> update_peer_query_index/3 :3816-3829,
+ * get_current_query_quorum/1 :3831-3832 over query_indexes/1 :3659-3669 */
+static void heartbeat_rpc_quorum(oscal *s, uint64_t new_query_index, unsigned peer, ofx *fx) {
+  if (is_present(s, peer) && peer < RGB_MAX_MEMBERS && new_query_index > s->peer_query_index[peer])
+    s->peer_query_index[peer] = new_query_index;
+  uint64_t list[RGB_MAX_MEMBERS + 1];
+  uint32_t n = 0;
+  list[n++] = s->query_index;
+  for (unsigned i = 0; i < s->n_members; i++) {
+    if (i == s->self || !is_present(s, i)) continue;
+    if (!((s->voter_mask >> i) & 1u)) continue;            /* membership =/= voter excluded */
+    list[n++] = s->peer_query_index[i];
+  }
+  fx->flags |= RGB_F_QUERY_QUORUM;
+  fx->q_consensus = ora_agreed_commit(list, n);
 }
 
 static void emit_rpc(ofx *fx, const rgb_rpc *r) {
@@ -586,6 +657,7 @@ static int process_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx) {
  * snapshot_backoff peers are outside the device model.) */
 static int make_all_rpcs(oserver *sv, uint32_t srv_id, ofx *fx) {
   oscal *s = &sv->s;
+  update_heartbeat_rpc_effects(s, fx);                      /* :2354-2355 */
   for (unsigned i = 0; i < s->n_members; i++) {
     if (i == s->self || !is_present(s, i)) continue;
     if (!((s->status_mask >> i) & 1u)) continue;
@@ -776,6 +848,18 @@ static int handle_follower(oserver *sv, const rgb_msg *m, ofx *fx) {
       update_term(&sv->s, m->term, fx);
       return 0;
     }
+    case RGB_MSG_HEARTBEAT_RPC:
+      if (m->term >= sv->s.current_term) {                 /* :1441-1450 */
+        update_term(&sv->s, m->term, fx);
+        set_leader_id(&sv->s, m->from, fx);
+        heartbeat_reply(m->term, m->a, m->from, fx);
+      } else {
+        heartbeat_reply(sv->s.current_term, m->a, m->from, fx); /* :1451-1456 */
+      }
+      return 0;
+    case RGB_MSG_HEARTBEAT_REPLY:                          /* :1534-1537 Term = max(TheirTerm, CurTerm) */
+      update_term(&sv->s, m->term, fx);
+      return 0;
     case RGB_MSG_VOTE_RESULT:  return 0;                   /* :1609-1611 ignored */
     case RGB_MSG_PRE_VOTE_RESULT: return 0;                /* :1612-1614 ignored */
     case RGB_MSG_PRE_VOTE_RPC:
@@ -911,6 +995,33 @@ static int handle_leader(struct ora_ctx *c, oserver *sv, uint32_t srv_id, const 
     case RGB_MSG_VOTE_RESULT:                              /* :967-969 */
     case RGB_MSG_PRE_VOTE_RESULT:                          /* :970-972 */
       return 0;
+    case RGB_MSG_CONSISTENT_QUERY:
+      /* :855-860 / :868-873 with cluster_change_permitted = true (the host holds queries while it
+       * is false, :861-867) */
+      make_heartbeat_rpc_effects(s, fx);
+      return 0;
+    case RGB_MSG_HEARTBEAT_RPC:
+      if (m->term > s->current_term) {                     /* :880-889 */
+        set_leader_id(s, RGB_NONE, fx);
+        update_term(s, m->term, fx);
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      if (s->current_term > m->term) {                     /* :890-897 */
+        heartbeat_reply(s->current_term, m->a, m->from, fx);
+        return 0;
+      }
+      return RGB_INV_LEADER_SAW_HEARTBEAT_SAME_TERM;       /* :898-903 */
+    case RGB_MSG_HEARTBEAT_REPLY:                          /* :904-927 */
+      if (m->term == s->current_term) {
+        heartbeat_rpc_quorum(s, m->a, m->from, fx);
+      } else if (m->term > s->current_term) {
+        set_leader_id(s, RGB_NONE, fx);
+        update_term(s, m->term, fx);
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+      }
+      return 0;
     case RGB_MSG_SNAPSHOT_WRITTEN:                         /* :745-747 other ra_log_events */
       log_snapshot_written(l, m->a, m->b);
       return 0;
@@ -976,6 +1087,23 @@ static int handle_candidate(oserver *sv, const rgb_msg *m, ofx *fx, int *reproce
         return 0;
       }
       return process_pre_vote(sv, m, fx);                   /* :1127-1131 */
+    case RGB_MSG_HEARTBEAT_RPC:
+      if (m->term >= s->current_term) {                     /* :1081-1084 */
+        update_term_and_voted_for(s, m->term, RGB_NONE, fx);
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      heartbeat_reply(s->current_term, m->a, m->from, fx);  /* :1085-1090 */
+      return 0;
+    case RGB_MSG_HEARTBEAT_REPLY:
+      if (m->term > s->current_term) {                      /* :1091-1099 */
+        update_term_and_voted_for(s, m->term, RGB_NONE, fx);
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        return 0;
+      }
+      fx->flags |= RGB_F_UNHANDLED;                         /* catch-all: {error, unsupported_call} */
+      return 0;
     case RGB_MSG_PRE_VOTE_RESULT: return 0;                 /* :1135-1137 */
     case RGB_MSG_SNAPSHOT_WRITTEN:
       log_snapshot_written(&sv->log, m->a, m->b);           /* :1157-1160 */
@@ -1034,6 +1162,25 @@ static int handle_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx, int *reproces
       }
       return 0;                                             /* :1247-1249 */
     }
+    case RGB_MSG_HEARTBEAT_RPC:
+      if (m->term >= s->current_term) {                     /* :1198-1203 */
+        update_term(s, m->term, fx);
+        s->votes = 0;
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        *reprocess = 1;
+        return 0;
+      }
+      heartbeat_reply(s->current_term, m->a, m->from, fx);  /* :1204-1208 */
+      return 0;
+    case RGB_MSG_HEARTBEAT_REPLY:
+      if (m->term > s->current_term) {                      /* :1209-1212 */
+        update_term(s, m->term, fx);
+        s->votes = 0;
+        set_role(s, RGB_ROLE_FOLLOWER, fx);
+        return 0;
+      }
+      fx->flags |= RGB_F_UNHANDLED;                         /* catch-all */
+      return 0;
     case RGB_MSG_SNAPSHOT_WRITTEN:
       log_snapshot_written(&sv->log, m->a, m->b);           /* :1257-1260 */
       return 0;
@@ -1136,7 +1283,7 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
     sv->log = saved_log;
     d->role = saved.role;
     d->flags = RGB_F_INVARIANT;
-    d->invariant = (uint32_t)rc;
+    d->invariant = (uint16_t)rc;
     d->commit_index = saved.commit_index;
     d->last_applied = saved.last_applied;
     *n_rpcs = rpcs_before;
@@ -1153,6 +1300,13 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
   } else if (fx.flags & RGB_F_WROTE) {
     d->reply_next_index = fx.w_first; d->reply_last_index = fx.w_last;
   }
+  if ((fx.flags & RGB_F_SEND_HEARTBEATS) || m->kind == RGB_MSG_CONSISTENT_QUERY) {
+    /* never together with a reply: #heartbeat_rpc{term, query_index} for the peers in heartbeat_to;
+     * for a consistent query also the index the host queues the query under */
+    d->heartbeat_to = fx.hb_mask;
+    d->reply_term = fx.hb_term; d->reply_last_term = fx.hb_query_index;
+  }
+  if (fx.flags & RGB_F_QUERY_QUORUM) d->reply_next_index = fx.q_consensus;
   d->commit_index = sv->s.commit_index;
   d->last_applied = sv->s.last_applied;
 }
@@ -1224,6 +1378,8 @@ int ora_set_state(ora_ctx *c, uint32_t first, uint32_t n, const rgb_server_state
     s->pre_vote_token = h->pre_vote_token;
     s->machine_version = h->machine_version;
     s->effective_machine_version = h->effective_machine_version;
+    s->query_index = h->query_index;
+    memcpy(s->peer_query_index, h->peer_query_index, sizeof s->peer_query_index);
     olog *l = &sv->log;
     free(l->terms);
     memset(l, 0, sizeof *l);
@@ -1271,6 +1427,8 @@ int ora_get_state(const ora_ctx *c, uint32_t first, uint32_t n, rgb_server_state
     h->votes = s->votes; h->present_mask = s->present_mask; h->voter_mask = s->voter_mask;
     h->status_mask = s->status_mask; h->self_nonvoter = s->self_nonvoter;
     h->cond_leader = s->cond_leader;
+    h->query_index = s->query_index;
+    memcpy(h->peer_query_index, s->peer_query_index, sizeof s->peer_query_index);
     h->pre_vote_token = s->pre_vote_token;
     h->machine_version = s->machine_version;
     h->effective_machine_version = s->effective_machine_version;
@@ -1359,6 +1517,8 @@ uint64_t ora_server_checksum(const rgb_server_state *h) {
   x = fnv_word(x, masks);
   x = fnv_word(x, h->pre_vote_token);
   x = fnv_word(x, h->pending_first);
+  x = fnv_word(x, h->query_index);
+  for (unsigned i = 0; i < h->n_members && i < RGB_MAX_MEMBERS; i++) x = fnv_word(x, h->peer_query_index[i]);
   x = fnv_word(x, (uint64_t)h->machine_version | ((uint64_t)h->effective_machine_version << 32));
   for (unsigned i = 0; i < h->n_members && i < RGB_MAX_MEMBERS; i++) {
     x = fnv_word(x, h->match_index[i]); x = fnv_word(x, h->next_index[i]);

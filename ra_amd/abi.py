@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 UNDEF = np.uint64(0xFFFFFFFFFFFFFFFF)  # Erlang 'undefined'
 UNDEF_INT = 0xFFFFFFFFFFFFFFFF
 NONE = 0xFF                            # undefined member slot
@@ -24,12 +24,13 @@ COND_NONE, COND_MISSING, COND_TERM_MISMATCH = range(3)
 
 (MSG_NOP, MSG_AER, MSG_AER_REPLY, MSG_REQUEST_VOTE, MSG_VOTE_RESULT, MSG_WRITTEN,
  MSG_PIPELINE_RPCS, MSG_APPEND, MSG_AWAIT_TIMEOUT, MSG_ELECTION_TIMEOUT, MSG_PRE_VOTE_RPC,
- MSG_PRE_VOTE_RESULT, MSG_SNAPSHOT_WRITTEN) = range(13)
-N_KINDS = 13
+ MSG_PRE_VOTE_RESULT, MSG_SNAPSHOT_WRITTEN, MSG_HEARTBEAT_RPC, MSG_HEARTBEAT_REPLY,
+ MSG_CONSISTENT_QUERY) = range(16)
+N_KINDS = 16
 PROTO_VERSION = 1
 # device order of a tick: clause family = (class rank of the kind, success flag); the four hot
 # kinds first (each has a specialised kernel), the rest after (ra_amd/csrc/rgb_internal.h)
-KIND_RANK = np.array([12, 0, 1, 5, 6, 2, 4, 3, 7, 8, 9, 10, 11], dtype=np.int64)
+KIND_RANK = np.array([15, 0, 1, 5, 6, 2, 4, 3, 7, 8, 9, 10, 11, 12, 13, 14], dtype=np.int64)
 MF_SUCCESS = 0x01
 MF_FORCE = 0x02
 
@@ -56,11 +57,15 @@ F_START_ELECTION_TIMEOUT = 1 << 19
 F_SEND_VOTE_REQUESTS = 1 << 20
 F_PRE_VOTE_REQS = 1 << 21
 F_RESEND_PENDING = 1 << 22
+F_REPLY_HEARTBEAT = 1 << 23
+F_SEND_HEARTBEATS = 1 << 24
+F_QUERY_QUORUM = 1 << 25
+F_QUERY_APPLY = 1 << 26
 
 (INV_NONE, INV_LEADER_SAW_AER_SAME_TERM, INV_TRUNCATE_BELOW_APPLIED, INV_WRITE_BELOW_APPLIED,
  INV_MISMATCH_TERM_UNDEFINED, INV_WRITE_INTEGRITY, INV_SET_LAST_INDEX_NOT_FOUND,
  INV_LAST_WRITTEN_TERM, INV_NEXT_INDEX_REGRESSED, INV_PIPELINE_PREV_UNDEFINED,
- INV_WRITTEN_NOT_PREFIX) = range(11)
+ INV_WRITTEN_NOT_PREFIX, INV_LEADER_SAW_HEARTBEAT_SAME_TERM) = range(12)
 
 RPC_AER, RPC_SNAPSHOT = 1, 2
 
@@ -77,7 +82,7 @@ MSG_DTYPE = np.dtype([
 
 DECISION_DTYPE = np.dtype([
     ("server", u32), ("role", u8), ("reply_to", u8), ("n_rpcs", u8), ("kind", u8),
-    ("flags", u32), ("invariant", u32),
+    ("flags", u32), ("invariant", u16), ("heartbeat_to", u8), ("_rsv", u8),
     ("reply_term", u64), ("reply_next_index", u64), ("reply_last_index", u64),
     ("reply_last_term", u64), ("commit_index", u64), ("last_applied", u64),
 ])
@@ -102,7 +107,8 @@ SERVER_STATE_DTYPE = np.dtype([
     ("voted_for", u8), ("leader_id", u8), ("votes", u8), ("n_runs", u8),
     ("present_mask", u8), ("voter_mask", u8), ("status_mask", u8), ("self_nonvoter", u8),
     ("cond_leader", u8), ("_pad", u8, (3,)),
-    ("pre_vote_token", u64), ("pending_first", u64),
+    ("pre_vote_token", u64), ("query_index", u64), ("peer_query_index", u64, (MAX_MEMBERS,)),
+    ("pending_first", u64),
     ("machine_version", u32), ("effective_machine_version", u32),
 ])
 
@@ -118,7 +124,7 @@ CONFIG_DTYPE = np.dtype([
 
 STRUCT_DTYPES = [MSG_DTYPE, DECISION_DTYPE, RPC_DTYPE, SERVER_STATE_DTYPE, LEADERBOARD_DTYPE,
                  CONFIG_DTYPE]
-EXPECTED_SIZES = [64, 64, 56, 600, 32, 32]
+EXPECTED_SIZES = [64, 64, 56, 672, 32, 32]
 for _dt, _sz in zip(STRUCT_DTYPES, EXPECTED_SIZES):
     assert _dt.itemsize == _sz, (_dt, _dt.itemsize, _sz)
 

@@ -140,6 +140,7 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->dev.peers) (void)hipFree(ctx->dev.peers);
   if (ctx->dev.runs) (void)hipFree(ctx->dev.runs);
   if (ctx->dev.cond) (void)hipFree(ctx->dev.cond);
+  if (ctx->dev.qry) (void)hipFree(ctx->dev.qry);
   if (ctx->d_stage) (void)hipFree(ctx->d_stage);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
@@ -214,6 +215,7 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.runs, (size_t)S * d.max_runs * 2 * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.cond, (size_t)S * 4 * sizeof(u64)));
+  HIPCHK(ctx, hipMalloc((void **)&d.qry, (size_t)S * RGB_QRY_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMemsetAsync(d.runs, 0, (size_t)S * d.max_runs * 2 * sizeof(u64), ctx->stream));
   ctx->stage_cap = S < 16384u ? S : 16384u;
   HIPCHK(ctx, hipMalloc((void **)&ctx->d_stage, (size_t)ctx->stage_cap * sizeof(rgb_server_state)));

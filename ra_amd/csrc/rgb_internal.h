@@ -17,6 +17,7 @@
  *   runs [S][K][2] u64 (start, term) of each term run of the ra_log range; only probed when an
  *        index older than the last run is looked up (log-matching repair)
  *   cond [S][4] u64    stored reply of await_condition (cold)
+ *   qry  [S][16] u64   consistent-query heartbeats (cold): 0 query_index, 1+i query_index of peer slot i
  */
 #ifndef RGB_INTERNAL_H
 #define RGB_INTERNAL_H
@@ -28,6 +29,7 @@ typedef unsigned long long u64;
 typedef uint32_t u32;
 
 #define RGB_HOT_WORDS 16
+#define RGB_QRY_WORDS 16
 
 #define HOT_CT    0
 #define HOT_CI    1
@@ -59,11 +61,13 @@ typedef uint32_t u32;
 #define PK_PRESENT_SH   32  /* 8 */
 #define PK_VOTER_SH     40  /* 8 */
 #define PK_STATUS_SH    48  /* 8 */
+#define PK_QSELF_SH     56  /* 1: query_index > 0 (qry row word 0 is worth reading)      */
+#define PK_QPEER_SH     57  /* 1: some peer query_index > 0 (reset_query_index has work) */
 
 /* Device order of a tick: clause family = (class rank of the message kind, success flag).  Every
  * kind is its own kernel class: a wavefront of the class-dispatch kernel runs the code path
  * specialised (compile-time kind) for its 64-message slice. */
-#define RGB_N_CLASSES 12
+#define RGB_N_CLASSES 15
 static inline __host__ __device__ unsigned rgb_kind_rank(unsigned kind) {
   switch (kind) {
     case RGB_MSG_AER: return 0;
@@ -78,10 +82,13 @@ static inline __host__ __device__ unsigned rgb_kind_rank(unsigned kind) {
     case RGB_MSG_PRE_VOTE_RPC: return 9;
     case RGB_MSG_PRE_VOTE_RESULT: return 10;
     case RGB_MSG_SNAPSHOT_WRITTEN: return 11;
-    default: return 12;   /* NOP */
+    case RGB_MSG_HEARTBEAT_RPC: return 12;
+    case RGB_MSG_HEARTBEAT_REPLY: return 13;
+    case RGB_MSG_CONSISTENT_QUERY: return 14;
+    default: return 15;   /* NOP */
   }
 }
-#define RGB_N_FAMILIES 26
+#define RGB_N_FAMILIES 32
 static inline __host__ __device__ unsigned rgb_family(unsigned kind, unsigned flags) {
   return 2u * rgb_kind_rank(kind) + ((flags & RGB_MF_SUCCESS) ? 1u : 0u);
 }
@@ -96,6 +103,7 @@ struct rgb_dev {
   u64 *peers;
   u64 *runs;
   u64 *cond;
+  u64 *qry;
   u32 n_servers;
   u32 n_members;
   u32 max_runs;

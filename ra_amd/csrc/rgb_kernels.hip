@@ -108,6 +108,13 @@ struct Lane {
   unsigned dmi, dni, dcs;
   bool peers_loaded;
   bool rpc_nt;            /* profiling knob: non-temporal rpc record stores */
+  /* consistent-query heartbeats (cold row, loaded on demand) */
+  u64 *qry_base;          /* uniform: the row address is recomputed where it is needed */
+  u64 qself, qp[8];
+  bool q_loaded;
+  unsigned q_dirty;       /* bit 0: query_index, bit 1+i: peer slot i */
+  unsigned hb_mask;
+  u64 hb_term, hb_qi, q_consensus;
 };
 
 template <int N>
@@ -223,6 +230,140 @@ __device__ __forceinline__ void update_term_and_voted_for(Lane &L, u64 term, uns
   L.flags |= RGB_F_PERSIST;
   L.ct = term;
   L.pk = pk_set(L.pk, PK_VOTED_SH, 4, voted4);
+  /* reset_query_index/1 :3769-3773: only when some peer query_index is non-zero */
+  if (pk_get(L.pk, PK_QPEER_SH, 1)) {
+    /* the cleared bit IS the reset: readers take the peers as zero, the commit stage zeroes the
+     * row when the bit went from set to clear */
+    L.pk = pk_set(L.pk, PK_QPEER_SH, 1, 0);
+    if (L.q_loaded) {      /* never on the hot kinds: their paths do not load the row */
+#pragma unroll
+      for (int i = 0; i < 8; ++i) L.qp[i] = 0;
+    }
+  }
+}
+
+__device__ __forceinline__ u64 *qry_row(const Lane &L) { return L.qry_base + (size_t)L.server * RGB_QRY_WORDS; }
+
+/* the qry row: query_index | per-peer query_index */
+template <int N>
+__device__ __forceinline__ void load_qry(Lane &L) {
+  if (L.q_loaded) return;
+  const ulonglong2 *qp = reinterpret_cast<const ulonglong2 *>(qry_row(L));
+  u64 w[N + 2];
+#pragma unroll
+  for (int k = 0; k < (N + 2) / 2; ++k) { ulonglong2 v = qp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+  L.qself = w[0];
+  if (pk_get(L.pk, PK_QPEER_SH, 1)) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) L.qp[i] = w[1 + i];
+  }
+  L.q_loaded = true;
+}
+
+/* heartbeat_reply/2 :3727-3729 cast to the sender of the #heartbeat_rpc{} */
+__device__ __forceinline__ void heartbeat_reply(Lane &L, u64 term, u64 query_index, unsigned to8) {
+  L.has_reply = true;
+  L.flags |= RGB_F_REPLY | RGB_F_REPLY_HEARTBEAT;
+  L.r_term = term; L.r_next = query_index; L.r_last = 0; L.r_lterm = 0;
+  L.reply_to = to8;
+}
+
+template <int N>
+__device__ __forceinline__ unsigned n_other_members(const Lane &L) {
+  const unsigned present = (unsigned)pk_get(L.pk, PK_PRESENT_SH, 8) & ((1u << N) - 1u);
+  return (unsigned)__popc(present & ~(1u << (unsigned)pk_get(L.pk, PK_SELF_SH, 4)));
+}
+
+/* heartbeat_rpc_effects/4 + heartbeat_rpc_effect_for_peer/5 :3775-3795 */
+template <int N>
+__device__ __forceinline__ void heartbeat_rpc_effects(Lane &L, u64 query_index) {
+  const unsigned self = (unsigned)pk_get(L.pk, PK_SELF_SH, 4);
+  const unsigned present = (unsigned)pk_get(L.pk, PK_PRESENT_SH, 8);
+  const unsigned status = (unsigned)pk_get(L.pk, PK_STATUS_SH, 8);
+  unsigned mask = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if ((unsigned)i == self || !((present >> i) & 1u) || !((status >> i) & 1u)) continue;
+    if (L.qp[i] < query_index) mask |= 1u << i;
+  }
+  if (mask) {
+    L.flags |= RGB_F_SEND_HEARTBEATS;
+    L.hb_mask |= mask;
+    L.hb_term = L.ct; L.hb_qi = query_index;
+  }
+}
+
+/* peers (of `candidates`) whose query_index is below the row's own query_index, straight from
+ * memory: the election paths that call it must not carry the row in registers */
+__device__ __forceinline__ unsigned heartbeat_targets(const u64 *qry, unsigned candidates, bool peers_zero, u64 *qself) {
+  const u64 q0 = qry[0];
+  unsigned mask = 0;
+  for (unsigned i = 0; i < 8; ++i) {
+    if (!((candidates >> i) & 1u)) continue;
+    const u64 qi = peers_zero ? 0 : qry[1 + i];
+    if (qi < q0) mask |= 1u << i;
+  }
+  *qself = q0;
+  return mask;
+}
+
+/* update_heartbeat_rpc_effects/1 :3731-3747 (the waiting queue lives on the host) */
+template <int N>
+__device__ __forceinline__ void update_heartbeat_rpc_effects(Lane &L) {
+  if (n_other_members<N>(L) == 0) { L.flags |= RGB_F_QUERY_APPLY; return; }
+  if (!pk_get(L.pk, PK_QSELF_SH, 1)) return;      /* query_index == 0: no peer can be below it */
+  const unsigned self = (unsigned)pk_get(L.pk, PK_SELF_SH, 4);
+  const unsigned cand = (unsigned)pk_get(L.pk, PK_PRESENT_SH, 8) & (unsigned)pk_get(L.pk, PK_STATUS_SH, 8) &
+                        ((1u << N) - 1u) & ~(1u << self);
+  u64 q0;
+  const unsigned mask = heartbeat_targets(qry_row(L), cand, !pk_get(L.pk, PK_QPEER_SH, 1), &q0);
+  if (mask) {
+    L.flags |= RGB_F_SEND_HEARTBEATS;
+    L.hb_mask |= mask;
+    L.hb_term = L.ct; L.hb_qi = q0;
+  }
+}
+
+/* make_heartbeat_rpc_effects/2 :3749-3767 */
+template <int N>
+__device__ __forceinline__ void make_heartbeat_rpc_effects(Lane &L) {
+  if (n_other_members<N>(L) == 0) { L.flags |= RGB_F_QUERY_APPLY; return; }
+  load_qry<N>(L);
+  L.qself += 1; L.q_dirty |= 1u;
+  L.pk = pk_set(L.pk, PK_QSELF_SH, 1, 1);
+  heartbeat_rpc_effects<N>(L, L.qself);
+  L.hb_term = L.ct; L.hb_qi = L.qself;            /* the host queues the query under this index */
+}
+
+template <int N> __device__ __forceinline__ u64 agreed_commit(const u64 (&v)[N], const bool (&use)[N], int n);
+
+/* heartbeat_rpc_quorum/3 :3797-3814, update_peer_query_index/3 :3816-3829,
+ * get_current_query_quorum/1 :3831-3832 over query_indexes/1 :3659-3669 */
+template <int N>
+__device__ __forceinline__ void heartbeat_rpc_quorum(Lane &L, u64 new_qi, unsigned peer) {
+  const unsigned self = (unsigned)pk_get(L.pk, PK_SELF_SH, 4);
+  const unsigned present = (unsigned)pk_get(L.pk, PK_PRESENT_SH, 8);
+  const unsigned voters = (unsigned)pk_get(L.pk, PK_VOTER_SH, 8);
+  load_qry<N>(L);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if ((unsigned)i == peer && ((present >> i) & 1u) && new_qi > L.qp[i]) {
+      L.qp[i] = new_qi; L.q_dirty |= 2u << i;
+      L.pk = pk_set(L.pk, PK_QPEER_SH, 1, 1);
+    }
+  }
+  u64 v[N]; bool use[N]; int n = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if ((unsigned)i == self) { v[i] = L.qself; use[i] = true; n += 1; }
+    else {
+      use[i] = ((present >> i) & 1u) && ((voters >> i) & 1u);
+      v[i] = L.qp[i];
+      n += use[i] ? 1 : 0;
+    }
+  }
+  L.flags |= RGB_F_QUERY_QUORUM;
+  L.q_consensus = agreed_commit<N>(v, use, n);
 }
 /* update_term/2 (src/ra_server.erl:3060-3064) */
 __device__ __forceinline__ void update_term(Lane &L, u64 term) {
@@ -670,6 +811,7 @@ template <int N>
 __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *rpcs, u32 slot_base,
                                              u32 msg_index) {
   const unsigned self = self_of(L);
+  update_heartbeat_rpc_effects<N>(L);                                /* :2354-2355 */
   load_peers<N>(L);
   n_out = 0;
 #pragma unroll
@@ -856,6 +998,16 @@ __device__ __forceinline__ int handle_follower(Lane &L) {
     }
     case RGB_MSG_AER_REPLY:    update_term(L, L.term); return 0;     /* :1530-1533 */
     case RGB_MSG_VOTE_RESULT:  return 0;                             /* :1609-1611 */
+    case RGB_MSG_HEARTBEAT_RPC:
+      if (L.term >= L.ct) {                                          /* :1441-1450 */
+        update_term(L, L.term);
+        set_leader_id(L, slot8to4(L.from));
+        heartbeat_reply(L, L.term, L.a, L.from);
+      } else {
+        heartbeat_reply(L, L.ct, L.a, L.from);                       /* :1451-1456 */
+      }
+      return 0;
+    case RGB_MSG_HEARTBEAT_REPLY: update_term(L, L.term); return 0;  /* :1534-1537 */
     case RGB_MSG_PRE_VOTE_RESULT: return 0;                          /* :1612-1614 */
     case RGB_MSG_PRE_VOTE_RPC:
       if (pk_get(L.pk, PK_NONVOTER_SH, 1)) return 0;                 /* :1475-1480 */
@@ -999,6 +1151,30 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
       n_rpcs = cnt;
       return 0;
     }
+    case RGB_MSG_CONSISTENT_QUERY:
+      /* :855-860 / :868-873 with cluster_change_permitted = true (the host holds queries while
+       * it is false, :861-867) */
+      make_heartbeat_rpc_effects<N>(L);
+      return 0;
+    case RGB_MSG_HEARTBEAT_RPC:
+      if (L.term > L.ct) {                                           /* :880-889 */
+        set_leader_id(L, SLOT_NONE4);
+        update_term(L, L.term);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      if (L.ct > L.term) { heartbeat_reply(L, L.ct, L.a, L.from); return 0; }   /* :890-897 */
+      return RGB_INV_LEADER_SAW_HEARTBEAT_SAME_TERM;                 /* :898-903 */
+    case RGB_MSG_HEARTBEAT_REPLY:                                    /* :904-927 */
+      if (L.term == L.ct) {
+        heartbeat_rpc_quorum<N>(L, L.a, L.from);
+      } else if (L.term > L.ct) {
+        set_leader_id(L, SLOT_NONE4);
+        update_term(L, L.term);
+        set_role(L, RGB_ROLE_FOLLOWER);
+      }
+      return 0;
     case RGB_MSG_VOTE_RESULT:                                        /* :967-969 */
     case RGB_MSG_PRE_VOTE_RESULT:                                    /* :970-972 */
       return 0;
@@ -1061,6 +1237,23 @@ __device__ __forceinline__ int handle_candidate(Lane &L, bool &reprocess) {
         return 0;
       }
       return process_pre_vote(L);                                    /* :1127-1131 */
+    case RGB_MSG_HEARTBEAT_RPC:
+      if (L.term >= L.ct) {                                          /* :1081-1084 */
+        update_term_and_voted_for(L, L.term, SLOT_NONE4);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      heartbeat_reply(L, L.ct, L.a, L.from);                         /* :1085-1090 */
+      return 0;
+    case RGB_MSG_HEARTBEAT_REPLY:
+      if (L.term > L.ct) {                                           /* :1091-1099 */
+        update_term_and_voted_for(L, L.term, SLOT_NONE4);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        return 0;
+      }
+      L.flags |= RGB_F_UNHANDLED;                                    /* catch-all */
+      return 0;
     case RGB_MSG_PRE_VOTE_RESULT: return 0;                          /* :1135-1137 */
     case RGB_MSG_SNAPSHOT_WRITTEN:
       log_snapshot_written(L, L.a, L.b);                             /* :1157-1160 */
@@ -1117,6 +1310,25 @@ __device__ __forceinline__ int handle_pre_vote(Lane &L, bool &reprocess) {
     case RGB_MSG_SNAPSHOT_WRITTEN:
       log_snapshot_written(L, L.a, L.b);                             /* :1257-1260 */
       return 0;
+    case RGB_MSG_HEARTBEAT_RPC:
+      if (L.term >= L.ct) {                                          /* :1198-1203 */
+        update_term(L, L.term);
+        L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        reprocess = true;
+        return 0;
+      }
+      heartbeat_reply(L, L.ct, L.a, L.from);                         /* :1204-1208 */
+      return 0;
+    case RGB_MSG_HEARTBEAT_REPLY:
+      if (L.term > L.ct) {                                           /* :1209-1212 */
+        update_term(L, L.term);
+        L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
+        set_role(L, RGB_ROLE_FOLLOWER);
+        return 0;
+      }
+      L.flags |= RGB_F_UNHANDLED;                                    /* catch-all */
+      return 0;
     case RGB_MSG_PRE_VOTE_RPC: return process_pre_vote(L);           /* :1250-1251 */
     case RGB_MSG_ELECTION_TIMEOUT:
       call_for_election_pre_vote<N>(L, L.c);                         /* :1255-1256 */
@@ -1172,10 +1384,10 @@ struct Dec { u64 w[8]; };
 
 __device__ __forceinline__ void make_decision(Dec &d, u32 server, unsigned role, unsigned reply_to,
                                               unsigned n_rpcs, unsigned kind, u32 flags, u32 inv, u64 w2,
-                                              u64 w3, u64 w4, u64 w5, u64 ci, u64 la) {
+                                              u64 w3, u64 w4, u64 w5, u64 ci, u64 la, unsigned hb_mask = 0) {
   d.w[0] = (u64)server | ((u64)(role & 0xFF) << 32) | ((u64)(reply_to & 0xFF) << 40) |
            ((u64)(n_rpcs & 0xFF) << 48) | ((u64)(kind & 0xFF) << 56);
-  d.w[1] = (u64)flags | ((u64)inv << 32);
+  d.w[1] = (u64)flags | ((u64)(inv & 0xFFFFu) << 32) | ((u64)(hb_mask & 0xFFu) << 48);
   d.w[2] = w2; d.w[3] = w3; d.w[4] = w4; d.w[5] = w5; d.w[6] = ci; d.w[7] = la;
 }
 
@@ -1218,6 +1430,11 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; h7 = hp[7];
   }
   L.rpc_nt = (dev.dbg & 4096u) != 0;
+  L.qry_base = dev.qry;
+  L.q_loaded = false; L.q_dirty = 0; L.hb_mask = 0;
+  L.qself = 0; L.hb_term = L.hb_qi = L.q_consensus = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) L.qp[i] = 0;
   L.runs = dev.runs + (size_t)L.server * dev.max_runs * 2;
   L.peers = dev.peers + (size_t)L.server * dev.peer_stride;
   L.max_runs = dev.max_runs;
@@ -1302,6 +1519,15 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     ST16(cp, make_ulonglong2(L.cr0, L.cr1), wt);
     ST16(cp + 1, make_ulonglong2(L.cr2, L.cr3), wt);
   }
+  /* ---- commit: query row (rare) ---- */
+  const bool q_reset = pk_get(h3.y, PK_QPEER_SH, 1) && !pk_get(L.pk, PK_QPEER_SH, 1);
+  if ((L.q_dirty || q_reset) && !(dev.dbg & 1u)) {
+    u64 *q = qry_row(L);
+    if (L.q_dirty & 1u) q[0] = L.qself;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (q_reset || (L.q_dirty & (2u << i))) q[1 + i] = L.qp[i];
+  }
   /* ---- commit: peers row (dirty words only) ---- */
   if (L.dmi | L.dni | L.dcs) {
 #pragma unroll
@@ -1338,8 +1564,10 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
   if (L.has_reply || L.vote_reqs) { w2 = L.r_term; w3 = L.r_next; w4 = L.r_last; w5 = L.r_lterm; }
   else if (L.flags & RGB_F_WROTE) { w3 = L.w_first; w4 = L.w_last; }
+  if ((L.flags & RGB_F_SEND_HEARTBEATS) || L.kind == RGB_MSG_CONSISTENT_QUERY) { w2 = L.hb_term; w5 = L.hb_qi; }
+  if (L.flags & RGB_F_QUERY_QUORUM) w3 = L.q_consensus;
   make_decision(out, L.server, role_of(L), L.has_reply ? L.reply_to : (unsigned)RGB_NONE, n_rpcs, L.kind,
-                L.flags, 0, w2, w3, w4, w5, L.ci, L.la);
+                L.flags, 0, w2, w3, w4, w5, L.ci, L.la, L.hb_mask);
 }
 
 /* The tick kernel: one lane per message, one wavefront per 64 consecutive messages.  Messages
@@ -1416,8 +1644,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   }
   /* block -> class, heaviest classes first (ranks: 3 append, 4 pipeline_rpcs, 9 pre_vote_rpc,
    * 8 election_timeout, 10 pre_vote_result, 6 vote_result, 5 request_vote, 7 await_timeout,
-   * 11 snapshot_written, 1 append_entries_reply, 0 append_entries_rpc, 2 written) */
-  constexpr int order[RGB_N_CLASSES] = {3, 4, 9, 8, 10, 6, 5, 7, 11, 1, 0, 2};
+   * 11 snapshot_written, 14 consistent_query, 13 heartbeat_reply, 12 heartbeat_rpc,
+   * 1 append_entries_reply, 0 append_entries_rpc, 2 written) */
+  constexpr int order[RGB_N_CLASSES] = {3, 4, 9, 8, 10, 6, 5, 7, 11, 14, 13, 12, 1, 0, 2};
   u32 blk = blockIdx.x;
   int cls = -1;
 #pragma unroll
@@ -1465,8 +1694,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(3, RGB_MSG_APPEND) RGB_CASE(4, RGB_MSG_PIPELINE_RPCS) RGB_CASE(5, RGB_MSG_REQUEST_VOTE)
       RGB_CASE(6, RGB_MSG_VOTE_RESULT) RGB_CASE(7, RGB_MSG_AWAIT_TIMEOUT)
       RGB_CASE(8, RGB_MSG_ELECTION_TIMEOUT) RGB_CASE(9, RGB_MSG_PRE_VOTE_RPC)
-      RGB_CASE(10, RGB_MSG_PRE_VOTE_RESULT)
-      default: process_message<N, RGB_MSG_SNAPSHOT_WRITTEN>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
+      RGB_CASE(10, RGB_MSG_PRE_VOTE_RESULT) RGB_CASE(11, RGB_MSG_SNAPSHOT_WRITTEN)
+      RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
+      default: process_message<N, RGB_MSG_CONSISTENT_QUERY>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
                                                             msg_index_base, d, &tl); break;
     }
 #undef RGB_CASE
@@ -1791,6 +2021,16 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
   hot[HOT_TOKEN] = h.pre_vote_token;
   hot[HOT_MACVER] = (u64)h.machine_version | ((u64)h.effective_machine_version << 32);
   hot[HOT_PEND] = h.pending_first;
+  {
+    u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
+    bool peer_nz = false;
+    q[0] = h.query_index;
+    for (unsigned i = 0; i < 8; ++i) { q[1 + i] = h.peer_query_index[i]; peer_nz = peer_nz || h.peer_query_index[i] != 0; }
+    for (unsigned i = 9; i < RGB_QRY_WORDS; ++i) q[i] = 0;
+    pk = pk_set(pk, PK_QSELF_SH, 1, h.query_index != 0 ? 1 : 0);
+    pk = pk_set(pk, PK_QPEER_SH, 1, peer_nz ? 1 : 0);
+    hot[HOT_PK] = pk;
+  }
   u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < dev.peer_stride; ++i) pr[i] = 0;
   for (unsigned i = 0; i < N; ++i) {
@@ -1841,6 +2081,11 @@ __global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ ou
   h.machine_version = (uint32_t)(hot[HOT_MACVER] & 0xFFFFFFFFull);
   h.effective_machine_version = (uint32_t)(hot[HOT_MACVER] >> 32);
   h.pending_first = hot[HOT_PEND];
+  {
+    const u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
+    h.query_index = q[0];
+    for (unsigned i = 0; i < 8; ++i) h.peer_query_index[i] = q[1 + i];
+  }
   out[k] = h;
 }
 
@@ -1905,6 +2150,11 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   x = fnv_word(x, masks);
   x = fnv_word(x, hot[HOT_TOKEN]);
   x = fnv_word(x, hot[HOT_PEND]);
+  {
+    const u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
+    x = fnv_word(x, q[0]);
+    for (unsigned i = 0; i < N && i < 8; ++i) x = fnv_word(x, q[1 + i]);
+  }
   x = fnv_word(x, hot[HOT_MACVER]);
   const u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < N; ++i) {

@@ -434,7 +434,8 @@ def algorithmic_bytes(msgs: np.ndarray, n_members: int) -> int:
     n_aer = int((k == abi.MSG_AER).sum())
     n_rep = int((k == abi.MSG_AER_REPLY).sum())
     n_vote = int(np.isin(k, [abi.MSG_REQUEST_VOTE, abi.MSG_VOTE_RESULT, abi.MSG_ELECTION_TIMEOUT,
-                             abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT]).sum())
+                             abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT, abi.MSG_HEARTBEAT_RPC,
+                             abi.MSG_HEARTBEAT_REPLY, abi.MSG_CONSISTENT_QUERY]).sum())
     # housekeeping kinds are priced like the class they resemble: written/await_timeout touch the
     # follower cursor like a vote (112 B); append/pipeline_rpcs walk the peer arrays like a reply
     n_small = int(np.isin(k, [abi.MSG_WRITTEN, abi.MSG_AWAIT_TIMEOUT, abi.MSG_SNAPSHOT_WRITTEN]).sum())
@@ -452,6 +453,7 @@ def algorithmic_bytes_from_counts(kind_counts: np.ndarray, n_members: int) -> np
         price[k] = rep
     for k in (abi.MSG_REQUEST_VOTE, abi.MSG_VOTE_RESULT, abi.MSG_WRITTEN, abi.MSG_AWAIT_TIMEOUT,
               abi.MSG_ELECTION_TIMEOUT, abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT,
-              abi.MSG_SNAPSHOT_WRITTEN):
+              abi.MSG_SNAPSHOT_WRITTEN, abi.MSG_HEARTBEAT_RPC, abi.MSG_HEARTBEAT_REPLY,
+              abi.MSG_CONSISTENT_QUERY):
         price[k] = 112
     return (kc * price).sum(axis=-1)

@@ -75,6 +75,10 @@ def random_states(rng: np.random.Generator, n_groups: int, n_members: int, max_r
         st["status_mask"][s] = 0xFF if rng.random() < 0.85 else int(rng.integers(0, 256))
         st["self_nonvoter"][s] = 1 if rng.random() < 0.05 else 0
         st["pre_vote_token"][s] = int(rng.integers(0, 3))
+        if rng.random() < 0.35:
+            st["query_index"][s] = int(rng.integers(0, 6))
+        if rng.random() < 0.3:
+            st["peer_query_index"][s, :n_members] = rng.integers(0, 6, size=n_members)
         st["machine_version"][s] = int(rng.integers(0, 3))
         st["effective_machine_version"][s] = int(rng.integers(0, 3))
         for j in range(n_members):
@@ -122,17 +126,18 @@ def random_msgs(rng: np.random.Generator, st: np.ndarray, n_members: int, frac: 
         kinds = [abi.MSG_AER, abi.MSG_AER_REPLY, abi.MSG_REQUEST_VOTE, abi.MSG_VOTE_RESULT,
                  abi.MSG_WRITTEN, abi.MSG_PIPELINE_RPCS, abi.MSG_APPEND, abi.MSG_AWAIT_TIMEOUT,
                  abi.MSG_NOP, abi.MSG_ELECTION_TIMEOUT, abi.MSG_PRE_VOTE_RPC, abi.MSG_PRE_VOTE_RESULT,
-                 abi.MSG_SNAPSHOT_WRITTEN]
+                 abi.MSG_SNAPSHOT_WRITTEN, abi.MSG_HEARTBEAT_RPC, abi.MSG_HEARTBEAT_REPLY,
+                 abi.MSG_CONSISTENT_QUERY]
         if role == abi.ROLE_LEADER:
-            p = [0.1, 0.38, 0.08, 0.02, 0.1, 0.1, 0.12, 0.01, 0.02, 0.01, 0.02, 0.01, 0.03]
+            p = [0.082, 0.3116, 0.0656, 0.0164, 0.082, 0.082, 0.0984, 0.0082, 0.0164, 0.0082, 0.0164, 0.0082, 0.0246, 0.02, 0.1, 0.06]
         elif role == abi.ROLE_CANDIDATE:
-            p = [0.18, 0.08, 0.13, 0.33, 0.1, 0.01, 0.01, 0.01, 0.02, 0.04, 0.04, 0.02, 0.03]
+            p = [0.1602, 0.0712, 0.1157, 0.2937, 0.089, 0.0089, 0.0089, 0.0089, 0.0178, 0.0356, 0.0356, 0.0178, 0.0267, 0.06, 0.04, 0.01]
         elif role == abi.ROLE_AWAIT_CONDITION:
-            p = [0.47, 0.05, 0.1, 0.02, 0.1, 0.01, 0.01, 0.12, 0.02, 0.03, 0.03, 0.01, 0.03]
+            p = [0.4371, 0.0465, 0.093, 0.0186, 0.093, 0.0093, 0.0093, 0.1116, 0.0186, 0.0279, 0.0279, 0.0093, 0.0279, 0.04, 0.02, 0.01]
         elif role == abi.ROLE_PRE_VOTE:
-            p = [0.25, 0.04, 0.1, 0.02, 0.1, 0.01, 0.01, 0.01, 0.02, 0.06, 0.08, 0.27, 0.03]
+            p = [0.2225, 0.0356, 0.089, 0.0178, 0.089, 0.0089, 0.0089, 0.0089, 0.0178, 0.0534, 0.0712, 0.2403, 0.0267, 0.06, 0.04, 0.01]
         else:
-            p = [0.42, 0.06, 0.18, 0.03, 0.13, 0.01, 0.02, 0.01, 0.02, 0.04, 0.03, 0.01, 0.04]
+            p = [0.3696, 0.0528, 0.1584, 0.0264, 0.1144, 0.0088, 0.0176, 0.0088, 0.0176, 0.0352, 0.0264, 0.0088, 0.0352, 0.08, 0.03, 0.01]
         kind = int(rng.choice(kinds, p=p))
         m["kind"][q] = kind
         term = ct + int(rng.choice([-1, 0, 0, 0, 0, 1, 2], p=[0.1, 0.2, 0.2, 0.2, 0.1, 0.15, 0.05]))
@@ -207,6 +212,10 @@ def random_msgs(rng: np.random.Generator, st: np.ndarray, n_members: int, frac: 
             m["a"][q] = si
             tt = _term_at(row, si)
             m["b"][q] = tt if tt is not None else max(0, lt - int(rng.integers(0, 2)))
+        elif kind in (abi.MSG_HEARTBEAT_RPC, abi.MSG_HEARTBEAT_REPLY):
+            m["a"][q] = int(rng.integers(0, 8))
+            if rng.random() < 0.1:
+                m["from"][q] = abi.NONE
         elif kind == abi.MSG_ELECTION_TIMEOUT:
             m["c"][q] = int(rng.integers(0, 3))
         elif kind == abi.MSG_PRE_VOTE_RPC:

@@ -619,6 +619,135 @@ vec("P3", "test/ra_log_2_SUITE.erl:710-760 written_event_after_snapshot (driven 
     ], tweak=dict(current_term=1, role="leader", leader_id="n1", commit_index=2, last_applied=2),
     log_model="real")
 
+# -------------------------------------------- A.9 heartbeats / consistent-query quorum ----
+# base_state/2: self n1, term 5, leader n1, query_index 0, every peer query_index 0.
+def hb(term, leader, qi):
+    return dict(kind="heartbeat_rpc", term=term, **{"from": leader}, query_index=qi)
+
+
+def hb_reply(peer, term, qi):
+    d = dict(kind="heartbeat_reply", term=term, query_index=qi)
+    if peer is not None:
+        d["from"] = peer
+    return d
+
+
+vec("H1", "test/ra_server_SUITE.erl:3349-3388 follower_heartbeat", 3, "n1", "base", [
+    dict(reset=True, **step("follower", hb(4, "n1", 1), role="follower", state_unchanged=True,
+                             reply=dict(heartbeat=True, to="n1", term=5, query_index=1), effects_only_reply=True)),
+    dict(reset=True, **step("follower", hb(5, "n1", 1), role="follower", state_unchanged=True,
+                             reply=dict(heartbeat=True, to="n1", term=5, query_index=1), effects_only_reply=True)),
+    dict(reset=True, **step("follower", hb(6, "n1", 1), role="follower",
+                             state=dict(current_term=6, voted_for=None),
+                             reply=dict(heartbeat=True, to="n1", term=6, query_index=1), effects_only_reply=True)),
+])
+
+vec("H2", "test/ra_server_SUITE.erl:3390-3406 follower_heartbeat_reply", 3, "n1", "base", [
+    dict(reset=True, **step("follower", hb_reply("n1", 5, 2), role="follower", state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("follower", hb_reply("n1", 4, 2), role="follower", state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("follower", hb_reply("n1", 6, 2), role="follower",
+                             state=dict(current_term=6, voted_for=None), no_reply=True)),
+])
+
+vec("H3", "test/ra_server_SUITE.erl:3408-3440 candidate_heartbeat", 3, "n1", "base", [
+    dict(reset=True, **step("candidate", hb(5, "n1", 1), role="follower", state=dict(current_term=5),
+                             flags_set=["REPROCESSED"],
+                             reply=dict(heartbeat=True, to="n1", term=5, query_index=1))),
+    dict(reset=True, **step("candidate", hb(6, "n1", 1), role="follower",
+                             state=dict(current_term=6, voted_for=None), flags_set=["REPROCESSED"],
+                             reply=dict(heartbeat=True, to="n1", term=6, query_index=1))),
+    dict(reset=True, **step("candidate", hb(4, "n1", 1), role="candidate", state_unchanged=True,
+                             reply=dict(heartbeat=True, to="n1", term=5, query_index=1), effects_only_reply=True)),
+], note="the reference returns {next_event, Heartbeat}; the engine re-processes it as follower in the same "
+        "decision (the follower clause replies)")
+
+vec("H4", "test/ra_server_SUITE.erl:3442-3459 candidate_heartbeat_reply", 3, "n1", "base", [
+    dict(reset=True, **step("candidate", hb_reply(None, 5, 2), role="candidate", state_unchanged=True,
+                             no_reply=True, flags_set=["UNHANDLED"])),
+    dict(reset=True, **step("candidate", hb_reply(None, 4, 2), role="candidate", state_unchanged=True,
+                             no_reply=True, flags_set=["UNHANDLED"])),
+    dict(reset=True, **step("candidate", hb_reply(None, 6, 2), role="follower",
+                             state=dict(current_term=6, voted_for=None), no_reply=True)),
+])
+
+vec("H5", "test/ra_server_SUITE.erl:3488-3520 pre_vote_heartbeat", 3, "n1", "base", [
+    dict(reset=True, **step("pre_vote", hb(5, "n1", 1), role="follower", state=dict(votes=0, current_term=5),
+                             flags_set=["REPROCESSED"],
+                             reply=dict(heartbeat=True, to="n1", term=5, query_index=1))),
+    dict(reset=True, **step("pre_vote", hb(6, "n1", 1), role="follower",
+                             state=dict(votes=0, current_term=6, voted_for=None), flags_set=["REPROCESSED"],
+                             reply=dict(heartbeat=True, to="n1", term=6, query_index=1))),
+    dict(reset=True, **step("pre_vote", hb(4, "n1", 1), role="pre_vote", state_unchanged=True,
+                             reply=dict(heartbeat=True, to="n1", term=5, query_index=1), effects_only_reply=True)),
+], tweak=dict(votes=1))
+
+vec("H6", "test/ra_server_SUITE.erl:3522-3546 pre_vote_heartbeat_reply", 3, "n1", "base", [
+    dict(reset=True, **step("pre_vote", hb_reply(None, 5, 2), role="pre_vote", state_unchanged=True,
+                             no_reply=True, flags_set=["UNHANDLED"])),
+    dict(reset=True, **step("pre_vote", hb_reply(None, 4, 2), role="pre_vote", state_unchanged=True,
+                             no_reply=True, flags_set=["UNHANDLED"])),
+    dict(reset=True, **step("pre_vote", hb_reply(None, 6, 2), role="follower",
+                             state=dict(votes=0, current_term=6, voted_for=None), no_reply=True)),
+])
+
+vec("H7", "test/ra_server_SUITE.erl:3548-3586 leader_heartbeat", 3, "n1", "base", [
+    dict(reset=True, **step("leader", hb(5, "n1", 1), invariant=11)),
+    dict(reset=True, **step("leader", hb(6, "n1", 1), role="follower",
+                             state=dict(current_term=6, voted_for=None), flags_set=["REPROCESSED"],
+                             reply=dict(heartbeat=True, to="n1", term=6, query_index=1))),
+    dict(reset=True, **step("leader", hb(4, "n1", 1), role="leader", state_unchanged=True,
+                             reply=dict(heartbeat=True, to="n1", term=5, query_index=1), effects_only_reply=True)),
+], note="same term: exit(leader_saw_heartbeat_rpc_in_same_term); higher term: the reference clears "
+        "leader_id and returns {next_event, Msg}, re-processed here as follower")
+
+vec("H8", "test/ra_server_SUITE.erl:3614-3694 leader_heartbeat_reply_same_term", 3, "n1", "base", [
+    dict(reset=True, **step("leader", hb_reply("n2", 5, 2), role="leader", no_reply=True,
+                             peers=dict(n2=dict(peer_query_index=2)), query_quorum=2)),
+    dict(reset=True, **step("leader", hb_reply(None, 5, 2), role="leader", no_reply=True, state_unchanged=True,
+                             query_quorum=0)),
+    dict(reset=True, **step("leader", hb_reply("n2", 5, 1), role="leader", no_reply=True,
+                             peers=dict(n2=dict(peer_query_index=1)), query_quorum=1)),
+    dict(reset=True, **step("leader", hb_reply("n2", 5, 3), role="leader", no_reply=True,
+                             peers=dict(n2=dict(peer_query_index=3)), query_quorum=3)),
+], tweak=dict(query_index=3),
+    note="query_index=3 on the leader; a single reply is a consensus in a 3-node cluster: queued queries "
+         "with an index <= the consensus index are released by the host (queries_waiting_heartbeats)")
+
+vec("H9", "test/ra_server_SUITE.erl:3588-3612 leader_heartbeat_reply_node_size_5", 5, "n1", "base", [
+    step("leader", hb_reply("n2", 5, 2), role="leader", no_reply=True,
+         peers=dict(n2=dict(peer_query_index=2)), query_quorum=0),
+    step("leader", hb_reply("n3", 5, 2), role="leader", no_reply=True,
+         peers=dict(n3=dict(peer_query_index=2)), query_quorum=2),
+], tweak=dict(query_index=2), note="two of four peers are needed before query 2 is released")
+
+vec("H10", "test/ra_server_SUITE.erl:3922-3963 leader_heartbeat_reply_lower_term / _higher_term", 3, "n1", "base", [
+    dict(reset=True, **step("leader", hb_reply("n2", 4, 0), role="leader", state_unchanged=True, no_reply=True,
+                             flags_clear=["QUERY_QUORUM"])),
+    dict(reset=True, **step("leader", hb_reply("n2", 4, 1), role="leader", state_unchanged=True, no_reply=True,
+                             flags_clear=["QUERY_QUORUM"])),
+    dict(reset=True, **step("leader", hb_reply("n2", 6, 0), role="follower", no_reply=True,
+                             state=dict(current_term=6, voted_for=None, leader_id=None),
+                             flags_clear=["REPROCESSED"])),
+    dict(reset=True, **step("leader", hb_reply("n2", 6, 1), role="follower", no_reply=True,
+                             state=dict(current_term=6, voted_for=None, leader_id=None))),
+])
+
+vec("H11", "test/ra_server_SUITE.erl:3752-3790 leader_consistent_query", 3, "n1", "base", [
+    step("leader", dict(kind="consistent_query"), role="leader", state=dict(query_index=1), no_reply=True,
+         heartbeats=dict(to=["n2", "n3"], term=5, query_index=1)),
+    step("leader", dict(kind="consistent_query"), role="leader", state=dict(query_index=2), no_reply=True,
+         heartbeats=dict(to=["n2", "n3"], term=5, query_index=2)),
+], note="cluster_change_permitted = true; the QueryRef is queued by the host under the returned index")
+
+vec("H12", "test/ra_server_SUITE.erl:3800-3840 await_condition_heartbeat_dropped / _reply_dropped", 3, "n1", "base", [
+    dict(reset=True, **step("await_condition", hb(5, "n1", 0), role="await_condition", state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("await_condition", hb(6, "n1", 0), role="await_condition", state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("await_condition", hb(4, "n1", 0), role="await_condition", state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("await_condition", hb_reply("n2", 5, 0), role="await_condition", state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("await_condition", hb_reply("n2", 6, 0), role="await_condition", state_unchanged=True, no_reply=True)),
+    dict(reset=True, **step("await_condition", hb_reply("n2", 4, 0), role="await_condition", state_unchanged=True, no_reply=True)),
+], tweak=dict(role="await_condition", cond_reason="missing"))
+
 AGREED_COMMIT = [([4], 4), ([4, 3], 3), ([4, 4, 4], 4), ([4, 4, 3], 4), ([3, 4, 4], 4),
                  ([4, 2, 3], 3)]
 

@@ -46,7 +46,7 @@ def initial_state(v) -> np.ndarray:
         st["match_index"][i, :n] = 3
     tw = v.get("tweak") or {}
     for k in ("commit_index", "last_applied", "current_term", "votes", "pre_vote_token", "machine_version",
-              "effective_machine_version"):
+              "effective_machine_version", "query_index"):
         if k in tw:
             st[k][i] = tw[k]
     if "voted_for" in tw:
@@ -139,6 +139,16 @@ def make_msg(v, m) -> np.ndarray:
         out["kind"] = abi.MSG_APPEND
         out["n_entries"] = m["n"]
         out["flags"] = abi.MF_FORCE if m.get("force") else 0
+    elif k == "heartbeat_rpc":
+        out["kind"] = abi.MSG_HEARTBEAT_RPC
+        out["term"] = m["term"]
+        out["a"] = m["query_index"]
+    elif k == "heartbeat_reply":
+        out["kind"] = abi.MSG_HEARTBEAT_REPLY
+        out["term"] = m["term"]
+        out["a"] = m["query_index"]
+    elif k == "consistent_query":
+        out["kind"] = abi.MSG_CONSISTENT_QUERY
     elif k == "await_timeout":
         out["kind"] = abi.MSG_AWAIT_TIMEOUT
     elif k == "snapshot_written":
@@ -231,6 +241,11 @@ def run_vector(engine_factory, v):
         row = after[i]
         exp = s["expect"]
         flags = int(d["flags"])
+        if "invariant" in exp:
+            assert flags & abi.F_INVARIANT, f"{where}: expected the reference to exit"
+            assert int(d["invariant"]) == exp["invariant"], f"{where}: invariant {int(d['invariant'])}"
+            assert states_equal(canonical(cur[i]), canonical(row)), f"{where}: state changed by a crash"
+            continue
         assert not (flags & abi.F_INVARIANT), f"{where}: invariant {int(d['invariant'])}"
         if "role" in exp:
             assert int(d["role"]) == ROLE[exp["role"]], \
@@ -255,6 +270,9 @@ def run_vector(engine_factory, v):
             assert flags & abi.F_REPLY, f"{where}: no reply"
             assert bool(flags & abi.F_REPLY_VOTE) == bool(r.get("vote", False)), f"{where}: reply kind"
             assert bool(flags & abi.F_REPLY_PRE_VOTE) == bool(r.get("pre_vote", False)), f"{where}: reply kind"
+            assert bool(flags & abi.F_REPLY_HEARTBEAT) == bool(r.get("heartbeat", False)), f"{where}: reply kind"
+            if "query_index" in r:
+                assert int(d["reply_next_index"]) == r["query_index"], f"{where}: reply query_index"
             if "token" in r:
                 assert int(d["reply_next_index"]) == r["token"], f"{where}: reply token"
             if "to" in r:
@@ -273,9 +291,20 @@ def run_vector(engine_factory, v):
             assert [int(d["reply_last_index"]), int(d["reply_last_term"])] == q["last"], f"{where}: last log"
             if "token" in q:
                 assert int(d["reply_next_index"]) == q["token"], f"{where}: request token"
+        if "heartbeats" in exp:
+            hb = exp["heartbeats"]
+            want = sum(1 << slot(x) for x in hb["to"])
+            assert bool(flags & abi.F_SEND_HEARTBEATS) == bool(want), f"{where}: send heartbeats flag"
+            assert int(d["heartbeat_to"]) == want, f"{where}: heartbeat_to={int(d['heartbeat_to']):#x}"
+            assert int(d["reply_term"]) == hb["term"], f"{where}: heartbeat term"
+            assert int(d["reply_last_term"]) == hb["query_index"], f"{where}: heartbeat query_index"
+        if "query_quorum" in exp:
+            assert flags & abi.F_QUERY_QUORUM, f"{where}: no query quorum"
+            assert int(d["reply_next_index"]) == exp["query_quorum"], \
+                f"{where}: consensus query index {int(d['reply_next_index'])}"
         if exp.get("effects_only_reply"):
             other = flags & ~(abi.F_REPLY | abi.F_REPLY_SUCCESS | abi.F_REPLY_VOTE | abi.F_REPLY_PRE_VOTE |
-                              abi.F_PERSIST |
+                              abi.F_REPLY_HEARTBEAT | abi.F_PERSIST |
                               abi.F_LEADER_CHANGED | abi.F_ROLE_CHANGED | abi.F_REPROCESSED)
             assert other == 0, f"{where}: extra effects flags {other:#x}"
         for fn in exp.get("flags_set", []):
