@@ -9,7 +9,7 @@
 %%     server:32, kind:8, from:8, flags:8, gap:8, term:64, a:64, b:64, c:64,
 %%     n_entries:32, n_run0:32, run0_term:64, run1_term:64
 %%   rgb_decision 64 bytes:
-%%     server:32, role:8, reply_to:8, n_rpcs:8, kind:8, flags:32, invariant:32,
+%%     server:32, role:8, reply_to:8, n_rpcs:8, kind:8, flags:32, invariant:16, heartbeat_to:8, _:8,
 %%     reply_term:64, reply_next_index:64, reply_last_index:64, reply_last_term:64,
 %%     commit_index:64, last_applied:64
 -module(ra_gpu_batch).
@@ -33,6 +33,10 @@
 -define(MSG_ELECTION_TIMEOUT, 9).
 -define(MSG_PRE_VOTE_RPC, 10).
 -define(MSG_PRE_VOTE_RESULT, 11).
+-define(MSG_SNAPSHOT_WRITTEN, 12).
+-define(MSG_HEARTBEAT_RPC, 13).
+-define(MSG_HEARTBEAT_REPLY, 14).
+-define(MSG_CONSISTENT_QUERY, 15).
 -define(NONE, 255).
 -define(UNDEF, 16#FFFFFFFFFFFFFFFF).
 
@@ -46,6 +50,11 @@
 -define(F_PIPELINE, 1024).
 -define(F_INVARIANT, 32768).
 -define(F_REPLY_PRE_VOTE, 262144).
+-define(F_RESEND_PENDING, 4194304).
+-define(F_REPLY_HEARTBEAT, 8388608).
+-define(F_SEND_HEARTBEATS, 16777216).
+-define(F_QUERY_QUORUM, 33554432).
+-define(F_QUERY_APPLY, 67108864).
 
 init() ->
     erlang:load_nif(filename:join(code:priv_dir(ra), "ra_gpu_batch_nif"), 0).
@@ -79,6 +88,19 @@ encode_msg(Server, #request_vote_rpc{term = T, candidate_id = C, last_log_index 
 encode_msg(Server, {ra_log_event, {written, T, {From, To}}}, _Slot) ->
     <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, 0:8, 0:8, T:64/little, From:64/little,
       To:64/little, 0:64, 0:64, 0:64, 0:64>>;
+encode_msg(Server, {ra_log_event, {snapshot_written, {Idx, T}, _, snapshot, _, _}}, _Slot) ->
+    <<Server:32/little, ?MSG_SNAPSHOT_WRITTEN:8, ?NONE:8, 0:8, 0:8, 0:64, Idx:64/little,
+      T:64/little, 0:64, 0:64, 0:64, 0:64>>;
+encode_msg(Server, #heartbeat_rpc{term = T, leader_id = L, query_index = QI}, Slot) ->
+    <<Server:32/little, ?MSG_HEARTBEAT_RPC:8, (Slot(L)):8, 0:8, 0:8, T:64/little, QI:64/little,
+      0:(5 * 64)>>;
+encode_msg(Server, {Peer, #heartbeat_reply{term = T, query_index = QI}}, Slot) ->
+    <<Server:32/little, ?MSG_HEARTBEAT_REPLY:8, (Slot(Peer)):8, 0:8, 0:8, T:64/little,
+      QI:64/little, 0:(5 * 64)>>;
+encode_msg(Server, {consistent_query, _From, _Fun}, _Slot) ->
+    %% only while cluster_change_permitted; the QueryRef is queued by the caller under the
+    %% query index the decision returns (reply_last_term)
+    <<Server:32/little, ?MSG_CONSISTENT_QUERY:8, ?NONE:8, 0:8, 0:8, 0:(7 * 64)>>;
 encode_msg(Server, pipeline_rpcs, _Slot) ->
     <<Server:32/little, ?MSG_PIPELINE_RPCS:8, ?NONE:8, 0:8, 0:8, 0:(7 * 64)>>.
 
@@ -93,10 +115,10 @@ term_or_undef(undefined) -> ?UNDEF;
 term_or_undef(T) -> T.
 
 decode_decision(<<Server:32/little, Role:8, ReplyTo:8, NRpcs:8, Kind:8, Flags:32/little,
-                  Inv:32/little, RT:64/little, RNI:64/little, RLI:64/little, RLT:64/little,
+                  Inv:16/little, HbTo:8, _:8, RT:64/little, RNI:64/little, RLI:64/little, RLT:64/little,
                   CI:64/little, LA:64/little>>) ->
     #{server => Server, role => role(Role), reply_to => ReplyTo, n_rpcs => NRpcs, kind => Kind,
-      flags => Flags, invariant => Inv, reply_term => RT, reply_next_index => RNI,
+      flags => Flags, invariant => Inv, heartbeat_to => HbTo, reply_term => RT, reply_next_index => RNI,
       reply_last_index => RLI, reply_last_term => RLT, commit_index => CI, last_applied => LA}.
 
 role(0) -> follower; role(1) -> candidate; role(2) -> leader; role(3) -> pre_vote;
@@ -114,6 +136,10 @@ decision_to_effects(Id, Member, #{flags := F, reply_to := To} = D) ->
            F band ?F_REPLY_VOTE =/= 0 ->
                [{reply, #request_vote_result{term = maps:get(reply_term, D),
                                              vote_granted = F band ?F_REPLY_SUCCESS =/= 0}}];
+           F band ?F_REPLY_HEARTBEAT =/= 0 ->
+               [{cast, Member(To),
+                 {Id, #heartbeat_reply{term = maps:get(reply_term, D),
+                                       query_index = maps:get(reply_next_index, D)}}}];
            F band ?F_REPLY_PRE_VOTE =/= 0 ->
                [{reply, {pre_vote_result, maps:get(reply_term, D), maps:get(reply_next_index, D),
                          F band ?F_REPLY_SUCCESS =/= 0}}];
@@ -125,7 +151,16 @@ decision_to_effects(Id, Member, #{flags := F, reply_to := To} = D) ->
                                             last_index = maps:get(reply_last_index, D),
                                             last_term = maps:get(reply_last_term, D)}}}]
         end,
-    Reply
+    Heartbeats =
+        [{send_rpc, Member(Slot),
+          #heartbeat_rpc{term = maps:get(reply_term, D), leader_id = Id,
+                         query_index = maps:get(reply_last_term, D)}}
+         || F band ?F_SEND_HEARTBEATS =/= 0, Slot <- lists:seq(0, 7),
+            maps:get(heartbeat_to, D) band (1 bsl Slot) =/= 0],
+    %% F_QUERY_QUORUM: release queued queries with index =< reply_next_index (the caller owns
+    %% queries_waiting_heartbeats); F_QUERY_APPLY: no peers, apply now; F_RESEND_PENDING:
+    %% ra_log:resend_pending/2 on the host log
+    Reply ++ Heartbeats
     ++ [{record_leader_msg, Member(To)} || F band ?F_LEADER_MSG =/= 0]
     ++ [{next_event, info, pipeline_rpcs} || F band ?F_PIPELINE =/= 0]
     ++ [{aux, eval} || F band ?F_AUX_EVAL =/= 0].

@@ -5,9 +5,9 @@
  * 64/128-byte lines so that a sparse gather of servers never fetches a line it does not use.
  *
  *   hot  [S][16] u64   128 B  every message reads it, most write it back
- *        0 current_term   1 commit_index   2 last_applied     3 last_index
- *        4 last_term      5 last_written_index               6 last_written_term
- *        7 packed (role, condition, slots, masks -- see PK_*)
+ *        0 current_term   1 packed (role, condition, slots, masks -- see PK_*)
+ *        2 commit_index   3 last_applied     4 last_index       5 last_term
+ *        6 last_written_index               7 last_written_term
  *        8 snapshot_index 9 snapshot_term  10 first_index
  *        11 last-run start index           12 last-run term
  *        13 pre_vote_token   14 machine_version | effective_machine_version << 32
@@ -31,14 +31,18 @@ typedef uint32_t u32;
 #define RGB_HOT_WORDS 16
 #define RGB_QRY_WORDS 16
 
+/* 16-byte pieces hold what changes together, so a message dirties as few pieces as possible:
+ * (term, packed) votes/roles | (commit, applied) every commit advance | (last index, last term)
+ * appends | (last written index, term) written events | snapshot | range start, last-run start |
+ * last-run term, pre-vote token | machine versions, first pending index */
 #define HOT_CT    0
-#define HOT_CI    1
-#define HOT_LA    2
-#define HOT_LI    3
-#define HOT_LT    4
-#define HOT_LWI   5
-#define HOT_LWT   6
-#define HOT_PK    7
+#define HOT_PK    1
+#define HOT_CI    2
+#define HOT_LA    3
+#define HOT_LI    4
+#define HOT_LT    5
+#define HOT_LWI   6
+#define HOT_LWT   7
 #define HOT_SI    8
 #define HOT_ST    9
 #define HOT_FIRST 10

@@ -1425,7 +1425,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   u64 *hot = dev.hot + (size_t)L.server * RGB_HOT_WORDS;
   const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(hot);
   ulonglong2 h0, h1, h2, h3, h4, h5, h6, h7;
-  if (dev.dbg & 8u) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_ulonglong2(0, 0); h3.y = 0x1Full << PK_PRESENT_SH; }
+  if (dev.dbg & 8u) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_ulonglong2(0, 0); h0.y = 0x1Full << PK_PRESENT_SH; }
   else {
     h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; h7 = hp[7];
   }
@@ -1449,8 +1449,8 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(h0.x), "v"(h6.y) : "memory");
     *t_loaded = wall_clock64();
   }
-  L.ct = h0.x; L.ci = h0.y; L.la = h1.x; L.li = h1.y; L.lt = h2.x; L.lwi = h2.y; L.lwt = h3.x;
-  L.pk = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
+  L.ct = h0.x; L.pk = h0.y; L.ci = h1.x; L.la = h1.y; L.li = h2.x; L.lt = h2.y; L.lwi = h3.x;
+  L.lwt = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
   L.token = h6.y; L.macver = h7.x; L.pend = h7.y; L.vote_reqs = false;
   L.flags = 0; L.inv = 0; L.has_reply = false; L.reply_to = RGB_NONE;
   L.r_term = L.r_next = L.r_last = L.r_lterm = 0; L.w_first = L.w_last = 0;
@@ -1520,7 +1520,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     ST16(cp + 1, make_ulonglong2(L.cr2, L.cr3), wt);
   }
   /* ---- commit: query row (rare) ---- */
-  const bool q_reset = pk_get(h3.y, PK_QPEER_SH, 1) && !pk_get(L.pk, PK_QPEER_SH, 1);
+  const bool q_reset = pk_get(h0.y, PK_QPEER_SH, 1) && !pk_get(L.pk, PK_QPEER_SH, 1);
   if ((L.q_dirty || q_reset) && !(dev.dbg & 1u)) {
     u64 *q = qry_row(L);
     if (L.q_dirty & 1u) q[0] = L.qself;
@@ -1539,22 +1539,22 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
-  const bool hot_dirty = L.ct != h0.x || L.ci != h0.y || L.la != h1.x || L.li != h1.y || L.lt != h2.x ||
-                         L.lwi != h2.y || L.lwt != h3.x || L.pk != h3.y || L.si != h4.x || L.st != h4.y ||
+  const bool hot_dirty = L.ct != h0.x || L.pk != h0.y || L.ci != h1.x || L.la != h1.y || L.li != h2.x ||
+                         L.lt != h2.y || L.lwi != h3.x || L.lwt != h3.y || L.si != h4.x || L.st != h4.y ||
                          L.first != h5.x || L.lrs != h5.y || L.lrt != h6.x || L.token != h6.y ||
                          L.pend != h7.y;
   if ((dev.dbg & 64u) && hot_dirty && !(dev.dbg & 1u)) {
     /* experiment: rewrite the whole 128-byte line (no partial-line read-modify-write at memory) */
-    ho[0] = make_ulonglong2(L.ct, L.ci); ho[1] = make_ulonglong2(L.la, L.li);
-    ho[2] = make_ulonglong2(L.lt, L.lwi); ho[3] = make_ulonglong2(L.lwt, L.pk);
+    ho[0] = make_ulonglong2(L.ct, L.pk); ho[1] = make_ulonglong2(L.ci, L.la);
+    ho[2] = make_ulonglong2(L.li, L.lt); ho[3] = make_ulonglong2(L.lwi, L.lwt);
     ho[4] = make_ulonglong2(L.si, L.st); ho[5] = make_ulonglong2(L.first, L.lrs);
     ho[6] = make_ulonglong2(L.lrt, L.token); ho[7] = make_ulonglong2(L.macver, L.pend);
   } else
   if (!(dev.dbg & 1u)) {
-  if (L.ct != h0.x || L.ci != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.ci), wt);
-  if (L.la != h1.x || L.li != h1.y) ST16(ho + 1, make_ulonglong2(L.la, L.li), wt);
-  if (L.lt != h2.x || L.lwi != h2.y) ST16(ho + 2, make_ulonglong2(L.lt, L.lwi), wt);
-  if (L.lwt != h3.x || L.pk != h3.y) ST16(ho + 3, make_ulonglong2(L.lwt, L.pk), wt);
+  if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk), wt);
+  if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la), wt);
+  if (L.li != h2.x || L.lt != h2.y) ST16(ho + 2, make_ulonglong2(L.li, L.lt), wt);
+  if (L.lwi != h3.x || L.lwt != h3.y) ST16(ho + 3, make_ulonglong2(L.lwi, L.lwt), wt);
   if (L.si != h4.x || L.st != h4.y) ST16(ho + 4, make_ulonglong2(L.si, L.st), wt);
   if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs), wt);
   if (L.lrt != h6.x || L.token != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.token), wt);
@@ -1779,8 +1779,8 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
   for (int m = 0; m < N; ++m) {
     const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(dev.hot + ((size_t)g * N + m) * RGB_HOT_WORDS);
     const ulonglong2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h5 = hp[5], h6 = hp[6];
-    mb[m].ct = h0.x; mb[m].ci = h0.y; mb[m].la = h1.x; mb[m].li = h1.y; mb[m].lt = h2.x;
-    mb[m].lwi = h2.y; mb[m].lwt = h3.x; mb[m].pk = h3.y; mb[m].first = h5.x; mb[m].lrs = h5.y;
+    mb[m].ct = h0.x; mb[m].pk = h0.y; mb[m].ci = h1.x; mb[m].la = h1.y; mb[m].li = h2.x;
+    mb[m].lt = h2.y; mb[m].lwi = h3.x; mb[m].lwt = h3.y; mb[m].first = h5.x; mb[m].lrs = h5.y;
     mb[m].lrt = h6.x; mb[m].token = h6.y;
   }
 #pragma unroll
@@ -2103,11 +2103,11 @@ __global__ void rgb_leaderboard_kernel(rgb_dev dev, rgb_leaderboard_row *__restr
     const u64 pk = hot[HOT_PK];
     const u64 ct = h0.x;
     if (ct > term) term = ct;
-    if (h0.y > max_ci) max_ci = h0.y;
-    if (h1.x > max_la) max_la = h1.x;
+    if (h1.x > max_ci) max_ci = h1.x;
+    if (h1.y > max_la) max_la = h1.y;
     if (pk_get(pk, PK_ROLE_SH, 3) == RGB_ROLE_LEADER) {
       n_leaders++;
-      if (leader == RGB_NONE || ct > lead_term) { leader = m; lead_term = ct; ci = h0.y; la = h1.x; }
+      if (leader == RGB_NONE || ct > lead_term) { leader = m; lead_term = ct; ci = h1.x; la = h1.y; }
     }
   }
   rgb_leaderboard_row r;
