@@ -15,6 +15,10 @@
  *   follower    append_entries_rpc with probability 1/2 (80 % append at the tail, 5 % empty
  *               heartbeat, 5 % gap -> missing, 5 % wrong prev_log_term -> term_mismatch,
  *               5 % overlapping resend), else {written,..} for its unwritten entries (80 %)
+ *   queries     2 % of the leader's turns are a consistent_query (query_index + 1, heartbeats
+ *               requested); while a follower has not confirmed the leader's query_index it
+ *               receives the #heartbeat_rpc{} with probability 1/8, and the leader the
+ *               #heartbeat_reply{} of the first such follower with probability 1/3
  *   term churn  5 % of the groups: one member gets a request_vote_rpc with term+1
  *   elections   a leader that is behind a member's term receives that member's failed reply
  *               (steps down); a leaderless group runs election_timeout -> pre_vote_result x

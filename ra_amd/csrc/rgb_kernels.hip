@@ -1852,6 +1852,20 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
     emit(syn_msg(sid(m), RGB_MSG_SNAPSHOT_WRITTEN, RGB_NONE, 0, 0, x.la, t, 0));
     used[m] = true;
   }
+  /* ---- consistent-query heartbeats in flight: the leader's query_index and the first peer that
+   * has not confirmed it (the row is only read once a query was ever issued) ---- */
+  u64 lq = 0; int hb_lag = -1; unsigned hb_behind = 0;
+  if (pk_get(ld.pk, PK_QSELF_SH, 1)) {
+    const u64 *q = dev.qry + (size_t)sid(l) * RGB_QRY_WORDS;
+    lq = q[0];
+    const bool peers_nz = pk_get(ld.pk, PK_QPEER_SH, 1) != 0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+      if (m == l) continue;
+      const u64 qm = peers_nz ? q[1 + m] : 0;
+      if (qm < lq) { hb_behind |= 1u << m; if (hb_lag < 0) hb_lag = m; }
+    }
+  }
   /* ---- leader-side message ---- */
   if (!used[l]) {
     const u64 r = sm64(rs), r2 = sm64(rs);
@@ -1862,6 +1876,11 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
     } else if (ld.lwi < ld.li && (r & 3) == 0) {
       const u64 a = ld.lwi + 1 > ld.first ? ld.lwi + 1 : ld.first;
       emit(syn_msg(sid(l), RGB_MSG_WRITTEN, RGB_NONE, 0, ld.lt, a, ld.li, 0));
+    } else if (hb_lag >= 0 && (r >> 40) % 3 == 0) {
+      /* a follower that has not confirmed the current query index answers the heartbeat */
+      emit(syn_msg(sid(l), RGB_MSG_HEARTBEAT_REPLY, hb_lag, 0, ld.ct, lq, 0, 0));
+    } else if ((r >> 44) % 50 == 0) {
+      emit(syn_msg(sid(l), RGB_MSG_CONSISTENT_QUERY, RGB_NONE, 0, 0, 0, 0, 0));     /* 2 % */
     } else {
       const unsigned v = (unsigned)((r >> 8) % 100);
       const int j = other(l, r >> 16);
@@ -1897,7 +1916,9 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
     if (j == l || used[j]) continue;
     const SynMember &f = mb[j];
     const u64 r = sm64(rs), r2 = sm64(rs);
-    if ((r & 1) == 0) {
+    if (((hb_behind >> j) & 1u) && (r >> 40) % 8 == 0) {
+      emit(syn_msg(sid(j), RGB_MSG_HEARTBEAT_RPC, l, 0, ld.ct, lq, 0, 0));
+    } else if ((r & 1) == 0) {
       const unsigned v = (unsigned)((r >> 8) % 100);
       const u64 eterm = ld.ct > f.lt ? ld.ct : f.lt;
       u64 prev_i = f.li, prev_t = f.lt, run0 = eterm;
@@ -1948,10 +1969,11 @@ __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u6
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     u32 total = 0;
-    const unsigned kind_of_rank[13] = {RGB_MSG_AER, RGB_MSG_AER_REPLY, RGB_MSG_WRITTEN, RGB_MSG_APPEND,
-                                       RGB_MSG_PIPELINE_RPCS, RGB_MSG_REQUEST_VOTE, RGB_MSG_VOTE_RESULT,
-                                       RGB_MSG_AWAIT_TIMEOUT, RGB_MSG_ELECTION_TIMEOUT, RGB_MSG_PRE_VOTE_RPC,
-                                       RGB_MSG_PRE_VOTE_RESULT, RGB_MSG_SNAPSHOT_WRITTEN, RGB_MSG_NOP};
+    const unsigned kind_of_rank[RGB_N_CLASSES + 1] = {
+        RGB_MSG_AER, RGB_MSG_AER_REPLY, RGB_MSG_WRITTEN, RGB_MSG_APPEND, RGB_MSG_PIPELINE_RPCS,
+        RGB_MSG_REQUEST_VOTE, RGB_MSG_VOTE_RESULT, RGB_MSG_AWAIT_TIMEOUT, RGB_MSG_ELECTION_TIMEOUT,
+        RGB_MSG_PRE_VOTE_RPC, RGB_MSG_PRE_VOTE_RESULT, RGB_MSG_SNAPSHOT_WRITTEN, RGB_MSG_HEARTBEAT_RPC,
+        RGB_MSG_HEARTBEAT_REPLY, RGB_MSG_CONSISTENT_QUERY, RGB_MSG_NOP};
     for (unsigned f = 0; f < SYN_FAMILIES; ++f) {
       total += fam_total[f];
       if (kind_counts != nullptr && fam_total[f]) kind_counts[kind_of_rank[f >> 1]] += fam_total[f];

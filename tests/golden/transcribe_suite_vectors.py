@@ -527,6 +527,39 @@ vec("E9", "test/ra_server_SUITE.erl:350-353 election_timeout (non-voters ignore 
                              role="await_condition", state_unchanged=True, no_reply=True)),
 ], tweak=dict(self_nonvoter=True))
 
+# -------------------------------------------- A.6b role-specific clauses the suites also pin ----
+vec("C1", "test/ra_server_SUITE.erl:1188-1201 candidate_handles_append_entries_rpc", 3, "n1", "base", [
+    step("candidate", aer(4, "n1", (3, 5), 3, []), role="candidate",
+         reply=dict(to="n1", term=5, success=False, last_index=3, last_term=5), effects_only_reply=True),
+], tweak=dict(commit_index=1))
+
+vec("E10", "test/ra_server_SUITE.erl:1666-1680 pre_vote_receives_pre_vote", 3, "n1", "base", [
+    step("pre_vote", pre_vote(5, "n2", (3, 5), token=4242), role="pre_vote", state=dict(current_term=5),
+         reply=dict(pre_vote=True, term=5, token=4242, success=True)),
+])
+
+vec("E11", "test/ra_server_SUITE.erl:1682-1698 await_condition_receives_pre_vote", 3, "n1", "base", [
+    step("await_condition", pre_vote(5, "n2", (3, 5), token=4242), role="await_condition",
+         state=dict(current_term=5), reply=dict(pre_vote=True, term=5, token=4242, success=True)),
+], tweak=dict(role="await_condition", cond_reason="missing"))
+
+vec("E12", "test/ra_server_SUITE.erl:2620-2642 candidate_receives_pre_vote", 5, "n1", "base", [
+    dict(reset=True, **step("candidate", pre_vote(5, "n1", (3, 5), token=4242), role="candidate",
+                             reply=dict(pre_vote=True, token=4242, success=True))),
+    dict(reset=True, **step("candidate", pre_vote(5, "n1", (2, 5), token=4242), role="candidate",
+                             reply=dict(pre_vote=True, token=4242, success=False))),
+    dict(reset=True, **step("candidate", pre_vote(6, "n1", (3, 5), token=4242), role="follower",
+                             state=dict(current_term=6))),
+], tweak=dict(votes=1))
+
+vec("E13", "test/ra_server_SUITE.erl:2644-2662 leader_receives_pre_vote", 5, "n1", "base", [
+    dict(reset=True, **step("leader", pre_vote(5, "n1", (3, 5), token=4242), role="leader", no_reply=True,
+                             rpcs=[dict(peer="n2"), dict(peer="n3"), dict(peer="n4"), dict(peer="n5")],
+                             rpcs_exact=True)),
+    dict(reset=True, **step("leader", pre_vote(6, "n1", (3, 5), token=4242), role="follower",
+                             state=dict(current_term=6))),
+], tweak=dict(votes=1), note="a leader answers a same-term pre-vote with rpcs to every peer (make_all_rpcs)")
+
 # -------------------------------------------- A.7 real-log last_written cursor ----
 vec("R1", "test/ra_log_2_SUITE.erl:189-211 (driven through follower AERs)", 3, "n2", "empty", [
     step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1)]), role="follower"),
