@@ -15,8 +15,8 @@ _LIB_PATH = os.path.join(_HERE, "libra_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "ra_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ra_oracle.c", "wal_oracle.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libra_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -50,8 +50,30 @@ def lib():
         L.ora_struct_size.argtypes = [C.c_int]
         for i, dt in enumerate(abi.STRUCT_DTYPES):
             assert L.ora_struct_size(i) == dt.itemsize, (i, L.ora_struct_size(i), dt.itemsize)
+        L.ora_adler32_update.restype = C.c_uint32
+        L.ora_adler32_update.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
+        L.ora_wal_entry_checksum.restype = C.c_uint32
+        L.ora_wal_entry_checksum.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32]
         _lib = L
     return _lib
+
+
+def adler32(data: bytes, start: int = 1) -> int:
+    """RFC 1950 Adler-32 (wal_oracle.c)."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    return int(lib().ora_adler32_update(start, buf.ctypes.data if len(buf) else None, len(buf)))
+
+
+def wal_entry_checksums(entries: np.ndarray, data: np.ndarray) -> np.ndarray:
+    """erlang:adler32([<<Idx:64, Term:64>> | EntryData]) per rgb_wal_entry (src/ra_log_wal.erl:528-534)."""
+    L = lib()
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros(len(entries), dtype=np.uint32)
+    for i, e in enumerate(entries):
+        off, ln = int(e["data_offset"]), int(e["data_len"])
+        out[i] = L.ora_wal_entry_checksum(int(e["index"]), int(e["term"]),
+                                          data.ctypes.data + off if ln else None, ln)
+    return out
 
 
 def agreed_commit(indexes) -> int:

@@ -122,6 +122,11 @@ CONFIG_DTYPE = np.dtype([
     ("ring_capacity", u32), ("max_pipeline_count", u32), ("max_aer_batch", u32), ("flags", u32),
 ])
 
+# include/ra_gpu_wal.h
+WAL_ENTRY_DTYPE = np.dtype([("index", u64), ("term", u64), ("data_offset", u64), ("data_len", u32),
+                            ("_pad", u32)])
+assert WAL_ENTRY_DTYPE.itemsize == 32
+
 STRUCT_DTYPES = [MSG_DTYPE, DECISION_DTYPE, RPC_DTYPE, SERVER_STATE_DTYPE, LEADERBOARD_DTYPE,
                  CONFIG_DTYPE]
 EXPECTED_SIZES = [64, 64, 56, 672, 32, 32]

@@ -1,0 +1,143 @@
+/*
+ * rgb_wal.hip -- Adler-32 of a batch of WAL entries (include/ra_gpu_wal.h; reference
+ * src/ra_log_wal.erl:528-534, 861, 873, 1028).  One wavefront (or a quarter of one) per entry; bytes
+ * stream through 16-byte lane loads, sums through v_dot4_u32_u8.  HBM-bound: every payload byte is read once.
+ *
+ * Adler-32 (RFC 1950 8.2) of bytes d_0..d_{n-1}:  A = 1 + sum d_i,  B = n + sum (n - i) d_i,
+ * both mod 65521, checksum = B << 16 | A.  The weighted sum is additive over any partition of the
+ * bytes, so each lane handles whole 16-byte aligned chunks with local sums
+ *     a = sum d_j,  b = sum (16 - j) d_j        (j = 0..15 inside the chunk)
+ * and a chunk that starts s bytes into the stream contributes  (W - s - 16) * a + b  where W is
+ * the weight of the stream's first byte.  Bytes outside the payload are masked to zero, which
+ * makes the entry's alignment irrelevant.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ra_gpu_wal.h"
+
+namespace {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+#define ADLER_MOD 65521u
+#define WAL_WAVES_PER_BLOCK 4
+#define WAL_UNROLL 4            /* 16-byte loads in flight per lane: 4 KiB per wavefront iteration */
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32 dot4(u32 a, u32 b, u32 c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+
+/* local sums of one 16-byte chunk (little-endian dwords, byte 0 = lowest address) */
+__device__ __forceinline__ void chunk_sums(const uint4 v, u32 &a, u32 &b) {
+  a = dot4(v.x, 0x01010101u, 0); a = dot4(v.y, 0x01010101u, a);
+  a = dot4(v.z, 0x01010101u, a); a = dot4(v.w, 0x01010101u, a);
+  b = dot4(v.x, 0x0D0E0F10u, 0); b = dot4(v.y, 0x090A0B0Cu, b);
+  b = dot4(v.z, 0x05060708u, b); b = dot4(v.w, 0x01020304u, b);
+}
+
+/* 0xFF for every byte of the dword at chunk bytes [first, first+4) that lies inside [lo, hi) */
+__device__ __forceinline__ u32 byte_mask(u32 first, u32 lo, u32 hi) {
+  u32 m = 0;
+#pragma unroll
+  for (u32 b = 0; b < 4; ++b) if (first + b >= lo && first + b < hi) m |= 0xFFu << (8 * b);
+  return m;
+}
+
+/* sum over the GROUP lanes that share a record (xor butterflies stay inside aligned groups) */
+template <int GROUP>
+__device__ __forceinline__ u32 group_sum(u32 v) {
+#pragma unroll
+  for (int off = GROUP / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+/* GROUP lanes per entry: 64 (one wavefront per entry) for KiB-sized payloads, 16 (four entries per
+ * wavefront) for small ones -- the host picks by the batch's mean payload size. */
+template <int GROUP>
+__global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_adler32_kernel(
+    const rgb_wal_entry *__restrict__ entries, u32 n, const unsigned char *__restrict__ data,
+    u32 *__restrict__ out) {
+  constexpr u32 PER_BLOCK = WAL_WAVES_PER_BLOCK * 64 / GROUP;
+  const u32 lane = threadIdx.x & (GROUP - 1);
+  const u32 e = blockIdx.x * PER_BLOCK + threadIdx.x / GROUP;
+  const bool live = e < n;
+  rgb_wal_entry en;
+  en.index = en.term = en.data_offset = 0; en.data_len = 0; en._pad = 0;
+  if (live) en = entries[e];
+  const u64 off = en.data_offset;
+  const u32 len = en.data_len;
+  const u32 lead = (u32)(off & 15ull);                 /* masked bytes in front of the payload */
+  const v4u *base = reinterpret_cast<const v4u *>(data + (off - lead));
+  const u32 span = lead + len;                         /* aligned stream: [0, span) */
+  const u32 n_chunks = live ? (span + 15u) >> 4 : 0u;
+  const u32 span_q = span % ADLER_MOD;
+  /* weight of stream byte j is (len + lead) - j: the last payload byte weighs 1 */
+  u32 a_acc = 0, b_acc = 0;                            /* per lane, folded before they can wrap */
+  for (u32 c0 = 0; c0 < n_chunks; c0 += GROUP * WAL_UNROLL) {
+    uint4 v[WAL_UNROLL];
+#pragma unroll
+    for (int k = 0; k < WAL_UNROLL; ++k) {
+      const u32 c = c0 + (u32)k * GROUP + lane;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (c < n_chunks) { const v4u t = __builtin_nontemporal_load(base + c); v[k] = make_uint4(t.x, t.y, t.z, t.w); }
+    }
+#pragma unroll
+    for (int k = 0; k < WAL_UNROLL; ++k) {
+      const u32 c = c0 + (u32)k * GROUP + lane;
+      if (c >= n_chunks) continue;
+      const u32 s = c << 4;
+      uint4 w = v[k];
+      /* mask the bytes before the payload (first chunk) and after it (last chunk) */
+      if (s < lead || s + 16u > span) {
+        const u32 lo = s < lead ? lead - s : 0u, hi = span - s < 16u ? span - s : 16u;
+        w.x &= byte_mask(0, lo, hi); w.y &= byte_mask(4, lo, hi);
+        w.z &= byte_mask(8, lo, hi); w.w &= byte_mask(12, lo, hi);
+      }
+      u32 a, b;
+      chunk_sums(w, a, b);
+      /* (W - s - 16) may be negative on the last chunk: work modulo 65521 */
+      const u32 wq = (span_q + 2u * ADLER_MOD - (s % ADLER_MOD) - 16u) % ADLER_MOD;
+      a_acc += a;                                      /* <= 4080 per chunk */
+      b_acc += (wq * a + b) % ADLER_MOD;
+      if (b_acc >= 0x7FFF0000u) b_acc %= ADLER_MOD;
+      if (a_acc >= 0x7FFF0000u) a_acc %= ADLER_MOD;
+    }
+  }
+  const u32 a_sum = group_sum<GROUP>(a_acc % ADLER_MOD);   /* GROUP * 65520 fits */
+  const u32 b_sum = group_sum<GROUP>(b_acc % ADLER_MOD);
+  if (live && lane == 0) {
+    /* the 16 framed bytes <<Idx:64, Term:64>> in front are one more chunk whose byte k weighs
+     * n - k = len + (16 - k): big-endian words, so the dot4 weight vectors run the other way */
+    const u32 ih = (u32)(en.index >> 32), il = (u32)en.index, th = (u32)(en.term >> 32), tl = (u32)en.term;
+    u32 pa = dot4(ih, 0x01010101u, 0); pa = dot4(il, 0x01010101u, pa);
+    pa = dot4(th, 0x01010101u, pa); pa = dot4(tl, 0x01010101u, pa);
+    u32 pb = dot4(ih, 0x100F0E0Du, 0); pb = dot4(il, 0x0C0B0A09u, pb);
+    pb = dot4(th, 0x08070605u, pb); pb = dot4(tl, 0x04030201u, pb);
+    const u32 len_q = len % ADLER_MOD;
+    const u32 A = (1u + pa + a_sum) % ADLER_MOD;
+    const u32 B = ((16u + len_q) + (len_q * pa + pb) % ADLER_MOD + b_sum) % ADLER_MOD;
+    out[e] = (B << 16) | A;
+  }
+}
+
+}  // namespace
+
+/* the context only supplies the default stream; rgb_api.hip exports the accessor */
+extern "C" void *rgb_ctx_stream(rgb_ctx *ctx);
+
+extern "C" int rgb_wal_adler32_device(rgb_ctx *ctx, const void *d_entries, uint32_t n, const void *d_data,
+                                      uint64_t data_bytes, void *d_checksums, void *stream) {
+  if (!ctx || (n && (!d_entries || !d_checksums))) return RGB_E_INVAL;
+  if (n == 0) return RGB_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)rgb_ctx_stream(ctx);
+  /* lanes per entry by the batch's mean payload: four entries per wavefront below 1 KiB */
+  if (data_bytes / n < 1024u) {
+    const u32 per = WAL_WAVES_PER_BLOCK * 64 / 16;
+    hipLaunchKernelGGL(rgb_wal_adler32_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                       (const rgb_wal_entry *)d_entries, n, (const unsigned char *)d_data, (u32 *)d_checksums);
+  } else {
+    const u32 per = WAL_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(rgb_wal_adler32_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                       (const rgb_wal_entry *)d_entries, n, (const unsigned char *)d_data, (u32 *)d_checksums);
+  }
+  return hipGetLastError() == hipSuccess ? RGB_OK : RGB_E_HIP;
+}

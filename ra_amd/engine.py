@@ -24,6 +24,7 @@ EXPORTS = [
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize",
 ]
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_apply_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
+WAL_EXPORTS = ["rgb_wal_adler32_device"]                                     # include/ra_gpu_wal.h
 
 
 class RgbError(RuntimeError):
@@ -34,7 +35,8 @@ class RgbError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("rgb_kernels.hip", "rgb_api.hip", "rgb_internal.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("rgb_kernels.hip", "rgb_api.hip", "rgb_wal.hip", "rgb_internal.h")]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "ra_gpu_wal.h"))
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "ra_gpu_batch.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -64,7 +66,7 @@ def lib():
     except Exception:  # pragma: no cover - torch is optional for the binding
         pass
     L = C.CDLL(LIB_PATH)
-    for name in EXPORTS:
+    for name in EXPORTS + SYNTH_EXPORTS + WAL_EXPORTS:
         if not hasattr(L, name):
             raise RuntimeError(f"libra_gpu_batch.so does not export {name}")
     vp, u32, u64p = C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)
@@ -91,6 +93,7 @@ def lib():
     L.rgb_synchronize.argtypes = [vp]
     L.rgb_synth_tick_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
+    L.rgb_wal_adler32_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, vp]
     if L.rgb_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("ABI version mismatch")
     for i, dt in enumerate(abi.STRUCT_DTYPES):
@@ -244,6 +247,14 @@ class RaGpuBatch:
         """Apply the tick just generated by synth_tick_device (class-dispatch kernel sized on-device)."""
         self._check(self._L.rgb_synth_apply_tick_device(self._h, d_msgs, max_msgs, d_decisions, d_rpcs or None,
                                                         stream or None), "rgb_synth_apply_tick_device")
+
+    # -- WAL entry checksums (include/ra_gpu_wal.h) -----------------------------------
+    def wal_adler32_device(self, d_entries: int, n: int, d_data: int, data_bytes: int, d_checksums: int,
+                           stream: int = 0):
+        """adler32(<<Idx:64, Term:64, Payload>>) of n rgb_wal_entry records whose payloads are
+        resident in device memory (src/ra_log_wal.erl:528-534, 861, 873, 1028); enqueues and returns."""
+        self._check(self._L.rgb_wal_adler32_device(self._h, d_entries, n, d_data, data_bytes, d_checksums,
+                                                   stream or None), "rgb_wal_adler32_device")
 
     # -- observability -----------------------------------------------------------------
     def snapshot(self) -> np.ndarray:
