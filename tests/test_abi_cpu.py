@@ -11,8 +11,8 @@ from ra_amd import abi, engine
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "ra_gpu_batch.h")).read()
+def declared_functions(header="ra_gpu_batch.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(rgb_[a-z0-9_]+)\s*\(", src)))
 
@@ -29,6 +29,14 @@ def test_header_functions_are_all_exported(L):
     for n in names:
         assert hasattr(L, n), f"libra_gpu_batch.so does not export {n}"
     assert sorted(engine.EXPORTS) == names
+    # every header under include/ is covered: the load generator and the WAL checksum entry points
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["ra_gpu_batch.h", "ra_gpu_batch_synth.h",
+                                                                  "ra_gpu_wal.h"]
+    for header, listed in (("ra_gpu_batch_synth.h", engine.SYNTH_EXPORTS), ("ra_gpu_wal.h", engine.WAL_EXPORTS)):
+        names = declared_functions(header)
+        assert sorted(listed) == names, header
+        for n in names:
+            assert hasattr(L, n), f"libra_gpu_batch.so does not export {n} ({header})"
 
 
 def test_struct_sizes_match_numpy_mirrors(L):

@@ -59,6 +59,23 @@ def test_oracle_wal_entry_checksum_matches_zlib():
     assert O.wal_entry_checksums(entries[3:4], data)[0] == zlib.adler32(frame(int(e0["index"]), int(e0["term"]), payload))
 
 
+def test_oracle_detects_overwritten_bytes():
+    """test/ra_log_wal_SUITE.erl:1500-1528 checksum_failure_in_middle_of_file_should_fail: 1000-byte
+    entries, ten bytes of one record overwritten with zeros -> validation must fail for that record
+    (and only for it)."""
+    rng = np.random.default_rng(3)
+    entries, data = make_batch(rng, [1000] * 100, misalign=False)
+    entries["term"] = 1
+    entries["index"] = np.arange(1, 101)
+    stored = O.wal_entry_checksums(entries, data)
+    victim = 42
+    o = int(entries["data_offset"][victim])
+    data[o + 500:o + 510] = np.where(data[o + 500:o + 510] == 0, 1, 0)     # guaranteed to differ
+    again = O.wal_entry_checksums(entries, data)
+    assert again[victim] != stored[victim]
+    assert np.array_equal(np.delete(again, victim), np.delete(stored, victim))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("misalign", [True, False])
 def test_gpu_wal_checksums_match_oracle_and_zlib(misalign):
