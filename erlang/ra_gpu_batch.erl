@@ -15,7 +15,8 @@
 -module(ra_gpu_batch).
 
 -export([init/0, open/4, register_groups/3, upload_state/3, download_state/3,
-         submit/3, collect/1, start_collector/2, snapshot/2]).
+         submit/3, collect/1, start_collector/2, snapshot/2, wal_checksums/3]).
+-export([wal_batch_checksums/2]).
 -export([encode_msg/3, decode_decision/1, decision_to_effects/3]).
 
 -include_lib("ra/src/ra.hrl").
@@ -67,6 +68,19 @@ submit(_Ctx, _MsgsBin, _Tick) -> erlang:nif_error(not_loaded).
 collect(_Ctx) -> erlang:nif_error(not_loaded).
 start_collector(_Ctx, _Pid) -> erlang:nif_error(not_loaded).
 snapshot(_Ctx, _NGroups) -> erlang:nif_error(not_loaded).
+wal_checksums(_Ctx, _EntriesBin, _DataBin) -> erlang:nif_error(not_loaded).
+
+%% ra_log_wal:write_data/8 computes erlang:adler32([<<Idx:64, Term:64>> | EntryData]) per record
+%% (src/ra_log_wal.erl:528-534); for a whole write_batch: Entries = [{Idx, Term, Bin}].
+wal_batch_checksums(Ctx, Entries) ->
+    {EntriesBin, Data, _} =
+        lists:foldl(fun({Idx, Term, Bin}, {E, D, Off}) ->
+                            Len = byte_size(Bin),
+                            {<<E/binary, Idx:64/little, Term:64/little, Off:64/little,
+                               Len:32/little, 0:32>>, [D, Bin], Off + Len}
+                    end, {<<>>, [], 0}, Entries),
+    {ok, Sums} = wal_checksums(Ctx, EntriesBin, iolist_to_binary(Data)),
+    [C || <<C:32/little>> <= Sums].
 
 %% Slot = fun(ra_server_id()) -> 0..7 | 255, the member slot of a server id inside its group.
 encode_msg(Server, #append_entries_rpc{term = T, leader_id = L, leader_commit = LC,

@@ -40,6 +40,12 @@ typedef struct rgb_wal_entry {
 int rgb_wal_adler32_device(rgb_ctx *ctx, const void *d_entries, uint32_t n, const void *d_data,
                            uint64_t data_bytes, void *d_checksums, void *stream);
 
+/* Host-buffer form (what the NIF binds): entries and the packed payload bytes come from host
+ * memory, the n checksums go back to host memory.  Stages through device buffers the context
+ * keeps (grown on demand), synchronises before returning: PCIe-inclusive. */
+int rgb_wal_adler32(rgb_ctx *ctx, const rgb_wal_entry *entries, uint32_t n, const void *data,
+                    uint64_t data_bytes, uint32_t *checksums);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@
 
 #include "erl_nif.h"
 #include "ra_gpu_batch.h"
+#include "ra_gpu_wal.h"
 
 typedef struct {
   rgb_ctx *ctx;
@@ -191,6 +192,23 @@ static int on_load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info) {
   return CTX_TYPE == NULL || rgb_abi_version() != RGB_ABI_VERSION;
 }
 
+/* wal_checksums(Ctx, EntriesBin, DataBin) -> {ok, ChecksumsBin}: EntriesBin = n rgb_wal_entry records
+ * (index, term, data_offset, data_len), DataBin = the packed payload bytes of the write batch,
+ * ChecksumsBin = n little-endian 32-bit Adler-32 values (erlang:adler32([<<Idx:64,Term:64>> | Data]),
+ * src/ra_log_wal.erl:528-534) */
+static ERL_NIF_TERM nif_wal_checksums(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c; ErlNifBinary e, d, out;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &e) ||
+      !enif_inspect_binary(env, argv[2], &d) || e.size % sizeof(rgb_wal_entry) != 0)
+    return enif_make_badarg(env);
+  const uint32_t n = (uint32_t)(e.size / sizeof(rgb_wal_entry));
+  if (!enif_alloc_binary((size_t)n * sizeof(uint32_t), &out)) return mk_error(env, c, RGB_E_NOMEM);
+  int rc = rgb_wal_adler32(c->ctx, (const rgb_wal_entry *)e.data, n, d.data, d.size, (uint32_t *)out.data);
+  if (rc) { enif_release_binary(&out); return mk_error(env, c, rc); }
+  return enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_binary(env, &out));
+}
+
 static ErlNifFunc nif_funcs[] = {
   {"open", 4, nif_open, 0},
   {"register_groups", 3, nif_register_groups, ERL_NIF_DIRTY_JOB_IO_BOUND},
@@ -200,6 +218,7 @@ static ErlNifFunc nif_funcs[] = {
   {"collect", 1, nif_collect, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"start_collector", 2, nif_start_collector, 0},
   {"snapshot", 2, nif_snapshot, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"wal_checksums", 3, nif_wal_checksums, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(ra_gpu_batch, nif_funcs, on_load, NULL, NULL, NULL)

@@ -76,6 +76,8 @@ static int launch_tick_classes(rgb_ctx *ctx, const rgb_msg *m, rgb_decision *d, 
   return RGB_OK;
 }
 
+extern "C" void rgb_wal_release(rgb_ctx *ctx);   /* rgb_wal.hip: staging buffers of the host-buffer form */
+
 extern "C" {
 
 uint32_t rgb_abi_version(void) { return RGB_ABI_VERSION; }
@@ -135,6 +137,7 @@ static void free_slot(rgb_slot &s) {
 void rgb_close(rgb_ctx *ctx) {
   if (!ctx) return;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  rgb_wal_release(ctx);
   for (auto &s : ctx->ring) free_slot(s);
   if (ctx->dev.hot) (void)hipFree(ctx->dev.hot);
   if (ctx->dev.peers) (void)hipFree(ctx->dev.peers);

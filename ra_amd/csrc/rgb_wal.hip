@@ -141,3 +141,57 @@ extern "C" int rgb_wal_adler32_device(rgb_ctx *ctx, const void *d_entries, uint3
   }
   return hipGetLastError() == hipSuccess ? RGB_OK : RGB_E_HIP;
 }
+
+/* ---- host-buffer form: staging buffers live beside the context (keyed by it), grown on demand ---- */
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct wal_stage { void *d_entries = nullptr; void *d_data = nullptr; void *d_out = nullptr; size_t cap_e = 0, cap_d = 0; };
+std::mutex g_stage_mu;
+std::unordered_map<rgb_ctx *, wal_stage> g_stage;
+int grow(void **p, size_t *cap, size_t need) {
+  if (need <= *cap) return 0;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  const size_t want = need + need / 2 + 4096;
+  if (hipMalloc(p, want) != hipSuccess) return -1;
+  *cap = want;
+  return 0;
+}
+}  // namespace
+
+extern "C" void rgb_wal_release(rgb_ctx *ctx) {      /* called by rgb_close */
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  auto it = g_stage.find(ctx);
+  if (it == g_stage.end()) return;
+  if (it->second.d_entries) (void)hipFree(it->second.d_entries);
+  if (it->second.d_data) (void)hipFree(it->second.d_data);
+  if (it->second.d_out) (void)hipFree(it->second.d_out);
+  g_stage.erase(it);
+}
+
+extern "C" int rgb_wal_adler32(rgb_ctx *ctx, const rgb_wal_entry *entries, uint32_t n, const void *data,
+                               uint64_t data_bytes, uint32_t *checksums) {
+  if (!ctx || (n && (!entries || !checksums)) || (data_bytes && !data)) return RGB_E_INVAL;
+  if (n == 0) return RGB_OK;
+  for (uint32_t i = 0; i < n; ++i)
+    if (entries[i].data_offset + entries[i].data_len > data_bytes) return RGB_E_INVAL;
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  wal_stage &s = g_stage[ctx];
+  size_t cap_o = s.cap_e / sizeof(rgb_wal_entry) * sizeof(u32);
+  const size_t need_e = (size_t)n * sizeof(rgb_wal_entry);
+  if (need_e > s.cap_e) {
+    if (s.d_out) { (void)hipFree(s.d_out); s.d_out = nullptr; }
+    if (grow(&s.d_entries, &s.cap_e, need_e)) return RGB_E_NOMEM;
+    cap_o = s.cap_e / sizeof(rgb_wal_entry) * sizeof(u32);
+    if (hipMalloc(&s.d_out, cap_o) != hipSuccess) return RGB_E_NOMEM;
+  }
+  if (grow(&s.d_data, &s.cap_d, (size_t)data_bytes + 16)) return RGB_E_NOMEM;
+  hipStream_t st = (hipStream_t)rgb_ctx_stream(ctx);
+  if (hipMemcpyAsync(s.d_entries, entries, need_e, hipMemcpyHostToDevice, st) != hipSuccess) return RGB_E_HIP;
+  if (data_bytes && hipMemcpyAsync(s.d_data, data, data_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return RGB_E_HIP;
+  int rc = rgb_wal_adler32_device(ctx, s.d_entries, n, s.d_data, data_bytes, s.d_out, st);
+  if (rc) return rc;
+  if (hipMemcpyAsync(checksums, s.d_out, (size_t)n * sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess) return RGB_E_HIP;
+  return hipStreamSynchronize(st) == hipSuccess ? RGB_OK : RGB_E_HIP;
+}

@@ -24,7 +24,7 @@ EXPORTS = [
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize",
 ]
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_apply_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
-WAL_EXPORTS = ["rgb_wal_adler32_device"]                                     # include/ra_gpu_wal.h
+WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32"]                                     # include/ra_gpu_wal.h
 
 
 class RgbError(RuntimeError):
@@ -94,6 +94,7 @@ def lib():
     L.rgb_synth_tick_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     L.rgb_wal_adler32_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, vp]
+    L.rgb_wal_adler32.argtypes = [vp, vp, u32, vp, C.c_uint64, vp]
     if L.rgb_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("ABI version mismatch")
     for i, dt in enumerate(abi.STRUCT_DTYPES):
@@ -255,6 +256,16 @@ class RaGpuBatch:
         resident in device memory (src/ra_log_wal.erl:528-534, 861, 873, 1028); enqueues and returns."""
         self._check(self._L.rgb_wal_adler32_device(self._h, d_entries, n, d_data, data_bytes, d_checksums,
                                                    stream or None), "rgb_wal_adler32_device")
+
+    def wal_adler32(self, entries: np.ndarray, data: np.ndarray) -> np.ndarray:
+        """Host-buffer form: checksums of `entries` (abi.WAL_ENTRY_DTYPE) over the packed payload bytes."""
+        entries = np.ascontiguousarray(entries, dtype=abi.WAL_ENTRY_DTYPE)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        out = np.zeros(len(entries), dtype=np.uint32)
+        self._check(self._L.rgb_wal_adler32(self._h, entries.ctypes.data, len(entries),
+                                            data.ctypes.data if len(data) else None, len(data),
+                                            out.ctypes.data), "rgb_wal_adler32")
+        return out
 
     # -- observability -----------------------------------------------------------------
     def snapshot(self) -> np.ndarray:

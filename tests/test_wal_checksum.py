@@ -101,6 +101,22 @@ def test_gpu_wal_checksums_match_oracle_and_zlib(misalign):
 
 
 @pytest.mark.gpu
+def test_gpu_wal_host_buffer_form():
+    """rgb_wal_adler32: host buffers in, host checksums out (what the NIF binds); grows its staging."""
+    from ra_amd import engine
+    rng = np.random.default_rng(31)
+    eng = engine.RaGpuBatch(1, 1)
+    for lens in ([0, 5, 100, 4096], [int(x) for x in rng.integers(0, 9000, size=500)], [1 << 20, 3]):
+        entries, data = make_batch(rng, lens, True)
+        assert np.array_equal(eng.wal_adler32(entries, data), zlib_checksums(entries, data))
+    bad = np.zeros(1, dtype=abi.WAL_ENTRY_DTYPE)
+    bad["data_offset"] = 10; bad["data_len"] = 100
+    with pytest.raises(engine.RgbError):
+        eng.wal_adler32(bad, np.zeros(50, dtype=np.uint8))          # payload outside the buffer
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_gpu_wal_checksums_small_entries():
     """Mean payload below 1 KiB: the four-entries-per-wavefront variant."""
     import torch
