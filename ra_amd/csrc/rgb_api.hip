@@ -34,6 +34,8 @@ struct rgb_slot {
   rgb_msg *d_msgs = nullptr;
   rgb_decision *d_dec = nullptr;
   rgb_rpc *d_rpcs = nullptr;
+  rgb_rpc *h_rpcs = nullptr;        /* pinned: the fixed rpc slots of device positions [rpc_lo, rpc_lo+rpc_cnt) */
+  u32 rpc_lo = 0, rpc_cnt = 0;
   std::vector<u32> perm;            /* device position -> submission index */
   u32 n = 0;
   uint64_t tick = 0;
@@ -56,7 +58,7 @@ struct rgb_ctx {
   u32 head = 0, tail = 0, in_flight = 0;
   u32 rpc_cap = 0;      /* records per ring slot = ring_capacity * rpc_stride */
   u32 rpc_stride = 1;   /* fixed rpc slots per message = max(n_members-1, 1) */
-  std::vector<rgb_rpc> h_rpc_tmp;
+
   /* sub-tick scheduling scratch */
   std::vector<uint16_t> seen;
   std::vector<u32> touched;
@@ -130,6 +132,7 @@ static void free_slot(rgb_slot &s) {
   if (s.d_msgs) (void)hipFree(s.d_msgs);
   if (s.d_dec) (void)hipFree(s.d_dec);
   if (s.d_rpcs) (void)hipFree(s.d_rpcs);
+  if (s.h_rpcs) (void)hipHostFree(s.h_rpcs);
   if (s.done) (void)hipEventDestroy(s.done);
   s = rgb_slot();
 }
@@ -190,6 +193,7 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   HIPCHK(ctx, hipMalloc((void **)&s.d_msgs, (size_t)cap * sizeof(rgb_msg)));
   HIPCHK(ctx, hipMalloc((void **)&s.d_dec, (size_t)cap * sizeof(rgb_decision)));
   HIPCHK(ctx, hipMalloc((void **)&s.d_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc)));
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc), hipHostMallocDefault));
   HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   return RGB_OK;
 }
@@ -399,6 +403,25 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     }
     HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost,
                                ctx->stream));
+    /* the fixed rpc slots come back with the decisions, but only the span of device positions whose
+     * message kind can emit rpcs (the batch is in family order, so the append_entries_rpc / written
+     * bulk in front of and behind that span is never copied) */
+    u32 lo = n, hi = 0;
+    for (u32 p = 0; p < n; ++p) {
+      const unsigned k = s.h_msgs[p].kind;
+      if (k == RGB_MSG_AER_REPLY || k == RGB_MSG_APPEND || k == RGB_MSG_PIPELINE_RPCS ||
+          k == RGB_MSG_VOTE_RESULT || k == RGB_MSG_PRE_VOTE_RPC) {
+        if (p < lo) lo = p;
+        hi = p;
+      }
+    }
+    s.rpc_lo = lo < n ? lo : 0; s.rpc_cnt = lo < n ? hi - lo + 1 : 0;
+    if (s.rpc_cnt)
+      HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
+                                 (size_t)s.rpc_cnt * ctx->rpc_stride * sizeof(rgb_rpc), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+  } else {
+    s.rpc_lo = s.rpc_cnt = 0;
   }
   HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
   s.busy = true;
@@ -419,23 +442,21 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
   HIPCHK(ctx, hipEventSynchronize(s.done));
   /* decisions back in submission order; remember where each one ran on the device */
   std::vector<u32> pos_of(s.n);
-  u32 n_rpc = 0, last_with = 0;
-  bool any = false;
+  u32 n_rpc = 0;
   for (u32 p = 0; p < s.n; ++p) {
     out[s.perm[p]] = s.h_dec[p];
     pos_of[s.perm[p]] = p;
-    if (s.h_dec[p].n_rpcs) { n_rpc += s.h_dec[p].n_rpcs; last_with = p; any = true; }
+    n_rpc += s.h_dec[p].n_rpcs;
   }
-  if (any && rpc_out) {
-    /* the fixed rpc slots of messages [0, last_with] */
-    size_t recs = (size_t)(last_with + 1) * ctx->rpc_stride;
-    ctx->h_rpc_tmp.resize(recs);
-    HIPCHK(ctx, hipMemcpy(ctx->h_rpc_tmp.data(), s.d_rpcs, recs * sizeof(rgb_rpc), hipMemcpyDeviceToHost));
+  if (n_rpc && rpc_out) {
     u32 k = 0;
     for (u32 i = 0; i < s.n && k < rpc_cap; ++i) {           /* ordered by (msg_index, peer) */
-      u32 p = pos_of[i];
-      for (u32 q = 0; q < s.h_dec[p].n_rpcs && k < rpc_cap; ++q) {
-        rgb_rpc r = ctx->h_rpc_tmp[(size_t)p * ctx->rpc_stride + q];
+      const u32 p = pos_of[i];
+      const u32 nr = s.h_dec[p].n_rpcs;
+      if (!nr) continue;
+      if (p < s.rpc_lo || p >= s.rpc_lo + s.rpc_cnt) return RGB_E_STATE;   /* a kind that cannot emit rpcs did */
+      for (u32 q = 0; q < nr && k < rpc_cap; ++q) {
+        rgb_rpc r = s.h_rpcs[(size_t)(p - s.rpc_lo) * ctx->rpc_stride + q];
         r.msg_index = i;
         rpc_out[k++] = r;
       }

@@ -265,6 +265,31 @@ def test_device_generated_stream_matches_oracle(engine_mod, oracle_lib, n_member
         assert (rows["n_leaders"] == 1).mean() > 0.6
 
 
+def test_config2_small_batches_through_the_host_path(engine_mod, oracle_lib):
+    """BASELINE configs[1] as specified: 4 096 groups x 5 members, 256 messages per tick (50 % follower
+    append_entries, 50 % leader success replies, seed 0x5EED0002) through rgb_submit / rgb_collect --
+    the path the NIF binds; every decision, every rpc and the full final state equal the oracle's."""
+    from ra_amd import workload as W
+    G, N, seed = 4096, 5, 0x5EED0002
+    st = W.initial_states(G, N, seed)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(G, N, max_runs=16, ring_capacity=1024, ring_slots=4) as gpu:
+        gpu.set_state(0, st)
+        n_dec = 0
+        for t in range(200):
+            m = W.gen_tick(cpu.get_state(), N, t, seed, W.MIX_CONFIG2, groups_per_tick=256, housekeeping=False)
+            assert 0 < len(m) <= 256
+            do, ro = cpu.step(m)
+            dg, rg = gpu.step(m)
+            assert dg.tobytes() == do.tobytes(), f"tick {t}: decisions differ"
+            assert fuzz.sort_rpcs(rg).tobytes() == fuzz.sort_rpcs(ro).tobytes(), f"tick {t}: rpcs differ"
+            n_dec += len(m)
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes(), "final state differs"
+        assert gpu.state_checksum() == engine_mod.combine_checksums(oracle_lib.server_checksums(cpu.get_state()))
+        assert n_dec > 200 * 200
+
+
 def test_config5_log_matching_repair_matches_oracle(engine_mod, oracle_lib):
     """BASELINE config 5 shape at a size the oracle handles in seconds: 7 members, 1024-entry
     uncommitted backlogs crossing 3-6 term boundaries, AERs with prev_log_index inside the backlog

@@ -27,7 +27,8 @@ for size in (256, 4096, 65536, None):
     # keep the ring full: submit up to 3 batches ahead, then collect
     pending = 0
     for m in ticks:
-        chunks = [m] if size is None else [m[i:i + size] for i in range(0, len(m), size)]
+        step = 262144 if size is None else size          # never above the ring capacity
+        chunks = [m[i:i + step] for i in range(0, len(m), step)]
         if size is not None and size < 4096:
             chunks = chunks[:64]
         for c in chunks:
