@@ -1393,11 +1393,12 @@ __device__ __forceinline__ void make_decision(Dec &d, u32 server, unsigned role,
 
 /* One message against one server: everything between "message words in registers" and
  * "decision words in registers".  State loads/stores go straight to the server's lines. */
-template <int N, int KIND>
+template <int N, int KIND, bool PRE = false>
 __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
-                                                u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr) {
+                                                u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr,
+                                                const ulonglong2 *pre = nullptr) {
   Lane L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -1426,7 +1427,9 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(hot);
   ulonglong2 h0, h1, h2, h3, h4, h5, h6, h7;
   if (dev.dbg & 8u) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_ulonglong2(0, 0); h0.y = 0x1Full << PK_PRESENT_SH; }
-  else {
+  else if (PRE) {     /* the wavefront fetched the lines cooperatively into LDS: pre = this lane's row */
+    h0 = pre[0]; h1 = pre[1]; h2 = pre[2]; h3 = pre[3]; h4 = pre[4]; h5 = pre[5]; h6 = pre[6]; h7 = pre[7];
+  } else {
     h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; h7 = hp[7];
   }
   L.rpc_nt = (dev.dbg & 4096u) != 0;
@@ -1575,6 +1578,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
  * is a fully coalesced 1 KiB wave transaction (lane stride 16 B) instead of 64 strided 16-byte
  * pieces; LDS slots are padded to 80 B so the per-lane 16-byte reads/writes are conflict-free. */
 #define RGB_IO_SLOT 5   /* 16-byte units per LDS record slot: 64 B payload + 16 B pad */
+#define RGB_HOT_SLOT 9  /* 16-byte units per LDS hot-line row: 128 B + 16 B pad */
 
 template <int N, int KIND>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
@@ -1636,7 +1640,7 @@ template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_tick_classes_kernel(
     rgb_dev dev, const rgb_msg *__restrict__ msgs, rgb_class_counts cc, const u32 *__restrict__ fam_dev,
     rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base, u32 msg_index_base) {
-  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_IO_SLOT];
+  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];   /* records (5 per slot), then hot rows (9 per slot) */
   if (fam_dev != nullptr) {
     /* per-family totals written by a device-side producer (2 families per class) */
 #pragma unroll
@@ -1681,13 +1685,38 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   __syncthreads();
   if (dev.dbg & 16u) t1 = wall_clock64();
   const bool active = lane < cnt;
+  ulonglong2 m0 = make_ulonglong2(0, 0), m1 = m0, m2 = m0, m3 = m0;
   if (active) {
-    const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
-                     m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
-    Dec d;
+    m0 = io[lane * RGB_IO_SLOT + 0]; m1 = io[lane * RGB_IO_SLOT + 1];
+    m2 = io[lane * RGB_IO_SLOT + 2]; m3 = io[lane * RGB_IO_SLOT + 3];
+  }
+  /* Cooperative hot-line fetch: 8 lanes read one server's 128-byte line as ONE coalesced access, so
+   * an instruction touches 8 lines instead of 64 (the CU's L1 looks up one line per cycle); the lines
+   * reach their owners through LDS rows that overlay the record staging area (the messages are in
+   * registers by now), and process_message reads its row from LDS piece by piece, when it needs it.
+   * Measured -3 % per tick against per-lane 16-byte gathers. */
+  constexpr bool PRE = true;
+  __syncthreads();
+  {
+    const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
+    const u32 srv = (active && sv < dev.n_servers) ? sv : 0u;
+    ulonglong2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 sj = __shfl(srv, 8 * k + (int)(lane >> 3), 64);
+      v[k] = reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS)[lane & 7u];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) io[(8 * k + (lane >> 3)) * RGB_HOT_SLOT + (lane & 7u)] = v[k];
+  }
+  __syncthreads();
+  const ulonglong2 *hrow = io + lane * RGB_HOT_SLOT;
+  Dec d;
+  if (active) {
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
-    process_message<N, KIND>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, &tl); \
+    process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, &tl, \
+                                  hrow);                                                                \
     break;
     switch (cls) {
       RGB_CASE(0, RGB_MSG_AER) RGB_CASE(1, RGB_MSG_AER_REPLY) RGB_CASE(2, RGB_MSG_WRITTEN)
@@ -1696,11 +1725,14 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(8, RGB_MSG_ELECTION_TIMEOUT) RGB_CASE(9, RGB_MSG_PRE_VOTE_RPC)
       RGB_CASE(10, RGB_MSG_PRE_VOTE_RESULT) RGB_CASE(11, RGB_MSG_SNAPSHOT_WRITTEN)
       RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
-      default: process_message<N, RGB_MSG_CONSISTENT_QUERY>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                            msg_index_base, d, &tl); break;
+      default: process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
+                                                                 msg_index_base, d, &tl, hrow); break;
     }
 #undef RGB_CASE
     if (dev.dbg & 16u) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
+  }
+  __syncthreads();      /* every lane is done with its hot row before the decisions overlay the rows */
+  if (active) {
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
     io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
