@@ -560,6 +560,14 @@ vec("E13", "test/ra_server_SUITE.erl:2644-2662 leader_receives_pre_vote", 5, "n1
                              state=dict(current_term=6))),
 ], tweak=dict(votes=1), note="a leader answers a same-term pre-vote with rpcs to every peer (make_all_rpcs)")
 
+vec("PLA", "test/ra_server_SUITE.erl:3888-3909 persist_last_applied_with_unwritten", 3, "n1", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 1, [(1, 1)]), role="follower",
+         state=dict(leader_id="n1", current_term=1, commit_index=1, last_applied=1, last_written=[0, 0])),
+    step("follower", written(1, 1, 1), role="follower", state=dict(last_applied=1, last_written=[1, 1])),
+], note="persist_last_applied/1 (src/ra_server.erl:2539-2559) stays on the host: it stores "
+        "min(last_applied, last_written_index) when that exceeds the persisted value -- 0 after the "
+        "first step, 1 after the second, from exactly the two cursors this vector pins")
+
 # -------------------------------------------- A.7 real-log last_written cursor ----
 vec("R1", "test/ra_log_2_SUITE.erl:189-211 (driven through follower AERs)", 3, "n2", "empty", [
     step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1)]), role="follower"),
