@@ -58,6 +58,15 @@ def main():
     import torch
     import torch.distributed as dist
     from ra_amd import abi, engine, shard, workload as W
+    if not os.path.exists(engine.LIB_PATH):
+        # fresh checkout: local rank 0 compiles the HIP library in-tree (hipcc, gfx950), the others wait
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            engine.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(engine.LIB_PATH) and time.time() - t_wait < 900:
+                time.sleep(2.0)
+            time.sleep(2.0)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) with the CPU checker and with the vectors
 transcribed from the reference's own tests.  Bit-exact: decisions, pipelined rpcs and the full
 final state must be identical.  Runs only on the GPU box (-m gpu)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -16,6 +18,8 @@ DATA = VR.load()
 @pytest.fixture(scope="module")
 def engine_mod():
     from ra_amd import engine
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build()    # a fresh checkout on the GPU box: hipcc is there, the .so is not in git
     engine.lib()          # raises if the HIP library is missing: no fallback
     return engine
 

@@ -15,6 +15,14 @@ def frame(index, term, payload: bytes) -> bytes:
     return struct.pack(">QQ", index, term) + payload
 
 
+def _engine():
+    import os
+    engine = _engine()
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build()
+    return engine
+
+
 def make_batch(rng, lens, misalign=True):
     """Payloads packed back to back (arbitrary alignment) into one buffer, 16 spare bytes behind."""
     entries = np.zeros(len(lens), dtype=abi.WAL_ENTRY_DTYPE)
@@ -80,7 +88,7 @@ def test_oracle_detects_overwritten_bytes():
 @pytest.mark.parametrize("misalign", [True, False])
 def test_gpu_wal_checksums_match_oracle_and_zlib(misalign):
     import torch
-    from ra_amd import engine
+    engine = _engine()
     rng = np.random.default_rng(11 + misalign)
     lens = [0, 1, 2, 15, 16, 17, 31, 32, 33, 1023, 1024, 1025, 4095, 4096, 4097, 65535, 65536, 70001,
             1 << 20] + [int(x) for x in rng.integers(0, 20000, size=300)]
@@ -103,7 +111,7 @@ def test_gpu_wal_checksums_match_oracle_and_zlib(misalign):
 @pytest.mark.gpu
 def test_gpu_wal_host_buffer_form():
     """rgb_wal_adler32: host buffers in, host checksums out (what the NIF binds); grows its staging."""
-    from ra_amd import engine
+    engine = _engine()
     rng = np.random.default_rng(31)
     eng = engine.RaGpuBatch(1, 1)
     for lens in ([0, 5, 100, 4096], [int(x) for x in rng.integers(0, 9000, size=500)], [1 << 20, 3]):
@@ -120,7 +128,7 @@ def test_gpu_wal_host_buffer_form():
 def test_gpu_wal_checksums_small_entries():
     """Mean payload below 1 KiB: the four-entries-per-wavefront variant."""
     import torch
-    from ra_amd import engine
+    engine = _engine()
     rng = np.random.default_rng(23)
     lens = [0, 1, 15, 16, 17, 240, 255, 256, 257, 1023] + [int(x) for x in rng.integers(0, 700, size=1013)]
     entries, data = make_batch(rng, lens, True)
@@ -145,7 +153,7 @@ def test_gpu_wal_checksums_full_size_properties():
     Adler-32 offers -- the checksum of a record is a function of (A, B) sums that are additive, so
     flipping one byte by +1 at position p from the end changes A by 1 and B by p (mod 65521)."""
     import torch
-    from ra_amd import engine
+    engine = _engine()
     rng = np.random.default_rng(5)
     n, ln = 4096, 65536
     entries = np.zeros(n, dtype=abi.WAL_ENTRY_DTYPE)
