@@ -42,6 +42,7 @@ def lib():
         L.ora_step_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int,
                                         C.c_void_p]
         L.ora_max_threads.restype = C.c_int
+        L.ora_set_max_runs.argtypes = [C.c_void_p, C.c_uint32]
         L.ora_agreed_commit.restype = C.c_uint64
         L.ora_agreed_commit.argtypes = [C.c_void_p, C.c_uint32]
         L.ora_server_checksum.restype = C.c_uint64
@@ -85,11 +86,13 @@ class Oracle:
     """Sequential CPU restatement of the reference transition over n_groups x n_members servers."""
 
     def __init__(self, n_groups: int, n_members: int, max_pipeline_count: int = 0,
-                 max_aer_batch: int = 0):
+                 max_aer_batch: int = 0, max_runs: int = 0):
         self._L = lib()
         self._h = self._L.ora_new(n_groups, n_members, max_pipeline_count, max_aer_batch)
         if not self._h:
             raise MemoryError("ora_new failed")
+        if max_runs:      # model the engine's bounded term-run table (RGB_F_RUNS_OVERFLOW)
+            self._L.ora_set_max_runs(self._h, max_runs)
         self.n_groups, self.n_members = n_groups, n_members
         self.n_servers = n_groups * n_members
 

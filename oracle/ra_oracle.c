@@ -65,6 +65,7 @@ typedef struct {
 struct ora_ctx {
   uint32_t n_servers, n_members;
   uint32_t max_pipeline_count, max_aer_batch;
+  uint32_t max_runs;              /* 0 = unbounded; else the engine's term-run table size (ora_set_max_runs) */
   oserver *sv;
 };
 
@@ -1289,6 +1290,24 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
     *n_rpcs = rpcs_before;
     return;
   }
+  /* The engine keeps the log's term structure as at most max_runs (first index, term) runs; when a
+   * message leaves more, it forgets the oldest runs -- the range then starts at the oldest run it
+   * still knows -- and raises RGB_F_RUNS_OVERFLOW (include/ra_gpu_batch.h).  Not reference
+   * behaviour: a bound of the engine, modelled here so that parity also covers it. */
+  if (c->max_runs && sv->log.has_range) {
+    olog *l = &sv->log;
+    uint32_t runs = 1;
+    for (uint64_t i = l->first + 1; i <= l->last; i++)
+      if (l->terms[i - l->base] != l->terms[i - 1 - l->base]) runs++;
+    if (runs > c->max_runs) {
+      uint32_t drop = runs - c->max_runs;
+      uint64_t i = l->first + 1;
+      for (; i <= l->last && drop; i++)
+        if (l->terms[i - l->base] != l->terms[i - 1 - l->base]) drop--;
+      l->first = i - 1;                                     /* start of the oldest run kept */
+      fx.flags |= RGB_F_RUNS_OVERFLOW;
+    }
+  }
   *n_rpcs = fx.n_rpcs_total;
   d->role = sv->s.role;
   d->flags = fx.flags;
@@ -1484,6 +1503,8 @@ int ora_step_parallel(ora_ctx *c, const rgb_msg *msgs, uint32_t n, rgb_decision 
   (void)n_threads;
   return RGB_OK;
 }
+
+void ora_set_max_runs(ora_ctx *c, uint32_t max_runs) { if (c) c->max_runs = max_runs; }
 
 int ora_max_threads(void) {
 #ifdef _OPENMP

@@ -213,6 +213,28 @@ def test_run_table_overflow_is_flagged(engine_mod):
         assert int(st["first_index"]) == int(st["run_start"][0]) == 3
 
 
+@pytest.mark.parametrize("n_members,seed,groups,max_runs", [(5, 211, 300, 4), (3, 212, 300, 3), (7, 213, 200, 5)])
+def test_bounded_run_table_matches_oracle(engine_mod, oracle_lib, n_members, seed, groups, max_runs):
+    """A run table smaller than the logs' term structure: the engine forgets its oldest runs
+    (RGB_F_RUNS_OVERFLOW, first_index raised); the checker models the same bound, so decisions and
+    states stay bit-identical through overflows."""
+    rng = np.random.default_rng(seed)
+    st = fuzz.random_states(rng, groups, n_members, max_runs=max_runs + 2)     # <= max_runs - 1 runs each
+    assert int(st["n_runs"].max()) <= max_runs
+    cpu = oracle_lib.Oracle(groups, n_members, max_runs=max_runs)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(groups, n_members, ring_capacity=4096, ring_slots=2, max_runs=max_runs) as gpu:
+        gpu.set_state(0, st)
+        overflows = 0
+        for tick in range(12):
+            msgs = fuzz.random_msgs(rng, cpu.get_state(), n_members)
+            do, ro = cpu.step(msgs)
+            dg, rg = gpu.step(msgs)
+            assert_same(f"bounded runs N={n_members} tick {tick}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+            overflows += int(((do["flags"] & abi.F_RUNS_OVERFLOW) != 0).sum())
+        assert overflows > 0, "the fuzz never overflowed the run table"
+
+
 @pytest.mark.parametrize("n_members,groups,ticks", [(5, 2048, 48), (7, 1024, 32), (3, 1024, 32)])
 def test_device_generated_stream_matches_oracle(engine_mod, oracle_lib, n_members, groups, ticks):
     """The bench's tick stream (device-side load generator incl. term churn and on-device
