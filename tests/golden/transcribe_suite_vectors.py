@@ -605,6 +605,44 @@ vec("R4", "test/ra_log_2_SUITE.erl:295-327 (driven through follower AERs)", 3, "
     step("follower", written(3, 2, 3), role="follower", state=dict(last_written=[3, 3])),
 ], log_model="real")
 
+vec("R6", "test/ra_log_2_SUITE.erl:928-940 last_written_overwrite (driven through follower AERs)", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1), (3, 1), (4, 1)]), role="follower"),
+    step("follower", written(1, 1, 4), role="follower", state=dict(last_written=[4, 1], pending_first=5)),
+    step("follower", aer(2, "n1", (2, 1), 0, [(3, 2)]), role="follower",
+         state=dict(last_written=[2, 1], last_index=3, last_term=2, pending_first=3)),
+    step("follower", written(2, 3, 3), role="follower", state=dict(last_written=[3, 2], pending_first=4)),
+], log_model="real")
+
+vec("R7", "test/ra_log_2_SUITE.erl:942-968 last_written_overwrite_2 (driven through follower AERs)", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1), (3, 1), (4, 1)]), role="follower",
+         state=dict(last_written=[0, 0], pending_first=1)),
+    step("follower", aer(2, "n1", (3, 1), 0, [(4, 2), (5, 2)]), role="follower",
+         state=dict(last_written=[0, 0], last_index=5, last_term=2, pending_first=1)),
+    # the first batch's written event arrives after the overwrite: applied up to the last index
+    # whose term still matches
+    step("follower", written(1, 1, 4), role="follower", state=dict(last_written=[3, 1], pending_first=4)),
+    step("follower", written(2, 4, 5), role="follower", state=dict(last_written=[5, 2], pending_first=6)),
+], log_model="real")
+
+vec("R8", "test/ra_log_2_SUITE.erl:970-1000 last_index_reset (driven through follower AERs)", 3, "n2", "empty", [
+    step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1)]), role="follower"),
+    step("follower", written(1, 1, 5), role="follower", state=dict(last_written=[5, 1])),
+    step("follower", aer(2, "n1", (3, 1), 0, []), role="follower", flags_set=["TRUNCATED"],
+         state=dict(last_written=[3, 1], last_index=3, last_term=1)),
+    step("follower", aer(2, "n1", (3, 1), 0, [(4, 2)]), role="follower",
+         state=dict(last_index=4, last_term=2, first_index=0, log=[[0, 0], [1, 1], [2, 1], [3, 1], [4, 2]])),
+], log_model="real")
+
+vec("R9", "test/ra_log_2_SUITE.erl:1208-1230 last_index_reset_before_written (driven through follower AERs)",
+    3, "n2", "empty", [
+        step("follower", aer(1, "n1", (0, 0), 0, [(1, 1), (2, 1), (3, 1), (4, 1)]), role="follower",
+             state=dict(last_written=[0, 0], last_index=4)),
+        step("follower", aer(2, "n1", (3, 1), 0, []), role="follower", flags_set=["TRUNCATED"],
+             state=dict(last_written=[0, 0], last_index=3, last_term=1)),
+        # the written event of 1..4 must not move last_written beyond the reset
+        step("follower", written(1, 1, 4), role="follower", state=dict(last_written=[3, 1], last_index=3)),
+    ], log_model="real")
+
 vec("R5", "test/ra_log_2_SUITE.erl:157-186 snapshot_before_written (driven as follower log events)",
     3, "n2", "empty", [
         step("follower", dict(kind="snapshot_written", index=10, term=1), role="follower",
