@@ -17,7 +17,7 @@ def frame(index, term, payload: bytes) -> bytes:
 
 def _engine():
     import os
-    engine = _engine()
+    from ra_amd import engine
     if not os.path.exists(engine.LIB_PATH):
         engine.build()
     return engine
