@@ -47,11 +47,13 @@ def test_hip_matches_reference_vector(engine_mod, v):
     VR.run_vector(lambda g, n: engine_mod.RaGpuBatch(g, n, ring_capacity=64, ring_slots=2), v)
 
 
-# the last three cases carry >= 4096 messages per round: rgb_submit then takes the class-dispatch kernel
+# the cases from seed 107 on carry >= 4096 messages per round: rgb_submit then takes the class-dispatch kernel
 # (one compile-time specialised path per message kind) instead of the kind-generic one
 @pytest.mark.parametrize("n_members,seed,groups", [(3, 101, 300), (5, 102, 400), (7, 103, 300),
                                                    (8, 104, 150), (1, 105, 50), (2, 106, 100),
-                                                   (5, 107, 1300), (3, 108, 2200), (7, 109, 900)])
+                                                   (5, 107, 1300), (3, 108, 2200), (7, 109, 900),
+                                                   (8, 110, 600), (1, 111, 4300), (2, 112, 2200),
+                                                   (4, 113, 1100), (6, 114, 800)])
 def test_hip_equals_oracle_on_random_ticks(engine_mod, oracle_lib, n_members, seed, groups):
     rng = np.random.default_rng(seed)
     st = fuzz.random_states(rng, groups, n_members, max_runs=6)
