@@ -114,9 +114,12 @@ struct rgb_dev {
   u32 peer_stride;
   u32 max_pipeline_count;
   u32 max_aer_batch;
-  u32 dbg;   /* profiling knobs (env RGB_DEBUG, 0 in production): 1 = no state write-back, 2 = no
-                decision store, 4 = no peers prefetch, 8 = no hot-line load (zero state),
-                16 = per-wave timestamps into dbg_buf, 32 = write-through (sc1) stores */
+  u32 dbg;   /* profiling knobs (env RGB_DEBUG, 0 in production; everything but 16 breaks parity or only
+                changes memory-access flavours): 1 = no state write-back, 2 = no decision store, 4 = no
+                peers prefetch, 8 = no hot-line load (zero state), 16 = per-wave timestamps into dbg_buf,
+                32 = write-through (sc1) stores, 64 = whole-line hot write-back, 128 = plain instead of
+                non-temporal decision stores, 1024 = non-temporal state stores, 2048 = plain instead of
+                non-temporal message loads, 4096 = non-temporal rpc record stores */
   u64 *dbg_buf;
 };
 
