@@ -517,7 +517,8 @@ static int make_pipelined_rpc_effects(struct ora_ctx *c, oserver *sv, uint32_t s
     uint64_t new_ni;
     if (prev_term == UNDEF && !(sv->log.snap_idx != UNDEF && sv->log.snap_idx == prev)) {
       /* {send_snapshot,..}: next index is NOT advanced past SnapIdx, :2403-2415 */
-      if (sv->log.snap_idx == UNDEF || !(prev < sv->log.snap_idx))
+      /* next_index 0: PrevIdx is -1 in the reference's integers, below any snapshot index */
+      if (sv->log.snap_idx == UNDEF || !(ni == 0 || prev < sv->log.snap_idx))
         return RGB_INV_PIPELINE_PREV_UNDEFINED;            /* case_clause / ?assert(PrevIdx < SnapIdx) */
       r.kind = RGB_RPC_SNAPSHOT;
       r.prev_log_index = sv->log.snap_idx;
@@ -669,7 +670,8 @@ static int make_all_rpcs(oserver *sv, uint32_t srv_id, ofx *fx) {
     r.msg_index = fx->msg_index; r.server = srv_id; r.peer = (uint8_t)i;
     r.term = s->current_term; r.leader_commit = s->commit_index;
     if (prev_term == UNDEF && !(sv->log.snap_idx != UNDEF && sv->log.snap_idx == prev)) {
-      if (sv->log.snap_idx == UNDEF || !(prev < sv->log.snap_idx)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
+      if (sv->log.snap_idx == UNDEF || !(s->next_index[i] == 0 || prev < sv->log.snap_idx))
+        return RGB_INV_PIPELINE_PREV_UNDEFINED;            /* PrevIdx = -1 is below any snapshot index */
       r.kind = RGB_RPC_SNAPSHOT; r.prev_log_index = sv->log.snap_idx; r.prev_log_term = sv->log.snap_term;
       r.next_index = sv->log.snap_idx;
       fx->flags |= RGB_F_SEND_SNAPSHOT;

@@ -472,11 +472,15 @@ __device__ __forceinline__ int log_write(Lane &L, u32 k0) {
     else truncate_runs_to(L, fst - 1);
   }
   /* entries k0.. : first the rest of term run 0, then term run 1 */
+  /* the range keeps its Start (src/ra_log.erl:1617-1622): indexes written below first_index stay
+   * invisible, so the runs begin at max(fst, first_index) */
+  const u64 lo = (had_range && L.first > fst) ? L.first : fst;
   if (k0 < L.n_run0) {
-    push_segment(L, fst, L.run0_term);
-    if (L.n_run0 < L.n_entries) push_segment(L, base + L.n_run0, L.run1_term);
+    const u64 s1 = base + L.n_run0;
+    if (L.n_run0 == L.n_entries || lo < s1) push_segment(L, lo, L.run0_term);
+    if (L.n_run0 < L.n_entries) push_segment(L, s1 > lo ? s1 : lo, L.run1_term);
   } else {
-    push_segment(L, fst, L.run1_term);
+    push_segment(L, lo, L.run1_term);
   }
   L.li = lst;
   L.lt = (L.n_entries - 1) < L.n_run0 ? L.run0_term : L.run1_term;
@@ -685,7 +689,8 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
     u64 new_ni, rp_idx, rp_term;
     unsigned kind, n_ent = 0;
     if (prev_term == UNDEF && !(L.si != UNDEF && L.si == prev)) {
-      if (L.si == UNDEF || !(prev < L.si)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
+      /* next_index 0: PrevIdx is -1 in the reference's integers, below any snapshot index */
+      if (L.si == UNDEF || !(ni == 0 || prev < L.si)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
       kind = RGB_RPC_SNAPSHOT; rp_idx = L.si; rp_term = L.st; new_ni = L.si;
       if (EMIT) L.flags |= RGB_F_SEND_SNAPSHOT;
     } else {
@@ -822,7 +827,7 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
     u64 rp_idx, rp_term, new_ni;
     unsigned kind, n_ent = 0;
     if (prev_term == UNDEF && !(L.si != UNDEF && L.si == prev)) {
-      if (L.si == UNDEF || !(prev < L.si)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
+      if (L.si == UNDEF || !(L.pni[i] == 0 || prev < L.si)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
       kind = RGB_RPC_SNAPSHOT; rp_idx = L.si; rp_term = L.st; new_ni = L.si;
       L.flags |= RGB_F_SEND_SNAPSHOT;
     } else {

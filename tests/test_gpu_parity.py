@@ -215,6 +215,35 @@ def test_run_table_overflow_is_flagged(engine_mod):
         assert int(st["first_index"]) == int(st["run_start"][0]) == 3
 
 
+@pytest.mark.parametrize("n_run0", [3, 1, 2])
+def test_write_below_first_index_keeps_the_range_start(engine_mod, oracle_lib, n_run0):
+    """A sparse log (snapshot at 44, only entry 47 in the range) overwritten from 45: the range
+    keeps its Start (src/ra_log.erl:1617-1622 `{Start, _} -> ra_range:new(Start, LastIdx)`), so the
+    exported term runs begin at first_index, wherever the message's own term boundary lies."""
+    st = abi.empty_server_states(1, 3)
+    for i in range(3):
+        st["current_term"][i] = 3
+        st["role"][i] = abi.ROLE_FOLLOWER
+        abi.set_log(st, i, [(47, 2)], last_written=(44, 2), snapshot=(44, 2))
+        st["commit_index"][i] = st["last_applied"][i] = 44
+        st["pending_first"][i] = 45
+    m = np.zeros(1, dtype=abi.MSG_DTYPE)
+    m["server"], m["kind"], m["from"], m["term"] = 1, abi.MSG_AER, 0, 3
+    m["a"], m["b"], m["c"] = 44, 2, 47
+    m["n_entries"], m["n_run0"] = 3, n_run0
+    m["run0_term"], m["run1_term"] = (3, 3) if n_run0 == 3 else (2, 3)
+    cpu = oracle_lib.Oracle(1, 3)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(1, 3, ring_capacity=16, ring_slots=1) as gpu:
+        gpu.set_state(0, st)
+        do, ro = cpu.step(m)
+        dg, rg = gpu.step(m)
+        so = cpu.get_state()
+        assert_same(f"sparse overwrite n_run0={n_run0}", dg, rg, gpu.get_state(), do, ro, so)
+        assert int(do["flags"][0]) & abi.F_WROTE
+        assert int(so["first_index"][1]) == 47 == int(so["run_start"][1][0]) and int(so["last_index"][1]) == 47
+
+
 @pytest.mark.parametrize("n_members,seed,groups,max_runs", [(5, 211, 300, 4), (3, 212, 300, 3), (7, 213, 200, 5)])
 def test_bounded_run_table_matches_oracle(engine_mod, oracle_lib, n_members, seed, groups, max_runs):
     """A run table smaller than the logs' term structure: the engine forgets its oldest runs
