@@ -55,6 +55,9 @@ def lib():
         L.ora_adler32_update.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
         L.ora_wal_entry_checksum.restype = C.c_uint32
         L.ora_wal_entry_checksum.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32]
+        L.ora_wal_frame_record.restype = C.c_uint64
+        L.ora_wal_frame_record.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                           C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -75,6 +78,92 @@ def wal_entry_checksums(entries: np.ndarray, data: np.ndarray) -> np.ndarray:
         out[i] = L.ora_wal_entry_checksum(int(e["index"]), int(e["term"]),
                                           data.ctypes.data + off if ln else None, ln)
     return out
+
+
+def wal_frame(records: np.ndarray, data: np.ndarray, out_bytes: int, compute_checksums: bool = True) -> np.ndarray:
+    """The batch's on-disk bytes: every rgb_wal_record framed at its out_offset (src/ra_log_wal.erl:513-537)."""
+    L = lib()
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros(out_bytes, dtype=np.uint8)
+    for r in records:
+        o, n = int(r["data_offset"]), int(r["data_len"])
+        h, hn = int(r["hdr_offset"]), int(r["hdr_len"])
+        at = int(r["out_offset"])
+        assert at + hn + 24 + n <= out_bytes
+        L.ora_wal_frame_record(int(r["index"]), int(r["term"]), data.ctypes.data + h, hn,
+                               data.ctypes.data + o if n else None, n, int(compute_checksums),
+                               out.ctypes.data + at)
+    return out
+
+
+WAL_FILE_HEADER = b"RAWA\x01"          # <<?MAGIC, ?CURRENT_VERSION:8/unsigned>> (src/ra_log_wal.erl:34-36)
+
+
+def wal_recover_records(file_bytes: bytes, registered=lambda uid: True):
+    """recover_records/5 (src/ra_log_wal.erl:877-984) restated clause by clause on a whole file.
+    Returns (records, outcome): records = [(uid, trunc, idx, term, payload)] that pass validation, in
+    order, outcome in {"zeros", "eof", "dropped_last", "corrupt"} ("corrupt" = the reference throws
+    wal_checksum_validation_failure)."""
+    assert file_bytes[:5] == WAL_FILE_HEADER, "unknown_wal_file_format"      # :826-835
+    b = file_bytes[5:]
+    cache = {}
+    out = []
+
+    def validate(checksum, idx, term, payload):                               # :1022-1033
+        if checksum == 0:
+            return True
+        return adler32(idx.to_bytes(8, "big") + term.to_bytes(8, "big") + payload) == checksum
+
+    def is_last_record(rest):                                                 # :994-1010
+        return rest[:13] == bytes(13) or len(rest) < 13
+
+    while True:
+        if len(b) < 3:
+            return out, "eof"
+        h = int.from_bytes(b[:3], "big")
+        trunc, form, id_ref = h >> 23, (h >> 22) & 1, h & 0x3FFFFF
+        if form == 0:
+            if len(b) < 5:
+                return out, "eof"
+            uid_len = int.from_bytes(b[3:5], "big")
+            fixed = 5 + uid_len
+            if len(b) < fixed + 8:
+                return out, "eof"
+            checksum = int.from_bytes(b[fixed:fixed + 4], "big")
+            dlen = int.from_bytes(b[fixed + 4:fixed + 8], "big")
+            if h == 0 and checksum == 0 and dlen == 0:                        # clause 1, :877-883
+                return out, "zeros"
+            if len(b) < fixed + 24 + dlen:
+                return out, "eof"                                             # last clause at end of file
+            uid = b[5:5 + uid_len]
+            idx = int.from_bytes(b[fixed + 8:fixed + 16], "big")
+            term = int.from_bytes(b[fixed + 16:fixed + 24], "big")
+            payload = b[fixed + 24:fixed + 24 + dlen]
+            rest = b[fixed + 24 + dlen:]
+            if registered(uid):                                               # clause 2, :885-930
+                cache[id_ref] = uid
+                if validate(checksum, idx, term, payload):
+                    out.append((uid, trunc, idx, term, payload))
+                else:
+                    return out, ("dropped_last" if is_last_record(rest) else "corrupt")
+            b = rest
+        else:                                                                 # clause 3, :931-972
+            if len(b) < 3 + 24:
+                return out, "eof"
+            checksum = int.from_bytes(b[3:7], "big")
+            dlen = int.from_bytes(b[7:11], "big")
+            if len(b) < 27 + dlen:
+                return out, "eof"
+            idx = int.from_bytes(b[11:19], "big")
+            term = int.from_bytes(b[19:27], "big")
+            payload = b[27:27 + dlen]
+            rest = b[27 + dlen:]
+            if id_ref in cache:
+                if validate(checksum, idx, term, payload):
+                    out.append((cache[id_ref], trunc, idx, term, payload))
+                else:
+                    return out, ("dropped_last" if is_last_record(rest) else "corrupt")
+            b = rest
 
 
 def agreed_commit(indexes) -> int:

@@ -41,3 +41,20 @@ void ora_wal_checksums(const uint64_t *idx_term_off, const uint32_t *lens, uint3
     out[i] = ora_wal_entry_checksum(idx_term_off[3 * i], idx_term_off[3 * i + 1],
                                     data + idx_term_off[3 * i + 2], lens[i]);
 }
+
+/* Record = [HeaderData, <<Checksum:32/integer, EntryDataLen:32/unsigned>>,
+ *           <<Idx:64/unsigned, Term:64/unsigned>> | EntryData]      (src/ra_log_wal.erl:513-537)
+ * written at out + out_offset; returns the record's size (HeaderLen + 24 + EntryDataLen, :526).
+ * compute_checksums = false stores Checksum 0 (:531-534). */
+uint64_t ora_wal_frame_record(uint64_t index, uint64_t term, const uint8_t *hdr, uint32_t hdr_len,
+                              const uint8_t *data, uint32_t len, int compute_checksums, uint8_t *out) {
+  uint32_t cs = compute_checksums ? ora_wal_entry_checksum(index, term, data, len) : 0u;
+  uint8_t *p = out;
+  for (uint32_t k = 0; k < hdr_len; k++) *p++ = hdr[k];
+  for (int k = 3; k >= 0; k--) *p++ = (uint8_t)(cs >> (8 * k));
+  for (int k = 3; k >= 0; k--) *p++ = (uint8_t)(len >> (8 * k));
+  for (int k = 7; k >= 0; k--) *p++ = (uint8_t)(index >> (8 * k));
+  for (int k = 7; k >= 0; k--) *p++ = (uint8_t)(term >> (8 * k));
+  for (uint32_t k = 0; k < len; k++) *p++ = data[k];
+  return (uint64_t)(p - out);
+}

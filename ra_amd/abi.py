@@ -126,6 +126,18 @@ CONFIG_DTYPE = np.dtype([
 WAL_ENTRY_DTYPE = np.dtype([("index", u64), ("term", u64), ("data_offset", u64), ("data_len", u32),
                             ("_pad", u32)])
 assert WAL_ENTRY_DTYPE.itemsize == 32
+WAL_RECORD_DTYPE = np.dtype([("index", u64), ("term", u64), ("data_offset", u64), ("data_len", u32),
+                             ("hdr_len", u32), ("hdr_offset", u64), ("out_offset", u64)])
+assert WAL_RECORD_DTYPE.itemsize == 48
+WAL_SCANNED_DTYPE = np.dtype([("index", u64), ("term", u64), ("data_offset", u64), ("data_len", u32),
+                              ("checksum", u32), ("uid_offset", u64), ("id_ref", u32), ("uid_len", np.uint16),
+                              ("trunc", np.uint8), ("flags", np.uint8), ("next_offset", u64)])
+assert WAL_SCANNED_DTYPE.itemsize == 56
+WAL_NO_CHECKSUMS = 1
+WAL_REC_FIRST, WAL_REC_VALIDATE, WAL_REC_UNKNOWN = 1, 2, 4
+WAL_END_ZEROS, WAL_END_DATA, WAL_END_CAP = 0, 1, 2
+WAL_CLEAN, WAL_DROPPED_LAST, WAL_CORRUPT = 0, 1, 2
+WAL_FILE_HEADER = b"RAWA\x01"
 
 STRUCT_DTYPES = [MSG_DTYPE, DECISION_DTYPE, RPC_DTYPE, SERVER_STATE_DTYPE, LEADERBOARD_DTYPE,
                  CONFIG_DTYPE]

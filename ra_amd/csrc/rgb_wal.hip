@@ -119,6 +119,117 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_adler32_kern
   }
 }
 
+
+/* ---- record framing: checksum + header + payload copy in one pass (src/ra_log_wal.erl:513-537) ----
+ *
+ * Same lane partition as the checksum kernel, but the 16-byte chunks are aligned to the
+ * DESTINATION (the payload's place in the output), so interior chunks are one unaligned 16-byte
+ * load (gfx950 global loads take any alignment) and one aligned 16-byte store; the at most two
+ * partial chunks at the payload's ends go byte by byte (neighbouring records share those 16-byte
+ * lines of the output, so nothing outside the record may be written).  The 24 fixed bytes and the
+ * host's HeaderData are written once the group's checksum is known. */
+__device__ __forceinline__ v4u load16_any(const unsigned char *p) {
+  v4u t;
+  __builtin_memcpy(&t, p, 16);
+  return t;
+}
+
+template <int GROUP>
+__global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel(
+    const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data,
+    unsigned char *__restrict__ out, u32 *__restrict__ sums_out, u32 flags) {
+  constexpr u32 PER_BLOCK = WAL_WAVES_PER_BLOCK * 64 / GROUP;
+  const u32 lane = threadIdx.x & (GROUP - 1);
+  const u32 e = blockIdx.x * PER_BLOCK + threadIdx.x / GROUP;
+  const bool live = e < n;
+  rgb_wal_record r;
+  r.index = r.term = r.data_offset = r.hdr_offset = r.out_offset = 0; r.data_len = r.hdr_len = 0;
+  if (live) r = recs[e];
+  const u32 len = r.data_len;
+  const u32 prefix = r.hdr_len + 24u;                   /* HeaderData + Checksum, Len, Idx, Term */
+  const u64 d0 = r.out_offset + prefix;                 /* output offset of payload byte 0 */
+  const u32 lead = (u32)(d0 & 15ull);
+  const unsigned char *src = data + r.data_offset;      /* payload byte p = src[p] */
+  unsigned char *dst = out + d0;                        /* ... goes to dst[p] */
+  const u32 span = lead + len;                          /* destination-aligned stream [0, span) */
+  const u32 n_chunks = live ? (span + 15u) >> 4 : 0u;
+  const u32 span_q = span % ADLER_MOD;
+  u32 a_acc = 0, b_acc = 0;
+  for (u32 c0 = 0; c0 < n_chunks; c0 += GROUP * WAL_UNROLL) {
+    uint4 v[WAL_UNROLL];
+#pragma unroll
+    for (int k = 0; k < WAL_UNROLL; ++k) {
+      const u32 c = c0 + (u32)k * GROUP + lane;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (c >= n_chunks) continue;
+      const u32 s = c << 4;                             /* stream byte s+j is payload byte s+j-lead */
+      if (s >= lead && s + 16u <= span) {
+        const v4u t = load16_any(src + (s - lead));
+        v[k] = make_uint4(t.x, t.y, t.z, t.w);
+      } else {                                          /* partial chunk: bytes outside stay zero */
+        u32 w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (u32 j = 0; j < 16u; ++j) {
+          const u32 q = s + j;
+          if (q >= lead && q < span) {
+            const u32 byte = src[q - lead];
+            dst[(long long)q - (long long)lead] = (unsigned char)byte;
+            w[j >> 2] |= byte << (8 * (j & 3));
+          }
+        }
+        v[k] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WAL_UNROLL; ++k) {
+      const u32 c = c0 + (u32)k * GROUP + lane;
+      if (c >= n_chunks) continue;
+      const u32 s = c << 4;
+      const uint4 w = v[k];
+      if (s >= lead && s + 16u <= span) {
+        v4u t; t.x = w.x; t.y = w.y; t.z = w.z; t.w = w.w;
+        *reinterpret_cast<v4u *>(dst + (s - lead)) = t;   /* d0 - lead is 16-byte aligned */
+      }
+      u32 a, b;
+      chunk_sums(w, a, b);
+      const u32 wq = (span_q + 2u * ADLER_MOD - (s % ADLER_MOD) - 16u) % ADLER_MOD;
+      a_acc += a;
+      b_acc += (wq * a + b) % ADLER_MOD;
+      if (b_acc >= 0x7FFF0000u) b_acc %= ADLER_MOD;
+      if (a_acc >= 0x7FFF0000u) a_acc %= ADLER_MOD;
+    }
+  }
+  const u32 a_sum = group_sum<GROUP>(a_acc % ADLER_MOD);
+  const u32 b_sum = group_sum<GROUP>(b_acc % ADLER_MOD);
+  if (!live) return;
+  const u32 ih = (u32)(r.index >> 32), il = (u32)r.index, th = (u32)(r.term >> 32), tl = (u32)r.term;
+  u32 pa = dot4(ih, 0x01010101u, 0); pa = dot4(il, 0x01010101u, pa);
+  pa = dot4(th, 0x01010101u, pa); pa = dot4(tl, 0x01010101u, pa);
+  u32 pb = dot4(ih, 0x100F0E0Du, 0); pb = dot4(il, 0x0C0B0A09u, pb);
+  pb = dot4(th, 0x08070605u, pb); pb = dot4(tl, 0x04030201u, pb);
+  const u32 len_q = len % ADLER_MOD;
+  const u32 A = (1u + pa + a_sum) % ADLER_MOD;
+  const u32 B = ((16u + len_q) + (len_q * pa + pb) % ADLER_MOD + b_sum) % ADLER_MOD;
+  const u32 cs = (flags & RGB_WAL_NO_CHECKSUMS) ? 0u : ((B << 16) | A);
+  if (lane == 0 && sums_out) sums_out[e] = cs;
+  /* the prefix: HeaderData verbatim, then Checksum:32, EntryDataLen:32, Idx:64, Term:64 big endian */
+  unsigned char *rec = out + r.out_offset;
+  const unsigned char *hdr = data + r.hdr_offset;
+  for (u32 j = lane; j < prefix; j += GROUP) {
+    u32 byte;
+    if (j < r.hdr_len) {
+      byte = hdr[j];
+    } else {
+      const u32 q = j - r.hdr_len;                      /* 0..23 */
+      if (q < 4u) byte = cs >> (8 * (3 - q));
+      else if (q < 8u) byte = len >> (8 * (7 - q));
+      else if (q < 16u) byte = (u32)(r.index >> (8 * (15 - q)));
+      else byte = (u32)(r.term >> (8 * (23 - q)));
+    }
+    rec[j] = (unsigned char)byte;
+  }
+}
+
 }  // namespace
 
 /* the context only supplies the default stream; rgb_api.hip exports the accessor */
@@ -142,11 +253,44 @@ extern "C" int rgb_wal_adler32_device(rgb_ctx *ctx, const void *d_entries, uint3
   return hipGetLastError() == hipSuccess ? RGB_OK : RGB_E_HIP;
 }
 
+extern "C" uint64_t rgb_wal_layout(rgb_wal_record *records, uint32_t n, uint64_t base) {
+  for (uint32_t i = 0; i < n; ++i) {
+    records[i].out_offset = base;
+    base += (uint64_t)records[i].hdr_len + 24u + records[i].data_len;   /* DataSize, src/ra_log_wal.erl:526 */
+  }
+  return base;
+}
+
+extern "C" int rgb_wal_frame_device(rgb_ctx *ctx, const void *d_records, uint32_t n, const void *d_data,
+                                    uint64_t data_bytes, void *d_out, uint64_t out_bytes, void *d_checksums,
+                                    uint32_t flags, void *stream) {
+  if (!ctx || (n && (!d_records || !d_out)) || (flags & ~RGB_WAL_NO_CHECKSUMS)) return RGB_E_INVAL;
+  if (n == 0) return RGB_OK;
+  if (out_bytes < 27ull * n) return RGB_E_INVAL;       /* the shortest record is 3 + 24 bytes */
+  hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)rgb_ctx_stream(ctx);
+  if (data_bytes / n < 1024u) {
+    const u32 per = WAL_WAVES_PER_BLOCK * 64 / 16;
+    hipLaunchKernelGGL(rgb_wal_frame_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data, (unsigned char *)d_out,
+                       (u32 *)d_checksums, flags);
+  } else {
+    const u32 per = WAL_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(rgb_wal_frame_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data, (unsigned char *)d_out,
+                       (u32 *)d_checksums, flags);
+  }
+  return hipGetLastError() == hipSuccess ? RGB_OK : RGB_E_HIP;
+}
+
 /* ---- host-buffer form: staging buffers live beside the context (keyed by it), grown on demand ---- */
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 namespace {
-struct wal_stage { void *d_entries = nullptr; void *d_data = nullptr; void *d_out = nullptr; size_t cap_e = 0, cap_d = 0; };
+struct wal_stage {
+  void *d_entries = nullptr; void *d_data = nullptr; void *d_out = nullptr; size_t cap_e = 0, cap_d = 0;
+  void *d_records = nullptr; void *d_frame = nullptr; size_t cap_r = 0, cap_f = 0;   /* rgb_wal_frame */
+};
 std::mutex g_stage_mu;
 std::unordered_map<rgb_ctx *, wal_stage> g_stage;
 int grow(void **p, size_t *cap, size_t need) {
@@ -167,6 +311,8 @@ extern "C" void rgb_wal_release(rgb_ctx *ctx) {      /* called by rgb_close */
   if (it->second.d_entries) (void)hipFree(it->second.d_entries);
   if (it->second.d_data) (void)hipFree(it->second.d_data);
   if (it->second.d_out) (void)hipFree(it->second.d_out);
+  if (it->second.d_records) (void)hipFree(it->second.d_records);
+  if (it->second.d_frame) (void)hipFree(it->second.d_frame);
   g_stage.erase(it);
 }
 
@@ -194,4 +340,128 @@ extern "C" int rgb_wal_adler32(rgb_ctx *ctx, const rgb_wal_entry *entries, uint3
   if (rc) return rc;
   if (hipMemcpyAsync(checksums, s.d_out, (size_t)n * sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess) return RGB_E_HIP;
   return hipStreamSynchronize(st) == hipSuccess ? RGB_OK : RGB_E_HIP;
+}
+
+extern "C" int rgb_wal_frame(rgb_ctx *ctx, const rgb_wal_record *records, uint32_t n, const void *data,
+                             uint64_t data_bytes, void *out, uint64_t out_bytes, uint32_t flags) {
+  if (!ctx || (n && (!records || !out)) || (data_bytes && !data)) return RGB_E_INVAL;
+  if (n == 0) return RGB_OK;
+  /* every slice inside its buffer, records ascending and disjoint in the output */
+  uint64_t floor_off = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const rgb_wal_record &r = records[i];
+    if (r.data_offset + r.data_len > data_bytes || r.hdr_offset + r.hdr_len > data_bytes) return RGB_E_INVAL;
+    if (r.hdr_len < 3u || r.out_offset < floor_off) return RGB_E_INVAL;
+    floor_off = r.out_offset + r.hdr_len + 24u + r.data_len;
+    if (floor_off > out_bytes) return RGB_E_INVAL;
+  }
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  wal_stage &s = g_stage[ctx];
+  const size_t need_r = (size_t)n * sizeof(rgb_wal_record);
+  if (grow(&s.d_records, &s.cap_r, need_r)) return RGB_E_NOMEM;
+  if (grow(&s.d_data, &s.cap_d, (size_t)data_bytes + 16)) return RGB_E_NOMEM;
+  if (grow(&s.d_frame, &s.cap_f, (size_t)out_bytes + 16)) return RGB_E_NOMEM;
+  hipStream_t st = (hipStream_t)rgb_ctx_stream(ctx);
+  if (hipMemcpyAsync(s.d_records, records, need_r, hipMemcpyHostToDevice, st) != hipSuccess) return RGB_E_HIP;
+  if (data_bytes && hipMemcpyAsync(s.d_data, data, data_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return RGB_E_HIP;
+  /* gaps between records (none when laid out by rgb_wal_layout) read back as zeros */
+  if (hipMemsetAsync(s.d_frame, 0, out_bytes, st) != hipSuccess) return RGB_E_HIP;
+  int rc = rgb_wal_frame_device(ctx, s.d_records, n, s.d_data, data_bytes, s.d_frame, out_bytes, nullptr, flags, st);
+  if (rc) return rc;
+  if (hipMemcpyAsync(out, s.d_frame, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return RGB_E_HIP;
+  return hipStreamSynchronize(st) == hipSuccess ? RGB_OK : RGB_E_HIP;
+}
+
+/* ---- recovery: the record walk of recover_records/5 (src/ra_log_wal.erl:877-984), host code ---- */
+namespace {
+inline uint64_t be(const unsigned char *p, int nbytes) {
+  uint64_t v = 0;
+  for (int k = 0; k < nbytes; ++k) v = (v << 8) | p[k];
+  return v;
+}
+}  // namespace
+
+extern "C" int rgb_wal_scan(const void *bytes, uint64_t n_bytes, rgb_wal_scanned *out, uint32_t cap,
+                            uint32_t *n_out, uint64_t *consumed, uint32_t *end) {
+  if (!bytes || !n_out || !consumed || !end || (cap && !out)) return RGB_E_INVAL;
+  const unsigned char *b = (const unsigned char *)bytes;
+  /* <<"RAWA", 1:8/unsigned>> (:34-36, :826-835) */
+  if (n_bytes < 5 || b[0] != 'R' || b[1] != 'A' || b[2] != 'W' || b[3] != 'A' || b[4] != 1) return RGB_E_INVAL;
+  std::vector<bool> named(1u << 22, false);             /* IdRefs introduced by a long header so far */
+  uint64_t pos = 5;
+  uint32_t n = 0;
+  *end = RGB_WAL_END_DATA;
+  for (;;) {
+    const uint64_t left = n_bytes - pos;
+    if (left < 3) break;
+    const uint32_t h = (uint32_t)be(b + pos, 3);
+    const uint32_t trunc = h >> 23, form = (h >> 22) & 1u, id_ref = h & 0x3FFFFFu;
+    uint64_t fixed = pos + 3;                           /* -> Checksum */
+    uint32_t uid_len = 0;
+    uint64_t uid_off = 0;
+    if (form == 0) {
+      if (left < 5) break;
+      uid_len = (uint32_t)be(b + pos + 3, 2);
+      uid_off = pos + 5;
+      fixed = uid_off + uid_len;
+    }
+    if (fixed + 8 > n_bytes) break;
+    const uint32_t checksum = (uint32_t)be(b + fixed, 4), data_len = (uint32_t)be(b + fixed + 4, 4);
+    /* first clause: an all-zero record ends a pre-allocated file (:877-883) */
+    if (h == 0 && checksum == 0 && data_len == 0) { *end = RGB_WAL_END_ZEROS; break; }
+    if (fixed + 24 > n_bytes || fixed + 24 + (uint64_t)data_len > n_bytes) break;
+    if (n == cap) { *end = RGB_WAL_END_CAP; break; }
+    rgb_wal_scanned &r = out[n++];
+    r.index = be(b + fixed + 8, 8);
+    r.term = be(b + fixed + 16, 8);
+    r.data_offset = fixed + 24;
+    r.data_len = data_len;
+    r.checksum = checksum;
+    r.uid_offset = uid_off;
+    r.id_ref = id_ref;
+    r.uid_len = (uint16_t)uid_len;
+    r.trunc = (uint8_t)trunc;
+    r.next_offset = fixed + 24 + data_len;
+    if (form == 0) {
+      named[id_ref] = true;
+      r.flags = RGB_WAL_REC_FIRST | RGB_WAL_REC_VALIDATE;
+    } else {
+      r.flags = named[id_ref] ? RGB_WAL_REC_VALIDATE : RGB_WAL_REC_UNKNOWN;
+    }
+    pos = r.next_offset;
+  }
+  *n_out = n;
+  *consumed = pos;
+  return RGB_OK;
+}
+
+extern "C" int rgb_wal_validate(rgb_ctx *ctx, const void *bytes, uint64_t n_bytes, const rgb_wal_scanned *recs,
+                                uint32_t n, uint32_t *n_ok, uint32_t *status) {
+  if (!ctx || !n_ok || !status || (n && (!recs || !bytes))) return RGB_E_INVAL;
+  *n_ok = n;
+  *status = RGB_WAL_CLEAN;
+  if (n == 0) return RGB_OK;
+  std::vector<rgb_wal_entry> entries(n);
+  std::vector<uint32_t> sums(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    entries[i].index = recs[i].index; entries[i].term = recs[i].term;
+    entries[i].data_offset = recs[i].data_offset; entries[i].data_len = recs[i].data_len; entries[i]._pad = 0;
+  }
+  int rc = rgb_wal_adler32(ctx, entries.data(), n, bytes, n_bytes, sums.data());
+  if (rc) return rc;
+  const unsigned char *b = (const unsigned char *)bytes;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!(recs[i].flags & RGB_WAL_REC_VALIDATE)) continue;
+    if (recs[i].checksum == 0 || recs[i].checksum == sums[i]) continue;   /* validate_checksum/4 :1022-1033 */
+    /* is_last_record/3 (:994-1010): 104 zero bits behind it, or fewer than 13 bytes to the end */
+    *n_ok = i;
+    const uint64_t rest = recs[i].next_offset;
+    bool last = true;
+    if (n_bytes - rest >= 13) {
+      for (int k = 0; k < 13; ++k) if (b[rest + k] != 0) { last = false; break; }
+    }
+    *status = last ? RGB_WAL_DROPPED_LAST : RGB_WAL_CORRUPT;
+    return RGB_OK;
+  }
+  return RGB_OK;
 }

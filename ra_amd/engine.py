@@ -24,7 +24,8 @@ EXPORTS = [
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize",
 ]
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_apply_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
-WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32"]                                     # include/ra_gpu_wal.h
+WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
+               "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
 
 class RgbError(RuntimeError):
@@ -95,6 +96,12 @@ def lib():
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     L.rgb_wal_adler32_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, vp]
     L.rgb_wal_adler32.argtypes = [vp, vp, u32, vp, C.c_uint64, vp]
+    L.rgb_wal_layout.restype = C.c_uint64
+    L.rgb_wal_layout.argtypes = [vp, u32, C.c_uint64]
+    L.rgb_wal_frame_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, C.c_uint64, vp, u32, vp]
+    L.rgb_wal_frame.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, C.c_uint64, u32]
+    L.rgb_wal_scan.argtypes = [vp, C.c_uint64, vp, u32, C.POINTER(C.c_uint32), u64p, C.POINTER(C.c_uint32)]
+    L.rgb_wal_validate.argtypes = [vp, vp, C.c_uint64, vp, u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     if L.rgb_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("ABI version mismatch")
     for i, dt in enumerate(abi.STRUCT_DTYPES):
@@ -267,6 +274,34 @@ class RaGpuBatch:
                                             out.ctypes.data), "rgb_wal_adler32")
         return out
 
+    # -- WAL record framing and recovery validation (include/ra_gpu_wal.h) ---------------
+    def wal_frame_device(self, d_records: int, n: int, d_data: int, data_bytes: int, d_out: int, out_bytes: int,
+                         d_checksums: int = 0, flags: int = 0, stream: int = 0):
+        """Frame n rgb_wal_record records into d_out (src/ra_log_wal.erl:513-537); enqueues and returns."""
+        self._check(self._L.rgb_wal_frame_device(self._h, d_records, n, d_data, data_bytes, d_out, out_bytes,
+                                                 d_checksums or None, flags, stream or None), "rgb_wal_frame_device")
+
+    def wal_frame(self, records: np.ndarray, data: np.ndarray, out_bytes: int, flags: int = 0) -> np.ndarray:
+        """Host-buffer form: the framed bytes [0, out_bytes) of `records` (abi.WAL_RECORD_DTYPE)."""
+        records = np.ascontiguousarray(records, dtype=abi.WAL_RECORD_DTYPE)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        out = np.zeros(out_bytes, dtype=np.uint8)
+        self._check(self._L.rgb_wal_frame(self._h, records.ctypes.data, len(records),
+                                          data.ctypes.data if len(data) else None, len(data),
+                                          out.ctypes.data if out_bytes else None, out_bytes, flags), "rgb_wal_frame")
+        return out
+
+    def wal_validate(self, file_bytes: np.ndarray, scanned: np.ndarray):
+        """(n_ok, status) of the scanned records of a WAL file: validate_checksum/4 on every record
+        flagged WAL_REC_VALIDATE, is_last_record/3 on the first failure (src/ra_log_wal.erl:994-1033)."""
+        file_bytes = np.ascontiguousarray(file_bytes, dtype=np.uint8)
+        scanned = np.ascontiguousarray(scanned, dtype=abi.WAL_SCANNED_DTYPE)
+        n_ok, status = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.rgb_wal_validate(self._h, file_bytes.ctypes.data, len(file_bytes),
+                                             scanned.ctypes.data if len(scanned) else None, len(scanned),
+                                             C.byref(n_ok), C.byref(status)), "rgb_wal_validate")
+        return n_ok.value, status.value
+
     # -- observability -----------------------------------------------------------------
     def snapshot(self) -> np.ndarray:
         rows = np.zeros(self.n_groups, dtype=abi.LEADERBOARD_DTYPE)
@@ -284,6 +319,27 @@ class RaGpuBatch:
 
     def synchronize(self):
         self._check(self._L.rgb_synchronize(self._h), "rgb_synchronize")
+
+
+def wal_layout(records: np.ndarray, base: int = 0) -> int:
+    """Fill out_offset for back-to-back records from `base`; returns the end offset (host helper)."""
+    assert records.dtype == abi.WAL_RECORD_DTYPE and records.flags["C_CONTIGUOUS"]
+    return int(lib().rgb_wal_layout(records.ctypes.data if len(records) else None, len(records), base))
+
+
+def wal_scan(file_bytes, cap: int | None = None):
+    """recover_records/5's record walk over a whole WAL file (host code, no device):
+    (records as abi.WAL_SCANNED_DTYPE, consumed bytes, end reason abi.WAL_END_*)."""
+    buf = np.frombuffer(bytes(file_bytes), dtype=np.uint8) if not isinstance(file_bytes, np.ndarray) else \
+        np.ascontiguousarray(file_bytes, dtype=np.uint8)
+    cap = max(1, len(buf) // 27) if cap is None else cap
+    out = np.zeros(cap, dtype=abi.WAL_SCANNED_DTYPE)
+    n, consumed, end = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
+    rc = lib().rgb_wal_scan(buf.ctypes.data if len(buf) else None, len(buf), out.ctypes.data, cap,
+                            C.byref(n), C.byref(consumed), C.byref(end))
+    if rc != 0:
+        raise RgbError(rc, "rgb_wal_scan")
+    return out[:n.value].copy(), consumed.value, end.value
 
 
 def combine_checksums(per_server: np.ndarray, first: int = 0) -> int:
