@@ -16,7 +16,7 @@
 
 -export([init/0, open/4, register_groups/3, upload_state/3, download_state/3,
          submit/3, collect/1, start_collector/2, snapshot/2, wal_checksums/3]).
--export([wal_batch_checksums/2]).
+-export([wal_batch_checksums/2, wal_frame/4, wal_recover_check/2, wal_frame_batch/3, wal_recover/2]).
 -export([encode_msg/3, decode_decision/1, decision_to_effects/3]).
 
 -include_lib("ra/src/ra.hrl").
@@ -70,6 +70,9 @@ start_collector(_Ctx, _Pid) -> erlang:nif_error(not_loaded).
 snapshot(_Ctx, _NGroups) -> erlang:nif_error(not_loaded).
 wal_checksums(_Ctx, _EntriesBin, _DataBin) -> erlang:nif_error(not_loaded).
 
+wal_frame(_Ctx, _RecordsBin, _DataBin, _Flags) -> erlang:nif_error(not_loaded).
+wal_recover_check(_Ctx, _FileBin) -> erlang:nif_error(not_loaded).
+
 %% ra_log_wal:write_data/8 computes erlang:adler32([<<Idx:64, Term:64>> | EntryData]) per record
 %% (src/ra_log_wal.erl:528-534); for a whole write_batch: Entries = [{Idx, Term, Bin}].
 wal_batch_checksums(Ctx, Entries) ->
@@ -81,6 +84,48 @@ wal_batch_checksums(Ctx, Entries) ->
                     end, {<<>>, [], 0}, Entries),
     {ok, Sums} = wal_checksums(Ctx, EntriesBin, iolist_to_binary(Data)),
     [C || <<C:32/little>> <= Sums].
+
+%% The record bytes of a whole WAL batch.  Records = [{HeaderData, Idx, Term, EntryData}] where
+%% HeaderData is what ra_log_wal:serialize_header/3 returned for the writer (the writer-name cache
+%% stays in #wal{}); the result is the iodata write_data/8 would have accumulated in
+%% #batch.pending (src/ra_log_wal.erl:513-537), ready for file:write/2 in flush_pending/1.
+wal_frame_batch(Ctx, Records, ComputeChecksums) ->
+    {RecsBin, Data, _} =
+        lists:foldl(fun({Hdr, Idx, Term, Bin}, {R, D, Off}) ->
+                            HLen = byte_size(Hdr),
+                            Len = byte_size(Bin),
+                            {<<R/binary, Idx:64/little, Term:64/little, (Off + HLen):64/little,
+                               Len:32/little, HLen:32/little, Off:64/little, 0:64>>,
+                             [D, Hdr, Bin], Off + HLen + Len}
+                    end, {<<>>, [], 0}, Records),
+    Flags = case ComputeChecksums of true -> 0; false -> 1 end,
+    {ok, Framed} = wal_frame(Ctx, RecsBin, iolist_to_binary(Data), Flags),
+    Framed.
+
+%% Recovery of one WAL file (src/ra_log_wal.erl:877-1033): the walk and every checksum in one
+%% call; returns the records to hand to recover_entry/5, in file order, or throws like the
+%% reference.  IsRegistered = fun(UId) -> boolean() (ra_directory:is_registered_uid/2).
+wal_recover(Ctx, FileBin) ->
+    {ok, Scanned, NOk, Status} = wal_recover_check(Ctx, FileBin),
+    Status =:= corrupt andalso throw(wal_checksum_validation_failure),
+    Recs = [R || <<R:56/binary>> <= Scanned],
+    {Good, _} = lists:split(NOk, Recs),
+    {_, Out} =
+        lists:foldl(
+          fun(<<Idx:64/little, Term:64/little, DOff:64/little, DLen:32/little, _Crc:32/little,
+                UOff:64/little, IdRef:32/little, ULen:16/little, Trunc:8, Flags:8, _Next:64/little>>,
+              {Names0, Acc}) ->
+                  Names = case Flags band 1 of
+                              1 -> Names0#{IdRef => binary:part(FileBin, UOff, ULen)};
+                              0 -> Names0
+                          end,
+                  case Flags band 4 of
+                      4 -> {Names, Acc};            %% IdRef of a deleted writer: skipped
+                      0 -> {Names, [{maps:get(IdRef, Names), Trunc =:= 1, Idx, Term,
+                                     binary:part(FileBin, DOff, DLen)} | Acc]}
+                  end
+          end, {#{}, []}, Good),
+    lists:reverse(Out).
 
 %% Slot = fun(ra_server_id()) -> 0..7 | 255, the member slot of a server id inside its group.
 encode_msg(Server, #append_entries_rpc{term = T, leader_id = L, leader_commit = LC,

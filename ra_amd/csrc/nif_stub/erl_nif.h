@@ -30,8 +30,10 @@ typedef struct {
 ERL_NIF_TERM enif_make_atom(ErlNifEnv *, const char *);
 ERL_NIF_TERM enif_make_tuple2(ErlNifEnv *, ERL_NIF_TERM, ERL_NIF_TERM);
 ERL_NIF_TERM enif_make_tuple3(ErlNifEnv *, ERL_NIF_TERM, ERL_NIF_TERM, ERL_NIF_TERM);
+ERL_NIF_TERM enif_make_tuple4(ErlNifEnv *, ERL_NIF_TERM, ERL_NIF_TERM, ERL_NIF_TERM, ERL_NIF_TERM);
 ERL_NIF_TERM enif_make_tuple5(ErlNifEnv *, ERL_NIF_TERM, ERL_NIF_TERM, ERL_NIF_TERM, ERL_NIF_TERM, ERL_NIF_TERM);
 ERL_NIF_TERM enif_make_int(ErlNifEnv *, int);
+ERL_NIF_TERM enif_make_uint(ErlNifEnv *, unsigned);
 ERL_NIF_TERM enif_make_uint64(ErlNifEnv *, uint64_t);
 ERL_NIF_TERM enif_make_badarg(ErlNifEnv *);
 ERL_NIF_TERM enif_make_binary(ErlNifEnv *, ErlNifBinary *);
@@ -44,6 +46,9 @@ int enif_get_local_pid(ErlNifEnv *, ERL_NIF_TERM, ErlNifPid *);
 int enif_inspect_binary(ErlNifEnv *, ERL_NIF_TERM, ErlNifBinary *);
 int enif_alloc_binary(size_t, ErlNifBinary *);
 void enif_release_binary(ErlNifBinary *);
+int enif_realloc_binary(ErlNifBinary *, size_t);
+void *enif_alloc(size_t);
+void enif_free(void *);
 void *enif_alloc_resource(ErlNifResourceType *, size_t);
 void enif_release_resource(void *);
 void enif_keep_resource(void *);

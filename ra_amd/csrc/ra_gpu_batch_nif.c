@@ -209,6 +209,49 @@ static ERL_NIF_TERM nif_wal_checksums(ErlNifEnv *env, int argc, const ERL_NIF_TE
   return enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_binary(env, &out));
 }
 
+/* wal_frame(Ctx, RecordsBin, DataBin, Flags) -> {ok, FramedBin}: RecordsBin = n rgb_wal_record
+ * descriptors (out_offset is filled here, back to back from 0), DataBin = the HeaderData and payload
+ * bytes they point into; FramedBin = the batch's on-disk bytes, what write_data/8 accumulates in
+ * #batch.pending and flush_pending/1 hands to file:write/2 (src/ra_log_wal.erl:513-537, 638-650) */
+static ERL_NIF_TERM nif_wal_frame(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c; ErlNifBinary r, d, out; unsigned flags;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &r) ||
+      !enif_inspect_binary(env, argv[2], &d) || !enif_get_uint(env, argv[3], &flags) ||
+      r.size % sizeof(rgb_wal_record) != 0)
+    return enif_make_badarg(env);
+  const uint32_t n = (uint32_t)(r.size / sizeof(rgb_wal_record));
+  rgb_wal_record *recs = (rgb_wal_record *)enif_alloc(r.size ? r.size : 1);
+  if (!recs) return mk_error(env, c, RGB_E_NOMEM);
+  memcpy(recs, r.data, r.size);                       /* binaries are immutable: lay out a copy */
+  const uint64_t total = rgb_wal_layout(recs, n, 0);
+  if (!enif_alloc_binary((size_t)total, &out)) { enif_free(recs); return mk_error(env, c, RGB_E_NOMEM); }
+  int rc = rgb_wal_frame(c->ctx, recs, n, d.data, d.size, out.data, total, flags);
+  enif_free(recs);
+  if (rc) { enif_release_binary(&out); return mk_error(env, c, rc); }
+  return enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_binary(env, &out));
+}
+
+/* wal_recover_check(Ctx, FileBin) -> {ok, ScannedBin, NOk, clean | dropped_last | corrupt}: the
+ * record walk of recover_records/5 plus validate_checksum/4 for every record, is_last_record/3 on
+ * the first failure (src/ra_log_wal.erl:877-1033).  ScannedBin = n rgb_wal_scanned records; the
+ * caller recovers the first NOk of them and throws wal_checksum_validation_failure on `corrupt`. */
+static ERL_NIF_TERM nif_wal_recover_check(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c; ErlNifBinary f, out;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &f)) return enif_make_badarg(env);
+  const uint32_t cap = (uint32_t)(f.size / 27 + 1);   /* the shortest record is 27 bytes */
+  if (!enif_alloc_binary((size_t)cap * sizeof(rgb_wal_scanned), &out)) return mk_error(env, c, RGB_E_NOMEM);
+  uint32_t n = 0, end = 0, n_ok = 0, status = 0; uint64_t consumed = 0;
+  int rc = rgb_wal_scan(f.data, f.size, (rgb_wal_scanned *)out.data, cap, &n, &consumed, &end);
+  if (!rc) rc = rgb_wal_validate(c->ctx, f.data, f.size, (const rgb_wal_scanned *)out.data, n, &n_ok, &status);
+  if (rc) { enif_release_binary(&out); return mk_error(env, c, rc); }
+  enif_realloc_binary(&out, (size_t)n * sizeof(rgb_wal_scanned));
+  const char *st = status == RGB_WAL_CLEAN ? "clean" : status == RGB_WAL_DROPPED_LAST ? "dropped_last" : "corrupt";
+  return enif_make_tuple4(env, enif_make_atom(env, "ok"), enif_make_binary(env, &out),
+                          enif_make_uint(env, n_ok), enif_make_atom(env, st));
+}
+
 static ErlNifFunc nif_funcs[] = {
   {"open", 4, nif_open, 0},
   {"register_groups", 3, nif_register_groups, ERL_NIF_DIRTY_JOB_IO_BOUND},
@@ -219,6 +262,8 @@ static ErlNifFunc nif_funcs[] = {
   {"start_collector", 2, nif_start_collector, 0},
   {"snapshot", 2, nif_snapshot, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"wal_checksums", 3, nif_wal_checksums, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"wal_frame", 4, nif_wal_frame, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"wal_recover_check", 2, nif_wal_recover_check, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(ra_gpu_batch, nif_funcs, on_load, NULL, NULL, NULL)
