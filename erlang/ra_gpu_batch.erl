@@ -161,7 +161,10 @@ encode_msg(Server, {consistent_query, _From, _Fun}, _Slot) ->
     %% query index the decision returns (reply_last_term)
     <<Server:32/little, ?MSG_CONSISTENT_QUERY:8, ?NONE:8, 0:8, 0:8, 0:(7 * 64)>>;
 encode_msg(Server, pipeline_rpcs, _Slot) ->
-    <<Server:32/little, ?MSG_PIPELINE_RPCS:8, ?NONE:8, 0:8, 0:8, 0:(7 * 64)>>.
+    <<Server:32/little, ?MSG_PIPELINE_RPCS:8, ?NONE:8, 0:8, 0:8, 0:(7 * 64)>>;
+encode_msg(Server, tick_timeout, _Slot) ->
+    %% leader(_, tick_timeout, _) -> make_rpcs/1 (src/ra_server_proc.erl:613-616): RGB_MF_TICK = 4
+    <<Server:32/little, ?MSG_PIPELINE_RPCS:8, ?NONE:8, 4:8, 0:8, 0:(7 * 64)>>.
 
 entry_runs(_PI, []) -> {0, 0, 0, 0, 0};
 entry_runs(PI, [{I0, T0, _} | _] = Es) ->

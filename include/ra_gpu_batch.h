@@ -85,6 +85,9 @@ enum {
 /* rgb_msg.flags */
 #define RGB_MF_SUCCESS  0x01u  /* AER_REPLY: success=true; VOTE_RESULT: vote_granted=true */
 #define RGB_MF_FORCE    0x02u  /* APPEND: noop command => Force pipelining (src/ra_server.erl:682-689) */
+#define RGB_MF_TICK     0x04u  /* PIPELINE_RPCS: the leader's tick_timeout -- ra_server:make_rpcs/1: heartbeats for
+                                  waiting queries plus one batch-of-1 rpc per stale peer, next_index not advanced
+                                  (src/ra_server.erl:2348-2351, 2369-2377, 3012-3030; src/ra_server_proc.erl:613-616) */
 
 /*
  * One inbound message, 64 bytes.  Field use by kind:
@@ -96,6 +99,7 @@ enum {
  *   VOTE_RESULT   term, from=voter, flags&SUCCESS=vote_granted
  *   WRITTEN       term, a=first index of the written range, b=last index of the written range
  *   APPEND        n_entries = number of commands appended by the leader (flags&FORCE for noop)
+ *   PIPELINE_RPCS (no fields); flags&TICK = tick_timeout on a leader (make_rpcs/1 over stale_peers/1)
  *   ELECTION_TIMEOUT  c = fresh pre-vote token (the host's make_ref())
  *   PRE_VOTE_RPC  term, from=candidate_id, a=last_log_index, b=last_log_term, c=token,
  *                 n_entries=candidate machine_version, gap=protocol version

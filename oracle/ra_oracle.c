@@ -657,12 +657,15 @@ static int process_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx) {
 /* make_all_rpcs/1 :2353-2367 -> make_rpcs_for/2 :2369-2377: one append_entries_rpc (batch size 1)
  * to every peer with status normal; next_index is NOT advanced.  (heartbeat effects and
  * snapshot_backoff peers are outside the device model.) */
-static int make_all_rpcs(oserver *sv, uint32_t srv_id, ofx *fx) {
+static int make_rpcs_for_peers(oserver *sv, uint32_t srv_id, int only_stale, ofx *fx) {
   oscal *s = &sv->s;
-  update_heartbeat_rpc_effects(s, fx);                      /* :2354-2355 */
+  update_heartbeat_rpc_effects(s, fx);                      /* :2349 / :2354-2355 */
   for (unsigned i = 0; i < s->n_members; i++) {
     if (i == s->self || !is_present(s, i)) continue;
     if (!((s->status_mask >> i) & 1u)) continue;
+    /* make_rpcs/1 on tick: stale_peers/1 :3012-3030 -- unconfirmed items or a newer commit index */
+    if (only_stale && !(s->match_index[i] + 1 < s->next_index[i] || s->commit_index_sent[i] < s->commit_index))
+      continue;
     uint64_t prev = s->next_index[i] - 1;
     uint64_t prev_term = log_fetch_term(&sv->log, prev);
     rgb_rpc r;
@@ -688,6 +691,8 @@ static int make_all_rpcs(oserver *sv, uint32_t srv_id, ofx *fx) {
   }
   return 0;
 }
+
+static int make_all_rpcs(oserver *sv, uint32_t srv_id, ofx *fx) { return make_rpcs_for_peers(sv, srv_id, 0, fx); }
 
 /* ------------------------------------------------------------- follower clauses -- */
 static int follower_aer(oserver *sv, const rgb_msg *m, ofx *fx);
@@ -968,6 +973,8 @@ static int handle_leader(struct ora_ctx *c, oserver *sv, uint32_t srv_id, const 
       return 0;
     }
     case RGB_MSG_PIPELINE_RPCS: {
+      if (m->flags & RGB_MF_TICK)                          /* leader tick_timeout: make_rpcs/1 :2348-2351 */
+        return make_rpcs_for_peers(sv, srv_id, 1, fx);
       /* :793-801 */
       int more;
       int rc = make_pipelined_rpc_effects(c, sv, srv_id, 0, &more, fx);

@@ -33,6 +33,7 @@ PROTO_VERSION = 1
 KIND_RANK = np.array([15, 0, 1, 5, 6, 2, 4, 3, 7, 8, 9, 10, 11, 12, 13, 14], dtype=np.int64)
 MF_SUCCESS = 0x01
 MF_FORCE = 0x02
+MF_TICK = 0x04
 
 F_REPLY = 1 << 0
 F_REPLY_SUCCESS = 1 << 1

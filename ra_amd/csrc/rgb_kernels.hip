@@ -814,7 +814,7 @@ __device__ __forceinline__ int process_pre_vote(Lane &L) {
  * next_index NOT advanced */
 template <int N>
 __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *rpcs, u32 slot_base,
-                                             u32 msg_index) {
+                                             u32 msg_index, bool only_stale = false) {
   const unsigned self = self_of(L);
   update_heartbeat_rpc_effects<N>(L);                                /* :2354-2355 */
   load_peers<N>(L);
@@ -822,6 +822,8 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if ((unsigned)i == self || !present(L, i) || !status_normal(L, i)) continue;
+    /* make_rpcs/1 on tick: stale_peers/1 :3012-3030 -- unconfirmed items or a newer commit index */
+    if (only_stale && !(L.pmi[i] + 1 < L.pni[i] || L.pcs[i] < L.ci)) continue;
     const u64 prev = L.pni[i] - 1;
     u64 prev_term = fetch_term(L, prev);
     u64 rp_idx, rp_term, new_ni;
@@ -1118,6 +1120,13 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
     }
     case RGB_MSG_PIPELINE_RPCS:
     case RGB_MSG_APPEND: {
+      if (L.kind == RGB_MSG_PIPELINE_RPCS && (L.mflags & RGB_MF_TICK)) {
+        unsigned cnt;                                                /* tick_timeout: make_rpcs/1 :2348-2351 */
+        int rc = make_all_rpcs<N>(L, cnt, rpcs, slot_base, msg_index, true);
+        if (rc) return rc;
+        n_rpcs = cnt;
+        return 0;
+      }
       bool force = false;
       load_peers<N>(L);
       if (L.kind == RGB_MSG_APPEND) {

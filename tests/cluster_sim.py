@@ -1,0 +1,289 @@
+"""Closed-loop driver for the batched engine: the part of ra_server_proc that turns the effects of
+one transition into the next messages, written in Python for the tests (TEST TOOLING).
+
+Every member of every group is a row of the engine (or of the checker).  A tick hands each server at
+most one message; the decisions and rpc records that come back are routed exactly the way the owning
+gen_statem would route the reference's effects:
+
+  {send_rpc, Peer, #append_entries_rpc{}}      rgb_rpc record   -> AER to the peer (entries' terms read
+                                                                  from the leader's log, like ra_log does)
+  {cast, Leader, {Id, #append_entries_reply{}}} RGB_F_REPLY      -> AER_REPLY
+  {reply, #request_vote_result{}} / pre_vote    RGB_F_REPLY_VOTE / _PRE_VOTE -> VOTE_RESULT / PRE_VOTE_RESULT
+  {send_vote_requests, _}                       RGB_F_SEND_VOTE_REQUESTS     -> REQUEST_VOTE / PRE_VOTE_RPC
+  {next_event, info, pipeline_rpcs}             RGB_F_PIPELINE   -> PIPELINE_RPCS to itself
+  post_election_effects: noop command           RGB_F_BECAME_LEADER -> APPEND(1, force)
+  ra_log:write / ra_log:append -> WAL           RGB_F_WROTE / APPEND -> {written, Term, Seq} later, in
+                                                order, one event per term (ra_log_wal batch writers,
+                                                src/ra_log_wal.erl:596-635, 785-807)
+  heartbeat_rpc / heartbeat_reply               RGB_F_SEND_HEARTBEATS / RGB_F_REPLY_HEARTBEAT
+  leader tick_timeout -> ra_server:make_rpcs/1  PIPELINE_RPCS with RGB_MF_TICK (re-sends to stale peers)
+
+The network between members drops, delays, reorders and duplicates; local events (WAL, next_event)
+are reliable and ordered.  Timers (election_timeout, await_condition_timeout) and client commands
+fire at random.  Snapshots are not taken, so every log is complete and the Raft safety properties
+can be checked on the full logs after every tick (check_safety)."""
+from __future__ import annotations
+
+from collections import deque
+
+import numpy as np
+
+from ra_amd import abi
+
+
+def _msg(server, kind, frm=abi.NONE, **kw):
+    m = np.zeros(1, dtype=abi.MSG_DTYPE)
+    m["server"], m["kind"], m["from"] = server, kind, frm
+    for k, v in kw.items():
+        m[k] = v
+    return m[0]
+
+
+class ClusterSim:
+    def __init__(self, eng, n_groups, n_members, seed, drop=0.1, dup=0.03, max_delay=3,
+                 p_election=0.02, p_command=0.3, p_query=0.05, p_tick=0.3, max_leaders=9):
+        self.eng, self.G, self.N = eng, n_groups, n_members
+        self.S = n_groups * n_members
+        self.rng = np.random.default_rng(seed)
+        self.drop, self.dup, self.max_delay = drop, dup, max_delay
+        self.p_election, self.p_command, self.p_query, self.p_tick = p_election, p_command, p_query, p_tick
+        self.max_leaders = max_leaders
+        self.tick = 0
+        self.net = [[] for _ in range(self.S)]          # [(deliver_at, msg)]
+        self.local = [deque() for _ in range(self.S)]   # reliable, ordered
+        self.wal = [[] for _ in range(self.S)]          # writes the WAL has not confirmed: (first, last, term)
+        self.token = 1
+        self.leaders_of_term = [dict() for _ in range(n_groups)]   # term -> member slot
+        self.committed = [dict() for _ in range(n_groups)]         # index -> term, once any member committed it
+        self.elections = np.zeros(n_groups, dtype=np.int64)
+        self.stats = {"msgs": 0, "dropped": 0, "invariants": 0, "commands": 0, "queries_answered": 0}
+        self.history = []                                # the batches fed to the engine, for replay
+        self.leader_contact = np.full(self.S, -10**9, dtype=np.int64)   # tick of the last {record_leader_msg, _}
+        self.election_silence = 0                        # ticks without a leader message before a timeout may fire
+        self.quiet = 0                                   # consecutive ticks that produced no effect to route
+        self.state = eng.get_state()
+
+    # ------------------------------------------------------------------ network
+    def send(self, to_server, msg):
+        if self.rng.random() < self.drop:
+            self.stats["dropped"] += 1
+            return
+        # Erlang distribution delivers a message at most once.  ra_server counts granted votes with a
+        # plain counter (src/ra_server.erl:1045-1061, 1229-1246), which is only safe under that guarantee,
+        # so vote results are never duplicated here; the idempotent rpcs and replies are.
+        once = int(msg["kind"]) in (abi.MSG_VOTE_RESULT, abi.MSG_PRE_VOTE_RESULT)
+        copies = 2 if (not once and self.rng.random() < self.dup) else 1
+        for _ in range(copies):
+            self.net[to_server].append((self.tick + 1 + int(self.rng.integers(0, self.max_delay)), msg))
+
+    def heal(self):
+        """A reliable network from now on, and election timers that behave: they only fire after a
+        silence from the leader (liveness checks)."""
+        self.drop, self.dup = 0.0, 0.0
+        self.election_silence = 40
+
+    def idle(self):
+        return not any(self.net) and not any(self.local) and not any(self.wal)
+
+    # ------------------------------------------------------------------ one tick
+    def choose(self, s):
+        st = self.state[s]
+        role = int(st["role"])
+        r = self.rng.random()
+        if self.local[s] and r < 0.8:
+            return self.local[s].popleft()
+        ready = [k for k, (at, _) in enumerate(self.net[s]) if at <= self.tick]
+        if ready and r < 0.97:
+            k = ready[int(self.rng.integers(0, len(ready)))]
+            return self.net[s].pop(k)[1]
+        g = s // self.N
+        if role == abi.ROLE_LEADER:
+            if self.rng.random() < self.p_command:
+                self.stats["commands"] += 1
+                return _msg(s, abi.MSG_APPEND, n_entries=int(self.rng.integers(1, 4)))
+            if self.rng.random() < self.p_query:
+                return _msg(s, abi.MSG_CONSISTENT_QUERY)
+            if self.rng.random() < self.p_tick:                      # tick_timeout -> make_rpcs/1
+                return _msg(s, abi.MSG_PIPELINE_RPCS, flags=abi.MF_TICK)
+        elif role == abi.ROLE_AWAIT_CONDITION:
+            if self.rng.random() < 0.2:
+                return _msg(s, abi.MSG_AWAIT_TIMEOUT)
+        elif self.elections[g] < self.max_leaders and self.rng.random() < self.p_election and \
+                self.tick - self.leader_contact[s] >= self.election_silence:
+            self.token += 1
+            return _msg(s, abi.MSG_ELECTION_TIMEOUT, c=self.token)
+        return None
+
+    def step(self):
+        batch = [m for m in (self.choose(s) for s in range(self.S)) if m is not None]
+        self.tick += 1
+        if not batch:
+            self.flush_wals()
+            return None
+        msgs = np.array(batch, dtype=abi.MSG_DTYPE)
+        before = self.state
+        dec, rpcs = self.eng.step(msgs)
+        self.state = after = self.eng.get_state()
+        self.history.append(msgs)
+        self.stats["msgs"] += len(msgs)
+        by_msg = {}
+        for r in rpcs:
+            by_msg.setdefault(int(r["msg_index"]), []).append(r)
+        for i, (m, d) in enumerate(zip(msgs, dec)):
+            self.route(m, d, by_msg.get(i, []), before[int(m["server"])], after[int(m["server"])])
+        self.flush_wals()
+        return msgs, dec, rpcs
+
+    # ------------------------------------------------------------------ effects -> messages
+    def route(self, m, d, rpcs, st0, st1):
+        s = int(m["server"]); g = s // self.N; me = s % self.N
+        fl = int(d["flags"]); kind = int(m["kind"])
+        if fl & abi.F_LEADER_MSG:
+            self.leader_contact[s] = self.tick
+        if fl & abi.F_INVARIANT:
+            self.stats["invariants"] += 1
+            raise AssertionError(f"tick {self.tick}: server {s} hit reference invariant {int(d['invariant'])} "
+                                 f"on {m} in state {st0}")
+        peer = lambda slot: g * self.N + int(slot)
+        if fl & abi.F_REPLY:
+            to = int(d["reply_to"])
+            ok = abi.MF_SUCCESS if fl & abi.F_REPLY_SUCCESS else 0
+            if fl & abi.F_REPLY_VOTE:
+                self.send(peer(to), _msg(peer(to), abi.MSG_VOTE_RESULT, me, term=d["reply_term"], flags=ok))
+            elif fl & abi.F_REPLY_PRE_VOTE:
+                self.send(peer(to), _msg(peer(to), abi.MSG_PRE_VOTE_RESULT, me, term=d["reply_term"], flags=ok,
+                                         c=d["reply_next_index"]))
+            elif fl & abi.F_REPLY_HEARTBEAT:
+                self.send(peer(to), _msg(peer(to), abi.MSG_HEARTBEAT_REPLY, me, term=d["reply_term"],
+                                         a=d["reply_next_index"]))
+            else:
+                self.send(peer(to), _msg(peer(to), abi.MSG_AER_REPLY, me, term=d["reply_term"], flags=ok,
+                                         a=d["reply_next_index"], b=d["reply_last_index"], c=d["reply_last_term"]))
+        if fl & abi.F_SEND_VOTE_REQUESTS:
+            for slot in range(self.N):
+                if slot == me or not (int(st1["present_mask"]) >> slot) & 1:
+                    continue
+                if fl & abi.F_PRE_VOTE_REQS:
+                    self.send(peer(slot), _msg(peer(slot), abi.MSG_PRE_VOTE_RPC, me, term=d["reply_term"],
+                                               a=d["reply_last_index"], b=d["reply_last_term"],
+                                               c=d["reply_next_index"], n_entries=st1["machine_version"],
+                                               gap=abi.PROTO_VERSION))
+                else:
+                    self.send(peer(slot), _msg(peer(slot), abi.MSG_REQUEST_VOTE, me, term=d["reply_term"],
+                                               a=d["reply_last_index"], b=d["reply_last_term"]))
+        if fl & abi.F_SEND_HEARTBEATS:
+            for slot in range(self.N):
+                if (int(d["heartbeat_to"]) >> slot) & 1:
+                    self.send(peer(slot), _msg(peer(slot), abi.MSG_HEARTBEAT_RPC, me, term=d["reply_term"],
+                                               a=d["reply_last_term"]))
+        if fl & (abi.F_QUERY_QUORUM | abi.F_QUERY_APPLY):
+            self.stats["queries_answered"] += 1
+        if fl & abi.F_PIPELINE:
+            self.local[s].append(_msg(s, abi.MSG_PIPELINE_RPCS))
+        if fl & abi.F_BECAME_LEADER:
+            self.elections[g] += 1
+            self.local[s].append(_msg(s, abi.MSG_APPEND, n_entries=1, flags=abi.MF_FORCE))
+        # the log writes of this transition go to the WAL
+        if kind == abi.MSG_APPEND and not fl & abi.F_UNHANDLED and int(st1["last_index"]) > int(st0["last_index"]) \
+                and int(st1["role"]) == abi.ROLE_LEADER and int(st0["role"]) == abi.ROLE_LEADER:
+            self.wal[s].append((int(st0["last_index"]) + 1, int(st1["last_index"]), int(st1["current_term"])))
+        if fl & abi.F_WROTE:
+            base = int(m["a"]) + 1 + int(m["gap"])
+            split = base + int(m["n_run0"])
+            lo, hi = int(d["reply_next_index"]), int(d["reply_last_index"])
+            if lo < split:
+                self.wal[s].append((lo, min(hi, split - 1), int(m["run0_term"])))
+            if hi >= split:
+                self.wal[s].append((max(lo, split), hi, int(m["run1_term"])))
+        # outbound append_entries_rpcs: entries come from the leader's log as it is now
+        if rpcs:
+            log = dict(abi.log_entries(st1))
+            for r in rpcs:
+                assert int(r["kind"]) == abi.RPC_AER, "no snapshots are taken in this simulation"
+                self.send_aer(peer(r["peer"]), me, r, log)
+
+    def send_aer(self, to, me, r, log):
+        prev, n = int(r["prev_log_index"]), int(r["n_entries"])
+        terms = [log[prev + 1 + k] for k in range(n)]
+        pt = int(r["prev_log_term"])
+        if n == 0:
+            self.send(to, _msg(to, abi.MSG_AER, me, term=r["term"], a=prev, b=pt, c=r["leader_commit"]))
+            return
+        # at most two term runs ride in one rgb_msg: longer batches are cut at the third run
+        k = 0
+        while k < n:
+            t0 = terms[k]; e0 = k
+            while e0 < n and terms[e0] == t0:
+                e0 += 1
+            e1 = e0
+            if e0 < n:
+                t1 = terms[e0]
+                while e1 < n and terms[e1] == t1:
+                    e1 += 1
+            else:
+                t1 = 0
+            self.send(to, _msg(to, abi.MSG_AER, me, term=r["term"], a=prev + k, b=pt, c=r["leader_commit"],
+                               n_entries=e1 - k, n_run0=e0 - k, run0_term=t0, run1_term=t1))
+            pt = terms[e1 - 1]
+            k = e1
+
+    def flush_wals(self):
+        """complete_batch: one {written, Term, Seq} per writer and term, oldest first."""
+        for s in range(self.S):
+            if not self.wal[s] or self.rng.random() < 0.5:
+                continue
+            cur = None                                   # (term, lo, hi) of the open batch writer
+            for lo, hi, term in self.wal[s]:
+                if cur and cur[0] == term:
+                    # ra_seq:append, or limit(Idx-1) then append on a rewrite (:607-616)
+                    clo, chi = cur[1], cur[2]
+                    if lo > chi:
+                        assert lo == chi + 1
+                        cur = (term, clo, hi)
+                    else:
+                        cur = (term, min(clo, lo), hi)
+                else:
+                    if cur:
+                        self.local[s].append(_msg(s, abi.MSG_WRITTEN, term=cur[0], a=cur[1], b=cur[2]))
+                    cur = (term, lo, hi)
+            self.local[s].append(_msg(s, abi.MSG_WRITTEN, term=cur[0], a=cur[1], b=cur[2]))
+            self.wal[s] = []
+
+    # ------------------------------------------------------------------ Raft safety
+    def check_safety(self):
+        st = self.state
+        for g in range(self.G):
+            rows = st[g * self.N:(g + 1) * self.N]
+            logs = [dict(abi.log_entries(r)) for r in rows]
+            # election safety: at most one leader per term
+            for slot, r in enumerate(rows):
+                if int(r["role"]) == abi.ROLE_LEADER:
+                    t = int(r["current_term"])
+                    prev = self.leaders_of_term[g].setdefault(t, slot)
+                    assert prev == slot, f"group {g}: members {prev} and {slot} both led term {t}"
+            # log matching: same (index, term) => identical prefixes
+            for a in range(self.N):
+                for b in range(a + 1, self.N):
+                    common = [i for i in logs[a] if i in logs[b] and logs[a][i] == logs[b][i]]
+                    if common:
+                        top = max(common)
+                        for i in range(1, top + 1):
+                            assert logs[a].get(i) == logs[b].get(i), \
+                                f"group {g}: logs of {a} and {b} match at {top} but differ at {i}"
+            # state machine safety: a committed index never changes its term, on any member
+            for slot, r in enumerate(rows):
+                # (a follower takes LeaderCommit as it comes, src/ra_server.erl:1331-1332, 1366: its
+                # commit_index may step back below last_applied under a new leader; both bound what is known
+                # committed)
+                ci = max(int(r["commit_index"]), int(r["last_applied"]))
+                assert int(r["last_applied"]) <= int(r["last_index"])
+                for i in range(1, min(ci, int(r["last_index"])) + 1):
+                    t = logs[slot][i]
+                    was = self.committed[g].setdefault(i, t)
+                    assert was == t, f"group {g} member {slot}: committed index {i} had term {was}, now {t}"
+            # leader completeness: a leader holds every entry committed so far
+            for slot, r in enumerate(rows):
+                if int(r["role"]) == abi.ROLE_LEADER and int(r["current_term"]) == max(self.leaders_of_term[g]):
+                    for i, t in self.committed[g].items():
+                        assert logs[slot].get(i) == t, \
+                            f"group {g}: leader {slot} of term {int(r['current_term'])} lacks committed {i}:{t}"

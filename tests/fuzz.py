@@ -230,6 +230,8 @@ def random_msgs(rng: np.random.Generator, st: np.ndarray, n_members: int, frac: 
         elif kind == abi.MSG_APPEND:
             m["n_entries"][q] = int(rng.integers(0, 5))
             m["flags"][q] = abi.MF_FORCE if rng.random() < 0.2 else 0
+        elif kind == abi.MSG_PIPELINE_RPCS:
+            m["flags"][q] = abi.MF_TICK if rng.random() < 0.4 else 0      # tick_timeout: make_rpcs/1
         _ = self_
     return m
 

@@ -1,0 +1,97 @@
+"""Closed-loop clusters (tests/cluster_sim.py): the decisions and rpc records of the restated
+transition are routed back as the next messages over a lossy, reordering, duplicating network, and
+the Raft safety properties are checked on the full logs after every tick -- election safety, log
+matching, state-machine safety and leader completeness (Ongaro & Ousterhout, figure 3; the properties
+ra_server's clauses exist to keep).  After the network heals every group must elect one leader and
+replicate every command to every member.  No transcribed vector takes part: this is an end-to-end
+check of the semantics themselves, and on the GPU the same message streams must give bit-identical
+decisions and states."""
+import numpy as np
+import pytest
+
+from ra_amd import abi
+from cluster_sim import ClusterSim
+
+
+def run_lossy_then_heal(eng, G, N, seed, lossy_ticks=500, heal_ticks=500):
+    sim = ClusterSim(eng, G, N, seed)
+    for _ in range(lossy_ticks):
+        sim.step()
+        sim.check_safety()
+    sim.heal()
+    sim.p_command = 0.05
+    for t in range(heal_ticks):
+        sim.step()
+        sim.check_safety()
+    sim.p_command = sim.p_query = 0.0               # let the tail replicate: run until nothing is in flight
+    calm = 0
+    for t in range(3000):
+        sim.step()
+        sim.check_safety()
+        calm = calm + 1 if sim.idle() else 0
+        if calm >= 60:
+            break
+    return sim
+
+
+@pytest.mark.parametrize("n_members,seed", [(3, 1), (5, 2), (3, 3), (7, 4), (2, 5), (1, 6)])
+def test_closed_loop_clusters_keep_raft_safety_and_converge(oracle_lib, n_members, seed):
+    G = 6
+    cpu = oracle_lib.Oracle(G, n_members)
+    cpu.set_state(0, abi.empty_server_states(G, n_members))
+    sim = run_lossy_then_heal(cpu, G, n_members, seed)
+    st = sim.state
+    assert sim.stats["invariants"] == 0
+    assert sim.stats["commands"] > 0 and sim.stats["msgs"] > 1000
+    progressed = 0
+    for g in range(G):
+        rows = st[g * n_members:(g + 1) * n_members]
+        leaders = [i for i, r in enumerate(rows) if int(r["role"]) == abi.ROLE_LEADER]
+        if not sim.leaders_of_term[g]:
+            continue                                 # no election timeout ever fired in this group
+        top = max(int(r["current_term"]) for r in rows)
+        live = [i for i in leaders if int(rows[i]["current_term"]) == top]
+        if sim.elections[g] >= sim.max_leaders and not live:
+            continue                                 # ran out of its election budget while partitioned
+        assert len(live) == 1, f"group {g}: leaders {leaders} terms {[int(r['current_term']) for r in rows]}"
+        lead = rows[live[0]]
+        li = int(lead["last_index"])
+        assert li >= 1
+        for i, r in enumerate(rows):                 # everything replicated, written and committed everywhere
+            assert int(r["last_index"]) == li and int(r["last_term"]) == int(lead["last_term"]), (g, i)
+            # (a reordered, older append_entries_rpc may have stepped commit_index back -- the follower
+            # takes LeaderCommit as it comes, src/ra_server.erl:1331-1332 -- but never last_applied)
+            assert int(r["last_applied"]) == li and int(r["commit_index"]) <= li, (g, i, int(r["commit_index"]), li)
+            assert abi.log_entries(r) == abi.log_entries(lead)
+        progressed += 1
+    assert progressed >= G - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_members,seed", [(3, 11), (5, 12), (7, 13)])
+def test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, n_members, seed):
+    """The streams a live cluster produces (elections, repairs after drops, overwrites by new leaders,
+    stale and duplicated rpcs) replayed through the HIP engine: decisions, rpcs and states bit-identical
+    to the checker's at every tick."""
+    import os
+    from ra_amd import engine
+    from test_gpu_parity import assert_same
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build()
+    G = 32
+    cpu = oracle_lib.Oracle(G, n_members)
+    st0 = abi.empty_server_states(G, n_members)
+    cpu.set_state(0, st0)
+    sim = run_lossy_then_heal(cpu, G, n_members, seed, lossy_ticks=250, heal_ticks=150)
+    ref = oracle_lib.Oracle(G, n_members)
+    ref.set_state(0, st0)
+    seen = 0
+    with engine.RaGpuBatch(G, n_members, ring_capacity=max(4096, G * n_members), ring_slots=2, max_runs=16) as gpu:
+        gpu.set_state(0, st0)
+        for t, msgs in enumerate(sim.history):
+            do, ro = ref.step(msgs)
+            dg, rg = gpu.step(msgs)
+            assert_same(f"closed loop N={n_members} tick {t}", dg, rg, gpu.get_state(), do, ro, ref.get_state())
+            seen |= int(np.bitwise_or.reduce(do["flags"]))
+    for f in (abi.F_REPLY, abi.F_WROTE, abi.F_BECAME_LEADER, abi.F_SEND_VOTE_REQUESTS, abi.F_PIPELINE, abi.F_APPLIED):
+        assert seen & f, hex(f)
