@@ -20,8 +20,10 @@ gen_statem would route the reference's effects:
 
 The network between members drops, delays, reorders and duplicates; local events (WAL, next_event)
 are reliable and ordered.  Timers (election_timeout, await_condition_timeout) and client commands
-fire at random.  Snapshots are not taken, so every log is complete and the Raft safety properties
-can be checked on the full logs after every tick (check_safety)."""
+fire at random.  With p_snapshot > 0 members also take snapshots (SNAPSHOT_WRITTEN truncates their logs) and a
+leader whose peer fell behind its snapshot sends it: that transfer is ra_server's business, emulated
+here on the rows and written back with set_state.  The Raft safety properties are checked on what the
+logs still hold after every tick (check_safety)."""
 from __future__ import annotations
 
 from collections import deque
@@ -41,13 +43,15 @@ def _msg(server, kind, frm=abi.NONE, **kw):
 
 class ClusterSim:
     def __init__(self, eng, n_groups, n_members, seed, drop=0.1, dup=0.03, max_delay=3,
-                 p_election=0.02, p_command=0.3, p_query=0.05, p_tick=0.3, max_leaders=9):
+                 p_election=0.02, p_command=0.3, p_query=0.05, p_tick=0.3, max_leaders=9, p_snapshot=0.0):
         self.eng, self.G, self.N = eng, n_groups, n_members
         self.S = n_groups * n_members
         self.rng = np.random.default_rng(seed)
         self.drop, self.dup, self.max_delay = drop, dup, max_delay
         self.p_election, self.p_command, self.p_query, self.p_tick = p_election, p_command, p_query, p_tick
         self.max_leaders = max_leaders
+        self.p_snapshot = p_snapshot                     # > 0: members take snapshots at last_applied
+        self.host = []                                   # host-level snapshot transfers: (deliver_at, what, args)
         self.tick = 0
         self.net = [[] for _ in range(self.S)]          # [(deliver_at, msg)]
         self.local = [deque() for _ in range(self.S)]   # reliable, ordered
@@ -56,7 +60,8 @@ class ClusterSim:
         self.leaders_of_term = [dict() for _ in range(n_groups)]   # term -> member slot
         self.committed = [dict() for _ in range(n_groups)]         # index -> term, once any member committed it
         self.elections = np.zeros(n_groups, dtype=np.int64)
-        self.stats = {"msgs": 0, "dropped": 0, "invariants": 0, "commands": 0, "queries_answered": 0}
+        self.stats = {"msgs": 0, "dropped": 0, "invariants": 0, "commands": 0, "queries_answered": 0,
+                      "snapshots": 0, "installs": 0, "install_refused": 0}
         self.history = []                                # the batches fed to the engine, for replay
         self.leader_contact = np.full(self.S, -10**9, dtype=np.int64)   # tick of the last {record_leader_msg, _}
         self.election_silence = 0                        # ticks without a leader message before a timeout may fire
@@ -83,7 +88,7 @@ class ClusterSim:
         self.election_silence = 40
 
     def idle(self):
-        return not any(self.net) and not any(self.local) and not any(self.wal)
+        return not any(self.net) and not any(self.local) and not any(self.wal) and not self.host
 
     # ------------------------------------------------------------------ one tick
     def choose(self, s):
@@ -97,6 +102,14 @@ class ClusterSim:
             k = ready[int(self.rng.integers(0, len(ready)))]
             return self.net[s].pop(k)[1]
         g = s // self.N
+        if self.p_snapshot and self.rng.random() < self.p_snapshot:
+            # ra_snapshot finished writing a snapshot of the machine at last_applied
+            la = int(st["last_applied"])
+            si = 0 if int(st["snapshot_index"]) == abi.UNDEF_INT else int(st["snapshot_index"])
+            if la >= si + 3 and la >= int(st["first_index"]):
+                term = dict(abi.log_entries(st))[la]
+                self.stats["snapshots"] += 1
+                return _msg(s, abi.MSG_SNAPSHOT_WRITTEN, a=la, b=term)
         if role == abi.ROLE_LEADER:
             if self.rng.random() < self.p_command:
                 self.stats["commands"] += 1
@@ -114,7 +127,14 @@ class ClusterSim:
             return _msg(s, abi.MSG_ELECTION_TIMEOUT, c=self.token)
         return None
 
+    def edit(self, s, row):
+        """A host-side change of one server's integer state (rgb_upload_state): recorded for replay."""
+        self.eng.set_state(s, row.reshape(1))
+        self.history.append(("set", s, row.copy()))
+        self.state = self.eng.get_state()
+
     def step(self):
+        self.run_host_events()
         batch = [m for m in (self.choose(s) for s in range(self.S)) if m is not None]
         self.tick += 1
         if not batch:
@@ -199,8 +219,85 @@ class ClusterSim:
         if rpcs:
             log = dict(abi.log_entries(st1))
             for r in rpcs:
-                assert int(r["kind"]) == abi.RPC_AER, "no snapshots are taken in this simulation"
-                self.send_aer(peer(r["peer"]), me, r, log)
+                if int(r["kind"]) == abi.RPC_SNAPSHOT:
+                    self.send_snapshot(s, int(r["peer"]), int(r["prev_log_index"]), int(r["prev_log_term"]),
+                                       int(r["term"]))
+                else:
+                    self.send_aer(peer(r["peer"]), me, r, log)
+
+    # ------------------------------------------------------------------ snapshot transfer (host side)
+    # {send_snapshot, Peer, _} is not part of the batched path: ra_server_proc spawns a sender, marks the
+    # peer {sending_snapshot, _} (no rpcs to it meanwhile), the follower goes through receive_snapshot
+    # and ra_log:install_snapshot, and the leader handles #install_snapshot_result{}
+    # (src/ra_server.erl:764-792, 1556-1590, 1744-1806; src/ra_log.erl:1216-1260).  Those transitions
+    # stay in ra_server; the shell re-uploads the integer state they produce.  Here they are emulated
+    # on the rows and written back with set_state.
+    def send_snapshot(self, leader, slot, idx, term, leader_term):
+        row = self.state[leader].copy()
+        row["status_mask"] &= np.uint8(~(1 << slot) & 0xFF)          # {sending_snapshot, Pid}
+        self.edit(leader, row)
+        g = leader // self.N
+        self.host.append((self.tick + 1 + int(self.rng.integers(0, 4)), "install",
+                          (leader, g * self.N + slot, idx, term, leader_term)))
+
+    def run_host_events(self):
+        due = [e for e in self.host if e[0] <= self.tick]
+        self.host = [e for e in self.host if e[0] > self.tick]
+        for _, what, args in due:
+            getattr(self, "host_" + what)(*args)
+
+    def host_install(self, leader, follower, idx, term, leader_term):
+        st = self.state[follower]
+        ok = (int(st["role"]) == abi.ROLE_FOLLOWER and leader_term >= int(st["current_term"])
+              and idx > int(st["last_applied"]))
+        if ok and (self.wal[follower] or any(int(m["kind"]) == abi.MSG_WRITTEN for m in self.local[follower])):
+            # {awaiting_pending, ..}: the last chunk waits until the WAL has confirmed everything
+            self.host.append((self.tick + 2, "install", (leader, follower, idx, term, leader_term)))
+            return
+        if not ok:
+            self.stats["install_refused"] += 1
+            self.host.append((self.tick + 1, "sender_down", (leader, follower % self.N, leader_term)))
+            return
+        row = st.copy()
+        if leader_term > int(row["current_term"]):
+            row["current_term"] = leader_term
+            row["voted_for"] = abi.NONE
+        row["leader_id"] = leader % self.N
+        # ra_log:install_snapshot: range = undefined, last_term = SnapTerm, last_written = {SnapIdx, SnapTerm}
+        row["snapshot_index"], row["snapshot_term"] = idx, term
+        row["last_index"], row["last_term"] = idx, term
+        row["last_written_index"], row["last_written_term"] = idx, term
+        row["first_index"] = idx + 1
+        row["pending_first"] = idx + 1
+        row["n_runs"] = 0
+        row["run_start"] = 0
+        row["run_term"] = 0
+        row["commit_index"] = row["last_applied"] = idx
+        self.edit(follower, row)
+        self.leader_contact[follower] = self.tick
+        self.stats["installs"] += 1
+        self.host.append((self.tick + 1 + int(self.rng.integers(0, 3)), "result",
+                          (leader, follower % self.N, idx, leader_term)))
+
+    def host_result(self, leader, slot, idx, leader_term):
+        st = self.state[leader]
+        if int(st["role"]) != abi.ROLE_LEADER or int(st["current_term"]) != leader_term:
+            return                                                  # no longer that leader: the peers were reset
+        row = st.copy()
+        row["match_index"][slot] = idx
+        row["next_index"][slot] = idx + 1
+        row["commit_index_sent"][slot] = idx
+        row["status_mask"] |= np.uint8(1 << slot)
+        self.edit(leader, row)
+        self.local[leader].append(_msg(leader, abi.MSG_PIPELINE_RPCS))
+
+    def host_sender_down(self, leader, slot, leader_term):
+        st = self.state[leader]
+        if int(st["role"]) != abi.ROLE_LEADER or int(st["current_term"]) != leader_term:
+            return
+        row = st.copy()
+        row["status_mask"] |= np.uint8(1 << slot)                   # 'DOWN' of the sender: back to normal
+        self.edit(leader, row)
 
     def send_aer(self, to, me, r, log):
         prev, n = int(r["prev_log_index"]), int(r["n_entries"])
@@ -261,13 +358,14 @@ class ClusterSim:
                     t = int(r["current_term"])
                     prev = self.leaders_of_term[g].setdefault(t, slot)
                     assert prev == slot, f"group {g}: members {prev} and {slot} both led term {t}"
-            # log matching: same (index, term) => identical prefixes
+            # log matching: same (index, term) => identical prefixes (as far as both logs still hold them)
             for a in range(self.N):
                 for b in range(a + 1, self.N):
                     common = [i for i in logs[a] if i in logs[b] and logs[a][i] == logs[b][i]]
                     if common:
                         top = max(common)
-                        for i in range(1, top + 1):
+                        lo = max(min(logs[a]), min(logs[b]), 1)
+                        for i in range(lo, top + 1):
                             assert logs[a].get(i) == logs[b].get(i), \
                                 f"group {g}: logs of {a} and {b} match at {top} but differ at {i}"
             # state machine safety: a committed index never changes its term, on any member
@@ -277,13 +375,20 @@ class ClusterSim:
                 # committed)
                 ci = max(int(r["commit_index"]), int(r["last_applied"]))
                 assert int(r["last_applied"]) <= int(r["last_index"])
-                for i in range(1, min(ci, int(r["last_index"])) + 1):
+                for i in range(max(1, int(r["first_index"])), min(ci, int(r["last_index"])) + 1):
                     t = logs[slot][i]
                     was = self.committed[g].setdefault(i, t)
                     assert was == t, f"group {g} member {slot}: committed index {i} had term {was}, now {t}"
+            for slot, r in enumerate(rows):
+                si = int(r["snapshot_index"])
+                if si != abi.UNDEF_INT and si in self.committed[g]:
+                    assert self.committed[g][si] == int(r["snapshot_term"]), \
+                        f"group {g} member {slot}: snapshot {si}:{int(r['snapshot_term'])} vs committed {self.committed[g][si]}"
             # leader completeness: a leader holds every entry committed so far
             for slot, r in enumerate(rows):
                 if int(r["role"]) == abi.ROLE_LEADER and int(r["current_term"]) == max(self.leaders_of_term[g]):
                     for i, t in self.committed[g].items():
+                        if i < int(r["first_index"]):
+                            continue                                 # below its snapshot: committed by definition
                         assert logs[slot].get(i) == t, \
                             f"group {g}: leader {slot} of term {int(r['current_term'])} lacks committed {i}:{t}"

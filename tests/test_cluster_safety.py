@@ -13,8 +13,8 @@ from ra_amd import abi
 from cluster_sim import ClusterSim
 
 
-def run_lossy_then_heal(eng, G, N, seed, lossy_ticks=500, heal_ticks=500):
-    sim = ClusterSim(eng, G, N, seed)
+def run_lossy_then_heal(eng, G, N, seed, lossy_ticks=500, heal_ticks=500, **kw):
+    sim = ClusterSim(eng, G, N, seed, **kw)
     for _ in range(lossy_ticks):
         sim.step()
         sim.check_safety()
@@ -23,7 +23,7 @@ def run_lossy_then_heal(eng, G, N, seed, lossy_ticks=500, heal_ticks=500):
     for t in range(heal_ticks):
         sim.step()
         sim.check_safety()
-    sim.p_command = sim.p_query = 0.0               # let the tail replicate: run until nothing is in flight
+    sim.p_command = sim.p_query = sim.p_snapshot = 0.0   # let the tail replicate: run until nothing is in flight
     calm = 0
     for t in range(3000):
         sim.step()
@@ -40,6 +40,10 @@ def test_closed_loop_clusters_keep_raft_safety_and_converge(oracle_lib, n_member
     cpu = oracle_lib.Oracle(G, n_members)
     cpu.set_state(0, abi.empty_server_states(G, n_members))
     sim = run_lossy_then_heal(cpu, G, n_members, seed)
+    check_converged(sim, G, n_members)
+
+
+def check_converged(sim, G, n_members):
     st = sim.state
     assert sim.stats["invariants"] == 0
     assert sim.stats["commands"] > 0 and sim.stats["msgs"] > 1000
@@ -62,14 +66,31 @@ def test_closed_loop_clusters_keep_raft_safety_and_converge(oracle_lib, n_member
             # (a reordered, older append_entries_rpc may have stepped commit_index back -- the follower
             # takes LeaderCommit as it comes, src/ra_server.erl:1331-1332 -- but never last_applied)
             assert int(r["last_applied"]) == li and int(r["commit_index"]) <= li, (g, i, int(r["commit_index"]), li)
-            assert abi.log_entries(r) == abi.log_entries(lead)
+            mine, theirs = dict(abi.log_entries(r)), dict(abi.log_entries(lead))
+            assert all(theirs[k] == t for k, t in mine.items() if k in theirs)
         progressed += 1
     assert progressed >= G - 1
+    return sim
+
+
+@pytest.mark.parametrize("n_members,seed", [(3, 21), (5, 22), (7, 23)])
+def test_closed_loop_clusters_with_snapshots(oracle_lib, n_members, seed):
+    """The same, with members taking snapshots at last_applied (SNAPSHOT_WRITTEN truncates the log) and
+    leaders sending their snapshot to peers that fell behind it (RGB_RPC_SNAPSHOT / RGB_F_SEND_SNAPSHOT;
+    the transfer itself is emulated on the host side, tests/cluster_sim.py)."""
+    G = 6
+    cpu = oracle_lib.Oracle(G, n_members)
+    cpu.set_state(0, abi.empty_server_states(G, n_members))
+    sim = run_lossy_then_heal(cpu, G, n_members, seed, lossy_ticks=900, heal_ticks=300,
+                              p_snapshot=0.03, max_leaders=14, drop=0.15)
+    check_converged(sim, G, n_members)
+    assert sim.stats["snapshots"] > 50 and sim.stats["installs"] > 0
+    assert int(sim.elections.max()) > 9
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_members,seed", [(3, 11), (5, 12), (7, 13)])
-def test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, n_members, seed):
+@pytest.mark.parametrize("n_members,seed,snapshots", [(3, 11, False), (5, 12, False), (7, 13, False), (5, 14, True)])
+def test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, n_members, seed, snapshots):
     """The streams a live cluster produces (elections, repairs after drops, overwrites by new leaders,
     stale and duplicated rpcs) replayed through the HIP engine: decisions, rpcs and states bit-identical
     to the checker's at every tick."""
@@ -82,16 +103,24 @@ def test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, n_memb
     cpu = oracle_lib.Oracle(G, n_members)
     st0 = abi.empty_server_states(G, n_members)
     cpu.set_state(0, st0)
-    sim = run_lossy_then_heal(cpu, G, n_members, seed, lossy_ticks=250, heal_ticks=150)
+    kw = dict(p_snapshot=0.03, max_leaders=14, drop=0.15) if snapshots else {}
+    sim = run_lossy_then_heal(cpu, G, n_members, seed, lossy_ticks=250, heal_ticks=150, **kw)
     ref = oracle_lib.Oracle(G, n_members)
     ref.set_state(0, st0)
     seen = 0
     with engine.RaGpuBatch(G, n_members, ring_capacity=max(4096, G * n_members), ring_slots=2, max_runs=16) as gpu:
         gpu.set_state(0, st0)
         for t, msgs in enumerate(sim.history):
+            if isinstance(msgs, tuple):                  # a host-side state edit (snapshot transfer)
+                _, server, row = msgs
+                ref.set_state(server, row.reshape(1))
+                gpu.set_state(server, row.reshape(1))
+                continue
             do, ro = ref.step(msgs)
             dg, rg = gpu.step(msgs)
             assert_same(f"closed loop N={n_members} tick {t}", dg, rg, gpu.get_state(), do, ro, ref.get_state())
             seen |= int(np.bitwise_or.reduce(do["flags"]))
     for f in (abi.F_REPLY, abi.F_WROTE, abi.F_BECAME_LEADER, abi.F_SEND_VOTE_REQUESTS, abi.F_PIPELINE, abi.F_APPLIED):
         assert seen & f, hex(f)
+    if snapshots:
+        assert seen & abi.F_SEND_SNAPSHOT
