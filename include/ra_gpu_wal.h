@@ -119,7 +119,8 @@ typedef struct rgb_wal_scanned {
 #define RGB_WAL_END_CAP   2u     /* `cap` records written, more may follow from *consumed */
 
 /* Parse `bytes` (a whole WAL file including its 5-byte "RAWA", version 1 header, :826-835; an
- * unknown header gives RGB_E_INVAL) into at most `cap` records.  Pure host code. */
+ * unknown header gives RGB_E_INVAL) into at most `cap` records.  out = NULL counts the records of the
+ * file into *n_out without storing them (size the array, then scan again).  Pure host code. */
 int rgb_wal_scan(const void *bytes, uint64_t n_bytes, rgb_wal_scanned *out, uint32_t cap,
                  uint32_t *n_out, uint64_t *consumed, uint32_t *end);
 

@@ -240,10 +240,11 @@ static ERL_NIF_TERM nif_wal_recover_check(ErlNifEnv *env, int argc, const ERL_NI
   nif_ctx *c; ErlNifBinary f, out;
   (void)argc;
   if (!get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &f)) return enif_make_badarg(env);
-  const uint32_t cap = (uint32_t)(f.size / 27 + 1);   /* the shortest record is 27 bytes */
-  if (!enif_alloc_binary((size_t)cap * sizeof(rgb_wal_scanned), &out)) return mk_error(env, c, RGB_E_NOMEM);
-  uint32_t n = 0, end = 0, n_ok = 0, status = 0; uint64_t consumed = 0;
-  int rc = rgb_wal_scan(f.data, f.size, (rgb_wal_scanned *)out.data, cap, &n, &consumed, &end);
+  uint32_t cap = 0, n = 0, end = 0, n_ok = 0, status = 0; uint64_t consumed = 0;
+  int rc = rgb_wal_scan(f.data, f.size, NULL, 0, &cap, &consumed, &end);   /* count, then size the binary */
+  if (rc) return mk_error(env, c, rc);
+  if (!enif_alloc_binary((size_t)(cap ? cap : 1) * sizeof(rgb_wal_scanned), &out)) return mk_error(env, c, RGB_E_NOMEM);
+  rc = rgb_wal_scan(f.data, f.size, (rgb_wal_scanned *)out.data, cap, &n, &consumed, &end);
   if (!rc) rc = rgb_wal_validate(c->ctx, f.data, f.size, (const rgb_wal_scanned *)out.data, n, &n_ok, &status);
   if (rc) { enif_release_binary(&out); return mk_error(env, c, rc); }
   enif_realloc_binary(&out, (size_t)n * sizeof(rgb_wal_scanned));

@@ -383,7 +383,8 @@ inline uint64_t be(const unsigned char *p, int nbytes) {
 
 extern "C" int rgb_wal_scan(const void *bytes, uint64_t n_bytes, rgb_wal_scanned *out, uint32_t cap,
                             uint32_t *n_out, uint64_t *consumed, uint32_t *end) {
-  if (!bytes || !n_out || !consumed || !end || (cap && !out)) return RGB_E_INVAL;
+  if (!bytes || !n_out || !consumed || !end) return RGB_E_INVAL;
+  const bool count_only = out == nullptr;              /* out = NULL: count the records, store nothing */
   const unsigned char *b = (const unsigned char *)bytes;
   /* <<"RAWA", 1:8/unsigned>> (:34-36, :826-835) */
   if (n_bytes < 5 || b[0] != 'R' || b[1] != 'A' || b[2] != 'W' || b[3] != 'A' || b[4] != 1) return RGB_E_INVAL;
@@ -410,6 +411,12 @@ extern "C" int rgb_wal_scan(const void *bytes, uint64_t n_bytes, rgb_wal_scanned
     /* first clause: an all-zero record ends a pre-allocated file (:877-883) */
     if (h == 0 && checksum == 0 && data_len == 0) { *end = RGB_WAL_END_ZEROS; break; }
     if (fixed + 24 > n_bytes || fixed + 24 + (uint64_t)data_len > n_bytes) break;
+    if (count_only) {
+      if (form == 0) named[id_ref] = true;
+      n += 1;
+      pos = fixed + 24 + data_len;
+      continue;
+    }
     if (n == cap) { *end = RGB_WAL_END_CAP; break; }
     rgb_wal_scanned &r = out[n++];
     r.index = be(b + fixed + 8, 8);

@@ -332,9 +332,14 @@ def wal_scan(file_bytes, cap: int | None = None):
     (records as abi.WAL_SCANNED_DTYPE, consumed bytes, end reason abi.WAL_END_*)."""
     buf = np.frombuffer(bytes(file_bytes), dtype=np.uint8) if not isinstance(file_bytes, np.ndarray) else \
         np.ascontiguousarray(file_bytes, dtype=np.uint8)
-    cap = max(1, len(buf) // 27) if cap is None else cap
-    out = np.zeros(cap, dtype=abi.WAL_SCANNED_DTYPE)
     n, consumed, end = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
+    if cap is None:                                   # count first, then size the array
+        rc = lib().rgb_wal_scan(buf.ctypes.data if len(buf) else None, len(buf), None, 0,
+                                C.byref(n), C.byref(consumed), C.byref(end))
+        if rc != 0:
+            raise RgbError(rc, "rgb_wal_scan")
+        cap = max(1, n.value)
+    out = np.zeros(cap, dtype=abi.WAL_SCANNED_DTYPE)
     rc = lib().rgb_wal_scan(buf.ctypes.data if len(buf) else None, len(buf), out.ctypes.data, cap,
                             C.byref(n), C.byref(consumed), C.byref(end))
     if rc != 0:
