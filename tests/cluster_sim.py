@@ -1,5 +1,6 @@
 """Closed-loop driver for the batched engine: the part of ra_server_proc that turns the effects of
-one transition into the next messages, written in Python for the tests (TEST TOOLING).
+one transition into the next messages (TEST TOOLING; the record/effect vocabulary and the encoding are
+ra_amd/effects.py, the Python twin of erlang/ra_gpu_batch.erl).
 
 Every member of every group is a row of the engine (or of the checker).  A tick hands each server at
 most one message; the decisions and rpc records that come back are routed exactly the way the owning
@@ -18,8 +19,9 @@ gen_statem would route the reference's effects:
   heartbeat_rpc / heartbeat_reply               RGB_F_SEND_HEARTBEATS / RGB_F_REPLY_HEARTBEAT
   leader tick_timeout -> ra_server:make_rpcs/1  PIPELINE_RPCS with RGB_MF_TICK (re-sends to stale peers)
 
-The network between members drops, delays, reorders and duplicates; local events (WAL, next_event)
-are reliable and ordered.  Timers (election_timeout, await_condition_timeout) and client commands
+The network between members drops and delays, and reorders between different senders (never between
+the same two members, never duplicating: Erlang distribution); local events (WAL, next_event) are
+reliable and ordered.  Timers (election_timeout, await_condition_timeout) and client commands
 fire at random.  With p_snapshot > 0 members also take snapshots (SNAPSHOT_WRITTEN truncates their logs) and a
 leader whose peer fell behind its snapshot sends it: that transfer is ra_server's business, emulated
 here on the rows and written back with set_state.  The Raft safety properties are checked on what the
@@ -30,24 +32,16 @@ from collections import deque
 
 import numpy as np
 
-from ra_amd import abi
-
-
-def _msg(server, kind, frm=abi.NONE, **kw):
-    m = np.zeros(1, dtype=abi.MSG_DTYPE)
-    m["server"], m["kind"], m["from"] = server, kind, frm
-    for k, v in kw.items():
-        m[k] = v
-    return m[0]
+from ra_amd import abi, effects
 
 
 class ClusterSim:
-    def __init__(self, eng, n_groups, n_members, seed, drop=0.1, dup=0.03, max_delay=3,
+    def __init__(self, eng, n_groups, n_members, seed, drop=0.1, max_delay=3,
                  p_election=0.02, p_command=0.3, p_query=0.05, p_tick=0.3, max_leaders=9, p_snapshot=0.0):
         self.eng, self.G, self.N = eng, n_groups, n_members
         self.S = n_groups * n_members
         self.rng = np.random.default_rng(seed)
-        self.drop, self.dup, self.max_delay = drop, dup, max_delay
+        self.drop, self.max_delay = drop, max_delay
         self.p_election, self.p_command, self.p_query, self.p_tick = p_election, p_command, p_query, p_tick
         self.max_leaders = max_leaders
         self.p_snapshot = p_snapshot                     # > 0: members take snapshots at last_applied
@@ -70,21 +64,20 @@ class ClusterSim:
 
     # ------------------------------------------------------------------ network
     def send(self, to_server, msg):
+        """Erlang distribution between two processes: messages may be lost (a dropped connection) but are
+        never duplicated and never overtake each other.  ra_server relies on both -- granted votes are
+        counted with a plain counter (src/ra_server.erl:1045-1061), and an old empty append_entries_rpc
+        overtaken by newer ones would trip ?assertNot(PLIdx < LastApplied) (:1317) -- so the simulated
+        network drops and delays, and reorders only between different senders."""
         if self.rng.random() < self.drop:
             self.stats["dropped"] += 1
             return
-        # Erlang distribution delivers a message at most once.  ra_server counts granted votes with a
-        # plain counter (src/ra_server.erl:1045-1061, 1229-1246), which is only safe under that guarantee,
-        # so vote results are never duplicated here; the idempotent rpcs and replies are.
-        once = int(msg["kind"]) in (abi.MSG_VOTE_RESULT, abi.MSG_PRE_VOTE_RESULT)
-        copies = 2 if (not once and self.rng.random() < self.dup) else 1
-        for _ in range(copies):
-            self.net[to_server].append((self.tick + 1 + int(self.rng.integers(0, self.max_delay)), msg))
+        self.net[to_server].append((self.tick + 1 + int(self.rng.integers(0, self.max_delay)), msg))
 
     def heal(self):
         """A reliable network from now on, and election timers that behave: they only fire after a
         silence from the leader (liveness checks)."""
-        self.drop, self.dup = 0.0, 0.0
+        self.drop = 0.0
         self.election_silence = 40
 
     def idle(self):
@@ -97,7 +90,15 @@ class ClusterSim:
         r = self.rng.random()
         if self.local[s] and r < 0.8:
             return self.local[s].popleft()
-        ready = [k for k, (at, _) in enumerate(self.net[s]) if at <= self.tick]
+        # the oldest message of every sender (FIFO per pair), once its delay has passed
+        heads, ready = set(), []
+        for k, (at, msg) in enumerate(self.net[s]):
+            frm = int(msg["from"])
+            if frm in heads:
+                continue
+            heads.add(frm)
+            if at <= self.tick:
+                ready.append(k)
         if ready and r < 0.97:
             k = ready[int(self.rng.integers(0, len(ready)))]
             return self.net[s].pop(k)[1]
@@ -109,22 +110,24 @@ class ClusterSim:
             if la >= si + 3 and la >= int(st["first_index"]):
                 term = dict(abi.log_entries(st))[la]
                 self.stats["snapshots"] += 1
-                return _msg(s, abi.MSG_SNAPSHOT_WRITTEN, a=la, b=term)
+                return effects.encode(s, effects.SnapshotWritten(la, term))
         if role == abi.ROLE_LEADER:
             if self.rng.random() < self.p_command:
                 self.stats["commands"] += 1
-                return _msg(s, abi.MSG_APPEND, n_entries=int(self.rng.integers(1, 4)))
+                return effects.encode(s, effects.Commands(int(self.rng.integers(1, 4))))
             if self.rng.random() < self.p_query:
-                return _msg(s, abi.MSG_CONSISTENT_QUERY)
+                return effects.encode(s, effects.CONSISTENT_QUERY)
             if self.rng.random() < self.p_tick:                      # tick_timeout -> make_rpcs/1
-                return _msg(s, abi.MSG_PIPELINE_RPCS, flags=abi.MF_TICK)
+                return effects.encode(s, effects.TICK_TIMEOUT)
         elif role == abi.ROLE_AWAIT_CONDITION:
             if self.rng.random() < 0.2:
-                return _msg(s, abi.MSG_AWAIT_TIMEOUT)
-        elif self.elections[g] < self.max_leaders and self.rng.random() < self.p_election and \
+                return effects.encode(s, effects.AWAIT_CONDITION_TIMEOUT)
+        elif (self.elections[g] < self.max_leaders or
+              int(self.state["n_runs"][g * self.N:(g + 1) * self.N].max()) <= 5) and \
+                self.rng.random() < self.p_election and \
                 self.tick - self.leader_contact[s] >= self.election_silence:
             self.token += 1
-            return _msg(s, abi.MSG_ELECTION_TIMEOUT, c=self.token)
+            return effects.encode(s, effects.ElectionTimeout(self.token))
         return None
 
     def edit(self, s, row):
@@ -160,49 +163,38 @@ class ClusterSim:
         fl = int(d["flags"]); kind = int(m["kind"])
         if fl & abi.F_LEADER_MSG:
             self.leader_contact[s] = self.tick
-        if fl & abi.F_INVARIANT:
-            self.stats["invariants"] += 1
-            raise AssertionError(f"tick {self.tick}: server {s} hit reference invariant {int(d['invariant'])} "
-                                 f"on {m} in state {st0}")
         peer = lambda slot: g * self.N + int(slot)
-        if fl & abi.F_REPLY:
-            to = int(d["reply_to"])
-            ok = abi.MF_SUCCESS if fl & abi.F_REPLY_SUCCESS else 0
-            if fl & abi.F_REPLY_VOTE:
-                self.send(peer(to), _msg(peer(to), abi.MSG_VOTE_RESULT, me, term=d["reply_term"], flags=ok))
-            elif fl & abi.F_REPLY_PRE_VOTE:
-                self.send(peer(to), _msg(peer(to), abi.MSG_PRE_VOTE_RESULT, me, term=d["reply_term"], flags=ok,
-                                         c=d["reply_next_index"]))
-            elif fl & abi.F_REPLY_HEARTBEAT:
-                self.send(peer(to), _msg(peer(to), abi.MSG_HEARTBEAT_REPLY, me, term=d["reply_term"],
-                                         a=d["reply_next_index"]))
-            else:
-                self.send(peer(to), _msg(peer(to), abi.MSG_AER_REPLY, me, term=d["reply_term"], flags=ok,
-                                         a=d["reply_next_index"], b=d["reply_last_index"], c=d["reply_last_term"]))
-        if fl & abi.F_SEND_VOTE_REQUESTS:
-            for slot in range(self.N):
-                if slot == me or not (int(st1["present_mask"]) >> slot) & 1:
-                    continue
-                if fl & abi.F_PRE_VOTE_REQS:
-                    self.send(peer(slot), _msg(peer(slot), abi.MSG_PRE_VOTE_RPC, me, term=d["reply_term"],
-                                               a=d["reply_last_index"], b=d["reply_last_term"],
-                                               c=d["reply_next_index"], n_entries=st1["machine_version"],
-                                               gap=abi.PROTO_VERSION))
+        for e in effects.decode(m, d, rpcs, st1, self.N):
+            tag = e if isinstance(e, str) else e[0]
+            if tag == "exit":
+                self.stats["invariants"] += 1
+                raise AssertionError(f"tick {self.tick}: server {s} hit reference invariant {e[1]} "
+                                     f"on {m} in state {st0}")
+            elif tag == "reply":                                     # {reply, _}: back to the caller
+                to = int(m["from"])
+                self.send(peer(to), effects.encode(peer(to), e[1], from_slot=me))
+            elif tag == "cast":                                      # {cast, To, {Id, Reply}}
+                to, (frm, rec) = e[1], e[2]
+                self.send(peer(to), effects.encode(peer(to), rec, from_slot=frm))
+            elif tag == "send_vote_requests":
+                for slot, rec in e[1]:
+                    self.send(peer(slot), effects.encode(peer(slot), rec))
+            elif tag == "send_rpc":
+                slot, rec = e[1], e[2]
+                if isinstance(rec, effects.AppendEntriesRpc):
+                    for piece in effects.split_entries(rec):         # at most two term runs per message
+                        self.send(peer(slot), effects.encode(peer(slot), piece))
                 else:
-                    self.send(peer(slot), _msg(peer(slot), abi.MSG_REQUEST_VOTE, me, term=d["reply_term"],
-                                               a=d["reply_last_index"], b=d["reply_last_term"]))
-        if fl & abi.F_SEND_HEARTBEATS:
-            for slot in range(self.N):
-                if (int(d["heartbeat_to"]) >> slot) & 1:
-                    self.send(peer(slot), _msg(peer(slot), abi.MSG_HEARTBEAT_RPC, me, term=d["reply_term"],
-                                               a=d["reply_last_term"]))
-        if fl & (abi.F_QUERY_QUORUM | abi.F_QUERY_APPLY):
-            self.stats["queries_answered"] += 1
-        if fl & abi.F_PIPELINE:
-            self.local[s].append(_msg(s, abi.MSG_PIPELINE_RPCS))
-        if fl & abi.F_BECAME_LEADER:
-            self.elections[g] += 1
-            self.local[s].append(_msg(s, abi.MSG_APPEND, n_entries=1, flags=abi.MF_FORCE))
+                    self.send(peer(slot), effects.encode(peer(slot), rec))
+            elif tag == "send_snapshot":
+                self.send_snapshot(s, e[1], e[2][0], e[2][1], int(st1["current_term"]))
+            elif tag == "next_event" and e[1] == "info":
+                self.local[s].append(effects.encode(s, effects.PIPELINE_RPCS))
+            elif tag == "next_event":                                # the noop command of a new leader
+                self.elections[g] += 1
+                self.local[s].append(effects.encode(s, effects.Commands(1, noop=True)))
+            elif tag in ("query_quorum", "query_apply"):
+                self.stats["queries_answered"] += 1
         # the log writes of this transition go to the WAL
         if kind == abi.MSG_APPEND and not fl & abi.F_UNHANDLED and int(st1["last_index"]) > int(st0["last_index"]) \
                 and int(st1["role"]) == abi.ROLE_LEADER and int(st0["role"]) == abi.ROLE_LEADER:
@@ -215,15 +207,6 @@ class ClusterSim:
                 self.wal[s].append((lo, min(hi, split - 1), int(m["run0_term"])))
             if hi >= split:
                 self.wal[s].append((max(lo, split), hi, int(m["run1_term"])))
-        # outbound append_entries_rpcs: entries come from the leader's log as it is now
-        if rpcs:
-            log = dict(abi.log_entries(st1))
-            for r in rpcs:
-                if int(r["kind"]) == abi.RPC_SNAPSHOT:
-                    self.send_snapshot(s, int(r["peer"]), int(r["prev_log_index"]), int(r["prev_log_term"]),
-                                       int(r["term"]))
-                else:
-                    self.send_aer(peer(r["peer"]), me, r, log)
 
     # ------------------------------------------------------------------ snapshot transfer (host side)
     # {send_snapshot, Peer, _} is not part of the batched path: ra_server_proc spawns a sender, marks the
@@ -289,7 +272,7 @@ class ClusterSim:
         row["commit_index_sent"][slot] = idx
         row["status_mask"] |= np.uint8(1 << slot)
         self.edit(leader, row)
-        self.local[leader].append(_msg(leader, abi.MSG_PIPELINE_RPCS))
+        self.local[leader].append(effects.encode(leader, effects.PIPELINE_RPCS))
 
     def host_sender_down(self, leader, slot, leader_term):
         st = self.state[leader]
@@ -298,31 +281,6 @@ class ClusterSim:
         row = st.copy()
         row["status_mask"] |= np.uint8(1 << slot)                   # 'DOWN' of the sender: back to normal
         self.edit(leader, row)
-
-    def send_aer(self, to, me, r, log):
-        prev, n = int(r["prev_log_index"]), int(r["n_entries"])
-        terms = [log[prev + 1 + k] for k in range(n)]
-        pt = int(r["prev_log_term"])
-        if n == 0:
-            self.send(to, _msg(to, abi.MSG_AER, me, term=r["term"], a=prev, b=pt, c=r["leader_commit"]))
-            return
-        # at most two term runs ride in one rgb_msg: longer batches are cut at the third run
-        k = 0
-        while k < n:
-            t0 = terms[k]; e0 = k
-            while e0 < n and terms[e0] == t0:
-                e0 += 1
-            e1 = e0
-            if e0 < n:
-                t1 = terms[e0]
-                while e1 < n and terms[e1] == t1:
-                    e1 += 1
-            else:
-                t1 = 0
-            self.send(to, _msg(to, abi.MSG_AER, me, term=r["term"], a=prev + k, b=pt, c=r["leader_commit"],
-                               n_entries=e1 - k, n_run0=e0 - k, run0_term=t0, run1_term=t1))
-            pt = terms[e1 - 1]
-            k = e1
 
     def flush_wals(self):
         """complete_batch: one {written, Term, Seq} per writer and term, oldest first."""
@@ -341,9 +299,9 @@ class ClusterSim:
                         cur = (term, min(clo, lo), hi)
                 else:
                     if cur:
-                        self.local[s].append(_msg(s, abi.MSG_WRITTEN, term=cur[0], a=cur[1], b=cur[2]))
+                        self.local[s].append(effects.encode(s, effects.Written(cur[0], cur[1], cur[2])))
                     cur = (term, lo, hi)
-            self.local[s].append(_msg(s, abi.MSG_WRITTEN, term=cur[0], a=cur[1], b=cur[2]))
+            self.local[s].append(effects.encode(s, effects.Written(cur[0], cur[1], cur[2])))
             self.wal[s] = []
 
     # ------------------------------------------------------------------ Raft safety
