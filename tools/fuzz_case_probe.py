@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Replay one case of tests/test_gpu_parity.py::test_hip_equals_oracle_on_random_ticks and print the first
+server whose state differs between the engine and the checker, with its message, both decisions and the
+state before and after (edit n, seed, groups, target below).  Needs the GPU."""
 import sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, fuzz
