@@ -73,6 +73,21 @@ def check_converged(sim, G, n_members):
     return sim
 
 
+def test_closed_loop_with_tiny_pipeline_limits(oracle_lib):
+    """max_append_entries_rpc_batch_size = 2 and max_pipeline_count = 3 (src/ra_server.erl:2285-2346): bursts
+    of commands leave the leader with more to send than one round allows, so replication advances through
+    the {next_event, info, pipeline_rpcs} loop and the in-flight clamp; safety and convergence as before."""
+    G, N = 6, 3
+    cpu = oracle_lib.Oracle(G, N, max_pipeline_count=3, max_aer_batch=2)
+    cpu.set_state(0, abi.empty_server_states(G, N))
+    sim = run_lossy_then_heal(cpu, G, N, 31, lossy_ticks=500, heal_ticks=400, p_command=0.6, drop=0.05)
+    check_converged(sim, G, N)
+    assert int(sim.state["last_index"].max()) > 60
+    loops = sum(int(((h["kind"] == abi.MSG_PIPELINE_RPCS) & (h["flags"] == 0)).sum()) for h in sim.history
+                if not isinstance(h, tuple))
+    assert loops > 300, loops                        # the pipeline_rpcs round trips carried the replication
+
+
 @pytest.mark.parametrize("n_members,seed", [(3, 21), (5, 22), (7, 23)])
 def test_closed_loop_clusters_with_snapshots(oracle_lib, n_members, seed):
     """The same, with members taking snapshots at last_applied (SNAPSHOT_WRITTEN truncates the log) and
