@@ -76,3 +76,26 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"ra_oracle|libra_oracle|from oracle|import oracle|ora_step", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_erlang_stub_constants_agree_with_the_abi():
+    """erlang/ra_gpu_batch.erl (the reference-side binding, never compiled here) carries its own copies of
+    the message kinds and decision flags: they must be the numbers of include/ra_gpu_batch.h."""
+    import os
+    import re
+    from ra_amd import abi
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "erlang",
+                            "ra_gpu_batch.erl")).read()
+    defs = {}
+    for name, val in re.findall(r"^-define\((\w+),\s*([^)]+)\)\.", src, flags=re.M):
+        val = val.strip()
+        defs[name] = int(val[3:], 16) if val.startswith("16#") else int(val)
+    checked = 0
+    for name, val in defs.items():
+        if name.startswith(("MSG_", "F_")):
+            assert getattr(abi, name) == val, name
+            checked += 1
+    assert defs["NONE"] == abi.NONE and defs["UNDEF"] == abi.UNDEF_INT
+    assert checked >= 25
+    # every struct the stub packs by hand has the size the header says
+    assert "0:(7 * 64)" in src                                   # 64-byte rgb_msg: 8 header bytes + 7 words
