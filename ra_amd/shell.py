@@ -9,8 +9,9 @@ on the host (they never cross the C ABI).
     shell.run_until_quiet()
     shell.machines[group * n_members + member].state
 
-`engine` is anything with step(msgs) -> (decisions, rpcs) and get_state(): ra_amd.engine.RaGpuBatch on
-an MI355X, or the checker (oracle.Oracle) in the CPU tests.  One `tick()` hands every server at most
+`engine` is ra_amd.engine.RaGpuBatch on an MI355X (the shell itself has no compute path and no
+fallback: it only calls step(msgs) -> (decisions, rpcs) and get_state(), which is also how the CPU tests
+put it in front of their reference checker).  One `tick()` hands every server at most
 one pending message (mailbox order), submits the batch, and turns the decisions into the next
 messages with ra_amd.effects -- the same routing erlang/ra_gpu_batch.erl does for a real Ra node:
 
