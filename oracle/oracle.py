@@ -166,6 +166,40 @@ def wal_recover_records(file_bytes: bytes, registered=lambda uid: True):
             b = rest
 
 
+def wal_scan_records(file_bytes: bytes):
+    """The record walk of recover_records/5 alone (no validation, no registration): every record the
+    binary patterns of src/ra_log_wal.erl:877-984 match, in file order, as
+    (first_appearance, trunc, id_ref, uid_offset, uid_len, checksum, index, term, data_offset, data_len),
+    offsets relative to the whole file, plus the end reason ("zeros" | "eof") and the bytes consumed."""
+    assert file_bytes[:5] == WAL_FILE_HEADER, "unknown_wal_file_format"
+    b, pos, out = file_bytes, 5, []
+    n = len(b)
+    while True:
+        if n - pos < 3:
+            return out, "eof", pos
+        h = int.from_bytes(b[pos:pos + 3], "big")
+        trunc, form, id_ref = h >> 23, (h >> 22) & 1, h & 0x3FFFFF
+        if form == 0:
+            if n - pos < 5:
+                return out, "eof", pos
+            uid_len = int.from_bytes(b[pos + 3:pos + 5], "big")
+            fixed = pos + 5 + uid_len
+        else:
+            uid_len, fixed = 0, pos + 3
+        if fixed + 8 > n:
+            return out, "eof", pos
+        checksum = int.from_bytes(b[fixed:fixed + 4], "big")
+        dlen = int.from_bytes(b[fixed + 4:fixed + 8], "big")
+        if h == 0 and checksum == 0 and dlen == 0:
+            return out, "zeros", pos
+        if fixed + 24 + dlen > n:
+            return out, "eof", pos
+        idx = int.from_bytes(b[fixed + 8:fixed + 16], "big")
+        term = int.from_bytes(b[fixed + 16:fixed + 24], "big")
+        out.append((form == 0, trunc, id_ref, pos + 5 if form == 0 else 0, uid_len, checksum, idx, term, fixed + 24, dlen))
+        pos = fixed + 24 + dlen
+
+
 def agreed_commit(indexes) -> int:
     a = np.ascontiguousarray(indexes, dtype=np.uint64)
     return int(lib().ora_agreed_commit(a.ctypes.data, len(a)))

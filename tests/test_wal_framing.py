@@ -157,6 +157,45 @@ def test_scan_rejects_an_unknown_file_header_and_honours_cap():
     assert len(part) == 4 and end == abi.WAL_END_CAP and consumed == int(part["next_offset"][3])
 
 
+def test_scan_survives_damaged_files_and_agrees_with_the_restatement():
+    """recover_records/5 parses whatever is on disk: bit flips in headers and lengths, truncation at any
+    byte, garbage tails.  The C walk must never read outside the buffer and must find exactly the records
+    the clause-by-clause restatement finds."""
+    rng = np.random.default_rng(77)
+    clean, _, _ = build_file(rng, n=25, n_writers=3)
+    cases = 0
+    for trial in range(400):
+        f = bytearray(clean)
+        r = rng.random()
+        if r < 0.35:
+            for _ in range(int(rng.integers(1, 4))):
+                f[int(rng.integers(5, len(f)))] ^= 1 << int(rng.integers(0, 8))
+        elif r < 0.7:
+            del f[int(rng.integers(5, len(f))):]
+        elif r < 0.85:
+            f += bytes(rng.integers(0, 256, size=int(rng.integers(1, 200)), dtype=np.uint8))
+        else:
+            cut = int(rng.integers(5, len(f)))
+            f = f[:cut] + bytes(int(rng.integers(0, 64))) + f[cut:]
+        f = bytes(f)
+        # a copy with nothing behind it: an out-of-bounds read would land in unmapped or foreign memory
+        buf = np.frombuffer(f, dtype=np.uint8).copy()
+        scanned, consumed, end = engine.wal_scan(buf)
+        want, reason, want_consumed = O.wal_scan_records(f)
+        assert len(scanned) == len(want), trial
+        assert consumed == want_consumed and end == (abi.WAL_END_ZEROS if reason == "zeros" else abi.WAL_END_DATA), trial
+        for rec, w in zip(scanned, want):
+            first, trunc, id_ref, uoff, ulen, cs, idx, term, doff, dlen = w
+            assert bool(int(rec["flags"]) & abi.WAL_REC_FIRST) == first and int(rec["trunc"]) == trunc, trial
+            assert (int(rec["id_ref"]), int(rec["checksum"]), int(rec["index"]), int(rec["term"])) == (id_ref, cs, idx, term)
+            assert (int(rec["data_offset"]), int(rec["data_len"]), int(rec["uid_len"])) == (doff, dlen, ulen), trial
+            assert int(rec["data_offset"]) + int(rec["data_len"]) <= len(f)
+            if first:
+                assert int(rec["uid_offset"]) == uoff
+        cases += len(want) != 25
+    assert cases > 100
+
+
 # ------------------------------------------------------------------------------------------ GPU
 
 def _open():
