@@ -36,7 +36,7 @@ class RgbError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("rgb_kernels.hip", "rgb_api.hip", "rgb_wal.hip", "rgb_internal.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("rgb_kernels.hip", "rgb_api.hip", "rgb_wal.hip", "rgb_wal_host.cpp", "rgb_internal.h")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "ra_gpu_wal.h"))
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "ra_gpu_batch.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(

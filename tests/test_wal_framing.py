@@ -196,6 +196,48 @@ def test_scan_survives_damaged_files_and_agrees_with_the_restatement():
     assert cases > 100
 
 
+def test_scan_under_sanitizers(tmp_path):
+    """The same walk compiled with AddressSanitizer + UBSan (host-only translation unit, plain g++): 300
+    damaged files, each in an exactly-sized heap block; any out-of-bounds read or overflow aborts."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "wal_scan_harness"
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I", os.path.join(root, "include"), "-o", str(exe),
+           os.path.join(root, "tests", "native", "wal_scan_harness.cpp"),
+           os.path.join(root, "ra_amd", "csrc", "rgb_wal_host.cpp")]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    if built.returncode != 0 and "sanitize" in built.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert built.returncode == 0, built.stderr
+    rng = np.random.default_rng(78)
+    clean, _, _ = build_file(rng, n=30, n_writers=3)
+    files, want = [], []
+    for trial in range(300):
+        f = bytearray(clean)
+        r = rng.random()
+        if r < 0.4:
+            for _ in range(int(rng.integers(1, 6))):
+                f[int(rng.integers(5, len(f)))] = int(rng.integers(0, 256))
+        elif r < 0.8:
+            del f[int(rng.integers(5, len(f))):]
+        else:
+            f = f[:int(rng.integers(5, len(f)))] + bytes(rng.integers(0, 256, size=int(rng.integers(0, 80)), dtype=np.uint8))
+        path = tmp_path / f"w{trial}.wal"
+        path.write_bytes(bytes(f))
+        files.append(str(path))
+        recs, reason, consumed = O.wal_scan_records(bytes(f))
+        want.append((0, len(recs), consumed, abi.WAL_END_ZEROS if reason == "zeros" else abi.WAL_END_DATA))
+    run = subprocess.run([str(exe)] + files, capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr[-2000:]
+    got = [tuple(int(x) for x in line.split()) for line in run.stdout.splitlines()]
+    assert got == want
+
+
 # ------------------------------------------------------------------------------------------ GPU
 
 def _open():
