@@ -18,3 +18,12 @@ def oracle_lib():
     from oracle import oracle as O
     O.build()
     return O
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU run order: the direct parity tests (vectors, differential ticks, WAL kernels) first, the long
+    closed-loop replays last -- with `-x` a failure in the broadest test must not hide the focused ones."""
+    late = [it for it in items if "test_cluster_safety" in it.nodeid and it.get_closest_marker("gpu")]
+    if late:
+        rest = [it for it in items if it not in late]
+        items[:] = rest + late
