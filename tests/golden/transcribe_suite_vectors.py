@@ -339,6 +339,16 @@ vec("L7", "test/ra_server_SUITE.erl:1715-1732 leader_does_not_abdicate_to_unknow
                              state_unchanged=True, no_reply=True)),
 ])
 
+vec("S1", "test/ra_server_SUITE.erl:2438-2467 follower_state_resets_peer_status", 3, "n1", "base", [
+    # the reference calls handle_state_enter(follower, leader, State) on a leader whose peers are
+    # {sending_snapshot, _, _} and disconnected; here the state-enter half is part of whatever transition
+    # makes the leader a follower (a reply from a higher term): every peer status is normal afterwards
+    dict(reset=True, **step("leader", reply("n2", 6, False, 4, 3, 5), role="follower",
+                             state=dict(current_term=6, leader_id=None, status_mask=255), no_reply=True)),
+    dict(reset=True, **step("leader", aer(6, "n3", (3, 5), 3, []), role="follower",
+                             state=dict(current_term=6, status_mask=255))),
+], tweak=dict(peers_not_normal=["n2", "n3"]))
+
 vec("L8", "test/ra_server_SUITE.erl:1752-1794 higher_term_detected", 3, "n1", "base", [
     dict(reset=True, **step("leader", reply("n2", 6, False, 4, 3, 5), role="follower",
                              state=dict(current_term=6, leader_id=None), no_reply=True,

@@ -70,6 +70,11 @@ def initial_state(v) -> np.ndarray:
         for nm in tw["nonvoters"]:
             m &= ~(1 << slot(nm))
         st["voter_mask"][i] = m
+    if "peers_not_normal" in tw:                      # status =/= normal: sending_snapshot, disconnected, ...
+        m = int(st["status_mask"][i])
+        for nm in tw["peers_not_normal"]:
+            m &= ~(1 << slot(nm))
+        st["status_mask"][i] = m
     if "log" in tw:
         abi.set_log(st, i, [tuple(e) for e in tw["log"]],
                     last_written=tuple(tw["last_written"]) if "last_written" in tw else None)
