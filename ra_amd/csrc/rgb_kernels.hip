@@ -38,13 +38,21 @@ __device__ __forceinline__ void store16_wt(void *p, ulonglong2 v) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   v4u d;
   d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
+#ifndef RGB_HOST_EMULATION
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#else
+  *reinterpret_cast<v4u *>(p) = d;
+#endif
 }
 __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   v4u d;
   d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
+#ifndef RGB_HOST_EMULATION
   asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+#else
+  *reinterpret_cast<v4u *>(p) = d;
+#endif
 }
 __device__ __forceinline__ void store8_wt(u64 *p, u64 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1463,7 +1471,9 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     load_peers<N>(L);
   if (t_loaded && (dev.dbg & 16u)) {
     /* profiling: force the state round trip to complete here */
+#ifndef RGB_HOST_EMULATION
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(h0.x), "v"(h6.y) : "memory");
+#endif
     *t_loaded = wall_clock64();
   }
   L.ct = h0.x; L.pk = h0.y; L.ci = h1.x; L.la = h1.y; L.li = h2.x; L.lt = h2.y; L.lwi = h3.x;
@@ -1743,7 +1753,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
                                                                  msg_index_base, d, &tl, hrow); break;
     }
 #undef RGB_CASE
+#ifndef RGB_HOST_EMULATION
     if (dev.dbg & 16u) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
+#endif
   }
   __syncthreads();      /* every lane is done with its hot row before the decisions overlay the rows */
   if (active) {

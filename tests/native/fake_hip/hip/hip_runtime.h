@@ -1,0 +1,48 @@
+/* Stand-in for <hip/hip_runtime.h> used ONLY by tests/native/kernel_on_cpu.cpp (TEST INFRASTRUCTURE):
+ * it lets ra_amd/csrc/rgb_kernels.hip compile as plain x86 C++ so that the per-lane transition code
+ * (process_message<N, KIND>, the pack/unpack kernels) can be executed lane by lane on the CPU and compared
+ * with the checker without a GPU.  Cross-lane constructs (__shfl, __syncthreads, LDS) are given inert
+ * definitions: the kernels that rely on them (class dispatch, load generator) compile but are never run. */
+#ifndef RGB_FAKE_HIP_RUNTIME_H
+#define RGB_FAKE_HIP_RUNTIME_H
+#include <stdint.h>
+#include <string.h>
+#include <chrono>
+
+#define __host__
+#define __device__
+#define __global__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#ifndef __restrict__
+#define __restrict__
+#endif
+
+struct ulonglong2 { unsigned long long x, y; };
+static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { ulonglong2 v; v.x = x; v.y = y; return v; }
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+static inline void __syncthreads() {}
+template <typename T> static inline T __shfl(T v, int, int = 64) { return v; }
+template <typename T> static inline T __shfl_xor(T v, int, int = 64) { return v; }
+static inline unsigned long long wall_clock64() {
+  return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+}
+template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+
+typedef void *hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) do { (void)(stream); } while (0)
+static inline hipError_t hipMemsetAsync(void *, int, size_t, hipStream_t) { return hipSuccess; }
+#endif

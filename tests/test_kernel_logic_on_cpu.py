@@ -1,0 +1,144 @@
+"""The device transition code itself, without a GPU: ra_amd/csrc/rgb_kernels.hip compiled as x86 C++
+(tests/native/kernel_on_cpu.cpp + tests/native/fake_hip) and run one lane per message -- the generic path
+process_message<N, -1> and every clause-folded specialisation process_message<N, KIND> the class-dispatch
+kernel instantiates, plus the pack/unpack kernels -- bit for bit against the checker on the same random
+ticks, bounded run tables and closed-loop cluster streams the -m gpu tests use.  The kernels' launch
+structure (LDS staging, cooperative fetch, class dispatch) only runs on the GPU."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from ra_amd import abi
+import fuzz
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = shutil.which("clang++", path="/opt/rocm/lib/llvm/bin") or shutil.which("clang++")
+
+
+@pytest.fixture(scope="module")
+def emu_lib(tmp_path_factory):
+    if CLANG is None:
+        pytest.skip("no clang++ (the emulation build needs __builtin_nontemporal_*)")
+    out = tmp_path_factory.mktemp("emu") / "libkernel_on_cpu.so"
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-pass-failed",
+           "-Wno-unused-function", "-Wno-unused-variable",
+           "-I", os.path.join(ROOT, "tests", "native", "fake_hip"), "-I", os.path.join(ROOT, "include"),
+           "-o", str(out), os.path.join(ROOT, "tests", "native", "kernel_on_cpu.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    L = C.CDLL(str(out))
+    L.emu_new.restype = C.c_void_p
+    L.emu_new.argtypes = [C.c_uint32] * 5
+    L.emu_free.argtypes = [C.c_void_p]
+    L.emu_set_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.emu_get_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.emu_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                           C.POINTER(C.c_uint32), C.c_int]
+    return L
+
+
+class Emu:
+    """Same step/get_state/set_state interface as the engine and the checker."""
+
+    def __init__(self, L, n_groups, n_members, max_runs=16, max_pipeline_count=0, max_aer_batch=0, specialised=False):
+        self.L, self.S, self.N, self.spec = L, n_groups * n_members, n_members, int(specialised)
+        self.h = L.emu_new(n_groups, n_members, max_runs, max_pipeline_count, max_aer_batch)
+
+    def set_state(self, first, states):
+        st = np.ascontiguousarray(states, dtype=abi.SERVER_STATE_DTYPE)
+        self.L.emu_set_state(self.h, first, len(st), st.ctypes.data)
+
+    def get_state(self):
+        out = np.zeros(self.S, dtype=abi.SERVER_STATE_DTYPE)
+        self.L.emu_get_state(self.h, 0, self.S, out.ctypes.data)
+        return out
+
+    def step(self, msgs):
+        m = np.ascontiguousarray(msgs, dtype=abi.MSG_DTYPE)
+        dec = np.zeros(len(m), dtype=abi.DECISION_DTYPE)
+        cap = max(1, len(m) * abi.MAX_MEMBERS)
+        rpcs = np.zeros(cap, dtype=abi.RPC_DTYPE)
+        n = C.c_uint32(0)
+        assert self.L.emu_step(self.h, m.ctypes.data, len(m), dec.ctypes.data, rpcs.ctypes.data, cap, C.byref(n),
+                               self.spec) == 0
+        return dec, rpcs[:n.value]
+
+    def close(self):
+        self.L.emu_free(self.h)
+
+
+def assert_same(tag, dg, rg, sg, do, ro, so):
+    for name, a, b in (("decisions", dg, do), ("rpcs", fuzz.sort_rpcs(rg), fuzz.sort_rpcs(ro))):
+        assert len(a) == len(b), f"{tag}: {name} count {len(a)} vs {len(b)}"
+        bad = [i for i in range(len(a)) if a[i].tobytes() != b[i].tobytes()]
+        assert not bad, f"{tag}: {name}[{bad[0]}] emulated kernel {a[bad[0]]} checker {b[bad[0]]}"
+    bad = [i for i in range(len(sg)) if sg[i].tobytes() != so[i].tobytes()]
+    if bad:
+        i = bad[0]
+        diff = [f for f in abi.SERVER_STATE_DTYPE.names if sg[i][f].tobytes() != so[i][f].tobytes()]
+        raise AssertionError(f"{tag}: state of server {i} differs in {diff}: kernel {[sg[i][f] for f in diff]} "
+                             f"checker {[so[i][f] for f in diff]}")
+
+
+@pytest.mark.parametrize("specialised", [False, True], ids=["generic", "per_kind"])
+@pytest.mark.parametrize("n_members,seed", [(1, 301), (2, 302), (3, 303), (5, 304), (7, 305), (8, 306)])
+def test_kernel_code_equals_checker_on_random_ticks(emu_lib, oracle_lib, n_members, seed, specialised):
+    rng = np.random.default_rng(seed)
+    G = 300
+    st = fuzz.random_states(rng, G, n_members, max_runs=6)
+    cpu = oracle_lib.Oracle(G, n_members); cpu.set_state(0, st)
+    emu = Emu(emu_lib, G, n_members, specialised=specialised); emu.set_state(0, st)
+    assert_same("upload/download", [], np.zeros(0, dtype=abi.RPC_DTYPE), emu.get_state(), [], np.zeros(0, dtype=abi.RPC_DTYPE),
+                cpu.get_state())
+    seen = 0
+    for tick in range(10):
+        msgs = fuzz.random_msgs(rng, cpu.get_state(), n_members)
+        do, ro = cpu.step(msgs)
+        dg, rg = emu.step(msgs)
+        assert_same(f"N={n_members} tick {tick}", dg, rg, emu.get_state(), do, ro, cpu.get_state())
+        seen |= int(np.bitwise_or.reduce(do["flags"]))
+    emu.close()
+    for f in (abi.F_REPLY, abi.F_WROTE, abi.F_TRUNCATED, abi.F_PIPELINE, abi.F_INVARIANT, abi.F_REPROCESSED, abi.F_APPLIED):
+        assert seen & f, hex(f)
+
+
+@pytest.mark.parametrize("n_members,seed,max_runs", [(5, 311, 4), (3, 312, 3)])
+def test_kernel_code_with_bounded_run_tables(emu_lib, oracle_lib, n_members, seed, max_runs):
+    rng = np.random.default_rng(seed)
+    G = 300
+    st = fuzz.random_states(rng, G, n_members, max_runs=max_runs + 2)
+    cpu = oracle_lib.Oracle(G, n_members, max_runs=max_runs); cpu.set_state(0, st)
+    emu = Emu(emu_lib, G, n_members, max_runs=max_runs, specialised=True); emu.set_state(0, st)
+    overflows = 0
+    for tick in range(12):
+        msgs = fuzz.random_msgs(rng, cpu.get_state(), n_members)
+        do, ro = cpu.step(msgs)
+        dg, rg = emu.step(msgs)
+        assert_same(f"bounded runs tick {tick}", dg, rg, emu.get_state(), do, ro, cpu.get_state())
+        overflows += int(((do["flags"] & abi.F_RUNS_OVERFLOW) != 0).sum())
+    emu.close()
+    assert overflows > 0
+
+
+@pytest.mark.parametrize("n_members,seed,snapshots", [(3, 41, False), (5, 42, True)])
+def test_kernel_code_on_closed_loop_cluster_streams(emu_lib, oracle_lib, n_members, seed, snapshots):
+    from test_cluster_safety import run_lossy_then_heal
+    G = 8
+    st0 = abi.empty_server_states(G, n_members)
+    cpu = oracle_lib.Oracle(G, n_members); cpu.set_state(0, st0)
+    kw = dict(p_snapshot=0.03, max_leaders=11, drop=0.15) if snapshots else {}
+    sim = run_lossy_then_heal(cpu, G, n_members, seed, lossy_ticks=250, heal_ticks=150, **kw)
+    ref = oracle_lib.Oracle(G, n_members); ref.set_state(0, st0)
+    emu = Emu(emu_lib, G, n_members, specialised=True); emu.set_state(0, st0)
+    for t, h in enumerate(sim.history):
+        if isinstance(h, tuple):
+            ref.set_state(h[1], h[2].reshape(1)); emu.set_state(h[1], h[2].reshape(1))
+            continue
+        do, ro = ref.step(h)
+        dg, rg = emu.step(h)
+        assert_same(f"closed loop tick {t}", dg, rg, emu.get_state(), do, ro, ref.get_state())
+    emu.close()
