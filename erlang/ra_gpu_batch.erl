@@ -9,7 +9,7 @@
 %%     server:32, kind:8, from:8, flags:8, gap:8, term:64, a:64, b:64, c:64,
 %%     n_entries:32, n_run0:32, run0_term:64, run1_term:64
 %%   rgb_decision 64 bytes:
-%%     server:32, role:8, reply_to:8, n_rpcs:8, kind:8, flags:32, invariant:16, heartbeat_to:8, _:8,
+%%     server:32, role:8, reply_to:8, n_rpcs:8, kind:8, flags:32, invariant:16, heartbeat_to:8, cancel_backoff:8,
 %%     reply_term:64, reply_next_index:64, reply_last_index:64, reply_last_term:64,
 %%     commit_index:64, last_applied:64
 -module(ra_gpu_batch).
@@ -56,6 +56,7 @@
 -define(F_SEND_HEARTBEATS, 16777216).
 -define(F_QUERY_QUORUM, 33554432).
 -define(F_QUERY_APPLY, 67108864).
+-define(F_CANCEL_SNAPSHOT_RETRY, 134217728).
 
 init() ->
     erlang:load_nif(filename:join(code:priv_dir(ra), "ra_gpu_batch_nif"), 0).
@@ -177,10 +178,10 @@ term_or_undef(undefined) -> ?UNDEF;
 term_or_undef(T) -> T.
 
 decode_decision(<<Server:32/little, Role:8, ReplyTo:8, NRpcs:8, Kind:8, Flags:32/little,
-                  Inv:16/little, HbTo:8, _:8, RT:64/little, RNI:64/little, RLI:64/little, RLT:64/little,
+                  Inv:16/little, HbTo:8, Cancel:8, RT:64/little, RNI:64/little, RLI:64/little, RLT:64/little,
                   CI:64/little, LA:64/little>>) ->
     #{server => Server, role => role(Role), reply_to => ReplyTo, n_rpcs => NRpcs, kind => Kind,
-      flags => Flags, invariant => Inv, heartbeat_to => HbTo, reply_term => RT, reply_next_index => RNI,
+      flags => Flags, invariant => Inv, heartbeat_to => HbTo, cancel_backoff => Cancel, reply_term => RT, reply_next_index => RNI,
       reply_last_index => RLI, reply_last_term => RLT, commit_index => CI, last_applied => LA}.
 
 role(0) -> follower; role(1) -> candidate; role(2) -> leader; role(3) -> pre_vote;
@@ -222,7 +223,11 @@ decision_to_effects(Id, Member, #{flags := F, reply_to := To} = D) ->
     %% F_QUERY_QUORUM: release queued queries with index =< reply_next_index (the caller owns
     %% queries_waiting_heartbeats); F_QUERY_APPLY: no peers, apply now; F_RESEND_PENDING:
     %% ra_log:resend_pending/2 on the host log
-    Reply ++ Heartbeats
+    Cancels =
+        [{cancel_snapshot_retry_timer, Member(Slot)}
+         || F band ?F_CANCEL_SNAPSHOT_RETRY =/= 0, Slot <- lists:seq(0, 7),
+            maps:get(cancel_backoff, D) band (1 bsl Slot) =/= 0],
+    Cancels ++ Reply ++ Heartbeats
     ++ [{record_leader_msg, Member(To)} || F band ?F_LEADER_MSG =/= 0]
     ++ [{next_event, info, pipeline_rpcs} || F band ?F_PIPELINE =/= 0]
     ++ [{aux, eval} || F band ?F_AUX_EVAL =/= 0].

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGB_ABI_VERSION   3u
+#define RGB_ABI_VERSION   4u
 #define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
 #define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
 #define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
@@ -159,6 +159,9 @@ typedef struct rgb_msg {
                                            releases its queued queries up to it (heartbeat_rpc_quorum/3 :3797-3814) */
 #define RGB_F_QUERY_APPLY    (1u << 26) /* no peers: the consistent query (or every waiting one) applies now
                                            (src/ra_server.erl:3738-3743, 3757-3760)                                */
+#define RGB_F_CANCEL_SNAPSHOT_RETRY (1u << 27) /* {cancel_snapshot_retry_timer, Peer} for every member slot set in
+                                                   rgb_decision.cancel_backoff: make_all_rpcs/1 also contacts peers in
+                                                   {snapshot_backoff, _} (src/ra_server.erl:2353-2367)                  */
 #define RGB_F_RESEND_PENDING (1u << 22) /* the written event is not a prefix of `pending` (a WAL gap): the host runs
                                            ra_log:resend_pending/2 (src/ra_log.erl:917-919, 1663-1700); the log
                                            cursors are unchanged                                                 */
@@ -196,7 +199,7 @@ typedef struct rgb_decision {
   uint32_t flags;      /* RGB_F_*                                  */
   uint16_t invariant;  /* RGB_INV_*                                */
   uint8_t  heartbeat_to; /* RGB_F_SEND_HEARTBEATS: bit i = member slot i gets a #heartbeat_rpc{} */
-  uint8_t  _rsv;
+  uint8_t  cancel_backoff; /* RGB_F_CANCEL_SNAPSHOT_RETRY: bit i = cancel member slot i's snapshot retry timer */
   uint64_t reply_term;
   uint64_t reply_next_index;
   uint64_t reply_last_index;
@@ -235,6 +238,10 @@ typedef struct rgb_rpc {
  * The log's index->term map is a run-length table: run i covers indexes
  * run_start[i] .. run_start[i+1]-1 (the last run ends at last_index) with
  * term run_term[i]; run_start[0] == first_index when the range is not empty.
+ * Peer status is two masks: status_mask bit i = peer i is `normal`; backoff_mask bit i = peer i is
+ * {snapshot_backoff, _} (the only non-normal status the path tells apart, make_all_rpcs/1
+ * src/ra_server.erl:2356-2363); every other status is "neither bit".  become(follower,_,_) and
+ * initialise_peers/1 make every peer normal.
  * The ra_log range is {first_index, last_index}; it is empty (undefined)
  * iff first_index > last_index, in which case (last_index,last_term) equal
  * the snapshot's (src/ra_log.erl:831-835).
@@ -269,7 +276,8 @@ typedef struct rgb_server_state {
   uint8_t  status_mask;         /* bit i: peer i status == normal                         */
   uint8_t  self_nonvoter;       /* own `membership` =/= voter                             */
   uint8_t  cond_leader;         /* await_condition: who the stored reply is cast to       */
-  uint8_t  _pad[3];
+  uint8_t  backoff_mask;  /* bit i = peer i's status is {snapshot_backoff, _} (its status_mask bit is 0) */
+  uint8_t  _pad[2];
   uint64_t pre_vote_token;      /* pre_vote_token (an Erlang reference, opaque 64 bits)   */
   uint64_t query_index;         /* query_index (src/ra_server.erl:96): consistent-query heartbeat counter */
   uint64_t peer_query_index[RGB_MAX_MEMBERS]; /* #{query_index} of every peer (src/ra.hrl:61-73); own slot unused (0) */

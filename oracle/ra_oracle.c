@@ -51,6 +51,7 @@ typedef struct {
            commit_index_sent[RGB_MAX_MEMBERS];
   uint8_t  role, cond_reason, self, n_members, voted_for, leader_id, votes;
   uint8_t  present_mask, voter_mask, status_mask, self_nonvoter, cond_leader;
+  uint8_t  backoff_mask;           /* peers whose status is {snapshot_backoff, _} (never normal at the same time) */
   uint64_t pre_vote_token;
   uint32_t machine_version, effective_machine_version;
   uint64_t query_index;                       /* src/ra_server.erl:96 */
@@ -307,6 +308,7 @@ typedef struct {
   uint32_t msg_index;
   int      vote_reqs;              /* {send_vote_requests,..}: request fields ride in r_* */
   uint8_t  hb_mask;                /* heartbeat_rpc_effects/4: peers that get a #heartbeat_rpc{} */
+  uint8_t  cancel_mask;            /* {cancel_snapshot_retry_timer, Peer}: make_all_rpcs/1 :2356-2363 */
   uint64_t hb_term, hb_query_index;
   uint64_t q_consensus;            /* RGB_F_QUERY_QUORUM */
 } ofx;
@@ -318,8 +320,10 @@ static int is_present(const oscal *s, unsigned i) {
 /* become(follower,_,_) resets every peer status to normal, src/ra_server.erl:2183-2192 */
 static void set_role(oscal *s, uint8_t role, ofx *fx) {
   if (s->role != role) fx->flags |= RGB_F_ROLE_CHANGED;
-  if (role == RGB_ROLE_FOLLOWER && s->role != RGB_ROLE_FOLLOWER)
+  if (role == RGB_ROLE_FOLLOWER && s->role != RGB_ROLE_FOLLOWER) {
     s->status_mask = 0xFF;
+    s->backoff_mask = 0;
+  }
   if (role != RGB_ROLE_AWAIT_CONDITION) s->cond_reason = RGB_COND_NONE;
   s->role = role;
 }
@@ -565,6 +569,7 @@ static void become_leader(oserver *sv, ofx *fx) {
     s->next_index[i] = ni; s->match_index[i] = 0; s->commit_index_sent[i] = 0;
   }
   s->status_mask = 0xFF;
+  s->backoff_mask = 0;
   set_leader_id(s, s->self, fx);
   s->votes = 0;
   set_role(s, RGB_ROLE_LEADER, fx);
@@ -662,7 +667,13 @@ static int make_rpcs_for_peers(oserver *sv, uint32_t srv_id, int only_stale, ofx
   update_heartbeat_rpc_effects(s, fx);                      /* :2349 / :2354-2355 */
   for (unsigned i = 0; i < s->n_members; i++) {
     if (i == s->self || !is_present(s, i)) continue;
-    if (!((s->status_mask >> i) & 1u)) continue;
+    if (!((s->status_mask >> i) & 1u)) {
+      /* make_all_rpcs/1 keeps {snapshot_backoff,_} peers and cancels their retry timers (:2356-2363);
+       * stale_peers/1 (the tick) only takes normal ones */
+      if (only_stale || !((s->backoff_mask >> i) & 1u)) continue;
+      fx->cancel_mask |= (uint8_t)(1u << i);
+      fx->flags |= RGB_F_CANCEL_SNAPSHOT_RETRY;
+    }
     /* make_rpcs/1 on tick: stale_peers/1 :3012-3030 -- unconfirmed items or a newer commit index */
     if (only_stale && !(s->match_index[i] + 1 < s->next_index[i] || s->commit_index_sent[i] < s->commit_index))
       continue;
@@ -1335,6 +1346,7 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
     d->reply_term = fx.hb_term; d->reply_last_term = fx.hb_query_index;
   }
   if (fx.flags & RGB_F_QUERY_QUORUM) d->reply_next_index = fx.q_consensus;
+  d->cancel_backoff = fx.cancel_mask;
   d->commit_index = sv->s.commit_index;
   d->last_applied = sv->s.last_applied;
 }
@@ -1402,6 +1414,8 @@ int ora_set_state(ora_ctx *c, uint32_t first, uint32_t n, const rgb_server_state
     s->n_members = h->n_members; s->voted_for = h->voted_for; s->leader_id = h->leader_id;
     s->votes = h->votes; s->present_mask = h->present_mask; s->voter_mask = h->voter_mask;
     s->status_mask = h->status_mask; s->self_nonvoter = h->self_nonvoter;
+    /* canonical: backed-off peers are members, not self, not normal */
+    s->backoff_mask = (uint8_t)(h->backoff_mask & ~h->status_mask & h->present_mask & ~(1u << h->self));
     s->cond_leader = h->cond_leader;
     s->pre_vote_token = h->pre_vote_token;
     s->machine_version = h->machine_version;
@@ -1454,6 +1468,7 @@ int ora_get_state(const ora_ctx *c, uint32_t first, uint32_t n, rgb_server_state
     h->n_members = s->n_members; h->voted_for = s->voted_for; h->leader_id = s->leader_id;
     h->votes = s->votes; h->present_mask = s->present_mask; h->voter_mask = s->voter_mask;
     h->status_mask = s->status_mask; h->self_nonvoter = s->self_nonvoter;
+    h->backoff_mask = s->backoff_mask;
     h->cond_leader = s->cond_leader;
     h->query_index = s->query_index;
     memcpy(h->peer_query_index, s->peer_query_index, sizeof s->peer_query_index);

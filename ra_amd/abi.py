@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 UNDEF = np.uint64(0xFFFFFFFFFFFFFFFF)  # Erlang 'undefined'
 UNDEF_INT = 0xFFFFFFFFFFFFFFFF
 NONE = 0xFF                            # undefined member slot
@@ -62,6 +62,7 @@ F_REPLY_HEARTBEAT = 1 << 23
 F_SEND_HEARTBEATS = 1 << 24
 F_QUERY_QUORUM = 1 << 25
 F_QUERY_APPLY = 1 << 26
+F_CANCEL_SNAPSHOT_RETRY = 1 << 27
 
 (INV_NONE, INV_LEADER_SAW_AER_SAME_TERM, INV_TRUNCATE_BELOW_APPLIED, INV_WRITE_BELOW_APPLIED,
  INV_MISMATCH_TERM_UNDEFINED, INV_WRITE_INTEGRITY, INV_SET_LAST_INDEX_NOT_FOUND,
@@ -83,7 +84,7 @@ MSG_DTYPE = np.dtype([
 
 DECISION_DTYPE = np.dtype([
     ("server", u32), ("role", u8), ("reply_to", u8), ("n_rpcs", u8), ("kind", u8),
-    ("flags", u32), ("invariant", u16), ("heartbeat_to", u8), ("_rsv", u8),
+    ("flags", u32), ("invariant", u16), ("heartbeat_to", u8), ("cancel_backoff", u8),
     ("reply_term", u64), ("reply_next_index", u64), ("reply_last_index", u64),
     ("reply_last_term", u64), ("commit_index", u64), ("last_applied", u64),
 ])
@@ -107,7 +108,7 @@ SERVER_STATE_DTYPE = np.dtype([
     ("role", u8), ("cond_reason", u8), ("self", u8), ("n_members", u8),
     ("voted_for", u8), ("leader_id", u8), ("votes", u8), ("n_runs", u8),
     ("present_mask", u8), ("voter_mask", u8), ("status_mask", u8), ("self_nonvoter", u8),
-    ("cond_leader", u8), ("_pad", u8, (3,)),
+    ("cond_leader", u8), ("backoff_mask", u8), ("_pad", u8, (2,)),
     ("pre_vote_token", u64), ("query_index", u64), ("peer_query_index", u64, (MAX_MEMBERS,)),
     ("pending_first", u64),
     ("machine_version", u32), ("effective_machine_version", u32),

@@ -67,6 +67,8 @@ typedef uint32_t u32;
 #define PK_STATUS_SH    48  /* 8 */
 #define PK_QSELF_SH     56  /* 1: query_index > 0 (qry row word 0 is worth reading)      */
 #define PK_QPEER_SH     57  /* 1: some peer query_index > 0 (reset_query_index has work) */
+#define PK_BACKOFF_SH   58  /* 1: some peer is in {snapshot_backoff,_}: qry row word QRY_BACKOFF holds the mask */
+#define QRY_BACKOFF     9   /* qry row: word 0 query_index, 1..8 peer query_index, 9 backoff mask */
 
 /* Device order of a tick: clause family = (class rank of the message kind, success flag).  Every
  * kind is its own kernel class: a wavefront of the class-dispatch kernel runs the code path

@@ -122,6 +122,7 @@ struct Lane {
   bool q_loaded;
   unsigned q_dirty;       /* bit 0: query_index, bit 1+i: peer slot i */
   unsigned hb_mask;
+  unsigned cancel_mask;   /* RGB_F_CANCEL_SNAPSHOT_RETRY: backed-off peers contacted by make_all_rpcs */
   u64 hb_term, hb_qi, q_consensus;
 };
 
@@ -225,8 +226,10 @@ __device__ __forceinline__ bool status_normal(const Lane &L, unsigned i) { retur
 __device__ __forceinline__ void set_role(Lane &L, unsigned role) {
   unsigned old = role_of(L);
   if (old != role) L.flags |= RGB_F_ROLE_CHANGED;
-  if (role == RGB_ROLE_FOLLOWER && old != RGB_ROLE_FOLLOWER)
+  if (role == RGB_ROLE_FOLLOWER && old != RGB_ROLE_FOLLOWER) {
     L.pk = pk_set(L.pk, PK_STATUS_SH, 8, 0xFF);
+    L.pk = pk_set(L.pk, PK_BACKOFF_SH, 1, 0);         /* status => normal for every peer */
+  }
   if (role != RGB_ROLE_AWAIT_CONDITION) L.pk = pk_set(L.pk, PK_COND_SH, 2, RGB_COND_NONE);
   L.pk = pk_set(L.pk, PK_ROLE_SH, 3, role);
 }
@@ -743,6 +746,7 @@ __device__ __forceinline__ void become_leader(Lane &L) {
     L.dmi |= 1u << i; L.dni |= 1u << i; L.dcs |= 1u << i;
   }
   L.pk = pk_set(L.pk, PK_STATUS_SH, 8, 0xFF);
+  L.pk = pk_set(L.pk, PK_BACKOFF_SH, 1, 0);
   set_leader_id(L, self_of(L));
   L.pk = pk_set(L.pk, PK_VOTES_SH, 4, 0);
   set_role(L, RGB_ROLE_LEADER);
@@ -827,9 +831,18 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
   update_heartbeat_rpc_effects<N>(L);                                /* :2354-2355 */
   load_peers<N>(L);
   n_out = 0;
+  /* make_all_rpcs/1 keeps peers in {snapshot_backoff,_} as well and cancels their retry timers
+   * (:2356-2363); stale_peers/1 (the tick) only takes normal ones */
+  unsigned backoff = 0;
+  if (!only_stale && pk_get(L.pk, PK_BACKOFF_SH, 1)) backoff = (unsigned)qry_row(L)[QRY_BACKOFF] & 0xFFu;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    if ((unsigned)i == self || !present(L, i) || !status_normal(L, i)) continue;
+    if ((unsigned)i == self || !present(L, i)) continue;
+    if (!status_normal(L, i)) {
+      if (!((backoff >> i) & 1u)) continue;
+      L.cancel_mask |= 1u << i;
+      L.flags |= RGB_F_CANCEL_SNAPSHOT_RETRY;
+    }
     /* make_rpcs/1 on tick: stale_peers/1 :3012-3030 -- unconfirmed items or a newer commit index */
     if (only_stale && !(L.pmi[i] + 1 < L.pni[i] || L.pcs[i] < L.ci)) continue;
     const u64 prev = L.pni[i] - 1;
@@ -1406,10 +1419,12 @@ struct Dec { u64 w[8]; };
 
 __device__ __forceinline__ void make_decision(Dec &d, u32 server, unsigned role, unsigned reply_to,
                                               unsigned n_rpcs, unsigned kind, u32 flags, u32 inv, u64 w2,
-                                              u64 w3, u64 w4, u64 w5, u64 ci, u64 la, unsigned hb_mask = 0) {
+                                              u64 w3, u64 w4, u64 w5, u64 ci, u64 la, unsigned hb_mask = 0,
+                                              unsigned cancel_mask = 0) {
   d.w[0] = (u64)server | ((u64)(role & 0xFF) << 32) | ((u64)(reply_to & 0xFF) << 40) |
            ((u64)(n_rpcs & 0xFF) << 48) | ((u64)(kind & 0xFF) << 56);
-  d.w[1] = (u64)flags | ((u64)(inv & 0xFFFFu) << 32) | ((u64)(hb_mask & 0xFFu) << 48);
+  d.w[1] = (u64)flags | ((u64)(inv & 0xFFFFu) << 32) | ((u64)(hb_mask & 0xFFu) << 48) |
+           ((u64)(cancel_mask & 0xFFu) << 56);
   d.w[2] = w2; d.w[3] = w3; d.w[4] = w4; d.w[5] = w5; d.w[6] = ci; d.w[7] = la;
 }
 
@@ -1457,7 +1472,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   L.rpc_nt = (dev.dbg & 4096u) != 0;
   L.qry_base = dev.qry;
   L.q_loaded = false; L.q_dirty = 0; L.hb_mask = 0;
-  L.qself = 0; L.hb_term = L.hb_qi = L.q_consensus = 0;
+  L.qself = 0; L.hb_term = L.hb_qi = L.q_consensus = 0; L.cancel_mask = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) L.qp[i] = 0;
   L.runs = dev.runs + (size_t)L.server * dev.max_runs * 2;
@@ -1594,7 +1609,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if ((L.flags & RGB_F_SEND_HEARTBEATS) || L.kind == RGB_MSG_CONSISTENT_QUERY) { w2 = L.hb_term; w5 = L.hb_qi; }
   if (L.flags & RGB_F_QUERY_QUORUM) w3 = L.q_consensus;
   make_decision(out, L.server, role_of(L), L.has_reply ? L.reply_to : (unsigned)RGB_NONE, n_rpcs, L.kind,
-                L.flags, 0, w2, w3, w4, w5, L.ci, L.la, L.hb_mask);
+                L.flags, 0, w2, w3, w4, w5, L.ci, L.la, L.hb_mask, L.cancel_mask);
 }
 
 /* The tick kernel: one lane per message, one wavefront per 64 consecutive messages.  Messages
@@ -2107,6 +2122,11 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
     q[0] = h.query_index;
     for (unsigned i = 0; i < 8; ++i) { q[1 + i] = h.peer_query_index[i]; peer_nz = peer_nz || h.peer_query_index[i] != 0; }
     for (unsigned i = 9; i < RGB_QRY_WORDS; ++i) q[i] = 0;
+    /* {snapshot_backoff,_} peers: never normal at the same time, never self, only members */
+    const unsigned backoff = (unsigned)h.backoff_mask & ~(unsigned)h.status_mask & (unsigned)h.present_mask &
+                             ~(1u << h.self) & 0xFFu;
+    q[QRY_BACKOFF] = backoff;
+    pk = pk_set(pk, PK_BACKOFF_SH, 1, backoff ? 1 : 0);
     pk = pk_set(pk, PK_QSELF_SH, 1, h.query_index != 0 ? 1 : 0);
     pk = pk_set(pk, PK_QPEER_SH, 1, peer_nz ? 1 : 0);
     hot[HOT_PK] = pk;
@@ -2165,6 +2185,7 @@ __global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ ou
     const u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
     h.query_index = q[0];
     for (unsigned i = 0; i < 8; ++i) h.peer_query_index[i] = q[1 + i];
+    h.backoff_mask = pk_get(pk, PK_BACKOFF_SH, 1) ? (uint8_t)(q[QRY_BACKOFF] & 0xFFu) : 0;
   }
   out[k] = h;
 }

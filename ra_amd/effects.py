@@ -259,6 +259,10 @@ def decode(msg, dec, rpcs, state_after, n_members: int) -> list:
                 fx.append(("send_rpc", int(r["peer"]),
                            AppendEntriesRpc(int(r["term"]), me, int(r["leader_commit"]), prev,
                                             int(r["prev_log_term"]), ents)))
+    if fl & abi.F_CANCEL_SNAPSHOT_RETRY:                               # make_all_rpcs/1 :2356-2363
+        for slot in range(n_members):
+            if (int(dec["cancel_backoff"]) >> slot) & 1:
+                fx.append(("cancel_snapshot_retry_timer", slot))
     if fl & abi.F_SEND_HEARTBEATS:
         for slot in range(n_members):
             if (int(dec["heartbeat_to"]) >> slot) & 1:

@@ -73,6 +73,10 @@ def random_states(rng: np.random.Generator, n_groups: int, n_members: int, max_r
         st["present_mask"][s] = full if rng.random() < 0.85 else (int(rng.integers(0, full + 1)) | (1 << (s % n_members)))
         st["voter_mask"][s] = full if rng.random() < 0.85 else (int(rng.integers(0, full + 1)) | (1 << (s % n_members)))
         st["status_mask"][s] = 0xFF if rng.random() < 0.85 else int(rng.integers(0, 256))
+        # some of the peers that are not normal are in {snapshot_backoff, _} (never self, only members)
+        if int(st["status_mask"][s]) != 0xFF and rng.random() < 0.6:
+            st["backoff_mask"][s] = (int(rng.integers(0, 256)) & ~int(st["status_mask"][s]) &
+                                     int(st["present_mask"][s]) & ~(1 << (s % n_members)) & 0xFF)
         st["self_nonvoter"][s] = 1 if rng.random() < 0.05 else 0
         st["pre_vote_token"][s] = int(rng.integers(0, 3))
         if rng.random() < 0.35:

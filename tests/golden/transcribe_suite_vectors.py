@@ -339,6 +339,18 @@ vec("L7", "test/ra_server_SUITE.erl:1715-1732 leader_does_not_abdicate_to_unknow
                              state_unchanged=True, no_reply=True)),
 ])
 
+vec("S2", "test/ra_server_SUITE.erl:2665-2688 leader_pre_vote_sends_snapshot_to_backoff_peer", 3, "n1", "base", [
+    # a leader answering a pre_vote_rpc of its own term enforces its leadership with make_all_rpcs/1, which
+    # also contacts the peer in {snapshot_backoff, 2} and cancels its retry timer
+    dict(reset=True, **step("leader", pre_vote(5, "n1", (3, 5)), role="leader", no_reply=True,
+                             cancel_backoff=["n2"], flags_set=["CANCEL_SNAPSHOT_RETRY"],
+                             rpcs=[dict(peer="n2", prev=[3, 5], commit=3),
+                                   dict(peer="n3", prev=[3, 5], commit=3)], rpcs_exact=True)),
+    # the tick (make_rpcs/1 over stale_peers/1) only takes normal peers: n2 stays out
+    dict(reset=True, **step("leader", dict(kind="tick"), role="leader", cancel_backoff=[],
+                             rpcs=[dict(peer="n3", prev=[3, 5], commit=3)], rpcs_exact=True)),
+], tweak=dict(peers_backoff=["n2"], votes=1))
+
 vec("S1", "test/ra_server_SUITE.erl:2438-2467 follower_state_resets_peer_status", 3, "n1", "base", [
     # the reference calls handle_state_enter(follower, leader, State) on a leader whose peers are
     # {sending_snapshot, _, _} and disconnected; here the state-enter half is part of whatever transition

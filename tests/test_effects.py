@@ -152,3 +152,22 @@ def test_encode_rejects_what_one_message_cannot_carry():
     m = fx.encode(4, pieces[1])
     assert (int(m["a"]), int(m["b"]), int(m["n_entries"]), int(m["n_run0"]), int(m["run0_term"]), int(m["run1_term"])) == \
         (13, 3, 3, 1, 4, 5)
+
+
+def test_leader_pre_vote_sends_rpc_to_backoff_peer(oracle_lib):
+    """SUITE:2665-2688 leader_pre_vote_sends_snapshot_to_backoff_peer: answering a pre_vote_rpc of its own
+    term the leader enforces its leadership with make_all_rpcs/1 -- a cancel_snapshot_retry_timer effect and
+    a send_rpc for the peer in {snapshot_backoff, 2}."""
+    s = base_state(oracle_lib)
+    st = s.o.get_state()
+    st["status_mask"][N1] &= ~(1 << N2) & 0xFF
+    st["backoff_mask"][N1] = 1 << N2
+    s.o.set_state(0, st)
+    role, st, effs = s.handle(PreVoteRpc(term=5, token=123, candidate_id=N1, last_log_index=3, last_log_term=5))
+    assert role == "leader"
+    assert ("cancel_snapshot_retry_timer", N2) in effs
+    assert any(e[0] == "send_rpc" and e[1] == N2 and isinstance(e[2], AppendEntriesRpc) for e in effs)
+    assert int(st["backoff_mask"]) == 1 << N2                         # statuses only change on role changes
+    role, st, effs = s.handle(AppendEntriesReply(term=6, success=False, next_index=4, last_index=3, last_term=5),
+                              from_slot=N3)
+    assert role == "follower" and int(st["status_mask"]) == 0xFF and int(st["backoff_mask"]) == 0

@@ -52,9 +52,10 @@ class Emu:
         st = np.ascontiguousarray(states, dtype=abi.SERVER_STATE_DTYPE)
         self.L.emu_set_state(self.h, first, len(st), st.ctypes.data)
 
-    def get_state(self):
-        out = np.zeros(self.S, dtype=abi.SERVER_STATE_DTYPE)
-        self.L.emu_get_state(self.h, 0, self.S, out.ctypes.data)
+    def get_state(self, first=0, n=None):
+        n = self.S - first if n is None else n
+        out = np.zeros(n, dtype=abi.SERVER_STATE_DTYPE)
+        self.L.emu_get_state(self.h, first, n, out.ctypes.data)
         return out
 
     def step(self, msgs):
@@ -142,3 +143,18 @@ def test_kernel_code_on_closed_loop_cluster_streams(emu_lib, oracle_lib, n_membe
         dg, rg = emu.step(h)
         assert_same(f"closed loop tick {t}", dg, rg, emu.get_state(), do, ro, ref.get_state())
     emu.close()
+
+
+import vector_runner as VR  # noqa: E402
+
+_VECTORS = VR.load()["vectors"]
+
+
+@pytest.mark.parametrize("specialised", [False, True], ids=["generic", "per_kind"])
+def test_kernel_code_passes_the_reference_vectors(emu_lib, specialised):
+    """The 80 vectors transcribed from the reference's suites, through the emulated device code."""
+    for v in _VECTORS:
+        try:
+            VR.run_vector(lambda g, n: Emu(emu_lib, g, n, specialised=specialised), v)
+        except AssertionError as e:
+            raise AssertionError(f"vector {v['id']}: {e}") from e

@@ -29,6 +29,10 @@ def test_leader_stepdown_clauses_match_the_model(oracle_lib, n, seed):
     for sv in np.flatnonzero(gone):
         others = [i for i in range(n) if i != int(st["self"][sv])]
         st["present_mask"][sv] &= np.uint8(~(1 << int(rng.choice(others))) & 0xFF)
+    # and some have peers in snapshot back-off (not normal, not self)
+    for sv in np.flatnonzero(rng.random(S) < 0.4):
+        st["status_mask"][sv] = int(rng.integers(0, 256))
+        st["backoff_mask"][sv] = ~int(st["status_mask"][sv]) & int(st["present_mask"][sv]) & ~(1 << int(st["self"][sv])) & 0xFF
     cpu = oracle_lib.Oracle(G, n)
     cpu.set_state(0, st)
     before = cpu.get_state()
@@ -36,7 +40,7 @@ def test_leader_stepdown_clauses_match_the_model(oracle_lib, n, seed):
     dec, rpcs = cpu.step(msgs)
     after = cpu.get_state()
     n_rpcs = np.bincount(rpcs["msg_index"], minlength=S) if len(rpcs) else np.zeros(S, dtype=int)
-    seen = {"abdicate": 0, "exit": 0, "reply": 0, "unknown": 0, "enforce": 0, "ignored": 0}
+    seen = {"abdicate": 0, "exit": 0, "reply": 0, "unknown": 0, "enforce": 0, "ignored": 0, "backoff": 0}
     for i, (m, d) in enumerate(zip(msgs, dec)):
         sv = int(m["server"])
         row0, row1 = before[sv], after[sv]
@@ -107,8 +111,13 @@ def test_leader_stepdown_clauses_match_the_model(oracle_lib, n, seed):
             if fl & abi.F_INVARIANT:
                 assert int(d["invariant"]) == abi.INV_PIPELINE_PREV_UNDEFINED, tag
                 continue
+            # make_all_rpcs/1 :2353-2367: peers that are normal or in {snapshot_backoff, _}
             normal = [p for p in range(n) if p != s.me and (int(row0["present_mask"]) >> p) & 1
-                      and (int(row0["status_mask"]) >> p) & 1]
+                      and ((int(row0["status_mask"]) >> p) & 1 or (int(row0["backoff_mask"]) >> p) & 1)]
+            backed_off = sum(1 << p for p in normal if not (int(row0["status_mask"]) >> p) & 1)
+            assert int(d["cancel_backoff"]) == backed_off, tag
+            assert bool(fl & abi.F_CANCEL_SNAPSHOT_RETRY) == bool(backed_off), tag
+            seen["backoff"] += bool(backed_off)
             assert int(n_rpcs[i]) == len(normal) == int(d["n_rpcs"]), tag
             mine = rpcs[rpcs["msg_index"] == i]
             assert sorted(int(p) for p in mine["peer"]) == normal, tag

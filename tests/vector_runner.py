@@ -75,6 +75,10 @@ def initial_state(v) -> np.ndarray:
         for nm in tw["peers_not_normal"]:
             m &= ~(1 << slot(nm))
         st["status_mask"][i] = m
+    if "peers_backoff" in tw:                         # status = {snapshot_backoff, _}
+        for nm in tw["peers_backoff"]:
+            st["status_mask"][i] = int(st["status_mask"][i]) & ~(1 << slot(nm))
+            st["backoff_mask"][i] = int(st["backoff_mask"][i]) | (1 << slot(nm))
     if "log" in tw:
         abi.set_log(st, i, [tuple(e) for e in tw["log"]],
                     last_written=tuple(tw["last_written"]) if "last_written" in tw else None)
@@ -140,6 +144,9 @@ def make_msg(v, m) -> np.ndarray:
         out["a"], out["b"] = m["range"]
     elif k == "pipeline_rpcs":
         out["kind"] = abi.MSG_PIPELINE_RPCS
+    elif k == "tick":                                  # leader tick_timeout -> make_rpcs/1
+        out["kind"] = abi.MSG_PIPELINE_RPCS
+        out["flags"] = abi.MF_TICK
     elif k == "append":
         out["kind"] = abi.MSG_APPEND
         out["n_entries"] = m["n"]
@@ -303,6 +310,10 @@ def run_vector(engine_factory, v):
             assert int(d["heartbeat_to"]) == want, f"{where}: heartbeat_to={int(d['heartbeat_to']):#x}"
             assert int(d["reply_term"]) == hb["term"], f"{where}: heartbeat term"
             assert int(d["reply_last_term"]) == hb["query_index"], f"{where}: heartbeat query_index"
+        if "cancel_backoff" in exp:
+            want = sum(1 << slot(x) for x in exp["cancel_backoff"])
+            assert bool(flags & abi.F_CANCEL_SNAPSHOT_RETRY) == bool(want), f"{where}: cancel_snapshot_retry_timer flag"
+            assert int(d["cancel_backoff"]) == want, f"{where}: cancel_backoff={int(d['cancel_backoff']):#x}"
         if "query_quorum" in exp:
             assert flags & abi.F_QUERY_QUORUM, f"{where}: no query quorum"
             assert int(d["reply_next_index"]) == exp["query_quorum"], \
