@@ -158,3 +158,27 @@ def test_kernel_code_passes_the_reference_vectors(emu_lib, specialised):
             VR.run_vector(lambda g, n: Emu(emu_lib, g, n, specialised=specialised), v)
         except AssertionError as e:
             raise AssertionError(f"vector {v['id']}: {e}") from e
+
+
+@pytest.mark.parametrize("name,G,N,kw,mix,bm", [
+    ("config3", 256, 5, {}, "MIX_CONFIG3", False),
+    ("config5", 96, 7, dict(backlog=1024, boundaries=(3, 6)), "MIX_CONFIG5", True),
+])
+def test_kernel_code_on_the_baseline_workload_shapes(emu_lib, oracle_lib, name, G, N, kw, mix, bm):
+    """BASELINE configs[2] (mixed append/vote traffic) and configs[4] (7 members, 1024-entry backlogs crossing
+    term boundaries, wrong prev_log_term half of the time: the log-matching repair path) from the CPU workload
+    generator, through the emulated device code."""
+    from ra_amd import workload as W
+    seed = 0x5EED0005
+    st = W.initial_states(G, N, seed, **kw)
+    cpu = oracle_lib.Oracle(G, N); cpu.set_state(0, st)
+    emu = Emu(emu_lib, G, N, specialised=True); emu.set_state(0, st)
+    for t in range(8):
+        cur = cpu.get_state()
+        m = W.gen_tick(cur, N, t, seed, getattr(W, mix), backlog_mode=bm)
+        do, ro = cpu.step(m)
+        dg, rg = emu.step(m)
+        assert_same(f"{name} tick {t}", dg, rg, emu.get_state(), do, ro, cpu.get_state())
+    emu.close()
+    if bm:
+        assert (cpu.get_state()["role"] == abi.ROLE_AWAIT_CONDITION).sum() > 0
