@@ -1,8 +1,8 @@
 /* Stand-in for <hip/hip_runtime.h> used ONLY by tests/native/kernel_on_cpu.cpp (TEST INFRASTRUCTURE):
  * it lets ra_amd/csrc/rgb_kernels.hip compile as plain x86 C++ so that the per-lane transition code
  * (process_message<N, KIND>, the pack/unpack kernels) can be executed lane by lane on the CPU and compared
- * with the checker without a GPU.  Cross-lane constructs (__shfl, __syncthreads, LDS) are given inert
- * definitions: the kernels that rely on them (class dispatch, load generator) compile but are never run. */
+ * with the checker without a GPU.  Whole kernels run too: emu::launch makes every lane of a block a fiber,
+ * so __syncthreads, __shfl and __shared__ arrays behave as on one workgroup (blocks run one after another). */
 #ifndef RGB_FAKE_HIP_RUNTIME_H
 #define RGB_FAKE_HIP_RUNTIME_H
 #include <stdint.h>
@@ -29,9 +29,17 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
-static inline void __syncthreads() {}
-template <typename T> static inline T __shfl(T v, int, int = 64) { return v; }
-template <typename T> static inline T __shfl_xor(T v, int, int = 64) { return v; }
+/* Block emulation (tests/native/kernel_on_cpu.cpp): every lane of a block is a fiber; __syncthreads() hands
+ * control back to the scheduler until all live lanes of the block have arrived, __shfl exchanges through a
+ * per-block buffer between two such barriers.  Outside emu::launch both are inert. */
+namespace emu {
+void barrier();
+void shfl(void *value, size_t size, int src_lane);
+int lane();
+}
+static inline void __syncthreads() { emu::barrier(); }
+template <typename T> static inline T __shfl(T v, int src, int = 64) { emu::shfl(&v, sizeof v, src); return v; }
+template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { emu::shfl(&v, sizeof v, emu::lane() ^ mask); return v; }
 static inline unsigned long long wall_clock64() {
   return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
 }
@@ -43,6 +51,9 @@ typedef void *hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) do { (void)(stream); } while (0)
+#include <functional>
+namespace emu { void launch(dim3 grid, dim3 block, const std::function<void()> &body); }
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  do { (void)(stream); emu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); }); } while (0)
 static inline hipError_t hipMemsetAsync(void *, int, size_t, hipStream_t) { return hipSuccess; }
 #endif

@@ -4,15 +4,81 @@
  *
  * What runs is the product source itself: rgb_pack_kernel / rgb_unpack_kernel (one lane per server) and
  * process_message<N, KIND, false> (one lane per message; KIND = -1 is the generic path of rgb_tick_kernel,
- * KIND >= 0 the clause-folded specialisations the class-dispatch kernel instantiates).  What does not run:
- * the kernel wrappers' LDS staging, the cooperative hot-line fetch and the load generator.  So this checks
- * the transition logic, the HBM layout and the write-back of every clause against the checker without a
- * GPU; the launch structure is covered by the -m gpu tests.
+ * KIND >= 0 the clause-folded specialisations the class-dispatch kernel instantiates) -- and, through the
+ * product's own launchers, the whole kernels: every lane of a block is a fiber, so the LDS staging, the
+ * cooperative hot-line fetch, the class dispatch, the checksum / leaderboard kernels and the load generator
+ * execute as on one workgroup.  What the CPU cannot show is timing, occupancy and cross-workgroup races.
  */
 #define RGB_HOST_EMULATION 1
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+/* ---- block emulation: one ucontext fiber per lane ------------------------------------------------ */
+#include <ucontext.h>
+#include <vector>
+namespace emu {
+namespace {
+struct Fiber { ucontext_t ctx; char *stack; bool done; };
+std::vector<Fiber> fibers;
+ucontext_t sched_ctx;
+int cur = -1;
+const std::function<void()> *body_fn = nullptr;
+unsigned char shfl_buf[1024][16];
+constexpr size_t STACK = 512 * 1024;
+void entry() {
+  (*body_fn)();
+  fibers[cur].done = true;
+  swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+}  // namespace
+int lane() { return cur < 0 ? 0 : cur; }
+void barrier() {
+  if (cur < 0) return;                                  /* not inside a launch: single lane, nothing to wait for */
+  swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+void shfl(void *value, size_t size, int src_lane) {
+  if (cur < 0) return;
+  memcpy(shfl_buf[cur], value, size);
+  barrier();
+  memcpy(value, shfl_buf[src_lane], size);
+  barrier();
+}
+void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+  const unsigned nl = block.x;
+  body_fn = &body;
+  blockDim = block; gridDim = grid;
+  if (fibers.size() < nl) {
+    size_t old = fibers.size();
+    fibers.resize(nl);
+    for (size_t i = old; i < nl; ++i) fibers[i].stack = (char *)malloc(STACK);
+  }
+  for (unsigned b = 0; b < grid.x; ++b) {
+    blockIdx = dim3(b);
+    for (unsigned i = 0; i < nl; ++i) {
+      getcontext(&fibers[i].ctx);
+      fibers[i].ctx.uc_stack.ss_sp = fibers[i].stack;
+      fibers[i].ctx.uc_stack.ss_size = STACK;
+      fibers[i].ctx.uc_link = nullptr;
+      fibers[i].done = false;
+      makecontext(&fibers[i].ctx, entry, 0);
+    }
+    bool live = true;
+    while (live) {                                      /* one pass = one barrier interval */
+      live = false;
+      for (unsigned i = 0; i < nl; ++i) {
+        if (fibers[i].done) continue;
+        cur = (int)i;
+        threadIdx = dim3(i);
+        swapcontext(&sched_ctx, &fibers[i].ctx);
+        live = live || !fibers[i].done;
+      }
+    }
+  }
+  cur = -1;
+  body_fn = nullptr;
+}
+}  // namespace emu
 #include "../../ra_amd/csrc/rgb_kernels.hip"
 
 namespace {
@@ -107,6 +173,74 @@ int emu_step(void *h, const rgb_msg *msgs, uint32_t n, rgb_decision *dec, rgb_rp
   }
   *n_rpcs_out = out;
   return 0;
+}
+
+/* ---- whole kernels through the product's own launchers (grid computation, class dispatch, LDS staging,
+ * cooperative hot-line fetch) ---- */
+static int compact_rpcs(Emu *e, const rgb_decision *dec, uint32_t n, rgb_rpc *rpcs, uint32_t rpc_cap, uint32_t *n_out) {
+  const u32 N = e->dev.n_members, per = N > 1 ? N - 1 : 1;
+  u32 out = 0;
+  for (u32 i = 0; i < n; ++i)
+    for (u32 k = 0; k < dec[i].n_rpcs; ++k) {
+      if (out < rpc_cap) rpcs[out] = e->slots[(size_t)i * per + k];
+      out++;
+    }
+  *n_out = out;
+  return 0;
+}
+static void need_slots(Emu *e, uint32_t n) {
+  const u32 N = e->dev.n_members, per = N > 1 ? N - 1 : 1;
+  if ((size_t)n * per > e->slot_cap) {
+    free(e->slots);
+    e->slot_cap = n * per;
+    e->slots = (rgb_rpc *)calloc(e->slot_cap, sizeof(rgb_rpc));
+  }
+}
+
+/* cls = -1: the kind-generic kernel; 0..3: the single-kind kernels */
+int emu_launch_tick(void *h, int cls, const rgb_msg *msgs, uint32_t n, rgb_decision *dec, rgb_rpc *rpcs,
+                    uint32_t rpc_cap, uint32_t *n_rpcs_out) {
+  Emu *e = (Emu *)h;
+  need_slots(e, n);
+  int rc = rgb_launch_tick(e->dev, cls, msgs, n, nullptr, dec, e->slots, 0, 0, nullptr);
+  if (rc) return rc;
+  return compact_rpcs(e, dec, n, rpcs, rpc_cap, n_rpcs_out);
+}
+
+/* messages ordered by clause family, counts per class: the class-dispatch kernel, one launch */
+int emu_launch_classes(void *h, const rgb_msg *msgs, const uint32_t *counts, uint32_t n, rgb_decision *dec,
+                       rgb_rpc *rpcs, uint32_t rpc_cap, uint32_t *n_rpcs_out) {
+  Emu *e = (Emu *)h;
+  need_slots(e, n);
+  int rc = rgb_launch_tick_classes(e->dev, msgs, counts, nullptr, n, dec, e->slots, 0, 0, nullptr);
+  if (rc) return rc;
+  return compact_rpcs(e, dec, n, rpcs, rpc_cap, n_rpcs_out);
+}
+
+/* the tick the load generator just wrote: class sizes come from its per-family totals (device side) */
+int emu_launch_classes_dev(void *h, const rgb_msg *msgs, const uint32_t *family_totals, uint32_t max_msgs,
+                           rgb_decision *dec) {
+  Emu *e = (Emu *)h;
+  need_slots(e, max_msgs);
+  return rgb_launch_tick_classes(e->dev, msgs, nullptr, family_totals, max_msgs, dec, e->slots, 0, 0, nullptr);
+}
+
+int emu_launch_pack(void *h, uint32_t first, uint32_t n, const rgb_server_state *in) {
+  return rgb_launch_pack(((Emu *)h)->dev, in, first, n, nullptr);
+}
+int emu_launch_unpack(void *h, uint32_t first, uint32_t n, rgb_server_state *out) {
+  return rgb_launch_unpack(((Emu *)h)->dev, out, first, n, nullptr);
+}
+int emu_launch_checksum(void *h, uint32_t first, uint32_t n, uint64_t *out) {
+  return rgb_launch_checksum(((Emu *)h)->dev, first, n, (u64 *)out, nullptr);
+}
+int emu_launch_leaderboard(void *h, rgb_leaderboard_row *rows) {
+  return rgb_launch_leaderboard(((Emu *)h)->dev, rows, nullptr);
+}
+/* the load generator: scratch = 2 * RGB_N_FAMILIES u32, kind_counts = RGB_MSG_KIND_MAX + 1 u32 */
+int emu_launch_synth(void *h, uint64_t seed, uint64_t tick, rgb_msg *msgs, uint32_t *scratch, uint32_t *kind_counts,
+                     uint32_t *n_out) {
+  return rgb_launch_synth(((Emu *)h)->dev, seed, tick, msgs, scratch, kind_counts, n_out, nullptr);
 }
 
 }  // extern "C"

@@ -182,3 +182,133 @@ def test_kernel_code_on_the_baseline_workload_shapes(emu_lib, oracle_lib, name, 
     emu.close()
     if bm:
         assert (cpu.get_state()["role"] == abi.ROLE_AWAIT_CONDITION).sum() > 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# Whole kernels through the product's launchers: every lane of a block is a fiber (tests/native), so the LDS
+# staging, the cooperative hot-line fetch, the block -> class mapping and the generator's atomics execute.
+
+def _bind_launchers(L):
+    vp, u32 = C.c_void_p, C.c_uint32
+    L.emu_launch_tick.argtypes = [vp, C.c_int, vp, u32, vp, vp, u32, C.POINTER(u32)]
+    L.emu_launch_classes.argtypes = [vp, vp, vp, u32, vp, vp, u32, C.POINTER(u32)]
+    L.emu_launch_classes_dev.argtypes = [vp, vp, vp, u32, vp]
+    L.emu_launch_pack.argtypes = [vp, u32, u32, vp]
+    L.emu_launch_unpack.argtypes = [vp, u32, u32, vp]
+    L.emu_launch_checksum.argtypes = [vp, u32, u32, vp]
+    L.emu_launch_leaderboard.argtypes = [vp, vp]
+    L.emu_launch_synth.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
+    return L
+
+
+class KernelEmu(Emu):
+    """State through the pack/unpack KERNELS; a tick through the class-dispatch kernel (messages ordered by
+    clause family like rgb_submit does, NOP slots through the generic kernel) or through the generic kernel."""
+
+    def __init__(self, L, n_groups, n_members, mode="classes", **kw):
+        super().__init__(_bind_launchers(L), n_groups, n_members, **kw)
+        self.mode = mode
+
+    def set_state(self, first, states):
+        st = np.ascontiguousarray(states, dtype=abi.SERVER_STATE_DTYPE)
+        assert self.L.emu_launch_pack(self.h, first, len(st), st.ctypes.data) == 0
+
+    def get_state(self, first=0, n=None):
+        n = self.S - first if n is None else n
+        out = np.zeros(n, dtype=abi.SERVER_STATE_DTYPE)
+        assert self.L.emu_launch_unpack(self.h, first, n, out.ctypes.data) == 0
+        return out
+
+    def step(self, msgs):
+        m = np.ascontiguousarray(msgs, dtype=abi.MSG_DTYPE)
+        n = len(m)
+        dec = np.zeros(n, dtype=abi.DECISION_DTYPE)
+        cap = max(1, n * abi.MAX_MEMBERS)
+        rpcs = np.zeros(cap, dtype=abi.RPC_DTYPE)
+        nr = C.c_uint32(0)
+        if self.mode == "generic":
+            assert self.L.emu_launch_tick(self.h, -1, m.ctypes.data, n, dec.ctypes.data, rpcs.ctypes.data, cap,
+                                          C.byref(nr)) == 0
+            return dec, rpcs[:nr.value]
+        perm = np.argsort(abi.family(m), kind="stable")            # the device order of rgb_submit
+        ms = np.ascontiguousarray(m[perm])
+        real = int((ms["kind"] != abi.MSG_NOP).sum())               # NOP has the last rank: a tail
+        counts = np.bincount(abi.KIND_RANK[ms["kind"][:real]], minlength=15).astype(np.uint32)[:15]
+        ds = np.zeros(n, dtype=abi.DECISION_DTYPE)
+        assert self.L.emu_launch_classes(self.h, ms.ctypes.data, counts.ctypes.data, real, ds.ctypes.data,
+                                         rpcs.ctypes.data, cap, C.byref(nr)) == 0
+        if real < n:
+            tail = np.zeros(n - real, dtype=abi.DECISION_DTYPE)
+            nr2 = C.c_uint32(0)
+            assert self.L.emu_launch_tick(self.h, -1, ms[real:].ctypes.data, n - real, tail.ctypes.data,
+                                          rpcs[nr.value:].ctypes.data, cap - nr.value, C.byref(nr2)) == 0
+            ds[real:] = tail
+        dec[perm] = ds
+        out = rpcs[:nr.value].copy()
+        out["msg_index"] = perm[out["msg_index"]]                   # back to submission order, like rgb_collect
+        return dec, out
+
+
+@pytest.mark.parametrize("mode", ["classes", "generic"])
+@pytest.mark.parametrize("n_members,seed", [(3, 321), (5, 322), (8, 323)])
+def test_whole_kernels_equal_checker_on_random_ticks(emu_lib, oracle_lib, n_members, seed, mode):
+    rng = np.random.default_rng(seed)
+    G = 120
+    st = fuzz.random_states(rng, G, n_members, max_runs=6)
+    cpu = oracle_lib.Oracle(G, n_members); cpu.set_state(0, st)
+    emu = KernelEmu(emu_lib, G, n_members, mode=mode); emu.set_state(0, st)
+    empty = np.zeros(0, dtype=abi.RPC_DTYPE)
+    assert_same("pack/unpack kernels", [], empty, emu.get_state(), [], empty, cpu.get_state())
+    for tick in range(5):
+        msgs = fuzz.random_msgs(rng, cpu.get_state(), n_members)
+        do, ro = cpu.step(msgs)
+        dg, rg = emu.step(msgs)
+        assert_same(f"{mode} kernel N={n_members} tick {tick}", dg, rg, emu.get_state(), do, ro, cpu.get_state())
+    # checksum and leaderboard kernels against their host-side definitions
+    sums = np.zeros(emu.S, dtype=np.uint64)
+    assert emu.L.emu_launch_checksum(emu.h, 0, emu.S, sums.ctypes.data) == 0
+    assert np.array_equal(sums, oracle_lib.server_checksums(cpu.get_state()))
+    from ra_amd import shard
+    rows = np.zeros(G, dtype=abi.LEADERBOARD_DTYPE)
+    assert emu.L.emu_launch_leaderboard(emu.h, rows.ctypes.data) == 0
+    assert rows.tobytes() == shard.leaderboard_rows_from_states(cpu.get_state(), n_members).tobytes()
+    emu.close()
+
+
+@pytest.mark.parametrize("n_members,groups,ticks", [(5, 192, 24), (3, 128, 16)])
+def test_load_generator_and_device_sized_dispatch(emu_lib, oracle_lib, n_members, groups, ticks):
+    """The bench's inner loop on the CPU: rgb_synth_kernel (both passes, block reservations through atomics)
+    writes a compacted, family-ordered tick from the device state; the class-dispatch kernel sizes itself from
+    the generator's per-family totals; the checker replays every tick."""
+    from ra_amd import workload as W
+    G, N = groups, n_members
+    S = G * N
+    seed = 0x5EED0003
+    st0 = W.initial_states(G, N, seed)
+    cpu = oracle_lib.Oracle(G, N); cpu.set_state(0, st0)
+    emu = KernelEmu(emu_lib, G, N); emu.set_state(0, st0)
+    seen = 0
+    for t in range(ticks):
+        msgs = np.zeros(S, dtype=abi.MSG_DTYPE)
+        scratch = np.zeros(64, dtype=np.uint32)
+        kc = np.zeros(abi.N_KINDS, dtype=np.uint32)
+        n = np.zeros(1, dtype=np.uint32)
+        assert emu.L.emu_launch_synth(emu.h, seed, t, msgs.ctypes.data, scratch.ctypes.data, kc.ctypes.data,
+                                      n.ctypes.data) == 0
+        nt = int(n[0])
+        m = msgs[:nt]
+        assert nt > G and not np.any(m["kind"] == abi.MSG_NOP)
+        assert len(np.unique(m["server"])) == nt
+        assert np.array_equal(np.bincount(m["kind"], minlength=abi.N_KINDS), kc)
+        assert np.all(np.diff(abi.family(m)) >= 0), "tick is not ordered by clause family"
+        dec = np.zeros(S, dtype=abi.DECISION_DTYPE)
+        assert emu.L.emu_launch_classes_dev(emu.h, msgs.ctypes.data, scratch.ctypes.data, S, dec.ctypes.data) == 0
+        want, _ = cpu.step(m)
+        bad = [i for i in range(nt) if dec[i].tobytes() != want[i].tobytes()]
+        assert not bad, f"tick {t} slot {bad[0]}: msg={m[bad[0]]}\n kernel={dec[bad[0]]}\n checker={want[bad[0]]}"
+        assert not np.any(want["flags"] & abi.F_INVARIANT)
+        seen |= int(np.bitwise_or.reduce(want["flags"]))
+    assert emu.get_state().tobytes() == cpu.get_state().tobytes()
+    emu.close()
+    for f in (abi.F_WROTE, abi.F_APPLIED, abi.F_PIPELINE, abi.F_REPLY):
+        assert seen & f
