@@ -20,6 +20,26 @@ def oracle_lib():
     return O
 
 
+@pytest.fixture(scope="session")
+def emulated_kernels_so(tmp_path_factory):
+    """The product's HIP sources compiled as x86 C++ over tests/native/fake_hip (one build per session):
+    rgb_kernels.hip, rgb_wal.hip and rgb_wal_host.cpp with the fiber-per-lane block emulation."""
+    import shutil
+    import subprocess
+    clang = shutil.which("clang++", path="/opt/rocm/lib/llvm/bin") or shutil.which("clang++")
+    if clang is None:
+        pytest.skip("no clang++ (the emulation build needs __builtin_nontemporal_*)")
+    out = tmp_path_factory.mktemp("emu") / "libkernels_on_cpu.so"
+    nat = os.path.join(ROOT, "tests", "native")
+    cmd = [clang, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-pass-failed",
+           "-Wno-unused-function", "-Wno-unused-variable", "-I", os.path.join(nat, "fake_hip"),
+           "-I", os.path.join(ROOT, "include"), "-o", str(out),
+           os.path.join(nat, "kernel_on_cpu.cpp"), os.path.join(nat, "wal_on_cpu.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return str(out)
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU run order: the direct parity tests (vectors, differential ticks, WAL kernels) first, the long
     closed-loop replays last -- with `-x` a failure in the broadest test must not hide the focused ones."""

@@ -55,5 +55,18 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 namespace emu { void launch(dim3 grid, dim3 block, const std::function<void()> &body); }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   do { (void)(stream); emu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); }); } while (0)
-static inline hipError_t hipMemsetAsync(void *, int, size_t, hipStream_t) { return hipSuccess; }
+/* "device memory" is host memory, copies are memcpy, streams are synchronous */
+#include <stdlib.h>
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+/* v_dot4_u32_u8 */
+static inline unsigned emu_udot4(unsigned a, unsigned b, unsigned c) {
+  for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xFFu) * ((b >> (8 * k)) & 0xFFu);
+  return c;
+}
+#define __builtin_amdgcn_udot4(a, b, c, clamp) emu_udot4((a), (b), (c))
 #endif

@@ -1,0 +1,14 @@
+/*
+ * wal_on_cpu.cpp -- TEST INFRASTRUCTURE: ra_amd/csrc/rgb_wal.hip (checksum and framing kernels, staging,
+ * validation) and rgb_wal_host.cpp compiled as x86 C++ over tests/native/fake_hip, kernels executed by the
+ * fiber-per-lane block emulation of kernel_on_cpu.cpp.  The C entry points of include/ra_gpu_wal.h are exported
+ * unchanged; "device" buffers are host buffers.
+ */
+#define RGB_HOST_EMULATION 1
+#include <stdlib.h>
+#include <hip/hip_runtime.h>
+struct rgb_ctx { int unused; };
+extern "C" void *rgb_ctx_stream(rgb_ctx *) { return nullptr; }
+#include "../../ra_amd/csrc/rgb_wal.hip"
+#include "../../ra_amd/csrc/rgb_wal_host.cpp"
+extern "C" rgb_ctx *emu_wal_ctx() { static rgb_ctx c; return &c; }

@@ -6,8 +6,6 @@ ticks, bounded run tables and closed-loop cluster streams the -m gpu tests use. 
 structure (LDS staging, cooperative fetch, class dispatch) only runs on the GPU."""
 import ctypes as C
 import os
-import shutil
-import subprocess
 
 import numpy as np
 import pytest
@@ -16,20 +14,11 @@ from ra_amd import abi
 import fuzz
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLANG = shutil.which("clang++", path="/opt/rocm/lib/llvm/bin") or shutil.which("clang++")
 
 
 @pytest.fixture(scope="module")
-def emu_lib(tmp_path_factory):
-    if CLANG is None:
-        pytest.skip("no clang++ (the emulation build needs __builtin_nontemporal_*)")
-    out = tmp_path_factory.mktemp("emu") / "libkernel_on_cpu.so"
-    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-pass-failed",
-           "-Wno-unused-function", "-Wno-unused-variable",
-           "-I", os.path.join(ROOT, "tests", "native", "fake_hip"), "-I", os.path.join(ROOT, "include"),
-           "-o", str(out), os.path.join(ROOT, "tests", "native", "kernel_on_cpu.cpp")]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
+def emu_lib(emulated_kernels_so):
+    out = emulated_kernels_so
     L = C.CDLL(str(out))
     L.emu_new.restype = C.c_void_p
     L.emu_new.argtypes = [C.c_uint32] * 5

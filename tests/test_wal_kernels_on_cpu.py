@@ -1,0 +1,143 @@
+"""The WAL kernels without a GPU: ra_amd/csrc/rgb_wal.hip (Adler-32 and record framing kernels with their
+staging and validation code) compiled as x86 C++ and executed by the fiber-per-lane block emulation of
+tests/native (wal_on_cpu.cpp + kernel_on_cpu.cpp), against zlib / struct.pack and the reference's corruption
+scenarios -- the same checks the -m gpu tests make on the real kernels."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from ra_amd import abi
+from oracle import oracle as O
+from test_wal_framing import make_batch as make_records, python_frame, random_specs, scanned_as_tuples
+from test_wal_checksum import make_batch as make_entries, zlib_checksums
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class WalEmu:
+    def __init__(self, L):
+        self.L = L
+        self.ctx = L.emu_wal_ctx()
+
+    def wal_adler32(self, entries, data):
+        entries = np.ascontiguousarray(entries, dtype=abi.WAL_ENTRY_DTYPE)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        out = np.zeros(len(entries), dtype=np.uint32)
+        rc = self.L.rgb_wal_adler32(self.ctx, entries.ctypes.data, len(entries), data.ctypes.data, len(data),
+                                    out.ctypes.data)
+        assert rc == 0, rc
+        return out
+
+    def wal_frame(self, records, data, out_bytes, flags=0):
+        records = np.ascontiguousarray(records, dtype=abi.WAL_RECORD_DTYPE)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        out = np.zeros(out_bytes, dtype=np.uint8)
+        rc = self.L.rgb_wal_frame(self.ctx, records.ctypes.data, len(records), data.ctypes.data, len(data),
+                                  out.ctypes.data, out_bytes, flags)
+        return rc, out
+
+    def wal_layout(self, records, base=0):
+        return int(self.L.rgb_wal_layout(records.ctypes.data, len(records), base))
+
+    def wal_scan(self, f):
+        buf = np.frombuffer(bytes(f), dtype=np.uint8).copy()
+        n, consumed, end = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
+        assert self.L.rgb_wal_scan(buf.ctypes.data, len(buf), None, 0, C.byref(n), C.byref(consumed), C.byref(end)) == 0
+        out = np.zeros(max(1, n.value), dtype=abi.WAL_SCANNED_DTYPE)
+        assert self.L.rgb_wal_scan(buf.ctypes.data, len(buf), out.ctypes.data, len(out), C.byref(n), C.byref(consumed),
+                                   C.byref(end)) == 0
+        return out[:n.value].copy()
+
+    def wal_validate(self, f, scanned):
+        buf = np.frombuffer(bytes(f), dtype=np.uint8).copy()
+        scanned = np.ascontiguousarray(scanned, dtype=abi.WAL_SCANNED_DTYPE)
+        n_ok, status = C.c_uint32(0), C.c_uint32(0)
+        assert self.L.rgb_wal_validate(self.ctx, buf.ctypes.data, len(buf), scanned.ctypes.data, len(scanned),
+                                       C.byref(n_ok), C.byref(status)) == 0
+        return n_ok.value, status.value
+
+
+@pytest.fixture(scope="module")
+def wal(emulated_kernels_so):
+    out = emulated_kernels_so
+    L = C.CDLL(str(out))
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.emu_wal_ctx.restype = vp
+    L.rgb_wal_adler32.argtypes = [vp, vp, u32, vp, u64, vp]
+    L.rgb_wal_frame.argtypes = [vp, vp, u32, vp, u64, vp, u64, u32]
+    L.rgb_wal_layout.restype = u64
+    L.rgb_wal_layout.argtypes = [vp, u32, u64]
+    L.rgb_wal_scan.argtypes = [vp, u64, vp, u32, C.POINTER(u32), C.POINTER(u64), C.POINTER(u32)]
+    L.rgb_wal_validate.argtypes = [vp, vp, u64, vp, u32, C.POINTER(u32), C.POINTER(u32)]
+    return WalEmu(L)
+
+
+@pytest.mark.parametrize("small", [False, True], ids=["wave_per_entry", "four_per_wave"])
+def test_checksum_kernel_matches_zlib(wal, small):
+    rng = np.random.default_rng(50 + small)
+    if small:
+        lens = [0, 1, 15, 16, 17, 240, 255, 256, 257, 1023] + [int(x) for x in rng.integers(0, 700, size=150)]
+    else:
+        lens = [0, 1, 2, 15, 16, 17, 31, 32, 33, 1023, 1024, 1025, 4095, 4096, 4097, 65535, 65536, 70001] + \
+               [int(x) for x in rng.integers(0, 20000, size=40)]
+    entries, data = make_entries(rng, lens, True)
+    assert (len(data) / len(lens) < 1024) == small
+    got = wal.wal_adler32(entries, data)
+    want = zlib_checksums(entries, data)
+    bad = np.flatnonzero(got != want)
+    assert len(bad) == 0, f"entry {bad[0]} len {lens[bad[0]]}: kernel {got[bad[0]]:#x} zlib {want[bad[0]]:#x}"
+
+
+@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+@pytest.mark.parametrize("flags", [0, abi.WAL_NO_CHECKSUMS])
+def test_framing_kernel_matches_struct_pack(wal, small, flags):
+    rng = np.random.default_rng(60 + small)
+    if small:
+        lens = [0, 1, 2, 15, 16, 17, 31, 32, 33, 255, 256, 257] + [int(x) for x in rng.integers(0, 600, size=150)]
+    else:
+        lens = [0, 1, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 4097, 65535, 65536, 70001] + \
+               [int(x) for x in rng.integers(0, 20000, size=40)]
+    specs = random_specs(rng, len(lens), lens, n_writers=7)
+    recs, data, payloads = make_records(rng, specs)
+    total = wal.wal_layout(recs, 0)
+    assert (len(data) / len(lens) < 1024) == small
+    rc, out = wal.wal_frame(recs, data, total, flags)
+    assert rc == 0
+    want = python_frame(specs, payloads, not flags)
+    assert len(want) == total
+    bad = np.flatnonzero(out != np.frombuffer(want, dtype=np.uint8))
+    assert len(bad) == 0, f"first differing output byte {bad[0]} of {total}"
+
+
+def test_recovery_scenarios_of_the_reference(wal):
+    """test/ra_log_wal_SUITE.erl:1439-1528 on 100 entries of 1006 bytes, framed by the kernel."""
+    rng = np.random.default_rng(70)
+    uid = b"recover_with_last_entry_corruption_pre_allocate"
+    specs = [(int(i == 0), 0, uid if i == 0 else None, i + 1, 1, 1006) for i in range(100)]
+    recs, data, payloads = make_records(rng, specs)
+    total = wal.wal_layout(recs, 0)
+    rc, body = wal.wal_frame(recs, data, total)
+    assert rc == 0 and body.tobytes() == python_frame(specs, payloads)
+    clean = abi.WAL_FILE_HEADER + body.tobytes()
+    assert len(clean) == 103354
+
+    def recover(f):
+        scanned = wal.wal_scan(f)
+        n_ok, status = wal.wal_validate(f, scanned)
+        want, outcome = O.wal_recover_records(f)
+        assert scanned_as_tuples(f, scanned[:n_ok]) == want
+        return n_ok, status, outcome
+
+    assert recover(clean) == (100, abi.WAL_CLEAN, "eof")
+    f = bytearray(clean); f[-10:] = bytes(10)
+    assert recover(bytes(f)) == (99, abi.WAL_DROPPED_LAST, "dropped_last")
+    f = bytearray(clean + bytes(4096)); f[103331:103341] = bytes(10)
+    assert recover(bytes(f)) == (99, abi.WAL_DROPPED_LAST, "dropped_last")
+    f = bytearray(clean); f[1000:1010] = bytes(10)
+    assert recover(bytes(f)) == (0, abi.WAL_CORRUPT, "corrupt")
+    bad = recs.copy(); bad["out_offset"][5] = bad["out_offset"][4]
+    assert wal.wal_frame(bad, data, total)[0] == abi.E_INVAL          # overlapping records
