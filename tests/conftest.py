@@ -23,7 +23,8 @@ def oracle_lib():
 @pytest.fixture(scope="session")
 def emulated_kernels_so(tmp_path_factory):
     """The product's HIP sources compiled as x86 C++ over tests/native/fake_hip (one build per session):
-    rgb_kernels.hip, rgb_wal.hip and rgb_wal_host.cpp with the fiber-per-lane block emulation."""
+    rgb_kernels.hip, rgb_api.hip, rgb_wal.hip and rgb_wal_host.cpp with the fiber-per-lane block emulation --
+    a library with the exports of libra_gpu_batch.so (plus the emu_* lane-level entry points)."""
     import shutil
     import subprocess
     clang = shutil.which("clang++", path="/opt/rocm/lib/llvm/bin") or shutil.which("clang++")
@@ -31,13 +32,26 @@ def emulated_kernels_so(tmp_path_factory):
         pytest.skip("no clang++ (the emulation build needs __builtin_nontemporal_*)")
     out = tmp_path_factory.mktemp("emu") / "libkernels_on_cpu.so"
     nat = os.path.join(ROOT, "tests", "native")
-    cmd = [clang, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-pass-failed",
-           "-Wno-unused-function", "-Wno-unused-variable", "-I", os.path.join(nat, "fake_hip"),
-           "-I", os.path.join(ROOT, "include"), "-o", str(out),
-           os.path.join(nat, "kernel_on_cpu.cpp"), os.path.join(nat, "wal_on_cpu.cpp")]
+    cmd = [clang, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-DRGB_EMU_FULL_API",
+           "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-function", "-Wno-unused-variable",
+           "-I", os.path.join(nat, "fake_hip"), "-I", os.path.join(ROOT, "include"), "-o", str(out),
+           os.path.join(nat, "api_on_cpu.cpp"), os.path.join(nat, "kernel_on_cpu.cpp"),
+           os.path.join(nat, "wal_on_cpu.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return str(out)
+
+
+@pytest.fixture(scope="module")
+def emulated_engine(emulated_kernels_so):
+    """ra_amd.engine bound to the emulated library for the tests of one module (TEST PROCESS ONLY: the product
+    has no such switch and no CPU path); the real library is re-bound afterwards."""
+    from ra_amd import engine
+    saved = (engine.LIB_PATH, engine._lib)
+    engine.LIB_PATH, engine._lib = emulated_kernels_so, None
+    engine.lib()
+    yield engine
+    engine.LIB_PATH, engine._lib = saved
 
 
 def pytest_collection_modifyitems(config, items):

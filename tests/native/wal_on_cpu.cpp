@@ -7,8 +7,12 @@
 #define RGB_HOST_EMULATION 1
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
+#ifndef RGB_EMU_FULL_API   /* stand-alone WAL build: a dummy context; with rgb_api.hip the real one is used */
 struct rgb_ctx { int unused; };
 extern "C" void *rgb_ctx_stream(rgb_ctx *) { return nullptr; }
+#endif
 #include "../../ra_amd/csrc/rgb_wal.hip"
 #include "../../ra_amd/csrc/rgb_wal_host.cpp"
+#ifndef RGB_EMU_FULL_API
 extern "C" rgb_ctx *emu_wal_ctx() { static rgb_ctx c; return &c; }
+#endif

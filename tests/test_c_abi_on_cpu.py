@@ -1,0 +1,46 @@
+"""The C ABI end to end without a GPU: ra_amd/csrc/rgb_api.hip (contexts, the staging ring, rgb_submit's
+sub-tick rounds and family ordering, rgb_collect's un-permutation, state upload/download, snapshots, checksums)
+together with the kernels, all compiled as x86 C++ on the block emulation (tests/native).  ra_amd.engine is
+bound to that library in this test process only, and the C-ABI parity tests of tests/test_gpu_parity.py and
+tests/test_cluster_safety.py are re-run through it unchanged.  (Tests that need torch device tensors -- the
+device-resident paths -- only run on the GPU.)"""
+import numpy as np
+import pytest
+
+import test_gpu_parity as G
+import vector_runner as VR
+from ra_amd import abi
+
+
+def test_all_reference_vectors_through_the_c_abi(emulated_engine):
+    for v in G.DATA["vectors"]:
+        try:
+            G.test_hip_matches_reference_vector(emulated_engine, v)
+        except AssertionError as e:
+            raise AssertionError(f"vector {v['id']}: {e}") from e
+
+
+@pytest.mark.parametrize("n_members,seed,groups", [(3, 101, 300), (5, 102, 400), (8, 106, 150), (5, 107, 1300)])
+def test_random_ticks_through_the_c_abi(emulated_engine, oracle_lib, n_members, seed, groups):
+    """(5, 107, 1300) carries >= 4096 messages per round: rgb_submit takes the class-dispatch kernel."""
+    G.test_hip_equals_oracle_on_random_ticks(emulated_engine, oracle_lib, n_members, seed, groups)
+
+
+def test_sub_ticks_ring_and_overflow(emulated_engine, oracle_lib):
+    G.test_same_server_messages_are_serialised_in_submission_order(emulated_engine, oracle_lib)
+    G.test_pipelined_ring_keeps_batches_in_order(emulated_engine, oracle_lib)
+    G.test_run_table_overflow_is_flagged(emulated_engine)
+    G.test_leaderboard_snapshot(emulated_engine)
+    for n_run0 in (3, 1, 2):
+        G.test_write_below_first_index_keeps_the_range_start(emulated_engine, oracle_lib, n_run0)
+
+
+def test_bounded_run_tables_and_repair_workload(emulated_engine, oracle_lib):
+    G.test_bounded_run_table_matches_oracle(emulated_engine, oracle_lib, 5, 211, 300, 4)
+    G.test_config5_log_matching_repair_matches_oracle(emulated_engine, oracle_lib)
+
+
+def test_closed_loop_stream_through_the_c_abi(emulated_engine, oracle_lib):
+    import test_cluster_safety as CS
+    # the GPU test builds its own engine from ra_amd.engine, which is bound to the emulated library here
+    CS.test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, 5, 14, True)

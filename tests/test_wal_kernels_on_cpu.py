@@ -2,7 +2,6 @@
 staging and validation code) compiled as x86 C++ and executed by the fiber-per-lane block emulation of
 tests/native (wal_on_cpu.cpp + kernel_on_cpu.cpp), against zlib / struct.pack and the reference's corruption
 scenarios -- the same checks the -m gpu tests make on the real kernels."""
-import ctypes as C
 import os
 import struct
 import zlib
@@ -19,61 +18,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class WalEmu:
-    def __init__(self, L):
-        self.L = L
-        self.ctx = L.emu_wal_ctx()
+    """The WAL entry points through ra_amd.engine (bound to the emulated library by the fixture)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.eng = engine.RaGpuBatch(1, 1)
 
     def wal_adler32(self, entries, data):
-        entries = np.ascontiguousarray(entries, dtype=abi.WAL_ENTRY_DTYPE)
-        data = np.ascontiguousarray(data, dtype=np.uint8)
-        out = np.zeros(len(entries), dtype=np.uint32)
-        rc = self.L.rgb_wal_adler32(self.ctx, entries.ctypes.data, len(entries), data.ctypes.data, len(data),
-                                    out.ctypes.data)
-        assert rc == 0, rc
-        return out
+        return self.eng.wal_adler32(entries, data)
 
     def wal_frame(self, records, data, out_bytes, flags=0):
-        records = np.ascontiguousarray(records, dtype=abi.WAL_RECORD_DTYPE)
-        data = np.ascontiguousarray(data, dtype=np.uint8)
-        out = np.zeros(out_bytes, dtype=np.uint8)
-        rc = self.L.rgb_wal_frame(self.ctx, records.ctypes.data, len(records), data.ctypes.data, len(data),
-                                  out.ctypes.data, out_bytes, flags)
-        return rc, out
+        try:
+            return 0, self.eng.wal_frame(records, data, out_bytes, flags)
+        except self.engine.RgbError as e:
+            return e.code, None
 
     def wal_layout(self, records, base=0):
-        return int(self.L.rgb_wal_layout(records.ctypes.data, len(records), base))
+        return self.engine.wal_layout(records, base)
 
     def wal_scan(self, f):
-        buf = np.frombuffer(bytes(f), dtype=np.uint8).copy()
-        n, consumed, end = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
-        assert self.L.rgb_wal_scan(buf.ctypes.data, len(buf), None, 0, C.byref(n), C.byref(consumed), C.byref(end)) == 0
-        out = np.zeros(max(1, n.value), dtype=abi.WAL_SCANNED_DTYPE)
-        assert self.L.rgb_wal_scan(buf.ctypes.data, len(buf), out.ctypes.data, len(out), C.byref(n), C.byref(consumed),
-                                   C.byref(end)) == 0
-        return out[:n.value].copy()
+        return self.engine.wal_scan(f)[0]
 
     def wal_validate(self, f, scanned):
-        buf = np.frombuffer(bytes(f), dtype=np.uint8).copy()
-        scanned = np.ascontiguousarray(scanned, dtype=abi.WAL_SCANNED_DTYPE)
-        n_ok, status = C.c_uint32(0), C.c_uint32(0)
-        assert self.L.rgb_wal_validate(self.ctx, buf.ctypes.data, len(buf), scanned.ctypes.data, len(scanned),
-                                       C.byref(n_ok), C.byref(status)) == 0
-        return n_ok.value, status.value
+        return self.eng.wal_validate(np.frombuffer(bytes(f), dtype=np.uint8), scanned)
 
 
 @pytest.fixture(scope="module")
-def wal(emulated_kernels_so):
-    out = emulated_kernels_so
-    L = C.CDLL(str(out))
-    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
-    L.emu_wal_ctx.restype = vp
-    L.rgb_wal_adler32.argtypes = [vp, vp, u32, vp, u64, vp]
-    L.rgb_wal_frame.argtypes = [vp, vp, u32, vp, u64, vp, u64, u32]
-    L.rgb_wal_layout.restype = u64
-    L.rgb_wal_layout.argtypes = [vp, u32, u64]
-    L.rgb_wal_scan.argtypes = [vp, u64, vp, u32, C.POINTER(u32), C.POINTER(u64), C.POINTER(u32)]
-    L.rgb_wal_validate.argtypes = [vp, vp, u64, vp, u32, C.POINTER(u32), C.POINTER(u32)]
-    return WalEmu(L)
+def wal(emulated_engine):
+    w = WalEmu(emulated_engine)
+    yield w
+    w.eng.close()
 
 
 @pytest.mark.parametrize("small", [False, True], ids=["wave_per_entry", "four_per_wave"])
