@@ -1558,7 +1558,8 @@ uint64_t ora_server_checksum(const rgb_server_state *h) {
                     ((uint64_t)h->n_runs << 56);
   x = fnv_word(x, packed);
   uint64_t masks = (uint64_t)h->present_mask | ((uint64_t)h->voter_mask << 8) |
-                   ((uint64_t)h->status_mask << 16) | ((uint64_t)h->self_nonvoter << 24);
+                   ((uint64_t)h->status_mask << 16) | ((uint64_t)h->self_nonvoter << 24) |
+                   ((uint64_t)h->backoff_mask << 32);
   x = fnv_word(x, masks);
   x = fnv_word(x, h->pre_vote_token);
   x = fnv_word(x, h->pending_first);

@@ -2248,6 +2248,7 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   x = fnv_word(x, packed);
   u64 masks = pk_get(pk, PK_PRESENT_SH, 8) | (pk_get(pk, PK_VOTER_SH, 8) << 8) |
               (pk_get(pk, PK_STATUS_SH, 8) << 16) | (pk_get(pk, PK_NONVOTER_SH, 1) << 24);
+  if (pk_get(pk, PK_BACKOFF_SH, 1)) masks |= ((dev.qry + (size_t)s * RGB_QRY_WORDS)[QRY_BACKOFF] & 0xFFull) << 32;
   x = fnv_word(x, masks);
   x = fnv_word(x, hot[HOT_TOKEN]);
   x = fnv_word(x, hot[HOT_PEND]);
