@@ -121,7 +121,9 @@ struct rgb_dev {
                 peers prefetch, 8 = no hot-line load (zero state), 16 = per-wave timestamps into dbg_buf,
                 32 = write-through (sc1) stores, 64 = whole-line hot write-back, 128 = plain instead of
                 non-temporal decision stores, 1024 = non-temporal state stores, 2048 = plain instead of
-                non-temporal message loads, 4096 = non-temporal rpc record stores */
+                non-temporal message loads, 4096 = non-temporal rpc record stores, 8192 = two launches per tick
+                (bulk classes / long classes, same stream), 16384 = the same with the long classes on a
+                forked side stream (parallel graph branches under capture); the last two keep parity */
   u64 *dbg_buf;
 };
 

@@ -1675,8 +1675,17 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
  * (host-known) or from device memory (device-side producers). */
 struct rgb_class_counts { u32 n[RGB_N_CLASSES]; };
 
-template <int N>
-__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_tick_classes_kernel(
+/* PART selects the classes a launch serves: 0 = all of them (the production launch); 1 = the bulk
+ * (append_entries_rpc, append_entries_reply, written) and 2 = every other class, for the experimental
+ * two-launch tick (RGB_DEBUG 8192 / 16384): the bulk keeps the 128-VGPR, four-wavefront budget, the long
+ * pipelining / election paths get 256 VGPRs (two wavefronts per SIMD).  The parts touch disjoint
+ * servers (at most one message per server per tick), so the two launches need no ordering. */
+template <int PART> __host__ __device__ constexpr bool rgb_class_in_part(int c) {
+  return PART == 0 || (PART == 1) == (c <= 2);
+}
+
+template <int N, int PART = 0>
+__global__ __launch_bounds__(RGB_TICK_BLOCK, PART == 2 ? 2 : RGB_CLASS_MIN_WAVES(N)) void rgb_tick_classes_kernel(
     rgb_dev dev, const rgb_msg *__restrict__ msgs, rgb_class_counts cc, const u32 *__restrict__ fam_dev,
     rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base, u32 msg_index_base) {
   __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];   /* records (5 per slot), then hot rows (9 per slot) */
@@ -1695,6 +1704,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #pragma unroll
   for (int q = 0; q < RGB_N_CLASSES; ++q) {
     const int c = order[q];
+    if (!rgb_class_in_part<PART>(c)) continue;
     const u32 nb = (cc.n[c] + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
     if (cls < 0) {
       if (blk < nb) cls = c;
@@ -1754,8 +1764,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   if (active) {
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
-    process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, &tl, \
-                                  hrow);                                                                \
+    if constexpr (rgb_class_in_part<PART>(RANK))                                                        \
+      process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, &tl, \
+                                    hrow);                                                              \
     break;
     switch (cls) {
       RGB_CASE(0, RGB_MSG_AER) RGB_CASE(1, RGB_MSG_AER_REPLY) RGB_CASE(2, RGB_MSG_WRITTEN)
@@ -1764,8 +1775,11 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(8, RGB_MSG_ELECTION_TIMEOUT) RGB_CASE(9, RGB_MSG_PRE_VOTE_RPC)
       RGB_CASE(10, RGB_MSG_PRE_VOTE_RESULT) RGB_CASE(11, RGB_MSG_SNAPSHOT_WRITTEN)
       RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
-      default: process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                                 msg_index_base, d, &tl, hrow); break;
+      default:
+        if constexpr (rgb_class_in_part<PART>(14))
+          process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
+                                                            msg_index_base, d, &tl, hrow);
+        break;
     }
 #undef RGB_CASE
 #ifndef RGB_HOST_EMULATION
@@ -2301,6 +2315,47 @@ int rgb_launch_tick(const rgb_dev &dev, int cls, const rgb_msg *d_msgs, u32 n, c
   }
 }
 
+/* Experimental two-launch tick (RGB_DEBUG 8192: both parts on the caller's stream; 16384: the long classes
+ * on a side stream forked from and joined back into the caller's stream, which also works under stream
+ * capture and then yields two parallel graph branches).  Not the production path: rgb_dev.dbg is 0 there. */
+static int launch_tick_classes_split(const rgb_dev &dev, const rgb_msg *d_msgs, const rgb_class_counts &cc,
+                                     const u32 *d_family_totals, u32 all_blocks, rgb_decision *d_dec,
+                                     rgb_rpc *d_rpcs, u32 rpc_slot_base, u32 msg_index_base, hipStream_t st) {
+  static hipStream_t side = nullptr;
+  static hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  const bool forked = (dev.dbg & 16384u) != 0;
+  if (forked && side == nullptr) {
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return -1;
+  }
+  u32 nb[3] = {0, 0, 0};
+  for (int c = 0; c < RGB_N_CLASSES; ++c)
+    nb[rgb_class_in_part<1>(c) ? 1 : 2] += (cc.n[c] + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
+  if (d_family_totals) nb[1] = nb[2] = all_blocks;      /* device-side counts: surplus blocks return at once */
+  hipStream_t s2 = forked ? side : st;
+  if (forked && nb[2]) {
+    if (hipEventRecord(fork_ev, st) != hipSuccess || hipStreamWaitEvent(side, fork_ev, 0) != hipSuccess) return -1;
+  }
+  dim3 block(RGB_TICK_BLOCK);
+#define LAUNCH(NN)                                                                                       \
+  case NN:                                                                                               \
+    if (nb[2]) hipLaunchKernelGGL((rgb_tick_classes_kernel<NN, 2>), dim3(nb[2]), block, 0, s2, dev, d_msgs, cc, \
+                                  d_family_totals, d_dec, d_rpcs, rpc_slot_base, msg_index_base);         \
+    if (nb[1]) hipLaunchKernelGGL((rgb_tick_classes_kernel<NN, 1>), dim3(nb[1]), block, 0, st, dev, d_msgs, cc, \
+                                  d_family_totals, d_dec, d_rpcs, rpc_slot_base, msg_index_base);         \
+    break;
+  switch (dev.n_members) {
+    LAUNCH(3) LAUNCH(5) LAUNCH(7)         /* the measured group sizes only: an experiment, not the product path */
+    default: return -1;
+  }
+#undef LAUNCH
+  if (forked && nb[2]) {
+    if (hipEventRecord(join_ev, side) != hipSuccess || hipStreamWaitEvent(st, join_ev, 0) != hipSuccess) return -1;
+  }
+  return (int)hipGetLastError();
+}
+
 int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32 counts[RGB_N_CLASSES],
                             const u32 *d_family_totals, u32 max_msgs, rgb_decision *d_dec, rgb_rpc *d_rpcs,
                             u32 rpc_slot_base, u32 msg_index_base, void *stream) {
@@ -2313,6 +2368,9 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
   }
   if (d_family_totals) blocks = (max_msgs + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK + RGB_N_CLASSES;
   if (blocks == 0) return 0;
+  if (dev.dbg & (8192u | 16384u))
+    return launch_tick_classes_split(dev, d_msgs, cc, d_family_totals, blocks, d_dec, d_rpcs, rpc_slot_base,
+                                     msg_index_base, st);
   dim3 grid(blocks), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                                     \
   case NN:                                                                                             \

@@ -37,6 +37,17 @@ def emulated_kernels_so(tmp_path_factory):
            "-I", os.path.join(nat, "fake_hip"), "-I", os.path.join(ROOT, "include"), "-o", str(out),
            os.path.join(nat, "api_on_cpu.cpp"), os.path.join(nat, "kernel_on_cpu.cpp"),
            os.path.join(nat, "wal_on_cpu.cpp")]
+    san = os.environ.get("RGB_EMU_SANITIZE")
+    if san:
+        # opt-in: a sanitizer over the emulated device code (every global / LDS index the kernels form, every
+        # shift count and alignment); run as
+        #   RGB_EMU_SANITIZE=address LD_PRELOAD=<clang lib dir>/libclang_rt.asan-x86_64.so \
+        #       ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 pytest tests/test_*_on_cpu.py
+        #   RGB_EMU_SANITIZE=undefined LD_PRELOAD=<clang lib dir>/libclang_rt.ubsan_standalone-x86_64.so \
+        #       UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 pytest tests/test_*_on_cpu.py
+        cmd[1:1] = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-shared-libsan", "-g"]
+        if san == "undefined":
+            cmd[1:1] = ["-fno-sanitize-recover=undefined"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return str(out)

@@ -79,6 +79,7 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e =
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 /* v_dot4_u32_u8 */
 static inline unsigned emu_udot4(unsigned a, unsigned b, unsigned c) {
   for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xFFu) * ((b >> (8 * k)) & 0xFFu);
