@@ -10,8 +10,9 @@
  * {ra_gpu_batch, Tick, Decisions, Rpcs} to the owning process (fan-back to the gen_statems is
  * done there).  The resource destructor calls rgb_close.
  *
- * Cannot be compiled in this image (no erl_nif.h): `make nif-check` only syntax-checks it
- * against ra_amd/csrc/nif_stub/erl_nif.h.  Build line for a machine with OTP >= 26:
+ * Cannot be built against the real erl_nif.h in this image (no OTP): `make nif-check` syntax-checks it
+ * against ra_amd/csrc/nif_stub/erl_nif.h, and tests/test_nif_shim_mock_beam.py EXECUTES it against a functional
+ * mock of that API (tests/native/mock_beam) on top of the CPU-emulated library.  Build line for a machine with OTP >= 26:
  *   cc -O2 -fPIC -shared -I$ERL_INCLUDE -Iinclude ra_amd/csrc/ra_gpu_batch_nif.c \
  *      -Lra_amd/csrc -lra_gpu_batch -o priv/ra_gpu_batch_nif.so
  */
@@ -126,7 +127,11 @@ static int do_collect(nif_ctx *c, ErlNifBinary *dec, ErlNifBinary *rpc, uint32_t
   if (!enif_alloc_binary((size_t)c->ring_capacity * sizeof(rgb_decision), dec)) return RGB_E_NOMEM;
   if (!enif_alloc_binary((size_t)rcap * sizeof(rgb_rpc), rpc)) { enif_release_binary(dec); return RGB_E_NOMEM; }
   int rc = rgb_collect(c->ctx, (rgb_decision *)dec->data, c->ring_capacity, n, (rgb_rpc *)rpc->data, rcap, nr, tick);
-  if (rc) { enif_release_binary(dec); enif_release_binary(rpc); }
+  if (rc) { enif_release_binary(dec); enif_release_binary(rpc); return rc; }
+  /* the binaries carry exactly the records that were produced: byte_size(DecisionsBin) div 64 decisions,
+   * byte_size(RpcsBin) div 56 rpc records */
+  enif_realloc_binary(dec, (size_t)*n * sizeof(rgb_decision));
+  enif_realloc_binary(rpc, (size_t)*nr * sizeof(rgb_rpc));
   return rc;
 }
 

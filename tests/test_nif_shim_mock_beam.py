@@ -1,0 +1,252 @@
+"""The Erlang NIF shim (ra_amd/csrc/ra_gpu_batch_nif.c) EXECUTED without OTP: compiled against a functional mock
+of the erl_nif subset it uses (tests/native/mock_beam: heap terms, owned binaries, reference-counted resources
+with destructors, enif_send into a queue, pthreads) and linked to the CPU-emulated library.  The test plays the
+Erlang caller of erlang/ra_gpu_batch.erl -- open/4, register_groups/3, upload_state/3, submit/3, collect/1,
+download_state/3, snapshot/2, start_collector/2, the WAL calls -- and checks what comes back, record for record,
+against the checker.  What it cannot show is the BEAM itself (scheduling, real binaries' reference counts)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import fuzz
+from ra_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T_ATOM, T_INT, T_BIN, T_TUPLE, T_RES, T_PID, T_BADARG = 1, 2, 3, 4, 5, 6, 7
+
+
+@pytest.fixture(scope="module")
+def beam(emulated_kernels_so, tmp_path_factory):
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    out = tmp_path_factory.mktemp("nif") / "ra_gpu_batch_nif_mock.so"
+    emu_dir, emu_name = os.path.split(emulated_kernels_so)
+    cmd = ["gcc", "-std=c11", "-D_GNU_SOURCE", "-O1", "-g", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter",
+           "-I", os.path.join(ROOT, "tests", "native", "mock_beam"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "ra_amd", "csrc", "ra_gpu_batch_nif.c"),
+           os.path.join(ROOT, "tests", "native", "mock_beam", "mock_beam.c"),
+           "-L", emu_dir, "-l:" + emu_name, "-Wl,-rpath," + emu_dir, "-lpthread", "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    L = C.CDLL(str(out))
+    vp, u64 = C.c_void_p, C.c_uint64
+    for name, res, args in [("mock_load", C.c_int, []), ("mock_call", vp, [C.c_char_p, C.c_int, C.POINTER(vp)]),
+                            ("mock_func_flags", C.c_uint, [C.c_char_p, C.c_int]),
+                            ("mock_uint", vp, [u64]), ("mock_int", vp, [C.c_int]), ("mock_atom", vp, [C.c_char_p]),
+                            ("mock_pid", vp, [u64]), ("mock_binary", vp, [vp, C.c_size_t]), ("mock_tag", C.c_int, [vp]),
+                            ("mock_atom_name", C.c_char_p, [vp]), ("mock_arity", C.c_int, [vp]),
+                            ("mock_elem", vp, [vp, C.c_int]), ("mock_uint_value", u64, [vp]),
+                            ("mock_int_value", C.c_int64, [vp]), ("mock_bin_data", vp, [vp]),
+                            ("mock_bin_size", C.c_size_t, [vp]), ("mock_gc_resource_term", None, [vp]),
+                            ("mock_live_resources", C.c_long, []), ("mock_dtor_calls", C.c_long, []),
+                            ("mock_recv", vp, [C.c_int, C.POINTER(u64)])]:
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    assert L.mock_load() == 0, "on_load: resource type or ABI version"
+    return Beam(L)
+
+
+class Beam:
+    """Term construction / inspection on the Python side of the mock."""
+
+    def __init__(self, L):
+        self.L = L
+
+    def to_term(self, x):
+        if isinstance(x, Opaque):
+            return x.t
+        if isinstance(x, (bytes, bytearray)):
+            buf = (C.c_char * max(len(x), 1)).from_buffer_copy(bytes(x) or b"\0")
+            return self.L.mock_binary(C.cast(buf, C.c_void_p), len(x))
+        if isinstance(x, str):
+            return self.L.mock_atom(x.encode())
+        if isinstance(x, int):
+            return self.L.mock_int(x) if x < 0 else self.L.mock_uint(x)
+        raise TypeError(x)
+
+    def from_term(self, t):
+        tag = self.L.mock_tag(t)
+        if tag == T_ATOM:
+            return self.L.mock_atom_name(t).decode()
+        if tag == T_INT:
+            return int(self.L.mock_uint_value(t))
+        if tag == T_BIN:
+            return C.string_at(self.L.mock_bin_data(t), self.L.mock_bin_size(t))
+        if tag == T_TUPLE:
+            return tuple(self.from_term(self.L.mock_elem(t, k)) for k in range(self.L.mock_arity(t)))
+        if tag == T_BADARG:
+            return "badarg"
+        if tag in (T_RES, T_PID):
+            return Opaque(t)
+        raise AssertionError(f"term tag {tag}")
+
+    def call(self, name, *args):
+        argv = (C.c_void_p * max(len(args), 1))(*[self.to_term(a) for a in args])
+        t = self.L.mock_call(name.encode(), len(args), argv)
+        assert t, f"undef: {name}/{len(args)}"
+        return self.from_term(t)
+
+    def recv(self, timeout_ms=20000):
+        to = C.c_uint64(0)
+        t = self.L.mock_recv(timeout_ms, C.byref(to))
+        return (None, None) if not t else (int(to.value), self.from_term(t))
+
+
+class Opaque:
+    def __init__(self, t):
+        self.t = t
+
+
+def test_shim_round_trip_against_the_checker(beam, oracle_lib):
+    """open -> register_groups -> upload_state -> (submit, collect) x ticks -> download_state / snapshot, every
+    record compared with the checker; then the destructor path."""
+    G, N = 96, 5
+    rng = np.random.default_rng(77)
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    live0, dtors0 = beam.L.mock_live_resources(), beam.L.mock_dtor_calls()
+
+    ok, ctx = beam.call("open", 0, 16, 2, 1024)
+    assert ok == "ok" and isinstance(ctx, Opaque)
+    assert beam.L.mock_live_resources() == live0 + 1
+    assert beam.call("register_groups", ctx, G, N) == "ok"
+    assert beam.call("upload_state", ctx, 0, st.tobytes()) == "ok"
+    # malformed arguments are badarg, not crashes (badarg only for malformed binaries)
+    assert beam.call("upload_state", ctx, 0, st.tobytes()[:-1]) == "badarg"
+    assert beam.call("submit", ctx, b"\0" * 63, 1) == "badarg"
+    assert beam.call("submit", 17, b"", 1) == "badarg"
+    assert beam.call("collect", ctx) == ("error", "empty")
+
+    for tick in range(1, 5):
+        msgs = fuzz.random_msgs(rng, cpu.get_state(), N)
+        want_d, want_r = cpu.step(msgs)
+        assert beam.call("submit", ctx, msgs.tobytes(), tick) == "ok"
+        ok, got_tick, n, dec_bin, rpc_bin = beam.call("collect", ctx)
+        assert (ok, got_tick, n) == ("ok", tick, len(msgs))
+        assert len(dec_bin) == n * abi.DECISION_DTYPE.itemsize          # binaries carry exactly the records
+        assert dec_bin == want_d.tobytes(), f"tick {tick}: decisions differ"
+        got_r = np.frombuffer(rpc_bin, dtype=abi.RPC_DTYPE)
+        assert len(got_r) == len(want_r)
+        assert fuzz.sort_rpcs(got_r.copy()).tobytes() == fuzz.sort_rpcs(want_r).tobytes(), f"tick {tick}: rpcs"
+
+    ok, state_bin = beam.call("download_state", ctx, 0, G * N)
+    assert ok == "ok" and state_bin == cpu.get_state().tobytes()
+    ok, lb = beam.call("snapshot", ctx, G)
+    assert ok == "ok" and len(lb) == G * 32
+    # an error code from the library comes back as {error, Atom}
+    assert beam.call("download_state", ctx, G * N, 8) == ("error", "invalid")
+
+    # the last reference goes away: the destructor runs rgb_close exactly once
+    beam.L.mock_gc_resource_term(ctx.t)
+    assert beam.L.mock_live_resources() == live0 and beam.L.mock_dtor_calls() == dtors0 + 1
+    cpu.close()
+
+
+def test_collector_thread_fans_batches_back_in_order(beam, oracle_lib):
+    """start_collector/2: a thread owns rgb_collect and enif_send()s {ra_gpu_batch, Tick, N, Decisions, Rpcs}
+    to the owner; submit/3 stays non-blocking.  The resource stays alive while the thread holds it."""
+    G, N = 64, 3
+    rng = np.random.default_rng(78)
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    dtors0 = beam.L.mock_dtor_calls()
+    ok, ctx = beam.call("open", 0, 16, 4, 512)
+    assert ok == "ok"
+    assert beam.call("register_groups", ctx, G, N) == "ok"
+    assert beam.call("upload_state", ctx, 0, st.tobytes()) == "ok"
+    owner = Opaque(beam.L.mock_pid(4242))
+    assert beam.call("start_collector", ctx, 99) == "badarg"           # not a pid
+    assert beam.call("start_collector", ctx, owner) == "ok"
+    assert beam.call("start_collector", ctx, owner) == "badarg"        # already running
+    wants = []
+    for tick in range(10, 16):
+        msgs = fuzz.random_msgs(rng, cpu.get_state(), N)
+        wants.append((tick, len(msgs), cpu.step(msgs)[0].tobytes()))
+        assert beam.call("submit", ctx, msgs.tobytes(), tick) == "ok"
+        to, msg = beam.recv()                      # one batch in flight at a time keeps this test deterministic
+        assert msg is not None, "collector sent nothing"
+        tag, got_tick, n, dec_bin, _rpc_bin = msg
+        assert to == 4242 and tag == "ra_gpu_batch"
+        assert (got_tick, n, dec_bin) == wants[-1]
+    # dropping the term does not destroy the context while the collector thread holds its reference ...
+    beam.L.mock_gc_resource_term(ctx.t)
+    assert beam.L.mock_dtor_calls() == dtors0
+    cpu.close()
+
+
+def test_nif_table_matches_the_erlang_stub(beam):
+    """Every NIF the Erlang module declares (erlang/ra_gpu_batch.erl: `Name(_Args) -> erlang:nif_error(not_loaded)`)
+    is in the shim's table with the same arity, and the blocking ones are dirty-scheduler NIFs."""
+    import re
+    src = open(os.path.join(ROOT, "erlang", "ra_gpu_batch.erl")).read()
+    stubs = re.findall(r"^(\w+)\(([^)]*)\)\s*->\s*erlang:nif_error\(not_loaded\)\.", src, flags=re.M)
+    assert len(stubs) >= 11
+    for name, args in stubs:
+        arity = len([a for a in args.split(",") if a.strip()])
+        flags = beam.L.mock_func_flags(name.encode(), arity)
+        assert flags != 0xFFFFFFFF, f"{name}/{arity} is not in the NIF table"
+        if name in ("submit", "open", "start_collector"):
+            assert flags == 0, f"{name} must not be a dirty NIF (non-blocking)"
+        else:
+            assert flags == 2, f"{name} waits on the GPU / copies: dirty IO-bound"
+
+
+def test_wal_nifs(beam):
+    """wal_checksums/3, wal_frame/4 and wal_recover_check/2 through the shim: checksums against zlib, the framed
+    batch round-trips through the recovery check, a flipped byte in the middle is `corrupt`."""
+    ok, ctx = beam.call("open", 0, 16, 2, 256)
+    assert ok == "ok"
+    rng = np.random.default_rng(5)
+    n = 40
+    payloads = [rng.integers(0, 256, int(rng.integers(0, 700)), dtype=np.uint8).tobytes() for _ in range(n)]
+    entries = np.zeros(n, dtype=abi.WAL_ENTRY_DTYPE)
+    off = 0
+    for i, p in enumerate(payloads):
+        entries[i]["index"], entries[i]["term"] = 1000 + i, 7
+        entries[i]["data_offset"], entries[i]["data_len"] = off, len(p)
+        off += len(p)
+    data = b"".join(payloads)
+    ok, sums = beam.call("wal_checksums", ctx, entries.tobytes(), data)
+    assert ok == "ok"
+    got = np.frombuffer(sums, dtype="<u4")
+    for i, p in enumerate(payloads):
+        want = zlib.adler32((1000 + i).to_bytes(8, "big") + (7).to_bytes(8, "big") + p) & 0xFFFFFFFF
+        assert int(got[i]) == want, f"entry {i}"
+    assert beam.call("wal_checksums", ctx, entries.tobytes()[:-1], data) == "badarg"
+
+    # wal_frame/4: the batch's on-disk bytes equal struct.pack + zlib, written independently
+    import test_wal_framing as WF
+    lens = [0, 1, 15, 16, 17, 1000] + [int(x) for x in rng.integers(0, 900, size=30)]
+    specs = WF.random_specs(rng, len(lens), lens)
+    recs, rdata, rpayloads = WF.make_batch(rng, specs)
+    ok, framed = beam.call("wal_frame", ctx, recs.tobytes(), rdata.tobytes(), 0)
+    assert ok == "ok" and framed == WF.python_frame(specs, rpayloads)
+    assert beam.call("wal_frame", ctx, recs.tobytes()[:-3], rdata.tobytes(), 0) == "badarg"
+
+    # wal_recover_check/2 over a file made of that batch: every record back, status clean; one flipped payload
+    # byte in the middle is `corrupt` (wal_checksum_validation_failure), in the last record `dropped_last`
+    file_bytes = abi.WAL_FILE_HEADER + framed
+    ok, scanned_bin, n_ok, status = beam.call("wal_recover_check", ctx, file_bytes)
+    scanned = np.frombuffer(scanned_bin, dtype=abi.WAL_SCANNED_DTYPE)
+    assert (ok, n_ok, status) == ("ok", len(specs), "clean") and len(scanned) == len(specs)
+    assert [(int(r["index"]), int(r["term"]), int(r["data_len"])) for r in scanned] == \
+           [(idx, term, ln) for (_t, _w, _u, idx, term, ln) in specs]
+    mid = next(i for i in range(len(specs) // 2, len(specs)) if specs[i][5] > 0)
+    bad = bytearray(file_bytes)
+    bad[int(scanned[mid]["data_offset"])] ^= 0x40
+    ok, _sb, n_ok, status = beam.call("wal_recover_check", ctx, bytes(bad))
+    assert (ok, n_ok, status) == ("ok", mid, "corrupt")
+    last = len(specs) - 1
+    assert specs[last][5] > 0
+    bad = bytearray(file_bytes)
+    bad[int(scanned[last]["data_offset"])] ^= 0x40
+    ok, _sb, n_ok, status = beam.call("wal_recover_check", ctx, bytes(bad))
+    assert (ok, n_ok, status) == ("ok", last, "dropped_last")
+    beam.L.mock_gc_resource_term(ctx.t)
