@@ -15,7 +15,7 @@
 -module(ra_gpu_batch).
 
 -export([init/0, open/4, register_groups/3, upload_state/3, download_state/3,
-         submit/3, collect/1, start_collector/2, snapshot/2, wal_checksums/3]).
+         submit/3, collect/1, start_collector/2, stop_collector/1, snapshot/2, wal_checksums/3]).
 -export([wal_batch_checksums/2, wal_frame/4, wal_recover_check/2, wal_frame_batch/3, wal_recover/2]).
 -export([encode_msg/3, decode_decision/1, decision_to_effects/3]).
 
@@ -68,6 +68,7 @@ download_state(_Ctx, _First, _N) -> erlang:nif_error(not_loaded).
 submit(_Ctx, _MsgsBin, _Tick) -> erlang:nif_error(not_loaded).
 collect(_Ctx) -> erlang:nif_error(not_loaded).
 start_collector(_Ctx, _Pid) -> erlang:nif_error(not_loaded).
+stop_collector(_Ctx) -> erlang:nif_error(not_loaded).
 snapshot(_Ctx, _NGroups) -> erlang:nif_error(not_loaded).
 wal_checksums(_Ctx, _EntriesBin, _DataBin) -> erlang:nif_error(not_loaded).
 

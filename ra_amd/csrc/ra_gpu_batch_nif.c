@@ -180,6 +180,19 @@ static ERL_NIF_TERM nif_start_collector(ErlNifEnv *env, int argc, const ERL_NIF_
   return enif_make_atom(env, "ok");
 }
 
+/* stop_collector(Ctx) -> ok: ends the collector thread and drops the reference it held on the context (without
+ * it the thread would keep the resource alive for ever and the destructor could never run) */
+static ERL_NIF_TERM nif_stop_collector(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c) || !c->collector_on) return enif_make_badarg(env);
+  c->stop = 1;
+  enif_thread_join(c->tid, NULL);
+  c->collector_on = 0;
+  c->stop = 0;
+  return enif_make_atom(env, "ok");
+}
+
 /* snapshot(Ctx, NGroups) -> {ok, <<rgb_leaderboard_row x NGroups>>} */
 static ERL_NIF_TERM nif_snapshot(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c; unsigned g; ErlNifBinary b;
@@ -266,6 +279,7 @@ static ErlNifFunc nif_funcs[] = {
   {"submit", 3, nif_submit, 0},
   {"collect", 1, nif_collect, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"start_collector", 2, nif_start_collector, 0},
+  {"stop_collector", 1, nif_stop_collector, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"snapshot", 2, nif_snapshot, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"wal_checksums", 3, nif_wal_checksums, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"wal_frame", 4, nif_wal_frame, ERL_NIF_DIRTY_JOB_IO_BOUND},

@@ -175,9 +175,13 @@ def test_collector_thread_fans_batches_back_in_order(beam, oracle_lib):
         tag, got_tick, n, dec_bin, _rpc_bin = msg
         assert to == 4242 and tag == "ra_gpu_batch"
         assert (got_tick, n, dec_bin) == wants[-1]
-    # dropping the term does not destroy the context while the collector thread holds its reference ...
-    beam.L.mock_gc_resource_term(ctx.t)
+    # the collector thread holds its own reference: stop_collector/1 joins it, and only then does dropping the
+    # term run the destructor
+    assert beam.call("stop_collector", ctx) == "ok"
+    assert beam.call("stop_collector", ctx) == "badarg"
     assert beam.L.mock_dtor_calls() == dtors0
+    beam.L.mock_gc_resource_term(ctx.t)
+    assert beam.L.mock_dtor_calls() == dtors0 + 1
     cpu.close()
 
 
