@@ -31,6 +31,12 @@ def beam(emulated_kernels_so, tmp_path_factory):
            os.path.join(ROOT, "ra_amd", "csrc", "ra_gpu_batch_nif.c"),
            os.path.join(ROOT, "tests", "native", "mock_beam", "mock_beam.c"),
            "-L", emu_dir, "-l:" + emu_name, "-Wl,-rpath," + emu_dir, "-lpthread", "-o", str(out)]
+    san = os.environ.get("RGB_EMU_SANITIZE")
+    if san:                                   # same opt-in as the emulation build (tests/conftest.py): one runtime
+        clang = shutil.which("clang", path="/opt/rocm/lib/llvm/bin") or shutil.which("clang")
+        cmd[0] = clang
+        cmd[1:1] = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-shared-libsan"] + \
+                   (["-fno-sanitize-recover=undefined"] if san == "undefined" else [])
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     L = C.CDLL(str(out))
