@@ -12,6 +12,28 @@ from ra_amd.shell import RaShell, KvMachine, NOOP
 def test_kv_commands_replicate_to_every_member(oracle_lib, n_members):
     G = 8
     eng = oracle_lib.Oracle(G, n_members)
+    kv_commands_replicate(eng, G, n_members)
+
+
+def test_kv_commands_replicate_through_the_emulated_product_engine(emulated_engine):
+    """The same shell over ra_amd.engine.RaGpuBatch bound (in this test process only) to the product's HIP
+    sources compiled for the CPU: rgb_submit / rgb_collect and the kernels decide, not the checker."""
+    G, N = 8, 3
+    with emulated_engine.RaGpuBatch(G, N, ring_capacity=G * N, ring_slots=2, max_runs=8) as eng:
+        kv_commands_replicate(eng, G, N)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_members", [3, 5])
+def test_kv_commands_replicate_on_the_gpu(n_members):
+    """examples/kv_cluster.py in small: the shell drives the HIP engine on the MI355X."""
+    from ra_amd import engine
+    G = 64
+    with engine.RaGpuBatch(G, n_members, ring_capacity=G * n_members, ring_slots=2, max_runs=8) as eng:
+        kv_commands_replicate(eng, G, n_members)
+
+
+def kv_commands_replicate(eng, G, n_members):
     eng.set_state(0, abi.empty_server_states(G, n_members))
     sh = RaShell(eng, G, n_members)
     for g in range(G):
