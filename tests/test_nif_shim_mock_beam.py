@@ -181,6 +181,17 @@ def test_collector_thread_fans_batches_back_in_order(beam, oracle_lib):
         tag, got_tick, n, dec_bin, _rpc_bin = msg
         assert to == 4242 and tag == "ra_gpu_batch"
         assert (got_tick, n, dec_bin) == wants[-1]
+    # several batches in flight (ring_slots = 4): submit/3 on this thread races the collector's rgb_collect on
+    # its own; the batches still come back whole and in submission order
+    burst = []
+    for tick in range(20, 23):
+        msgs = fuzz.random_msgs(rng, cpu.get_state(), N)
+        burst.append((tick, len(msgs), cpu.step(msgs)[0].tobytes()))
+        assert beam.call("submit", ctx, msgs.tobytes(), tick) == "ok"
+    for want in burst:
+        to, msg = beam.recv()
+        assert msg is not None and to == 4242
+        assert (msg[1], msg[2], msg[3]) == want
     # the collector thread holds its own reference: stop_collector/1 joins it, and only then does dropping the
     # term run the destructor
     assert beam.call("stop_collector", ctx) == "ok"
