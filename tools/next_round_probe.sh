@@ -1,7 +1,8 @@
 #!/bin/bash
 # First gpurun of the next round (one call, ~6 GPU-minutes):  gpurun --timeout 900 -- 'bash tools/next_round_probe.sh'
 # 1. parity on the GPU for everything that was only verified on the CPU emulation at the end of round 1
-#    (ABI v4 backoff mask, checksum over it), 2. the single-launch tick against the experimental two-launch tick
+#    (ABI v4 backoff mask, checksum over it, class-kernel PART parameter, commit_index_sent without per-peer
+#    copies -- expect a slightly shorter tick than profiles/r01_bench.json from the last one), 2. the single-launch tick against the experimental two-launch tick
 #    (RGB_DEBUG 8192 = same stream, 16384 = forked side stream / parallel graph branches; parity-preserving knobs),
 # 3. a fresh rocprofv3 kernel trace of the default bench for profiles/.
 set -u
