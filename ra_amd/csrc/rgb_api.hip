@@ -213,11 +213,15 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   d.peer_stride = rgb_peer_stride(n_members);
   d.max_pipeline_count = ctx->cfg.max_pipeline_count;
   d.max_aer_batch = ctx->cfg.max_aer_batch;
-  { const char *e = getenv("RGB_DEBUG"); d.dbg = e ? (u32)atoi(e) : 0u; d.dbg_buf = nullptr; }
+  d.dbg = 0; d.dbg_buf = nullptr;
+#ifdef RGB_PROFILE
+  /* the profiling build only (libra_gpu_batch_prof.so): knobs from the environment */
+  { const char *e = getenv("RGB_DEBUG"); d.dbg = e ? (u32)atoi(e) : 0u; }
   if (d.dbg & 16u) {
-    HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(S / 64 + 16) * 4 * sizeof(u64)));
-    HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 4 * sizeof(u64)));
+    HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
+    HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
   }
+#endif
   HIPCHK(ctx, hipMalloc((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.runs, (size_t)S * d.max_runs * 2 * sizeof(u64)));
@@ -569,7 +573,8 @@ int rgb_state_checksum(rgb_ctx *ctx, uint32_t first, uint32_t n, uint64_t *out) 
   return RGB_OK;
 }
 
-/* profiling aid (RGB_DEBUG & 16): per-wave timestamps of the last class-dispatch launch */
+/* profiling aid (the -DRGB_PROFILE build with RGB_DEBUG & 16): per-wave timestamps of the last class-dispatch
+ * launch; RGB_E_INVAL in the product library */
 int rgb_debug_read(rgb_ctx *ctx, uint64_t *out, uint32_t n_words) {
   if (!ctx || !out || !ctx->dev.dbg_buf) return RGB_E_INVAL;
   HIPCHK(ctx, hipMemcpy(out, ctx->dev.dbg_buf, (size_t)n_words * sizeof(u64), hipMemcpyDeviceToHost));

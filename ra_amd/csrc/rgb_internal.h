@@ -10,14 +10,16 @@
  *        6 last_written_index               7 last_written_term
  *        8 snapshot_index 9 snapshot_term  10 first_index
  *        11 last-run start index           12 last-run term
- *        13 pre_vote_token   14 machine_version | effective_machine_version << 32
+ *        13 start, 14 term of the run before the last (mirrors of the run table: a term lookup
+ *           touches memory only below the newest two runs)
  *        15 first pending index (ra_log `pending` = [this .. last_index])
  *   peers[S][PS] u64   PS = roundup(3*N, 8): match_index[N] | next_index[N] | commit_index_sent[N]
  *        only leader-side messages touch it
  *   runs [S][K][2] u64 (start, term) of each term run of the ra_log range; only probed when an
  *        index older than the last run is looked up (log-matching repair)
  *   cond [S][4] u64    stored reply of await_condition (cold)
- *   qry  [S][16] u64   consistent-query heartbeats (cold): 0 query_index, 1+i query_index of peer slot i
+ *   qry  [S][16] u64   consistent-query heartbeats (cold): 0 query_index, 1+i query_index of peer slot i,
+ *        9 snapshot_backoff mask, 10 pre_vote_token, 11 machine versions (election kinds only)
  */
 #ifndef RGB_INTERNAL_H
 #define RGB_INTERNAL_H
@@ -48,8 +50,8 @@ typedef uint32_t u32;
 #define HOT_FIRST 10
 #define HOT_LRS   11
 #define HOT_LRT   12
-#define HOT_TOKEN 13
-#define HOT_MACVER 14
+#define HOT_PRS   13   /* (start, term) of run n_runs-2: a mirror of the run table, like 11/12 of the last run */
+#define HOT_PRT   14
 #define HOT_PEND  15
 
 /* packed word: bit offset / width */
@@ -69,6 +71,8 @@ typedef uint32_t u32;
 #define PK_QPEER_SH     57  /* 1: some peer query_index > 0 (reset_query_index has work) */
 #define PK_BACKOFF_SH   58  /* 1: some peer is in {snapshot_backoff,_}: qry row word QRY_BACKOFF holds the mask */
 #define QRY_BACKOFF     9   /* qry row: word 0 query_index, 1..8 peer query_index, 9 backoff mask */
+#define QRY_TOKEN       10  /* pre_vote_token (election kinds only)                                   */
+#define QRY_MACVER      11  /* machine_version | effective_machine_version << 32                      */
 
 /* Device order of a tick: clause family = (class rank of the message kind, success flag).  Every
  * kind is its own kernel class: a wavefront of the class-dispatch kernel runs the code path
@@ -116,14 +120,9 @@ struct rgb_dev {
   u32 peer_stride;
   u32 max_pipeline_count;
   u32 max_aer_batch;
-  u32 dbg;   /* profiling knobs (env RGB_DEBUG, 0 in production; everything but 16 breaks parity or only
-                changes memory-access flavours): 1 = no state write-back, 2 = no decision store, 4 = no
-                peers prefetch, 8 = no hot-line load (zero state), 16 = per-wave timestamps into dbg_buf,
-                32 = write-through (sc1) stores, 64 = whole-line hot write-back, 128 = plain instead of
-                non-temporal decision stores, 1024 = non-temporal state stores, 2048 = plain instead of
-                non-temporal message loads, 4096 = non-temporal rpc record stores, 8192 = two launches per tick
-                (bulk classes / long classes, same stream), 16384 = the same with the long classes on a
-                forked side stream (parallel graph branches under capture); the last two keep parity */
+  u32 dbg;   /* always 0 in the product library.  The -DRGB_PROFILE build (libra_gpu_batch_prof.so, tools/ only)
+                reads RGB_DEBUG: 1 = no state write-back, 2 = no decision store, 8 = no hot-line load (zero
+                state), 16 = per-wave timestamps into dbg_buf; all but 16 break parity */
   u64 *dbg_buf;
 };
 

@@ -20,6 +20,18 @@
 #define UNDEF 0xFFFFFFFFFFFFFFFFull
 #define SLOT_NONE4 0xFu
 
+/* Profiling knobs exist only in the -DRGB_PROFILE build (libra_gpu_batch_prof.so, used by tools/): the
+ * product library has no run-time switch that changes what a tick computes.
+ *   1 = no state write-back, 2 = no decision store, 8 = no hot-line load (zero state),
+ *   16 = per-wave timestamps into dbg_buf, 32 = run-table probes answer from the last run (no dependent
+ *   loads), 64 = the peers row is not loaded (zeros), 128 = the load generator emits benign traffic only
+ *   (no term churn, no append_entries anomalies, no failed replies) */
+#ifdef RGB_PROFILE
+#define RGB_KNOB(dev, bit) (((dev).dbg & (bit)) != 0)
+#else
+#define RGB_KNOB(dev, bit) false
+#endif
+
 #ifndef RGB_TICK_BLOCK
 #define RGB_TICK_BLOCK 64
 #endif
@@ -32,18 +44,6 @@
 
 namespace {
 
-/* write-through (sc1) stores: the bytes leave the XCD's L2 at once instead of sitting dirty until
- * the kernel-end write-back (which the next dependent launch has to wait for) */
-__device__ __forceinline__ void store16_wt(void *p, ulonglong2 v) {
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  v4u d;
-  d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
-#ifndef RGB_HOST_EMULATION
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-#else
-  *reinterpret_cast<v4u *>(p) = d;
-#endif
-}
 __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   v4u d;
@@ -54,12 +54,22 @@ __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
   *reinterpret_cast<v4u *>(p) = d;
 #endif
 }
-__device__ __forceinline__ void store8_wt(u64 *p, u64 v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+/* state and rpc-record stores are plain (write-back L2): write-through and non-temporal flavours were
+ * measured slower in round 1 */
+#define ST16(ptr, val) do { *(ptr) = (val); } while (0)
+#define ST8(ptr, val) do { *(ptr) = (val); } while (0)
+
+/* workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global
+ * store (vmcnt(0)), which put the state write-back's acknowledgement on the decision store's path */
+__device__ __forceinline__ void lds_barrier() {
+#ifdef RGB_HOST_EMULATION
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
 }
-/* store mode: 0 plain, 1 write-through (sc1), 2 non-temporal */
-#define ST16(ptr, val, wt) do { if ((wt) == 1) store16_wt((void *)(ptr), (val)); else if ((wt) == 2) store16_nt((void *)(ptr), (val)); else *(ptr) = (val); } while (0)
-#define ST8(ptr, val, wt) do { if ((wt) == 1) store8_wt((u64 *)(ptr), (val)); else if ((wt) == 2) __builtin_nontemporal_store((u64)(val), (u64 *)(ptr)); else *(ptr) = (val); } while (0)
 
 /* non-temporal 16-byte load: message records are read exactly once */
 typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
@@ -84,7 +94,9 @@ __device__ __forceinline__ unsigned slot4to8(unsigned s) { return s >= 8u ? (uns
  * the effects being accumulated and the pending (uncommitted) log-table edits. */
 struct Lane {
   /* hot line */
-  u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt, token, macver, pend;
+  u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt, prs, prt, pend;
+  /* cold words (qry row), loaded only by the election kinds */
+  u64 token, macver;
   /* message */
   u32 server, n_entries, n_run0;
   unsigned kind, from, mflags, gap;
@@ -102,10 +114,10 @@ struct Lane {
   u64 w_first, w_last;
   bool vote_reqs;        /* {send_vote_requests,..}: the request fields ride in r_* */
   /* pending run-table edits: n_runs is the NEW count; the last `push_cnt` runs are not in
-   * memory yet: (ps0,pt0) then (lrs,lrt) */
+   * memory yet: (prs,prt) [when push_cnt == 2] then (lrs,lrt).  (prs,prt) always mirror run
+   * n_runs-2 and (lrs,lrt) run n_runs-1: a lookup only touches memory for run n_runs-3 and older. */
   unsigned n_runs;
   unsigned push_cnt;
-  u64 ps0, pt0;
   bool cond_dirty;
   u64 cr0, cr1, cr2, cr3;
   /* the server's peers row in registers (leader-side messages): match_index / next_index /
@@ -116,7 +128,6 @@ struct Lane {
   unsigned dmi, dni, dcs;
   unsigned dcs_ci;   /* peers whose commit_index_sent becomes L.ci at commit (pipelining): no per-peer copy is kept */
   bool peers_loaded;
-  bool rpc_nt;            /* profiling knob: non-temporal rpc record stores */
   /* consistent-query heartbeats (cold row, loaded on demand) */
   u64 *qry_base;          /* uniform: the row address is recomputed where it is needed */
   u64 qself, qp[8];
@@ -124,6 +135,10 @@ struct Lane {
   unsigned q_dirty;       /* bit 0: query_index, bit 1+i: peer slot i */
   unsigned hb_mask;
   unsigned cancel_mask;   /* RGB_F_CANCEL_SNAPSHOT_RETRY: backed-off peers contacted by make_all_rpcs */
+#ifdef RGB_PROFILE
+  unsigned prof_nloads;   /* run-table words read by this lane */
+  bool prof_noprobe;      /* knob 32: run-table probes answer from the last run (timing experiments only) */
+#endif
   u64 hb_term, hb_qi, q_consensus;
 };
 
@@ -158,19 +173,26 @@ __device__ __forceinline__ void peer_set(u64 (&a)[8], unsigned &dirty, unsigned 
 
 __device__ __forceinline__ bool range_nonempty(const Lane &L) { return L.first <= L.li; }
 
+/* word i of this server's in-memory run table: (start, term) of run k at words 2k, 2k+1 */
+__device__ __forceinline__ u64 run_word(const Lane &L, int i) {
+#ifdef RGB_PROFILE
+  const_cast<Lane &>(L).prof_nloads += 1;
+#endif
+  return L.runs[i];
+}
+
 /* ra_log:fetch_term/2 (src/ra_log.erl:1186-1200): defined only inside the range */
 __device__ __forceinline__ u64 fetch_term(const Lane &L, u64 idx) {
   if (!(range_nonempty(L) && idx >= L.first && idx <= L.li)) return UNDEF;
   if (idx >= L.lrs) return L.lrt;
-  /* older runs are all in memory (only the newest may be pending) */
-  int k = (int)L.n_runs - 2;
-  if (L.push_cnt == 2) {
-    if (idx >= L.ps0) return L.pt0;
-    k -= 1;
-  }
-  for (; k >= 0; --k) {
-    u64 s = L.runs[2 * k];
-    if (idx >= s) return L.runs[2 * k + 1];
+#ifdef RGB_PROFILE
+  if (L.prof_noprobe) return L.lrt;
+#endif
+  if (L.n_runs >= 2 && idx >= L.prs) return L.prt;
+  /* runs n_runs-3 and older are all in memory (at most the newest two are pending) */
+  for (int k = (int)L.n_runs - 3; k >= 0; --k) {
+    u64 s = run_word(L, 2 * k);
+    if (idx >= s) return run_word(L, 2 * k + 1);
   }
   return UNDEF;
 }
@@ -187,8 +209,12 @@ __device__ __forceinline__ u64 srv_fetch_term(const Lane &L, u64 idx) {
 __device__ __forceinline__ int find_run(const Lane &L, u64 idx) {
   if (L.n_runs == 0) return -1;
   if (idx >= L.lrs) return (int)L.n_runs - 1;
-  for (int k = (int)L.n_runs - 2; k >= 0; --k)
-    if (idx >= L.runs[2 * k]) return k;
+#ifdef RGB_PROFILE
+  if (L.prof_noprobe) return (int)L.n_runs - 1;
+#endif
+  if (L.n_runs >= 2 && idx >= L.prs) return (int)L.n_runs - 2;
+  for (int k = (int)L.n_runs - 3; k >= 0; --k)
+    if (idx >= run_word(L, 2 * k)) return k;
   return -1;
 }
 
@@ -434,7 +460,7 @@ __device__ __forceinline__ void evaluate_commit_index_follower(Lane &L) {
 /* append one segment [s..e] of term t after the current last run */
 __device__ __forceinline__ void push_segment(Lane &L, u64 s, u64 t) {
   if (L.n_runs > 0 && L.lrt == t) return;            /* extends the last run */
-  if (L.push_cnt == 1) { L.ps0 = L.lrs; L.pt0 = L.lrt; }
+  L.prs = L.lrs; L.prt = L.lrt;                      /* the old last run is now run n-2 */
   L.push_cnt += 1;
   L.n_runs += 1;
   L.lrs = s; L.lrt = t;
@@ -446,9 +472,10 @@ __device__ __forceinline__ void truncate_runs_to(Lane &L, u64 keep_idx) {
   int k = find_run(L, keep_idx);
   if (k < 0) { L.n_runs = 0; return; }
   if ((unsigned)k != L.n_runs - 1) {
-    L.lrs = L.runs[2 * k];
-    L.lrt = L.runs[2 * k + 1];
+    if ((unsigned)k == L.n_runs - 2) { L.lrs = L.prs; L.lrt = L.prt; }
+    else { L.lrs = run_word(L, 2 * k); L.lrt = run_word(L, 2 * k + 1); }
     L.n_runs = (unsigned)k + 1;
+    if (k >= 1) { L.prs = run_word(L, 2 * k - 2); L.prt = run_word(L, 2 * k - 1); }   /* the new run n-2 */
   }
 }
 
@@ -554,7 +581,13 @@ __device__ __forceinline__ int log_written(Lane &L, u64 term, u64 from, u64 to, 
       for (int k = (int)L.n_runs - 1; k >= 0; --k) {
         u64 s, t;
         if ((unsigned)k == L.n_runs - 1) { s = L.lrs; t = L.lrt; }
-        else { s = L.runs[2 * k]; t = L.runs[2 * k + 1]; }
+        else if ((unsigned)k == L.n_runs - 2) { s = L.prs; t = L.prt; }
+        else {
+#ifdef RGB_PROFILE
+          if (L.prof_noprobe) break;
+#endif
+          s = run_word(L, 2 * k); t = run_word(L, 2 * k + 1);
+        }
         const u64 rs = s < L.first ? L.first : s;
         if (rs <= hi && end >= lo && t == term) {
           const u64 idx = end < hi ? end : hi;
@@ -614,13 +647,18 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
     u64 *runs = const_cast<u64 *>(L.runs);
     if (k > 0) {
       for (unsigned j = (unsigned)k; j < L.n_runs; ++j) {
-        runs[2 * (j - k)] = runs[2 * j];
-        runs[2 * (j - k) + 1] = runs[2 * j + 1];
+        u64 rs, rt;                                     /* the newest two runs are in registers */
+        if (j == L.n_runs - 1) { rs = L.lrs; rt = L.lrt; }
+        else if (j == L.n_runs - 2) { rs = L.prs; rt = L.prt; }
+        else { rs = runs[2 * j]; rt = runs[2 * j + 1]; }
+        runs[2 * (j - k)] = rs;
+        runs[2 * (j - k) + 1] = rt;
       }
       L.n_runs -= (unsigned)k;
     }
     if (L.n_runs > 0) runs[0] = nf;
     if (L.lrs < nf) L.lrs = nf;
+    if (L.n_runs == 2) L.prs = nf;                      /* run n-2 is now run 0 */
     L.first = nf;
   }
   L.si = idx; L.st = term;
@@ -725,10 +763,9 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
       if (rpcs != nullptr) {
         /* fixed slot: this message's (n_out-1)-th record; 56 B = 7 x 8-B stores */
         u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
-        const int rm = L.rpc_nt ? 2 : 0;
-        ST8(o + 0, (u64)msg_index | ((u64)L.server << 32), rm);
-        ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16), rm);
-        ST8(o + 2, L.ct, rm); ST8(o + 3, rp_idx, rm); ST8(o + 4, rp_term, rm); ST8(o + 5, L.ci, rm); ST8(o + 6, new_ni, rm);
+        ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
+        ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
+        ST8(o + 2, L.ct); ST8(o + 3, rp_idx); ST8(o + 4, rp_term); ST8(o + 5, L.ci); ST8(o + 6, new_ni);
       }
     }
   }
@@ -867,10 +904,9 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
     n_out += 1;
     if (rpcs != nullptr) {
       u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
-      const int rm = L.rpc_nt ? 2 : 0;
-      ST8(o + 0, (u64)msg_index | ((u64)L.server << 32), rm);
-      ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16), rm);
-      ST8(o + 2, L.ct, rm); ST8(o + 3, rp_idx, rm); ST8(o + 4, rp_term, rm); ST8(o + 5, L.ci, rm); ST8(o + 6, new_ni, rm);
+      ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
+      ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
+      ST8(o + 2, L.ct); ST8(o + 3, rp_idx); ST8(o + 4, rp_term); ST8(o + 5, L.ci); ST8(o + 6, new_ni);
     }
   }
   return 0;
@@ -896,9 +932,10 @@ __device__ __forceinline__ u32 drop_existing(const Lane &L) {
     if (s > L.li) return k;
     int r = find_run(L, s);
     if (r < 0) return k;
-    u64 rterm = ((unsigned)r == L.n_runs - 1) ? L.lrt : L.runs[2 * r + 1];
+    u64 rterm = ((unsigned)r == L.n_runs - 1) ? L.lrt : ((unsigned)r == L.n_runs - 2) ? L.prt : run_word(L, 2 * r + 1);
     if (rterm != t) return k;
-    u64 rend = ((unsigned)r == L.n_runs - 1) ? L.li : L.runs[2 * (r + 1)] - 1;
+    u64 rend = ((unsigned)r == L.n_runs - 1) ? L.li : ((unsigned)r == L.n_runs - 2) ? L.lrs - 1 :
+               ((unsigned)r == L.n_runs - 3) ? L.prs - 1 : run_word(L, 2 * (r + 1)) - 1;
     if (rend >= e) { k += cnt; continue; }
     k += (u32)(rend - s + 1);
     return k;
@@ -1467,13 +1504,15 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   u64 *hot = dev.hot + (size_t)L.server * RGB_HOT_WORDS;
   const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(hot);
   ulonglong2 h0, h1, h2, h3, h4, h5, h6, h7;
-  if (dev.dbg & 8u) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_ulonglong2(0, 0); h0.y = 0x1Full << PK_PRESENT_SH; }
+  if (RGB_KNOB(dev, 8u)) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_ulonglong2(0, 0); h0.y = 0x1Full << PK_PRESENT_SH; }
   else if (PRE) {     /* the wavefront fetched the lines cooperatively into LDS: pre = this lane's row */
     h0 = pre[0]; h1 = pre[1]; h2 = pre[2]; h3 = pre[3]; h4 = pre[4]; h5 = pre[5]; h6 = pre[6]; h7 = pre[7];
   } else {
     h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; h7 = hp[7];
   }
-  L.rpc_nt = (dev.dbg & 4096u) != 0;
+#ifdef RGB_PROFILE
+  L.prof_noprobe = RGB_KNOB(dev, 32u); L.prof_nloads = 0;
+#endif
   L.qry_base = dev.qry;
   L.q_loaded = false; L.q_dirty = 0; L.hb_mask = 0;
   L.qself = 0; L.hb_term = L.hb_qi = L.q_consensus = 0; L.cancel_mask = 0;
@@ -1486,9 +1525,17 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   /* leader-side kinds: fetch the peers row in the same round trip as the hot line (the address
    * only depends on the message); kinds that need it rarely load it lazily */
   if ((L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS) &&
-      !(dev.dbg & 4u))
-    load_peers<N>(L);
-  if (t_loaded && (dev.dbg & 16u)) {
+      !RGB_KNOB(dev, 64u)) {
+    load_peers<N>(L);      /* the class kernel has pulled the row's line into the cache with the hot lines */
+  }
+#ifdef RGB_PROFILE
+  if (RGB_KNOB(dev, 64u)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { L.pmi[i] = 0; L.pni[i] = 1; L.pcs[i] = 0; }
+    L.peers_loaded = true;
+  }
+#endif
+  if (t_loaded && RGB_KNOB(dev, 16u)) {
     /* profiling: force the state round trip to complete here */
 #ifndef RGB_HOST_EMULATION
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(h0.x), "v"(h6.y) : "memory");
@@ -1497,11 +1544,20 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   }
   L.ct = h0.x; L.pk = h0.y; L.ci = h1.x; L.la = h1.y; L.li = h2.x; L.lt = h2.y; L.lwi = h3.x;
   L.lwt = h3.y; L.si = h4.x; L.st = h4.y; L.first = h5.x; L.lrs = h5.y; L.lrt = h6.x;
-  L.token = h6.y; L.macver = h7.x; L.pend = h7.y; L.vote_reqs = false;
+  L.prs = h6.y; L.prt = h7.x; L.pend = h7.y; L.vote_reqs = false;
+  /* pre-vote token and machine versions live in the cold qry row: only the election kinds use them */
+  constexpr bool TM = KIND < 0 || KIND == RGB_MSG_ELECTION_TIMEOUT || KIND == RGB_MSG_PRE_VOTE_RPC ||
+                      KIND == RGB_MSG_PRE_VOTE_RESULT;
+  u64 token0 = 0;
+  L.token = 0; L.macver = 0;
+  if (TM && (L.kind == RGB_MSG_ELECTION_TIMEOUT || L.kind == RGB_MSG_PRE_VOTE_RPC || L.kind == RGB_MSG_PRE_VOTE_RESULT)) {
+    const ulonglong2 tm = *reinterpret_cast<const ulonglong2 *>(qry_row(L) + QRY_TOKEN);
+    L.token = token0 = tm.x; L.macver = tm.y;
+  }
   L.flags = 0; L.inv = 0; L.has_reply = false; L.reply_to = RGB_NONE;
   L.r_term = L.r_next = L.r_last = L.r_lterm = 0; L.w_first = L.w_last = 0;
   L.n_runs = (unsigned)pk_get(L.pk, PK_NRUNS_SH, 5);
-  L.push_cnt = 0; L.ps0 = L.pt0 = 0;
+  L.push_cnt = 0;
   L.cond_dirty = false; L.cr0 = L.cr1 = L.cr2 = L.cr3 = 0;
 
   const unsigned role0 = role_of(L);
@@ -1534,7 +1590,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   }
 
   /* ---- commit: run table ---- */
-  if (dev.dbg & 1u) { L.n_runs = n_runs0; L.push_cnt = 0; L.cond_dirty = false; L.dmi = L.dni = L.dcs = 0; L.dcs_ci = 0; }
+  if (RGB_KNOB(dev, 1u)) { L.n_runs = n_runs0; L.push_cnt = 0; L.cond_dirty = false; L.dmi = L.dni = L.dcs = 0; L.dcs_ci = 0; }
   if (L.n_runs != n_runs0 || L.push_cnt) {
     u64 *runs = const_cast<u64 *>(L.runs);
     unsigned nr = L.n_runs;
@@ -1550,24 +1606,23 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
       L.flags |= RGB_F_RUNS_OVERFLOW;
       /* new first index = start of the new oldest run */
       u64 nf;
-      if (L.push_cnt >= nr) nf = (L.push_cnt == 2 && nr == 2) ? L.ps0 : L.lrs;
+      if (L.push_cnt >= nr) nf = (L.push_cnt == 2 && nr == 2) ? L.prs : L.lrs;
       else nf = runs[0];
       L.first = nf;
       L.n_runs = nr;
     }
-    if (L.push_cnt == 2) { runs[2 * (nr - 2)] = L.ps0; runs[2 * (nr - 2) + 1] = L.pt0; }
+    if (L.push_cnt == 2) { runs[2 * (nr - 2)] = L.prs; runs[2 * (nr - 2) + 1] = L.prt; }
     if (L.push_cnt >= 1) { runs[2 * (nr - 1)] = L.lrs; runs[2 * (nr - 1) + 1] = L.lrt; }
   }
   L.pk = pk_set(L.pk, PK_NRUNS_SH, 5, L.n_runs);
-  const int wt = (dev.dbg & 32u) ? 1 : (dev.dbg & 1024u) ? 2 : 0;
   if (L.cond_dirty) {
     ulonglong2 *cp = reinterpret_cast<ulonglong2 *>(dev.cond + (size_t)L.server * 4);
-    ST16(cp, make_ulonglong2(L.cr0, L.cr1), wt);
-    ST16(cp + 1, make_ulonglong2(L.cr2, L.cr3), wt);
+    ST16(cp, make_ulonglong2(L.cr0, L.cr1));
+    ST16(cp + 1, make_ulonglong2(L.cr2, L.cr3));
   }
   /* ---- commit: query row (rare) ---- */
   const bool q_reset = pk_get(h0.y, PK_QPEER_SH, 1) && !pk_get(L.pk, PK_QPEER_SH, 1);
-  if ((L.q_dirty || q_reset) && !(dev.dbg & 1u)) {
+  if ((L.q_dirty || q_reset) && !RGB_KNOB(dev, 1u)) {
     u64 *q = qry_row(L);
     if (L.q_dirty & 1u) q[0] = L.qself;
 #pragma unroll
@@ -1578,34 +1633,25 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (L.dmi | L.dni | L.dcs | L.dcs_ci) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      if (L.dmi & (1u << k)) ST8(L.peers + k, L.pmi[k], wt);
-      if (L.dni & (1u << k)) ST8(L.peers + N + k, L.pni[k], wt);
-      if (L.dcs & (1u << k)) ST8(L.peers + 2 * N + k, L.pcs[k], wt);
-      else if (L.dcs_ci & (1u << k)) ST8(L.peers + 2 * N + k, L.ci, wt);
+      if (L.dmi & (1u << k)) ST8(L.peers + k, L.pmi[k]);
+      if (L.dni & (1u << k)) ST8(L.peers + N + k, L.pni[k]);
+      if (L.dcs & (1u << k)) ST8(L.peers + 2 * N + k, L.pcs[k]);
+      else if (L.dcs_ci & (1u << k)) ST8(L.peers + 2 * N + k, L.ci);
     }
   }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
-  const bool hot_dirty = L.ct != h0.x || L.pk != h0.y || L.ci != h1.x || L.la != h1.y || L.li != h2.x ||
-                         L.lt != h2.y || L.lwi != h3.x || L.lwt != h3.y || L.si != h4.x || L.st != h4.y ||
-                         L.first != h5.x || L.lrs != h5.y || L.lrt != h6.x || L.token != h6.y ||
-                         L.pend != h7.y;
-  if ((dev.dbg & 64u) && hot_dirty && !(dev.dbg & 1u)) {
-    /* experiment: rewrite the whole 128-byte line (no partial-line read-modify-write at memory) */
-    ho[0] = make_ulonglong2(L.ct, L.pk); ho[1] = make_ulonglong2(L.ci, L.la);
-    ho[2] = make_ulonglong2(L.li, L.lt); ho[3] = make_ulonglong2(L.lwi, L.lwt);
-    ho[4] = make_ulonglong2(L.si, L.st); ho[5] = make_ulonglong2(L.first, L.lrs);
-    ho[6] = make_ulonglong2(L.lrt, L.token); ho[7] = make_ulonglong2(L.macver, L.pend);
-  } else
-  if (!(dev.dbg & 1u)) {
-  if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk), wt);
-  if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la), wt);
-  if (L.li != h2.x || L.lt != h2.y) ST16(ho + 2, make_ulonglong2(L.li, L.lt), wt);
-  if (L.lwi != h3.x || L.lwt != h3.y) ST16(ho + 3, make_ulonglong2(L.lwi, L.lwt), wt);
-  if (L.si != h4.x || L.st != h4.y) ST16(ho + 4, make_ulonglong2(L.si, L.st), wt);
-  if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs), wt);
-  if (L.lrt != h6.x || L.token != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.token), wt);
-  if (L.pend != h7.y) ST16(ho + 7, make_ulonglong2(L.macver, L.pend), wt);
+  if (!RGB_KNOB(dev, 1u)) {
+  if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
+  if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la));
+  if (L.li != h2.x || L.lt != h2.y) ST16(ho + 2, make_ulonglong2(L.li, L.lt));
+  if (L.lwi != h3.x || L.lwt != h3.y) ST16(ho + 3, make_ulonglong2(L.lwi, L.lwt));
+  if (L.si != h4.x || L.st != h4.y) ST16(ho + 4, make_ulonglong2(L.si, L.st));
+  if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs));
+  if (L.n_runs < 2) { L.prs = 0; L.prt = 0; }         /* canonical: no run n-2 */
+  if (L.lrt != h6.x || L.prs != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.prs));
+  if (L.prt != h7.x || L.pend != h7.y) ST16(ho + 7, make_ulonglong2(L.prt, L.pend));
+  if (TM && L.token != token0) ST8(qry_row(L) + QRY_TOKEN, L.token);
   }
 
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
@@ -1615,6 +1661,9 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (L.flags & RGB_F_QUERY_QUORUM) w3 = L.q_consensus;
   make_decision(out, L.server, role_of(L), L.has_reply ? L.reply_to : (unsigned)RGB_NONE, n_rpcs, L.kind,
                 L.flags, 0, w2, w3, w4, w5, L.ci, L.la, L.hb_mask, L.cancel_mask);
+#ifdef RGB_PROFILE
+  if (t_loaded) t_loaded[1] = L.prof_nloads;
+#endif
 }
 
 /* The tick kernel: one lane per message, one wavefront per 64 consecutive messages.  Messages
@@ -1640,13 +1689,21 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
   }
   const u32 cnt = n - base < RGB_TICK_BLOCK ? n - base : RGB_TICK_BLOCK;
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
+  {
+    const u32 last = cnt * 4u - 1u;                       /* four wave loads in flight; see the class kernel */
+    ulonglong2 v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const u32 piece = k * RGB_TICK_BLOCK + lane;          /* 16-byte piece of the 64-message block */
-    const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) io[j * RGB_IO_SLOT + part] = ld16<true>(src + piece);
+    for (int k = 0; k < 4; ++k) {
+      const u32 piece = k * RGB_TICK_BLOCK + lane;        /* 16-byte piece of the 64-message block */
+      v[k] = ld16<true>(src + (piece < last ? piece : last));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 piece = k * RGB_TICK_BLOCK + lane;
+      io[(piece >> 2) * RGB_IO_SLOT + (piece & 3u)] = v[k];
+    }
   }
-  __syncthreads();
+  lds_barrier();
   const bool active = lane < cnt;
   Dec d;
   if (active) {
@@ -1658,8 +1715,8 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
     io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
     io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
   }
-  __syncthreads();
-  if (dev.dbg & 2u) return;
+  lds_barrier();
+  if (RGB_KNOB(dev, 2u)) return;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -1676,84 +1733,122 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
  * four wavefronts per SIMD stay resident, against two for the kind-generic kernel).  One class per
  * message kind, in family order.  Blocks are handed to classes heaviest-first (pipelining kinds,
  * elections, replies, then the cheap append_entries_rpc / written bulk) so the long paths start
- * on an idle memory system and finish under the cover of the bulk.  Class sizes come by value
- * (host-known) or from device memory (device-side producers). */
-struct rgb_class_counts { u32 n[RGB_N_CLASSES]; };
+ * on an idle memory system and finish under the cover of the bulk.
+ *
+ * The block -> (class, slice) map is a PLAN: 15 cumulative block counts in heaviest-first order plus the
+ * class offsets and sizes.  The host builds it when it knows the class sizes (it travels in the kernel
+ * arguments: the lookup is 14 scalar compares and three scalar loads); for device-produced ticks the
+ * kernel derives the same plan from the per-family totals in device memory. */
+struct rgb_tick_plan {
+  u32 blk_end[RGB_N_CLASSES];   /* blocks of positions 0..q, cumulative            */
+  u32 off[RGB_N_CLASSES];       /* first message of the class at position q         */
+  u32 cnt[RGB_N_CLASSES];       /* messages of the class at position q              */
+};
 
-/* PART selects the classes a launch serves: 0 = all of them (the production launch); 1 = the bulk
- * (append_entries_rpc, append_entries_reply, written) and 2 = every other class, for the experimental
- * two-launch tick (RGB_DEBUG 8192 / 16384): the bulk keeps the 128-VGPR, four-wavefront budget, the long
- * pipelining / election paths get 256 VGPRs (two wavefronts per SIMD).  The parts touch disjoint
- * servers (at most one message per server per tick), so the two launches need no ordering. */
-template <int PART> __host__ __device__ constexpr bool rgb_class_in_part(int c) {
-  return PART == 0 || (PART == 1) == (c <= 2);
-}
+/* heaviest classes first (ranks: 3 append, 4 pipeline_rpcs, 9 pre_vote_rpc, 8 election_timeout,
+ * 10 pre_vote_result, 6 vote_result, 5 request_vote, 7 await_timeout, 11 snapshot_written,
+ * 14 consistent_query, 13 heartbeat_reply, 12 heartbeat_rpc, 1 append_entries_reply,
+ * 0 append_entries_rpc, 2 written), 4 bits per position */
+#define RGB_CLASS_ORDER 0x201CDEB756A8943ull
+__host__ __device__ constexpr int rgb_class_at(unsigned q) { return (int)((RGB_CLASS_ORDER >> (4u * q)) & 0xFu); }
+static_assert(rgb_class_at(0) == 3 && rgb_class_at(1) == 4 && rgb_class_at(2) == 9 && rgb_class_at(3) == 8 &&
+              rgb_class_at(4) == 10 && rgb_class_at(5) == 6 && rgb_class_at(6) == 5 && rgb_class_at(7) == 7 &&
+              rgb_class_at(8) == 11 && rgb_class_at(9) == 14 && rgb_class_at(10) == 13 && rgb_class_at(11) == 12 &&
+              rgb_class_at(12) == 1 && rgb_class_at(13) == 0 && rgb_class_at(14) == 2, "class order");
 
-template <int N, int PART = 0>
-__global__ __launch_bounds__(RGB_TICK_BLOCK, PART == 2 ? 2 : RGB_CLASS_MIN_WAVES(N)) void rgb_tick_classes_kernel(
-    rgb_dev dev, const rgb_msg *__restrict__ msgs, rgb_class_counts cc, const u32 *__restrict__ fam_dev,
-    rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base, u32 msg_index_base) {
-  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];   /* records (5 per slot), then hot rows (9 per slot) */
-  if (fam_dev != nullptr) {
-    /* per-family totals written by a device-side producer (2 families per class) */
-#pragma unroll
-    for (int c = 0; c < RGB_N_CLASSES; ++c) cc.n[c] = fam_dev[2 * c] + fam_dev[2 * c + 1];
-  }
-  /* block -> class, heaviest classes first (ranks: 3 append, 4 pipeline_rpcs, 9 pre_vote_rpc,
-   * 8 election_timeout, 10 pre_vote_result, 6 vote_result, 5 request_vote, 7 await_timeout,
-   * 11 snapshot_written, 14 consistent_query, 13 heartbeat_reply, 12 heartbeat_rpc,
-   * 1 append_entries_reply, 0 append_entries_rpc, 2 written) */
-  constexpr int order[RGB_N_CLASSES] = {3, 4, 9, 8, 10, 6, 5, 7, 11, 14, 13, 12, 1, 0, 2};
-  u32 blk = blockIdx.x;
-  int cls = -1;
+/* n[c] = messages of class c (family order in memory) */
+__host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLASSES], rgb_tick_plan &p) {
+  u32 blocks = 0;
 #pragma unroll
   for (int q = 0; q < RGB_N_CLASSES; ++q) {
-    const int c = order[q];
-    if (!rgb_class_in_part<PART>(c)) continue;
-    const u32 nb = (cc.n[c] + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
-    if (cls < 0) {
-      if (blk < nb) cls = c;
-      else blk -= nb;
-    }
+    const int c = rgb_class_at((unsigned)q);
+    u32 off = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < RGB_N_CLASSES; ++k) { off += k < c ? n[k] : 0u; cnt = k == c ? n[k] : cnt; }
+    blocks += (cnt + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
+    p.blk_end[q] = blocks; p.off[q] = off; p.cnt[q] = cnt;
   }
-  if (cls < 0) return;
-  u32 off = 0;                                            /* memory offset of the class: family order */
+}
+
+template <int N>
+__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_tick_classes_kernel(
+    rgb_dev dev, const rgb_msg *__restrict__ msgs, rgb_tick_plan plan, const u32 *__restrict__ fam_dev,
+    rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base, u32 msg_index_base) {
+  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];   /* records (5 per slot), then hot rows (9 per slot) */
+  const u32 blk_id = blockIdx.x;
+  u32 q = 0, off, ncls, blk;
+  if (fam_dev != nullptr) {
+    /* per-family totals written by a device-side producer (2 families per class) */
+    u32 n[RGB_N_CLASSES];
 #pragma unroll
-  for (int c = 0; c < RGB_N_CLASSES; ++c) off += c < cls ? cc.n[c] : 0u;
-  u32 ncls = 0;
+    for (int c = 0; c < RGB_N_CLASSES; ++c) n[c] = fam_dev[2 * c] + fam_dev[2 * c + 1];
+    rgb_tick_plan p;
+    rgb_make_plan(n, p);
+    if (blk_id >= p.blk_end[RGB_N_CLASSES - 1]) return;
+    off = p.off[0]; ncls = p.cnt[0]; blk = blk_id;
 #pragma unroll
-  for (int c = 0; c < RGB_N_CLASSES; ++c) ncls = c == cls ? cc.n[c] : ncls;
+    for (int i = 1; i < RGB_N_CLASSES; ++i)
+      if (blk_id >= p.blk_end[i - 1]) { q = (u32)i; off = p.off[i]; ncls = p.cnt[i]; blk = blk_id - p.blk_end[i - 1]; }
+  } else {
+    if (blk_id >= plan.blk_end[RGB_N_CLASSES - 1]) return;
+#pragma unroll
+    for (int i = 0; i < RGB_N_CLASSES - 1; ++i) q += blk_id >= plan.blk_end[i] ? 1u : 0u;
+    off = plan.off[q]; ncls = plan.cnt[q];
+    blk = blk_id - (q ? plan.blk_end[q - 1] : 0u);
+  }
+  const int cls = rgb_class_at(q);
   const u32 lane = threadIdx.x;
-  u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl = 0;
-  if (dev.dbg & 16u) t0 = wall_clock64();
+#ifdef RGB_PROFILE
+  u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl[2] = {0, 0};
+  if (RGB_KNOB(dev, 16u)) t0 = wall_clock64();
+#endif
   const u32 base = off + blk * RGB_TICK_BLOCK;            /* first message of this wavefront */
   const u32 end = off + ncls;
   const u32 cnt = end - base < RGB_TICK_BLOCK ? end - base : RGB_TICK_BLOCK;
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
+  {
+    /* four coalesced 1 KiB wave loads in flight at once (read once: non-temporal); pieces past the
+     * slice's end re-read its last piece, their LDS slots are never consumed */
+    const u32 last = cnt * 4u - 1u;
+    ulonglong2 v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const u32 piece = k * RGB_TICK_BLOCK + lane;
-    const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) io[j * RGB_IO_SLOT + part] = (dev.dbg & 2048u) ? src[piece] : ld16<true>(src + piece);   /* read once */
+    for (int k = 0; k < 4; ++k) {
+      const u32 piece = k * RGB_TICK_BLOCK + lane;
+      v[k] = ld16<true>(src + (piece < last ? piece : last));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 piece = k * RGB_TICK_BLOCK + lane;
+      io[(piece >> 2) * RGB_IO_SLOT + (piece & 3u)] = v[k];
+    }
   }
-  __syncthreads();
-  if (dev.dbg & 16u) t1 = wall_clock64();
+  lds_barrier();
+#ifdef RGB_PROFILE
+  if (RGB_KNOB(dev, 16u)) t1 = wall_clock64();
+#endif
   const bool active = lane < cnt;
-  ulonglong2 m0 = make_ulonglong2(0, 0), m1 = m0, m2 = m0, m3 = m0;
-  if (active) {
-    m0 = io[lane * RGB_IO_SLOT + 0]; m1 = io[lane * RGB_IO_SLOT + 1];
-    m2 = io[lane * RGB_IO_SLOT + 2]; m3 = io[lane * RGB_IO_SLOT + 3];
-  }
+  const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
+                   m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
   /* Cooperative hot-line fetch: 8 lanes read one server's 128-byte line as ONE coalesced access, so
    * an instruction touches 8 lines instead of 64 (the CU's L1 looks up one line per cycle); the lines
    * reach their owners through LDS rows that overlay the record staging area (the messages are in
-   * registers by now), and process_message reads its row from LDS piece by piece, when it needs it.
-   * Measured -3 % per tick against per-lane 16-byte gathers. */
+   * registers by now), and process_message reads its row from LDS piece by piece, when it needs it. */
   constexpr bool PRE = true;
-  __syncthreads();
+  u64 pf0 = 0, pf1 = 0;
+  const bool lead_cls = cls == 1 || cls == 3 || cls == 4;   /* append_entries_reply, append, pipeline_rpcs */
+  lds_barrier();
   {
     const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
     const u32 srv = (active && sv < dev.n_servers) ? sv : 0u;
+    /* leader-side classes: one word of the peers row is requested in the same round trip as the hot
+     * lines, so the row's line(s) are in the cache when the lane loads the row into registers (a second
+     * full-latency round trip otherwise; keeping the whole row in registers across the fetch costs
+     * spills on the pipelining paths) */
+    if (lead_cls) {
+      const u64 *pp = dev.peers + (size_t)srv * dev.peer_stride;
+      pf0 = pp[0];
+      if (3 * N > 16) pf1 = pp[16];
+    }
     ulonglong2 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1763,15 +1858,21 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, PART == 2 ? 2 : RGB_CLASS_MIN_WAVES
 #pragma unroll
     for (int k = 0; k < 8; ++k) io[(8 * k + (lane >> 3)) * RGB_HOT_SLOT + (lane & 7u)] = v[k];
   }
-  __syncthreads();
+  lds_barrier();
   const ulonglong2 *hrow = io + lane * RGB_HOT_SLOT;
+#ifndef RGB_HOST_EMULATION
+  asm volatile("" ::"v"(pf0), "v"(pf1));   /* the touch loads above stay in the program */
+#endif
   Dec d;
+  u64 *tlp = nullptr;
+#ifdef RGB_PROFILE
+  tlp = tl;
+#endif
   if (active) {
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
-    if constexpr (rgb_class_in_part<PART>(RANK))                                                        \
-      process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, &tl, \
-                                    hrow);                                                              \
+    process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
+                                  hrow);                                                                \
     break;
     switch (cls) {
       RGB_CASE(0, RGB_MSG_AER) RGB_CASE(1, RGB_MSG_AER_REPLY) RGB_CASE(2, RGB_MSG_WRITTEN)
@@ -1781,41 +1882,48 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, PART == 2 ? 2 : RGB_CLASS_MIN_WAVES
       RGB_CASE(10, RGB_MSG_PRE_VOTE_RESULT) RGB_CASE(11, RGB_MSG_SNAPSHOT_WRITTEN)
       RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
       default:
-        if constexpr (rgb_class_in_part<PART>(14))
-          process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                            msg_index_base, d, &tl, hrow);
+        process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
+                                                          msg_index_base, d, tlp, hrow);
         break;
     }
 #undef RGB_CASE
-#ifndef RGB_HOST_EMULATION
-    if (dev.dbg & 16u) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
+#if defined(RGB_PROFILE) && !defined(RGB_HOST_EMULATION)
+    if (RGB_KNOB(dev, 16u)) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
 #endif
   }
-  __syncthreads();      /* every lane is done with its hot row before the decisions overlay the rows */
+  lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
   if (active) {
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
     io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
     io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
   }
-  __syncthreads();
-  if (dev.dbg & 2u) return;
+  lds_barrier();
+  if (RGB_KNOB(dev, 2u)) return;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
-  const int wt = (dev.dbg & 32u) ? 1 : 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) {
-      /* decisions are never re-read on the device: non-temporal (measured -5 % per tick) */
-      if (dev.dbg & 128u) ST16(dst + piece, io[j * RGB_IO_SLOT + part], wt);
-      else store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+    /* decisions are never re-read on the device: non-temporal (measured -5 % per tick) */
+    if (j < cnt) store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+  }
+#ifdef RGB_PROFILE
+  if (RGB_KNOB(dev, 16u)) {
+    /* run-table words read per lane: wave maximum, sum, lanes that read any */
+    unsigned mx = (unsigned)tl[1], sm = (unsigned)tl[1], nz = tl[1] ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned a = __shfl_xor(mx, o, 64), b = __shfl_xor(sm, o, 64), c = __shfl_xor(nz, o, 64);
+      mx = a > mx ? a : mx; sm += b; nz += c;
+    }
+    if (lane == 0) {
+      u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 8;
+      o[0] = t0; o[1] = t1 | ((tl[0] - t1) << 40); o[2] = t2 | ((t2b - t2) << 40) | ((u64)cls << 60); o[3] = wall_clock64();
+      o[4] = mx; o[5] = sm; o[6] = nz; o[7] = cnt;
     }
   }
-  if ((dev.dbg & 16u) && lane == 0) {
-    u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 4;
-    o[0] = t0; o[1] = t1 | ((tl - t1) << 40); o[2] = t2 | ((t2b - t2) << 40) | ((u64)cls << 60); o[3] = wall_clock64();
-  }
+#endif
 }
 
 /* ------------------------------------------------------------ synthetic load ---- */
@@ -1836,7 +1944,17 @@ __device__ __forceinline__ u64 sm64(u64 &x) {
   return z ^ (z >> 31);
 }
 
-struct SynMember { u64 ct, ci, la, li, lt, lwi, lwt, pk, first, lrs, lrt, token; };
+struct SynMember { u64 ct, ci, la, li, lt, lwi, lwt, pk, first, lrs, lrt, prs, prt; };
+
+/* a Lane good for fetch_term against member x's log */
+__device__ __forceinline__ void syn_lane(Lane &T, const SynMember &x, const u64 *runs) {
+  T.first = x.first; T.li = x.li; T.lrs = x.lrs; T.lrt = x.lrt; T.prs = x.prs; T.prt = x.prt;
+  T.push_cnt = 0; T.n_runs = (unsigned)pk_get(x.pk, PK_NRUNS_SH, 5);
+  T.runs = runs;
+#ifdef RGB_PROFILE
+  T.prof_noprobe = false; T.prof_nloads = 0;
+#endif
+}
 
 struct SynMsg {
   u32 server; unsigned kind, from, flags, gap; u64 term, a, b, c; u32 n_entries, n_run0; u64 run0, run1;
@@ -1870,10 +1988,10 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
 #pragma unroll
   for (int m = 0; m < N; ++m) {
     const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(dev.hot + ((size_t)g * N + m) * RGB_HOT_WORDS);
-    const ulonglong2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h5 = hp[5], h6 = hp[6];
+    const ulonglong2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h5 = hp[5], h6 = hp[6], h7 = hp[7];
     mb[m].ct = h0.x; mb[m].pk = h0.y; mb[m].ci = h1.x; mb[m].la = h1.y; mb[m].li = h2.x;
     mb[m].lt = h2.y; mb[m].lwi = h3.x; mb[m].lwt = h3.y; mb[m].first = h5.x; mb[m].lrs = h5.y;
-    mb[m].lrt = h6.x; mb[m].token = h6.y;
+    mb[m].lrt = h6.x; mb[m].prs = h6.y; mb[m].prt = h7.x;
   }
 #pragma unroll
   for (int m = 0; m < N; ++m) {
@@ -1907,7 +2025,7 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
       emit(syn_msg(sid(cand), RGB_MSG_VOTE_RESULT, other(cand, r), RGB_MF_SUCCESS, mb[cand].ct, 0, 0, 0));
     } else if (prev >= 0) {
       emit(syn_msg(sid(prev), RGB_MSG_PRE_VOTE_RESULT, other(prev, r), RGB_MF_SUCCESS, mb[prev].ct, 0, 0,
-                   mb[prev].token));
+                   (dev.qry + (size_t)sid(prev) * RGB_QRY_WORDS)[QRY_TOKEN]));
     } else {
       emit(syn_msg(sid(hi), RGB_MSG_ELECTION_TIMEOUT, RGB_NONE, 0, 0, 0, 0, (r | 1ull) & 0xFFFFFFFFFFFFull));
     }
@@ -1920,7 +2038,7 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
   for (int m = 0; m < N; ++m) used[m] = false;
   /* term churn: 5 % of the groups, one member gets request_vote term+1 */
   const u64 rc = sm64(rs);
-  if (rc % 100 < 5) {
+  if (rc % 100 < 5 && !RGB_KNOB(dev, 128u)) {
     const int churn = (int)((rc >> 8) % N);
     const u64 r2 = sm64(rs);
     const u64 lli = mb[churn].li + (r2 % 3) > 0 ? mb[churn].li + (r2 % 3) - 1 : 0;
@@ -1937,8 +2055,7 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
     const unsigned nr = (unsigned)pk_get(x.pk, PK_NRUNS_SH, 5);
     if (nr < 4 || !(x.first <= x.li) || x.la < x.first || x.la > x.li) continue;
     Lane T;
-    T.first = x.first; T.li = x.li; T.lrs = x.lrs; T.lrt = x.lrt; T.push_cnt = 0; T.n_runs = nr;
-    T.runs = dev.runs + (size_t)sid(m) * dev.max_runs * 2;
+    syn_lane(T, x, dev.runs + (size_t)sid(m) * dev.max_runs * 2);
     const u64 t = fetch_term(T, x.la);
     if (t == UNDEF) continue;
     emit(syn_msg(sid(m), RGB_MSG_SNAPSHOT_WRITTEN, RGB_NONE, 0, 0, x.la, t, 0));
@@ -1974,14 +2091,13 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
     } else if ((r >> 44) % 50 == 0) {
       emit(syn_msg(sid(l), RGB_MSG_CONSISTENT_QUERY, RGB_NONE, 0, 0, 0, 0, 0));     /* 2 % */
     } else {
-      const unsigned v = (unsigned)((r >> 8) % 100);
+      unsigned v = (unsigned)((r >> 8) % 100);
+      if (RGB_KNOB(dev, 128u) && v >= 75 && v < 80) v = 0;   /* profiling: no failed replies */
       const int j = other(l, r >> 16);
       const u64 *pr = dev.peers + (size_t)sid(l) * dev.peer_stride;
       const u64 mi = pr[j];
       Lane T;                                   /* term lookups against the leader's log */
-      T.first = ld.first; T.li = ld.li; T.lrs = ld.lrs; T.lrt = ld.lrt; T.push_cnt = 0;
-      T.n_runs = (unsigned)pk_get(ld.pk, PK_NRUNS_SH, 5);
-      T.runs = dev.runs + (size_t)sid(l) * dev.max_runs * 2;
+      syn_lane(T, ld, dev.runs + (size_t)sid(l) * dev.max_runs * 2);
       if (v < 75) {
         /* what follower j has durably written (its first reply after an election jumps the
          * leader's match_index from 0 to there), else a small step past the known match */
@@ -2011,7 +2127,8 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
     if (((hb_behind >> j) & 1u) && (r >> 40) % 8 == 0) {
       emit(syn_msg(sid(j), RGB_MSG_HEARTBEAT_RPC, l, 0, ld.ct, lq, 0, 0));
     } else if ((r & 1) == 0) {
-      const unsigned v = (unsigned)((r >> 8) % 100);
+      unsigned v = (unsigned)((r >> 8) % 100);
+      if (RGB_KNOB(dev, 128u)) v = 0;                           /* profiling: tail appends only */
       const u64 eterm = ld.ct > f.lt ? ld.ct : f.lt;
       u64 prev_i = f.li, prev_t = f.lt, run0 = eterm;
       u32 n_ent = 1 + (u32)(r2 % 8);
@@ -2094,7 +2211,7 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
   u64 *runs = dev.runs + (size_t)s * dev.max_runs * 2;
   unsigned nr = 0;
   u64 first_index = h.first_index;
-  u64 lrs = 0, lrt = 0;
+  u64 lrs = 0, lrt = 0, prs = 0, prt = 0;
   if (h.first_index <= h.last_index) {
     unsigned src_n = h.n_runs > RGB_MAX_RUNS ? RGB_MAX_RUNS : h.n_runs;
     /* count canonical runs */
@@ -2108,6 +2225,7 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
       if (ci >= skip) {
         if (nr == 0 && skip) first_index = h.run_start[r];
         runs[2 * nr] = h.run_start[r]; runs[2 * nr + 1] = h.run_term[r];
+        prs = lrs; prt = lrt;
         lrs = h.run_start[r]; lrt = h.run_term[r];
         nr++;
       }
@@ -2132,8 +2250,8 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
   hot[HOT_LWI] = h.last_written_index; hot[HOT_LWT] = h.last_written_term;
   hot[HOT_PK] = pk; hot[HOT_SI] = h.snapshot_index; hot[HOT_ST] = h.snapshot_term;
   hot[HOT_FIRST] = first_index; hot[HOT_LRS] = lrs; hot[HOT_LRT] = lrt;
-  hot[HOT_TOKEN] = h.pre_vote_token;
-  hot[HOT_MACVER] = (u64)h.machine_version | ((u64)h.effective_machine_version << 32);
+  if (nr < 2) { prs = 0; prt = 0; }
+  hot[HOT_PRS] = prs; hot[HOT_PRT] = prt;
   hot[HOT_PEND] = h.pending_first;
   {
     u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
@@ -2145,6 +2263,8 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
     const unsigned backoff = (unsigned)h.backoff_mask & ~(unsigned)h.status_mask & (unsigned)h.present_mask &
                              ~(1u << h.self) & 0xFFu;
     q[QRY_BACKOFF] = backoff;
+    q[QRY_TOKEN] = h.pre_vote_token;
+    q[QRY_MACVER] = (u64)h.machine_version | ((u64)h.effective_machine_version << 32);
     pk = pk_set(pk, PK_BACKOFF_SH, 1, backoff ? 1 : 0);
     pk = pk_set(pk, PK_QSELF_SH, 1, h.query_index != 0 ? 1 : 0);
     pk = pk_set(pk, PK_QPEER_SH, 1, peer_nz ? 1 : 0);
@@ -2196,9 +2316,12 @@ __global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ ou
   h.status_mask = (uint8_t)pk_get(pk, PK_STATUS_SH, 8);
   h.self_nonvoter = (uint8_t)pk_get(pk, PK_NONVOTER_SH, 1);
   h.cond_leader = (uint8_t)slot4to8((unsigned)pk_get(pk, PK_CONDLDR_SH, 4));
-  h.pre_vote_token = hot[HOT_TOKEN];
-  h.machine_version = (uint32_t)(hot[HOT_MACVER] & 0xFFFFFFFFull);
-  h.effective_machine_version = (uint32_t)(hot[HOT_MACVER] >> 32);
+  {
+    const u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
+    h.pre_vote_token = q[QRY_TOKEN];
+    h.machine_version = (uint32_t)(q[QRY_MACVER] & 0xFFFFFFFFull);
+    h.effective_machine_version = (uint32_t)(q[QRY_MACVER] >> 32);
+  }
   h.pending_first = hot[HOT_PEND];
   {
     const u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
@@ -2269,14 +2392,14 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
               (pk_get(pk, PK_STATUS_SH, 8) << 16) | (pk_get(pk, PK_NONVOTER_SH, 1) << 24);
   if (pk_get(pk, PK_BACKOFF_SH, 1)) masks |= ((dev.qry + (size_t)s * RGB_QRY_WORDS)[QRY_BACKOFF] & 0xFFull) << 32;
   x = fnv_word(x, masks);
-  x = fnv_word(x, hot[HOT_TOKEN]);
+  x = fnv_word(x, (dev.qry + (size_t)s * RGB_QRY_WORDS)[QRY_TOKEN]);
   x = fnv_word(x, hot[HOT_PEND]);
   {
     const u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
     x = fnv_word(x, q[0]);
     for (unsigned i = 0; i < N && i < 8; ++i) x = fnv_word(x, q[1 + i]);
   }
-  x = fnv_word(x, hot[HOT_MACVER]);
+  x = fnv_word(x, (dev.qry + (size_t)s * RGB_QRY_WORDS)[QRY_MACVER]);
   const u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < N; ++i) {
     x = fnv_word(x, pr[i]); x = fnv_word(x, pr[N + i]); x = fnv_word(x, pr[2 * N + i]);
@@ -2320,66 +2443,22 @@ int rgb_launch_tick(const rgb_dev &dev, int cls, const rgb_msg *d_msgs, u32 n, c
   }
 }
 
-/* Experimental two-launch tick (RGB_DEBUG 8192: both parts on the caller's stream; 16384: the long classes
- * on a side stream forked from and joined back into the caller's stream, which also works under stream
- * capture and then yields two parallel graph branches).  Not the production path: rgb_dev.dbg is 0 there. */
-static int launch_tick_classes_split(const rgb_dev &dev, const rgb_msg *d_msgs, const rgb_class_counts &cc,
-                                     const u32 *d_family_totals, u32 all_blocks, rgb_decision *d_dec,
-                                     rgb_rpc *d_rpcs, u32 rpc_slot_base, u32 msg_index_base, hipStream_t st) {
-  static hipStream_t side = nullptr;
-  static hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-  const bool forked = (dev.dbg & 16384u) != 0;
-  if (forked && side == nullptr) {
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
-    if (hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) != hipSuccess) return -1;
-    if (hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return -1;
-  }
-  u32 nb[3] = {0, 0, 0};
-  for (int c = 0; c < RGB_N_CLASSES; ++c)
-    nb[rgb_class_in_part<1>(c) ? 1 : 2] += (cc.n[c] + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
-  if (d_family_totals) nb[1] = nb[2] = all_blocks;      /* device-side counts: surplus blocks return at once */
-  hipStream_t s2 = forked ? side : st;
-  if (forked && nb[2]) {
-    if (hipEventRecord(fork_ev, st) != hipSuccess || hipStreamWaitEvent(side, fork_ev, 0) != hipSuccess) return -1;
-  }
-  dim3 block(RGB_TICK_BLOCK);
-#define LAUNCH(NN)                                                                                       \
-  case NN:                                                                                               \
-    if (nb[2]) hipLaunchKernelGGL((rgb_tick_classes_kernel<NN, 2>), dim3(nb[2]), block, 0, s2, dev, d_msgs, cc, \
-                                  d_family_totals, d_dec, d_rpcs, rpc_slot_base, msg_index_base);         \
-    if (nb[1]) hipLaunchKernelGGL((rgb_tick_classes_kernel<NN, 1>), dim3(nb[1]), block, 0, st, dev, d_msgs, cc, \
-                                  d_family_totals, d_dec, d_rpcs, rpc_slot_base, msg_index_base);         \
-    break;
-  switch (dev.n_members) {
-    LAUNCH(3) LAUNCH(5) LAUNCH(7)         /* the measured group sizes only: an experiment, not the product path */
-    default: return -1;
-  }
-#undef LAUNCH
-  if (forked && nb[2]) {
-    if (hipEventRecord(join_ev, side) != hipSuccess || hipStreamWaitEvent(st, join_ev, 0) != hipSuccess) return -1;
-  }
-  return (int)hipGetLastError();
-}
-
 int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32 counts[RGB_N_CLASSES],
                             const u32 *d_family_totals, u32 max_msgs, rgb_decision *d_dec, rgb_rpc *d_rpcs,
                             u32 rpc_slot_base, u32 msg_index_base, void *stream) {
   hipStream_t st = (hipStream_t)stream;
-  rgb_class_counts cc;
-  u32 blocks = 0;
-  for (int c = 0; c < RGB_N_CLASSES; ++c) {
-    cc.n[c] = counts ? counts[c] : 0;
-    blocks += (cc.n[c] + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
-  }
+  u32 n[RGB_N_CLASSES];
+  for (int c = 0; c < RGB_N_CLASSES; ++c) n[c] = counts ? counts[c] : 0;
+  rgb_tick_plan plan;
+  rgb_make_plan(n, plan);
+  u32 blocks = plan.blk_end[RGB_N_CLASSES - 1];
+  /* device-side counts: enough blocks for any split of max_msgs into classes; surplus blocks return at once */
   if (d_family_totals) blocks = (max_msgs + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK + RGB_N_CLASSES;
   if (blocks == 0) return 0;
-  if (dev.dbg & (8192u | 16384u))
-    return launch_tick_classes_split(dev, d_msgs, cc, d_family_totals, blocks, d_dec, d_rpcs, rpc_slot_base,
-                                     msg_index_base, st);
   dim3 grid(blocks), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                                     \
   case NN:                                                                                             \
-    hipLaunchKernelGGL(rgb_tick_classes_kernel<NN>, grid, block, 0, st, dev, d_msgs, cc, d_family_totals, \
+    hipLaunchKernelGGL(rgb_tick_classes_kernel<NN>, grid, block, 0, st, dev, d_msgs, plan, d_family_totals, \
                        d_dec, d_rpcs, rpc_slot_base, msg_index_base);                                  \
     break;
   switch (dev.n_members) {

@@ -44,13 +44,3 @@ def test_closed_loop_stream_through_the_c_abi(emulated_engine, oracle_lib):
     import test_cluster_safety as CS
     # the GPU test builds its own engine from ra_amd.engine, which is bound to the emulated library here
     CS.test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, 5, 14, True)
-
-
-@pytest.mark.parametrize("knob", [8192, 16384])
-def test_two_launch_tick_gives_the_same_decisions(emulated_engine, oracle_lib, monkeypatch, knob):
-    """The experimental split of the class-dispatch kernel (RGB_DEBUG 8192 / 16384: bulk classes and long
-    classes as two launches, rgb_tick_classes_kernel<N, 1> and <N, 2>) must decide exactly what the single
-    launch decides: the same >= 4096-message rounds against the checker."""
-    monkeypatch.setenv("RGB_DEBUG", str(knob))
-    G.test_hip_equals_oracle_on_random_ticks(emulated_engine, oracle_lib, 5, 107, 1300)
-    G.test_hip_equals_oracle_on_random_ticks(emulated_engine, oracle_lib, 7, 108, 800)

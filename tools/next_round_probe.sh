@@ -25,3 +25,11 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/r02a/prof" -- \
     python "$GRAFT_REPO_ROOT/bench.py" --steps 400 --warmup 32 --no-cpu-baseline --no-host-path --check-ticks 0 \
     > "$GRAFT_REPO_ROOT/gpurun_out/r02a/prof.log" 2>&1
+cd "$GRAFT_REPO_ROOT"
+# 4. per-class wave timeline at steady state (400 generator ticks) and the SQ counter set for profiles/
+TL_TICKS=400 timeout 300 python tools/wave_timeline.py > gpurun_out/r02a/wave_timeline.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+CMDS="python $GRAFT_REPO_ROOT/bench.py --steps 48 --warmup 400 --no-cpu-baseline --no-host-path --check-ticks 0 --no-graph"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r02a/sq1" -o p -- $CMDS > "$GRAFT_REPO_ROOT/gpurun_out/r02a/sq1.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r02a/pmc_fetch" -o p -- $CMDS > "$GRAFT_REPO_ROOT/gpurun_out/r02a/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r02a/pmc_write" -o p -- $CMDS > "$GRAFT_REPO_ROOT/gpurun_out/r02a/pmc_write.log" 2>&1

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""RGB_DEBUG=16: per-wave timestamps of one class-dispatch tick -> concurrency picture."""
+"""RGB_DEBUG=16 on the profiling build (make -C ra_amd/csrc prof): per-wave timestamps of one class-dispatch
+tick -> concurrency picture."""
 import os, sys, ctypes as C
 os.environ["RGB_DEBUG"] = "16"
+os.environ.setdefault("RGB_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                              "ra_amd", "csrc", "libra_gpu_batch_prof.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ra_amd import abi, engine, workload as W
-G, N = 65536, 5
+G, N = int(os.environ.get('TL_GROUPS', '65536')), 5
 S = G * N
 eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
 eng.set_state(0, W.initial_states(G, N, 0x5EED0003))
@@ -19,12 +22,12 @@ for t in range(int(os.environ.get("TL_TICKS", "24"))):
     eng.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), sp)
     torch.cuda.synchronize()
 nblk = S // 64 + 16
-buf = np.zeros(nblk * 4, dtype=np.uint64)
+buf = np.zeros(nblk * 8, dtype=np.uint64)
 L = engine.lib(); L.rgb_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 assert L.rgb_debug_read(eng._h, buf.ctypes.data, len(buf)) == 0
-b = buf.reshape(nblk, 4)
+b = buf.reshape(nblk, 8)
 b = b[b[:, 0] > 0]
-b = b[b[:, 0].astype(np.int64) > b[:, 0].astype(np.int64).max() - 20000]   # the last launch only (200 us window)
+b = b[b[:, 0].astype(np.int64) > b[:, 0].astype(np.int64).max() - 5000]   # the last launch only (50 us window)
 cls = (b[:, 2] >> np.uint64(60)).astype(int)
 M40 = np.uint64((1 << 40) - 1)
 t0 = b[:, 0].astype(np.int64); t1 = (b[:, 1] & M40).astype(np.int64); dl = (b[:, 1] >> np.uint64(40)).astype(np.int64)
@@ -39,6 +42,11 @@ for c in range(12):
     print(f"class {c}: waves {m.sum():5d} start {((t0[m]-z).min()*tick/1e3):6.1f}..{((t0[m]-z).max()*tick/1e3):6.1f} us | "
           f"msg-load {np.median(t1[m]-t0[m])*tick/1e3:5.2f} | state-load {np.median(dl[m])*tick/1e3:5.2f} | store-drain {np.median(dst[m])*tick/1e3:5.2f} | process {np.median(t2[m]-t1[m])*tick/1e3:5.2f} (p90 {np.percentile(t2[m]-t1[m],90)*tick/1e3:5.2f}) | "
           f"dec-store {np.median(t3[m]-t2[m])*tick/1e3:5.2f} | wave life {np.median(t3[m]-t0[m])*tick/1e3:5.2f} us")
+    mx, sm, nz, cn = b[m, 4].astype(int), b[m, 5].astype(int), b[m, 6].astype(int), b[m, 7].astype(int)
+    print(f"          run-table words read: lanes reading {nz.sum()}/{cn.sum()} ({100.0*nz.sum()/max(cn.sum(),1):.1f} %), per reading lane {sm.sum()/max(nz.sum(),1):.1f}, "
+          f"waves with a reader {100.0*(nz>0).mean():.0f} %, wave max p50/p90/max {np.percentile(mx,50):.0f}/{np.percentile(mx,90):.0f}/{mx.max()}; "
+          f"wave life by wave-max words 0/1-2/3-6/7+: " + "/".join(
+              f"{np.median((t3[m]-t0[m])[sel])*tick/1e3:.1f}" if sel.any() else "-" for sel in (mx == 0, (mx >= 1) & (mx <= 2), (mx >= 3) & (mx <= 6), mx >= 7)))
 # concurrency over time
 ev = np.concatenate([np.stack([t0 - z, np.ones_like(t0)], 1), np.stack([t3 - z, -np.ones_like(t3)], 1)])
 ev = ev[np.argsort(ev[:, 0], kind="stable")]
