@@ -222,8 +222,17 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
     HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
   }
 #endif
+#if defined(RGB_X_STATE_MEM) && RGB_X_STATE_MEM
+  /* experiment (tools/build_variants.sh): the two hot state arrays in fine-grained (1) / uncached (2) memory */
+  {
+    const unsigned fl = RGB_X_STATE_MEM == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached;
+    HIPCHK(ctx, hipExtMallocWithFlags((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64), fl));
+    HIPCHK(ctx, hipExtMallocWithFlags((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64), fl));
+  }
+#else
   HIPCHK(ctx, hipMalloc((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));
+#endif
   HIPCHK(ctx, hipMalloc((void **)&d.runs, (size_t)S * d.max_runs * 2 * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.cond, (size_t)S * 4 * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.qry, (size_t)S * RGB_QRY_WORDS * sizeof(u64)));

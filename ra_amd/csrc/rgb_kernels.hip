@@ -59,6 +59,82 @@ __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
 #define ST16(ptr, val) do { *(ptr) = (val); } while (0)
 #define ST8(ptr, val) do { *(ptr) = (val); } while (0)
 
+/* 16-byte / 8-byte stores with an explicit cache policy: POL 0 plain (write-back L2), 1 non-temporal,
+ * 2 system-scope write-through (sc0 sc1).  The 16-byte form takes any 4-byte aligned address. */
+template <int POL>
+__device__ __forceinline__ void store16_pol(void *p, ulonglong2 v) {
+#ifndef RGB_HOST_EMULATION
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u d;
+  d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
+  if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+  else if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(d) : "memory");
+#else
+  memcpy(p, &v, 16);
+#endif
+}
+template <int POL>
+__device__ __forceinline__ void store8_pol(void *p, u64 v) {
+#ifndef RGB_HOST_EMULATION
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  v2u d;
+  d.x = (unsigned)v; d.y = (unsigned)(v >> 32);
+  if (POL == 1) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
+  else if (POL == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(d) : "memory");
+#else
+  memcpy(p, &v, 8);
+#endif
+}
+
+/* experiment switches (compile time; the defaults are the product): see tools/build_variants.sh
+ *   RGB_X_COOPWB  0 = each lane stores its dirty 16-byte pieces; 1/2/3 = dirty pieces go to the lane's LDS row and
+ *                 the wavefront writes whole dirty 128-byte lines back cooperatively (policy 0/1/2 = value - 1)
+ *   RGB_X_RPC16   0 = seven 8-byte stores per rpc record; 1/2/3 = 16+16+16+8-byte stores, policy value - 1
+ *   RGB_X_PEERS   peers-row word stores: policy 0/1/2 */
+#ifndef RGB_X_COOPWB
+#define RGB_X_COOPWB 0
+#endif
+#ifndef RGB_X_RPC16
+#define RGB_X_RPC16 0
+#endif
+#ifndef RGB_X_HOTNT
+#define RGB_X_HOTNT 0      /* 1 = the cooperative hot-line fetch uses non-temporal loads */
+#endif
+#ifndef RGB_X_REREAD
+#define RGB_X_REREAD 0     /* with RGB_X_COOPWB: compare against the LDS row at commit instead of the first read */
+#endif
+#ifndef RGB_X_PEERS
+#define RGB_X_PEERS 0
+#endif
+
+#if RGB_X_PEERS
+#define PEER_ST8(ptr, val) store8_pol<RGB_X_PEERS>((ptr), (val))
+#else
+#define PEER_ST8(ptr, val) ST8(ptr, val)
+#endif
+
+/* -DRGB_X_MARK: comment markers around every class path in the assembly (tools/class_isa.py counts per class) */
+#if defined(RGB_X_MARK) && !defined(RGB_HOST_EMULATION)
+#define RGB_MARK(what, rank) asm volatile("; RGB_MARK " what " %0" ::"n"(rank));
+#else
+#define RGB_MARK(what, rank)
+#endif
+
+/* one outbound rpc record (56 B, layout of rgb_rpc) */
+__device__ __forceinline__ void store_rpc(rgb_rpc *slot, u64 w0, u64 w1, u64 w2, u64 w3, u64 w4, u64 w5, u64 w6) {
+  u64 *o = reinterpret_cast<u64 *>(slot);
+#if RGB_X_RPC16
+  store16_pol<RGB_X_RPC16 - 1>(o + 0, make_ulonglong2(w0, w1));
+  store16_pol<RGB_X_RPC16 - 1>(o + 2, make_ulonglong2(w2, w3));
+  store16_pol<RGB_X_RPC16 - 1>(o + 4, make_ulonglong2(w4, w5));
+  store8_pol<RGB_X_RPC16 - 1>(o + 6, w6);
+#else
+  ST8(o + 0, w0); ST8(o + 1, w1); ST8(o + 2, w2); ST8(o + 3, w3); ST8(o + 4, w4); ST8(o + 5, w5); ST8(o + 6, w6);
+#endif
+}
+
 /* workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global
  * store (vmcnt(0)), which put the state write-back's acknowledgement on the decision store's path */
 __device__ __forceinline__ void lds_barrier() {
@@ -761,11 +837,10 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
        * VGPRs fewer across the loop for N = 5) */
       L.dcs_ci |= 1u << i;
       if (rpcs != nullptr) {
-        /* fixed slot: this message's (n_out-1)-th record; 56 B = 7 x 8-B stores */
-        u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
-        ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
-        ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
-        ST8(o + 2, L.ct); ST8(o + 3, rp_idx); ST8(o + 4, rp_term); ST8(o + 5, L.ci); ST8(o + 6, new_ni);
+        /* fixed slot: this message's (n_out-1)-th record */
+        store_rpc(rpcs + (size_t)slot_base + (n_out - 1), (u64)msg_index | ((u64)L.server << 32),
+                  (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16), L.ct, rp_idx, rp_term, L.ci,
+                  new_ni);
       }
     }
   }
@@ -903,10 +978,9 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
     }
     n_out += 1;
     if (rpcs != nullptr) {
-      u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
-      ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
-      ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
-      ST8(o + 2, L.ct); ST8(o + 3, rp_idx); ST8(o + 4, rp_term); ST8(o + 5, L.ci); ST8(o + 6, new_ni);
+      store_rpc(rpcs + (size_t)slot_base + (n_out - 1), (u64)msg_index | ((u64)L.server << 32),
+                (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16), L.ct, rp_idx, rp_term, L.ci,
+                new_ni);
     }
   }
   return 0;
@@ -1476,7 +1550,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
                                                 u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr,
-                                                const ulonglong2 *pre = nullptr) {
+                                                const ulonglong2 *pre = nullptr, unsigned *row_dirty = nullptr) {
   Lane L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -1633,14 +1707,35 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (L.dmi | L.dni | L.dcs | L.dcs_ci) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      if (L.dmi & (1u << k)) ST8(L.peers + k, L.pmi[k]);
-      if (L.dni & (1u << k)) ST8(L.peers + N + k, L.pni[k]);
-      if (L.dcs & (1u << k)) ST8(L.peers + 2 * N + k, L.pcs[k]);
-      else if (L.dcs_ci & (1u << k)) ST8(L.peers + 2 * N + k, L.ci);
+      if (L.dmi & (1u << k)) PEER_ST8(L.peers + k, L.pmi[k]);
+      if (L.dni & (1u << k)) PEER_ST8(L.peers + N + k, L.pni[k]);
+      if (L.dcs & (1u << k)) PEER_ST8(L.peers + 2 * N + k, L.pcs[k]);
+      else if (L.dcs_ci & (1u << k)) PEER_ST8(L.peers + 2 * N + k, L.ci);
     }
   }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
+#if RGB_X_COOPWB
+  if (PRE && row_dirty != nullptr) {
+    /* the class kernel writes whole dirty lines back cooperatively: the changed pieces go to this lane's LDS row */
+    ulonglong2 *row = const_cast<ulonglong2 *>(pre);
+#if !defined(RGB_HOST_EMULATION) && RGB_X_REREAD
+    asm volatile("" : "+v"(row));      /* the originals are re-read from the row: h0..h7 need not stay in registers */
+#endif
+    unsigned dirty = 0;
+    if (L.n_runs < 2) { L.prs = 0; L.prt = 0; }         /* canonical: no run n-2 */
+#if RGB_X_REREAD
+#define RGB_WB(K, A, B) { const ulonglong2 o = row[K]; if ((A) != o.x || (B) != o.y) { row[K] = make_ulonglong2((A), (B)); dirty = 1; } }
+#else
+#define RGB_WB(K, A, B) { if ((A) != h##K.x || (B) != h##K.y) { row[K] = make_ulonglong2((A), (B)); dirty = 1; } }
+#endif
+    RGB_WB(0, L.ct, L.pk) RGB_WB(1, L.ci, L.la) RGB_WB(2, L.li, L.lt) RGB_WB(3, L.lwi, L.lwt)
+    RGB_WB(4, L.si, L.st) RGB_WB(5, L.first, L.lrs) RGB_WB(6, L.lrt, L.prs) RGB_WB(7, L.prt, L.pend)
+#undef RGB_WB
+    if (TM && L.token != token0) ST8(qry_row(L) + QRY_TOKEN, L.token);
+    *row_dirty = dirty;
+  } else
+#endif
   if (!RGB_KNOB(dev, 1u)) {
   if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
   if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la));
@@ -1853,7 +1948,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const u32 sj = __shfl(srv, 8 * k + (int)(lane >> 3), 64);
-      v[k] = reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS)[lane & 7u];
+      v[k] = ld16<(RGB_X_HOTNT != 0)>(reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS) + (lane & 7u));
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) io[(8 * k + (lane >> 3)) * RGB_HOT_SLOT + (lane & 7u)] = v[k];
@@ -1868,11 +1963,18 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #ifdef RGB_PROFILE
   tlp = tl;
 #endif
+  unsigned *rdp = nullptr;
+#if RGB_X_COOPWB
+  unsigned row_dirty = 0;
+  rdp = &row_dirty;
+#endif
   if (active) {
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
+    RGB_MARK("begin", RANK)                                                                             \
     process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
-                                  hrow);                                                                \
+                                  hrow, rdp);                                                           \
+    RGB_MARK("end", RANK)                                                                               \
     break;
     switch (cls) {
       RGB_CASE(0, RGB_MSG_AER) RGB_CASE(1, RGB_MSG_AER_REPLY) RGB_CASE(2, RGB_MSG_WRITTEN)
@@ -1883,7 +1985,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
       default:
         process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                          msg_index_base, d, tlp, hrow);
+                                                          msg_index_base, d, tlp, hrow, rdp);
         break;
     }
 #undef RGB_CASE
@@ -1892,6 +1994,25 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #endif
   }
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
+#if RGB_X_COOPWB
+  {
+    /* cooperative write-back: 8 lanes store one dirty server's whole 128-byte line (full-line writes, 8 lines
+     * per instruction), the mirror image of the fetch */
+    const unsigned long long dm = __ballot(row_dirty != 0);
+    const u32 sv = (u32)(d.w[0] & 0xFFFFFFFFull);   /* the decision's first word carries the server id */
+    if (dm != 0ull && !RGB_KNOB(dev, 1u)) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u32 r = 8 * k + (lane >> 3);
+        const u32 sj = __shfl(sv, (int)r, 64);
+        if ((dm >> r) & 1ull)
+          store16_pol<RGB_X_COOPWB - 1>(dev.hot + (size_t)sj * RGB_HOT_WORDS + 2u * (lane & 7u),
+                                        io[r * RGB_HOT_SLOT + (lane & 7u)]);
+      }
+    }
+    lds_barrier();
+  }
+#endif
   if (active) {
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
@@ -2412,6 +2533,13 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
 }  // namespace
 
 #define RGB_BLOCK 256
+/* variant builds of tools/build_variants.sh instantiate one group size only (-DRGB_X_ONLY_N=5): seconds instead
+ * of minutes per build */
+#ifdef RGB_X_ONLY_N
+#define RGB_LAUNCH_ALL_N LAUNCH(RGB_X_ONLY_N)
+#else
+#define RGB_LAUNCH_ALL_N LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
+#endif
 
 template <int KIND>
 static int launch_tick_kind(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, const u32 *d_n, rgb_decision *d_dec,
@@ -2423,7 +2551,7 @@ static int launch_tick_kind(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, co
                        d_rpcs, rpc_slot_base, msg_index_base);                                       \
     break;
   switch (dev.n_members) {
-    LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
+    RGB_LAUNCH_ALL_N
     default: return -1;
   }
 #undef LAUNCH
@@ -2462,7 +2590,7 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
                        d_dec, d_rpcs, rpc_slot_base, msg_index_base);                                  \
     break;
   switch (dev.n_members) {
-    LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
+    RGB_LAUNCH_ALL_N
     default: return -1;
   }
 #undef LAUNCH
@@ -2485,7 +2613,7 @@ int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u3
                        fam_total, fam_fill, d_kind_counts, d_n);                                       \
     break;
   switch (dev.n_members) {
-    LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
+    RGB_LAUNCH_ALL_N
     default: return -1;
   }
 #undef LAUNCH

@@ -37,6 +37,11 @@ def emulated_kernels_so(tmp_path_factory):
            "-I", os.path.join(nat, "fake_hip"), "-I", os.path.join(ROOT, "include"), "-o", str(out),
            os.path.join(nat, "api_on_cpu.cpp"), os.path.join(nat, "kernel_on_cpu.cpp"),
            os.path.join(nat, "wal_on_cpu.cpp")]
+    # opt-in: compile-time experiment switches of the kernels (tools/build_variants.sh) through the emulation,
+    # e.g. RGB_EMU_CXXFLAGS="-DRGB_X_COOPWB=2 -DRGB_X_RPC16=2"
+    extra = os.environ.get("RGB_EMU_CXXFLAGS")
+    if extra:
+        cmd[1:1] = extra.split()
     san = os.environ.get("RGB_EMU_SANITIZE")
     if san:
         # opt-in: a sanitizer over the emulated device code (every global / LDS index the kernels form, every

@@ -36,9 +36,11 @@ namespace emu {
 void barrier();
 void shfl(void *value, size_t size, int src_lane);
 int lane();
+unsigned long long ballot(int pred);
 }
 static inline void __syncthreads() { emu::barrier(); }
 template <typename T> static inline T __shfl(T v, int src, int = 64) { emu::shfl(&v, sizeof v, src); return v; }
+static inline unsigned long long __ballot(int pred) { return emu::ballot(pred); }
 template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { emu::shfl(&v, sizeof v, emu::lane() ^ mask); return v; }
 static inline unsigned long long wall_clock64() {
   return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();

@@ -44,6 +44,17 @@ void shfl(void *value, size_t size, int src_lane) {
   memcpy(value, shfl_buf[src_lane], size);
   barrier();
 }
+unsigned long long ballot(int pred) {
+  if (cur < 0) return pred ? 1ull : 0ull;
+  const unsigned char b = pred ? 1 : 0;
+  memcpy(shfl_buf[cur], &b, 1);
+  barrier();
+  unsigned long long m = 0;
+  for (unsigned i = 0; i < blockDim.x && i < 64; ++i)
+    if (!fibers[i].done && shfl_buf[i][0]) m |= 1ull << i;
+  barrier();
+  return m;
+}
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
   const unsigned nl = block.x;
   body_fn = &body;

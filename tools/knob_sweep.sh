@@ -10,7 +10,7 @@ one() {  # label lib dbg
   python -c "
 import json,sys
 try:
-    d=json.loads(open('$OUT/$1.json').read().strip().splitlines()[-1]); print('$1', round(d['roofline']['avg_launch_us'],2), 'us/tick', round(d['value']/1e9,2),'G/s', 'frac', round(d['roofline']['frac'],3))
+    d=json.loads(open('$OUT/$1.json').read().strip().splitlines()[-1]); print('$1', round(d['roofline']['avg_launch_us'],2), 'us/tick', round(d['value']/1e9,2),'G/s', 'frac', round(d['roofline']['frac'],3), d['config']['state_checksum'])
 except Exception as e: print('$1 failed', e)"
 }
 one product $PWD/ra_amd/csrc/libra_gpu_batch.so ""
