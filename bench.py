@@ -35,6 +35,109 @@ sys.path.insert(0, ROOT)
 SNAPSHOT_EVERY = 16
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+LITERAL = {
+    # (groups, members, seed, mix, gen_tick kwargs, initial_states kwargs)
+    "2": dict(groups=4096, members=5, seed=0x5EED0002, mix="MIX_CONFIG2", gen=dict(groups_per_tick=256, housekeeping=False),
+              init=dict(), what="configs[1]: 4096 groups x 5, 256 messages per tick, 50% follower append_entries / "
+                                "50% leader success replies"),
+    "3": dict(groups=65536, members=5, seed=0x5EED0003, mix="MIX_CONFIG3", gen=dict(housekeeping=False), init=dict(),
+              what="configs[2] literal: 65536 groups x 5, ONE message per group per tick (65536 per tick), 70% reply ok / "
+                   "20% append_entries / 5% reply failed / 5% request_vote term+1"),
+    "5": dict(groups=65536, members=7, seed=0x5EED0005, mix="MIX_CONFIG5", gen=dict(backlog_mode=True),
+              init=dict(backlog=1024, boundaries=(3, 6)),
+              what="configs[4]: 65536 groups x 7, 1024-entry uncommitted backlogs over 3-6 term boundaries, "
+                   "append_entries inside the backlog (prev_log_term wrong in 50%), failed replies driving the repair"),
+}
+
+
+def run_literal(name, ticks, torch, engine, W, abi, dev, local_rank, reps=3):
+    """One literal SURVEY 8(d) configuration: the host generator (ra_amd/workload.gen_tick) produces tick t from
+    the CHECKER's state after tick t-1 (the oracle is the state evolver here and nothing else), the stored ticks
+    are applied on the device once untimed with EVERY decision and the final state compared with the oracle's,
+    then replayed from the initial state inside one hipGraph between HIP events (best of `reps`)."""
+    from oracle import oracle as O
+    c = LITERAL[name]
+    G, N, seed = c["groups"], c["members"], c["seed"]
+    S = G * N
+    st0 = W.initial_states(G, N, seed, **c["init"])
+    cpu = O.Oracle(G, N, max_runs=16)
+    cpu.set_state(0, st0)
+    msgs, decs = [], []
+    t_host = time.perf_counter()
+    for t in range(ticks):
+        m = W.gen_tick(cpu.get_state(), N, t, seed, getattr(W, c["mix"]), **c["gen"])
+        d, _ = cpu.step_parallel(m)
+        msgs.append(m)
+        decs.append(d)
+    want_final = cpu.get_state()
+    cpu.close()
+    t_host = time.perf_counter() - t_host
+    NK = abi.N_KINDS
+    stride = max(len(m) for m in msgs)
+    kc = np.zeros((ticks, NK), dtype=np.uint32)
+    host = np.zeros(ticks * stride, dtype=abi.MSG_DTYPE)
+    for t, m in enumerate(msgs):
+        host[t * stride:t * stride + len(m)] = m
+        kc[t] = np.bincount(m["kind"], minlength=NK)[:NK]
+    stream = torch.cuda.current_stream(dev)
+    sptr = stream.cuda_stream
+    d_msgs = torch.from_numpy(host.view(np.uint8)).to(dev)
+    d_dec = torch.zeros(ticks * stride * 64, dtype=torch.uint8, device=dev)
+    d_rpcs = torch.empty(stride * max(N - 1, 1) * 56, dtype=torch.uint8, device=dev)
+    eng = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=1, ring_capacity=64)
+    try:
+        def enqueue():
+            eng.run_ticks_device(d_msgs.data_ptr(), stride, ticks, d_dec.data_ptr(), d_rpcs.data_ptr(), sptr,
+                                 tick_counts=kc.sum(axis=1).astype(np.uint32), kind_counts=kc)
+        # parity pass: every decision of every tick, then the whole final state
+        eng.set_state(0, st0)
+        enqueue()
+        torch.cuda.synchronize()
+        got = d_dec.cpu().numpy().view(abi.DECISION_DTYPE)
+        checked = 0
+        for t in range(ticks):
+            g = got[t * stride:t * stride + len(msgs[t])]
+            if g.tobytes() != decs[t].tobytes():
+                bad = int(np.flatnonzero((g.view(np.uint8).reshape(-1, 64) != decs[t].view(np.uint8).reshape(-1, 64)).any(axis=1))[0])
+                raise SystemExit(f"PARITY FAILURE config {name} tick {t} slot {bad}: msg={msgs[t][bad]} gpu={g[bad]} cpu={decs[t][bad]}")
+            checked += len(g)
+        assert eng.get_state().tobytes() == want_final.tobytes(), f"config {name}: final state differs from the oracle's"
+        # timed replays
+        g = torch.cuda.CUDAGraph()
+        eng.set_state(0, st0)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=stream):
+            enqueue()
+        best = None
+        for _ in range(reps):
+            eng.set_state(0, st0)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            g.replay()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+    finally:
+        eng.close()
+    n_dec = int(sum(len(m) for m in msgs))
+    alg = int(sum(W.algorithmic_bytes(m, N) for m in msgs))
+    tk = kc.sum(axis=0)
+    names = ["nop", "aer", "aer_reply", "request_vote", "vote_result", "written", "pipeline_rpcs", "append"]
+    return {
+        "workload": c["what"], "seed": hex(seed), "ticks": ticks, "decisions": n_dec,
+        "decisions_per_tick": n_dec / ticks, "us_per_tick": best * 1e3 / ticks,
+        "value": n_dec / (best / 1e3), "unit": "decisions/s",
+        "algorithmic_bytes_per_launch": alg / ticks, "achieved_GBps": alg / (best / 1e3) / 1e9,
+        "frac": alg / (best / 1e3) / 1e9 / HBM_PEAK_GBPS,
+        "message_mix": {names[i]: round(float(tk[i]) / float(tk.sum()), 4) for i in range(1, len(names)) if tk[i]},
+        "oracle_checked_decisions": checked, "oracle_checked_ticks": ticks, "final_state_equal": True,
+        "host_generation_s": round(t_host, 1),
+        "note": "every tick generated from the checker's state and checked decision by decision; one launch per tick, "
+                "device-resident batches, hipGraph replay from the initial state, best of %d" % reps,
+    }
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -52,7 +155,15 @@ def main():
                     help="the kind-generic kernel instead of the class-dispatch kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check-ticks", type=int, default=3,
-                    help="ticks compared bit-for-bit with the oracle before timing (rank 0)")
+                    help="ticks (the first of the timed window's stream, i.e. on the AGED state) compared "
+                         "bit-for-bit with the oracle before timing (rank 0)")
+    ap.add_argument("--age", type=int, default=512,
+                    help="untimed fast-forward: generator ticks applied before the warm-up/timed window, so that a "
+                         "short run (--steps 20) times the long-run state (term-run tables of 2..16 runs, "
+                         "compaction active) and not ticks 5..24 of a fresh one")
+    ap.add_argument("--literal-ticks", type=int, default=32,
+                    help="ticks of each literal SURVEY 8(d) configuration (configs 2, 3 and 5; host-generated, every "
+                         "tick oracle-checked, then replayed and timed on the device); 0 = skip (rank 0, N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -111,10 +222,19 @@ def main():
     lb_local = torch.empty(G * 32, dtype=torch.uint8, device=dev)
     lb_all = torch.empty(world * G * 32, dtype=torch.uint8, device=dev) if use_dist else None
 
-    # ---- pass 1 (untimed): generate tick t from the device state, then apply it ----
+    # ---- pass 0 (untimed): age the state.  `age` generator ticks are applied without being kept; the aged
+    # state is the starting point of both the generation pass and the timed replay ----
+    A = max(args.age, 0)
     t_gen = time.time()
+    for t in range(A):
+        eng.synth_tick_device(seed, t, d_msgs.data_ptr(), d_kc.data_ptr(), d_n.data_ptr(), sptr)
+        eng.synth_apply_tick_device(d_msgs.data_ptr(), S, d_dec.data_ptr(), d_rpcs.data_ptr(), sptr)
+    torch.cuda.synchronize()
+    d_kc.zero_()
+    st_aged = eng.get_state() if A else st0
+    # ---- pass 1 (untimed): generate tick A+t from the device state, then apply it ----
     for t in range(T):
-        eng.synth_tick_device(seed, t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
+        eng.synth_tick_device(seed, A + t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
                               d_n.data_ptr() + t * 4, sptr)
         eng.synth_apply_tick_device(d_msgs.data_ptr() + t * tick_bytes, S, d_dec.data_ptr() + t * tick_bytes,
                                     d_rpcs.data_ptr(), sptr)
@@ -126,6 +246,7 @@ def main():
     assert np.array_equal(n_dec, d_n.cpu().numpy().astype(np.int64))
     counts = n_dec.astype(np.uint32)
     alg_bytes = W.algorithmic_bytes_from_counts(kc, N)
+    n_runs_hist = np.bincount(st_aged["n_runs"], minlength=17).tolist()
 
     def tick_msgs(t):
         nt = int(n_dec[t])
@@ -139,8 +260,8 @@ def main():
         first_ticks = [tick_msgs(t) for t in range(min(n_keep, T))]
         if args.check_ticks > 0:
             from oracle import oracle as O
-            cpu = O.Oracle(G, N)
-            cpu.set_state(0, st0)
+            cpu = O.Oracle(G, N, max_runs=16)
+            cpu.set_state(0, st_aged)
             for t in range(min(args.check_ticks, T)):
                 want, _ = cpu.step_parallel(first_ticks[t])
                 nt = int(n_dec[t])
@@ -168,8 +289,8 @@ def main():
                     dist.all_gather_into_tensor(lb_all, lb_local)
             t = nxt
 
-    # ---- pass 2: reset, warm up, time exactly K ticks ----
-    eng.set_state(0, st0)
+    # ---- pass 2: back to the aged state, warm up, time exactly K ticks ----
+    eng.set_state(0, st_aged)
     run(0, Wm)
     torch.cuda.synchronize()
 
@@ -233,7 +354,7 @@ def main():
     ev_ms = ev0.elapsed_time(ev1)
     elapsed = max(wall, ev_ms / 1e3)
     checksum_pass2 = eng.state_checksum()
-    assert checksum_pass2 == checksum_pass1 or os.environ.get("RGB_DEBUG"), "replay diverged from the generation pass"
+    assert checksum_pass2 == checksum_pass1, "replay diverged from the generation pass"
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -244,11 +365,12 @@ def main():
     else:
         total_dec = int(n_dec[Wm:].sum())
 
-    # ---- cpu baseline (rank 0, N=1 only): the oracle on this box's host cores ----
+    # ---- cpu baseline (rank 0, N=1 only): the oracle on this box's host cores, 1 thread AND every usable
+    # core (both lines, core count and CPU model stated) ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        cpu = O.Oracle(G, N)
+        cpu = O.Oracle(G, N, max_runs=16)
         ncpu = os.cpu_count() or 1
         # a container may see every host core and still be limited to a few by its CPU quota
         quota = None
@@ -262,37 +384,38 @@ def main():
             affinity = len(os.sched_getaffinity(0))
         except Exception:
             affinity = ncpu
+        model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+        except Exception:
+            pass
         sample = first_ticks[:16]
-        best_thr, best_rate = 1, 0.0
-        usable = min(ncpu, affinity, quota or ncpu)
-        for thr in sorted({1, 2, 4, 8, 16, 32, 64, usable}):
-            if thr > usable:
-                continue
-            cpu.set_state(0, st0)
-            t0 = time.perf_counter()
-            nd = 0
-            for m in sample[:4]:
-                cpu.step_parallel(m, thr)
-                nd += len(m)
-            rate = nd / (time.perf_counter() - t0)
-            if rate > best_rate:
-                best_thr, best_rate = thr, rate
-        threads = best_thr
-        spent, done_dec, reps = 0.0, 0, 0
-        while spent < args.cpu_seconds and reps < 256:
-            cpu.set_state(0, st0)
-            for m in sample:
-                t0 = time.perf_counter()
-                cpu.step_parallel(m, threads)
-                spent += time.perf_counter() - t0
-                done_dec += len(m)
-            reps += 1
+        usable = max(1, min(ncpu, affinity, quota or ncpu))
+
+        def rate(threads, seconds):
+            spent, done, reps = 0.0, 0, 0
+            while spent < seconds and reps < 256:
+                cpu.set_state(0, st_aged)
+                for m in sample:
+                    t0 = time.perf_counter()
+                    cpu.step_parallel(m, threads)
+                    spent += time.perf_counter() - t0
+                    done += len(m)
+                reps += 1
+            return done / spent, done, spent, reps
+
+        one, d1, s1, r1 = rate(1, args.cpu_seconds / 2)
+        allc, da, sa, ra = rate(usable, args.cpu_seconds / 2)
         cpu_baseline = {
-            "value": done_dec / spent, "unit": "decisions/s", "cores": threads, "kind": "port",
-            "sample": f"first {len(sample)} ticks of the same stream x {reps} repetitions "
-                      f"({done_dec} decisions, {spent:.1f} s of oracle time, OpenMP over messages, "
-                      f"best of 1..{usable} threads; host cores {ncpu}, affinity {affinity}, "
-                      f"cgroup cpu quota {quota if quota else 'none'})",
+            "value": max(one, allc), "unit": "decisions/s", "cores": usable if allc >= one else 1, "kind": "port",
+            "one_thread": one, "all_cores": allc, "all_cores_threads": usable, "cpu_model": model,
+            "sample": f"first {len(sample)} ticks of the timed stream (aged state) x {r1}+{ra} repetitions: "
+                      f"{d1} decisions in {s1:.1f} s on 1 thread, {da} decisions in {sa:.1f} s on {usable} threads "
+                      f"(OpenMP static over the tick's messages); host cores {ncpu}, affinity {affinity}, "
+                      f"cgroup cpu quota {quota if quota else 'none'}; the Erlang reference itself: n/a (no OTP here)",
         }
         cpu.close()
 
@@ -306,7 +429,7 @@ def main():
         bufs = (np.empty(BATCH, dtype=abi.DECISION_DTYPE), np.empty(BATCH * max(N - 1, 1), dtype=abi.RPC_DTYPE))
         best = 0.0
         for rep in range(3):
-            eng_h.set_state(0, st0)
+            eng_h.set_state(0, st_aged)
             pending, nd = 0, 0
             t0 = time.perf_counter()
             for m in first_ticks[:12]:
@@ -393,6 +516,18 @@ def main():
             wal_frame = {"error": f"{type(e).__name__}: {e}"}
         del d_pay, d_ent, d_sum
 
+    # ---- the literal SURVEY 8(d) configurations (rank 0, N=1 only): reported beside the headline ----
+    literal = None
+    if rank == 0 and world == 1 and args.literal_ticks > 0:
+        literal = {}
+        for name in ("2", "3", "5"):
+            try:
+                literal["config" + name] = run_literal(name, args.literal_ticks, torch, engine, W, abi, dev, local_rank)
+            except SystemExit:
+                raise
+            except Exception as e:                                          # noqa: BLE001 - reported, not raised
+                literal["config" + name] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         per_launch_s = (ev_ms / 1e3) / K
         launch_bytes = float(alg_bytes[Wm:].mean())
@@ -402,10 +537,14 @@ def main():
                  "snapshot_written", "heartbeat_rpc", "heartbeat_reply", "consistent_query"]
         tk = kc[Wm:].sum(axis=0)
         mix = {names[i]: round(float(tk[i]) / float(tk[1:].sum()), 4) for i in range(1, NK) if tk[i]}
-        traffic = None
-        try:   # PMC passes cannot run inside this process: the committed per-launch figure, if any
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = float(json.load(f)["traffic_bytes_per_launch"])
+        traffic, traffic_src = None, None
+        try:   # PMC passes cannot run inside this process: the newest committed per-launch figure, if any
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if cands:
+                traffic_src = os.path.relpath(cands[-1], ROOT)
+                with open(cands[-1]) as f:
+                    traffic = float(json.load(f)["traffic_bytes_per_launch"])
         except Exception:
             traffic = None
         out = {
@@ -417,9 +556,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {
-                "workload": "configs[2]: 65536 groups x 5 members per GPU, mixed append_entries + "
-                            "request_vote (5% term churn), device-resident message batches, "
-                            "one kernel launch per tick",
+                "workload": "configs[2] closed loop: 65536 groups x 5 members per GPU, mixed append_entries + "
+                            "request_vote (5% of the groups per tick see a request_vote with term+1 and re-elect), "
+                            "every server may get a message every tick (device-side generator), device-resident "
+                            "message batches, one kernel launch per tick; the literal one-message-per-group form "
+                            "of SURVEY 8(d) is under literal_configs.config3",
+                "aged_ticks": A, "n_runs_histogram_at_start": n_runs_hist,
                 "groups_per_gpu": G, "members": N, "decisions_per_tick": float(n_dec[Wm:].mean()),
                 "message_mix": mix,
                 "leaderboard_allgather_every": SNAPSHOT_EVERY,
@@ -430,14 +572,15 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from profiles/r01_traffic.json (rocprofv3 PMC passes of "
-                                "tools/profile_round.sh, gfx950 x2 fetch correction); not re-measured in this run",
+                "traffic_note": f"HBM bytes per launch from {traffic_src} (rocprofv3 PMC passes, FETCH_SIZE with the "
+                                "guide's gfx950 x2 correction + WRITE_SIZE); not re-measured in this run",
                 "kernel": f"rgb_tick_classes_kernel<{N}>" if not args.generic_kernel
                           else f"rgb_tick_kernel<{N},generic>",
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "avg_launch_us": per_launch_s * 1e6,
             },
             "cpu_baseline": cpu_baseline,
+            "literal_configs": literal,
             "host_path": host_path,
             "aux_kernels": {"wal_adler32": wal, "wal_frame": wal_frame},
         }

@@ -14,7 +14,7 @@
 %%     commit_index:64, last_applied:64
 -module(ra_gpu_batch).
 
--export([init/0, open/4, register_groups/3, upload_state/3, download_state/3,
+-export([init/0, open/4, register_groups/3, upload_state/3, download_state/3, register_owner/4,
          submit/3, collect/1, start_collector/2, stop_collector/1, snapshot/2, wal_checksums/3]).
 -export([wal_batch_checksums/2, wal_frame/4, wal_recover_check/2, wal_frame_batch/3, wal_recover/2]).
 -export([encode_msg/3, decode_decision/1, decision_to_effects/3]).
@@ -65,6 +65,12 @@ open(_Device, _MaxRuns, _RingSlots, _RingCapacity) -> erlang:nif_error(not_loade
 register_groups(_Ctx, _NGroups, _NMembers) -> erlang:nif_error(not_loaded).
 upload_state(_Ctx, _First, _Bin) -> erlang:nif_error(not_loaded).
 download_state(_Ctx, _First, _N) -> erlang:nif_error(not_loaded).
+%% register_owner(Ctx, FirstServer, N, Pid): the collector thread sends every decision of servers
+%% [FirstServer, FirstServer+N) to Pid as {ra_gpu_batch, Tick, NDecisions, DecisionsBin, RpcsBin} (only that
+%% process's decisions, submission order; rpc msg_index = position inside DecisionsBin).  A ra_server_proc
+%% registers itself for its one server in init/1; unregistered servers go to the start_collector/2 pid.
+register_owner(_Ctx, _FirstServer, _N, _Pid) -> erlang:nif_error(not_loaded).
+%% submit/3 may be called from any process; batches above 2048 messages run on a dirty CPU scheduler.
 submit(_Ctx, _MsgsBin, _Tick) -> erlang:nif_error(not_loaded).
 collect(_Ctx) -> erlang:nif_error(not_loaded).
 start_collector(_Ctx, _Pid) -> erlang:nif_error(not_loaded).
@@ -130,6 +136,10 @@ wal_recover(Ctx, FileBin) ->
     lists:reverse(Out).
 
 %% Slot = fun(ra_server_id()) -> 0..7 | 255, the member slot of a server id inside its group.
+%% Returns the 64-byte record, or `fallback` for an event the batched path does not take (the caller runs
+%% ra_server:handle_* itself and re-uploads the server's integers with upload_state/3).  Every message kind
+%% of include/ra_gpu_batch.h has a clause; anything else (install_snapshot, cluster changes, ..) is not a
+%% message of this path and must not be passed in.
 encode_msg(Server, #append_entries_rpc{term = T, leader_id = L, leader_commit = LC,
                                        prev_log_index = PI, prev_log_term = PT,
                                        entries = Entries}, Slot) ->
@@ -146,9 +156,48 @@ encode_msg(Server, #request_vote_rpc{term = T, candidate_id = C, last_log_index 
                                      last_log_term = LLT}, Slot) ->
     <<Server:32/little, ?MSG_REQUEST_VOTE:8, (Slot(C)):8, 0:8, 0:8, T:64/little, LLI:64/little,
       LLT:64/little, 0:64, 0:64, 0:64, 0:64>>;
-encode_msg(Server, {ra_log_event, {written, T, {From, To}}}, _Slot) ->
-    <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, 0:8, 0:8, T:64/little, From:64/little,
-      To:64/little, 0:64, 0:64, 0:64, 0:64>>;
+encode_msg(Server, {ra_log_event, {written, T, Seq}}, _Slot) ->
+    %% the written event carries a ra_seq:state() -- a list of indexes and ranges, newest first
+    %% (src/ra_log_wal.erl:807, src/ra_log.erl:74,1641; ra_seq.erl:17-26) -- e.g. [{From,To}], [Idx] or
+    %% {written,0,[0]}.  One contiguous range rides in the message; anything else (write_sparse during a
+    %% snapshot install) returns `fallback` and the caller lets ra_server handle the event and re-uploads.
+    case ra_seq:length(Seq) of
+        0 -> fallback;
+        Len ->
+            From = ra_seq:first(Seq), To = ra_seq:last(Seq),
+            case To - From + 1 of
+                Len ->
+                    <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, 0:8, 0:8, T:64/little, From:64/little,
+                      To:64/little, 0:64, 0:64, 0:64, 0:64>>;
+                _ -> fallback
+            end
+    end;
+encode_msg(Server, {Peer, #request_vote_result{term = T, vote_granted = G}}, Slot) ->
+    Flags = case G of true -> 1; false -> 0 end,
+    <<Server:32/little, ?MSG_VOTE_RESULT:8, (Slot(Peer)):8, Flags:8, 0:8, T:64/little, 0:(6 * 64)>>;
+encode_msg(Server, #pre_vote_rpc{version = V, machine_version = MV, term = T, token = Tok, candidate_id = C,
+                                 last_log_index = LLI, last_log_term = LLT}, Slot) ->
+    %% the token is a reference in the reference; the caller maps it to a 64-bit integer (erlang:phash2 of the
+    %% ref is NOT unique enough: keep a per-server counter and a map Ref -> integer beside the gen_statem)
+    <<Server:32/little, ?MSG_PRE_VOTE_RPC:8, (Slot(C)):8, 0:8, V:8, T:64/little, LLI:64/little,
+      LLT:64/little, Tok:64/little, MV:32/little, 0:32, 0:64, 0:64>>;
+encode_msg(Server, {Peer, #pre_vote_result{term = T, token = Tok, vote_granted = G}}, Slot) ->
+    Flags = case G of true -> 1; false -> 0 end,
+    <<Server:32/little, ?MSG_PRE_VOTE_RESULT:8, (Slot(Peer)):8, Flags:8, 0:8, T:64/little, 0:64, 0:64,
+      Tok:64/little, 0:64, 0:64, 0:64>>;
+encode_msg(Server, {election_timeout, Tok}, _Slot) ->
+    %% election_timeout in follower / pre_vote / candidate; Tok = the integer standing for make_ref() of
+    %% call_for_election(pre_vote, ..) (src/ra_server.erl:2900-2924)
+    <<Server:32/little, ?MSG_ELECTION_TIMEOUT:8, ?NONE:8, 0:8, 0:8, 0:64, 0:64, 0:64, Tok:64/little,
+      0:64, 0:64, 0:64>>;
+encode_msg(Server, {commands, NEntries, Force}, _Slot) ->
+    %% {command, _} / {commands, _} on the leader: only the COUNT crosses (payloads go to ra_log:append on the
+    %% host, src/ra_server.erl:653-738); Force = true for the noop of a new term (RGB_MF_FORCE = 2)
+    Flags = case Force of true -> 2; false -> 0 end,
+    <<Server:32/little, ?MSG_APPEND:8, ?NONE:8, Flags:8, 0:8, 0:64, 0:64, 0:64, 0:64,
+      NEntries:32/little, 0:32, 0:64, 0:64>>;
+encode_msg(Server, await_condition_timeout, _Slot) ->
+    <<Server:32/little, ?MSG_AWAIT_TIMEOUT:8, ?NONE:8, 0:8, 0:8, 0:(7 * 64)>>;
 encode_msg(Server, {ra_log_event, {snapshot_written, {Idx, T}, _, snapshot, _, _}}, _Slot) ->
     <<Server:32/little, ?MSG_SNAPSHOT_WRITTEN:8, ?NONE:8, 0:8, 0:8, 0:64, Idx:64/little,
       T:64/little, 0:64, 0:64, 0:64, 0:64>>;

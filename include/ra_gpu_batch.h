@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGB_ABI_VERSION   4u
+#define RGB_ABI_VERSION   5u
 #define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
 #define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
 #define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
@@ -350,6 +350,26 @@ int  rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_sta
 int  rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick);
 int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
                  rgb_rpc *rpc_out, uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out);
+/* Threading (the interception point is per gen_statem, reference src/ra_server_proc.erl:1356-1397, so many
+ * scheduler threads reach the boundary at once): rgb_submit may be called from any number of threads --
+ * callers serialise on an internal lock and their batches reach the device in lock order; RGB_E_FULL when
+ * every ring slot is in flight (nothing was enqueued).  rgb_collect may be called from any thread,
+ * concurrently with submits; concurrent collectors serialise and each batch is handed out exactly once,
+ * oldest first.  A buffer that is too small leaves the batch in the ring: RGB_E_INVAL (cap) or RGB_E_FULL
+ * (rpc_cap) with the needed counts in *n_out / *n_rpc_out, the caller retries with larger buffers.
+ * RGB_E_STATE from rgb_collect (a batch whose records are inconsistent) consumes the batch.
+ * rgb_wait parks the calling thread until a batch is in flight (RGB_OK), timeout_ms have passed or rgb_wake
+ * was called (both RGB_E_EMPTY): a collector thread blocks here instead of polling rgb_collect.
+ * rgb_upload_state / rgb_download_state / rgb_snapshot / rgb_state_checksum use the context's stream and are
+ * ordered after the batches submitted before them; they may run beside submit/collect. */
+int      rgb_wait(rgb_ctx *ctx, uint32_t timeout_ms);
+void     rgb_wake(rgb_ctx *ctx);
+uint32_t rgb_in_flight(const rgb_ctx *ctx);
+
+/* Multi-GPU routing below any host language (the group -> node-local shard map that
+ * ra_leaderboard / the ra_directory lookup give the reference, src/ra_leaderboard.erl:18-26): the context
+ * (one per GPU) that owns a Raft group = splitmix64(group_uid) mod n_contexts.  Pure function. */
+uint32_t rgb_route(uint64_t group_uid, uint32_t n_contexts);
 
 /* Device-resident path (benchmarks, device-side producers): d_msgs holds n_ticks ticks laid out
  * tick_stride messages apart; tick t carries tick_counts[t] messages (host array; NULL = every

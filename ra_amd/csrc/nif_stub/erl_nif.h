@@ -60,6 +60,14 @@ void enif_clear_env(ErlNifEnv *);
 int enif_send(ErlNifEnv *, const ErlNifPid *, ErlNifEnv *, ERL_NIF_TERM);
 int enif_thread_create(char *, ErlNifTid *, void *(*)(void *), void *, ErlNifThreadOpts *);
 int enif_thread_join(ErlNifTid, void **);
+typedef struct ErlNifMutex_ ErlNifMutex;
+ErlNifMutex *enif_mutex_create(char *name);
+void enif_mutex_destroy(ErlNifMutex *);
+void enif_mutex_lock(ErlNifMutex *);
+void enif_mutex_unlock(ErlNifMutex *);
+ERL_NIF_TERM enif_schedule_nif(ErlNifEnv *, const char *fun_name, int flags,
+                               ERL_NIF_TERM (*fp)(ErlNifEnv *, int, const ERL_NIF_TERM[]), int argc,
+                               const ERL_NIF_TERM argv[]);
 
 #define ERL_NIF_INIT(MODULE, FUNCS, LOAD, RELOAD, UPGRADE, UNLOAD) \
   const ErlNifFunc *rgb_stub_nif_init_##MODULE(void) { (void)LOAD; return FUNCS; }

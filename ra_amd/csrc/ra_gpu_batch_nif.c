@@ -4,30 +4,48 @@
  * No logic lives here: every function unpacks its arguments, calls exactly one rgb_* entry
  * point and packs the result.  Records cross the boundary as binaries with the exact C layout
  * (erlang/ra_gpu_batch.erl builds and parses them), so the hot calls are one memcpy each.
- * Threading follows SURVEY.md section 8b: submit/2 is non-blocking (O(memcpy) into the pinned
- * ring); results come back either through the dirty NIF collect/1 or through the collector
- * thread started by start_collector/2, which loops on rgb_collect and enif_send()s
- * {ra_gpu_batch, Tick, Decisions, Rpcs} to the owning process (fan-back to the gen_statems is
- * done there).  The resource destructor calls rgb_close.
+ * Threading follows SURVEY.md section 8b and the reference's interception point, which is per gen_statem
+ * (src/ra_server_proc.erl:1356-1397):
+ *   - submit/3 may be called by any number of processes at once (rgb_submit serialises them); batches above
+ *     SUBMIT_DIRTY_MSGS messages reschedule themselves onto a dirty CPU scheduler (enif_schedule_nif) so that the
+ *     validation + family sort + memcpy never holds a normal scheduler;
+ *   - results come back either through the dirty NIF collect/1 or through the collector thread started by
+ *     start_collector/2.  The thread parks in rgb_wait (condition variable, no polling), and FANS EVERY BATCH BACK
+ *     PER OWNER: register_owner(Ctx, FirstServer, N, Pid) says which gen_statem owns servers
+ *     [FirstServer, FirstServer+N); each owner that has decisions in a batch receives ONE message
+ *     {ra_gpu_batch, Tick, NDecisions, DecisionsBin, RpcsBin} holding only its decisions (submission order) and
+ *     their rpc records (msg_index = index into that DecisionsBin); servers nobody registered go to the default
+ *     owner given to start_collector/2.  collect/1 is refused ({error, collector_running}) while the thread runs:
+ *     one consumer at a time is a contract of the shim, the C ABI itself tolerates several.
+ * The resource destructor stops the thread and calls rgb_close.
  *
  * Cannot be built against the real erl_nif.h in this image (no OTP): `make nif-check` syntax-checks it
  * against ra_amd/csrc/nif_stub/erl_nif.h, and tests/test_nif_shim_mock_beam.py EXECUTES it against a functional
- * mock of that API (tests/native/mock_beam) on top of the CPU-emulated library.  Build line for a machine with OTP >= 26:
+ * mock of that API (tests/native/mock_beam) on top of the CPU-emulated library (also under ThreadSanitizer).
+ * Build line for a machine with OTP >= 26:
  *   cc -O2 -fPIC -shared -I$ERL_INCLUDE -Iinclude ra_amd/csrc/ra_gpu_batch_nif.c \
  *      -Lra_amd/csrc -lra_gpu_batch -o priv/ra_gpu_batch_nif.so
  */
+#include <stdatomic.h>
 #include <string.h>
 
 #include "erl_nif.h"
 #include "ra_gpu_batch.h"
 #include "ra_gpu_wal.h"
 
+#define SUBMIT_DIRTY_MSGS 2048u   /* ~20 us of rgb_submit host work: above this the call goes to a dirty scheduler */
+
 typedef struct {
   rgb_ctx *ctx;
-  uint32_t ring_capacity, n_members;
+  uint32_t ring_capacity, n_members, n_groups, n_servers;
   ErlNifTid tid;
-  ErlNifPid owner;
-  volatile int collector_on, stop;
+  ErlNifPid owner;                 /* default owner (start_collector/2) */
+  /* per-process fan-back: owner_of[server] = 1 + index into pids, 0 = default owner (guarded by own_mu) */
+  ErlNifMutex *own_mu;
+  ErlNifPid *pids;
+  uint32_t n_pids, cap_pids;
+  uint32_t *owner_of;
+  atomic_int collector_on, stop;
 } nif_ctx;
 
 static ErlNifResourceType *CTX_TYPE;
@@ -46,10 +64,13 @@ static ERL_NIF_TERM mk_error(ErlNifEnv *env, nif_ctx *c, int rc) {
 static void ctx_dtor(ErlNifEnv *env, void *obj) {
   nif_ctx *c = (nif_ctx *)obj;
   (void)env;
-  c->stop = 1;
-  if (c->collector_on) enif_thread_join(c->tid, NULL);
+  atomic_store(&c->stop, 1);
+  if (atomic_load(&c->collector_on)) { rgb_wake(c->ctx); enif_thread_join(c->tid, NULL); }
   if (c->ctx) rgb_close(c->ctx);
   c->ctx = NULL;
+  if (c->own_mu) enif_mutex_destroy(c->own_mu);
+  if (c->pids) enif_free(c->pids);
+  if (c->owner_of) enif_free(c->owner_of);
 }
 
 static int get_ctx(ErlNifEnv *env, ERL_NIF_TERM t, nif_ctx **c) {
@@ -72,6 +93,7 @@ static ERL_NIF_TERM nif_open(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]
   nif_ctx *c = (nif_ctx *)enif_alloc_resource(CTX_TYPE, sizeof *c);
   memset(c, 0, sizeof *c);
   c->ctx = ctx; c->ring_capacity = cap;
+  c->own_mu = enif_mutex_create((char *)"rgb_owners");
   ERL_NIF_TERM term = enif_make_resource(env, c);
   enif_release_resource(c);
   return enif_make_tuple2(env, enif_make_atom(env, "ok"), term);
@@ -84,7 +106,34 @@ static ERL_NIF_TERM nif_register_groups(ErlNifEnv *env, int argc, const ERL_NIF_
     return enif_make_badarg(env);
   int rc = rgb_register_groups(c->ctx, g, n);
   if (rc) return mk_error(env, c, rc);
-  c->n_members = n;
+  c->n_members = n; c->n_groups = g; c->n_servers = rgb_n_servers(c->ctx);
+  c->owner_of = (uint32_t *)enif_alloc((size_t)c->n_servers * sizeof(uint32_t));
+  if (!c->owner_of) return mk_error(env, c, RGB_E_NOMEM);
+  memset(c->owner_of, 0, (size_t)c->n_servers * sizeof(uint32_t));
+  return enif_make_atom(env, "ok");
+}
+
+/* register_owner(Ctx, FirstServer, N, Pid) -> ok: the gen_statem Pid owns servers [FirstServer, FirstServer+N)
+ * (a ra_server_proc registers the one server it is; a batching process may own a range) */
+static ERL_NIF_TERM nif_register_owner(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c; unsigned first, n; ErlNifPid pid;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c) || !enif_get_uint(env, argv[1], &first) || !enif_get_uint(env, argv[2], &n) ||
+      !enif_get_local_pid(env, argv[3], &pid) || !c->owner_of || (uint64_t)first + n > c->n_servers)
+    return enif_make_badarg(env);
+  enif_mutex_lock(c->own_mu);
+  if (c->n_pids == c->cap_pids) {
+    uint32_t cap = c->cap_pids ? c->cap_pids * 2 : 64;
+    ErlNifPid *p = (ErlNifPid *)enif_alloc((size_t)cap * sizeof(ErlNifPid));
+    if (!p) { enif_mutex_unlock(c->own_mu); return mk_error(env, c, RGB_E_NOMEM); }
+    if (c->n_pids) memcpy(p, c->pids, (size_t)c->n_pids * sizeof(ErlNifPid));
+    if (c->pids) enif_free(c->pids);
+    c->pids = p; c->cap_pids = cap;
+  }
+  c->pids[c->n_pids] = pid;
+  const uint32_t idx = ++c->n_pids;
+  for (unsigned k = 0; k < n; ++k) c->owner_of[first + k] = idx;
+  enif_mutex_unlock(c->own_mu);
   return enif_make_atom(env, "ok");
 }
 
@@ -111,8 +160,8 @@ static ERL_NIF_TERM nif_download_state(ErlNifEnv *env, int argc, const ERL_NIF_T
   return enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_binary(env, &b));
 }
 
-/* submit(Ctx, <<rgb_msg x N>>, Tick): copies into the pinned ring and returns */
-static ERL_NIF_TERM nif_submit(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+/* submit(Ctx, <<rgb_msg x N>>, Tick): copies into the pinned ring and returns.  Thread-safe: any process may call it. */
+static ERL_NIF_TERM submit_body(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c; ErlNifBinary b; uint64_t tick;
   (void)argc;
   if (!get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &b) || b.size % sizeof(rgb_msg) ||
@@ -120,6 +169,12 @@ static ERL_NIF_TERM nif_submit(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv
     return enif_make_badarg(env);
   int rc = rgb_submit(c->ctx, (const rgb_msg *)b.data, (uint32_t)(b.size / sizeof(rgb_msg)), tick);
   return rc ? mk_error(env, c, rc) : enif_make_atom(env, "ok");
+}
+static ERL_NIF_TERM nif_submit(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  ErlNifBinary b;
+  if (enif_inspect_binary(env, argv[1], &b) && b.size / sizeof(rgb_msg) > SUBMIT_DIRTY_MSGS)
+    return enif_schedule_nif(env, "submit_dirty", ERL_NIF_DIRTY_JOB_CPU_BOUND, submit_body, argc, argv);
+  return submit_body(env, argc, argv);
 }
 
 static int do_collect(nif_ctx *c, ErlNifBinary *dec, ErlNifBinary *rpc, uint32_t *n, uint32_t *nr, uint64_t *tick) {
@@ -140,28 +195,109 @@ static ERL_NIF_TERM nif_collect(ErlNifEnv *env, int argc, const ERL_NIF_TERM arg
   nif_ctx *c; ErlNifBinary dec, rpc; uint32_t n = 0, nr = 0; uint64_t tick = 0;
   (void)argc;
   if (!get_ctx(env, argv[0], &c)) return enif_make_badarg(env);
+  if (atomic_load(&c->collector_on))     /* one consumer: the collector thread owns rgb_collect while it runs */
+    return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "collector_running"));
   int rc = do_collect(c, &dec, &rpc, &n, &nr, &tick);
   if (rc) return mk_error(env, c, rc);
   return enif_make_tuple5(env, enif_make_atom(env, "ok"), enif_make_uint64(env, tick), enif_make_uint64(env, n),
                           enif_make_binary(env, &dec), enif_make_binary(env, &rpc));
 }
 
-/* the collector thread: owns rgb_collect, fans whole batches back to the owner process */
+static void send_batch(ErlNifEnv *env, const ErlNifPid *to, uint64_t tick, uint32_t n, ErlNifBinary *dec, ErlNifBinary *rpc) {
+  ERL_NIF_TERM msg = enif_make_tuple5(env, enif_make_atom(env, "ra_gpu_batch"), enif_make_uint64(env, tick),
+                                      enif_make_uint64(env, n), enif_make_binary(env, dec), enif_make_binary(env, rpc));
+  enif_send(NULL, to, env, msg);
+  enif_clear_env(env);
+}
+
+/* One collected batch -> one message per owning process, in two linear passes: (1) count decisions and rpc records
+ * per owner and list the owners in order of first appearance, (2) append every decision (submission order is kept
+ * inside an owner) and its rpc records -- rgb_collect returns them ordered by msg_index -- to the owner's binaries,
+ * with msg_index rewritten to the decision's position inside that owner's DecisionsBin. */
+static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint32_t nr, ErlNifBinary *dec, ErlNifBinary *rpc) {
+  const rgb_decision *d = (const rgb_decision *)dec->data;
+  const rgb_rpc *r = (const rgb_rpc *)rpc->data;
+  (void)nr;
+  enif_mutex_lock(c->own_mu);
+  if (c->n_pids == 0) {
+    enif_mutex_unlock(c->own_mu);
+    send_batch(env, &c->owner, tick, n, dec, rpc);
+    return RGB_OK;
+  }
+  const uint32_t n_own = c->n_pids + 1;                       /* bucket 0 = default owner */
+  /* tix[o] = 1 + position of owner o in the first-appearance list (0 = not seen in this batch) */
+  uint32_t *tix = (uint32_t *)enif_alloc((size_t)n_own * sizeof(uint32_t));
+  uint32_t *own = (uint32_t *)enif_alloc((size_t)(n + 1) * 5 * sizeof(uint32_t));
+  ErlNifBinary *bins = NULL;
+  int rc = RGB_OK;
+  if (!tix || !own) rc = RGB_E_NOMEM;
+  uint32_t n_t = 0;
+  if (rc == RGB_OK) {
+    uint32_t *cnt_d = own + (n + 1), *cnt_r = cnt_d + (n + 1), *fill_d = cnt_r + (n + 1), *fill_r = fill_d + (n + 1);
+    memset(tix, 0, (size_t)n_own * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t o = d[i].server < c->n_servers ? c->owner_of[d[i].server] : 0;
+      if (!tix[o]) { own[n_t] = o; cnt_d[n_t] = cnt_r[n_t] = fill_d[n_t] = fill_r[n_t] = 0; tix[o] = ++n_t; }
+      cnt_d[tix[o] - 1] += 1; cnt_r[tix[o] - 1] += d[i].n_rpcs;
+    }
+    bins = (ErlNifBinary *)enif_alloc((size_t)(n_t ? n_t : 1) * 2 * sizeof(ErlNifBinary));
+    uint32_t made = 0;
+    if (!bins) rc = RGB_E_NOMEM;
+    for (; rc == RGB_OK && made < n_t; ++made) {
+      if (!enif_alloc_binary((size_t)cnt_d[made] * sizeof(rgb_decision), &bins[2 * made])) { rc = RGB_E_NOMEM; break; }
+      if (!enif_alloc_binary((size_t)cnt_r[made] * sizeof(rgb_rpc), &bins[2 * made + 1])) {
+        enif_release_binary(&bins[2 * made]); rc = RGB_E_NOMEM; break;
+      }
+    }
+    if (rc != RGB_OK) {
+      for (uint32_t t = 0; t < made; ++t) { enif_release_binary(&bins[2 * t]); enif_release_binary(&bins[2 * t + 1]); }
+    } else {
+      uint32_t k = 0;                                          /* cursor into the rpc records */
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t o = d[i].server < c->n_servers ? c->owner_of[d[i].server] : 0;
+        const uint32_t t = tix[o] - 1;
+        const uint32_t at = fill_d[t]++;
+        ((rgb_decision *)bins[2 * t].data)[at] = d[i];
+        for (uint32_t q = 0; q < d[i].n_rpcs; ++q) {
+          rgb_rpc x = r[k++];
+          x.msg_index = at;
+          ((rgb_rpc *)bins[2 * t + 1].data)[fill_r[t]++] = x;
+        }
+      }
+      for (uint32_t t = 0; t < n_t; ++t) {
+        const ErlNifPid to = own[t] ? c->pids[own[t] - 1] : c->owner;
+        send_batch(env, &to, tick, cnt_d[t], &bins[2 * t], &bins[2 * t + 1]);
+      }
+    }
+  }
+  enif_mutex_unlock(c->own_mu);
+  if (tix) enif_free(tix);
+  if (own) enif_free(own);
+  if (bins) enif_free(bins);
+  enif_release_binary(dec); enif_release_binary(rpc);
+  return rc;
+}
+
+/* the collector thread: owns rgb_collect, parks in rgb_wait while nothing is in flight */
 static void *collector_main(void *arg) {
   nif_ctx *c = (nif_ctx *)arg;
   ErlNifEnv *env = enif_alloc_env();
-  while (!c->stop) {
+  while (!atomic_load(&c->stop)) {
+    if (rgb_wait(c->ctx, 250) != RGB_OK) continue;            /* timeout or rgb_wake: re-check stop */
     ErlNifBinary dec, rpc; uint32_t n = 0, nr = 0; uint64_t tick = 0;
     int rc = do_collect(c, &dec, &rpc, &n, &nr, &tick);
-    if (rc == RGB_E_EMPTY) { continue; }          /* nothing in flight: a real shim parks on a condvar here */
-    ERL_NIF_TERM msg = rc ? enif_make_tuple2(env, enif_make_atom(env, "ra_gpu_batch_error"), mk_error(env, c, rc))
-                          : enif_make_tuple5(env, enif_make_atom(env, "ra_gpu_batch"), enif_make_uint64(env, tick),
-                                             enif_make_uint64(env, n), enif_make_binary(env, &dec),
-                                             enif_make_binary(env, &rpc));
-    enif_send(NULL, &c->owner, env, msg);
-    enif_clear_env(env);
+    if (rc == RGB_E_EMPTY) continue;
+    if (rc == RGB_OK) rc = fan_back(c, env, tick, n, nr, &dec, &rpc);
+    if (rc != RGB_OK) {
+      /* a persistent error is reported ONCE to the default owner and ends the thread (the owner falls back to
+       * ra_server and may start a new collector): no hot error loop */
+      enif_send(NULL, &c->owner, env, enif_make_tuple2(env, enif_make_atom(env, "ra_gpu_batch_error"), mk_error(env, c, rc)));
+      enif_clear_env(env);
+      break;
+    }
   }
   enif_free_env(env);
+  atomic_store(&c->collector_on, 2);                          /* finished: stop_collector/1 joins it */
   enif_release_resource(c);
   return NULL;
 }
@@ -169,14 +305,16 @@ static void *collector_main(void *arg) {
 static ERL_NIF_TERM nif_start_collector(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c;
   (void)argc;
-  if (!get_ctx(env, argv[0], &c) || c->collector_on || !enif_get_local_pid(env, argv[1], &c->owner))
+  if (!get_ctx(env, argv[0], &c) || atomic_load(&c->collector_on) || !enif_get_local_pid(env, argv[1], &c->owner))
     return enif_make_badarg(env);
   enif_keep_resource(c);
+  atomic_store(&c->stop, 0);
+  atomic_store(&c->collector_on, 1);
   if (enif_thread_create((char *)"rgb_collector", &c->tid, collector_main, c, NULL)) {
+    atomic_store(&c->collector_on, 0);
     enif_release_resource(c);
     return mk_error(env, c, RGB_E_NOMEM);
   }
-  c->collector_on = 1;
   return enif_make_atom(env, "ok");
 }
 
@@ -185,11 +323,12 @@ static ERL_NIF_TERM nif_start_collector(ErlNifEnv *env, int argc, const ERL_NIF_
 static ERL_NIF_TERM nif_stop_collector(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c;
   (void)argc;
-  if (!get_ctx(env, argv[0], &c) || !c->collector_on) return enif_make_badarg(env);
-  c->stop = 1;
+  if (!get_ctx(env, argv[0], &c) || !atomic_load(&c->collector_on)) return enif_make_badarg(env);
+  atomic_store(&c->stop, 1);
+  rgb_wake(c->ctx);                                            /* the thread may be parked in rgb_wait */
   enif_thread_join(c->tid, NULL);
-  c->collector_on = 0;
-  c->stop = 0;
+  atomic_store(&c->collector_on, 0);
+  atomic_store(&c->stop, 0);
   return enif_make_atom(env, "ok");
 }
 
@@ -197,8 +336,11 @@ static ERL_NIF_TERM nif_stop_collector(ErlNifEnv *env, int argc, const ERL_NIF_T
 static ERL_NIF_TERM nif_snapshot(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c; unsigned g; ErlNifBinary b;
   (void)argc;
-  if (!get_ctx(env, argv[0], &c) || !enif_get_uint(env, argv[1], &g)) return enif_make_badarg(env);
-  if (!enif_alloc_binary((size_t)g * sizeof(rgb_leaderboard_row), &b)) return mk_error(env, c, RGB_E_NOMEM);
+  /* rgb_snapshot writes one row per REGISTERED group: the binary is sized from the registration and a caller
+   * whose NGroups disagrees gets badarg (a smaller binary would be overrun) */
+  if (!get_ctx(env, argv[0], &c) || !enif_get_uint(env, argv[1], &g) || c->n_groups == 0 || g != c->n_groups)
+    return enif_make_badarg(env);
+  if (!enif_alloc_binary((size_t)c->n_groups * sizeof(rgb_leaderboard_row), &b)) return mk_error(env, c, RGB_E_NOMEM);
   int rc = rgb_snapshot(c->ctx, (rgb_leaderboard_row *)b.data);
   if (rc) { enif_release_binary(&b); return mk_error(env, c, rc); }
   return enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_binary(env, &b));
@@ -276,6 +418,7 @@ static ErlNifFunc nif_funcs[] = {
   {"register_groups", 3, nif_register_groups, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"upload_state", 3, nif_upload_state, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"download_state", 3, nif_download_state, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"register_owner", 4, nif_register_owner, 0},
   {"submit", 3, nif_submit, 0},
   {"collect", 1, nif_collect, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"start_collector", 2, nif_start_collector, 0},

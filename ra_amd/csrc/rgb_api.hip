@@ -11,8 +11,12 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -23,7 +27,7 @@
   do {                                             \
     hipError_t e__ = (expr);                       \
     if (e__ != hipSuccess) {                       \
-      (ctx)->last_hip = (int)e__;                  \
+      (ctx)->last_hip.store((int)e__, std::memory_order_relaxed); \
       return RGB_E_HIP;                            \
     }                                              \
   } while (0)
@@ -43,11 +47,19 @@ struct rgb_slot {
   bool busy = false;
 };
 
+/* Threading contract of the staging ring: any number of threads may call rgb_submit
+ * (they serialise on submit_mu: the ring slot, the sub-tick scratch and the order of the stream's work are
+ * one critical section -- batches reach the device in the order their submits acquired the lock), any number
+ * may call rgb_collect (serialised on collect_mu; every batch is handed out exactly once, oldest first), and
+ * the two sides only meet in `in_flight`: submit publishes a filled slot with a release increment after its
+ * event is recorded, collect acquires it, and gives the slot back with a release decrement that the next
+ * submit's full-check acquires.  head belongs to the producers' lock, tail to the consumers'.  rgb_wait parks
+ * a consumer on the condition variable until a batch is in flight (no polling). */
 struct rgb_ctx {
   rgb_config cfg;
   rgb_dev dev;
   hipStream_t stream = nullptr;
-  int last_hip = 0;
+  std::atomic<int> last_hip{0};
   bool registered = false;
   /* state transfer staging */
   rgb_server_state *d_stage = nullptr;
@@ -55,11 +67,17 @@ struct rgb_ctx {
   u32 stage_cap = 0;
   /* ring */
   std::vector<rgb_slot> ring;
-  u32 head = 0, tail = 0, in_flight = 0;
+  u32 head = 0;                          /* guarded by submit_mu  */
+  u32 tail = 0;                          /* guarded by collect_mu */
+  std::atomic<u32> in_flight{0};
+  std::mutex submit_mu, collect_mu, state_mu;   /* state_mu: the h_stage / d_stage transfer staging */
+  std::mutex wait_mu;
+  std::condition_variable wait_cv;
+  std::atomic<u32> wake_gen{0};
   u32 rpc_cap = 0;      /* records per ring slot = ring_capacity * rpc_stride */
   u32 rpc_stride = 1;   /* fixed rpc slots per message = max(n_members-1, 1) */
 
-  /* sub-tick scheduling scratch */
+  /* sub-tick scheduling scratch (submit_mu) */
   std::vector<uint16_t> seen;
   std::vector<u32> touched;
   std::vector<u32> round_of;
@@ -74,7 +92,7 @@ static int launch_tick_classes(rgb_ctx *ctx, const rgb_msg *m, rgb_decision *d, 
                                const u32 counts[RGB_N_CLASSES], u32 rpc_slot_base, u32 msg_index_base,
                                hipStream_t main) {
   int rc = rgb_launch_tick_classes(ctx->dev, m, counts, nullptr, 0, d, rpcs, rpc_slot_base, msg_index_base, main);
-  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   return RGB_OK;
 }
 
@@ -124,7 +142,7 @@ void rgb_default_config(rgb_config *cfg) {
   cfg->flags = 0;
 }
 
-int rgb_last_hip_error(const rgb_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+int rgb_last_hip_error(const rgb_ctx *ctx) { return ctx ? ctx->last_hip.load(std::memory_order_relaxed) : 0; }
 
 static void free_slot(rgb_slot &s) {
   if (s.h_msgs) (void)hipHostFree(s.h_msgs);
@@ -179,7 +197,7 @@ int rgb_open(const rgb_config *cfg_in, rgb_ctx **out) {
   e = hipSetDevice(cfg.device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 
-  if (e != hipSuccess) { ctx->last_hip = (int)e; delete ctx; return RGB_E_HIP; }
+  if (e != hipSuccess) { delete ctx; return RGB_E_HIP; }
   *out = ctx;
   return RGB_OK;
 }
@@ -222,17 +240,8 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
     HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
   }
 #endif
-#if defined(RGB_X_STATE_MEM) && RGB_X_STATE_MEM
-  /* experiment (tools/build_variants.sh): the two hot state arrays in fine-grained (1) / uncached (2) memory */
-  {
-    const unsigned fl = RGB_X_STATE_MEM == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached;
-    HIPCHK(ctx, hipExtMallocWithFlags((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64), fl));
-    HIPCHK(ctx, hipExtMallocWithFlags((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64), fl));
-  }
-#else
   HIPCHK(ctx, hipMalloc((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));
-#endif
   HIPCHK(ctx, hipMalloc((void **)&d.runs, (size_t)S * d.max_runs * 2 * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.cond, (size_t)S * 4 * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.qry, (size_t)S * RGB_QRY_WORDS * sizeof(u64)));
@@ -301,13 +310,14 @@ int rgb_upload_state(rgb_ctx *ctx, uint32_t first, uint32_t n, const rgb_server_
     if (rc) return rc;
   }
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  std::lock_guard<std::mutex> lk(ctx->state_mu);
   for (u32 base = 0; base < n; base += ctx->stage_cap) {
     u32 cnt = n - base < ctx->stage_cap ? n - base : ctx->stage_cap;
     memcpy(ctx->h_stage, in + base, (size_t)cnt * sizeof(rgb_server_state));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, (size_t)cnt * sizeof(rgb_server_state),
                                hipMemcpyHostToDevice, ctx->stream));
     int rc = rgb_launch_pack(ctx->dev, ctx->d_stage, first + base, cnt, ctx->stream);
-    if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+    if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return RGB_OK;
@@ -318,10 +328,11 @@ int rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_stat
   if (!ctx->registered) return RGB_E_STATE;
   if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  std::lock_guard<std::mutex> lk(ctx->state_mu);
   for (u32 base = 0; base < n; base += ctx->stage_cap) {
     u32 cnt = n - base < ctx->stage_cap ? n - base : ctx->stage_cap;
     int rc = rgb_launch_unpack(ctx->dev, ctx->d_stage, first + base, cnt, ctx->stream);
-    if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+    if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_stage, (size_t)cnt * sizeof(rgb_server_state),
                                hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -344,11 +355,13 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   if (!ctx || (!msgs && n)) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   if (n > ctx->cfg.ring_capacity) return RGB_E_INVAL;
-  if (ctx->in_flight == ctx->ring.size()) return RGB_E_FULL;
-  for (u32 i = 0; i < n; ++i) {
+  for (u32 i = 0; i < n; ++i) {                  /* validation needs no lock: it reads the batch only */
     int rc = validate_msg(ctx, msgs[i]);
     if (rc) return rc;
   }
+  std::lock_guard<std::mutex> lk(ctx->submit_mu);
+  /* acquire: a slot the consumer gave back (release decrement in rgb_collect) is really free */
+  if (ctx->in_flight.load(std::memory_order_acquire) == ctx->ring.size()) return RGB_E_FULL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   rgb_slot &s = ctx->ring[ctx->head];
   /* sub-tick rounds: round r = every server's r-th message of this batch, in order */
@@ -406,12 +419,12 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
         if (real < cnt) {      /* NOP slots sort last: the generic kernel writes their empty decisions */
           rc = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
                                s.d_rpcs, off + real, off + real, ctx->stream);
-          if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+          if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
         }
       } else {
         rc = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off,
                              ctx->stream);
-        if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+        if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
       }
     }
     HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost,
@@ -439,7 +452,10 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
   s.busy = true;
   ctx->head = (ctx->head + 1) % (u32)ctx->ring.size();
-  ctx->in_flight++;
+  /* publish: everything written to the slot above happens-before the consumer's acquire load */
+  ctx->in_flight.fetch_add(1, std::memory_order_release);
+  { std::lock_guard<std::mutex> wl(ctx->wait_mu); }
+  ctx->wait_cv.notify_one();
   return RGB_OK;
 }
 
@@ -448,27 +464,37 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
   if (!ctx) return RGB_E_INVAL;
   if (n_out) *n_out = 0;
   if (n_rpc_out) *n_rpc_out = 0;
-  if (ctx->in_flight == 0) return RGB_E_EMPTY;
+  std::lock_guard<std::mutex> lk(ctx->collect_mu);
+  if (ctx->in_flight.load(std::memory_order_acquire) == 0) return RGB_E_EMPTY;
   rgb_slot &s = ctx->ring[ctx->tail];
-  if (s.n > cap || (s.n && !out)) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   HIPCHK(ctx, hipEventSynchronize(s.done));
+  u32 n_rpc = 0;
+  for (u32 p = 0; p < s.n; ++p) n_rpc += s.h_dec[p].n_rpcs;
+  /* a buffer that is too small leaves the batch in the ring: the sizes it needs are reported and the
+   * caller retries (nothing is dropped, the ring is not wedged) */
+  if (s.n > cap || (s.n && !out) || (rpc_out && n_rpc > rpc_cap)) {
+    if (n_out) *n_out = s.n;
+    if (n_rpc_out) *n_rpc_out = n_rpc;
+    return (s.n > cap || (s.n && !out)) ? RGB_E_INVAL : RGB_E_FULL;
+  }
   /* decisions back in submission order; remember where each one ran on the device */
   std::vector<u32> pos_of(s.n);
-  u32 n_rpc = 0;
   for (u32 p = 0; p < s.n; ++p) {
     out[s.perm[p]] = s.h_dec[p];
     pos_of[s.perm[p]] = p;
-    n_rpc += s.h_dec[p].n_rpcs;
   }
+  int rc_out = RGB_OK;
   if (n_rpc && rpc_out) {
     u32 k = 0;
-    for (u32 i = 0; i < s.n && k < rpc_cap; ++i) {           /* ordered by (msg_index, peer) */
+    for (u32 i = 0; i < s.n && rc_out == RGB_OK; ++i) {      /* ordered by (msg_index, peer) */
       const u32 p = pos_of[i];
       const u32 nr = s.h_dec[p].n_rpcs;
       if (!nr) continue;
-      if (p < s.rpc_lo || p >= s.rpc_lo + s.rpc_cnt) return RGB_E_STATE;   /* a kind that cannot emit rpcs did */
-      for (u32 q = 0; q < nr && k < rpc_cap; ++q) {
+      /* a kind that cannot emit rpcs did: unrecoverable for this batch -- it is consumed all the same, so
+       * the ring moves on and the caller sees the error once */
+      if (p < s.rpc_lo || p >= s.rpc_lo + s.rpc_cnt || nr > ctx->rpc_stride) { rc_out = RGB_E_STATE; break; }
+      for (u32 q = 0; q < nr; ++q) {
         rgb_rpc r = s.h_rpcs[(size_t)(p - s.rpc_lo) * ctx->rpc_stride + q];
         r.msg_index = i;
         rpc_out[k++] = r;
@@ -476,12 +502,46 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
     }
   }
   if (n_out) *n_out = s.n;
-  if (n_rpc_out) *n_rpc_out = n_rpc;        /* may exceed rpc_cap: the caller sees the overflow */
+  if (n_rpc_out) *n_rpc_out = n_rpc;
   if (tick_out) *tick_out = s.tick;
   s.busy = false;
   ctx->tail = (ctx->tail + 1) % (u32)ctx->ring.size();
-  ctx->in_flight--;
-  return RGB_OK;
+  /* release: the slot's buffers are free for the next submit that observes the lower count */
+  ctx->in_flight.fetch_sub(1, std::memory_order_release);
+  return rc_out;
+}
+
+/* Park until a batch is in flight (RGB_OK), the timeout passes or rgb_wake is called (RGB_E_EMPTY). */
+int rgb_wait(rgb_ctx *ctx, uint32_t timeout_ms) {
+  if (!ctx) return RGB_E_INVAL;
+  std::unique_lock<std::mutex> lk(ctx->wait_mu);
+  const u32 gen = ctx->wake_gen.load(std::memory_order_acquire);
+  const bool ok = ctx->wait_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] {
+    return ctx->in_flight.load(std::memory_order_acquire) != 0 || ctx->wake_gen.load(std::memory_order_acquire) != gen;
+  });
+  if (!ok) return RGB_E_EMPTY;
+  return ctx->in_flight.load(std::memory_order_acquire) != 0 ? RGB_OK : RGB_E_EMPTY;
+}
+
+void rgb_wake(rgb_ctx *ctx) {
+  if (!ctx) return;
+  ctx->wake_gen.fetch_add(1, std::memory_order_release);
+  { std::lock_guard<std::mutex> wl(ctx->wait_mu); }
+  ctx->wait_cv.notify_all();
+}
+
+uint32_t rgb_in_flight(const rgb_ctx *ctx) { return ctx ? ctx->in_flight.load(std::memory_order_acquire) : 0; }
+
+/* splitmix64 finaliser: the hash of the group partition (ra_amd/shard.py computes the same) */
+static inline uint64_t rgb_mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+uint32_t rgb_route(uint64_t group_uid, uint32_t n_contexts) {
+  return n_contexts <= 1 ? 0u : (uint32_t)(rgb_mix64(group_uid) % n_contexts);
 }
 
 int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
@@ -511,7 +571,7 @@ int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
     if (cnt > tick_stride) return RGB_E_INVAL;
     int rc = rgb_launch_tick(ctx->dev, -1, m + off, cnt, dn ? dn + t : nullptr, d + off, (rgb_rpc *)d_rpcs, 0,
                              (u32)off, st);
-    if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+    if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
   return RGB_OK;
 }
@@ -527,7 +587,7 @@ int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_ms
   if (!ctx->d_synth) HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth, 4 * (RGB_MSG_KIND_MAX + 1) * sizeof(u32)));
   int rc = rgb_launch_synth(ctx->dev, seed, tick, (rgb_msg *)d_msgs, ctx->d_synth, (u32 *)d_kind_counts,
                             (u32 *)d_n, st);
-  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   return RGB_OK;
 }
 
@@ -538,7 +598,7 @@ int rgb_synth_apply_tick_device(rgb_ctx *ctx, const void *d_msgs, uint32_t max_m
   void *st = stream ? stream : (void *)ctx->stream;
   int rc = rgb_launch_tick_classes(ctx->dev, (const rgb_msg *)d_msgs, nullptr, ctx->d_synth, max_msgs,
                                    (rgb_decision *)d_decisions, (rgb_rpc *)d_rpcs, 0, 0, st);
-  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   return RGB_OK;
 }
 
@@ -547,7 +607,7 @@ int rgb_snapshot_device(rgb_ctx *ctx, void *d_rows, void *stream) {
   if (!ctx->registered) return RGB_E_STATE;
   void *st = stream ? stream : (void *)ctx->stream;
   int rc = rgb_launch_leaderboard(ctx->dev, (rgb_leaderboard_row *)d_rows, st);
-  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   return RGB_OK;
 }
 
@@ -570,7 +630,7 @@ int rgb_state_checksum(rgb_ctx *ctx, uint32_t first, uint32_t n, uint64_t *out) 
   if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   int rc = rgb_launch_checksum(ctx->dev, first, n, ctx->d_sums, ctx->stream);
-  if (rc) { ctx->last_hip = rc; return RGB_E_HIP; }
+  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   std::vector<u64> sums(n);
   HIPCHK(ctx, hipMemcpyAsync(sums.data(), ctx->d_sums, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost,
                              ctx->stream));

@@ -59,62 +59,6 @@ __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
 #define ST16(ptr, val) do { *(ptr) = (val); } while (0)
 #define ST8(ptr, val) do { *(ptr) = (val); } while (0)
 
-/* 16-byte / 8-byte stores with an explicit cache policy: POL 0 plain (write-back L2), 1 non-temporal,
- * 2 system-scope write-through (sc0 sc1).  The 16-byte form takes any 4-byte aligned address. */
-template <int POL>
-__device__ __forceinline__ void store16_pol(void *p, ulonglong2 v) {
-#ifndef RGB_HOST_EMULATION
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  v4u d;
-  d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
-  if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
-  else if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(d) : "memory");
-#else
-  memcpy(p, &v, 16);
-#endif
-}
-template <int POL>
-__device__ __forceinline__ void store8_pol(void *p, u64 v) {
-#ifndef RGB_HOST_EMULATION
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  v2u d;
-  d.x = (unsigned)v; d.y = (unsigned)(v >> 32);
-  if (POL == 1) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
-  else if (POL == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
-  else asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(d) : "memory");
-#else
-  memcpy(p, &v, 8);
-#endif
-}
-
-/* experiment switches (compile time; the defaults are the product): see tools/build_variants.sh
- *   RGB_X_COOPWB  0 = each lane stores its dirty 16-byte pieces; 1/2/3 = dirty pieces go to the lane's LDS row and
- *                 the wavefront writes whole dirty 128-byte lines back cooperatively (policy 0/1/2 = value - 1)
- *   RGB_X_RPC16   0 = seven 8-byte stores per rpc record; 1/2/3 = 16+16+16+8-byte stores, policy value - 1
- *   RGB_X_PEERS   peers-row word stores: policy 0/1/2 */
-#ifndef RGB_X_COOPWB
-#define RGB_X_COOPWB 0
-#endif
-#ifndef RGB_X_RPC16
-#define RGB_X_RPC16 0
-#endif
-#ifndef RGB_X_HOTNT
-#define RGB_X_HOTNT 0      /* 1 = the cooperative hot-line fetch uses non-temporal loads */
-#endif
-#ifndef RGB_X_REREAD
-#define RGB_X_REREAD 0     /* with RGB_X_COOPWB: compare against the LDS row at commit instead of the first read */
-#endif
-#ifndef RGB_X_PEERS
-#define RGB_X_PEERS 0
-#endif
-
-#if RGB_X_PEERS
-#define PEER_ST8(ptr, val) store8_pol<RGB_X_PEERS>((ptr), (val))
-#else
-#define PEER_ST8(ptr, val) ST8(ptr, val)
-#endif
-
 /* -DRGB_X_MARK: comment markers around every class path in the assembly (tools/class_isa.py counts per class) */
 #if defined(RGB_X_MARK) && !defined(RGB_HOST_EMULATION)
 #define RGB_MARK(what, rank) asm volatile("; RGB_MARK " what " %0" ::"n"(rank));
@@ -122,16 +66,21 @@ __device__ __forceinline__ void store8_pol(void *p, u64 v) {
 #define RGB_MARK(what, rank)
 #endif
 
-/* one outbound rpc record (56 B, layout of rgb_rpc) */
-__device__ __forceinline__ void store_rpc(rgb_rpc *slot, u64 w0, u64 w1, u64 w2, u64 w3, u64 w4, u64 w5, u64 w6) {
-  u64 *o = reinterpret_cast<u64 *>(slot);
-#if RGB_X_RPC16
-  store16_pol<RGB_X_RPC16 - 1>(o + 0, make_ulonglong2(w0, w1));
-  store16_pol<RGB_X_RPC16 - 1>(o + 2, make_ulonglong2(w2, w3));
-  store16_pol<RGB_X_RPC16 - 1>(o + 4, make_ulonglong2(w4, w5));
-  store8_pol<RGB_X_RPC16 - 1>(o + 6, w6);
+/* Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): lane l's bytes land at lds_base + 16 * l -- the
+ * destination of the instruction is wave-uniform base + lane * 16 -- without passing through a register.  NT = data
+ * that is read once.  glds_wait() = the issuing wave's copies have landed (a one-wave workgroup needs nothing else). */
+template <bool NT>
+__device__ __forceinline__ void glds16(const void *g, void *lds_base) {
+#ifdef RGB_HOST_EMULATION
+  memcpy(static_cast<char *>(lds_base) + 16 * emu::lane(), g, 16);
 #else
-  ST8(o + 0, w0); ST8(o + 1, w1); ST8(o + 2, w2); ST8(o + 3, w3); ST8(o + 4, w4); ST8(o + 5, w5); ST8(o + 6, w6);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, NT ? 2 : 0);
+#endif
+}
+__device__ __forceinline__ void glds_wait() {
+#ifndef RGB_HOST_EMULATION
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 
@@ -837,10 +786,11 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
        * VGPRs fewer across the loop for N = 5) */
       L.dcs_ci |= 1u << i;
       if (rpcs != nullptr) {
-        /* fixed slot: this message's (n_out-1)-th record */
-        store_rpc(rpcs + (size_t)slot_base + (n_out - 1), (u64)msg_index | ((u64)L.server << 32),
-                  (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16), L.ct, rp_idx, rp_term, L.ci,
-                  new_ni);
+        /* fixed slot: this message's (n_out-1)-th record; 56 B = 7 x 8-B stores */
+        u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
+        ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
+        ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
+        ST8(o + 2, L.ct); ST8(o + 3, rp_idx); ST8(o + 4, rp_term); ST8(o + 5, L.ci); ST8(o + 6, new_ni);
       }
     }
   }
@@ -978,9 +928,10 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
     }
     n_out += 1;
     if (rpcs != nullptr) {
-      store_rpc(rpcs + (size_t)slot_base + (n_out - 1), (u64)msg_index | ((u64)L.server << 32),
-                (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16), L.ct, rp_idx, rp_term, L.ci,
-                new_ni);
+      u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
+      ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
+      ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
+      ST8(o + 2, L.ct); ST8(o + 3, rp_idx); ST8(o + 4, rp_term); ST8(o + 5, L.ci); ST8(o + 6, new_ni);
     }
   }
   return 0;
@@ -1550,7 +1501,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
                                                 u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr,
-                                                const ulonglong2 *pre = nullptr, unsigned *row_dirty = nullptr) {
+                                                const ulonglong2 *pre = nullptr, unsigned swz = 0) {
   Lane L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -1580,7 +1531,9 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   ulonglong2 h0, h1, h2, h3, h4, h5, h6, h7;
   if (RGB_KNOB(dev, 8u)) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_ulonglong2(0, 0); h0.y = 0x1Full << PK_PRESENT_SH; }
   else if (PRE) {     /* the wavefront fetched the lines cooperatively into LDS: pre = this lane's row */
-    h0 = pre[0]; h1 = pre[1]; h2 = pre[2]; h3 = pre[3]; h4 = pre[4]; h5 = pre[5]; h6 = pre[6]; h7 = pre[7];
+    /* unpadded 128-byte rows: piece p sits at position p ^ swz (conflict-free 16-byte LDS reads, see the fetch) */
+    h0 = pre[0 ^ swz]; h1 = pre[1 ^ swz]; h2 = pre[2 ^ swz]; h3 = pre[3 ^ swz];
+    h4 = pre[4 ^ swz]; h5 = pre[5 ^ swz]; h6 = pre[6 ^ swz]; h7 = pre[7 ^ swz];
   } else {
     h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; h7 = hp[7];
   }
@@ -1707,35 +1660,14 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (L.dmi | L.dni | L.dcs | L.dcs_ci) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      if (L.dmi & (1u << k)) PEER_ST8(L.peers + k, L.pmi[k]);
-      if (L.dni & (1u << k)) PEER_ST8(L.peers + N + k, L.pni[k]);
-      if (L.dcs & (1u << k)) PEER_ST8(L.peers + 2 * N + k, L.pcs[k]);
-      else if (L.dcs_ci & (1u << k)) PEER_ST8(L.peers + 2 * N + k, L.ci);
+      if (L.dmi & (1u << k)) ST8(L.peers + k, L.pmi[k]);
+      if (L.dni & (1u << k)) ST8(L.peers + N + k, L.pni[k]);
+      if (L.dcs & (1u << k)) ST8(L.peers + 2 * N + k, L.pcs[k]);
+      else if (L.dcs_ci & (1u << k)) ST8(L.peers + 2 * N + k, L.ci);
     }
   }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
-#if RGB_X_COOPWB
-  if (PRE && row_dirty != nullptr) {
-    /* the class kernel writes whole dirty lines back cooperatively: the changed pieces go to this lane's LDS row */
-    ulonglong2 *row = const_cast<ulonglong2 *>(pre);
-#if !defined(RGB_HOST_EMULATION) && RGB_X_REREAD
-    asm volatile("" : "+v"(row));      /* the originals are re-read from the row: h0..h7 need not stay in registers */
-#endif
-    unsigned dirty = 0;
-    if (L.n_runs < 2) { L.prs = 0; L.prt = 0; }         /* canonical: no run n-2 */
-#if RGB_X_REREAD
-#define RGB_WB(K, A, B) { const ulonglong2 o = row[K]; if ((A) != o.x || (B) != o.y) { row[K] = make_ulonglong2((A), (B)); dirty = 1; } }
-#else
-#define RGB_WB(K, A, B) { if ((A) != h##K.x || (B) != h##K.y) { row[K] = make_ulonglong2((A), (B)); dirty = 1; } }
-#endif
-    RGB_WB(0, L.ct, L.pk) RGB_WB(1, L.ci, L.la) RGB_WB(2, L.li, L.lt) RGB_WB(3, L.lwi, L.lwt)
-    RGB_WB(4, L.si, L.st) RGB_WB(5, L.first, L.lrs) RGB_WB(6, L.lrt, L.prs) RGB_WB(7, L.prt, L.pend)
-#undef RGB_WB
-    if (TM && L.token != token0) ST8(qry_row(L) + QRY_TOKEN, L.token);
-    *row_dirty = dirty;
-  } else
-#endif
   if (!RGB_KNOB(dev, 1u)) {
   if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
   if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la));
@@ -1766,7 +1698,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
  * is a fully coalesced 1 KiB wave transaction (lane stride 16 B) instead of 64 strided 16-byte
  * pieces; LDS slots are padded to 80 B so the per-lane 16-byte reads/writes are conflict-free. */
 #define RGB_IO_SLOT 5   /* 16-byte units per LDS record slot: 64 B payload + 16 B pad */
-#define RGB_HOT_SLOT 9  /* 16-byte units per LDS hot-line row: 128 B + 16 B pad */
+#define RGB_HOT_SLOT 9  /* 16-byte units reserved per lane in the class kernel's LDS area (rows use 8, unpadded) */
 
 template <int N, int KIND>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
@@ -1902,28 +1834,29 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   const u32 cnt = end - base < RGB_TICK_BLOCK ? end - base : RGB_TICK_BLOCK;
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
   {
-    /* four coalesced 1 KiB wave loads in flight at once (read once: non-temporal); pieces past the
-     * slice's end re-read its last piece, their LDS slots are never consumed */
+    /* four 1 KiB global -> LDS copies in flight (read once: non-temporal), no staging registers and no ds_write
+     * pass: record r lands at io[4 r ..], its piece p at position p ^ ((r >> 2) & 3).  The permutation is applied to
+     * the SOURCE address (the instruction's destination is lane-linear) and again when the owner reads its record:
+     * conflict-free 16-byte LDS reads without padding.  Pieces past the slice's end re-read its last piece, their
+     * LDS slots are never consumed. */
     const u32 last = cnt * 4u - 1u;
-    ulonglong2 v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const u32 piece = k * RGB_TICK_BLOCK + lane;
-      v[k] = ld16<true>(src + (piece < last ? piece : last));
+      const u32 r = piece >> 2;
+      const u32 sp = (r << 2) | ((piece & 3u) ^ ((r >> 2) & 3u));
+      glds16<true>(src + (sp < last ? sp : last), io + k * RGB_TICK_BLOCK);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const u32 piece = k * RGB_TICK_BLOCK + lane;
-      io[(piece >> 2) * RGB_IO_SLOT + (piece & 3u)] = v[k];
-    }
+    glds_wait();
   }
   lds_barrier();
 #ifdef RGB_PROFILE
   if (RGB_KNOB(dev, 16u)) t1 = wall_clock64();
 #endif
   const bool active = lane < cnt;
-  const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
-                   m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
+  const u32 mswz = (lane >> 2) & 3u;
+  const ulonglong2 m0 = io[lane * 4 + (0 ^ mswz)], m1 = io[lane * 4 + (1 ^ mswz)],
+                   m2 = io[lane * 4 + (2 ^ mswz)], m3 = io[lane * 4 + (3 ^ mswz)];
   /* Cooperative hot-line fetch: 8 lanes read one server's 128-byte line as ONE coalesced access, so
    * an instruction touches 8 lines instead of 64 (the CU's L1 looks up one line per cycle); the lines
    * reach their owners through LDS rows that overlay the record staging area (the messages are in
@@ -1944,17 +1877,20 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       pf0 = pp[0];
       if (3 * N > 16) pf1 = pp[16];
     }
-    ulonglong2 v[8];
+    /* row r = 8k + lane/8 lands at io[8 r ..] (1 KiB per instruction, lane-linear destination); position q of the
+     * row holds piece q ^ ((r >> 1) & 7): the 16 lanes the LDS serves together read 16 different bank groups */
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const u32 sj = __shfl(srv, 8 * k + (int)(lane >> 3), 64);
-      v[k] = ld16<(RGB_X_HOTNT != 0)>(reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS) + (lane & 7u));
+      const u32 r = 8 * k + (lane >> 3);
+      const u32 sj = __shfl(srv, (int)r, 64);
+      glds16<false>(reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS) + ((lane & 7u) ^ ((r >> 1) & 7u)),
+                    io + k * RGB_TICK_BLOCK);
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) io[(8 * k + (lane >> 3)) * RGB_HOT_SLOT + (lane & 7u)] = v[k];
+    glds_wait();
   }
   lds_barrier();
-  const ulonglong2 *hrow = io + lane * RGB_HOT_SLOT;
+  const ulonglong2 *hrow = io + lane * 8;
+  const unsigned hswz = (lane >> 1) & 7u;
 #ifndef RGB_HOST_EMULATION
   asm volatile("" ::"v"(pf0), "v"(pf1));   /* the touch loads above stay in the program */
 #endif
@@ -1963,17 +1899,12 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #ifdef RGB_PROFILE
   tlp = tl;
 #endif
-  unsigned *rdp = nullptr;
-#if RGB_X_COOPWB
-  unsigned row_dirty = 0;
-  rdp = &row_dirty;
-#endif
   if (active) {
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
     RGB_MARK("begin", RANK)                                                                             \
     process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
-                                  hrow, rdp);                                                           \
+                                  hrow, hswz);                                                          \
     RGB_MARK("end", RANK)                                                                               \
     break;
     switch (cls) {
@@ -1985,7 +1916,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
       default:
         process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                          msg_index_base, d, tlp, hrow, rdp);
+                                                          msg_index_base, d, tlp, hrow, hswz);
         break;
     }
 #undef RGB_CASE
@@ -1994,25 +1925,6 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #endif
   }
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
-#if RGB_X_COOPWB
-  {
-    /* cooperative write-back: 8 lanes store one dirty server's whole 128-byte line (full-line writes, 8 lines
-     * per instruction), the mirror image of the fetch */
-    const unsigned long long dm = __ballot(row_dirty != 0);
-    const u32 sv = (u32)(d.w[0] & 0xFFFFFFFFull);   /* the decision's first word carries the server id */
-    if (dm != 0ull && !RGB_KNOB(dev, 1u)) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const u32 r = 8 * k + (lane >> 3);
-        const u32 sj = __shfl(sv, (int)r, 64);
-        if ((dm >> r) & 1ull)
-          store16_pol<RGB_X_COOPWB - 1>(dev.hot + (size_t)sj * RGB_HOT_WORDS + 2u * (lane & 7u),
-                                        io[r * RGB_HOT_SLOT + (lane & 7u)]);
-      }
-    }
-    lds_barrier();
-  }
-#endif
   if (active) {
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);

@@ -21,7 +21,8 @@ EXPORTS = [
     "rgb_abi_version", "rgb_struct_size", "rgb_strerror", "rgb_default_config", "rgb_open",
     "rgb_close", "rgb_last_hip_error", "rgb_register_groups", "rgb_n_servers", "rgb_upload_state",
     "rgb_download_state", "rgb_submit", "rgb_collect", "rgb_run_ticks_device", "rgb_snapshot",
-    "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize",
+    "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize", "rgb_wait", "rgb_wake", "rgb_in_flight",
+    "rgb_route",
 ]
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_apply_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
@@ -92,6 +93,13 @@ def lib():
     L.rgb_snapshot_device.argtypes = [vp, vp, vp]
     L.rgb_state_checksum.argtypes = [vp, u32, u32, u64p]
     L.rgb_synchronize.argtypes = [vp]
+    L.rgb_wait.argtypes = [vp, u32]
+    L.rgb_wake.argtypes = [vp]
+    L.rgb_wake.restype = None
+    L.rgb_in_flight.argtypes = [vp]
+    L.rgb_in_flight.restype = C.c_uint32
+    L.rgb_route.argtypes = [C.c_uint64, u32]
+    L.rgb_route.restype = C.c_uint32
     L.rgb_synth_tick_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     L.rgb_wal_adler32_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, vp]
@@ -200,11 +208,28 @@ class RaGpuBatch:
             dec = np.empty(cap, dtype=abi.DECISION_DTYPE)
             rpcs = np.empty(max(rpc_cap, 1), dtype=abi.RPC_DTYPE)
         n, nr, tick = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
-        self._check(self._L.rgb_collect(self._h, dec.ctypes.data, cap, C.byref(n), rpcs.ctypes.data,
-                                        rpc_cap, C.byref(nr), C.byref(tick)), "rgb_collect")
-        if nr.value > rpc_cap:
-            raise RgbError(abi.E_FULL, f"rpc buffer overflow ({nr.value} > {rpc_cap})")
+        rc = self._L.rgb_collect(self._h, dec.ctypes.data, cap, C.byref(n), rpcs.ctypes.data,
+                                 rpc_cap, C.byref(nr), C.byref(tick))
+        if rc in (abi.E_FULL, abi.E_INVAL) and out is None and (n.value > cap or nr.value > rpc_cap):
+            # the batch stayed in the ring and reported the sizes it needs: retry once with them
+            cap, rpc_cap = max(cap, n.value), max(rpc_cap, nr.value)
+            dec = np.empty(max(cap, 1), dtype=abi.DECISION_DTYPE)
+            rpcs = np.empty(max(rpc_cap, 1), dtype=abi.RPC_DTYPE)
+            rc = self._L.rgb_collect(self._h, dec.ctypes.data, cap, C.byref(n), rpcs.ctypes.data,
+                                     rpc_cap, C.byref(nr), C.byref(tick))
+        self._check(rc, "rgb_collect")
         return dec[:n.value], rpcs[:nr.value], tick.value
+
+    def wait(self, timeout_ms: int = 1000) -> bool:
+        """Park until a batch is in flight (True) or the timeout / a wake() passes (False)."""
+        return self._L.rgb_wait(self._h, timeout_ms) == abi.OK
+
+    def wake(self):
+        self._L.rgb_wake(self._h)
+
+    @property
+    def in_flight(self) -> int:
+        return int(self._L.rgb_in_flight(self._h))
 
     def step(self, msgs: np.ndarray):
         """submit + collect: decisions in submission order and the pipelined rpcs."""

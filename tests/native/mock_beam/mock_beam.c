@@ -105,6 +105,21 @@ int enif_thread_create(char *name, ErlNifTid *tid, void *(*fn)(void *), void *ar
 }
 int enif_thread_join(ErlNifTid tid, void **ret) { int rc = pthread_join(tid->th, ret); free(tid); return rc; }
 
+struct ErlNifMutex_ { pthread_mutex_t mu; };
+ErlNifMutex *enif_mutex_create(char *name) { ErlNifMutex *m = (ErlNifMutex *)calloc(1, sizeof *m); pthread_mutex_init(&m->mu, NULL); return m; }
+void enif_mutex_destroy(ErlNifMutex *m) { pthread_mutex_destroy(&m->mu); free(m); }
+void enif_mutex_lock(ErlNifMutex *m) { pthread_mutex_lock(&m->mu); }
+void enif_mutex_unlock(ErlNifMutex *m) { pthread_mutex_unlock(&m->mu); }
+/* the BEAM would run fp later on a dirty scheduler thread; the mock runs it at once and counts the reschedules */
+static long dirty_reschedules = 0;
+ERL_NIF_TERM enif_schedule_nif(ErlNifEnv *e, const char *fun_name, int flags,
+                               ERL_NIF_TERM (*fp)(ErlNifEnv *, int, const ERL_NIF_TERM[]), int argc,
+                               const ERL_NIF_TERM argv[]) {
+  if (flags) __atomic_add_fetch(&dirty_reschedules, 1, __ATOMIC_RELAXED);
+  return fp(e, argc, argv);
+}
+long mock_dirty_reschedules(void) { return __atomic_load_n(&dirty_reschedules, __ATOMIC_RELAXED); }
+
 /* ---- the test driver's side (ctypes) ---- */
 const ErlNifFunc *mock_nif_funcs(int *n);
 int mock_nif_load(ErlNifEnv *env);

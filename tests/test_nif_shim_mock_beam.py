@@ -37,6 +37,9 @@ def beam(emulated_kernels_so, tmp_path_factory):
         cmd[0] = clang
         cmd[1:1] = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-shared-libsan"] + \
                    (["-fno-sanitize-recover=undefined"] if san == "undefined" else [])
+        # RGB_EMU_SANITIZE=thread: the concurrent-producer test below under ThreadSanitizer, run as
+        #   RGB_EMU_SANITIZE=thread LD_PRELOAD=<clang lib dir>/libclang_rt.tsan-x86_64.so \
+        #       TSAN_OPTIONS=halt_on_error=1 pytest tests/test_nif_shim_mock_beam.py -k "concurrent or fans"
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     L = C.CDLL(str(out))
@@ -50,7 +53,7 @@ def beam(emulated_kernels_so, tmp_path_factory):
                             ("mock_int_value", C.c_int64, [vp]), ("mock_bin_data", vp, [vp]),
                             ("mock_bin_size", C.c_size_t, [vp]), ("mock_gc_resource_term", None, [vp]),
                             ("mock_live_resources", C.c_long, []), ("mock_dtor_calls", C.c_long, []),
-                            ("mock_recv", vp, [C.c_int, C.POINTER(u64)])]:
+                            ("mock_recv", vp, [C.c_int, C.POINTER(u64)]), ("mock_dirty_reschedules", C.c_long, [])]:
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
     assert L.mock_load() == 0, "on_load: resource type or ABI version"
@@ -145,6 +148,9 @@ def test_shim_round_trip_against_the_checker(beam, oracle_lib):
     assert ok == "ok" and state_bin == cpu.get_state().tobytes()
     ok, lb = beam.call("snapshot", ctx, G)
     assert ok == "ok" and len(lb) == G * 32
+    # the binary is sized from the registration: a caller's smaller (or larger) NGroups is badarg, never an overrun
+    assert beam.call("snapshot", ctx, G - 1) == "badarg"
+    assert beam.call("snapshot", ctx, G + 1) == "badarg"
     # an error code from the library comes back as {error, Atom}
     assert beam.call("download_state", ctx, G * N, 8) == ("error", "invalid")
 
@@ -171,6 +177,7 @@ def test_collector_thread_fans_batches_back_in_order(beam, oracle_lib):
     assert beam.call("start_collector", ctx, 99) == "badarg"           # not a pid
     assert beam.call("start_collector", ctx, owner) == "ok"
     assert beam.call("start_collector", ctx, owner) == "badarg"        # already running
+    assert beam.call("collect", ctx) == ("error", "collector_running")  # one consumer at a time
     wants = []
     for tick in range(10, 16):
         msgs = fuzz.random_msgs(rng, cpu.get_state(), N)
@@ -202,6 +209,146 @@ def test_collector_thread_fans_batches_back_in_order(beam, oracle_lib):
     cpu.close()
 
 
+def test_collector_fans_decisions_back_to_the_owning_processes(beam, oracle_lib):
+    """register_owner/4: every gen_statem gets ONE message per batch holding only its servers' decisions, in
+    submission order, with their rpc records re-indexed; unregistered servers go to the default owner
+    (reference interception point: per process, src/ra_server_proc.erl:1356-1397)."""
+    G, N = 40, 5
+    rng = np.random.default_rng(79)
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    ok, ctx = beam.call("open", 0, 16, 4, 512)
+    assert ok == "ok"
+    assert beam.call("register_owner", ctx, 0, 1, Opaque(beam.L.mock_pid(1))) == "badarg"   # before register_groups
+    assert beam.call("register_groups", ctx, G, N) == "ok"
+    assert beam.call("upload_state", ctx, 0, st.tobytes()) == "ok"
+    # pid 1000+g owns the five servers of group g for g < 30; the last ten groups stay with the default owner
+    for g in range(30):
+        assert beam.call("register_owner", ctx, g * N, N, Opaque(beam.L.mock_pid(1000 + g))) == "ok"
+    assert beam.call("register_owner", ctx, G * N - 1, 2, Opaque(beam.L.mock_pid(7))) == "badarg"   # out of range
+    assert beam.call("start_collector", ctx, Opaque(beam.L.mock_pid(4242))) == "ok"
+    for tick in range(1, 4):
+        msgs = fuzz.random_msgs(rng, cpu.get_state(), N)
+        want_d, want_r = cpu.step(msgs)
+        assert beam.call("submit", ctx, msgs.tobytes(), tick) == "ok"
+        owner_of = lambda srv: 1000 + srv // N if srv // N < 30 else 4242
+        owners = []
+        for d in want_d:                                       # first-appearance order
+            if owner_of(int(d["server"])) not in owners:
+                owners.append(owner_of(int(d["server"])))
+        got = {}
+        for _ in owners:
+            to, msg = beam.recv()
+            assert msg is not None, "an owner got nothing"
+            assert msg[0] == "ra_gpu_batch" and msg[1] == tick and to not in got
+            got[to] = msg
+        assert sorted(got) == sorted(owners)
+        for o in owners:
+            idx = [i for i, d in enumerate(want_d) if owner_of(int(d["server"])) == o]
+            _tag, _t, n, dec_bin, rpc_bin = got[o]
+            assert n == len(idx) and dec_bin == want_d[idx].tobytes(), f"owner {o}: decisions"
+            rp = np.frombuffer(rpc_bin, dtype=abi.RPC_DTYPE)
+            exp = []
+            for pos, i in enumerate(idx):
+                for r in want_r[want_r["msg_index"] == i]:
+                    r = r.copy(); r["msg_index"] = pos; exp.append(r)
+            exp = np.array(exp, dtype=abi.RPC_DTYPE) if exp else np.zeros(0, dtype=abi.RPC_DTYPE)
+            assert fuzz.sort_rpcs(rp.copy()).tobytes() == fuzz.sort_rpcs(exp).tobytes(), f"owner {o}: rpcs"
+    assert beam.recv(timeout_ms=200) == (None, None)           # nothing else was sent
+    assert beam.call("stop_collector", ctx) == "ok"
+    beam.L.mock_gc_resource_term(ctx.t)
+    cpu.close()
+
+
+def test_concurrent_producers_and_the_collector_thread(beam, oracle_lib):
+    """Several processes submit at once (submit is thread-safe) while the collector thread consumes:
+    every batch comes back exactly once and whole, per-producer order is kept, the engine ends in the state the
+    checker reaches for the same batches in the order they were accepted.  (The sanitizer build of this module
+    runs it under ThreadSanitizer.)"""
+    import threading
+    G, N, P, ROUNDS = 64, 3, 4, 12
+    rng = np.random.default_rng(80)
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    ok, ctx = beam.call("open", 0, 16, 4, 512)
+    assert ok == "ok"
+    assert beam.call("register_groups", ctx, G, N) == "ok"
+    assert beam.call("upload_state", ctx, 0, st.tobytes()) == "ok"
+    assert beam.call("start_collector", ctx, Opaque(beam.L.mock_pid(4242))) == "ok"
+    # producer p owns the groups g with g % P == p: batches of different producers touch disjoint servers, so the
+    # final state does not depend on how their submits interleave
+    per = [[] for _ in range(P)]
+    states = cpu.get_state()
+    for p in range(P):
+        for r in range(ROUNDS):
+            m = fuzz.random_msgs(rng, states, N)
+            m = m[(m["server"] // N) % P == p]
+            per[p].append(m)
+    errors, full = [], [0]
+
+    def producer(p):
+        try:
+            for r, m in enumerate(per[p]):
+                while True:
+                    res = beam.call("submit", ctx, m.tobytes(), p * 1000 + r)
+                    if res == "ok":
+                        break
+                    assert res == ("error", "full"), res
+                    full[0] += 1
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=producer, args=(p,)) for p in range(P)]
+    for t in threads:
+        t.start()
+    seen = []
+    for _ in range(P * ROUNDS):
+        to, msg = beam.recv(timeout_ms=60000)
+        assert msg is not None, f"lost a batch after {len(seen)}"
+        assert to == 4242 and msg[0] == "ra_gpu_batch"
+        seen.append((int(msg[1]), int(msg[2]), msg[3]))
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert sorted(t for t, _, _ in seen) == sorted(p * 1000 + r for p in range(P) for r in range(ROUNDS))
+    for p in range(P):                                          # per-producer FIFO
+        ticks = [t for t, _, _ in seen if t // 1000 == p]
+        assert ticks == sorted(ticks)
+    # replay in acceptance order through the checker: same decisions batch by batch, same final state
+    for tick, n, dec_bin in seen:
+        m = per[tick // 1000][tick % 1000]
+        want_d, _ = cpu.step(m)
+        assert n == len(m) and dec_bin == want_d.tobytes(), f"batch {tick}"
+    assert beam.call("stop_collector", ctx) == "ok"
+    ok, state_bin = beam.call("download_state", ctx, 0, G * N)
+    assert ok == "ok" and state_bin == cpu.get_state().tobytes()
+    beam.L.mock_gc_resource_term(ctx.t)
+    cpu.close()
+
+
+def test_big_batches_go_to_a_dirty_scheduler(beam):
+    """submit/3 above 2048 messages reschedules itself as a dirty CPU-bound NIF (enif_schedule_nif); small ones
+    run inline."""
+    G, N = 1024, 3
+    ok, ctx = beam.call("open", 0, 16, 2, 4096)
+    assert ok == "ok" and beam.call("register_groups", ctx, G, N) == "ok"
+    m = np.zeros(64, dtype=abi.MSG_DTYPE)
+    m["kind"], m["server"] = abi.MSG_AER_REPLY, np.arange(64)
+    before = beam.L.mock_dirty_reschedules()
+    assert beam.call("submit", ctx, m.tobytes(), 1) == "ok"
+    assert beam.L.mock_dirty_reschedules() == before
+    big = np.zeros(3000, dtype=abi.MSG_DTYPE)
+    big["kind"], big["server"] = abi.MSG_AER_REPLY, np.arange(3000)
+    assert beam.call("submit", ctx, big.tobytes(), 2) == "ok"
+    assert beam.L.mock_dirty_reschedules() == before + 1
+    for want in (64, 3000):
+        ok, _t, n, _d, _r = beam.call("collect", ctx)
+        assert (ok, n) == ("ok", want)
+    beam.L.mock_gc_resource_term(ctx.t)
+
+
 def test_nif_table_matches_the_erlang_stub(beam):
     """Every NIF the Erlang module declares (erlang/ra_gpu_batch.erl: `Name(_Args) -> erlang:nif_error(not_loaded)`)
     is in the shim's table with the same arity, and the blocking ones are dirty-scheduler NIFs."""
@@ -213,7 +360,7 @@ def test_nif_table_matches_the_erlang_stub(beam):
         arity = len([a for a in args.split(",") if a.strip()])
         flags = beam.L.mock_func_flags(name.encode(), arity)
         assert flags != 0xFFFFFFFF, f"{name}/{arity} is not in the NIF table"
-        if name in ("submit", "open", "start_collector"):
+        if name in ("submit", "open", "start_collector", "register_owner"):
             assert flags == 0, f"{name} must not be a dirty NIF (non-blocking)"
         else:
             assert flags == 2, f"{name} waits on the GPU / copies: dirty IO-bound"
