@@ -158,19 +158,18 @@ encode_msg(Server, #request_vote_rpc{term = T, candidate_id = C, last_log_index 
       LLT:64/little, 0:64, 0:64, 0:64, 0:64>>;
 encode_msg(Server, {ra_log_event, {written, T, Seq}}, _Slot) ->
     %% the written event carries a ra_seq:state() -- a list of indexes and ranges, newest first
-    %% (src/ra_log_wal.erl:807, src/ra_log.erl:74,1641; ra_seq.erl:17-26) -- e.g. [{From,To}], [Idx] or
-    %% {written,0,[0]}.  One contiguous range rides in the message; anything else (write_sparse during a
-    %% snapshot install) returns `fallback` and the caller lets ra_server handle the event and re-uploads.
-    case ra_seq:length(Seq) of
-        0 -> fallback;
-        Len ->
-            From = ra_seq:first(Seq), To = ra_seq:last(Seq),
-            case To - From + 1 of
-                Len ->
-                    <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, 0:8, 0:8, T:64/little, From:64/little,
-                      To:64/little, 0:64, 0:64, 0:64, 0:64>>;
-                _ -> fallback
-            end
+    %% (src/ra_log_wal.erl:807, src/ra_log.erl:74,1641; ra_seq.erl:8-12) -- e.g. [{From,To}], [Idx],
+    %% {written,0,[0]} or, after ra_log:write_sparse/3, something like [14, {2,9}].  One range, or two
+    %% (RGB_MF_SEQ2 = 8: the lower one rides in the run0_term/run1_term fields), go to the engine; longer
+    %% sequences return `fallback` and the caller lets ra_server handle the event and re-uploads.
+    case seq_ranges(Seq) of
+        [{From, To}] ->
+            <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, 0:8, 0:8, T:64/little, From:64/little,
+              To:64/little, 0:64, 0:64, 0:64, 0:64>>;
+        [{From2, To2}, {From, To}] ->
+            <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, 8:8, 0:8, T:64/little, From:64/little,
+              To:64/little, 0:64, 0:64, From2:64/little, To2:64/little>>;
+        _ -> fallback
     end;
 encode_msg(Server, {Peer, #request_vote_result{term = T, vote_granted = G}}, Slot) ->
     Flags = case G of true -> 1; false -> 0 end,
@@ -223,6 +222,12 @@ entry_runs(PI, [{I0, T0, _} | _] = Es) ->
     T1 = case Rest of [] -> 0; [{_, T, _} | _] -> T end,
     true = lists:all(fun({_, T, _}) -> T =:= T1 end, Rest), %% else: fall back to ra_server
     {length(Es), length(Run0), T0, T1, I0 - (PI + 1)}.
+
+%% a ra_seq as ascending, merged {Lo, Hi} ranges
+seq_ranges(Seq) ->
+    lists:reverse(ra_seq:fold(fun (I, [{Lo, Hi} | R]) when I =:= Hi + 1 -> [{Lo, I} | R];
+                                  (I, Acc) -> [{I, I} | Acc]
+                              end, [], Seq)).
 
 term_or_undef(undefined) -> ?UNDEF;
 term_or_undef(T) -> T.

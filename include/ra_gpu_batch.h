@@ -34,6 +34,7 @@ extern "C" {
 #define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
 #define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
 #define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
+#define RGB_MAX_PENDING_RANGES 3u     /* ranges of the ra_log `pending` ra_seq held per server */
 #define RGB_MAX_RUNS      16u          /* (first_index, term) runs kept per server log  */
 
 /* reference src/ra_server.hrl:7-8 (cfg defaults) */
@@ -85,6 +86,8 @@ enum {
 /* rgb_msg.flags */
 #define RGB_MF_SUCCESS  0x01u  /* AER_REPLY: success=true; VOTE_RESULT: vote_granted=true */
 #define RGB_MF_FORCE    0x02u  /* APPEND: noop command => Force pipelining (src/ra_server.erl:682-689) */
+#define RGB_MF_SEQ2     0x08u  /* WRITTEN: the written ra_seq has TWO ranges: [run0_term .. run1_term] (the lower one, reusing
+                                  those two fields as indexes) and [a .. b] above it, run1_term + 1 < a */
 #define RGB_MF_TICK     0x04u  /* PIPELINE_RPCS: the leader's tick_timeout -- ra_server:make_rpcs/1: heartbeats for
                                   waiting queries plus one batch-of-1 rpc per stale peer, next_index not advanced
                                   (src/ra_server.erl:2348-2351, 2369-2377, 3012-3030; src/ra_server_proc.erl:613-616) */
@@ -277,7 +280,8 @@ typedef struct rgb_server_state {
   uint8_t  self_nonvoter;       /* own `membership` =/= voter                             */
   uint8_t  cond_leader;         /* await_condition: who the stored reply is cast to       */
   uint8_t  backoff_mask;  /* bit i = peer i's status is {snapshot_backoff, _} (its status_mask bit is 0) */
-  uint8_t  _pad[2];
+  uint8_t  n_pending_old; /* 0..2: ranges of `pending` BELOW its newest range, see pending_old */
+  uint8_t  _pad[1];
   uint64_t pre_vote_token;      /* pre_vote_token (an Erlang reference, opaque 64 bits)   */
   uint64_t query_index;         /* query_index (src/ra_server.erl:96): consistent-query heartbeat counter */
   uint64_t peer_query_index[RGB_MAX_MEMBERS]; /* #{query_index} of every peer (src/ra.hrl:61-73); own slot unused (0) */
@@ -286,6 +290,13 @@ typedef struct rgb_server_state {
                                    stored as last_index + 1 (set it so on upload)            */
   uint32_t machine_version;     /* cfg.machine_version                                    */
   uint32_t effective_machine_version; /* cfg.effective_machine_version                    */
+  uint64_t pending_old[2][2];   /* `pending` is a ra_seq (src/ra_seq.erl:8-12): after ra_log:write_sparse/3 (snapshot
+                                   installation with live indexes, src/ra_log.erl:601-635) it has gaps.  Up to
+                                   RGB_MAX_PENDING_RANGES = 3 ranges are held: the newest is [pending_first .. last_index]
+                                   (above), the n_pending_old older ones are pending_old[k] = {first, last}, ascending,
+                                   non-adjacent (pending_old[k][1] + 1 < the next range's first), all below the newest
+                                   range and below last_index + 1.  A server whose pending has more ranges stays on the
+                                   host until written events have shortened it.                                      */
 } rgb_server_state;
 
 /* ra_leaderboard row + key_metrics gauges per group (src/ra_leaderboard.erl:18-26, src/ra.erl:1242-1250) */

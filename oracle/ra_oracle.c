@@ -42,6 +42,14 @@ typedef struct {
   uint64_t base;                  /* index stored at terms[0] */
   uint64_t *terms;
   size_t   cap;
+  /* sparse pending (after ra_log:write_sparse/3, or while a two-range written event is handled): the ra_seq as
+   * an EXPLICIT ascending list of indexes, every ra_seq operation done index by index the way the reference's
+   * iterators do (src/ra_seq.erl:44-110, 144-160, 278-311) -- deliberately unlike the engine's interval
+   * arithmetic.  NULL = the contiguous-tail form above.  Lists are never edited in place (a failed assertion
+   * restores the message's starting state): pend_orig is the list the current message started with. */
+  uint64_t *pend_idx;
+  size_t   pend_n;
+  uint64_t *pend_orig;
 } olog;
 
 typedef struct {
@@ -121,6 +129,47 @@ static void log_pend_canon(olog *l) {
   }
 }
 
+/* ---- sparse pending: literal ra_seq operations on an explicit index list ---- */
+static void pend_replace(olog *l, uint64_t *nv, size_t n) {
+  if (l->pend_idx && l->pend_idx != l->pend_orig) free(l->pend_idx);
+  l->pend_idx = nv; l->pend_n = n;
+}
+/* pend_first <- the start of the list's trailing run when that run ends at the last index; the list is dropped
+ * once it is nothing but that run (or empty): back to the contiguous-tail form */
+static void pend_sync(olog *l) {
+  uint64_t li, lt;
+  log_last_index_term(l, &li, &lt);
+  size_t n = l->pend_n, k = n;
+  if (n && l->has_range && l->pend_idx[n - 1] == li) {
+    k = n - 1;
+    while (k > 0 && l->pend_idx[k - 1] + 1 == l->pend_idx[k]) k--;
+    l->pend_first = l->pend_idx[k];
+  } else {
+    l->pend_first = li + 1;
+  }
+  if (k == 0) pend_replace(l, NULL, 0);                     /* no index below the trailing run */
+}
+static int pend_materialize(olog *l) {                      /* contiguous-tail form -> explicit list */
+  if (l->pend_idx) return 0;
+  size_t n = log_pend_nonempty(l) ? (size_t)(l->last - l->pend_first + 1) : 0;
+  uint64_t *v = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+  if (!v) return -1;
+  for (size_t i = 0; i < n; i++) v[i] = l->pend_first + i;
+  pend_replace(l, v, n);
+  return 0;
+}
+/* a fresh list: the elements of the current one that satisfy lo <= x <= hi, followed by extra[0..n_extra) */
+static int pend_filter_append(olog *l, uint64_t lo, uint64_t hi, uint64_t app_first, uint64_t app_n) {
+  uint64_t *v = (uint64_t *)malloc((l->pend_n + app_n + 1) * sizeof(uint64_t));
+  if (!v) return -1;
+  size_t n = 0;
+  for (size_t i = 0; i < l->pend_n; i++)
+    if (l->pend_idx[i] >= lo && l->pend_idx[i] <= hi) v[n++] = l->pend_idx[i];
+  for (uint64_t i = 0; i < app_n; i++) v[n++] = app_first + i;   /* ra_seq:append/2 per index (Idx > last) */
+  pend_replace(l, v, n);
+  return 0;
+}
+
 /* ra_log:next_index/1, src/ra_log.erl:1166-1174 */
 static uint64_t log_next_index(const olog *l) {
   if (l->has_range) return l->last + 1;
@@ -192,6 +241,11 @@ static int log_write(olog *l, const rgb_msg *m, uint32_t k0) {
   l->last_term = msg_entry_term(m, m->n_entries - 1);
   l->lw_idx = lwi; l->lw_term = lwt;
   /* Pend = ra_seq:limit(FstIdx - 1, Pend0) :583, then ra_seq:append per entry :1610 */
+  if (l->pend_idx) {
+    if (pend_filter_append(l, 0, fst - 1, fst, lst - fst + 1)) return RGB_INV_WRITE_INTEGRITY;
+    pend_sync(l);
+    return 0;
+  }
   if (fst < l->pend_first) l->pend_first = fst;
   return 0;
 }
@@ -202,6 +256,12 @@ static int log_append(olog *l, uint64_t idx, uint64_t term) {
   l->terms[idx - l->base] = term;
   if (!l->has_range) { l->has_range = 1; l->first = idx; }
   l->last = idx; l->last_term = term;
+  if (l->pend_idx) {                                       /* limit(Idx-1) + append(Idx) :503-505 */
+    if (pend_filter_append(l, 0, idx ? idx - 1 : 0, idx, 1)) return -1;
+    if (idx == 0) { uint64_t *v = (uint64_t *)malloc(sizeof(uint64_t)); if (!v) return -1; v[0] = 0; pend_replace(l, v, 1); }
+    pend_sync(l);
+    return 0;
+  }
   if (idx < l->pend_first) l->pend_first = idx;           /* limit(Idx-1) + append(Idx) :503-505 */
   return 0;
 }
@@ -219,6 +279,7 @@ static int log_set_last_index(olog *l, uint64_t idx) {
     }
     l->last_term = l->snap_term;
     l->lw_idx = l->snap_idx; l->lw_term = l->snap_term;
+    if (l->pend_idx) { if (pend_filter_append(l, 0, idx, 0, 0)) return RGB_INV_SET_LAST_INDEX_NOT_FOUND; pend_sync(l); return 0; }
     if (idx + 1 < l->pend_first) l->pend_first = idx + 1;  /* pending = ra_seq:limit(Idx, Pend0) :868 */
     log_pend_canon(l);
     return 0;
@@ -234,6 +295,7 @@ static int log_set_last_index(olog *l, uint64_t idx) {
   }
   l->last_term = t;
   l->lw_idx = lwi; l->lw_term = lwt;
+  if (l->pend_idx) { if (pend_filter_append(l, 0, idx, 0, 0)) return RGB_INV_SET_LAST_INDEX_NOT_FOUND; pend_sync(l); return 0; }
   if (idx + 1 < l->pend_first) l->pend_first = idx + 1;    /* pending = ra_seq:limit(Idx, Pend0) :891 */
   log_pend_canon(l);
   return 0;
@@ -246,7 +308,59 @@ static int log_set_last_index(olog *l, uint64_t idx) {
  * *resend is set when the reference calls resend_pending/2 (:917-919, State0 otherwise
  * unchanged: the re-send itself is WAL I/O and stays on the host); *inv when the
  * {ok, Pend} = ... match of the snapshot clause (:929) would fail. */
+/* The same event for a sequence of two ranges and/or a sparse `pending`: the written sequence and `pending` as
+ * explicit index lists, the retry of :931-943 one index at a time from the top of the sequence, and
+ * ra_seq:remove_prefix/2 as the two-iterator walk of drop_prefix/2 (src/ra_seq.erl:278-291). */
+static int log_written_sparse(olog *l, uint64_t term, uint64_t lo_s, uint64_t lo_e, int two, uint64_t from, uint64_t to,
+                              int *resend, int *inv) {
+  size_t nw = (size_t)(to - from + 1) + (two ? (size_t)(lo_e - lo_s + 1) : 0);
+  uint64_t *w = (uint64_t *)malloc((nw ? nw : 1) * sizeof(uint64_t));
+  if (!w) return 0;
+  size_t n = 0;
+  if (two) for (uint64_t i = lo_s; i <= lo_e; i++) w[n++] = i;
+  for (uint64_t i = from; i <= to; i++) w[n++] = i;
+  int changed = 0;
+  for (size_t top = n; top > 0; top--) {                    /* WrittenSeq = w[0..top) */
+    const uint64_t idx = w[top - 1];
+    const uint64_t t = log_fetch_term(l, idx);
+    const int clause1 = (t != UNDEF && t == term);
+    const int clause2 = (t == UNDEF && l->snap_idx != UNDEF && idx <= l->snap_idx);
+    if (!clause1 && !clause2) continue;                     /* term mismatch: limit(Idx-1, Seq), retry */
+    if (pend_materialize(l)) break;
+    /* drop_prefix/2: P over w[0..top), S over pending */
+    size_t pi = 0, si = 0, keep_from = l->pend_n;
+    int not_prefix = 0;
+    for (;;) {
+      if (si >= l->pend_n) { keep_from = l->pend_n; break; }            /* drop_prefix(_, end_of_seq) -> {ok, []} */
+      if (pi >= top) { keep_from = si; break; }                         /* prefix exhausted: the rest stays */
+      if (w[pi] == l->pend_idx[si]) { pi++; si++; }
+      else if (w[pi] < l->pend_idx[si]) pi++;                           /* prefix index below the sequence: skipped */
+      else { not_prefix = 1; break; }
+    }
+    if (not_prefix) {
+      pend_sync(l);                                         /* unchanged content: back to its canonical form */
+      if (clause1) *resend = 1; else *inv = RGB_INV_WRITTEN_NOT_PREFIX;
+      free(w);
+      return 0;
+    }
+    uint64_t *v = (uint64_t *)malloc((l->pend_n - keep_from + 1) * sizeof(uint64_t));
+    if (!v) break;
+    memcpy(v, l->pend_idx + keep_from, (l->pend_n - keep_from) * sizeof(uint64_t));
+    pend_replace(l, v, l->pend_n - keep_from);
+    if (clause1) {
+      changed = !(l->lw_idx == idx && l->lw_term == term);
+      l->lw_idx = idx; l->lw_term = term;
+    }
+    pend_sync(l);
+    free(w);
+    return changed;
+  }
+  free(w);
+  return 0;
+}
+
 static int log_written(olog *l, uint64_t term, uint64_t from, uint64_t to, int *resend, int *inv) {
+  if (l->pend_idx) return log_written_sparse(l, term, 0, 0, 0, from, to, resend, inv);
   uint64_t idx = to;
   for (;;) {
     uint64_t t = log_fetch_term(l, idx);
@@ -291,6 +405,7 @@ static int log_snapshot_written(olog *l, uint64_t snap_idx, uint64_t snap_term) 
   l->snap_idx = snap_idx; l->snap_term = snap_term;
   /* Pend = ra_seq:floor(SmallestLiveIdx, Pend0) :1100-1107 with no live indexes below the
    * snapshot (live-index tracking is machine state and stays on the host) */
+  if (l->pend_idx) { if (!pend_filter_append(l, snap_idx + 1, UNDEF, 0, 0)) pend_sync(l); return changed; }
   if (snap_idx + 1 > l->pend_first) l->pend_first = snap_idx + 1;
   log_pend_canon(l);
   return changed;
@@ -832,7 +947,10 @@ static int follower_request_vote(oserver *sv, const rgb_msg *m, ofx *fx) {
  * request of a not_prefix written event is an effect flag (host I/O); returns an RGB_INV_* */
 static int srv_written(oserver *sv, const rgb_msg *m, ofx *fx, int *changed) {
   int resend = 0, inv = 0;
-  *changed = log_written(&sv->log, m->term, m->a, m->b, &resend, &inv);
+  if (m->flags & RGB_MF_SEQ2)
+    *changed = log_written_sparse(&sv->log, m->term, m->run0_term, m->run1_term, 1, m->a, m->b, &resend, &inv);
+  else
+    *changed = log_written(&sv->log, m->term, m->a, m->b, &resend, &inv);
   if (inv) return inv;
   if (resend) fx->flags |= RGB_F_RESEND_PENDING;
   return 0;
@@ -1276,6 +1394,7 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
   if (m->server >= c->n_servers) { d->flags = RGB_F_UNHANDLED; d->role = 0xFF; return; }
   oserver *sv = &c->sv[m->server];
   oscal saved = sv->s;                                      /* a crash leaves the old state */
+  sv->log.pend_orig = sv->log.pend_idx;
   olog saved_log = sv->log;                                 /* cursors only: ra_log:append (the one
                                                                edit a later assertion can follow)
                                                                writes above the old last index */
@@ -1301,6 +1420,7 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
   if (rc) {
     sv->s = saved;
     saved_log.terms = sv->log.terms; saved_log.cap = sv->log.cap; saved_log.base = sv->log.base;
+    if (sv->log.pend_idx && sv->log.pend_idx != saved_log.pend_idx) free(sv->log.pend_idx);
     sv->log = saved_log;
     d->role = saved.role;
     d->flags = RGB_F_INVARIANT;
@@ -1328,6 +1448,8 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
       fx.flags |= RGB_F_RUNS_OVERFLOW;
     }
   }
+  if (saved_log.pend_idx && saved_log.pend_idx != sv->log.pend_idx) free(saved_log.pend_idx);
+  sv->log.pend_orig = sv->log.pend_idx;
   *n_rpcs = fx.n_rpcs_total;
   d->role = sv->s.role;
   d->flags = fx.flags;
@@ -1366,6 +1488,7 @@ static void server_init_empty(oserver *sv, uint32_t n_members, uint32_t self) {
   for (unsigned i = 0; i < n_members; i++) sv->s.next_index[i] = 1;
   olog *l = &sv->log;
   free(l->terms);
+  free(l->pend_idx);
   memset(l, 0, sizeof *l);
   l->snap_idx = UNDEF; l->snap_term = UNDEF;
   log_append(l, 0, 0);                                      /* src/ra_log.erl:1637-1647 */
@@ -1390,7 +1513,7 @@ ora_ctx *ora_new(uint32_t n_groups, uint32_t n_members, uint32_t max_pipeline_co
 
 void ora_free(ora_ctx *c) {
   if (!c) return;
-  for (uint32_t i = 0; i < c->n_servers; i++) free(c->sv[i].log.terms);
+  for (uint32_t i = 0; i < c->n_servers; i++) { free(c->sv[i].log.terms); free(c->sv[i].log.pend_idx); }
   free(c->sv);
   free(c);
 }
@@ -1424,6 +1547,7 @@ int ora_set_state(ora_ctx *c, uint32_t first, uint32_t n, const rgb_server_state
     memcpy(s->peer_query_index, h->peer_query_index, sizeof s->peer_query_index);
     olog *l = &sv->log;
     free(l->terms);
+    free(l->pend_idx);
     memset(l, 0, sizeof *l);
     l->snap_idx = h->snapshot_index; l->snap_term = h->snapshot_term;
     l->lw_idx = h->last_written_index; l->lw_term = h->last_written_term;
@@ -1442,6 +1566,27 @@ int ora_set_state(ora_ctx *c, uint32_t first, uint32_t n, const rgb_server_state
     } else {
       l->has_range = 0; l->first = h->first_index; l->last = h->last_index;
     }
+    if (h->n_pending_old) {
+      /* sparse pending: the old ranges and the newest range as one explicit index list */
+      if (h->n_pending_old > 2) return RGB_E_INVAL;
+      size_t n = 0;
+      for (unsigned k = 0; k < h->n_pending_old; k++) {
+        if (h->pending_old[k][0] > h->pending_old[k][1]) return RGB_E_INVAL;
+        n += (size_t)(h->pending_old[k][1] - h->pending_old[k][0] + 1);
+      }
+      const int newest = l->has_range && h->pending_first <= h->last_index;
+      if (newest) n += (size_t)(h->last_index - h->pending_first + 1);
+      uint64_t *v = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+      if (!v) return RGB_E_NOMEM;
+      size_t j = 0;
+      for (unsigned k = 0; k < h->n_pending_old; k++)
+        for (uint64_t i = h->pending_old[k][0]; i <= h->pending_old[k][1]; i++) v[j++] = i;
+      if (newest) for (uint64_t i = h->pending_first; i <= h->last_index; i++) v[j++] = i;
+      for (size_t q = 1; q < j; q++) if (v[q] <= v[q - 1]) { free(v); return RGB_E_INVAL; }
+      l->pend_idx = v; l->pend_n = j; l->pend_orig = NULL;
+      pend_sync(l);
+      l->pend_orig = l->pend_idx;
+    }
   }
   return RGB_OK;
 }
@@ -1459,6 +1604,21 @@ int ora_get_state(const ora_ctx *c, uint32_t first, uint32_t n, rgb_server_state
     log_last_index_term(l, &h->last_index, &h->last_term);
     h->last_written_index = l->lw_idx; h->last_written_term = l->lw_term;
     h->pending_first = l->pend_first;
+    if (l->pend_idx) {
+      /* the runs of the list below the newest range [pend_first .. last] */
+      size_t top = l->pend_n;
+      while (top > 0 && l->pend_idx[top - 1] >= l->pend_first) top--;
+      unsigned nr = 0;
+      for (size_t i = 0; i < top; i++) {
+        if (i == 0 || l->pend_idx[i] != l->pend_idx[i - 1] + 1) {
+          if (nr == 2) { nr = 3; break; }                  /* more ranges than the boundary holds */
+          h->pending_old[nr][0] = l->pend_idx[i];
+          nr++;
+        }
+        h->pending_old[nr - 1][1] = l->pend_idx[i];
+      }
+      h->n_pending_old = (uint8_t)nr;
+    }
     h->snapshot_index = l->snap_idx; h->snapshot_term = l->snap_term;
     memcpy(h->cond_reply, s->cond_reply, sizeof s->cond_reply);
     memcpy(h->match_index, s->match_index, sizeof s->match_index);
@@ -1563,6 +1723,9 @@ uint64_t ora_server_checksum(const rgb_server_state *h) {
   x = fnv_word(x, masks);
   x = fnv_word(x, h->pre_vote_token);
   x = fnv_word(x, h->pending_first);
+  for (unsigned k = 0; k < h->n_pending_old && k < 2; k++) {
+    x = fnv_word(x, h->pending_old[k][0]); x = fnv_word(x, h->pending_old[k][1]);
+  }
   x = fnv_word(x, h->query_index);
   for (unsigned i = 0; i < h->n_members && i < RGB_MAX_MEMBERS; i++) x = fnv_word(x, h->peer_query_index[i]);
   x = fnv_word(x, (uint64_t)h->machine_version | ((uint64_t)h->effective_machine_version << 32));

@@ -34,6 +34,7 @@ KIND_RANK = np.array([15, 0, 1, 5, 6, 2, 4, 3, 7, 8, 9, 10, 11, 12, 13, 14], dty
 MF_SUCCESS = 0x01
 MF_FORCE = 0x02
 MF_TICK = 0x04
+MF_SEQ2 = 0x08
 
 F_REPLY = 1 << 0
 F_REPLY_SUCCESS = 1 << 1
@@ -108,10 +109,11 @@ SERVER_STATE_DTYPE = np.dtype([
     ("role", u8), ("cond_reason", u8), ("self", u8), ("n_members", u8),
     ("voted_for", u8), ("leader_id", u8), ("votes", u8), ("n_runs", u8),
     ("present_mask", u8), ("voter_mask", u8), ("status_mask", u8), ("self_nonvoter", u8),
-    ("cond_leader", u8), ("backoff_mask", u8), ("_pad", u8, (2,)),
+    ("cond_leader", u8), ("backoff_mask", u8), ("n_pending_old", u8), ("_pad", u8, (1,)),
     ("pre_vote_token", u64), ("query_index", u64), ("peer_query_index", u64, (MAX_MEMBERS,)),
     ("pending_first", u64),
     ("machine_version", u32), ("effective_machine_version", u32),
+    ("pending_old", u64, (2, 2)),
 ])
 
 LEADERBOARD_DTYPE = np.dtype([
@@ -143,7 +145,7 @@ WAL_FILE_HEADER = b"RAWA\x01"
 
 STRUCT_DTYPES = [MSG_DTYPE, DECISION_DTYPE, RPC_DTYPE, SERVER_STATE_DTYPE, LEADERBOARD_DTYPE,
                  CONFIG_DTYPE]
-EXPECTED_SIZES = [64, 64, 56, 672, 32, 32]
+EXPECTED_SIZES = [64, 64, 56, 704, 32, 32]
 for _dt, _sz in zip(STRUCT_DTYPES, EXPECTED_SIZES):
     assert _dt.itemsize == _sz, (_dt, _dt.itemsize, _sz)
 

@@ -298,6 +298,14 @@ static int validate_state(const rgb_ctx *ctx, const rgb_server_state &h) {
       if (!(h.run_start[r] > h.run_start[r - 1] && h.run_start[r] <= h.last_index)) return RGB_E_INVAL;
     if (h.run_term[h.n_runs - 1] != h.last_term) return RGB_E_INVAL;
   }
+  /* sparse pending: old ranges ascending, non-empty, non-adjacent, strictly below the newest range */
+  if (h.n_pending_old > 2) return RGB_E_INVAL;
+  uint64_t above = h.pending_first;                /* first index of the range above the one being checked */
+  for (int k = (int)h.n_pending_old - 1; k >= 0; --k) {
+    const uint64_t s = h.pending_old[k][0], e = h.pending_old[k][1];
+    if (s > e || e == RGB_UNDEF || !(e + 1 < above)) return RGB_E_INVAL;
+    above = s;
+  }
   return RGB_OK;
 }
 
@@ -348,6 +356,8 @@ static int validate_msg(const rgb_ctx *ctx, const rgb_msg &m) {
   if (m.from != RGB_NONE && m.from >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
   if (m.kind == RGB_MSG_AER && m.n_run0 > m.n_entries) return RGB_E_INVAL;
   if (m.kind == RGB_MSG_WRITTEN && m.a > m.b) return RGB_E_INVAL;
+  if (m.kind == RGB_MSG_WRITTEN && (m.flags & RGB_MF_SEQ2) &&
+      !(m.run0_term <= m.run1_term && m.run1_term != RGB_UNDEF && m.run1_term + 1 < m.a)) return RGB_E_INVAL;
   return RGB_OK;
 }
 

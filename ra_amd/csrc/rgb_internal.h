@@ -19,7 +19,8 @@
  *        index older than the last run is looked up (log-matching repair)
  *   cond [S][4] u64    stored reply of await_condition (cold)
  *   qry  [S][16] u64   consistent-query heartbeats (cold): 0 query_index, 1+i query_index of peer slot i,
- *        9 snapshot_backoff mask, 10 pre_vote_token, 11 machine versions (election kinds only)
+ *        9 snapshot_backoff mask, 10 pre_vote_token, 11 machine versions (election kinds only),
+ *        12..15 the two older ranges of a sparse `pending` (valid while packed-word bit 59 is set)
  */
 #ifndef RGB_INTERNAL_H
 #define RGB_INTERNAL_H
@@ -70,6 +71,9 @@ typedef uint32_t u32;
 #define PK_QSELF_SH     56  /* 1: query_index > 0 (qry row word 0 is worth reading)      */
 #define PK_QPEER_SH     57  /* 1: some peer query_index > 0 (reset_query_index has work) */
 #define PK_BACKOFF_SH   58  /* 1: some peer is in {snapshot_backoff,_}: qry row word QRY_BACKOFF holds the mask */
+#define PK_PENDX_SH     59  /* 1: `pending` has ranges below its newest one: qry row words QRY_PEND_LO.. hold them */
+#define QRY_PEND_LO     12  /* (first, last) of the lower old range, (1, 0) when there is only one */
+#define QRY_PEND_HI     14  /* (first, last) of the old range next below the newest range [HOT_PEND .. last_index] */
 #define QRY_BACKOFF     9   /* qry row: word 0 query_index, 1..8 peer query_index, 9 backoff mask */
 #define QRY_TOKEN       10  /* pre_vote_token (election kinds only)                                   */
 #define QRY_MACVER      11  /* machine_version | effective_machine_version << 32                      */

@@ -145,6 +145,10 @@ struct Lane {
   unsigned push_cnt;
   bool cond_dirty;
   u64 cr0, cr1, cr2, cr3;
+  /* sparse `pending` (packed-word bit PK_PENDX): the ranges below the newest one live in the qry row and are only
+   * ever CUT by a message -- ra_seq:limit keeps what is below po_cut, ra_seq:floor / remove_prefix what is at or
+   * above po_floor -- so the two bounds are collected here and applied at commit */
+  u64 po_floor, po_cut;
   /* the server's peers row in registers (leader-side messages): match_index / next_index /
    * commit_index_sent per member, loaded with the hot line (one round trip), written back
    * word by word where the dirty masks say so.  Only indexes < N are ever touched (loops are
@@ -509,6 +513,9 @@ __device__ __forceinline__ void truncate_runs_to(Lane &L, u64 keep_idx) {
  * last_index + 1. */
 __device__ __forceinline__ bool pend_nonempty(const Lane &L) { return range_nonempty(L) && L.pend <= L.li; }
 __device__ __forceinline__ void pend_canon(Lane &L) { if (!pend_nonempty(L)) L.pend = L.li + 1; }
+/* ra_seq:limit(CeilExcl - 1, Pend) / ra_seq:floor(Floor, Pend) on the ranges below the newest one */
+__device__ __forceinline__ void pend_old_limit(Lane &L, u64 ceil_excl) { if (ceil_excl < L.po_cut) L.po_cut = ceil_excl; }
+__device__ __forceinline__ void pend_old_floor(Lane &L, u64 floor_incl) { if (floor_incl > L.po_floor) L.po_floor = floor_incl; }
 
 /* ra_log:write/2 (src/ra_log.erl:547-599, range update :1618-1623) of entries k0..n-1.
  * Returns an RGB_INV_* code, 0 on success.  Validates before editing. */
@@ -550,6 +557,7 @@ __device__ __forceinline__ int log_write(Lane &L, u32 k0) {
   L.lt = (L.n_entries - 1) < L.n_run0 ? L.run0_term : L.run1_term;
   L.lwi = lwi; L.lwt = lwt;
   if (fst < L.pend) L.pend = fst;      /* ra_seq:limit(FstIdx-1, Pend0) :583 + ra_seq:append per entry :1610 */
+  pend_old_limit(L, fst);
   return 0;
 }
 
@@ -568,6 +576,7 @@ __device__ __forceinline__ int log_set_last_index(Lane &L, u64 idx) {
     L.lt = L.st;
     L.lwi = L.si; L.lwt = L.st;
     if (idx + 1 < L.pend) L.pend = idx + 1;   /* pending = ra_seq:limit(Idx, Pend0) :868 */
+    pend_old_limit(L, idx + 1);
     pend_canon(L);
     return 0;
   }
@@ -580,75 +589,117 @@ __device__ __forceinline__ int log_set_last_index(Lane &L, u64 idx) {
   L.lt = t;
   L.lwi = lwi; L.lwt = lwt;
   if (idx + 1 < L.pend) L.pend = idx + 1;     /* pending = ra_seq:limit(Idx, Pend0) :891 */
+  pend_old_limit(L, idx + 1);
   pend_canon(L);
   return 0;
 }
 
-/* ra_log:handle_event({written,Term,[from..to]}) (src/ra_log.erl:897-944).  The reference walks
- * the sequence down one index at a time (ra_seq:limit(Last-1)) until either the index's term is
- * Term (first clause: last_written moves there) or the index is undefined and at/below the
- * snapshot (second clause: only `pending` is trimmed).  Run-wise here: c1 = the highest index of
- * [from..to] inside the range whose run has term Term, c2 = the highest index of [from..to]
- * outside the range and at/below the snapshot; the higher one decides.  `pending` loses the
- * written prefix (ra_seq:remove_prefix/2); a written range that starts above the first pending
- * index is not a prefix: resend request (first clause, :917-919, cursors unchanged) or a failed
- * match (second clause, :929).  Returns an RGB_INV_* code; `changed` = last_written moved. */
+/* ra_log:handle_event({written,Term,WrittenSeq}) (src/ra_log.erl:897-944) for a WrittenSeq of one range
+ * [from..to] or two (RGB_MF_SEQ2: [w2s..w2e] below it).  The reference walks the sequence down one index at a time
+ * (ra_seq:limit(Last-1), the retry of :931-943) until either the index's term is Term (first clause: last_written
+ * moves there) or the index is undefined and at/below the snapshot (second clause: only `pending` is trimmed).
+ * Run-wise here: c1 = the highest index of the sequence inside the log range whose run has term Term, c2 = the
+ * highest index of the sequence outside the range and at/below the snapshot; the higher one decides and W_eff =
+ * the sequence limited to it.  `pending` loses the written prefix (ra_seq:remove_prefix/2, drop_prefix :278-291):
+ * every pending index at or below the stop index must be IN W_eff, else {error, not_prefix} -- a resend request
+ * in the first clause (:917-919, cursors unchanged), a failed match in the second (:929).
+ * Returns an RGB_INV_* code; `changed` = last_written moved. */
+
+/* c1 over one range [lo..hi] of the sequence */
+__device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u64 to, u64 &c1) {
+  const u64 hi = to < L.li ? to : L.li;
+  const u64 lo = from > L.first ? from : L.first;
+  if (hi < lo) return false;
+  /* walk runs from the newest: run k covers [start_k, end_k] */
+  u64 end = L.li;
+  for (int k = (int)L.n_runs - 1; k >= 0; --k) {
+    u64 s, t;
+    if ((unsigned)k == L.n_runs - 1) { s = L.lrs; t = L.lrt; }
+    else if ((unsigned)k == L.n_runs - 2) { s = L.prs; t = L.prt; }
+    else {
+#ifdef RGB_PROFILE
+      if (L.prof_noprobe) break;
+#endif
+      s = run_word(L, 2 * k); t = run_word(L, 2 * k + 1);
+    }
+    const u64 rs = s < L.first ? L.first : s;
+    if (rs <= hi && end >= lo && t == term) {
+      const u64 idx = end < hi ? end : hi;
+      if (idx >= lo && idx >= rs) { c1 = idx; return true; }
+    }
+    if (s <= lo) break;
+    end = s - 1;
+  }
+  return false;
+}
+/* c2 over one range of the sequence */
+__device__ __forceinline__ bool written_c2(const Lane &L, bool in_range, u64 from, u64 to, u64 &c2) {
+  if (L.si == UNDEF) return false;
+  u64 u = to < L.si ? to : L.si;
+  bool ok = u >= from;
+  if (ok && in_range && u >= L.first && u <= L.li) {      /* inside the range: next one below it */
+    ok = L.first > 0 && L.first - 1 >= from;
+    u = L.first - 1;
+  }
+  if (ok) c2 = u;
+  return ok;
+}
+/* is the pending range [ps..pe], cut at the stop index c, covered by W_eff = ([w2s..w2e] u [from..to]) limited to c?
+ * (a contiguous pending range cannot straddle the gap between the two written ranges) */
+__device__ __forceinline__ bool pend_range_written(u64 ps, u64 pe, u64 c, bool two, u64 w2s, u64 w2e, u64 from, u64 to) {
+  if (ps > pe || ps > c) return true;                     /* empty, or entirely above the stop index: stays */
+  const u64 e = pe < c ? pe : c;
+  const u64 te = to < c ? to : c, t2e = w2e < c ? w2e : c;
+  if (from <= c && ps >= from && e <= te) return true;
+  if (two && w2s <= c && ps >= w2s && e <= t2e) return true;
+  return false;
+}
+
 __device__ __forceinline__ int log_written(Lane &L, u64 term, u64 from, u64 to, bool &changed) {
   changed = false;
   const bool in_range = range_nonempty(L);
+  const bool two = (L.mflags & RGB_MF_SEQ2) != 0;
+  const u64 w2s = L.run0_term, w2e = L.run1_term;         /* the lower written range rides in these fields */
   bool have1 = false; u64 c1 = 0;
-  if (in_range) {
-    const u64 hi = to < L.li ? to : L.li;
-    const u64 lo = from > L.first ? from : L.first;
-    if (hi >= lo) {
-      /* walk runs from the newest: run k covers [start_k, end_k] */
-      u64 end = L.li;
-      for (int k = (int)L.n_runs - 1; k >= 0; --k) {
-        u64 s, t;
-        if ((unsigned)k == L.n_runs - 1) { s = L.lrs; t = L.lrt; }
-        else if ((unsigned)k == L.n_runs - 2) { s = L.prs; t = L.prt; }
-        else {
-#ifdef RGB_PROFILE
-          if (L.prof_noprobe) break;
-#endif
-          s = run_word(L, 2 * k); t = run_word(L, 2 * k + 1);
-        }
-        const u64 rs = s < L.first ? L.first : s;
-        if (rs <= hi && end >= lo && t == term) {
-          const u64 idx = end < hi ? end : hi;
-          if (idx >= lo && idx >= rs) { have1 = true; c1 = idx; break; }
-        }
-        if (s <= lo) break;
-        end = s - 1;
-      }
-    }
-  }
   bool have2 = false; u64 c2 = 0;
-  if (L.si != UNDEF) {
-    u64 u = to < L.si ? to : L.si;
-    bool ok = u >= from;
-    if (ok && in_range && u >= L.first && u <= L.li) {      /* inside the range: next one below it */
-      ok = L.first > 0 && L.first - 1 >= from;
-      u = L.first - 1;
-    }
-    if (ok) { have2 = true; c2 = u; }
+  /* the upper range first, then (two-range sequences only) the lower one: one copy of the walk in the code */
+#pragma unroll 1
+  for (int r = 0; r < (two ? 2 : 1); ++r) {
+    const u64 f = r ? w2s : from, t = r ? w2e : to;
+    if (in_range && !have1) have1 = written_c1(L, term, f, t, c1);
+    if (!have2) have2 = written_c2(L, in_range, f, t, c2);
   }
-  if (have1 && (!have2 || c1 > c2)) {
-    if (pend_nonempty(L)) {
-      if (from > L.pend) { L.flags |= RGB_F_RESEND_PENDING; return 0; }
-      if (c1 + 1 > L.pend) L.pend = c1 + 1;
-      pend_canon(L);
+  const bool first_clause = have1 && (!have2 || c1 > c2);
+  if (!first_clause && !have2) return 0;                  /* the sequence ran out: no change (:934-938) */
+  const u64 c = first_clause ? c1 : c2;
+  /* ra_seq:remove_prefix(W_eff, Pend) */
+  bool prefix = true;
+  const bool sparse = pk_get(L.pk, PK_PENDX_SH, 1) != 0;
+  if (pend_nonempty(L)) prefix = pend_range_written(L.pend, L.li, c, two, w2s, w2e, from, to);
+  if (sparse && prefix) {
+    const u64 *q = qry_row(L);
+    /* the old ranges as this message has cut them so far (nothing cuts them before a written event, but be exact) */
+#pragma unroll 1
+    for (int k = 0; k < 2 && prefix; ++k) {
+      u64 ps = q[QRY_PEND_LO + 2 * k], pe = q[QRY_PEND_LO + 2 * k + 1];
+      if (ps < L.po_floor) ps = L.po_floor;
+      if (L.po_cut != UNDEF && pe >= L.po_cut) pe = L.po_cut - 1;
+      if (L.po_cut == 0) continue;
+      prefix = pend_range_written(ps, pe, c, two, w2s, w2e, from, to);
     }
-    changed = !(L.lwi == c1 && L.lwt == term);
-    L.lwi = c1; L.lwt = term;
-    return 0;
   }
-  if (have2) {
-    if (pend_nonempty(L)) {
-      if (from > L.pend) return RGB_INV_WRITTEN_NOT_PREFIX;
-      if (c2 + 1 > L.pend) L.pend = c2 + 1;
-      pend_canon(L);
-    }
+  if (!prefix) {
+    if (first_clause) { L.flags |= RGB_F_RESEND_PENDING; return 0; }
+    return RGB_INV_WRITTEN_NOT_PREFIX;
+  }
+  if (pend_nonempty(L)) {
+    if (c + 1 > L.pend) L.pend = c + 1;
+    pend_canon(L);
+  }
+  pend_old_floor(L, c + 1);
+  if (first_clause) {
+    changed = !(L.lwi == c && L.lwt == term);
+    L.lwi = c; L.lwt = term;
   }
   return 0;
 }
@@ -688,6 +739,7 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
   }
   L.si = idx; L.st = term;
   if (idx + 1 > L.pend) L.pend = idx + 1;     /* ra_seq:floor(SnapIdx+1, Pend0) :1100-1107, no live indexes */
+  pend_old_floor(L, idx + 1);
   pend_canon(L);
   return changed;
 }
@@ -1227,6 +1279,7 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
           L.li = nidx + (L.n_entries - 1);
           L.lt = L.ct;
           if (nidx < L.pend) L.pend = nidx;   /* ra_seq:limit(Idx-1) + append(Idx) :503-505 */
+          pend_old_limit(L, nidx);
         }
       }
       bool more; unsigned cnt;
@@ -1586,6 +1639,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   L.n_runs = (unsigned)pk_get(L.pk, PK_NRUNS_SH, 5);
   L.push_cnt = 0;
   L.cond_dirty = false; L.cr0 = L.cr1 = L.cr2 = L.cr3 = 0;
+  L.po_floor = 0; L.po_cut = UNDEF;
 
   const unsigned role0 = role_of(L);
   const u64 ci0 = L.ci, la0 = L.la;
@@ -1665,6 +1719,29 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
       if (L.dcs & (1u << k)) ST8(L.peers + 2 * N + k, L.pcs[k]);
       else if (L.dcs_ci & (1u << k)) ST8(L.peers + 2 * N + k, L.ci);
     }
+  }
+  /* ---- commit: sparse `pending` (rare: only servers uploaded after a write_sparse) ---- */
+  if (pk_get(h0.y, PK_PENDX_SH, 1) && !RGB_KNOB(dev, 1u)) {
+    u64 *q = qry_row(L);
+    u64 s0 = q[QRY_PEND_LO], e0 = q[QRY_PEND_LO + 1], s1 = q[QRY_PEND_HI], e1 = q[QRY_PEND_HI + 1];
+    /* cut: keep [po_floor, po_cut) */
+    if (s0 < L.po_floor) s0 = L.po_floor;
+    if (s1 < L.po_floor) s1 = L.po_floor;
+    if (L.po_cut != UNDEF) {
+      if (L.po_cut == 0) { s0 = 1; e0 = 0; s1 = 1; e1 = 0; }
+      else { if (e0 >= L.po_cut) e0 = L.po_cut - 1; if (e1 >= L.po_cut) e1 = L.po_cut - 1; }
+    }
+    bool v0 = s0 <= e0, v1 = s1 <= e1;
+    /* canonical form: ranges ascending and non-adjacent, the one that ends at last_index is the newest range */
+    const bool newest = range_nonempty(L) && L.pend <= L.li;
+    if (v1 && newest && e1 + 1 == L.pend) { L.pend = s1; v1 = false; }          /* ra_seq:append merged them */
+    else if (v1 && !newest && range_nonempty(L) && e1 == L.li) { L.pend = s1; v1 = false; }
+    else if (!v1 && v0 && newest && e0 + 1 == L.pend) { L.pend = s0; v0 = false; }
+    else if (!v1 && v0 && !newest && range_nonempty(L) && e0 == L.li) { L.pend = s0; v0 = false; }
+    if (!v1 && v0) { s1 = s0; e1 = e0; v1 = true; v0 = false; }                  /* a single old range sits in HI */
+    q[QRY_PEND_LO] = v0 ? s0 : 1; q[QRY_PEND_LO + 1] = v0 ? e0 : 0;
+    q[QRY_PEND_HI] = v1 ? s1 : 1; q[QRY_PEND_HI + 1] = v1 ? e1 : 0;
+    L.pk = pk_set(L.pk, PK_PENDX_SH, 1, v1 ? 1 : 0);
   }
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
@@ -2298,6 +2375,11 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
     q[QRY_BACKOFF] = backoff;
     q[QRY_TOKEN] = h.pre_vote_token;
     q[QRY_MACVER] = (u64)h.machine_version | ((u64)h.effective_machine_version << 32);
+    /* sparse pending: a single old range sits in the HI slot */
+    const unsigned npo = h.n_pending_old > 2 ? 2u : h.n_pending_old;
+    q[QRY_PEND_LO] = npo == 2 ? h.pending_old[0][0] : 1; q[QRY_PEND_LO + 1] = npo == 2 ? h.pending_old[0][1] : 0;
+    q[QRY_PEND_HI] = npo ? h.pending_old[npo - 1][0] : 1; q[QRY_PEND_HI + 1] = npo ? h.pending_old[npo - 1][1] : 0;
+    pk = pk_set(pk, PK_PENDX_SH, 1, npo ? 1 : 0);
     pk = pk_set(pk, PK_BACKOFF_SH, 1, backoff ? 1 : 0);
     pk = pk_set(pk, PK_QSELF_SH, 1, h.query_index != 0 ? 1 : 0);
     pk = pk_set(pk, PK_QPEER_SH, 1, peer_nz ? 1 : 0);
@@ -2361,6 +2443,12 @@ __global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ ou
     h.query_index = q[0];
     for (unsigned i = 0; i < 8; ++i) h.peer_query_index[i] = q[1 + i];
     h.backoff_mask = pk_get(pk, PK_BACKOFF_SH, 1) ? (uint8_t)(q[QRY_BACKOFF] & 0xFFu) : 0;
+    if (pk_get(pk, PK_PENDX_SH, 1)) {
+      const bool two = q[QRY_PEND_LO] <= q[QRY_PEND_LO + 1];
+      h.n_pending_old = two ? 2 : 1;
+      if (two) { h.pending_old[0][0] = q[QRY_PEND_LO]; h.pending_old[0][1] = q[QRY_PEND_LO + 1]; }
+      h.pending_old[two ? 1 : 0][0] = q[QRY_PEND_HI]; h.pending_old[two ? 1 : 0][1] = q[QRY_PEND_HI + 1];
+    }
   }
   out[k] = h;
 }
@@ -2427,6 +2515,11 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   x = fnv_word(x, masks);
   x = fnv_word(x, (dev.qry + (size_t)s * RGB_QRY_WORDS)[QRY_TOKEN]);
   x = fnv_word(x, hot[HOT_PEND]);
+  if (pk_get(pk, PK_PENDX_SH, 1)) {      /* the old pending ranges, ascending */
+    const u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
+    if (q[QRY_PEND_LO] <= q[QRY_PEND_LO + 1]) { x = fnv_word(x, q[QRY_PEND_LO]); x = fnv_word(x, q[QRY_PEND_LO + 1]); }
+    x = fnv_word(x, q[QRY_PEND_HI]); x = fnv_word(x, q[QRY_PEND_HI + 1]);
+  }
   {
     const u64 *q = dev.qry + (size_t)s * RGB_QRY_WORDS;
     x = fnv_word(x, q[0]);

@@ -134,9 +134,27 @@ __device__ __forceinline__ v4u load16_any(const unsigned char *p) {
   return t;
 }
 
+/* bytes [lo, hi) of a 16-byte chunk held in registers to its 16-byte aligned place `base`: at most eight aligned
+ * power-of-two stores (1, 2, 4, 8 bytes going up to the first 8-byte boundary that fits, then 8, 4, 2, 1 coming
+ * down) instead of one byte store per byte -- the bytes outside [lo, hi) belong to the neighbouring records, which
+ * other lane groups write in no particular order, so they must not be touched */
+__device__ __forceinline__ void store_sub16(unsigned char *base, const uint4 w, u32 lo, u32 hi) {
+  const u64 lo64 = (u64)w.x | ((u64)w.y << 32), hi64 = (u64)w.z | ((u64)w.w << 32);
+  auto sub = [&](u32 p) -> u64 { return ((p & 8u) ? hi64 : lo64) >> (8u * (p & 7u)); };
+  u32 p = lo;
+  if ((p & 1u) && p + 1u <= hi) { base[p] = (unsigned char)sub(p); p += 1u; }
+  if ((p & 2u) && p + 2u <= hi) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
+  if ((p & 4u) && p + 4u <= hi) { *reinterpret_cast<u32 *>(base + p) = (u32)sub(p); p += 4u; }
+  if ((p & 8u) && p + 8u <= hi) { *reinterpret_cast<u64 *>(base + p) = sub(p); p += 8u; }
+  if (p + 8u <= hi) { *reinterpret_cast<u64 *>(base + p) = sub(p); p += 8u; }
+  if (p + 4u <= hi) { *reinterpret_cast<u32 *>(base + p) = (u32)sub(p); p += 4u; }
+  if (p + 2u <= hi) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
+  if (p + 1u <= hi) { base[p] = (unsigned char)sub(p); }
+}
+
 template <int GROUP>
 __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel(
-    const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data,
+    const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data, u64 data_bytes,
     unsigned char *__restrict__ out, u32 *__restrict__ sums_out, u32 flags) {
   constexpr u32 PER_BLOCK = WAL_WAVES_PER_BLOCK * 64 / GROUP;
   const u32 lane = threadIdx.x & (GROUP - 1);
@@ -154,6 +172,9 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel
   const u32 span = lead + len;                          /* destination-aligned stream [0, span) */
   const u32 n_chunks = live ? (span + 15u) >> 4 : 0u;
   const u32 span_q = span % ADLER_MOD;
+  /* a partial chunk at either end of the payload is read as one whole 16-byte load when the 16 bytes around it
+   * lie inside the data buffer (always, except for the first / last payload of the buffer) */
+  const bool wide_ok = r.data_offset >= 16ull && r.data_offset + len + 16ull <= data_bytes;
   u32 a_acc = 0, b_acc = 0;
   for (u32 c0 = 0; c0 < n_chunks; c0 += GROUP * WAL_UNROLL) {
     uint4 v[WAL_UNROLL];
@@ -166,7 +187,14 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel
       if (s >= lead && s + 16u <= span) {
         const v4u t = load16_any(src + (s - lead));
         v[k] = make_uint4(t.x, t.y, t.z, t.w);
-      } else {                                          /* partial chunk: bytes outside stay zero */
+      } else if (wide_ok) {                             /* partial chunk, one load: mask, store the sub-words */
+        const u32 lo = s < lead ? lead - s : 0u, hi = span - s < 16u ? span - s : 16u;
+        const v4u t = load16_any(src + ((long long)s - (long long)lead));
+        uint4 w = make_uint4(t.x & byte_mask(0, lo, hi), t.y & byte_mask(4, lo, hi), t.z & byte_mask(8, lo, hi),
+                             t.w & byte_mask(12, lo, hi));
+        store_sub16(dst + ((long long)s - (long long)lead), w, lo, hi);
+        v[k] = w;
+      } else {                                          /* partial chunk at the buffer's edge: byte by byte */
         u32 w[4] = {0, 0, 0, 0};
 #pragma unroll
         for (u32 j = 0; j < 16u; ++j) {
@@ -263,13 +291,13 @@ extern "C" int rgb_wal_frame_device(rgb_ctx *ctx, const void *d_records, uint32_
   if (data_bytes / n < 1024u) {
     const u32 per = WAL_WAVES_PER_BLOCK * 64 / 16;
     hipLaunchKernelGGL(rgb_wal_frame_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data, (unsigned char *)d_out,
-                       (u32 *)d_checksums, flags);
+                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data, (u64)data_bytes,
+                       (unsigned char *)d_out, (u32 *)d_checksums, flags);
   } else {
     const u32 per = WAL_WAVES_PER_BLOCK;
     hipLaunchKernelGGL(rgb_wal_frame_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data, (unsigned char *)d_out,
-                       (u32 *)d_checksums, flags);
+                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data, (u64)data_bytes,
+                       (unsigned char *)d_out, (u32 *)d_checksums, flags);
   }
   return hipGetLastError() == hipSuccess ? RGB_OK : RGB_E_HIP;
 }

@@ -35,6 +35,12 @@ def test_sub_ticks_ring_and_overflow(emulated_engine, oracle_lib):
         G.test_write_below_first_index_keeps_the_range_start(emulated_engine, oracle_lib, n_run0)
 
 
+def test_sparse_pending_through_the_c_abi(emulated_engine, oracle_lib):
+    for seed in range(8):
+        G.test_sparse_pending_and_two_range_written_events(emulated_engine, oracle_lib, seed)
+    G.test_written_event_for_a_live_index_below_the_snapshot(emulated_engine, oracle_lib)
+
+
 def test_bounded_run_tables_and_repair_workload(emulated_engine, oracle_lib):
     G.test_bounded_run_table_matches_oracle(emulated_engine, oracle_lib, 5, 211, 300, 4)
     G.test_config5_log_matching_repair_matches_oracle(emulated_engine, oracle_lib)

@@ -413,3 +413,57 @@ def test_full_size_properties_config3(engine_mod):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_sparse_pending_and_two_range_written_events(engine_mod, oracle_lib, seed):
+    """SURVEY 8(f) #2 on the device: `pending` with gaps (the host's re-upload after ra_log:write_sparse/3 +
+    install_snapshot, src/ra_log.erl:601-635) and written events whose ra_seq has two ranges (RGB_MF_SEQ2), in lock
+    step with the checker AND with the literal ra_seq model of tests/ra_log_model.py: the same last_written, the same
+    pending set, RGB_F_RESEND_PENDING exactly where the reference calls resend_pending/2 (:917-919), the
+    {ok, Pend} = ra_seq:remove_prefix(..) badmatch of the snapshot clause (:929) as an invariant."""
+    import test_pending_model as PM
+    cpu = oracle_lib.Oracle(1, 3)
+    with engine_mod.RaGpuBatch(1, 3, ring_capacity=64, ring_slots=2, max_runs=16) as gpu:
+        def step(m):
+            do, ro = cpu.step(m)
+            dg, rg = gpu.step(m)
+            assert_same("sparse pending", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+            return do
+
+        def set_state(st):
+            cpu.set_state(0, st)
+            gpu.set_state(0, st)
+        PM.sparse_history(step, cpu.get_state, set_state, seed, steps=120)
+        assert gpu.state_checksum() == engine_mod.combine_checksums(oracle_lib.server_checksums(cpu.get_state()))
+    cpu.close()
+
+
+def test_written_event_for_a_live_index_below_the_snapshot(engine_mod, oracle_lib):
+    """test/ra_log_2_SUITE.erl:1840-1880 snapshot_installation_with_live_indexes, the cursor part: indexes 1..9
+    written, live index 14 written sparsely (write_sparse({14,2,_}, 9, _)), snapshot {15,2} installed -- the host
+    re-uploads the server with the range emptied and 14 still pending -- then the suite asserts last_written = {15,_},
+    writes index 16 and waits for last_written = {16,2}: the late written event of 14 only trims `pending`
+    (handle_event's snapshot clause, src/ra_log.erl:921-930), the one of 16 moves last_written."""
+    import test_pending_model as PM
+    cpu = oracle_lib.Oracle(1, 3)
+    with engine_mod.RaGpuBatch(1, 3, ring_capacity=64, ring_slots=2, max_runs=16) as gpu:
+        st = cpu.get_state()
+        st[1] = PM.sparse_state(st[1:2], 15, 2, [14])[0]
+        cpu.set_state(0, st); gpu.set_state(0, st)
+        assert PM.pending_of(gpu.get_state()[1]) == [14]
+
+        def step(m):
+            do, ro = cpu.step(m)
+            dg, rg = gpu.step(m)
+            assert_same("live index", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+            return gpu.get_state()[1]
+        s = step(PM._msg(abi.MSG_AER, frm=0, term=2, a=15, b=2, c=15, n_entries=1, n_run0=1, run0_term=2))   # write 16
+        assert int(s["last_index"]) == 16 and PM.pending_of(s) == [14, 16]
+        assert (int(s["last_written_index"]), int(s["last_written_term"])) == (15, 2)
+        s = step(PM._msg(abi.MSG_WRITTEN, term=2, a=14, b=14))                   # the WAL confirms the live index
+        assert PM.pending_of(s) == [16] and int(s["n_pending_old"]) == 0
+        assert (int(s["last_written_index"]), int(s["last_written_term"])) == (15, 2)
+        s = step(PM._msg(abi.MSG_WRITTEN, term=2, a=16, b=16))
+        assert PM.pending_of(s) == [] and (int(s["last_written_index"]), int(s["last_written_term"])) == (16, 2)
+    cpu.close()

@@ -100,3 +100,178 @@ def test_oracle_pending_matches_ra_seq_model(oracle_lib, seed):
         got = list(range(int(st["pending_first"]), li + 1)) if int(st["first_index"]) <= li else []
         assert got == pend, f"step {step}: pending {got[:6]}.. vs ra_seq {pend[:6]}.."
     cpu.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sparse `pending`: after ra_log:write_sparse/3 + install_snapshot (src/ra_log.erl:601-635) the
+# live indexes written below the snapshot are still unconfirmed, so `pending` is a ra_seq with gaps; written events
+# carry sequences of one or two ranges.  The checker keeps the sequence as an explicit index list, the model as the
+# reference's own high -> low list of indexes and ranges.
+
+def _ranges(idxs):
+    out = []
+    for i in idxs:
+        if out and out[-1][1] + 1 == i:
+            out[-1][1] = i
+        else:
+            out.append([i, i])
+    return out
+
+
+def sparse_state(st, snap_idx, snap_term, live):
+    """The host's re-upload after install_snapshot: empty range above the snapshot, the unconfirmed live indexes
+    (at most two runs of them) as the old ranges of `pending`."""
+    s = st.copy()
+    s["snapshot_index"], s["snapshot_term"] = snap_idx, snap_term
+    s["last_index"], s["last_term"] = snap_idx, snap_term
+    s["first_index"] = snap_idx + 1
+    s["last_written_index"], s["last_written_term"] = snap_idx, snap_term
+    s["commit_index"], s["last_applied"] = snap_idx, snap_idx
+    s["n_runs"] = 0
+    s["run_start"] = 0
+    s["run_term"] = 0
+    s["current_term"] = snap_term
+    s["pending_first"] = snap_idx + 1
+    r = _ranges(live)
+    assert len(r) <= 2
+    s["n_pending_old"] = len(r)
+    s["pending_old"] = 0
+    for k, (a, b) in enumerate(r):
+        s["pending_old"][0, k] = (a, b)
+    return s
+
+
+def pending_of(st):
+    li = int(st["last_index"])
+    out = []
+    for k in range(int(st["n_pending_old"])):
+        out += list(range(int(st["pending_old"][k][0]), int(st["pending_old"][k][1]) + 1))
+    if int(st["first_index"]) <= li:
+        out += list(range(int(st["pending_first"]), li + 1))
+    return out
+
+
+def sparse_history(step_fn, get_state, set_state, seed, steps=200):
+    """Drives `step_fn(msg) -> decision` (the checker, or checker + engine in lock step) and the ra_seq model through
+    one random history; yields nothing, asserts equality of last_written, pending and the resend / crash decisions."""
+    from ra_log_model import LogModel, seq_expand, seq_from_list
+    rng = np.random.default_rng(5000 + seed)
+    snap_idx, term = int(rng.integers(20, 40)), int(rng.integers(1, 4))
+    picks = sorted(set(int(x) for x in rng.integers(1, snap_idx, size=int(rng.integers(1, 6)))))
+    live = []
+    for r in _ranges(picks)[:2]:
+        live += list(range(r[0], r[1] + 1))
+    st = get_state()
+    st[1] = sparse_state(st[1:2], snap_idx, term, live)[0]
+    set_state(st)
+    model = LogModel()
+    model.range, model.terms, model.snap, model.lw = None, {}, (snap_idx, term), (snap_idx, term)
+    model.last_term = term
+    model.pending = seq_from_list(live)
+    n_two, n_resend, n_clause2 = 0, 0, 0
+    for step in range(steps):
+        st1 = get_state()[1]
+        li, lt = int(st1["last_index"]), int(st1["last_term"])
+        assert (li, lt) == model.last_index_term(), f"step {step}"
+        assert pending_of(st1) == seq_expand(model.pending), f"step {step}: pending before"
+        r = rng.random()
+        if r < 0.30:                                        # append at the tail
+            if rng.random() < 0.15:
+                term += 1
+            n = int(rng.integers(1, 4))
+            d = step_fn(_msg(abi.MSG_AER, frm=0, term=term, a=li, b=lt, c=int(st1["commit_index"]), n_entries=n,
+                             n_run0=n, run0_term=term))
+            assert not (int(d["flags"][0]) & abi.F_INVARIANT), f"step {step}"
+            model.write([(li + 1 + k, term) for k in range(n)])
+        elif r < 0.38 and model.range and model.range[1] - max(model.range[0], int(st1["last_applied"])) >= 2:
+            lo = max(model.range[0], int(st1["last_applied"])) + 1       # overwrite the tail
+            fst = int(rng.integers(lo, model.range[1] + 1))
+            prev_t = model.fetch_term(fst - 1)
+            if prev_t is None:
+                continue
+            term += 1
+            n = int(rng.integers(1, 3))
+            d = step_fn(_msg(abi.MSG_AER, frm=0, term=term, a=fst - 1, b=prev_t, c=0, n_entries=n, n_run0=n,
+                             run0_term=term))
+            assert int(d["flags"][0]) & abi.F_WROTE
+            model.write([(fst + k, term) for k in range(n)])
+        elif r < 0.44 and model.range and model.range[1] - max(model.range[0], int(st1["last_applied"])) >= 1:
+            lo = max(model.range[0], int(st1["last_applied"]))           # truncation: ra_log:set_last_index/2
+            idx = int(rng.integers(lo, model.range[1]))
+            t = model.fetch_term(idx)
+            if t is None:
+                continue
+            term += 1
+            d = step_fn(_msg(abi.MSG_AER, frm=0, term=term, a=idx, b=t, c=0, n_entries=0))
+            assert int(d["flags"][0]) & abi.F_TRUNCATED
+            assert model.set_last_index(idx)
+        elif r < 0.92:                                      # a written event of one or two ranges
+            pend = seq_expand(model.pending)
+            runs = _ranges(pend)
+            mode = rng.random()
+            if len(runs) >= 2 and mode < 0.45:              # the two lowest pending runs (or prefixes of them)
+                lo_r, hi_r = runs[0], runs[1]
+                w_lo = list(range(lo_r[0], lo_r[1] + 1))
+                w_hi = list(range(hi_r[0], int(rng.integers(hi_r[0], hi_r[1] + 1)) + 1))
+            elif runs and mode < 0.75:                      # (a prefix of) the lowest run only
+                w_lo, w_hi = [], list(range(runs[0][0], int(rng.integers(runs[0][0], runs[0][1] + 1)) + 1))
+            elif len(runs) >= 2 and mode < 0.85:            # skips the lowest run: not a prefix
+                w_lo, w_hi = [], list(range(runs[1][0], runs[1][1] + 1))
+            else:                                           # anywhere
+                b = max(1, li + int(rng.integers(-6, 2))); a = max(1, b - int(rng.integers(0, 4)))
+                w_lo, w_hi = [], list(range(a, b + 1))
+                if a > 3 and rng.random() < 0.5:
+                    w_lo = list(range(max(1, a - 3 - int(rng.integers(0, 3))), a - 1))
+            if w_lo and w_lo[-1] + 1 >= w_hi[0]:
+                w_lo = []
+            top = w_hi[-1]
+            wt = model.fetch_term(min(top, li)) if model.range else None
+            if wt is None or rng.random() < 0.15:
+                wt = max(0, lt - int(rng.integers(0, 2)))
+            kw = dict(term=wt, a=w_hi[0], b=w_hi[-1])
+            if w_lo:
+                kw.update(flags=abi.MF_SEQ2, run0_term=w_lo[0], run1_term=w_lo[-1])
+                n_two += 1
+            d = step_fn(_msg(abi.MSG_WRITTEN, **kw))
+            seq = seq_from_list(w_lo + w_hi)
+            if int(d["flags"][0]) & abi.F_INVARIANT:
+                assert int(d["invariant"][0]) == abi.INV_WRITTEN_NOT_PREFIX
+                with pytest.raises(AssertionError):
+                    model.written(wt, seq)
+                return n_two, n_resend, n_clause2, True     # the reference process would have crashed
+            before = seq_expand(model.pending)
+            lw_before = model.lw
+            model.written(wt, seq)
+            assert bool(int(d["flags"][0]) & abi.F_RESEND_PENDING) == model.resend, f"step {step}"
+            n_resend += model.resend
+            n_clause2 += (not model.resend and model.lw == lw_before and seq_expand(model.pending) != before)
+        else:                                               # snapshot at last_applied
+            la = int(st1["last_applied"])
+            t = model.fetch_term(la)
+            if t is None or la == 0:
+                continue
+            step_fn(_msg(abi.MSG_SNAPSHOT_WRITTEN, a=la, b=t))
+            model.snapshot_written(la, t)
+        st1 = get_state()[1]
+        assert (int(st1["last_written_index"]), int(st1["last_written_term"])) == model.lw, f"step {step}"
+        assert pending_of(st1) == seq_expand(model.pending), f"step {step}: pending {pending_of(st1)[:8]} vs {seq_expand(model.pending)[:8]}"
+    return n_two, n_resend, n_clause2, False
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_oracle_sparse_pending_matches_ra_seq_model(oracle_lib, seed):
+    cpu = oracle_lib.Oracle(1, 3)
+    stats = sparse_history(lambda m: cpu.step(m)[0], cpu.get_state, lambda st: cpu.set_state(0, st), seed)
+    cpu.close()
+    assert stats is not None
+
+
+def test_sparse_histories_cover_the_interesting_cases(oracle_lib):
+    tot = np.zeros(4, dtype=np.int64)
+    for seed in range(40):
+        cpu = oracle_lib.Oracle(1, 3)
+        tot += np.array(sparse_history(lambda m: cpu.step(m)[0], cpu.get_state, lambda st: cpu.set_state(0, st), seed),
+                        dtype=np.int64)
+        cpu.close()
+    n_two, n_resend, n_clause2, crashed = tot
+    assert n_two > 100 and n_resend > 20 and n_clause2 > 20, tot
