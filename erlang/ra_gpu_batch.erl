@@ -14,7 +14,7 @@
 %%     commit_index:64, last_applied:64
 -module(ra_gpu_batch).
 
--export([init/0, open/4, register_groups/3, upload_state/3, download_state/3, register_owner/4,
+-export([init/0, open/4, register_groups/3, upload_state/3, download_state/3, register_owner/4, route/2,
          submit/3, collect/1, start_collector/2, stop_collector/1, snapshot/2, wal_checksums/3]).
 -export([wal_batch_checksums/2, wal_frame/4, wal_recover_check/2, wal_frame_batch/3, wal_recover/2]).
 -export([encode_msg/3, decode_decision/1, decision_to_effects/3]).
@@ -65,6 +65,10 @@ open(_Device, _MaxRuns, _RingSlots, _RingCapacity) -> erlang:nif_error(not_loade
 register_groups(_Ctx, _NGroups, _NMembers) -> erlang:nif_error(not_loaded).
 upload_state(_Ctx, _First, _Bin) -> erlang:nif_error(not_loaded).
 download_state(_Ctx, _First, _N) -> erlang:nif_error(not_loaded).
+%% route(GroupUId, NContexts) -> 0..NContexts-1: the context (one per GPU, one open/4 each) that owns a Raft group:
+%% splitmix64(GroupUId) rem NContexts, the partition of SURVEY.md section 8(e).  GroupUId = any stable 64-bit id of
+%% the cluster (e.g. erlang:phash2 is NOT stable across nodes; use the integer kept beside the ra_directory entry).
+route(_GroupUId, _NContexts) -> erlang:nif_error(not_loaded).
 %% register_owner(Ctx, FirstServer, N, Pid): the collector thread sends every decision of servers
 %% [FirstServer, FirstServer+N) to Pid as {ra_gpu_batch, Tick, NDecisions, DecisionsBin, RpcsBin} (only that
 %% process's decisions, submission order; rpc msg_index = position inside DecisionsBin).  A ra_server_proc

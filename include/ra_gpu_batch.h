@@ -54,7 +54,12 @@ enum {
 enum {
   RGB_COND_NONE          = 0,
   RGB_COND_MISSING       = 1,
-  RGB_COND_TERM_MISMATCH = 2
+  RGB_COND_TERM_MISMATCH = 2,
+  RGB_COND_WAL_DOWN      = 3   /* follower whose ra_log:write/2 returned {error, wal_down} (src/ra_server.erl:1377-1385,
+                                  wal_down_condition/2 :2232-2233).  The write is host I/O: the host re-uploads the server in
+                                  role await_condition with this reason and the log as it was BEFORE the write; from then on
+                                  it sets RGB_MF_CAN_WRITE on the server's messages once ra_log:can_write/1 is true again --
+                                  the predicate of the reference.  No stored reply: a timeout just returns to follower. */
 };
 
 /* message kinds (one inbound ra_msg() for one server) */
@@ -88,6 +93,7 @@ enum {
 #define RGB_MF_FORCE    0x02u  /* APPEND: noop command => Force pipelining (src/ra_server.erl:682-689) */
 #define RGB_MF_SEQ2     0x08u  /* WRITTEN: the written ra_seq has TWO ranges: [run0_term .. run1_term] (the lower one, reusing
                                   those two fields as indexes) and [a .. b] above it, run1_term + 1 < a */
+#define RGB_MF_CAN_WRITE 0x10u /* any kind, for a server awaiting RGB_COND_WAL_DOWN: ra_log:can_write(Log) is true */
 #define RGB_MF_TICK     0x04u  /* PIPELINE_RPCS: the leader's tick_timeout -- ra_server:make_rpcs/1: heartbeats for
                                   waiting queries plus one batch-of-1 rpc per stale peer, next_index not advanced
                                   (src/ra_server.erl:2348-2351, 2369-2377, 3012-3030; src/ra_server_proc.erl:613-616) */

@@ -1337,6 +1337,24 @@ static int handle_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx, int *reproces
 /* ------------------------------------------------------ await_condition clauses -- */
 static int handle_await_condition(oserver *sv, const rgb_msg *m, ofx *fx, int *reprocess) {
   oscal *s = &sv->s;
+  /* condition = #{predicate_fun => fun wal_down_condition/2} (src/ra_server.erl:1377-1385, 2232-2233): the predicate is
+   * ra_log:can_write(Log), host knowledge carried by RGB_MF_CAN_WRITE; the condition map has no timeout effects */
+  if (s->cond_reason == RGB_COND_WAL_DOWN) {
+    switch (m->kind) {
+      case RGB_MSG_REQUEST_VOTE: case RGB_MSG_PRE_VOTE_RPC: case RGB_MSG_ELECTION_TIMEOUT:
+      case RGB_MSG_WRITTEN: case RGB_MSG_SNAPSHOT_WRITTEN:
+        break;                                               /* their own clauses, below */
+      case RGB_MSG_AWAIT_TIMEOUT:
+        set_role(s, RGB_ROLE_FOLLOWER, fx);                  /* :1932-1945 with Timeout = #{}: no effects */
+        return 0;
+      default:
+        if (m->flags & RGB_MF_CAN_WRITE) {                   /* :1950-1955 {next_event, Msg} */
+          set_role(s, RGB_ROLE_FOLLOWER, fx);
+          *reprocess = 1;
+        }
+        return 0;
+    }
+  }
   switch (m->kind) {
     case RGB_MSG_REQUEST_VOTE:
       set_role(s, RGB_ROLE_FOLLOWER, fx);                   /* :1918-1919 */

@@ -20,7 +20,7 @@ DEFAULT_MAX_PIPELINE_COUNT = 4096
 # ra_state()
 ROLE_FOLLOWER, ROLE_CANDIDATE, ROLE_LEADER, ROLE_PRE_VOTE, ROLE_AWAIT_CONDITION = range(5)
 ROLE_NAMES = ["follower", "candidate", "leader", "pre_vote", "await_condition"]
-COND_NONE, COND_MISSING, COND_TERM_MISMATCH = range(3)
+COND_NONE, COND_MISSING, COND_TERM_MISMATCH, COND_WAL_DOWN = range(4)
 
 (MSG_NOP, MSG_AER, MSG_AER_REPLY, MSG_REQUEST_VOTE, MSG_VOTE_RESULT, MSG_WRITTEN,
  MSG_PIPELINE_RPCS, MSG_APPEND, MSG_AWAIT_TIMEOUT, MSG_ELECTION_TIMEOUT, MSG_PRE_VOTE_RPC,
@@ -35,6 +35,7 @@ MF_SUCCESS = 0x01
 MF_FORCE = 0x02
 MF_TICK = 0x04
 MF_SEQ2 = 0x08
+MF_CAN_WRITE = 0x10
 
 F_REPLY = 1 << 0
 F_REPLY_SUCCESS = 1 << 1

@@ -346,6 +346,15 @@ static ERL_NIF_TERM nif_snapshot(ErlNifEnv *env, int argc, const ERL_NIF_TERM ar
   return enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_binary(env, &b));
 }
 
+/* route(GroupUId, NContexts) -> 0..NContexts-1: which context (= GPU) of this node owns the Raft group; a pure
+ * function (rgb_route: splitmix64(GroupUId) rem NContexts), so every process routes without asking anybody */
+static ERL_NIF_TERM nif_route(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  uint64_t uid; unsigned n;
+  (void)argc;
+  if (!enif_get_uint64(env, argv[0], &uid) || !enif_get_uint(env, argv[1], &n) || n == 0) return enif_make_badarg(env);
+  return enif_make_uint(env, rgb_route(uid, n));
+}
+
 static int on_load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info) {
   (void)priv; (void)info;
   CTX_TYPE = enif_open_resource_type(env, NULL, "ra_gpu_batch_ctx", ctx_dtor, ERL_NIF_RT_CREATE, NULL);
@@ -418,6 +427,7 @@ static ErlNifFunc nif_funcs[] = {
   {"register_groups", 3, nif_register_groups, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"upload_state", 3, nif_upload_state, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"download_state", 3, nif_download_state, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"route", 2, nif_route, 0},
   {"register_owner", 4, nif_register_owner, 0},
   {"submit", 3, nif_submit, 0},
   {"collect", 1, nif_collect, ERL_NIF_DIRTY_JOB_IO_BOUND},

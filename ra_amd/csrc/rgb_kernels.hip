@@ -1494,12 +1494,19 @@ __device__ __forceinline__ int handle_pre_vote(Lane &L, bool &reprocess) {
 /* ----------------------------------------------------------- await_condition ---- */
 template <int N>
 __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, const u64 *cond_row) {
+  /* wal_down_condition/2 :2232-2233: the predicate is ra_log:can_write/1, which the host knows and passes along */
+  const bool wal_down = pk_get(L.pk, PK_COND_SH, 2) == RGB_COND_WAL_DOWN;
+  const bool can_write = (L.mflags & RGB_MF_CAN_WRITE) != 0;
   switch (L.kind) {
     case RGB_MSG_REQUEST_VOTE:
       set_role(L, RGB_ROLE_FOLLOWER);                                /* :1918-1919 */
       reprocess = true;
       return 0;
     case RGB_MSG_AWAIT_TIMEOUT: {
+      if (wal_down) {                    /* no timeout effects in this condition: back to follower either way */
+        set_role(L, RGB_ROLE_FOLLOWER);
+        return 0;
+      }
       /* :1932-1945: predicate false -> stored effects, back to follower */
       L.has_reply = true;
       L.flags |= RGB_F_REPLY | RGB_F_LEADER_MSG;
@@ -1521,7 +1528,9 @@ __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, 
     case RGB_MSG_AER: {
       /* follower_catchup_cond/3 :2201-2218 */
       bool pred = false;
-      if (L.term >= L.ct) {
+      if (wal_down) {
+        pred = can_write;
+      } else if (L.term >= L.ct) {
         int h = has_log_entry_or_snapshot(L, L.a, L.b);
         if (h == HLE_OK) pred = true;
         else if (h == HLE_MISMATCH) pred = pk_get(L.pk, PK_COND_SH, 2) == RGB_COND_MISSING;
@@ -1529,7 +1538,11 @@ __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, 
       if (pred) { set_role(L, RGB_ROLE_FOLLOWER); reprocess = true; } /* :1950-1955 */
       return 0;
     }
-    default: return 0;
+    default:
+      /* the catch-all clause :1950-1959: follower_catchup_cond/3 is false for anything but an append_entries_rpc;
+       * the wal_down predicate does not look at the message */
+      if (wal_down && can_write) { set_role(L, RGB_ROLE_FOLLOWER); reprocess = true; }
+      return 0;
   }
 }
 
@@ -1642,6 +1655,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   L.po_floor = 0; L.po_cut = UNDEF;
 
   const unsigned role0 = role_of(L);
+  const unsigned pkhi0 = (unsigned)(L.pk >> 56);      /* the packed word's flag bits 56.. as loaded */
   const u64 ci0 = L.ci, la0 = L.la;
   const unsigned n_runs0 = L.n_runs;
   unsigned n_rpcs = 0;
@@ -1664,6 +1678,9 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     if (!rc && reprocess) { L.flags |= RGB_F_REPROCESSED; to_follower = true; }
   }
   if (!rc && to_follower) rc = handle_follower<N>(L);
+#ifdef RGB_PROFILE
+  if (t_loaded && RGB_KNOB(dev, 16u)) t_loaded[2] = wall_clock64();     /* clause code done (stores of rpc records issued) */
+#endif
   if (rc) {
     /* the reference would exit/assert: nothing is committed */
     make_decision(out, L.server, role0, RGB_NONE, 0, L.kind, RGB_F_INVARIANT, (u32)rc, 0, 0, 0, 0, ci0, la0);
@@ -1702,7 +1719,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     ST16(cp + 1, make_ulonglong2(L.cr2, L.cr3));
   }
   /* ---- commit: query row (rare) ---- */
-  const bool q_reset = pk_get(h0.y, PK_QPEER_SH, 1) && !pk_get(L.pk, PK_QPEER_SH, 1);
+  const bool q_reset = ((pkhi0 >> (PK_QPEER_SH - 56)) & 1u) && !pk_get(L.pk, PK_QPEER_SH, 1);
   if ((L.q_dirty || q_reset) && !RGB_KNOB(dev, 1u)) {
     u64 *q = qry_row(L);
     if (L.q_dirty & 1u) q[0] = L.qself;
@@ -1721,7 +1738,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     }
   }
   /* ---- commit: sparse `pending` (rare: only servers uploaded after a write_sparse) ---- */
-  if (pk_get(h0.y, PK_PENDX_SH, 1) && !RGB_KNOB(dev, 1u)) {
+  if (((pkhi0 >> (PK_PENDX_SH - 56)) & 1u) && !RGB_KNOB(dev, 1u)) {
     u64 *q = qry_row(L);
     u64 s0 = q[QRY_PEND_LO], e0 = q[QRY_PEND_LO + 1], s1 = q[QRY_PEND_HI], e1 = q[QRY_PEND_HI + 1];
     /* cut: keep [po_floor, po_cut) */
@@ -1746,13 +1763,13 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   /* ---- commit: hot line (only the 16-B pieces that changed) ---- */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
   if (!RGB_KNOB(dev, 1u)) {
+  if (L.n_runs < 2) { L.prs = 0; L.prt = 0; }         /* canonical: no run n-2 */
   if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
   if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la));
   if (L.li != h2.x || L.lt != h2.y) ST16(ho + 2, make_ulonglong2(L.li, L.lt));
   if (L.lwi != h3.x || L.lwt != h3.y) ST16(ho + 3, make_ulonglong2(L.lwi, L.lwt));
   if (L.si != h4.x || L.st != h4.y) ST16(ho + 4, make_ulonglong2(L.si, L.st));
   if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs));
-  if (L.n_runs < 2) { L.prs = 0; L.prt = 0; }         /* canonical: no run n-2 */
   if (L.lrt != h6.x || L.prs != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.prs));
   if (L.prt != h7.x || L.pend != h7.y) ST16(ho + 7, make_ulonglong2(L.prt, L.pend));
   if (TM && L.token != token0) ST8(qry_row(L) + QRY_TOKEN, L.token);
@@ -1766,8 +1783,164 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   make_decision(out, L.server, role_of(L), L.has_reply ? L.reply_to : (unsigned)RGB_NONE, n_rpcs, L.kind,
                 L.flags, 0, w2, w3, w4, w5, L.ci, L.la, L.hb_mask, L.cancel_mask);
 #ifdef RGB_PROFILE
-  if (t_loaded) t_loaded[1] = L.prof_nloads;
+  if (t_loaded) { t_loaded[1] = L.prof_nloads; if (RGB_KNOB(dev, 16u)) t_loaded[3] = wall_clock64(); }   /* commit issued */
 #endif
+}
+
+/* ------------------------------------------------------------------ fast paths ----
+ * The three bulk kinds have ONE steady-state outcome each that takes a few dozen instructions, against the ~1000
+ * the general clause code executes per wavefront (every rare clause costs its region's bookkeeping even when no
+ * lane enters it).  fast_*() handle exactly that outcome: they test its preconditions on the hot row, and when all
+ * hold they produce the decision and the state changes process_message<N, KIND> would have produced, bit for bit
+ * (the parity tests run every stream through both); when any fails they touch nothing and return false.
+ * Row pieces are read from the lane's LDS row (piece p at pre[p ^ swz]). */
+#ifndef RGB_X_FAST
+#define RGB_X_FAST 1
+#endif
+
+/* follower, append_entries_rpc from the known leader in the current term, appended right after the last index with
+ * entries of the last run's term: ra_log:write of the tail (src/ra_server.erl:1283-1303, 1365-1389; ra_log:write/2
+ * src/ra_log.erl:547-599; evaluate_commit_index_follower/2 :2246-2280) */
+__device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1, const ulonglong2 m2,
+                                         const ulonglong2 m3, const ulonglong2 *pre, unsigned swz, Dec &out) {
+  const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), from = (unsigned)((m0.x >> 40) & 0xFF);
+  const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF), gap = (unsigned)((m0.x >> 56) & 0xFF);
+  const u32 n_entries = (u32)(m2.y & 0xFFFFFFFFull), n_run0 = (u32)(m2.y >> 32);
+  if (wire_kind != RGB_MSG_AER || server >= dev.n_servers || gap != 0 || n_entries == 0 || n_run0 < n_entries ||
+      from >= 8u || mflags != 0)
+    return false;
+  const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h5 = pre[5 ^ swz],
+                   h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
+  const u64 ct = h0.x, pk = h0.y, la = h1.y, li = h2.x, lt = h2.y, lwi = h3.x, first = h5.x, lrs = h5.y, lrt = h6.x,
+            pend = h7.y;
+  /* follower (role 0, no condition), the sender is the leader we know, nothing sparse pending, a run table */
+  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER || pk_get(pk, PK_LEADER_SH, 4) != from ||
+      pk_get(pk, PK_PENDX_SH, 1) || pk_get(pk, PK_NRUNS_SH, 5) == 0)
+    return false;
+  const u64 term = m0.y, pli = m1.x, plt = m1.y, leader_commit = m2.x, eterm = m3.x;
+  if (term != ct || !(first <= li) || li == UNDEF || pli != li || li < lrs || plt != lrt || lt != lrt ||
+      eterm != lrt || la > li + 1 || lwi > li || pend > li + 1)
+    return false;
+  if (pk_get(pk, PK_NRUNS_SH, 5) < 2 && (h6.y | h7.x) != 0) return false;   /* the commit would canonicalise the row */
+  /* has_log_entry_or_snapshot: entry_ok; drop_existing: nothing exists above the last index; ra_log:write extends
+   * the last run: last_index moves, last_written and pending keep their words ([pend..] simply grows) */
+  const u64 fst = li + 1, lst = li + n_entries;
+  u32 flags = RGB_F_WROTE | RGB_F_LEADER_MSG;
+  const u64 ci = leader_commit;
+  u64 nla = la;
+  const u64 at = lst < ci ? lst : ci;
+  if (at > la) { nla = at; flags |= RGB_F_APPLIED | RGB_F_AUX_EVAL; }     /* apply_to/5: at >= la + 1 */
+  ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS);
+  if (ci != h1.x || nla != la) ST16(ho + 1, make_ulonglong2(ci, nla));
+  ST16(ho + 2, make_ulonglong2(lst, lt));
+  make_decision(out, server, RGB_ROLE_FOLLOWER, RGB_NONE, 0, RGB_MSG_AER, flags, 0, 0, fst, lst, 0, ci, nla);
+  return true;
+}
+
+/* follower, {written, Term, [From..To]} that confirms (a prefix of) the pending tail inside the last term run:
+ * last_written moves to To, the reply goes to the known leader (src/ra_server.erl:1457-1474; ra_log:handle_event
+ * src/ra_log.erl:897-920) */
+__device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
+                                             const ulonglong2 *pre, unsigned swz, Dec &out) {
+  const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), mflags = (unsigned)((m0.x >> 48) & 0xFF);
+  if (wire_kind != RGB_MSG_WRITTEN || server >= dev.n_servers || mflags != 0) return false;
+  const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h4 = pre[4 ^ swz],
+                   h5 = pre[5 ^ swz], h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
+  const u64 ct = h0.x, pk = h0.y, li = h2.x, si = h4.x, first = h5.x, lrs = h5.y, lrt = h6.x, pend = h7.y;
+  const unsigned l4 = (unsigned)pk_get(pk, PK_LEADER_SH, 4);
+  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER || l4 == SLOT_NONE4 || pk_get(pk, PK_PENDX_SH, 1) ||
+      pk_get(pk, PK_NRUNS_SH, 5) == 0)
+    return false;
+  const u64 term = m0.y, from = m1.x, to = m1.y;
+  /* the whole of [from..to] ends inside the last run, which has the event's term; the snapshot lies below the range */
+  if (!(first <= li) || li == UNDEF || from > to || to > li || to < lrs || to < first || lrt != term ||
+      (si != UNDEF && si >= first) || pend > li + 1)
+    return false;
+  if (pk_get(pk, PK_NRUNS_SH, 5) < 2 && (h6.y | h7.x) != 0) return false;   /* the commit would canonicalise the row */
+  /* ra_seq:remove_prefix: the pending tail [pend..li] up to `to` must start inside [from..to] */
+  if (pend <= li && pend <= to && pend < from) return false;         /* not a prefix: the resend path */
+  u64 npend = pend;
+  if (pend <= li && to + 1 > pend) npend = to + 1;                    /* == li + 1 when everything is confirmed */
+  const bool changed = !(h3.x == to && h3.y == term);
+  ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS);
+  if (changed) ST16(ho + 3, make_ulonglong2(to, term));
+  if (npend != pend) ST16(ho + 7, make_ulonglong2(h7.x, npend));
+  u32 flags = 0;
+  u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
+  unsigned reply_to = RGB_NONE;
+  if (changed) {                                                      /* append_entries_reply/3 :3624-3631 */
+    flags = RGB_F_REPLY | RGB_F_REPLY_SUCCESS;
+    w2 = ct; w3 = li + 1; w4 = to; w5 = term; reply_to = slot4to8(l4);
+  }
+  make_decision(out, server, RGB_ROLE_FOLLOWER, reply_to, 0, RGB_MSG_WRITTEN, flags, 0, w2, w3, w4, w5, h1.x, h1.y);
+  return true;
+}
+
+/* leader, {Peer, #append_entries_reply{success = true}} of the current term from a member: match / next index of the
+ * peer, evaluate_quorum/2, apply (src/ra_server.erl:532-571, 3633-3688); the term of the agreed index must be
+ * answerable from the two newest runs (else the general path probes the run table) */
+template <int N>
+__device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
+                                               const ulonglong2 *pre, unsigned swz, Dec &out) {
+  const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), peer = (unsigned)((m0.x >> 40) & 0xFF);
+  const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF);
+  if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || mflags != RGB_MF_SUCCESS || peer >= (unsigned)N)
+    return false;
+  const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h4 = pre[4 ^ swz],
+                   h5 = pre[5 ^ swz], h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
+  const u64 ct = h0.x, pk = h0.y, ci0 = h1.x, la = h1.y, li = h2.x, lwi = h3.x, si = h4.x, st = h4.y, first = h5.x,
+            lrs = h5.y, lrt = h6.x, prs = h6.y, prt = h7.x;
+  const unsigned present = (unsigned)pk_get(pk, PK_PRESENT_SH, 8), voters = (unsigned)pk_get(pk, PK_VOTER_SH, 8);
+  const unsigned self = (unsigned)pk_get(pk, PK_SELF_SH, 4), n_runs = (unsigned)pk_get(pk, PK_NRUNS_SH, 5);
+  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_LEADER || m0.y != ct || !((present >> peer) & 1u)) return false;
+  if (n_runs < 2 && (h6.y | h7.x) != 0) return false;
+  u64 *peers = dev.peers + (size_t)server * dev.peer_stride;
+  u64 w[2 * N + (N & 1)];
+  {
+    const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(peers);
+#pragma unroll
+    for (int k = 0; k < (2 * N + 1) / 2; ++k) { const ulonglong2 v = pp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+  }
+  /* match_index / next_index of the peer only move forward (:540-547) */
+  u64 mi_new = 0, ni_new = 0; bool mi_dirty = false, ni_dirty = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if ((unsigned)i != peer) continue;
+    mi_new = w[i]; ni_new = w[N + i];
+    if (m1.y > w[i]) { mi_new = m1.y; mi_dirty = true; w[i] = m1.y; }
+    if (m1.x > w[N + i]) { ni_new = m1.x; ni_dirty = true; }
+  }
+  /* agreed_commit/1 over the voters' match indexes and the leader's last written index: descending order statistic
+   * n/2 + 1 by rank counting */
+  u64 v[N + 1]; bool use[N + 1]; int n = 1;
+  v[N] = lwi; use[N] = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const bool u = ((unsigned)i != self) && ((present >> i) & 1u) && ((voters >> i) & 1u);
+    v[i] = w[i]; use[i] = u; n += u ? 1 : 0;
+  }
+  const u64 p = agreed_commit<N + 1>(v, use, n);
+  u64 t = UNDEF;
+  if (first <= li && p >= first && p <= li) {
+    if (p >= lrs) t = lrt;
+    else if (n_runs >= 2 && p >= prs) t = prt;
+    else return false;                                               /* older than the mirrored runs: probe */
+  }
+  if (t == UNDEF && si != UNDEF && si == p) t = st;
+  u64 ci = ci0, nla = la;
+  u32 flags = RGB_F_PIPELINE;
+  if (t != UNDEF && t == ct) ci = p;                                 /* Raft 5.4.2; NO max() */
+  if (ci > ci0) flags |= RGB_F_AUX_EVAL;
+  if (ci > la) { const u64 to = li < ci ? li : ci; if (to >= la + 1) { nla = to; flags |= RGB_F_APPLIED; } }
+  if (mi_dirty) ST8(peers + peer, mi_new);
+  if (ni_dirty) ST8(peers + N + peer, ni_new);
+  if (ci != ci0 || nla != la)
+    ST16(reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS) + 1, make_ulonglong2(ci, nla));
+  make_decision(out, server, RGB_ROLE_LEADER, RGB_NONE, 0, RGB_MSG_AER_REPLY, flags, 0, 0, 0, 0, 0, ci, nla);
+  return true;
 }
 
 /* The tick kernel: one lane per message, one wavefront per 64 consecutive messages.  Messages
@@ -1903,7 +2076,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   const int cls = rgb_class_at(q);
   const u32 lane = threadIdx.x;
 #ifdef RGB_PROFILE
-  u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl[2] = {0, 0};
+  u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl[4] = {0, 0, 0, 0};
   if (RGB_KNOB(dev, 16u)) t0 = wall_clock64();
 #endif
   const u32 base = off + blk * RGB_TICK_BLOCK;            /* first message of this wavefront */
@@ -1976,7 +2149,16 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #ifdef RGB_PROFILE
   tlp = tl;
 #endif
+  bool done = false;
+#if RGB_X_FAST
+  /* the steady-state outcome of the three bulk kinds first; whoever is left takes the general clause code below */
   if (active) {
+    if (cls == 0) done = fast_aer(dev, m0, m1, m2, m3, hrow, hswz, d);
+    else if (cls == 1) done = fast_aer_reply<N>(dev, m0, m1, hrow, hswz, d);
+    else if (cls == 2) done = fast_written(dev, m0, m1, hrow, hswz, d);
+  }
+#endif
+  if (active && !done) {
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
     RGB_MARK("begin", RANK)                                                                             \
@@ -2030,7 +2212,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     if (lane == 0) {
       u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 8;
       o[0] = t0; o[1] = t1 | ((tl[0] - t1) << 40); o[2] = t2 | ((t2b - t2) << 40) | ((u64)cls << 60); o[3] = wall_clock64();
-      o[4] = mx; o[5] = sm; o[6] = nz; o[7] = cnt;
+      o[4] = mx; o[5] = sm | ((tl[2] > t1 ? tl[2] - t1 : 0) << 24); o[6] = nz | ((tl[3] > t1 ? tl[3] - t1 : 0) << 24); o[7] = cnt;
     }
   }
 #endif

@@ -35,10 +35,11 @@ def local_group_ids(n_global_groups: int, n_shards: int, shard: int, per_rank: i
     return out[:per_rank]
 
 
-def route(msgs: np.ndarray, group_uid_of_msg: np.ndarray, n_shards: int, n_members: int,
-          local_index: dict | None = None):
-    """Split a host batch by owning shard (the host batcher of the NIF does this per message).
-    Returns a list of per-shard index arrays into msgs."""
+def route(msgs: np.ndarray, group_uid_of_msg: np.ndarray, n_shards: int):
+    """Split a host batch by owning shard: per-shard index arrays into msgs, submission order kept inside a shard
+    (what a multi-context host does with rgb_route() per message before rgb_submit on each context; the server
+    field of a routed message is then rewritten to the owner's local numbering by the caller's uid -> local map)."""
+    assert len(msgs) == len(group_uid_of_msg)
     own = owner(group_uid_of_msg, n_shards)
     return [np.flatnonzero(own == s) for s in range(n_shards)]
 

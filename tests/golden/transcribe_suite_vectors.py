@@ -849,6 +849,23 @@ vec("H12", "test/ra_server_SUITE.erl:3800-3840 await_condition_heartbeat_dropped
     dict(reset=True, **step("await_condition", hb_reply("n2", 4, 0), role="await_condition", state_unchanged=True, no_reply=True)),
 ], tweak=dict(role="await_condition", cond_reason="missing"))
 
+WAL_AER = aer(5, "n1", (3, 5), 3, [(4, 5)])
+vec("W1", "test/ra_server_SUITE.erl:1004-1033 wal_down_condition_follower", 3, "n1", "base", [
+    dict(reset=True, **step("await_condition", WAL_AER, role="await_condition", state_unchanged=True, no_reply=True,
+                             flags_clear=["REPROCESSED", "WROTE", "LEADER_MSG"])),
+    dict(reset=True, **step("await_condition", dict(WAL_AER, can_write=True), role="follower",
+                             state=dict(last_index=4, last_term=5, commit_index=3, last_applied=3),
+                             flags_set=["REPROCESSED", "WROTE", "LEADER_MSG"], no_reply=True)),
+    dict(reset=True, **step("await_condition", dict(kind="await_timeout"), role="follower", no_reply=True,
+                             flags_clear=["LEADER_MSG"])),
+    dict(reset=True, **step("await_condition", dict(hb(5, "n1", 0), can_write=True), role="follower",
+                             flags_set=["REPROCESSED"], reply=dict(heartbeat=True, to="n1", term=5))),
+], tweak=dict(commit_index=3, role="await_condition", cond_reason="wal_down"),
+    note="the suite mocks ra_log:write/2 -> {error, wal_down}: that step is the HOST's (it re-uploads the server in "
+         "await_condition / RGB_COND_WAL_DOWN with the log as before the write and commit_index = LeaderCommit); steps 0-1 "
+         "are the suite's two handle_await_condition calls (can_write false, then true); the timeout and the "
+         "heartbeat steps follow src/ra_server.erl:1932-1959 with a condition map that has no timeout effects")
+
 AGREED_COMMIT = [([4], 4), ([4, 3], 3), ([4, 4, 4], 4), ([4, 4, 3], 4), ([3, 4, 4], 4),
                  ([4, 2, 3], 3)]
 

@@ -349,6 +349,15 @@ def test_big_batches_go_to_a_dirty_scheduler(beam):
     beam.L.mock_gc_resource_term(ctx.t)
 
 
+def test_route_nif_is_the_c_partition(beam):
+    from ra_amd import shard
+    ids = np.arange(300, dtype=np.uint64)
+    for world in (2, 8):
+        got = [beam.call("route", int(g), world) for g in ids]
+        assert got == shard.owner(ids, world).tolist()
+    assert beam.call("route", 5, 0) == "badarg"
+
+
 def test_nif_table_matches_the_erlang_stub(beam):
     """Every NIF the Erlang module declares (erlang/ra_gpu_batch.erl: `Name(_Args) -> erlang:nif_error(not_loaded)`)
     is in the shim's table with the same arity, and the blocking ones are dirty-scheduler NIFs."""
@@ -360,7 +369,7 @@ def test_nif_table_matches_the_erlang_stub(beam):
         arity = len([a for a in args.split(",") if a.strip()])
         flags = beam.L.mock_func_flags(name.encode(), arity)
         assert flags != 0xFFFFFFFF, f"{name}/{arity} is not in the NIF table"
-        if name in ("submit", "open", "start_collector", "register_owner"):
+        if name in ("submit", "open", "start_collector", "register_owner", "route"):
             assert flags == 0, f"{name} must not be a dirty NIF (non-blocking)"
         else:
             assert flags == 2, f"{name} waits on the GPU / copies: dirty IO-bound"

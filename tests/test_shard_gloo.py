@@ -70,6 +70,68 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _engine_worker(rank, world, port, out_dir, emu_so, g_global):
+    """The same, with the PRODUCT engine per rank (its device code compiled for the CPU, tests/conftest.py
+    `emulated_kernels_so`): C-level routing (rgb_route), rgb_submit/rgb_collect per tick, the leaderboard kernel for
+    the rank's rows, then the all-gather."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ra_amd import engine
+    engine.LIB_PATH, engine._lib = emu_so, None
+    L = engine.lib()
+    # the partition through the C entry point a NIF would call, checked against the numpy form
+    mine = np.array([g for g in range(g_global) if L.rgb_route(g, world) == rank], dtype=np.uint64)
+    assert np.array_equal(mine, shard.local_group_ids(g_global, world, rank))
+    G = len(mine)
+    st = np.concatenate([W.initial_states(1, N, SEED ^ int(g)) for g in mine])
+    st["self"] = np.arange(G * N) % N
+    with engine.RaGpuBatch(G, N, max_runs=16, ring_capacity=G * N, ring_slots=2) as eng:
+        eng.set_state(0, st)
+        for t in range(TICKS):
+            cur = eng.get_state()
+            if W.heal(cur, N, max_runs=16):
+                eng.set_state(0, cur)
+            msgs = []
+            for k, g in enumerate(mine):
+                m = W.gen_tick(cur[k * N:(k + 1) * N], N, t, SEED ^ int(g))
+                m["server"] += k * N
+                msgs.append(m)
+            eng.step(np.concatenate(msgs))
+        rows = eng.snapshot()
+    uids, allrows = shard.all_gather_leaderboard(rows, mine, dist)
+    np.save(os.path.join(out_dir, f"e_uids_{rank}.npy"), uids)
+    np.save(os.path.join(out_dir, f"e_rows_{rank}.npy"), allrows.view(np.uint8))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_with_the_product_engine_per_rank(tmp_path, oracle_lib, emulated_kernels_so):
+    """VERDICT round 1 (multi-GPU readiness): the 2-rank path drives the engine itself, not the checker -- one
+    rgb_ctx per rank over its hash shard, no data-path collective, the gathered leaderboard equal to what a single
+    process computing every group with the CHECKER gets."""
+    global G_GLOBAL
+    world, g_global = 2, 96
+    port = _free_port()
+    mp.spawn(_engine_worker, args=(world, port, str(tmp_path), emulated_kernels_so, g_global), nprocs=world, join=True)
+    all_g = np.arange(g_global, dtype=np.uint64)
+    ref_rows = shard.leaderboard_rows_from_states(_run_shard(all_g), N)
+    for r in range(world):
+        uids = np.load(tmp_path / f"e_uids_{r}.npy")
+        rows = np.load(tmp_path / f"e_rows_{r}.npy").view(abi.LEADERBOARD_DTYPE)
+        assert np.array_equal(uids, all_g)
+        assert rows.tobytes() == ref_rows.tobytes(), f"rank {r}: gathered leaderboard differs"
+
+
+def test_c_level_route_equals_the_numpy_partition():
+    """rgb_route (include/ra_gpu_batch.h) is what a NIF calls per group; ra_amd/shard.py must agree with it."""
+    from ra_amd import engine
+    L = engine.lib()
+    ids = np.arange(5000, dtype=np.uint64)
+    for world in (1, 2, 4, 8):
+        got = np.array([L.rgb_route(int(g), world) for g in ids])
+        assert np.array_equal(got, shard.owner(ids, world) if world > 1 else np.zeros(len(ids), dtype=np.int64))
+
+
 def test_owner_is_a_partition_and_roughly_balanced():
     ids = np.arange(200000, dtype=np.uint64)
     for world in (2, 4, 8):
@@ -90,7 +152,7 @@ def test_route_splits_a_batch_by_owner():
     rng = np.random.default_rng(0)
     guid = rng.integers(0, 10000, size=5000).astype(np.uint64)
     msgs = np.zeros(len(guid), dtype=abi.MSG_DTYPE)
-    parts = shard.route(msgs, guid, 4, N)
+    parts = shard.route(msgs, guid, 4)
     assert sum(len(p) for p in parts) == len(guid)
     for s, p in enumerate(parts):
         assert np.all(shard.owner(guid[p], 4) == s)

@@ -15,7 +15,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
 
 ROLE = {"follower": abi.ROLE_FOLLOWER, "candidate": abi.ROLE_CANDIDATE, "leader": abi.ROLE_LEADER,
         "pre_vote": abi.ROLE_PRE_VOTE, "await_condition": abi.ROLE_AWAIT_CONDITION}
-COND = {"none": abi.COND_NONE, "missing": abi.COND_MISSING, "term_mismatch": abi.COND_TERM_MISMATCH}
+COND = {"none": abi.COND_NONE, "missing": abi.COND_MISSING, "term_mismatch": abi.COND_TERM_MISMATCH,
+        "wal_down": abi.COND_WAL_DOWN}
 FLAG = {k[2:]: getattr(abi, k) for k in dir(abi) if k.startswith("F_")}
 
 
@@ -183,6 +184,8 @@ def make_msg(v, m) -> np.ndarray:
         out["c"] = m["token"]
     else:
         raise ValueError(k)
+    if m.get("can_write"):                            # ra_log:can_write/1 is true (wal_down_condition/2)
+        out["flags"] |= abi.MF_CAN_WRITE
     return out
 
 

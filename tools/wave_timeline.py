@@ -2,7 +2,7 @@
 """RGB_DEBUG=16 on the profiling build (make -C ra_amd/csrc prof): per-wave timestamps of one class-dispatch
 tick -> concurrency picture."""
 import os, sys, ctypes as C
-os.environ["RGB_DEBUG"] = "16"
+os.environ["RGB_DEBUG"] = os.environ.get("TL_DBG", "16")
 os.environ.setdefault("RGB_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                               "ra_amd", "csrc", "libra_gpu_batch_prof.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,7 +42,12 @@ for c in range(12):
     print(f"class {c}: waves {m.sum():5d} start {((t0[m]-z).min()*tick/1e3):6.1f}..{((t0[m]-z).max()*tick/1e3):6.1f} us | "
           f"msg-load {np.median(t1[m]-t0[m])*tick/1e3:5.2f} | state-load {np.median(dl[m])*tick/1e3:5.2f} | store-drain {np.median(dst[m])*tick/1e3:5.2f} | process {np.median(t2[m]-t1[m])*tick/1e3:5.2f} (p90 {np.percentile(t2[m]-t1[m],90)*tick/1e3:5.2f}) | "
           f"dec-store {np.median(t3[m]-t2[m])*tick/1e3:5.2f} | wave life {np.median(t3[m]-t0[m])*tick/1e3:5.2f} us")
-    mx, sm, nz, cn = b[m, 4].astype(int), b[m, 5].astype(int), b[m, 6].astype(int), b[m, 7].astype(int)
+    M24 = (1 << 24) - 1
+    d_disp, d_comm = (b[m, 5] >> np.uint64(24)).astype(np.int64), (b[m, 6] >> np.uint64(24)).astype(np.int64)
+    ok = d_disp > 0
+    if ok.any():
+        print(f"          lane 0, from messages-in-registers: state loaded {np.median(dl[m][ok])*tick/1e3:5.2f} | clause code done {np.median(d_disp[ok])*tick/1e3:5.2f} | commit issued {np.median(d_comm[ok])*tick/1e3:5.2f} | process returned {np.median((t2[m]-t1[m])[ok])*tick/1e3:5.2f} us")
+    mx, sm, nz, cn = b[m, 4].astype(int), (b[m, 5] & np.uint64(M24)).astype(int), (b[m, 6] & np.uint64(M24)).astype(int), b[m, 7].astype(int)
     print(f"          run-table words read: lanes reading {nz.sum()}/{cn.sum()} ({100.0*nz.sum()/max(cn.sum(),1):.1f} %), per reading lane {sm.sum()/max(nz.sum(),1):.1f}, "
           f"waves with a reader {100.0*(nz>0).mean():.0f} %, wave max p50/p90/max {np.percentile(mx,50):.0f}/{np.percentile(mx,90):.0f}/{mx.max()}; "
           f"wave life by wave-max words 0/1-2/3-6/7+: " + "/".join(
