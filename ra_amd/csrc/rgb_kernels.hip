@@ -48,11 +48,10 @@ __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   v4u d;
   d.x = (unsigned)v.x; d.y = (unsigned)(v.x >> 32); d.z = (unsigned)v.y; d.w = (unsigned)(v.y >> 32);
-#ifndef RGB_HOST_EMULATION
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
-#else
-  *reinterpret_cast<v4u *>(p) = d;
-#endif
+  /* the builtin, not inline assembly: the compiler must KNOW this is a 16-byte store to keep the next VALU write of
+   * a data register the required wait states away from it (an asm statement gets no hazard protection: round 2
+   * found decisions whose first dword was the NEXT store's index computation, in a few wavefronts per tick) */
+  __builtin_nontemporal_store(d, reinterpret_cast<v4u *>(p));
 }
 /* state and rpc-record stores are plain (write-back L2): write-through and non-temporal flavours were
  * measured slower in round 1 */
@@ -129,6 +128,8 @@ struct Lane {
   /* device */
   const u64 *runs;       /* this server's run table (start,term pairs) */
   u64 *peers;            /* this server's peers row                    */
+  const ulonglong2 *peers_lds;   /* the same row in LDS (class kernel, leader-side classes, 128-byte rows), or null */
+  unsigned peers_swz;            /* piece p of that row sits at position p ^ peers_swz */
   u32 max_runs;
   /* effects */
   u32 flags;
@@ -176,10 +177,17 @@ __device__ __forceinline__ void load_peers(Lane &L) {
   if (L.peers_loaded) return;
   constexpr int PS = (3 * N + 7) & ~7;
   u64 w[PS];
-  const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(L.peers);
+  if (PS == 16 && L.peers_lds != nullptr) {
 #pragma unroll
-  for (int k = 0; k < PS / 2; ++k) {
-    if (2 * k < 3 * N) { ulonglong2 v = pp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    for (int k = 0; k < PS / 2; ++k) {
+      if (2 * k < 3 * N) { ulonglong2 v = L.peers_lds[(unsigned)k ^ L.peers_swz]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    }
+  } else {
+    const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(L.peers);
+#pragma unroll
+    for (int k = 0; k < PS / 2; ++k) {
+      if (2 * k < 3 * N) { ulonglong2 v = pp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    }
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) { L.pmi[i] = w[i]; L.pni[i] = w[N + i]; L.pcs[i] = w[2 * N + i]; }
@@ -1567,7 +1575,8 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
                                                 u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr,
-                                                const ulonglong2 *pre = nullptr, unsigned swz = 0) {
+                                                const ulonglong2 *pre = nullptr, unsigned swz = 0,
+                                                const ulonglong2 *prepeers = nullptr) {
   Lane L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -1617,9 +1626,10 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   L.peers_loaded = false; L.dmi = L.dni = L.dcs = 0; L.dcs_ci = 0;
   /* leader-side kinds: fetch the peers row in the same round trip as the hot line (the address
    * only depends on the message); kinds that need it rarely load it lazily */
+  L.peers_lds = prepeers; L.peers_swz = swz;
   if ((L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS) &&
       !RGB_KNOB(dev, 64u)) {
-    load_peers<N>(L);      /* the class kernel has pulled the row's line into the cache with the hot lines */
+    load_peers<N>(L);      /* from the LDS row the class kernel fetched with the hot lines, else from memory */
   }
 #ifdef RGB_PROFILE
   if (RGB_KNOB(dev, 64u)) {
@@ -1883,7 +1893,8 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
  * answerable from the two newest runs (else the general path probes the run table) */
 template <int N>
 __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
-                                               const ulonglong2 *pre, unsigned swz, Dec &out) {
+                                               const ulonglong2 *pre, unsigned swz, Dec &out,
+                                               const ulonglong2 *prow = nullptr) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
   const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), peer = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF);
@@ -1899,7 +1910,10 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   if (n_runs < 2 && (h6.y | h7.x) != 0) return false;
   u64 *peers = dev.peers + (size_t)server * dev.peer_stride;
   u64 w[2 * N + (N & 1)];
-  {
+  if (prow != nullptr) {
+#pragma unroll
+    for (int k = 0; k < (2 * N + 1) / 2; ++k) { const ulonglong2 v = prow[(unsigned)k ^ swz]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+  } else {
     const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(peers);
 #pragma unroll
     for (int k = 0; k < (2 * N + 1) / 2; ++k) { const ulonglong2 v = pp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
@@ -2033,8 +2047,20 @@ static_assert(rgb_class_at(0) == 3 && rgb_class_at(1) == 4 && rgb_class_at(2) ==
               rgb_class_at(8) == 11 && rgb_class_at(9) == 14 && rgb_class_at(10) == 13 && rgb_class_at(11) == 12 &&
               rgb_class_at(12) == 1 && rgb_class_at(13) == 0 && rgb_class_at(14) == 2, "class order");
 
+/* Messages per wavefront of a class.  The leader-side classes (append_entries_reply, append, pipeline_rpcs) take 32
+ * when the peers row is one 128-byte line (3..5 members): their wavefronts fetch the peers rows WITH the hot rows --
+ * one round trip, 8 lanes per line, into the LDS half the other 32 hot rows would have used -- instead of a second,
+ * per-lane round trip once the clause code starts. */
+#ifndef RGB_X_LEAD32
+#define RGB_X_LEAD32 1
+#endif
+__host__ __device__ constexpr bool rgb_lead_class(int c) { return c == 1 || c == 3 || c == 4; }
+__host__ __device__ constexpr u32 rgb_class_slice(int c, unsigned n_members) {
+  return (RGB_X_LEAD32 && rgb_lead_class(c) && ((3u * n_members + 7u) & ~7u) == 16u) ? 32u : (u32)RGB_TICK_BLOCK;
+}
+
 /* n[c] = messages of class c (family order in memory) */
-__host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLASSES], rgb_tick_plan &p) {
+__host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLASSES], rgb_tick_plan &p, unsigned n_members) {
   u32 blocks = 0;
 #pragma unroll
   for (int q = 0; q < RGB_N_CLASSES; ++q) {
@@ -2042,7 +2068,8 @@ __host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLAS
     u32 off = 0, cnt = 0;
 #pragma unroll
     for (int k = 0; k < RGB_N_CLASSES; ++k) { off += k < c ? n[k] : 0u; cnt = k == c ? n[k] : cnt; }
-    blocks += (cnt + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK;
+    const u32 sl = rgb_class_slice(c, n_members);
+    blocks += (cnt + sl - 1) / sl;
     p.blk_end[q] = blocks; p.off[q] = off; p.cnt[q] = cnt;
   }
 }
@@ -2060,7 +2087,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #pragma unroll
     for (int c = 0; c < RGB_N_CLASSES; ++c) n[c] = fam_dev[2 * c] + fam_dev[2 * c + 1];
     rgb_tick_plan p;
-    rgb_make_plan(n, p);
+    rgb_make_plan(n, p, (unsigned)N);
     if (blk_id >= p.blk_end[RGB_N_CLASSES - 1]) return;
     off = p.off[0]; ncls = p.cnt[0]; blk = blk_id;
 #pragma unroll
@@ -2079,9 +2106,12 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl[4] = {0, 0, 0, 0};
   if (RGB_KNOB(dev, 16u)) t0 = wall_clock64();
 #endif
-  const u32 base = off + blk * RGB_TICK_BLOCK;            /* first message of this wavefront */
+  const bool lead_cls = rgb_lead_class(cls);              /* append_entries_reply, append, pipeline_rpcs */
+  constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
+  const u32 SL = (PEERS_LDS && lead_cls) ? 32u : (u32)RGB_TICK_BLOCK;      /* messages of this wavefront's slice */
+  const u32 base = off + blk * SL;                        /* first message of this wavefront */
   const u32 end = off + ncls;
-  const u32 cnt = end - base < RGB_TICK_BLOCK ? end - base : RGB_TICK_BLOCK;
+  const u32 cnt = end - base < SL ? end - base : SL;
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
   {
     /* four 1 KiB global -> LDS copies in flight (read once: non-temporal), no staging registers and no ds_write
@@ -2092,6 +2122,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     const u32 last = cnt * 4u - 1u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      if ((u32)k * 16u >= SL) break;                      /* a 32-message slice is two copies */
       const u32 piece = k * RGB_TICK_BLOCK + lane;
       const u32 r = piece >> 2;
       const u32 sp = (r << 2) | ((piece & 3u) ^ ((r >> 2) & 3u));
@@ -2113,7 +2144,6 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
    * registers by now), and process_message reads its row from LDS piece by piece, when it needs it. */
   constexpr bool PRE = true;
   u64 pf0 = 0, pf1 = 0;
-  const bool lead_cls = cls == 1 || cls == 3 || cls == 4;   /* append_entries_reply, append, pipeline_rpcs */
   lds_barrier();
   {
     const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
@@ -2122,7 +2152,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
      * lines, so the row's line(s) are in the cache when the lane loads the row into registers (a second
      * full-latency round trip otherwise; keeping the whole row in registers across the fetch costs
      * spills on the pipelining paths) */
-    if (lead_cls) {
+    if (lead_cls && !PEERS_LDS) {
       const u64 *pp = dev.peers + (size_t)srv * dev.peer_stride;
       pf0 = pp[0];
       if (3 * N > 16) pf1 = pp[16];
@@ -2131,16 +2161,28 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
      * row holds piece q ^ ((r >> 1) & 7): the 16 lanes the LDS serves together read 16 different bank groups */
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+      if ((u32)k * 8u >= SL) break;
       const u32 r = 8 * k + (lane >> 3);
       const u32 sj = __shfl(srv, (int)r, 64);
       glds16<false>(reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS) + ((lane & 7u) ^ ((r >> 1) & 7u)),
                     io + k * RGB_TICK_BLOCK);
+    }
+    if (PEERS_LDS && lead_cls) {
+      /* the peers rows (one 128-byte line each) of the slice's 32 servers behind the 32 hot rows, same shape */
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 r = 8 * k + (lane >> 3);
+        const u32 sj = __shfl(srv, (int)r, 64);
+        glds16<false>(reinterpret_cast<const ulonglong2 *>(dev.peers + (size_t)sj * 16u) + ((lane & 7u) ^ ((r >> 1) & 7u)),
+                      io + (4 + k) * RGB_TICK_BLOCK);
+      }
     }
     glds_wait();
   }
   lds_barrier();
   const ulonglong2 *hrow = io + lane * 8;
   const unsigned hswz = (lane >> 1) & 7u;
+  const ulonglong2 *prow = (PEERS_LDS && lead_cls) ? io + 4 * RGB_TICK_BLOCK + lane * 8 : nullptr;
 #ifndef RGB_HOST_EMULATION
   asm volatile("" ::"v"(pf0), "v"(pf1));   /* the touch loads above stay in the program */
 #endif
@@ -2154,7 +2196,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   /* the steady-state outcome of the three bulk kinds first; whoever is left takes the general clause code below */
   if (active) {
     if (cls == 0) done = fast_aer(dev, m0, m1, m2, m3, hrow, hswz, d);
-    else if (cls == 1) done = fast_aer_reply<N>(dev, m0, m1, hrow, hswz, d);
+    else if (cls == 1) done = fast_aer_reply<N>(dev, m0, m1, hrow, hswz, d, prow);
     else if (cls == 2) done = fast_written(dev, m0, m1, hrow, hswz, d);
   }
 #endif
@@ -2163,7 +2205,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   case RANK:                                                                                            \
     RGB_MARK("begin", RANK)                                                                             \
     process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
-                                  hrow, hswz);                                                          \
+                                  hrow, hswz, prow);                                                    \
     RGB_MARK("end", RANK)                                                                               \
     break;
     switch (cls) {
@@ -2175,7 +2217,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
       default:
         process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                          msg_index_base, d, tlp, hrow, hswz);
+                                                          msg_index_base, d, tlp, hrow, hswz, prow);
         break;
     }
 #undef RGB_CASE
@@ -2765,10 +2807,10 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
   u32 n[RGB_N_CLASSES];
   for (int c = 0; c < RGB_N_CLASSES; ++c) n[c] = counts ? counts[c] : 0;
   rgb_tick_plan plan;
-  rgb_make_plan(n, plan);
+  rgb_make_plan(n, plan, dev.n_members);
   u32 blocks = plan.blk_end[RGB_N_CLASSES - 1];
   /* device-side counts: enough blocks for any split of max_msgs into classes; surplus blocks return at once */
-  if (d_family_totals) blocks = (max_msgs + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK + RGB_N_CLASSES;
+  if (d_family_totals) blocks = (max_msgs + 31u) / 32u + RGB_N_CLASSES;   /* 32 = the smallest slice of any class */
   if (blocks == 0) return 0;
   dim3 grid(blocks), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                                     \
