@@ -44,6 +44,19 @@
 
 namespace {
 
+/* Messages per wavefront of a class.  The leader-side classes (append_entries_reply, append, pipeline_rpcs) take 32
+ * when the peers row is one 128-byte line (3..5 members): their wavefronts fetch the peers rows WITH the hot rows --
+ * one round trip, 8 lanes per line, into the LDS half the other 32 hot rows would have used -- instead of a second,
+ * per-lane round trip once the clause code starts. */
+#ifndef RGB_X_LEAD32
+#define RGB_X_LEAD32 1
+#endif
+__host__ __device__ constexpr bool rgb_lead_class(int c) { return c == 1 || c == 3 || c == 4; }
+__host__ __device__ constexpr u32 rgb_class_slice(int c, unsigned n_members) {
+  return (RGB_X_LEAD32 && rgb_lead_class(c) && ((3u * n_members + 7u) & ~7u) == 16u) ? 32u : (u32)RGB_TICK_BLOCK;
+}
+
+
 __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   v4u d;
@@ -79,7 +92,12 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_base) {
 }
 __device__ __forceinline__ void glds_wait() {
 #ifndef RGB_HOST_EMULATION
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  /* s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched) as a BUILTIN: the compiler's wait-count pass tracks LDS-DMA as a
+   * pending vector-memory event and, not seeing a wait it understands, would put a vmcnt(0) in front of every later LDS
+   * access -- on gfx950 that also waits for every global store issued meanwhile (the state write-back's
+   * acknowledgements, ~2 us in front of the decision staging) */
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::: "memory");
 #endif
 }
 
@@ -156,6 +174,7 @@ struct Lane {
    * fully unrolled on the template parameter, so these arrays live in VGPRs). */
   u64 pmi[8], pni[8], pcs[8];
   unsigned dmi, dni, dcs;
+  unsigned pdirty;   /* peers row in LDS (PL paths): bit w = word w of the row was written */
   unsigned dcs_ci;   /* peers whose commit_index_sent becomes L.ci at commit (pipelining): no per-peer copy is kept */
   bool peers_loaded;
   /* consistent-query heartbeats (cold row, loaded on demand) */
@@ -208,6 +227,33 @@ __device__ __forceinline__ void peer_set(u64 (&a)[8], unsigned &dirty, unsigned 
     if ((unsigned)i == p) { a[i] = v; dirty |= 1u << i; }
 }
 
+/* The peers row of a leader-side message handled by the class kernel lives in LDS (PL = true; fetched with the hot
+ * row, piece p at position p ^ peers_swz): its words are read and written THERE, the register arrays pmi/pni/pcs
+ * (30 VGPRs for five members) do not exist on those paths.  PL = false: the arrays, loaded from memory. */
+__device__ __forceinline__ unsigned prow_at(const Lane &L, unsigned w) { return (((w >> 1) ^ L.peers_swz) << 1) | (w & 1u); }
+__device__ __forceinline__ u64 prow_get(const Lane &L, unsigned w) {
+  return reinterpret_cast<const u64 *>(L.peers_lds)[prow_at(L, w)];
+}
+__device__ __forceinline__ void prow_set(Lane &L, unsigned w, u64 v) {
+  const_cast<u64 *>(reinterpret_cast<const u64 *>(L.peers_lds))[prow_at(L, w)] = v;
+  L.pdirty |= 1u << w;
+}
+template <int N, bool PL> __device__ __forceinline__ u64 mi_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)i) : L.pmi[i]; }
+template <int N, bool PL> __device__ __forceinline__ u64 ni_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)(N + i)) : L.pni[i]; }
+template <int N, bool PL> __device__ __forceinline__ u64 cs_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)(2 * N + i)) : L.pcs[i]; }
+template <int N, bool PL> __device__ __forceinline__ void ni_set(Lane &L, int i, u64 v) {
+  if (PL) prow_set(L, (unsigned)(N + i), v); else { L.pni[i] = v; L.dni |= 1u << i; }
+}
+/* run-time peer index (the sender of a reply) */
+template <int N, bool PL> __device__ __forceinline__ u64 mi_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, p) : 0) : peer_get<N>(L.pmi, p); }
+template <int N, bool PL> __device__ __forceinline__ u64 ni_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, (unsigned)N + p) : 0) : peer_get<N>(L.pni, p); }
+template <int N, bool PL> __device__ __forceinline__ void mi_put(Lane &L, unsigned p, u64 v) {
+  if (PL) { if (p < (unsigned)N) prow_set(L, p, v); } else peer_set<N>(L.pmi, L.dmi, p, v);
+}
+template <int N, bool PL> __device__ __forceinline__ void ni_put(Lane &L, unsigned p, u64 v) {
+  if (PL) { if (p < (unsigned)N) prow_set(L, (unsigned)N + p, v); } else peer_set<N>(L.pni, L.dni, p, v);
+}
+
 __device__ __forceinline__ bool range_nonempty(const Lane &L) { return L.first <= L.li; }
 
 /* word i of this server's in-memory run table: (start, term) of run k at words 2k, 2k+1 */
@@ -216,6 +262,27 @@ __device__ __forceinline__ u64 run_word(const Lane &L, int i) {
   const_cast<Lane &>(L).prof_nloads += 1;
 #endif
   return L.runs[i];
+}
+
+/* The in-memory runs (n_runs-3 and older) searched newest first for the one that holds idx: its number and term, -1 if
+ * idx is below the oldest.  A run's (start, term) is one 16-byte load and the next older run is requested before the
+ * current one is examined, so the walk overlaps its round trips two deep with two live pairs (requesting four at a
+ * time measured 15 % slower per tick: the extra live registers spilled in the clause code around every call site). */
+__device__ __forceinline__ int run_search(const Lane &L, u64 idx, u64 &term) {
+  const ulonglong2 *rt = reinterpret_cast<const ulonglong2 *>(L.runs);
+  int k = (int)L.n_runs - 3;
+  if (k < 0) return -1;
+  ulonglong2 cur = rt[k];
+#pragma unroll 1
+  for (; k >= 0; --k) {
+    const ulonglong2 nxt = rt[k > 0 ? k - 1 : 0];
+#ifdef RGB_PROFILE
+    const_cast<Lane &>(L).prof_nloads += 2u;
+#endif
+    if (idx >= cur.x) { term = cur.y; return k; }
+    cur = nxt;
+  }
+  return -1;
 }
 
 /* ra_log:fetch_term/2 (src/ra_log.erl:1186-1200): defined only inside the range */
@@ -227,11 +294,9 @@ __device__ __forceinline__ u64 fetch_term(const Lane &L, u64 idx) {
 #endif
   if (L.n_runs >= 2 && idx >= L.prs) return L.prt;
   /* runs n_runs-3 and older are all in memory (at most the newest two are pending) */
-  for (int k = (int)L.n_runs - 3; k >= 0; --k) {
-    u64 s = run_word(L, 2 * k);
-    if (idx >= s) return run_word(L, 2 * k + 1);
-  }
-  return UNDEF;
+  u64 term = UNDEF;
+  run_search(L, idx, term);
+  return term;
 }
 
 /* ra_server:fetch_term/2 with the snapshot fallback (src/ra_server.erl:3185-3196) */
@@ -250,9 +315,8 @@ __device__ __forceinline__ int find_run(const Lane &L, u64 idx) {
   if (L.prof_noprobe) return (int)L.n_runs - 1;
 #endif
   if (L.n_runs >= 2 && idx >= L.prs) return (int)L.n_runs - 2;
-  for (int k = (int)L.n_runs - 3; k >= 0; --k)
-    if (idx >= run_word(L, 2 * k)) return k;
-  return -1;
+  u64 term;
+  return run_search(L, idx, term);
 }
 
 /* ra_log:last_index_term/1 (src/ra_log.erl:830-835) is simply (L.li, L.lt): an empty range
@@ -628,7 +692,11 @@ __device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u6
 #ifdef RGB_PROFILE
       if (L.prof_noprobe) break;
 #endif
-      s = run_word(L, 2 * k); t = run_word(L, 2 * k + 1);
+      const ulonglong2 r = reinterpret_cast<const ulonglong2 *>(L.runs)[k];
+#ifdef RGB_PROFILE
+      const_cast<Lane &>(L).prof_nloads += 2;
+#endif
+      s = r.x; t = r.y;
     }
     const u64 rs = s < L.first ? L.first : s;
     if (rs <= hi && end >= lo && t == term) {
@@ -777,7 +845,7 @@ __device__ __forceinline__ u64 agreed_commit(const u64 (&v)[N], const bool (&use
 }
 
 /* match_indexes/1 :3671-3682, increment_commit_index/1 :3648-3657, evaluate_quorum/2 :3633-3646 */
-template <int N>
+template <int N, bool PL = false>
 __device__ __forceinline__ void evaluate_quorum(Lane &L) {
   u64 v[N + 1];
   bool use[N + 1];
@@ -787,7 +855,7 @@ __device__ __forceinline__ void evaluate_quorum(Lane &L) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     bool u = ((unsigned)i != self) && present(L, i) && voter(L, i);
-    v[i] = L.pmi[i]; use[i] = u;
+    v[i] = mi_get<N, PL>(L, i); use[i] = u;
     n += u ? 1 : 0;
   }
   const u64 ci0 = L.ci;
@@ -802,7 +870,7 @@ __device__ __forceinline__ void evaluate_quorum(Lane &L) {
  * make_append_entries_rpc/6 :2418-2435.  One pass: peer cursors change in registers and rpc
  * records go to this message's private slots, so when an assertion of the reference fails
  * (non-zero return) nothing has been committed: the decision reports n_rpcs = 0. */
-template <int N, bool EMIT>
+template <int N, bool EMIT, bool PL = false>
 __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, u32 max_batch, bool &more,
                              unsigned &n_out, rgb_rpc *rpcs, u32 slot_base, u32 msg_index) {
   const unsigned self = self_of(L);
@@ -812,7 +880,7 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if ((unsigned)i == self || !present(L, i) || !status_normal(L, i)) continue;
-    const u64 mi = L.pmi[i], ni = L.pni[i], cis = L.pcs[i];
+    const u64 mi = mi_get<N, PL>(L, i), ni = ni_get<N, PL>(L, i), cis = cs_get<N, PL>(L, i);
     if (!(ni < next_log || cis < L.ci)) continue;
     long long inflight = (long long)(ni - mi) - 1;
     if (!(inflight < (long long)max_pipe || force)) continue;
@@ -840,7 +908,7 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
     long long new_inflight = (long long)(new_ni - mi) - 1;
     if (new_ni < next_log && new_inflight < (long long)max_pipe) more = true;
     if (EMIT) {
-      L.pni[i] = new_ni; L.dni |= 1u << i;
+      ni_set<N, PL>(L, i, new_ni);
       /* commit_index_sent := commit_index.  The value is not kept per peer: nothing reads pcs[i] again in this
        * message and commit_index does not move after pipelining, so the commit step stores L.ci itself (ten
        * VGPRs fewer across the loop for N = 5) */
@@ -950,12 +1018,12 @@ __device__ __forceinline__ int process_pre_vote(Lane &L) {
 
 /* make_all_rpcs/1 :2353-2367 -> make_rpcs_for/2 :2369-2377: one rpc (batch 1) per normal peer,
  * next_index NOT advanced */
-template <int N>
+template <int N, bool PL = false>
 __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *rpcs, u32 slot_base,
                                              u32 msg_index, bool only_stale = false) {
   const unsigned self = self_of(L);
   update_heartbeat_rpc_effects<N>(L);                                /* :2354-2355 */
-  load_peers<N>(L);
+  if (!PL) load_peers<N>(L);
   n_out = 0;
   /* make_all_rpcs/1 keeps peers in {snapshot_backoff,_} as well and cancels their retry timers
    * (:2356-2363); stale_peers/1 (the tick) only takes normal ones */
@@ -970,13 +1038,14 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
       L.flags |= RGB_F_CANCEL_SNAPSHOT_RETRY;
     }
     /* make_rpcs/1 on tick: stale_peers/1 :3012-3030 -- unconfirmed items or a newer commit index */
-    if (only_stale && !(L.pmi[i] + 1 < L.pni[i] || L.pcs[i] < L.ci)) continue;
-    const u64 prev = L.pni[i] - 1;
+    const u64 ni_i = ni_get<N, PL>(L, i);
+    if (only_stale && !(mi_get<N, PL>(L, i) + 1 < ni_i || cs_get<N, PL>(L, i) < L.ci)) continue;
+    const u64 prev = ni_i - 1;
     u64 prev_term = fetch_term(L, prev);
     u64 rp_idx, rp_term, new_ni;
     unsigned kind, n_ent = 0;
     if (prev_term == UNDEF && !(L.si != UNDEF && L.si == prev)) {
-      if (L.si == UNDEF || !(L.pni[i] == 0 || prev < L.si)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
+      if (L.si == UNDEF || !(ni_i == 0 || prev < L.si)) return RGB_INV_PIPELINE_PREV_UNDEFINED;
       kind = RGB_RPC_SNAPSHOT; rp_idx = L.si; rp_term = L.st; new_ni = L.si;
       L.flags |= RGB_F_SEND_SNAPSHOT;
     } else {
@@ -1175,7 +1244,7 @@ __device__ __forceinline__ int handle_follower(Lane &L) {
 }
 
 /* -------------------------------------------------------------------- leader ---- */
-template <int N>
+template <int N, bool PL = false>
 __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_rpc *rpcs,
                              u32 slot_base, u32 msg_index, unsigned &n_rpcs) {
   switch (L.kind) {
@@ -1185,10 +1254,10 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
       if (success && L.term == L.ct) {
         /* :532-571 */
         if (!present(L, peer)) return 0;
-        load_peers<N>(L);
-        if (L.b > peer_get<N>(L.pmi, peer)) peer_set<N>(L.pmi, L.dmi, peer, L.b);
-        if (L.a > peer_get<N>(L.pni, peer)) peer_set<N>(L.pni, L.dni, peer, L.a);
-        evaluate_quorum<N>(L);
+        if (!PL) load_peers<N>(L);
+        if (L.b > mi_of<N, PL>(L, peer)) mi_put<N, PL>(L, peer, L.b);
+        if (L.a > ni_of<N, PL>(L, peer)) ni_put<N, PL>(L, peer, L.a);
+        evaluate_quorum<N, PL>(L);
         L.flags |= RGB_F_PIPELINE;
         return 0;
       }
@@ -1203,8 +1272,8 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
       if (!success) {
         /* :587-652 */
         if (!present(L, peer)) return 0;
-        load_peers<N>(L);
-        u64 mi = peer_get<N>(L.pmi, peer), ni = peer_get<N>(L.pni, peer);
+        if (!PL) load_peers<N>(L);
+        u64 mi = mi_of<N, PL>(L, peer), ni = ni_of<N, PL>(L, peer);
         const u64 peer_next = L.a, peer_last = L.b, peer_last_term = L.c;
         u64 t = fetch_term(L, peer_last);
         if (t == UNDEF) {
@@ -1220,10 +1289,10 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
           ni = (u64)(mn > lo ? mn : lo);
         }
         /* registers only: nothing reaches memory unless the message commits */
-        peer_set<N>(L.pmi, L.dmi, peer, mi);
-        peer_set<N>(L.pni, L.dni, peer, ni);
+        mi_put<N, PL>(L, peer, mi);
+        ni_put<N, PL>(L, peer, ni);
         bool more; unsigned cnt;
-        int rc = pipeline_rpcs<N, true>(L, false, dev.max_pipeline_count, dev.max_aer_batch, more, cnt,
+        int rc = pipeline_rpcs<N, true, PL>(L, false, dev.max_pipeline_count, dev.max_aer_batch, more, cnt,
                                         rpcs, slot_base, msg_index);
         if (rc) return rc;
         n_rpcs = cnt;
@@ -1260,8 +1329,8 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
       bool changed;
       int rc = log_written(L, L.term, L.a, L.b, changed);            /* :739-744 */
       if (rc) return rc;
-      load_peers<N>(L);
-      evaluate_quorum<N>(L);
+      if (!PL) load_peers<N>(L);
+      evaluate_quorum<N, PL>(L);
       L.flags |= RGB_F_PIPELINE;
       return 0;
     }
@@ -1269,13 +1338,13 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
     case RGB_MSG_APPEND: {
       if (L.kind == RGB_MSG_PIPELINE_RPCS && (L.mflags & RGB_MF_TICK)) {
         unsigned cnt;                                                /* tick_timeout: make_rpcs/1 :2348-2351 */
-        int rc = make_all_rpcs<N>(L, cnt, rpcs, slot_base, msg_index, true);
+        int rc = make_all_rpcs<N, PL>(L, cnt, rpcs, slot_base, msg_index, true);
         if (rc) return rc;
         n_rpcs = cnt;
         return 0;
       }
       bool force = false;
-      load_peers<N>(L);
+      if (!PL) load_peers<N>(L);
       if (L.kind == RGB_MSG_APPEND) {
         /* {command,_} :653-693 / {commands,_} :695-738: ra_log:append of n entries at
          * next_index in the current term (registers only until commit) */
@@ -1291,8 +1360,8 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
         }
       }
       bool more; unsigned cnt;
-      int rc = pipeline_rpcs<N, true>(L, force, dev.max_pipeline_count, dev.max_aer_batch, more, cnt,
-                                      rpcs, slot_base, msg_index);
+      int rc = pipeline_rpcs<N, true, PL>(L, force, dev.max_pipeline_count, dev.max_aer_batch, more, cnt,
+                                          rpcs, slot_base, msg_index);
       if (rc) return rc;
       n_rpcs = cnt;
       if (L.kind == RGB_MSG_PIPELINE_RPCS && more) L.flags |= RGB_F_PIPELINE;   /* :793-801 */
@@ -1308,7 +1377,7 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
         return 0;
       }
       unsigned cnt;
-      int rc = make_all_rpcs<N>(L, cnt, rpcs, slot_base, msg_index);  /* :961-966 */
+      int rc = make_all_rpcs<N, PL>(L, cnt, rpcs, slot_base, msg_index);  /* :961-966 */
       if (rc) return rc;
       n_rpcs = cnt;
       return 0;
@@ -1626,10 +1695,21 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   L.peers_loaded = false; L.dmi = L.dni = L.dcs = 0; L.dcs_ci = 0;
   /* leader-side kinds: fetch the peers row in the same round trip as the hot line (the address
    * only depends on the message); kinds that need it rarely load it lazily */
-  L.peers_lds = prepeers; L.peers_swz = swz;
-  if ((L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS) &&
+  L.peers_lds = prepeers; L.peers_swz = swz; L.pdirty = 0;
+  /* PL: the class kernel fetched this leader-side message's peers row into LDS with the hot row (128-byte rows:
+   * 3..5 members): the clause code reads and writes it there, no register copy */
+#ifndef RGB_X_COMMIT_WAIT
+#define RGB_X_COMMIT_WAIT 1
+#endif
+#ifndef RGB_X_PL
+#define RGB_X_PL 0     /* measured 1 % slower than the register arrays on the aged stream (23.6 vs 23.4 us), although it
+                          removes every spill of the leader-side classes: kept as an option */
+#endif
+  constexpr bool PL = RGB_X_PL && PRE && rgb_class_slice(1, (unsigned)N) == 32u &&
+                      (KIND == RGB_MSG_AER_REPLY || KIND == RGB_MSG_APPEND || KIND == RGB_MSG_PIPELINE_RPCS);
+  if (!PL && (L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS) &&
       !RGB_KNOB(dev, 64u)) {
-    load_peers<N>(L);      /* from the LDS row the class kernel fetched with the hot lines, else from memory */
+    load_peers<N>(L);      /* from memory (the class kernel touched the row's line with the hot-line fetch) */
   }
 #ifdef RGB_PROFILE
   if (RGB_KNOB(dev, 64u)) {
@@ -1676,7 +1756,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (!to_follower) {
     bool reprocess = false;
     switch (role0) {
-      case RGB_ROLE_LEADER:          rc = handle_leader<N>(L, reprocess, dev, rpcs,
+      case RGB_ROLE_LEADER:          rc = handle_leader<N, PL>(L, reprocess, dev, rpcs,
                                                            (rpc_slot_base + i) * (N > 1 ? N - 1 : 1),
                                                            msg_index_base + i, n_rpcs); break;
       case RGB_ROLE_CANDIDATE:       rc = handle_candidate<N>(L, reprocess); break;
@@ -1698,7 +1778,13 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   }
 
   /* ---- commit: run table ---- */
-  if (RGB_KNOB(dev, 1u)) { L.n_runs = n_runs0; L.push_cnt = 0; L.cond_dirty = false; L.dmi = L.dni = L.dcs = 0; L.dcs_ci = 0; }
+#if RGB_X_COMMIT_WAIT && !defined(RGB_HOST_EMULATION)
+  /* every load of the clause code has been consumed by now (the new state depends on them); saying so keeps the
+   * compiler from putting a vmcnt(0) -- which on gfx950 also waits for the STORES below to be acknowledged -- in
+   * front of the first use of the decision words after the function returns */
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+  if (RGB_KNOB(dev, 1u)) { L.n_runs = n_runs0; L.push_cnt = 0; L.cond_dirty = false; L.dmi = L.dni = L.dcs = 0; L.dcs_ci = 0; L.pdirty = 0; }
   if (L.n_runs != n_runs0 || L.push_cnt) {
     u64 *runs = const_cast<u64 *>(L.runs);
     unsigned nr = L.n_runs;
@@ -1738,7 +1824,16 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
       if (q_reset || (L.q_dirty & (2u << i))) q[1 + i] = L.qp[i];
   }
   /* ---- commit: peers row (dirty words only) ---- */
-  if (L.dmi | L.dni | L.dcs | L.dcs_ci) {
+  if (PL) {
+    if (L.pdirty | L.dcs_ci) {
+#pragma unroll
+      for (int w = 0; w < 2 * N; ++w)
+        if (L.pdirty & (1u << w)) ST8(L.peers + w, prow_get(L, (unsigned)w));
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (L.dcs_ci & (1u << k)) ST8(L.peers + 2 * N + k, L.ci);
+    }
+  } else if (L.dmi | L.dni | L.dcs | L.dcs_ci) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       if (L.dmi & (1u << k)) ST8(L.peers + k, L.pmi[k]);
@@ -2046,18 +2141,6 @@ static_assert(rgb_class_at(0) == 3 && rgb_class_at(1) == 4 && rgb_class_at(2) ==
               rgb_class_at(4) == 10 && rgb_class_at(5) == 6 && rgb_class_at(6) == 5 && rgb_class_at(7) == 7 &&
               rgb_class_at(8) == 11 && rgb_class_at(9) == 14 && rgb_class_at(10) == 13 && rgb_class_at(11) == 12 &&
               rgb_class_at(12) == 1 && rgb_class_at(13) == 0 && rgb_class_at(14) == 2, "class order");
-
-/* Messages per wavefront of a class.  The leader-side classes (append_entries_reply, append, pipeline_rpcs) take 32
- * when the peers row is one 128-byte line (3..5 members): their wavefronts fetch the peers rows WITH the hot rows --
- * one round trip, 8 lanes per line, into the LDS half the other 32 hot rows would have used -- instead of a second,
- * per-lane round trip once the clause code starts. */
-#ifndef RGB_X_LEAD32
-#define RGB_X_LEAD32 1
-#endif
-__host__ __device__ constexpr bool rgb_lead_class(int c) { return c == 1 || c == 3 || c == 4; }
-__host__ __device__ constexpr u32 rgb_class_slice(int c, unsigned n_members) {
-  return (RGB_X_LEAD32 && rgb_lead_class(c) && ((3u * n_members + 7u) & ~7u) == 16u) ? 32u : (u32)RGB_TICK_BLOCK;
-}
 
 /* n[c] = messages of class c (family order in memory) */
 __host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLASSES], rgb_tick_plan &p, unsigned n_members) {

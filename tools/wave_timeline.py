@@ -52,6 +52,18 @@ for c in range(12):
           f"waves with a reader {100.0*(nz>0).mean():.0f} %, wave max p50/p90/max {np.percentile(mx,50):.0f}/{np.percentile(mx,90):.0f}/{mx.max()}; "
           f"wave life by wave-max words 0/1-2/3-6/7+: " + "/".join(
               f"{np.median((t3[m]-t0[m])[sel])*tick/1e3:.1f}" if sel.any() else "-" for sel in (mx == 0, (mx >= 1) & (mx <= 2), (mx >= 3) & (mx <= 6), mx >= 7)))
+# who is the tail: end times per class, and the last waves to finish
+endt = (t3 - z) * tick / 1e3; startt = (t0 - z) * tick / 1e3
+print("end time per class (us): class waves p50 p90 p99 max | waves ending in the last 4 us of the kernel")
+for c in range(15):
+    m = cls == c
+    if not m.any(): continue
+    e = endt[m]
+    print(f"  class {c:2d} {m.sum():5d}  {np.percentile(e,50):5.1f} {np.percentile(e,90):5.1f} {np.percentile(e,99):5.1f} {e.max():5.1f} | {(e > endt.max() - 4).sum()}")
+order = np.argsort(-endt)[:24]
+print("last waves: class start end life lanes max-run-words")
+for i in order:
+    print(f"  {cls[i]:2d} {startt[i]:5.1f} {endt[i]:5.1f} {endt[i]-startt[i]:5.1f} {int(b[i,7]):3d} {int(b[i,4]):3d}")
 # concurrency over time
 ev = np.concatenate([np.stack([t0 - z, np.ones_like(t0)], 1), np.stack([t3 - z, -np.ones_like(t3)], 1)])
 ev = ev[np.argsort(ev[:, 0], kind="stable")]
