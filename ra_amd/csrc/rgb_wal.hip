@@ -20,7 +20,9 @@ namespace {
 typedef unsigned int u32;
 typedef unsigned long long u64;
 #define ADLER_MOD 65521u
+#ifndef WAL_WAVES_PER_BLOCK
 #define WAL_WAVES_PER_BLOCK 4
+#endif
 #define WAL_UNROLL 4            /* 16-byte loads in flight per lane: 4 KiB per wavefront iteration */
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
@@ -40,6 +42,14 @@ __device__ __forceinline__ u32 byte_mask(u32 first, u32 lo, u32 hi) {
 #pragma unroll
   for (u32 b = 0; b < 4; ++b) if (first + b >= lo && first + b < hi) m |= 0xFFu << (8 * b);
   return m;
+}
+/* the same for a whole 16-byte chunk, from two 64-bit shifts per half instead of sixteen byte tests */
+__device__ __forceinline__ u64 ones64(u32 nbytes) { return nbytes >= 8u ? ~0ull : ((1ull << (8u * nbytes)) - 1ull); }
+__device__ __forceinline__ uint4 keep_bytes(const uint4 w, u32 lo, u32 hi) {
+  const u32 lo_a = lo < 8u ? lo : 8u, hi_a = hi < 8u ? hi : 8u;
+  const u32 lo_b = lo > 8u ? lo - 8u : 0u, hi_b = hi > 8u ? hi - 8u : 0u;
+  const u64 ma = ones64(hi_a) & ~ones64(lo_a), mb = ones64(hi_b) & ~ones64(lo_b);
+  return make_uint4(w.x & (u32)ma, w.y & (u32)(ma >> 32), w.z & (u32)mb, w.w & (u32)(mb >> 32));
 }
 
 /* sum over the GROUP lanes that share a record (xor butterflies stay inside aligned groups) */
@@ -122,25 +132,52 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_adler32_kern
 
 /* ---- record framing: checksum + header + payload copy in one pass (src/ra_log_wal.erl:513-537) ----
  *
- * Same lane partition as the checksum kernel, but the 16-byte chunks are aligned to the
- * DESTINATION (the payload's place in the output), so interior chunks are one unaligned 16-byte
- * load (gfx950 global loads take any alignment) and one aligned 16-byte store; the at most two
- * partial chunks at the payload's ends go byte by byte (neighbouring records share those 16-byte
- * lines of the output, so nothing outside the record may be written).  The 24 fixed bytes and the
- * host's HeaderData are written once the group's checksum is known. */
-__device__ __forceinline__ v4u load16_any(const unsigned char *p) {
-  v4u t;
-  __builtin_memcpy(&t, p, 16);
-  return t;
-}
+ * A record is  HeaderData ++ <<Checksum:32, EntryDataLen:32, Idx:64, Term:64>> ++ Payload  at out + out_offset.
+ * The payload is READ in 16-byte chunks aligned to the SOURCE (non-temporal, one aligned request per lane; the
+ * checksum is taken on these chunks exactly as the checksum kernel does) and WRITTEN in 16-byte chunks aligned to
+ * the DESTINATION: destination chunk c is the byte-wise funnel of source chunks c - qd - 1 and c - qd (the shift
+ * is constant over the record), and the older of the two arrives from the neighbouring lane through DPP
+ * (row_ror / wave_ror), so no byte is loaded twice and no load is misaligned -- a 16-byte load that straddles two
+ * aligned granules cost the first version of this kernel 30 % of its rate (588 us vs 401 us per GiB of 4 KiB
+ * payloads, same kernel, source and destination in phase).  Only the destination chunks that hold the payload's
+ * first and last byte are partial (the rest of those 16 bytes is the prefix, or the neighbouring record, written by
+ * another lane group in no particular order): they go as at most four aligned power-of-two stores each.  The 24
+ * fixed bytes are two unaligned vector stores by the group's first lane once the checksum is known; HeaderData is
+ * copied byte per lane (3 bytes for a known writer). */
 
-/* bytes [lo, hi) of a 16-byte chunk held in registers to its 16-byte aligned place `base`: at most eight aligned
- * power-of-two stores (1, 2, 4, 8 bytes going up to the first 8-byte boundary that fits, then 8, 4, 2, 1 coming
- * down) instead of one byte store per byte -- the bytes outside [lo, hi) belong to the neighbouring records, which
- * other lane groups write in no particular order, so they must not be touched */
+/* bytes [lo, hi) of a 16-byte chunk held in registers to its 16-byte aligned place `base`: aligned power-of-two
+ * stores (1, 2, 4, 8 bytes going up to the first 8-byte boundary that fits, then 8, 4, 2, 1 coming down) */
+struct halves16 {
+  u64 lo, hi;
+  /* the 8 bytes from chunk byte q on (q and the store's size never straddle the halves).  By value: a lambda that
+   * captured the halves by reference made the compiler select between their ADDRESSES -- a scratch array, a pointer
+   * table in LDS and a flat load in front of every store */
+  __device__ __forceinline__ u64 operator()(u32 q) const { const u64 x = (q & 8u) ? hi : lo; return x >> (8u * (q & 7u)); }
+};
+__device__ __forceinline__ halves16 halves_of(const uint4 w) {
+  return halves16{(u64)w.x | ((u64)w.y << 32), (u64)w.z | ((u64)w.w << 32)};
+}
+/* bytes [lo, 16): the chunk that holds the payload's first byte */
+__device__ __forceinline__ void store_head16(unsigned char *base, const uint4 w, u32 lo) {
+  const halves16 sub = halves_of(w);
+  u32 p = lo;
+  if (p & 1u) { base[p] = (unsigned char)sub(p); p += 1u; }
+  if (p & 2u) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
+  if (p & 4u) { *reinterpret_cast<u32 *>(base + p) = (u32)sub(p); p += 4u; }
+  if (p & 8u) { *reinterpret_cast<u64 *>(base + p) = sub(p); }
+}
+/* bytes [0, hi): the chunk that holds the payload's last byte */
+__device__ __forceinline__ void store_tail16(unsigned char *base, const uint4 w, u32 hi) {
+  const halves16 sub = halves_of(w);
+  u32 p = 0;
+  if (hi & 8u) { *reinterpret_cast<u64 *>(base) = sub(0); p = 8u; }
+  if (hi & 4u) { *reinterpret_cast<u32 *>(base + p) = (u32)sub(p); p += 4u; }
+  if (hi & 2u) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
+  if (hi & 1u) { base[p] = (unsigned char)sub(p); }
+}
+/* bytes [lo, hi), both inside the chunk (a payload shorter than its chunk) */
 __device__ __forceinline__ void store_sub16(unsigned char *base, const uint4 w, u32 lo, u32 hi) {
-  const u64 lo64 = (u64)w.x | ((u64)w.y << 32), hi64 = (u64)w.z | ((u64)w.w << 32);
-  auto sub = [&](u32 p) -> u64 { return ((p & 8u) ? hi64 : lo64) >> (8u * (p & 7u)); };
+  const halves16 sub = halves_of(w);
   u32 p = lo;
   if ((p & 1u) && p + 1u <= hi) { base[p] = (unsigned char)sub(p); p += 1u; }
   if ((p & 2u) && p + 2u <= hi) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
@@ -152,79 +189,165 @@ __device__ __forceinline__ void store_sub16(unsigned char *base, const uint4 w, 
   if (p + 1u <= hi) { base[p] = (unsigned char)sub(p); }
 }
 
+/* whole aligned chunk, written once and not read again by the device: non-temporal */
+__device__ __forceinline__ void store16_stream(unsigned char *p, const uint4 w) {
+  v4u t; t.x = w.x; t.y = w.y; t.z = w.z; t.w = w.w;
+#ifdef RGB_HOST_EMULATION
+  *reinterpret_cast<v4u *>(p) = t;
+#else
+  __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(p));
+#endif
+}
+
+/* lane L of a GROUP-lane group receives the value of lane (L - 1) mod GROUP of the same group */
+template <int GROUP>
+__device__ __forceinline__ u32 rot1(u32 v) {
+#ifdef RGB_HOST_EMULATION
+  const int t = (int)threadIdx.x;                       /* the emulation's __shfl takes the lane's number in the block */
+  return __shfl(v, (t & ~(GROUP - 1)) | ((t - 1) & (GROUP - 1)), 64);
+#elif defined(WAL_X_NODPP)
+  const int t = (int)(threadIdx.x & 63u);
+  return __shfl(v, (t & ~(GROUP - 1)) | ((t - 1) & (GROUP - 1)), 64);
+#else
+  static_assert(GROUP == 16 || GROUP == 64, "a DPP row is 16 lanes, a wavefront 64");
+  if (GROUP == 16) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+#endif
+}
+template <int GROUP>
+__device__ __forceinline__ uint4 rot1(const uint4 v) {
+  return make_uint4(rot1<GROUP>(v.x), rot1<GROUP>(v.y), rot1<GROUP>(v.z), rot1<GROUP>(v.w));
+}
+/* ({hi, lo} >> 8 sb) & 0xFFFFFFFF, sb = 0..3: v_alignbyte_b32 */
+__device__ __forceinline__ u32 alignbyte(u32 hi, u32 lo, u32 sb) {
+#ifdef RGB_HOST_EMULATION
+  return (u32)((((u64)hi << 32) | lo) >> (8u * (sb & 3u)));
+#else
+  return __builtin_amdgcn_alignbyte(hi, lo, sb);
+#endif
+}
+
+/* bytes [o, o + 16) of the 32 bytes p ++ c, o = 0..16 */
+template <bool UNIFORM>
+__device__ __forceinline__ uint4 window16(const uint4 p, const uint4 c, u32 o) {
+  const u32 q = o >> 2, sb = o & 3u;
+  if (UNIFORM) {
+    /* o is the same in every lane of the wavefront: the dword offset selects straight-line code */
+#ifndef RGB_HOST_EMULATION
+    const u32 qs = (u32)__builtin_amdgcn_readfirstlane((int)q);
+#else
+    const u32 qs = q;
+#endif
+    switch (qs) {
+      case 0: return make_uint4(alignbyte(p.y, p.x, sb), alignbyte(p.z, p.y, sb), alignbyte(p.w, p.z, sb), alignbyte(c.x, p.w, sb));
+      case 1: return make_uint4(alignbyte(p.z, p.y, sb), alignbyte(p.w, p.z, sb), alignbyte(c.x, p.w, sb), alignbyte(c.y, c.x, sb));
+      case 2: return make_uint4(alignbyte(p.w, p.z, sb), alignbyte(c.x, p.w, sb), alignbyte(c.y, c.x, sb), alignbyte(c.z, c.y, sb));
+      case 3: return make_uint4(alignbyte(c.x, p.w, sb), alignbyte(c.y, c.x, sb), alignbyte(c.z, c.y, sb), alignbyte(c.w, c.z, sb));
+      default: return c;                                  /* o = 16 */
+    }
+  }
+  /* per-lane offset: byte shift of every neighbouring dword pair, then a three-stage dword selector */
+  const u32 A0 = alignbyte(p.y, p.x, sb), A1 = alignbyte(p.z, p.y, sb), A2 = alignbyte(p.w, p.z, sb),
+            A3 = alignbyte(c.x, p.w, sb), A4 = alignbyte(c.y, c.x, sb), A5 = alignbyte(c.z, c.y, sb),
+            A6 = alignbyte(c.w, c.z, sb);
+  const bool q0 = (q & 1u) != 0, q1 = (q & 2u) != 0, q2 = (q & 4u) != 0;
+  const u32 B0 = q0 ? A1 : A0, B1 = q0 ? A2 : A1, B2 = q0 ? A3 : A2, B3 = q0 ? A4 : A3, B4 = q0 ? A5 : A4, B5 = q0 ? A6 : A5;
+  uint4 e;
+  e.x = q2 ? c.x : q1 ? B2 : B0; e.y = q2 ? c.y : q1 ? B3 : B1;
+  e.z = q2 ? c.z : q1 ? B4 : B2; e.w = q2 ? c.w : q1 ? B5 : B3;
+  return e;
+}
+
 template <int GROUP>
 __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel(
-    const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data, u64 data_bytes,
+    const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data,
     unsigned char *__restrict__ out, u32 *__restrict__ sums_out, u32 flags) {
   constexpr u32 PER_BLOCK = WAL_WAVES_PER_BLOCK * 64 / GROUP;
+  constexpr bool UNI = GROUP == 64;                     /* one record per wavefront: its shifts are wave-uniform */
+  constexpr int UNROLL = GROUP == 64 ? WAL_UNROLL : 2;  /* small records: 512 bytes per round and group */
   const u32 lane = threadIdx.x & (GROUP - 1);
-  const u32 e = blockIdx.x * PER_BLOCK + threadIdx.x / GROUP;
+  u32 e = blockIdx.x * PER_BLOCK + threadIdx.x / GROUP;
+#ifndef RGB_HOST_EMULATION
+  /* one record per wavefront: say so, and the descriptor and everything derived from it live in scalar registers */
+  if (UNI) e = (u32)__builtin_amdgcn_readfirstlane((int)e);
+#endif
   const bool live = e < n;
   rgb_wal_record r;
   r.index = r.term = r.data_offset = r.hdr_offset = r.out_offset = 0; r.data_len = r.hdr_len = 0;
   if (live) r = recs[e];
   const u32 len = r.data_len;
   const u32 prefix = r.hdr_len + 24u;                   /* HeaderData + Checksum, Len, Idx, Term */
-  const u64 d0 = r.out_offset + prefix;                 /* output offset of payload byte 0 */
-  const u32 lead = (u32)(d0 & 15ull);
-  const unsigned char *src = data + r.data_offset;      /* payload byte p = src[p] */
-  unsigned char *dst = out + d0;                        /* ... goes to dst[p] */
-  const u32 span = lead + len;                          /* destination-aligned stream [0, span) */
-  const u32 n_chunks = live ? (span + 15u) >> 4 : 0u;
+  unsigned char *rec = out + r.out_offset;
+  const u32 lr = (u32)((uintptr_t)rec & 15u);           /* record byte b sits at destination stream position lr + b */
+  unsigned char *rec_al = rec - lr;                     /* destination chunk c is rec_al[16 c .. 16 c + 16) */
+  const unsigned char *pay = data + r.data_offset;
+  const u32 ls = (u32)((uintptr_t)pay & 15u);           /* payload byte p sits at source stream position ls + p */
+  const v4u *src = reinterpret_cast<const v4u *>(pay - ls);
+  const u32 span = ls + len;
+  const u32 n_src = (live && len) ? (span + 15u) >> 4 : 0u;
   const u32 span_q = span % ADLER_MOD;
-  /* a partial chunk at either end of the payload is read as one whole 16-byte load when the 16 bytes around it
-   * lie inside the data buffer (always, except for the first / last payload of the buffer) */
-  const bool wide_ok = r.data_offset >= 16ull && r.data_offset + len + 16ull <= data_bytes;
+  const u32 ps = lr + prefix, pe = ps + len;            /* the payload at destination positions [ps, pe) */
+  const u32 delta = ps - ls;                            /* destination position = source position + delta (> 0) */
+  const u32 qd = delta >> 4, dm = delta & 15u;
+  /* funnel i = (source chunks i - 1, i) is destination chunk i + qd; one more than the source chunks when the last
+   * source chunk's tail spills into a further destination chunk */
+  const u32 n_fun = n_src ? n_src + (((n_src + qd) << 4) < pe ? 1u : 0u) : 0u;
+  /* HeaderData: one byte per lane, requested now so that it arrives under the payload loads */
+  const unsigned char *hdr = data + r.hdr_offset;
+  u32 hbyte = 0;
+  if (live && lane < r.hdr_len) hbyte = hdr[lane];
   u32 a_acc = 0, b_acc = 0;
-  for (u32 c0 = 0; c0 < n_chunks; c0 += GROUP * WAL_UNROLL) {
-    uint4 v[WAL_UNROLL];
+  uint4 carry = make_uint4(0, 0, 0, 0);                 /* lane 0: the group's last lane's chunk of the previous round */
+  /* weight of the byte behind source chunk i, (span - 16 i - 16) mod 65521, kept per lane and stepped down by
+   * 16 GROUP per chunk instead of two divisions per chunk */
+  constexpr u32 STEP = (16u * GROUP) % ADLER_MOD;
+  u32 wq = (span_q + 2u * ADLER_MOD - ((lane << 4) % ADLER_MOD) - 16u) % ADLER_MOD;
+  for (u32 c0 = 0; c0 < n_fun; c0 += GROUP * UNROLL) {
+    uint4 v[UNROLL];
 #pragma unroll
-    for (int k = 0; k < WAL_UNROLL; ++k) {
-      const u32 c = c0 + (u32)k * GROUP + lane;
+    for (int k = 0; k < UNROLL; ++k) {
+      const u32 i = c0 + (u32)k * GROUP + lane;
       v[k] = make_uint4(0, 0, 0, 0);
-      if (c >= n_chunks) continue;
-      const u32 s = c << 4;                             /* stream byte s+j is payload byte s+j-lead */
-      if (s >= lead && s + 16u <= span) {
-        const v4u t = load16_any(src + (s - lead));
-        v[k] = make_uint4(t.x, t.y, t.z, t.w);
-      } else if (wide_ok) {                             /* partial chunk, one load: mask, store the sub-words */
-        const u32 lo = s < lead ? lead - s : 0u, hi = span - s < 16u ? span - s : 16u;
-        const v4u t = load16_any(src + ((long long)s - (long long)lead));
-        uint4 w = make_uint4(t.x & byte_mask(0, lo, hi), t.y & byte_mask(4, lo, hi), t.z & byte_mask(8, lo, hi),
-                             t.w & byte_mask(12, lo, hi));
-        store_sub16(dst + ((long long)s - (long long)lead), w, lo, hi);
-        v[k] = w;
-      } else {                                          /* partial chunk at the buffer's edge: byte by byte */
-        u32 w[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (u32 j = 0; j < 16u; ++j) {
-          const u32 q = s + j;
-          if (q >= lead && q < span) {
-            const u32 byte = src[q - lead];
-            dst[(long long)q - (long long)lead] = (unsigned char)byte;
-            w[j >> 2] |= byte << (8 * (j & 3));
-          }
-        }
-        v[k] = make_uint4(w[0], w[1], w[2], w[3]);
-      }
+      if (i < n_src) { const v4u t = __builtin_nontemporal_load(src + i); v[k] = make_uint4(t.x, t.y, t.z, t.w); }
     }
 #pragma unroll
-    for (int k = 0; k < WAL_UNROLL; ++k) {
-      const u32 c = c0 + (u32)k * GROUP + lane;
-      if (c >= n_chunks) continue;
-      const u32 s = c << 4;
-      const uint4 w = v[k];
-      if (s >= lead && s + 16u <= span) {
-        v4u t; t.x = w.x; t.y = w.y; t.z = w.z; t.w = w.w;
-        *reinterpret_cast<v4u *>(dst + (s - lead)) = t;   /* d0 - lead is 16-byte aligned */
+    for (int k = 0; k < UNROLL; ++k) {
+      if (c0 + (u32)k * GROUP >= n_fun) break;          /* the same for the whole group: a short last round is cheap */
+      const u32 i = c0 + (u32)k * GROUP + lane;
+      const u32 s = i << 4;
+      if (i < n_src) {
+        uint4 w = v[k];
+        if (s < ls || s + 16u > span) {                 /* bytes in front of the payload / behind it: zero */
+          w = keep_bytes(w, s < ls ? ls - s : 0u, span - s < 16u ? span - s : 16u);
+          v[k] = w;
+        }
+        u32 a, b;
+        chunk_sums(w, a, b);
+        a_acc += a;
+        b_acc += (wq * a + b) % ADLER_MOD;
+        if (b_acc >= 0x7FFF0000u) b_acc %= ADLER_MOD;
+        if (a_acc >= 0x7FFF0000u) a_acc %= ADLER_MOD;
       }
-      u32 a, b;
-      chunk_sums(w, a, b);
-      const u32 wq = (span_q + 2u * ADLER_MOD - (s % ADLER_MOD) - 16u) % ADLER_MOD;
-      a_acc += a;
-      b_acc += (wq * a + b) % ADLER_MOD;
-      if (b_acc >= 0x7FFF0000u) b_acc %= ADLER_MOD;
-      if (a_acc >= 0x7FFF0000u) a_acc %= ADLER_MOD;
+      wq = wq >= STEP ? wq - STEP : wq + (ADLER_MOD - STEP);
+    }
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      if (c0 + (u32)k * GROUP >= n_fun) break;
+      const u32 i = c0 + (u32)k * GROUP + lane;
+      /* every lane of the group takes part in the exchange, whatever it loaded */
+      const uint4 rot = rot1<GROUP>(v[k]);
+      const uint4 prev = lane == 0u ? carry : rot;
+      carry = rot;
+      const uint4 f = window16<UNI>(prev, v[k], 16u - dm);
+      const u32 dpos = (i + qd) << 4;
+      if (i < n_fun && dpos + 16u > ps && dpos < pe) {  /* the chunk holds payload bytes */
+        unsigned char *to = rec_al + dpos;
+        const bool head = dpos < ps, tail = dpos + 16u > pe;
+        if (!head && !tail) store16_stream(to, f);
+        else if (!head) store_tail16(to, f, pe - dpos);
+        else if (!tail) store_head16(to, f, ps - dpos);
+        else store_sub16(to, f, ps - dpos, pe - dpos);
+      }
     }
   }
   const u32 a_sum = group_sum<GROUP>(a_acc % ADLER_MOD);
@@ -239,22 +362,19 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel
   const u32 A = (1u + pa + a_sum) % ADLER_MOD;
   const u32 B = ((16u + len_q) + (len_q * pa + pb) % ADLER_MOD + b_sum) % ADLER_MOD;
   const u32 cs = (flags & RGB_WAL_NO_CHECKSUMS) ? 0u : ((B << 16) | A);
-  if (lane == 0 && sums_out) sums_out[e] = cs;
-  /* the prefix: HeaderData verbatim, then Checksum:32, EntryDataLen:32, Idx:64, Term:64 big endian */
-  unsigned char *rec = out + r.out_offset;
-  const unsigned char *hdr = data + r.hdr_offset;
-  for (u32 j = lane; j < prefix; j += GROUP) {
-    u32 byte;
-    if (j < r.hdr_len) {
-      byte = hdr[j];
-    } else {
-      const u32 q = j - r.hdr_len;                      /* 0..23 */
-      if (q < 4u) byte = cs >> (8 * (3 - q));
-      else if (q < 8u) byte = len >> (8 * (7 - q));
-      else if (q < 16u) byte = (u32)(r.index >> (8 * (15 - q)));
-      else byte = (u32)(r.term >> (8 * (23 - q)));
-    }
-    rec[j] = (unsigned char)byte;
+  /* HeaderData verbatim (a known writer's is 3 bytes, a new writer's carries its uid) */
+  if (lane < r.hdr_len) rec[lane] = (unsigned char)hbyte;
+  for (u32 j = GROUP + lane; j < r.hdr_len; j += GROUP) rec[j] = hdr[j];
+  if (lane == 0u) {
+    if (sums_out) sums_out[e] = cs;
+    /* <<Checksum:32, EntryDataLen:32, Idx:64, Term:64>> big endian: 16 + 8 bytes at any alignment (gfx950 global
+     * stores take any alignment) */
+    struct __attribute__((packed)) fixed24 { v4u a; u64 b; };
+    fixed24 fx;
+    fx.a.x = __builtin_bswap32(cs); fx.a.y = __builtin_bswap32(len);
+    fx.a.z = __builtin_bswap32(ih); fx.a.w = __builtin_bswap32(il);
+    fx.b = (u64)__builtin_bswap32(th) | ((u64)__builtin_bswap32(tl) << 32);
+    __builtin_memcpy(rec + r.hdr_len, &fx, 24);
   }
 }
 
@@ -291,12 +411,12 @@ extern "C" int rgb_wal_frame_device(rgb_ctx *ctx, const void *d_records, uint32_
   if (data_bytes / n < 1024u) {
     const u32 per = WAL_WAVES_PER_BLOCK * 64 / 16;
     hipLaunchKernelGGL(rgb_wal_frame_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data, (u64)data_bytes,
+                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
                        (unsigned char *)d_out, (u32 *)d_checksums, flags);
   } else {
     const u32 per = WAL_WAVES_PER_BLOCK;
     hipLaunchKernelGGL(rgb_wal_frame_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data, (u64)data_bytes,
+                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
                        (unsigned char *)d_out, (u32 *)d_checksums, flags);
   }
   return hipGetLastError() == hipSuccess ? RGB_OK : RGB_E_HIP;

@@ -286,6 +286,39 @@ def test_gpu_frame_matches_oracle_bytes(small, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+def test_gpu_frame_unaligned_device_pointers_and_long_header_data(small):
+    """The kernel reads the payload in chunks aligned to the source ADDRESS and writes chunks aligned to the
+    destination ADDRESS: device pointers at every phase mod 16, 200-byte uids (HeaderData longer than the lane
+    group that copies it), payloads shorter than a chunk."""
+    import torch
+    rng = np.random.default_rng(90 + small)
+    lens = ([0, 1, 2, 3, 5, 7, 11, 13, 15, 16, 17, 40, 100, 300] + [int(x) for x in rng.integers(0, 400, size=200)]) if small \
+        else ([0, 1, 5, 15, 2000, 4096, 9000, 33000] + [int(x) for x in rng.integers(1000, 9000, size=60)])
+    uids = [bytes(rng.integers(97, 123, size=200, dtype=np.uint8)) for _ in lens]
+    specs = [(i & 1, i % 1000, uids[i] if i < 12 else None, 10 + i, 3, ln) for i, ln in enumerate(lens)]
+    recs, data, payloads = make_batch(rng, specs)
+    assert (len(data) / len(lens) < 1024) == small
+    want = python_frame(specs, payloads)
+    eng = _open()
+    d_r = torch.from_numpy(recs.view(np.uint8)).cuda()
+    for skew_d, skew_o in ((0, 0), (1, 0), (0, 1), (7, 13), (15, 3), (9, 9)):
+        total = engine.wal_layout(recs, 0)
+        d_d = torch.zeros(len(data) + 32, dtype=torch.uint8, device="cuda")
+        d_d[skew_d:skew_d + len(data)] = torch.from_numpy(data).cuda()
+        d_o = torch.full((total + 96,), 0xEE, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        eng.wal_frame_device(d_r.data_ptr(), len(recs), d_d.data_ptr() + skew_d, len(data), d_o.data_ptr() + 32 + skew_o,
+                             total, 0, 0)
+        torch.cuda.synchronize()
+        got = d_o.cpu().numpy()
+        lo = 32 + skew_o
+        assert np.all(got[:lo] == 0xEE) and np.all(got[lo + total:] == 0xEE), "wrote outside the records"
+        assert got[lo:lo + total].tobytes() == want, (skew_d, skew_o)
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_gpu_frame_host_form_then_recovery_round_trip():
     """frame -> file -> scan -> validate: clean; then the three corruptions of
     test/ra_log_wal_SUITE.erl:1439-1528 on 100 entries of 1006 bytes."""

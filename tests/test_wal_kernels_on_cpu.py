@@ -87,6 +87,22 @@ def test_framing_kernel_matches_struct_pack(wal, small, flags):
     assert len(bad) == 0, f"first differing output byte {bad[0]} of {total}"
 
 
+@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+def test_framing_kernel_with_header_data_longer_than_a_lane_group(wal, small):
+    """A new writer's record carries its uid (src/ra_log_wal.erl:520-526): 200-byte uids make HeaderData longer than
+    the 16 / 64 lanes that copy it, next to payloads shorter than one 16-byte chunk (head and tail in one chunk)."""
+    rng = np.random.default_rng(80 + small)
+    lens = ([0, 1, 2, 3, 5, 7, 11, 13, 15, 16, 17, 40, 100, 300] if small else [0, 1, 5, 15, 2000, 4096, 9000, 33000])
+    uids = [bytes(rng.integers(97, 123, size=200, dtype=np.uint8)) for _ in lens]
+    specs = [(i & 1, i, uids[i], 10 + i, 3, ln) for i, ln in enumerate(lens)]
+    recs, data, payloads = make_records(rng, specs)
+    assert int(recs["hdr_len"].max()) >= 202 and (len(data) / len(lens) < 1024) == small
+    for base in (0, 5, 15):
+        total = wal.wal_layout(recs, base)
+        rc, out = wal.wal_frame(recs, data, total)
+        assert rc == 0 and out[base:].tobytes() == python_frame(specs, payloads)
+
+
 def test_recovery_scenarios_of_the_reference(wal):
     """test/ra_log_wal_SUITE.erl:1439-1528 on 100 entries of 1006 bytes, framed by the kernel."""
     rng = np.random.default_rng(70)

@@ -11,7 +11,19 @@ HBM_PEAK = 8000.0
 eng = engine.RaGpuBatch(1, 1)
 stream = torch.cuda.Stream(); sp = stream.cuda_stream
 res = []
-hdr = ((1 << 22) | 9).to_bytes(3, "big")
+ALIGNED = os.environ.get("WAL_ALIGNED") == "1"     # experiment: 8-byte header, base 0 -> source and destination share their 16-byte phase
+hdr = ((1 << 22) | 9).to_bytes(3, "big") + (b"\0" * 5 if ALIGNED else b"")
+BASE = 0 if ALIGNED else 5
+if os.environ.get("WAL_MEMCPY") == "1":
+    a = torch.randint(0, 256, (1 << 30,), dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
+    for _ in range(3): b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print(json.dumps({"calibration": "torch copy_ of 1 GiB (read + write)", "us": us, "GBps_read_plus_write": 2 * (1 << 30) / (us * 1e-6) / 1e9}))
+    del a, b
 for label, n, lo, hi in (("4 KiB payloads", 262144, 4096, 4096), ("1-16 KiB mixed", 131072, 1024, 16384),
                          ("256 B payloads", 1 << 21, 256, 256)):
     rng = np.random.default_rng(1)
@@ -21,10 +33,10 @@ for label, n, lo, hi in (("4 KiB payloads", 262144, 4096, 4096), ("1-16 KiB mixe
     recs = np.zeros(n, dtype=abi.WAL_RECORD_DTYPE)
     recs["index"] = np.arange(1, n + 1); recs["term"] = 3
     recs["data_offset"] = offs; recs["data_len"] = lens
-    recs["hdr_offset"] = 0; recs["hdr_len"] = 3
-    out_bytes = engine.wal_layout(recs, 5)
+    recs["hdr_offset"] = 0; recs["hdr_len"] = len(hdr)
+    out_bytes = engine.wal_layout(recs, BASE)
     d_d = torch.randint(0, 256, (total + 32,), dtype=torch.uint8, device="cuda")
-    d_d[:3] = torch.tensor(list(hdr), dtype=torch.uint8)
+    d_d[:len(hdr)] = torch.tensor(list(hdr), dtype=torch.uint8)
     d_r = torch.from_numpy(recs.view(np.uint8)).cuda()
     d_o = torch.zeros(out_bytes, dtype=torch.uint8, device="cuda")
     with torch.cuda.stream(stream):
@@ -38,14 +50,14 @@ for label, n, lo, hi in (("4 KiB payloads", 262144, 4096, 4096), ("1-16 KiB mixe
         e1.record(stream)
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    alg = 2 * total + n * (48 + 3 + 27)
+    alg = 2 * total + n * (48 + len(hdr) + 24 + len(hdr))
     gbps = alg / (us * 1e-6) / 1e9
     k = 500
     end_k = int(recs["out_offset"][k])
     host_in = d_d[: int(offs[k])].cpu().numpy()
     want = b"".join(hdr + struct.pack(">II", zlib.adler32(struct.pack(">QQ", i + 1, 3) + host_in[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes()), int(lens[i]))
                     + struct.pack(">QQ", i + 1, 3) + host_in[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes() for i in range(k))
-    assert d_o[5:end_k].cpu().numpy().tobytes() == want, label
+    assert d_o[BASE:end_k].cpu().numpy().tobytes() == want, label
     res.append({"kernel": "rgb_wal_frame_kernel", "workload": label, "records": n, "payload_bytes": total,
                 "us_per_launch": us, "algorithmic_bytes": alg, "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK,
                 "records_per_s": n / (us * 1e-6), "file_bytes_per_s": out_bytes / (us * 1e-6)})
