@@ -301,9 +301,9 @@ def test_gpu_frame_unaligned_device_pointers_and_long_header_data(small):
     assert (len(data) / len(lens) < 1024) == small
     want = python_frame(specs, payloads)
     eng = _open()
+    total = engine.wal_layout(recs, 0)                  # fills out_offset: before the descriptors go to the device
     d_r = torch.from_numpy(recs.view(np.uint8)).cuda()
     for skew_d, skew_o in ((0, 0), (1, 0), (0, 1), (7, 13), (15, 3), (9, 9)):
-        total = engine.wal_layout(recs, 0)
         d_d = torch.zeros(len(data) + 32, dtype=torch.uint8, device="cuda")
         d_d[skew_d:skew_d + len(data)] = torch.from_numpy(data).cuda()
         d_o = torch.full((total + 96,), 0xEE, dtype=torch.uint8, device="cuda")
