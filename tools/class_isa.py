@@ -7,7 +7,7 @@ guide.   usage: python tools/class_isa.py [-DFLAG ...]   (N = 5)"""
 import os, re, subprocess, sys, tempfile
 from collections import Counter, OrderedDict
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+flags = [a for a in sys.argv[1:] if a.startswith("-")]
 N = os.environ.get("ONLY_N", "5")
 names = ["aer", "aer_reply", "written", "append", "pipeline_rpcs", "request_vote", "vote_result", "await_timeout",
          "election_timeout", "pre_vote_rpc", "pre_vote_result", "snapshot_written", "heartbeat_rpc", "heartbeat_reply",
