@@ -115,7 +115,13 @@ typedef struct rgb_wal_scanned {
 
 #define RGB_WAL_REC_FIRST    1u  /* long header: first appearance of the writer in this file */
 #define RGB_WAL_REC_VALIDATE 2u  /* to be checksum-validated; the caller clears it for writers that are
-                                    not registered (ra_directory:is_registered_uid, :902) */
+                                    not registered (ra_directory:is_registered_uid, :902).  The scan
+                                    cannot ask the directory, so it treats every long header as
+                                    introducing its IdRef: for a writer the caller finds unregistered
+                                    the reference leaves the IdRef out of its cache (:902-904, :929-931) and
+                                    skips that writer's later short-header records (:968-971) — the
+                                    caller must therefore clear VALIDATE on EVERY later record of that
+                                    id_ref in this file, not only on the RGB_WAL_REC_FIRST one */
 #define RGB_WAL_REC_UNKNOWN  4u  /* short header whose IdRef was never introduced: skipped (:968-971) */
 
 #define RGB_WAL_END_ZEROS 0u     /* all-zero record: end of a pre-allocated file (:877-883) */

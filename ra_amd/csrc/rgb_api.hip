@@ -588,6 +588,7 @@ int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
 
 /* internal: the context's default stream (rgb_wal.hip) */
 void *rgb_ctx_stream(rgb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int rgb_ctx_device(rgb_ctx *ctx) { return ctx ? ctx->cfg.device : 0; }
 
 int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
                           void *d_n, void *stream) {

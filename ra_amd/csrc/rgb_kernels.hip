@@ -2260,6 +2260,26 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
                       io + (4 + k) * RGB_TICK_BLOCK);
       }
     }
+#if defined(RGB_X_EXTRA_FETCH) && !defined(RGB_HOST_EMULATION)
+    /* EXPERIMENT (never in the product): RGB_X_EXTRA_FETCH x 64 more bytes per message, gathered like the hot rows
+     * (coalesced per row) from the cold qry rows in the same round trip and thrown away -- the slope of the state
+     * round trip against the bytes it gathers, i.e. what a 64-byte hot row would buy */
+    {
+      constexpr u32 LPR = 4u * RGB_X_EXTRA_FETCH;           /* lanes per row (16 bytes each) */
+      constexpr u32 RPI = 64u / LPR;                        /* rows per instruction */
+      ulonglong2 xf[64u / RPI];
+#pragma unroll
+      for (u32 k = 0; k < 64u / RPI; ++k) {
+        xf[k] = make_ulonglong2(0, 0);
+        if (k * RPI >= SL) break;
+        const u32 r = RPI * k + lane / LPR;
+        const u32 sj = __shfl(srv, (int)r, 64);
+        xf[k] = ld16<false>(reinterpret_cast<const ulonglong2 *>(dev.qry + (size_t)sj * 16u) + (lane % LPR));
+      }
+#pragma unroll
+      for (u32 k = 0; k < 64u / RPI; ++k) asm volatile("" ::"v"(xf[k].x), "v"(xf[k].y));
+    }
+#endif
     glds_wait();
   }
   lds_barrier();

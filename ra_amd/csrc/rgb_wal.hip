@@ -382,6 +382,10 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel
 
 /* the context only supplies the default stream; rgb_api.hip exports the accessor */
 extern "C" void *rgb_ctx_stream(rgb_ctx *ctx);
+extern "C" int rgb_ctx_device(rgb_ctx *ctx);          /* the HIP device the context (and its stream) lives on */
+
+/* off + len <= bytes without the u64 wrap-around of the sum (descriptors come from the caller) */
+static inline bool wal_slice_ok(uint64_t off, uint64_t len, uint64_t bytes) { return off <= bytes && len <= bytes - off; }
 
 extern "C" int rgb_wal_adler32_device(rgb_ctx *ctx, const void *d_entries, uint32_t n, const void *d_data,
                                       uint64_t data_bytes, void *d_checksums, void *stream) {
@@ -461,7 +465,9 @@ extern "C" int rgb_wal_adler32(rgb_ctx *ctx, const rgb_wal_entry *entries, uint3
   if (!ctx || (n && (!entries || !checksums)) || (data_bytes && !data)) return RGB_E_INVAL;
   if (n == 0) return RGB_OK;
   for (uint32_t i = 0; i < n; ++i)
-    if (entries[i].data_offset + entries[i].data_len > data_bytes) return RGB_E_INVAL;
+    if (!wal_slice_ok(entries[i].data_offset, entries[i].data_len, data_bytes)) return RGB_E_INVAL;
+  /* a dirty-scheduler thread or a multi-context process: allocations must land on the context's device */
+  if (hipSetDevice(rgb_ctx_device(ctx)) != hipSuccess) return RGB_E_HIP;
   std::lock_guard<std::mutex> lk(g_stage_mu);
   wal_stage &s = g_stage[ctx];
   size_t cap_o = s.cap_e / sizeof(rgb_wal_entry) * sizeof(u32);
@@ -490,11 +496,14 @@ extern "C" int rgb_wal_frame(rgb_ctx *ctx, const rgb_wal_record *records, uint32
   uint64_t floor_off = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const rgb_wal_record &r = records[i];
-    if (r.data_offset + r.data_len > data_bytes || r.hdr_offset + r.hdr_len > data_bytes) return RGB_E_INVAL;
+    if (!wal_slice_ok(r.data_offset, r.data_len, data_bytes) || !wal_slice_ok(r.hdr_offset, r.hdr_len, data_bytes))
+      return RGB_E_INVAL;
     if (r.hdr_len < 3u || r.out_offset < floor_off) return RGB_E_INVAL;
-    floor_off = r.out_offset + r.hdr_len + 24u + r.data_len;
-    if (floor_off > out_bytes) return RGB_E_INVAL;
+    const uint64_t rec_len = (uint64_t)r.hdr_len + 24u + (uint64_t)r.data_len;   /* u32 + u32 + 24: no wrap */
+    if (!wal_slice_ok(r.out_offset, rec_len, out_bytes)) return RGB_E_INVAL;
+    floor_off = r.out_offset + rec_len;
   }
+  if (hipSetDevice(rgb_ctx_device(ctx)) != hipSuccess) return RGB_E_HIP;
   std::lock_guard<std::mutex> lk(g_stage_mu);
   wal_stage &s = g_stage[ctx];
   const size_t need_r = (size_t)n * sizeof(rgb_wal_record);
@@ -535,6 +544,7 @@ extern "C" int rgb_wal_validate(rgb_ctx *ctx, const void *bytes, uint64_t n_byte
     /* is_last_record/3 (:994-1010): 104 zero bits behind it, or fewer than 13 bytes to the end */
     *n_ok = i;
     const uint64_t rest = recs[i].next_offset;
+    if (rest > n_bytes) return RGB_E_INVAL;               /* a descriptor that points past the file */
     bool last = true;
     if (n_bytes - rest >= 13) {
       for (int k = 0; k < 13; ++k) if (b[rest + k] != 0) { last = false; break; }

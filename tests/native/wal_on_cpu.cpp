@@ -10,6 +10,7 @@
 #ifndef RGB_EMU_FULL_API   /* stand-alone WAL build: a dummy context; with rgb_api.hip the real one is used */
 struct rgb_ctx { int unused; };
 extern "C" void *rgb_ctx_stream(rgb_ctx *) { return nullptr; }
+extern "C" int rgb_ctx_device(rgb_ctx *) { return 0; }
 #endif
 #include "../../ra_amd/csrc/rgb_wal.hip"
 #include "../../ra_amd/csrc/rgb_wal_host.cpp"

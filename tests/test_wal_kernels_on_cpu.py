@@ -131,3 +131,34 @@ def test_recovery_scenarios_of_the_reference(wal):
     assert recover(bytes(f)) == (0, abi.WAL_CORRUPT, "corrupt")
     bad = recs.copy(); bad["out_offset"][5] = bad["out_offset"][4]
     assert wal.wal_frame(bad, data, total)[0] == abi.E_INVAL          # overlapping records
+
+
+def test_descriptors_whose_offset_plus_length_wraps_are_refused(wal):
+    """Descriptors come from the caller (a NIF): `offset + length` is checked without the u64 wrap-around of the
+    sum, so a wrapped slice is RGB_E_INVAL and nothing is read or written out of bounds."""
+    rng = np.random.default_rng(71)
+    specs = [(0, 0, None, i + 1, 1, 64) for i in range(4)]
+    recs, data, _ = make_records(rng, specs)
+    total = wal.wal_layout(recs, 0)
+    assert wal.wal_frame(recs, data, total)[0] == 0
+    for field, value in (("data_offset", 2 ** 64 - 8), ("hdr_offset", 2 ** 64 - 1), ("out_offset", 2 ** 64 - 16)):
+        bad = recs.copy(); bad[field][3] = value
+        assert wal.wal_frame(bad, data, total)[0] == abi.E_INVAL, field
+    entries, edata = make_entries(rng, [16, 32, 48])
+    bad = entries.copy(); bad["data_offset"][2] = 2 ** 64 - 4
+    with pytest.raises(wal.engine.RgbError) as e:
+        wal.wal_adler32(bad, edata)
+    assert e.value.code == abi.E_INVAL
+    # a scanned record whose `Rest` offset points past the file
+    uid = b"writer"
+    specs = [(int(i == 0), 0, uid if i == 0 else None, i + 1, 1, 100) for i in range(3)]
+    recs, data, _ = make_records(rng, specs)
+    total = wal.wal_layout(recs, 0)
+    body = wal.wal_frame(recs, data, total)[1]
+    f = bytearray(abi.WAL_FILE_HEADER + body.tobytes()); f[-5] ^= 0xFF       # the last record fails its checksum
+    scanned = wal.wal_scan(bytes(f))
+    assert wal.wal_validate(bytes(f), scanned) == (2, abi.WAL_DROPPED_LAST)
+    scanned["next_offset"][2] = len(f) + 1
+    with pytest.raises(wal.engine.RgbError) as e:
+        wal.wal_validate(bytes(f), scanned)
+    assert e.value.code == abi.E_INVAL
