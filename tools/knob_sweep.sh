@@ -5,7 +5,7 @@
 TAG=${1:-ks}; KNOBS=${2:-0}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 one() {  # label lib dbg
-  RGB_LIB=$2 RGB_DEBUG=$3 timeout 300 python bench.py --steps ${STEPS:-300} --warmup ${WARM:-300} --no-cpu-baseline --no-host-path --check-ticks 0 \
+  RGB_LIB=$2 RGB_DEBUG=$3 timeout 300 python bench.py --steps ${STEPS:-300} --warmup ${WARM:-300} --no-cpu-baseline --no-host-path --check-ticks 0 ${EXTRA:-} \
       > $OUT/$1.json 2> $OUT/$1.err
   python -c "
 import json,sys
