@@ -157,23 +157,28 @@ struct halves16 {
 __device__ __forceinline__ halves16 halves_of(const uint4 w) {
   return halves16{(u64)w.x | ((u64)w.y << 32), (u64)w.z | ((u64)w.w << 32)};
 }
-/* bytes [lo, 16): the chunk that holds the payload's first byte */
+/* bytes [lo, 16): the chunk that holds the payload's first byte.  From the top down -- 8, 4, 2, 1 bytes by the bits of
+ * 16 - lo -- as a shift chain over one 64-bit word: no extraction at a variable offset (which the compiler once
+ * turned into a scratch store of the chunk and loads at computed offsets) */
 __device__ __forceinline__ void store_head16(unsigned char *base, const uint4 w, u32 lo) {
-  const halves16 sub = halves_of(w);
-  u32 p = lo;
-  if (p & 1u) { base[p] = (unsigned char)sub(p); p += 1u; }
-  if (p & 2u) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
-  if (p & 4u) { *reinterpret_cast<u32 *>(base + p) = (u32)sub(p); p += 4u; }
-  if (p & 8u) { *reinterpret_cast<u64 *>(base + p) = sub(p); }
+  const halves16 h = halves_of(w);
+  const u32 n = 16u - lo;                               /* 1..15 bytes */
+  u64 cur = h.hi;
+  u32 e = 16u;                                          /* the bytes still to store end here */
+  if (n & 8u) { *reinterpret_cast<u64 *>(base + 8) = h.hi; cur = h.lo; e = 8u; }
+  if (n & 4u) { *reinterpret_cast<u32 *>(base + e - 4u) = (u32)(cur >> 32); cur <<= 32; e -= 4u; }
+  if (n & 2u) { *reinterpret_cast<unsigned short *>(base + e - 2u) = (unsigned short)(cur >> 48); cur <<= 16; e -= 2u; }
+  if (n & 1u) { base[e - 1u] = (unsigned char)(cur >> 56); }
 }
-/* bytes [0, hi): the chunk that holds the payload's last byte */
+/* bytes [0, hi): the chunk that holds the payload's last byte.  From the bottom up, the same chain mirrored */
 __device__ __forceinline__ void store_tail16(unsigned char *base, const uint4 w, u32 hi) {
-  const halves16 sub = halves_of(w);
+  const halves16 h = halves_of(w);
+  u64 cur = h.lo;
   u32 p = 0;
-  if (hi & 8u) { *reinterpret_cast<u64 *>(base) = sub(0); p = 8u; }
-  if (hi & 4u) { *reinterpret_cast<u32 *>(base + p) = (u32)sub(p); p += 4u; }
-  if (hi & 2u) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
-  if (hi & 1u) { base[p] = (unsigned char)sub(p); }
+  if (hi & 8u) { *reinterpret_cast<u64 *>(base) = h.lo; cur = h.hi; p = 8u; }
+  if (hi & 4u) { *reinterpret_cast<u32 *>(base + p) = (u32)cur; cur >>= 32; p += 4u; }
+  if (hi & 2u) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)cur; cur >>= 16; p += 2u; }
+  if (hi & 1u) { base[p] = (unsigned char)cur; }
 }
 /* bytes [lo, hi), both inside the chunk (a payload shorter than its chunk) */
 __device__ __forceinline__ void store_sub16(unsigned char *base, const uint4 w, u32 lo, u32 hi) {
@@ -258,6 +263,20 @@ __device__ __forceinline__ uint4 window16(const uint4 p, const uint4 c, u32 o) {
   return e;
 }
 
+/* destination chunk at stream position dpos (a multiple of 16) of the record whose payload sits at stream positions
+ * [ps, pe) = f: a whole chunk is streamed, the chunks that hold the payload's first / last byte go as aligned
+ * power-of-two stores.  Everything by value (see halves16). */
+__device__ __forceinline__ void emit_chunk(unsigned char *rec_al, u32 ps, u32 pe, u32 dpos, const uint4 f) {
+  if (dpos + 16u > ps && dpos < pe) {                   /* the chunk holds payload bytes */
+    unsigned char *to = rec_al + dpos;
+    const bool head = dpos < ps, tail = dpos + 16u > pe;
+    if (!head && !tail) store16_stream(to, f);
+    else if (!head) store_tail16(to, f, pe - dpos);
+    else if (!tail) store_head16(to, f, ps - dpos);
+    else store_sub16(to, f, ps - dpos, pe - dpos);
+  }
+}
+
 template <int GROUP>
 __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel(
     const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data,
@@ -339,15 +358,7 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel
       const uint4 prev = lane == 0u ? carry : rot;
       carry = rot;
       const uint4 f = window16<UNI>(prev, v[k], 16u - dm);
-      const u32 dpos = (i + qd) << 4;
-      if (i < n_fun && dpos + 16u > ps && dpos < pe) {  /* the chunk holds payload bytes */
-        unsigned char *to = rec_al + dpos;
-        const bool head = dpos < ps, tail = dpos + 16u > pe;
-        if (!head && !tail) store16_stream(to, f);
-        else if (!head) store_tail16(to, f, pe - dpos);
-        else if (!tail) store_head16(to, f, ps - dpos);
-        else store_sub16(to, f, ps - dpos, pe - dpos);
-      }
+      if (i < n_fun) emit_chunk(rec_al, ps, pe, (i + qd) << 4, f);
     }
   }
   const u32 a_sum = group_sum<GROUP>(a_acc % ADLER_MOD);

@@ -64,6 +64,48 @@ def random_specs(rng, n, lens, n_writers=5):
     return specs
 
 
+def phase_sweep_batch(rng, lens, src_phases=range(16), dst_phases=range(16)):
+    """Every payload length of `lens` at every source phase x destination phase (address mod 16, for 16-byte aligned
+    buffers): records with gaps between them in the output so that each starts at the phase wanted.  Returns
+    (records with out_offset set, data, out_bytes, [(out_offset, record bytes)])."""
+    hdr = header_bytes(0, 3, None)
+    specs = [(ln, sp, dp) for ln in lens for sp in src_phases for dp in dst_phases]
+    recs = np.zeros(len(specs), dtype=abi.WAL_RECORD_DTYPE)
+    chunks, pos, want, out = [hdr + bytes(13)], 16, [], 0
+    for i, (ln, sp, dp) in enumerate(specs):
+        pad = (sp - pos) % 16
+        chunks.append(bytes(pad)); pos += pad
+        payload = rng.integers(0, 256, size=ln, dtype=np.uint8).tobytes()
+        recs["index"][i], recs["term"][i] = i + 1, 7
+        recs["hdr_offset"][i], recs["hdr_len"][i] = 0, 3
+        recs["data_offset"][i], recs["data_len"][i] = pos, ln
+        chunks.append(payload); pos += ln
+        out += (dp - out) % 16
+        recs["out_offset"][i] = out
+        entry = struct.pack(">QQ", i + 1, 7) + payload
+        want.append((out, hdr + struct.pack(">II", zlib.adler32(entry), ln) + entry))
+        out += 27 + ln
+    data = np.frombuffer(b"".join(chunks) + bytes(16), dtype=np.uint8).copy()
+    return recs, data, out, want
+
+
+def check_phase_sweep(framed: bytes, want, out_bytes):
+    """Every record where it belongs, and nothing written in the gaps (the host forms zero the output first)."""
+    ref = bytearray(out_bytes)
+    for off, rec in want:
+        ref[off:off + len(rec)] = rec
+    if framed != bytes(ref):
+        got = np.frombuffer(framed, dtype=np.uint8); exp = np.frombuffer(bytes(ref), dtype=np.uint8)
+        bad = int(np.flatnonzero(got != exp)[0])
+        k = max(i for i, (off, _) in enumerate(want) if off <= bad) if bad >= want[0][0] else -1
+        raise AssertionError(f"first difference at output byte {bad} (record {k}, starts at {want[k][0]}, "
+                             f"{len(want[k][1])} bytes)")
+
+
+SWEEP_SMALL = [0, 1, 2, 3, 5, 8, 13, 15, 16, 17, 31, 32, 33, 47, 48, 49, 240, 255, 256, 257, 272]
+SWEEP_LARGE = [1007, 1008, 1023, 1024, 1025, 1040, 2047, 2048, 2049, 4096]
+
+
 # ------------------------------------------------------------------------------------------ CPU
 
 def test_oracle_frame_matches_struct_pack_and_zlib():
@@ -410,3 +452,19 @@ def test_gpu_frame_full_size_batch_round_trips_through_the_recovery_path():
     n_ok, status = eng.wal_validate(f, scanned)
     assert status == abi.WAL_CORRUPT and 0 < n_ok < n
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+def test_gpu_frame_every_source_and_destination_phase(small):
+    """Payload lengths around the 16-byte chunk and the lane-group boundaries at every source phase x destination
+    phase: the chunk that spills over behind the last source chunk is written by the lane that holds that chunk."""
+    rng = np.random.default_rng(95 + small)
+    lens = SWEEP_SMALL if small else SWEEP_LARGE
+    recs, data, out_bytes, want = phase_sweep_batch(rng, lens, range(16), range(16) if small else (0, 1, 5, 8, 11, 15))
+    assert (len(data) / len(recs) < 1024) == small
+    eng = _open()
+    try:
+        check_phase_sweep(eng.wal_frame(recs, data, out_bytes).tobytes(), want, out_bytes)
+    finally:
+        eng.close()

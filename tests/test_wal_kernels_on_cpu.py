@@ -11,7 +11,8 @@ import pytest
 
 from ra_amd import abi
 from oracle import oracle as O
-from test_wal_framing import make_batch as make_records, python_frame, random_specs, scanned_as_tuples
+from test_wal_framing import (make_batch as make_records, python_frame, random_specs, scanned_as_tuples,
+                               phase_sweep_batch, check_phase_sweep, SWEEP_SMALL, SWEEP_LARGE)
 from test_wal_checksum import make_batch as make_entries, zlib_checksums
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -162,3 +163,18 @@ def test_descriptors_whose_offset_plus_length_wraps_are_refused(wal):
     with pytest.raises(wal.engine.RgbError) as e:
         wal.wal_validate(bytes(f), scanned)
     assert e.value.code == abi.E_INVAL
+
+
+@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+def test_framing_kernel_at_every_source_and_destination_phase(wal, small):
+    """The -m gpu test of the same name on the emulated kernel (fewer phases for the large records: the fiber
+    emulation runs them at a few MB/s)."""
+    rng = np.random.default_rng(95 + small)
+    if small:
+        recs, data, out_bytes, want = phase_sweep_batch(rng, SWEEP_SMALL)
+    else:
+        recs, data, out_bytes, want = phase_sweep_batch(rng, SWEEP_LARGE, (0, 5, 15), (0, 3, 8, 13))
+    assert (len(data) / len(recs) < 1024) == small
+    rc, out = wal.wal_frame(recs, data, out_bytes)
+    assert rc == 0
+    check_phase_sweep(out.tobytes(), want, out_bytes)
