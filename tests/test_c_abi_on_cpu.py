@@ -41,6 +41,11 @@ def test_sparse_pending_through_the_c_abi(emulated_engine, oracle_lib):
     G.test_written_event_for_a_live_index_below_the_snapshot(emulated_engine, oracle_lib)
 
 
+def test_quorum_term_gate_on_any_run_table(emulated_engine, oracle_lib):
+    G.test_quorum_term_gate_on_any_run_table(emulated_engine, oracle_lib, 700, 231)
+    G.test_quorum_term_gate_on_any_run_table(emulated_engine, oracle_lib, 64, 232)
+
+
 def test_bounded_run_tables_and_repair_workload(emulated_engine, oracle_lib):
     G.test_bounded_run_table_matches_oracle(emulated_engine, oracle_lib, 5, 211, 300, 4)
     G.test_config5_log_matching_repair_matches_oracle(emulated_engine, oracle_lib)

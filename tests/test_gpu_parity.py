@@ -244,6 +244,80 @@ def test_write_below_first_index_keeps_the_range_start(engine_mod, oracle_lib, n
         assert int(so["first_index"][1]) == 47 == int(so["run_start"][1][0]) and int(so["last_index"][1]) == 47
 
 
+def _reply_ok(server, peer, term, next_index, last_index):
+    m = np.zeros(1, dtype=abi.MSG_DTYPE)
+    m["server"], m["kind"], m["from"], m["term"], m["flags"] = server, abi.MSG_AER_REPLY, peer, term, abi.MF_SUCCESS
+    m["a"], m["b"] = next_index, last_index
+    return m[0]
+
+
+@pytest.mark.parametrize("groups,seed", [(700, 231), (64, 232)])
+def test_quorum_term_gate_on_any_run_table(engine_mod, oracle_lib, groups, seed):
+    """evaluate_quorum's Raft 5.4.2 gate `fetch_term(Agreed) == current_term` (src/ra_server.erl:3633-3646) on run tables
+    Raft can produce and on ones it cannot (terms in any order, at, above and below current_term, the agreed index in
+    any run, so the lookup goes through the mirrored runs and through the table walk): leaders take success replies
+    for several ticks (the class kernel's fast path and its general path; 700 groups = 64+ messages per class slice),
+    decisions and states equal the checker's.  Written for a shortcut that answered the gate without the walk from a
+    derived "older runs are below current_term" flag (measured: no gain, removed); a mutant that
+    trusted the flag blindly fails here."""
+    rng = np.random.default_rng(seed)
+    N = 5
+    st = abi.empty_server_states(groups, N)
+    for s in range(groups * N):
+        n_runs = int(rng.integers(1, 7))
+        monotone = rng.random() < 0.5
+        terms, t = [], int(rng.integers(1, 4))
+        for r in range(n_runs):
+            if monotone:
+                t += int(rng.integers(1, 3)) if r else 0
+            else:
+                t = int(rng.choice([x for x in range(1, 8) if not terms or x != terms[-1]]))
+            terms.append(t)
+        first = int(rng.integers(1, 30))
+        entries, idx = [], first
+        for t in terms:
+            for _ in range(int(rng.integers(1, 6))):
+                entries.append((idx, t)); idx += 1
+        li = entries[-1][0]
+        lwi = int(rng.integers(first, li + 1))
+        abi.set_log(st, s, entries, last_written=(lwi, dict(entries)[lwi]))
+        st["pending_first"][s] = lwi + 1
+        ct = max(terms) if monotone and rng.random() < 0.7 else int(rng.integers(1, 9))
+        st["current_term"][s] = ct
+        la = int(rng.integers(first - 1, li + 1))
+        st["last_applied"][s] = la
+        st["commit_index"][s] = min(li, la + int(rng.integers(0, 4)))
+        st["role"][s] = abi.ROLE_LEADER if s % N == 0 else abi.ROLE_FOLLOWER
+        st["leader_id"][s] = 0
+        st["voted_for"][s] = 0
+        st["present_mask"][s] = st["voter_mask"][s] = 0x1F
+        st["status_mask"][s] = 0xFF
+        for j in range(N):
+            mi = int(rng.integers(max(first - 3, 0), li + 1))
+            st["match_index"][s, j] = mi
+            st["next_index"][s, j] = mi + 1 + int(rng.integers(0, 3))
+            st["commit_index_sent"][s, j] = st["commit_index"][s]
+    cpu = oracle_lib.Oracle(groups, N)
+    cpu.set_state(0, st)
+    moved = 0
+    with engine_mod.RaGpuBatch(groups, N, ring_capacity=8192, ring_slots=2) as gpu:
+        gpu.set_state(0, st)
+        for tick in range(6):
+            cur = cpu.get_state()
+            msgs = []
+            for g in range(groups):
+                s = g * N
+                li, first = int(cur["last_index"][s]), int(cur["first_index"][s])
+                last = int(rng.integers(first, li + 1))
+                msgs.append(_reply_ok(s, int(rng.integers(1, N)), int(cur["current_term"][s]), last + 1, last))
+            msgs = np.array(msgs, dtype=abi.MSG_DTYPE)
+            do, ro = cpu.step(msgs)
+            dg, rg = gpu.step(msgs)
+            assert_same(f"term gate tick {tick}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+            moved += int(np.count_nonzero(cpu.get_state()["commit_index"][::N] != cur["commit_index"][::N]))
+    assert moved > groups // 4          # the gate opened often enough to matter (up AND down: no max())
+
+
 @pytest.mark.parametrize("n_members,seed,groups,max_runs", [(5, 211, 300, 4), (3, 212, 300, 3), (7, 213, 200, 5)])
 def test_bounded_run_table_matches_oracle(engine_mod, oracle_lib, n_members, seed, groups, max_runs):
     """A run table smaller than the logs' term structure: the engine forgets its oldest runs
