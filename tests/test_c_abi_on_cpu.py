@@ -42,7 +42,7 @@ def test_sparse_pending_through_the_c_abi(emulated_engine, oracle_lib):
 
 
 def test_quorum_term_gate_on_any_run_table(emulated_engine, oracle_lib):
-    G.test_quorum_term_gate_on_any_run_table(emulated_engine, oracle_lib, 700, 231)
+    G.test_quorum_term_gate_on_any_run_table(emulated_engine, oracle_lib, 4200, 231)
     G.test_quorum_term_gate_on_any_run_table(emulated_engine, oracle_lib, 64, 232)
 
 

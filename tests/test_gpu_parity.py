@@ -251,12 +251,13 @@ def _reply_ok(server, peer, term, next_index, last_index):
     return m[0]
 
 
-@pytest.mark.parametrize("groups,seed", [(700, 231), (64, 232)])
+@pytest.mark.parametrize("groups,seed", [(4200, 231), (64, 232)])
 def test_quorum_term_gate_on_any_run_table(engine_mod, oracle_lib, groups, seed):
     """evaluate_quorum's Raft 5.4.2 gate `fetch_term(Agreed) == current_term` (src/ra_server.erl:3633-3646) on run tables
     Raft can produce and on ones it cannot (terms in any order, at, above and below current_term, the agreed index in
     any run, so the lookup goes through the mirrored runs and through the table walk): leaders take success replies
-    for several ticks (the class kernel's fast path and its general path; 700 groups = 64+ messages per class slice),
+    for several ticks (4 200 groups: rgb_submit takes the class-dispatch kernel from 4 096 messages per round on -- its
+    fast path and its general path; 64 groups: the kind-generic kernel),
     decisions and states equal the checker's.  Written for a shortcut that answered the gate without the walk from a
     derived "older runs are below current_term" flag (measured: no gain, removed); a mutant that
     trusted the flag blindly fails here."""
