@@ -160,6 +160,7 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   rgb_wal_release(ctx);
   for (auto &s : ctx->ring) free_slot(s);
+  if (ctx->dev.dbg_buf) (void)hipFree(ctx->dev.dbg_buf);
   if (ctx->dev.hot) (void)hipFree(ctx->dev.hot);
   if (ctx->dev.peers) (void)hipFree(ctx->dev.peers);
   if (ctx->dev.runs) (void)hipFree(ctx->dev.runs);
@@ -239,6 +240,11 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
     HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
     HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
   }
+#endif
+#ifdef RGB_X_EXTRA_STORE
+  /* EXPERIMENT (never in the product): a scratch line per server for the write-side probe of the class kernel */
+  HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)S * 16 * sizeof(u64)));
+  HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)S * 16 * sizeof(u64)));
 #endif
   HIPCHK(ctx, hipMalloc((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));

@@ -2328,6 +2328,16 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     if (RGB_KNOB(dev, 16u)) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
 #endif
   }
+#if defined(RGB_X_EXTRA_STORE) && !defined(RGB_HOST_EMULATION)
+  /* EXPERIMENT (never in the product): RGB_X_EXTRA_STORE more dirty bytes (16 or 64) per message in a line of its own
+   * (a scratch line per server), stored like the state write-back: is the end-of-kernel write-back priced per line or
+   * per byte -- the twin of RGB_X_EXTRA_FETCH */
+  if (active && (u32)(m0.x & 0xFFFFFFFFull) < dev.n_servers) {
+    ulonglong2 *xs = reinterpret_cast<ulonglong2 *>(dev.dbg_buf + (size_t)(u32)(m0.x & 0xFFFFFFFFull) * 16);
+#pragma unroll
+    for (int k = 0; k < RGB_X_EXTRA_STORE / 16; ++k) ST16(xs + k, make_ulonglong2(d.w[0], d.w[1] + (u64)k));
+  }
+#endif
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
   if (active) {
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
