@@ -15,5 +15,5 @@ except Exception as e: print('$1 failed', e)"
 }
 one product $PWD/ra_amd/csrc/libra_gpu_batch.so ""
 for v in ra_amd/csrc/variants/*.so; do [ -f "$v" ] && one $(basename $v .so) $PWD/$v ""; done
-for dbg in $KNOBS; do one prof_dbg$dbg $PWD/ra_amd/csrc/libra_gpu_batch_prof.so $dbg; done
+[ -f ra_amd/csrc/libra_gpu_batch_prof.so ] && for dbg in $KNOBS; do one prof_dbg$dbg $PWD/ra_amd/csrc/libra_gpu_batch_prof.so $dbg; done
 one product_again $PWD/ra_amd/csrc/libra_gpu_batch.so ""
