@@ -2303,6 +2303,10 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     else if (cls == 2) done = fast_written(dev, m0, m1, hrow, hswz, d);
   }
 #endif
+#if defined(RGB_PROFILE) && !defined(RGB_HOST_EMULATION)
+  u64 tf = 0; unsigned n_fast = 0;
+  if (RGB_KNOB(dev, 16u)) { tf = wall_clock64(); n_fast = (unsigned)__popcll(__ballot(done)); }   /* fast paths done */
+#endif
   if (active && !done) {
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
@@ -2367,7 +2371,8 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     if (lane == 0) {
       u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 8;
       o[0] = t0; o[1] = t1 | ((tl[0] - t1) << 40); o[2] = t2 | ((t2b - t2) << 40) | ((u64)cls << 60); o[3] = wall_clock64();
-      o[4] = mx; o[5] = sm | ((tl[2] > t1 ? tl[2] - t1 : 0) << 24); o[6] = nz | ((tl[3] > t1 ? tl[3] - t1 : 0) << 24); o[7] = cnt;
+      o[4] = mx; o[5] = sm | ((tl[2] > t1 ? tl[2] - t1 : 0) << 24); o[6] = nz | ((tl[3] > t1 ? tl[3] - t1 : 0) << 24);
+      o[7] = cnt | ((u64)n_fast << 8) | ((tf > t1 ? tf - t1 : 0) << 24);   /* lanes, lanes the fast paths took, fast paths done */
     }
   }
 #endif

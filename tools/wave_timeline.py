@@ -47,7 +47,14 @@ for c in range(12):
     ok = d_disp > 0
     if ok.any():
         print(f"          lane 0, from messages-in-registers: state loaded {np.median(dl[m][ok])*tick/1e3:5.2f} | clause code done {np.median(d_disp[ok])*tick/1e3:5.2f} | commit issued {np.median(d_comm[ok])*tick/1e3:5.2f} | process returned {np.median((t2[m]-t1[m])[ok])*tick/1e3:5.2f} us")
-    mx, sm, nz, cn = b[m, 4].astype(int), (b[m, 5] & np.uint64(M24)).astype(int), (b[m, 6] & np.uint64(M24)).astype(int), b[m, 7].astype(int)
+    mx, sm, nz, cn = b[m, 4].astype(int), (b[m, 5] & np.uint64(M24)).astype(int), (b[m, 6] & np.uint64(M24)).astype(int), (b[m, 7] & np.uint64(0xFF)).astype(int)
+    nfast, tfast = ((b[m, 7] >> np.uint64(8)) & np.uint64(0xFF)).astype(int), (b[m, 7] >> np.uint64(24)).astype(np.int64)
+    if c <= 2 and (tfast > 0).any():
+        gen = nfast < cn                 # wavefronts that went on to the general clause code
+        print(f"          fast paths done {np.median(tfast[tfast > 0])*tick/1e3:5.2f} us after messages-in-registers; lanes they took {nfast.sum()}/{cn.sum()} "
+              f"({100.0*nfast.sum()/max(cn.sum(),1):.1f} %); wavefronts left with general-path lanes {gen.sum()}/{len(cn)}, "
+              f"wave life with / without: {np.median((t3[m]-t0[m])[gen])*tick/1e3 if gen.any() else float('nan'):.1f} / "
+              f"{np.median((t3[m]-t0[m])[~gen])*tick/1e3 if (~gen).any() else float('nan'):.1f} us")
     print(f"          run-table words read: lanes reading {nz.sum()}/{cn.sum()} ({100.0*nz.sum()/max(cn.sum(),1):.1f} %), per reading lane {sm.sum()/max(nz.sum(),1):.1f}, "
           f"waves with a reader {100.0*(nz>0).mean():.0f} %, wave max p50/p90/max {np.percentile(mx,50):.0f}/{np.percentile(mx,90):.0f}/{mx.max()}; "
           f"wave life by wave-max words 0/1-2/3-6/7+: " + "/".join(
@@ -63,7 +70,7 @@ for c in range(15):
 order = np.argsort(-endt)[:24]
 print("last waves: class start end life lanes max-run-words")
 for i in order:
-    print(f"  {cls[i]:2d} {startt[i]:5.1f} {endt[i]:5.1f} {endt[i]-startt[i]:5.1f} {int(b[i,7]):3d} {int(b[i,4]):3d}")
+    print(f"  {cls[i]:2d} {startt[i]:5.1f} {endt[i]:5.1f} {endt[i]-startt[i]:5.1f} {int(b[i,7]) & 0xFF:3d} {int(b[i,4]):3d}")
 # concurrency over time
 ev = np.concatenate([np.stack([t0 - z, np.ones_like(t0)], 1), np.stack([t3 - z, -np.ones_like(t3)], 1)])
 ev = ev[np.argsort(ev[:, 0], kind="stable")]
