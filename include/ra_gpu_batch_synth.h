@@ -5,8 +5,10 @@
  * messages (at most one per server) straight into HBM, so long message streams can be produced
  * without a host round trip per tick.
  *
- * The tick is written COMPACTED (no empty slots) and ordered by clause family (message kind,
- * success flag) -- the order rgb_submit gives host batches; its message count goes to *d_n.
+ * The tick is written COMPACTED (no empty slots) and ordered by (class of the message kind, group mod 8, success
+ * flag) = rgb_train_bucket: every kernel class is contiguous (what the per-tick class kernel needs, like the
+ * family order rgb_submit gives host batches) and so is every (class, shard) pair (what a train launch needs); its
+ * message count goes to *d_n.
  *
  * Per group and tick (a fully loaded node):
  *   leader      append_entries_reply ok 75 % / failed 5 % / {commands,_} append of 1..4 entries
@@ -37,6 +39,10 @@ extern "C" {
  * context's stream); no synchronisation. */
 int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs,
                           void *d_kind_counts, void *d_n, void *stream);
+/* the same; d_bucket_counts (may be NULL): uint32[RGB_TRAIN_BUCKETS] = this tick's messages per train bucket
+ * (rgb_train_bucket) -- what rgb_train_plan_create wants.  Ticks are written in bucket order. */
+int rgb_synth_tick_buckets_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs,
+                                  void *d_kind_counts, void *d_n, void *d_bucket_counts, void *stream);
 
 /* Apply the tick that rgb_synth_tick_device just wrote (same stream): one launch of the
  * class-dispatch kernel sized from the family totals the generator left in device memory, so no

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 UNDEF = np.uint64(0xFFFFFFFFFFFFFFFF)  # Erlang 'undefined'
 UNDEF_INT = 0xFFFFFFFFFFFFFFFF
 NONE = 0xFF                            # undefined member slot

@@ -84,7 +84,17 @@ struct rgb_ctx {
   /* snapshot / checksum scratch */
   rgb_leaderboard_row *d_rows = nullptr;
   u64 *d_sums = nullptr;
-  u32 *d_synth = nullptr;     /* load-generator scratch (family counters) */
+  u32 *d_synth = nullptr;     /* load-generator scratch (family and bucket counters) */
+  /* train launches */
+  u32 *d_train_ctl = nullptr;           /* RGB_TRAIN_CTL_WORDS: sticky error flags | XCC id + 1 per shard */
+  unsigned char *d_seq_cnt = nullptr;   /* per-server stamp counters of rgb_train_stamp_device */
+};
+
+/* the device plan of a train: one rgb_train_tick per tick */
+struct rgb_train_plan {
+  rgb_train_tick *d_ticks = nullptr;
+  u32 n_ticks = 0;
+  u32 bpt = 0;            /* blocks per tick: RGB_TRAIN_SHARDS x the longest tick's rows */
 };
 
 /* A tick ordered by clause family: ONE launch of the class-dispatch kernel. */
@@ -171,6 +181,8 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->d_synth) (void)hipFree(ctx->d_synth);
+  if (ctx->d_train_ctl) (void)hipFree(ctx->d_train_ctl);
+  if (ctx->d_seq_cnt) (void)hipFree(ctx->d_seq_cnt);
 
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -596,15 +608,124 @@ int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
 void *rgb_ctx_stream(rgb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rgb_ctx_device(rgb_ctx *ctx) { return ctx ? ctx->cfg.device : 0; }
 
-int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
-                          void *d_n, void *stream) {
+int rgb_synth_tick_buckets_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
+                                  void *d_n, void *d_bucket_counts, void *stream) {
   if (!ctx || !d_msgs) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   void *st = stream ? stream : (void *)ctx->stream;
-  if (!ctx->d_synth) HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth, 4 * (RGB_MSG_KIND_MAX + 1) * sizeof(u32)));
+  if (!ctx->d_synth) HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth, RGB_SYNTH_SCRATCH_WORDS * sizeof(u32)));
   int rc = rgb_launch_synth(ctx->dev, seed, tick, (rgb_msg *)d_msgs, ctx->d_synth, (u32 *)d_kind_counts,
-                            (u32 *)d_n, st);
+                            (u32 *)d_n, (u32 *)d_bucket_counts, st);
   if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
+  return RGB_OK;
+}
+
+int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
+                          void *d_n, void *stream) {
+  return rgb_synth_tick_buckets_device(ctx, seed, tick, d_msgs, d_kind_counts, d_n, nullptr, stream);
+}
+
+/* ---- train launches (include/ra_gpu_batch.h) ---- */
+uint32_t rgb_train_bucket(uint32_t kind, uint32_t flags, uint32_t server, uint32_t n_members) {
+  return n_members ? rgb_bucket(kind, flags, server, n_members) : 0u;
+}
+
+int rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t n_ticks, rgb_train_plan **out) {
+  if (!ctx || !out || (!bucket_counts && n_ticks)) return RGB_E_INVAL;
+  *out = nullptr;
+  if (!ctx->registered) return RGB_E_STATE;
+  rgb_train_plan *p = new (std::nothrow) rgb_train_plan();
+  if (!p) return RGB_E_NOMEM;
+  std::vector<rgb_train_tick> ticks(n_ticks);
+  u32 rows = 0;
+  for (u32 t = 0; t < n_ticks; ++t) {
+    const u32 r = rgb_train_make_tick(bucket_counts + (size_t)t * RGB_N_BUCKETS, ctx->dev.n_members, &ticks[t]);
+    if (r > rows) rows = r;
+  }
+  p->n_ticks = n_ticks;
+  p->bpt = rows * RGB_TRAIN_SHARDS;
+  if (n_ticks) {
+    hipError_t e = hipMalloc((void **)&p->d_ticks, (size_t)n_ticks * sizeof(rgb_train_tick));
+    if (e == hipSuccess)
+      e = hipMemcpy(p->d_ticks, ticks.data(), (size_t)n_ticks * sizeof(rgb_train_tick), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      ctx->last_hip.store((int)e, std::memory_order_relaxed);
+      if (p->d_ticks) (void)hipFree(p->d_ticks);
+      delete p;
+      return RGB_E_HIP;
+    }
+  }
+  *out = p;
+  return RGB_OK;
+}
+
+void rgb_train_plan_destroy(rgb_train_plan *plan) {
+  if (!plan) return;
+  if (plan->d_ticks) (void)hipFree(plan->d_ticks);
+  delete plan;
+}
+
+uint32_t rgb_train_plan_blocks_per_tick(const rgb_train_plan *plan) { return plan ? plan->bpt : 0; }
+
+static int train_scratch(rgb_ctx *ctx) {
+  if (!ctx->d_train_ctl) {
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_train_ctl, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
+    HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
+  }
+  if (!ctx->d_seq_cnt) HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq_cnt, ctx->dev.n_servers));
+  return RGB_OK;
+}
+
+int rgb_train_stamp_device(rgb_ctx *ctx, void *d_msgs, uint32_t tick_stride, const uint32_t *tick_counts,
+                           uint32_t n_ticks, void *stream) {
+  if (!ctx || !d_msgs || (!tick_counts && n_ticks)) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  int rc = train_scratch(ctx);
+  if (rc) return rc;
+  void *st = stream ? stream : (void *)ctx->stream;
+  rgb_msg *m = (rgb_msg *)d_msgs;
+  for (u32 t = 0; t < n_ticks; ++t) {
+    if (tick_counts[t] > tick_stride) return RGB_E_INVAL;
+    rc = rgb_launch_train_seq(ctx->dev, m + (size_t)t * tick_stride, tick_counts[t], ctx->d_seq_cnt, t == 0, st);
+    if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
+  }
+  return RGB_OK;
+}
+
+int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
+                         const void *d_msgs, uint32_t tick_stride, void *d_decisions, void *d_rpcs,
+                         uint32_t rpc_ring, void *stream) {
+  if (!ctx || !plan || !d_msgs || !d_decisions) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  if ((uint64_t)first_tick + n_ticks > plan->n_ticks) return RGB_E_INVAL;
+  if (n_ticks == 0 || plan->bpt == 0) return RGB_OK;
+  if ((uint64_t)n_ticks * plan->bpt > 0x7FFFFFFFull) return RGB_E_INVAL;
+  int rc = train_scratch(ctx);
+  if (rc) return rc;
+  void *st = stream ? stream : (void *)ctx->stream;
+  const size_t off = (size_t)first_tick * tick_stride;
+  rc = rgb_launch_train(ctx->dev, (const rgb_msg *)d_msgs + off, tick_stride, plan->d_ticks + first_tick, n_ticks,
+                        plan->bpt, (rgb_decision *)d_decisions + off, (rgb_rpc *)d_rpcs, rpc_ring, (u32)off,
+                        ctx->d_train_ctl, st);
+  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
+  return RGB_OK;
+}
+
+int rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard) {
+  if (!ctx) return RGB_E_INVAL;
+  if (flags_out) *flags_out = 0;
+  if (!ctx->d_train_ctl) return RGB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  u32 w[RGB_TRAIN_CTL_WORDS];
+  HIPCHK(ctx, hipMemcpy(w, ctx->d_train_ctl, sizeof w, hipMemcpyDeviceToHost));
+  if (flags_out) *flags_out = w[0];
+  if (xcc_of_shard)
+    for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) xcc_of_shard[x] = w[1 + x] ? w[1 + x] - 1u : 0xFFFFFFFFu;
+  if (w[0]) {
+    HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, sizeof(u32)));
+    return RGB_E_STATE;
+  }
   return RGB_OK;
 }
 

@@ -72,6 +72,9 @@ typedef uint32_t u32;
 #define PK_QPEER_SH     57  /* 1: some peer query_index > 0 (reset_query_index has work) */
 #define PK_BACKOFF_SH   58  /* 1: some peer is in {snapshot_backoff,_}: qry row word QRY_BACKOFF holds the mask */
 #define PK_PENDX_SH     59  /* 1: `pending` has ranges below its newest one: qry row words QRY_PEND_LO.. hold them */
+#define PK_SEQ_SH        60  /* 4: train sequence stamp = messages applied to this server, mod 16.  Written only by
+                               the train kernel (rgb_train_kernel); pack sets it to 0, unpack / checksum / the
+                               per-tick kernels neither read nor change it */
 #define QRY_PEND_LO     12  /* (first, last) of the lower old range, (1, 0) when there is only one */
 #define QRY_PEND_HI     14  /* (first, last) of the old range next below the newest range [HOT_PEND .. last_index] */
 #define QRY_BACKOFF     9   /* qry row: word 0 query_index, 1..8 peer query_index, 9 backoff mask */
@@ -108,6 +111,33 @@ static inline __host__ __device__ unsigned rgb_family(unsigned kind, unsigned fl
 }
 static inline unsigned rgb_class_of_kind(unsigned kind) { return rgb_kind_rank(kind); }   /* NOP has no class */
 
+/* ---- train launches: several ticks in one launch (rgb_train_kernel) ----
+ * Servers are sharded by group: shard = group mod RGB_TRAIN_SHARDS (= the XCDs of the device); a train tick is
+ * ordered by (class, shard, success flag): see rgb_bucket. */
+#define RGB_TRAIN_SHARDS 8u
+#define RGB_N_BUCKETS ((RGB_N_CLASSES + 1u) * RGB_TRAIN_SHARDS * 2u)   /* 256 */
+#define RGB_TRAIN_ERR_PLACEMENT 1u   /* two blocks of one shard ran on different XCDs                    */
+#define RGB_TRAIN_ERR_SPIN      2u   /* a wavefront's dependencies did not commit within the spin bound */
+#define RGB_TRAIN_CTL_WORDS (1u + RGB_TRAIN_SHARDS)   /* error flags | XCC id + 1 of every shard */
+static inline __host__ __device__ unsigned rgb_shard_of_server(unsigned server, unsigned n_members) {
+  return (server / n_members) & (RGB_TRAIN_SHARDS - 1u);
+}
+/* bucket = (class rank (15 = NOP), shard, success flag): class-major, so a family-ordered consumer still finds every
+ * class contiguous, and (class, shard) is one contiguous range */
+static inline __host__ __device__ unsigned rgb_bucket(unsigned kind, unsigned flags, unsigned server, unsigned n_members) {
+  return (rgb_kind_rank(kind) * RGB_TRAIN_SHARDS + rgb_shard_of_server(server, n_members)) * 2u +
+         ((flags & RGB_MF_SUCCESS) ? 1u : 0u);
+}
+/* one tick of a train: rows of RGB_TRAIN_SHARDS blocks; row r of class position q serves slice r of every shard */
+struct rgb_train_tick {
+  u32 row_end[16];                              /* cumulative rows of class positions 0..14 ([15] = [14])  */
+  u32 off[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* first message of (class at position q, shard)           */
+  u32 cnt[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* its message count                                       */
+};
+/* words of the load generator's scratch: family totals (what rgb_tick_classes_kernel reads) | bucket totals |
+ * bucket fill | bucket bases */
+#define RGB_SYNTH_SCRATCH_WORDS (RGB_N_FAMILIES + 3u * RGB_N_BUCKETS)
+
 static inline __host__ __device__ unsigned rgb_peer_stride(unsigned n_members) {
   return (3u * n_members + 7u) & ~7u;
 }
@@ -143,8 +173,20 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
                             const u32 *d_family_totals, u32 max_msgs, rgb_decision *d_dec, rgb_rpc *d_rpcs,
                             u32 rpc_slot_base, u32 msg_index_base, void *stream);
 /* d_scratch: 2*RGB_N_FAMILIES u32 of device scratch */
+/* d_scratch: RGB_SYNTH_SCRATCH_WORDS u32; d_bucket_counts (may be NULL): RGB_N_BUCKETS u32 of this tick */
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
-                     u32 *d_kind_counts, u32 *d_n, void *stream);
+                     u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream);
+/* ticks [0, n_ticks) of d_plan in one launch; bpt = blocks per tick (multiple of RGB_TRAIN_SHARDS); d_rpcs (may be
+ * NULL): rpc_ring tick-sized regions, tick t uses region t mod rpc_ring; rgb_rpc.msg_index = index_base + t *
+ * tick_stride + i; d_ctl: RGB_TRAIN_CTL_WORDS u32 (word 0 = sticky
+ * error flags, never cleared here) */
+int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, u32 tick_stride, const rgb_train_tick *d_plan,
+                     u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base,
+                     u32 *d_ctl, void *stream);
+/* stamp n messages of one tick (ticks must be stamped in train order); init = first tick of a train */
+int rgb_launch_train_seq(const rgb_dev &dev, rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt, bool init, void *stream);
+/* host: the plan of one tick from its bucket counts (uint32[RGB_N_BUCKETS]); returns the tick's rows */
+u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out);
 int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream);
 int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u32 n, void *stream);
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream);

@@ -81,13 +81,14 @@ __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
 /* Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): lane l's bytes land at lds_base + 16 * l -- the
  * destination of the instruction is wave-uniform base + lane * 16 -- without passing through a register.  NT = data
  * that is read once.  glds_wait() = the issuing wave's copies have landed (a one-wave workgroup needs nothing else). */
-template <bool NT>
+enum { GLDS_DEFAULT = 0, GLDS_NT = 2, GLDS_SC1 = 16 };   /* cache policy: nt = read once; sc1 = served by L2 (L1 bypass) */
+template <int POLICY>
 __device__ __forceinline__ void glds16(const void *g, void *lds_base) {
 #ifdef RGB_HOST_EMULATION
   memcpy(static_cast<char *>(lds_base) + 16 * emu::lane(), g, 16);
 #else
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, NT ? 2 : 0);
+                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, POLICY);
 #endif
 }
 __device__ __forceinline__ void glds_wait() {
@@ -124,6 +125,28 @@ __device__ __forceinline__ ulonglong2 ld16(const ulonglong2 *p) {
   return *p;
 }
 
+/* State loads of the clause code.  coh = the multi-tick train launch (rgb_train_kernel): another CU may have written
+ * this server's rows earlier IN THE SAME LAUNCH, and a CU's vector L1 is never refreshed by another CU's stores, so the
+ * load must be served by the XCD's L2: a relaxed agent-scope atomic load (global_load ... sc1, which bypasses L1 only;
+ * the compiler tracks it like any load).  The per-tick kernels (coh = false) keep plain loads. */
+__device__ __forceinline__ u64 ldg8(bool coh, const u64 *p) {
+#ifndef RGB_HOST_EMULATION
+  if (coh) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  return *p;
+}
+__device__ __forceinline__ ulonglong2 ldg16(bool coh, const ulonglong2 *p) {
+#ifndef RGB_HOST_EMULATION
+  if (coh) {
+    const u64 *q = reinterpret_cast<const u64 *>(p);
+    const u64 x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_ulonglong2(x, y);
+  }
+#endif
+  return *p;
+}
+
 __device__ __forceinline__ u64 pk_get(u64 pk, int sh, int w) { return (pk >> sh) & ((1ull << w) - 1ull); }
 __device__ __forceinline__ u64 pk_set(u64 pk, int sh, int w, u64 v) {
   const u64 m = ((1ull << w) - 1ull) << sh;
@@ -134,7 +157,9 @@ __device__ __forceinline__ unsigned slot4to8(unsigned s) { return s >= 8u ? (uns
 
 /* Everything one lane needs for one message: the server's hot line in registers, the message,
  * the effects being accumulated and the pending (uncommitted) log-table edits. */
-struct Lane {
+template <bool COH>
+struct LaneT {
+  static constexpr bool coh = COH;   /* state loads must bypass the CU's L1 (train launch), see ldg8 */
   /* hot line */
   u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt, prs, prt, pend;
   /* cold words (qry row), loaded only by the election kinds */
@@ -191,7 +216,7 @@ struct Lane {
   u64 hb_term, hb_qi, q_consensus;
 };
 
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void load_peers(Lane &L) {
   if (L.peers_loaded) return;
   constexpr int PS = (3 * N + 7) & ~7;
@@ -205,7 +230,7 @@ __device__ __forceinline__ void load_peers(Lane &L) {
     const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(L.peers);
 #pragma unroll
     for (int k = 0; k < PS / 2; ++k) {
-      if (2 * k < 3 * N) { ulonglong2 v = pp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+      if (2 * k < 3 * N) { ulonglong2 v = ldg16(L.coh, pp + k); w[2 * k] = v.x; w[2 * k + 1] = v.y; }
     }
   }
 #pragma unroll
@@ -230,52 +255,58 @@ __device__ __forceinline__ void peer_set(u64 (&a)[8], unsigned &dirty, unsigned 
 /* The peers row of a leader-side message handled by the class kernel lives in LDS (PL = true; fetched with the hot
  * row, piece p at position p ^ peers_swz): its words are read and written THERE, the register arrays pmi/pni/pcs
  * (30 VGPRs for five members) do not exist on those paths.  PL = false: the arrays, loaded from memory. */
+template <class Lane>
 __device__ __forceinline__ unsigned prow_at(const Lane &L, unsigned w) { return (((w >> 1) ^ L.peers_swz) << 1) | (w & 1u); }
+template <class Lane>
 __device__ __forceinline__ u64 prow_get(const Lane &L, unsigned w) {
   return reinterpret_cast<const u64 *>(L.peers_lds)[prow_at(L, w)];
 }
+template <class Lane>
 __device__ __forceinline__ void prow_set(Lane &L, unsigned w, u64 v) {
   const_cast<u64 *>(reinterpret_cast<const u64 *>(L.peers_lds))[prow_at(L, w)] = v;
   L.pdirty |= 1u << w;
 }
-template <int N, bool PL> __device__ __forceinline__ u64 mi_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)i) : L.pmi[i]; }
-template <int N, bool PL> __device__ __forceinline__ u64 ni_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)(N + i)) : L.pni[i]; }
-template <int N, bool PL> __device__ __forceinline__ u64 cs_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)(2 * N + i)) : L.pcs[i]; }
-template <int N, bool PL> __device__ __forceinline__ void ni_set(Lane &L, int i, u64 v) {
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 mi_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)i) : L.pmi[i]; }
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 ni_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)(N + i)) : L.pni[i]; }
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 cs_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)(2 * N + i)) : L.pcs[i]; }
+template <int N, bool PL, class Lane> __device__ __forceinline__ void ni_set(Lane &L, int i, u64 v) {
   if (PL) prow_set(L, (unsigned)(N + i), v); else { L.pni[i] = v; L.dni |= 1u << i; }
 }
 /* run-time peer index (the sender of a reply) */
-template <int N, bool PL> __device__ __forceinline__ u64 mi_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, p) : 0) : peer_get<N>(L.pmi, p); }
-template <int N, bool PL> __device__ __forceinline__ u64 ni_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, (unsigned)N + p) : 0) : peer_get<N>(L.pni, p); }
-template <int N, bool PL> __device__ __forceinline__ void mi_put(Lane &L, unsigned p, u64 v) {
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 mi_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, p) : 0) : peer_get<N>(L.pmi, p); }
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 ni_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, (unsigned)N + p) : 0) : peer_get<N>(L.pni, p); }
+template <int N, bool PL, class Lane> __device__ __forceinline__ void mi_put(Lane &L, unsigned p, u64 v) {
   if (PL) { if (p < (unsigned)N) prow_set(L, p, v); } else peer_set<N>(L.pmi, L.dmi, p, v);
 }
-template <int N, bool PL> __device__ __forceinline__ void ni_put(Lane &L, unsigned p, u64 v) {
+template <int N, bool PL, class Lane> __device__ __forceinline__ void ni_put(Lane &L, unsigned p, u64 v) {
   if (PL) { if (p < (unsigned)N) prow_set(L, (unsigned)N + p, v); } else peer_set<N>(L.pni, L.dni, p, v);
 }
 
+template <class Lane>
 __device__ __forceinline__ bool range_nonempty(const Lane &L) { return L.first <= L.li; }
 
 /* word i of this server's in-memory run table: (start, term) of run k at words 2k, 2k+1 */
+template <class Lane>
 __device__ __forceinline__ u64 run_word(const Lane &L, int i) {
 #ifdef RGB_PROFILE
   const_cast<Lane &>(L).prof_nloads += 1;
 #endif
-  return L.runs[i];
+  return ldg8(L.coh, L.runs + i);
 }
 
 /* The in-memory runs (n_runs-3 and older) searched newest first for the one that holds idx: its number and term, -1 if
  * idx is below the oldest.  A run's (start, term) is one 16-byte load and the next older run is requested before the
  * current one is examined, so the walk overlaps its round trips two deep with two live pairs (requesting four at a
  * time measured 15 % slower per tick: the extra live registers spilled in the clause code around every call site). */
+template <class Lane>
 __device__ __forceinline__ int run_search(const Lane &L, u64 idx, u64 &term) {
   const ulonglong2 *rt = reinterpret_cast<const ulonglong2 *>(L.runs);
   int k = (int)L.n_runs - 3;
   if (k < 0) return -1;
-  ulonglong2 cur = rt[k];
+  ulonglong2 cur = ldg16(L.coh, rt + k);
 #pragma unroll 1
   for (; k >= 0; --k) {
-    const ulonglong2 nxt = rt[k > 0 ? k - 1 : 0];
+    const ulonglong2 nxt = ldg16(L.coh, rt + (k > 0 ? k - 1 : 0));
 #ifdef RGB_PROFILE
     const_cast<Lane &>(L).prof_nloads += 2u;
 #endif
@@ -286,6 +317,7 @@ __device__ __forceinline__ int run_search(const Lane &L, u64 idx, u64 &term) {
 }
 
 /* ra_log:fetch_term/2 (src/ra_log.erl:1186-1200): defined only inside the range */
+template <class Lane>
 __device__ __forceinline__ u64 fetch_term(const Lane &L, u64 idx) {
   if (!(range_nonempty(L) && idx >= L.first && idx <= L.li)) return UNDEF;
   if (idx >= L.lrs) return L.lrt;
@@ -300,6 +332,7 @@ __device__ __forceinline__ u64 fetch_term(const Lane &L, u64 idx) {
 }
 
 /* ra_server:fetch_term/2 with the snapshot fallback (src/ra_server.erl:3185-3196) */
+template <class Lane>
 __device__ __forceinline__ u64 srv_fetch_term(const Lane &L, u64 idx) {
   u64 t = fetch_term(L, idx);
   if (t == UNDEF && L.si != UNDEF && L.si == idx) return L.st;
@@ -308,6 +341,7 @@ __device__ __forceinline__ u64 srv_fetch_term(const Lane &L, u64 idx) {
 
 /* index of the run holding idx (largest k with start_k <= idx), -1 if none.  Only called
  * before any edit of this message is pending. */
+template <class Lane>
 __device__ __forceinline__ int find_run(const Lane &L, u64 idx) {
   if (L.n_runs == 0) return -1;
   if (idx >= L.lrs) return (int)L.n_runs - 1;
@@ -323,6 +357,7 @@ __device__ __forceinline__ int find_run(const Lane &L, u64 idx) {
  * keeps them equal to the snapshot's, see rgb_server_state. */
 
 /* ra_log:next_index/1 (src/ra_log.erl:1166-1174) */
+template <class Lane>
 __device__ __forceinline__ u64 next_log_index(const Lane &L) {
   if (range_nonempty(L)) return L.li + 1;
   if (L.si != UNDEF) return L.si + 1;
@@ -331,6 +366,7 @@ __device__ __forceinline__ u64 next_log_index(const Lane &L) {
 
 enum { HLE_OK = 0, HLE_MISMATCH = 1, HLE_MISSING = 2 };
 /* has_log_entry_or_snapshot/3 (src/ra_server.erl:3168-3183) */
+template <class Lane>
 __device__ __forceinline__ int has_log_entry_or_snapshot(const Lane &L, u64 idx, u64 term) {
   u64 t = fetch_term(L, idx);
   if (t == UNDEF) {
@@ -341,16 +377,22 @@ __device__ __forceinline__ int has_log_entry_or_snapshot(const Lane &L, u64 idx,
 }
 
 /* ---- state word helpers ---- */
+template <class Lane>
 __device__ __forceinline__ unsigned role_of(const Lane &L) { return (unsigned)pk_get(L.pk, PK_ROLE_SH, 3); }
+template <class Lane>
 __device__ __forceinline__ unsigned self_of(const Lane &L) { return (unsigned)pk_get(L.pk, PK_SELF_SH, 4); }
+template <class Lane>
 __device__ __forceinline__ bool present(const Lane &L, unsigned i) {
   return i < 8u && ((L.pk >> (PK_PRESENT_SH + i)) & 1ull);
 }
+template <class Lane>
 __device__ __forceinline__ bool voter(const Lane &L, unsigned i) { return (L.pk >> (PK_VOTER_SH + i)) & 1ull; }
+template <class Lane>
 __device__ __forceinline__ bool status_normal(const Lane &L, unsigned i) { return (L.pk >> (PK_STATUS_SH + i)) & 1ull; }
 
 /* role change; become(follower,..) resets every peer status to normal
  * (src/ra_server.erl:2183-2192) */
+template <class Lane>
 __device__ __forceinline__ void set_role(Lane &L, unsigned role) {
   unsigned old = role_of(L);
   if (old != role) L.flags |= RGB_F_ROLE_CHANGED;
@@ -363,6 +405,7 @@ __device__ __forceinline__ void set_role(Lane &L, unsigned role) {
 }
 
 /* update_term_and_voted_for/3 (src/ra_server.erl:3041-3058); voted4 is a 4-bit slot */
+template <class Lane>
 __device__ __forceinline__ void update_term_and_voted_for(Lane &L, u64 term, unsigned voted4) {
   unsigned cur = (unsigned)pk_get(L.pk, PK_VOTED_SH, 4);
   if (term == L.ct && voted4 == cur) return;
@@ -381,16 +424,17 @@ __device__ __forceinline__ void update_term_and_voted_for(Lane &L, u64 term, uns
   }
 }
 
+template <class Lane>
 __device__ __forceinline__ u64 *qry_row(const Lane &L) { return L.qry_base + (size_t)L.server * RGB_QRY_WORDS; }
 
 /* the qry row: query_index | per-peer query_index */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void load_qry(Lane &L) {
   if (L.q_loaded) return;
   const ulonglong2 *qp = reinterpret_cast<const ulonglong2 *>(qry_row(L));
   u64 w[N + 2];
 #pragma unroll
-  for (int k = 0; k < (N + 2) / 2; ++k) { ulonglong2 v = qp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+  for (int k = 0; k < (N + 2) / 2; ++k) { ulonglong2 v = ldg16(L.coh, qp + k); w[2 * k] = v.x; w[2 * k + 1] = v.y; }
   L.qself = w[0];
   if (pk_get(L.pk, PK_QPEER_SH, 1)) {
 #pragma unroll
@@ -400,6 +444,7 @@ __device__ __forceinline__ void load_qry(Lane &L) {
 }
 
 /* heartbeat_reply/2 :3727-3729 cast to the sender of the #heartbeat_rpc{} */
+template <class Lane>
 __device__ __forceinline__ void heartbeat_reply(Lane &L, u64 term, u64 query_index, unsigned to8) {
   L.has_reply = true;
   L.flags |= RGB_F_REPLY | RGB_F_REPLY_HEARTBEAT;
@@ -407,14 +452,14 @@ __device__ __forceinline__ void heartbeat_reply(Lane &L, u64 term, u64 query_ind
   L.reply_to = to8;
 }
 
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ unsigned n_other_members(const Lane &L) {
   const unsigned present = (unsigned)pk_get(L.pk, PK_PRESENT_SH, 8) & ((1u << N) - 1u);
   return (unsigned)__popc(present & ~(1u << (unsigned)pk_get(L.pk, PK_SELF_SH, 4)));
 }
 
 /* heartbeat_rpc_effects/4 + heartbeat_rpc_effect_for_peer/5 :3775-3795 */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void heartbeat_rpc_effects(Lane &L, u64 query_index) {
   const unsigned self = (unsigned)pk_get(L.pk, PK_SELF_SH, 4);
   const unsigned present = (unsigned)pk_get(L.pk, PK_PRESENT_SH, 8);
@@ -434,12 +479,13 @@ __device__ __forceinline__ void heartbeat_rpc_effects(Lane &L, u64 query_index) 
 
 /* peers (of `candidates`) whose query_index is below the row's own query_index, straight from
  * memory: the election paths that call it must not carry the row in registers */
-__device__ __forceinline__ unsigned heartbeat_targets(const u64 *qry, unsigned candidates, bool peers_zero, u64 *qself) {
-  const u64 q0 = qry[0];
+__device__ __forceinline__ unsigned heartbeat_targets(const u64 *qry, unsigned candidates, bool peers_zero, u64 *qself,
+                                                      bool coh) {
+  const u64 q0 = ldg8(coh, qry);
   unsigned mask = 0;
   for (unsigned i = 0; i < 8; ++i) {
     if (!((candidates >> i) & 1u)) continue;
-    const u64 qi = peers_zero ? 0 : qry[1 + i];
+    const u64 qi = peers_zero ? 0 : ldg8(coh, qry + 1 + i);
     if (qi < q0) mask |= 1u << i;
   }
   *qself = q0;
@@ -447,7 +493,7 @@ __device__ __forceinline__ unsigned heartbeat_targets(const u64 *qry, unsigned c
 }
 
 /* update_heartbeat_rpc_effects/1 :3731-3747 (the waiting queue lives on the host) */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void update_heartbeat_rpc_effects(Lane &L) {
   if (n_other_members<N>(L) == 0) { L.flags |= RGB_F_QUERY_APPLY; return; }
   if (!pk_get(L.pk, PK_QSELF_SH, 1)) return;      /* query_index == 0: no peer can be below it */
@@ -455,7 +501,7 @@ __device__ __forceinline__ void update_heartbeat_rpc_effects(Lane &L) {
   const unsigned cand = (unsigned)pk_get(L.pk, PK_PRESENT_SH, 8) & (unsigned)pk_get(L.pk, PK_STATUS_SH, 8) &
                         ((1u << N) - 1u) & ~(1u << self);
   u64 q0;
-  const unsigned mask = heartbeat_targets(qry_row(L), cand, !pk_get(L.pk, PK_QPEER_SH, 1), &q0);
+  const unsigned mask = heartbeat_targets(qry_row(L), cand, !pk_get(L.pk, PK_QPEER_SH, 1), &q0, L.coh);
   if (mask) {
     L.flags |= RGB_F_SEND_HEARTBEATS;
     L.hb_mask |= mask;
@@ -464,7 +510,7 @@ __device__ __forceinline__ void update_heartbeat_rpc_effects(Lane &L) {
 }
 
 /* make_heartbeat_rpc_effects/2 :3749-3767 */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void make_heartbeat_rpc_effects(Lane &L) {
   if (n_other_members<N>(L) == 0) { L.flags |= RGB_F_QUERY_APPLY; return; }
   load_qry<N>(L);
@@ -478,7 +524,7 @@ template <int N> __device__ __forceinline__ u64 agreed_commit(const u64 (&v)[N],
 
 /* heartbeat_rpc_quorum/3 :3797-3814, update_peer_query_index/3 :3816-3829,
  * get_current_query_quorum/1 :3831-3832 over query_indexes/1 :3659-3669 */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void heartbeat_rpc_quorum(Lane &L, u64 new_qi, unsigned peer) {
   const unsigned self = (unsigned)pk_get(L.pk, PK_SELF_SH, 4);
   const unsigned present = (unsigned)pk_get(L.pk, PK_PRESENT_SH, 8);
@@ -505,21 +551,25 @@ __device__ __forceinline__ void heartbeat_rpc_quorum(Lane &L, u64 new_qi, unsign
   L.q_consensus = agreed_commit<N>(v, use, n);
 }
 /* update_term/2 (src/ra_server.erl:3060-3064) */
+template <class Lane>
 __device__ __forceinline__ void update_term(Lane &L, u64 term) {
   if (term != UNDEF && term > L.ct) update_term_and_voted_for(L, term, SLOT_NONE4);
 }
+template <class Lane>
 __device__ __forceinline__ void set_leader_id(Lane &L, unsigned l4) {
   if ((unsigned)pk_get(L.pk, PK_LEADER_SH, 4) != l4) L.flags |= RGB_F_LEADER_CHANGED;
   L.pk = pk_set(L.pk, PK_LEADER_SH, 4, l4);
 }
 
 /* append_entries_reply/3 (src/ra_server.erl:3624-3631) */
+template <class Lane>
 __device__ __forceinline__ void aer_reply(Lane &L, u64 term, bool success, unsigned to8) {
   L.has_reply = true;
   L.flags |= RGB_F_REPLY | (success ? RGB_F_REPLY_SUCCESS : 0u);
   L.r_term = term; L.r_next = L.li + 1; L.r_last = L.lwi; L.r_lterm = L.lwt;
   L.reply_to = to8;
 }
+template <class Lane>
 __device__ __forceinline__ void vote_reply(Lane &L, u64 term, bool granted, unsigned to8) {
   L.has_reply = true;
   L.flags |= RGB_F_REPLY | RGB_F_REPLY_VOTE | (granted ? RGB_F_REPLY_SUCCESS : 0u);
@@ -527,6 +577,7 @@ __device__ __forceinline__ void vote_reply(Lane &L, u64 term, bool granted, unsi
   L.reply_to = to8;
 }
 
+template <class Lane>
 __device__ __forceinline__ void pre_vote_reply(Lane &L, u64 term, u64 token, bool granted, unsigned to8) {
   L.has_reply = true;
   L.flags |= RGB_F_REPLY | RGB_F_REPLY_PRE_VOTE | (granted ? RGB_F_REPLY_SUCCESS : 0u);
@@ -535,12 +586,14 @@ __device__ __forceinline__ void pre_vote_reply(Lane &L, u64 term, u64 token, boo
 }
 
 /* required_quorum/1 (src/ra_server.erl:3996-3999), count_voters/1 :4001-4009 */
+template <class Lane>
 __device__ __forceinline__ unsigned required_quorum(const Lane &L) {
   unsigned voters = __popc((unsigned)(pk_get(L.pk, PK_PRESENT_SH, 8) & pk_get(L.pk, PK_VOTER_SH, 8)));
   return voters / 2 + 1;
 }
 
 /* apply_to/5 (src/ra_server.erl:3250-3282): only the cursor moves on the device */
+template <class Lane>
 __device__ __forceinline__ bool apply_to(Lane &L, u64 upto) {
   if (upto > L.la) {
     u64 to = L.li < upto ? L.li : upto;
@@ -550,6 +603,7 @@ __device__ __forceinline__ bool apply_to(Lane &L, u64 upto) {
 }
 
 /* evaluate_commit_index_follower/2 (src/ra_server.erl:2246-2280) */
+template <class Lane>
 __device__ __forceinline__ void evaluate_commit_index_follower(Lane &L) {
   if (pk_get(L.pk, PK_LEADER_SH, 4) == SLOT_NONE4) return;
   u64 at = L.li < L.ci ? L.li : L.ci;
@@ -559,6 +613,7 @@ __device__ __forceinline__ void evaluate_commit_index_follower(Lane &L) {
 /* ---- log edits (register side; memory is touched at commit) ---- */
 
 /* append one segment [s..e] of term t after the current last run */
+template <class Lane>
 __device__ __forceinline__ void push_segment(Lane &L, u64 s, u64 t) {
   if (L.n_runs > 0 && L.lrt == t) return;            /* extends the last run */
   L.prs = L.lrs; L.prt = L.lrt;                      /* the old last run is now run n-2 */
@@ -569,6 +624,7 @@ __device__ __forceinline__ void push_segment(Lane &L, u64 s, u64 t) {
 
 /* cut the table so that its last run is the one holding `keep_idx` (largest start <=
  * keep_idx); runs starting above it disappear.  keep_term = term_at(keep_idx) if known. */
+template <class Lane>
 __device__ __forceinline__ void truncate_runs_to(Lane &L, u64 keep_idx) {
   int k = find_run(L, keep_idx);
   if (k < 0) { L.n_runs = 0; return; }
@@ -583,14 +639,19 @@ __device__ __forceinline__ void truncate_runs_to(Lane &L, u64 keep_idx) {
 /* ra_log `pending` (src/ra_log.erl:126): on this path always the contiguous tail
  * [pend .. last_index] of indexes handed to the WAL and not yet confirmed; empty is held as
  * last_index + 1. */
+template <class Lane>
 __device__ __forceinline__ bool pend_nonempty(const Lane &L) { return range_nonempty(L) && L.pend <= L.li; }
+template <class Lane>
 __device__ __forceinline__ void pend_canon(Lane &L) { if (!pend_nonempty(L)) L.pend = L.li + 1; }
 /* ra_seq:limit(CeilExcl - 1, Pend) / ra_seq:floor(Floor, Pend) on the ranges below the newest one */
+template <class Lane>
 __device__ __forceinline__ void pend_old_limit(Lane &L, u64 ceil_excl) { if (ceil_excl < L.po_cut) L.po_cut = ceil_excl; }
+template <class Lane>
 __device__ __forceinline__ void pend_old_floor(Lane &L, u64 floor_incl) { if (floor_incl > L.po_floor) L.po_floor = floor_incl; }
 
 /* ra_log:write/2 (src/ra_log.erl:547-599, range update :1618-1623) of entries k0..n-1.
  * Returns an RGB_INV_* code, 0 on success.  Validates before editing. */
+template <class Lane>
 __device__ __forceinline__ int log_write(Lane &L, u32 k0) {
   const u64 base = L.a + 1 + (u64)L.gap;
   const u64 fst = base + k0;
@@ -634,6 +695,7 @@ __device__ __forceinline__ int log_write(Lane &L, u32 k0) {
 }
 
 /* ra_log:set_last_index/2 (src/ra_log.erl:842-893) */
+template <class Lane>
 __device__ __forceinline__ int log_set_last_index(Lane &L, u64 idx) {
   u64 t = fetch_term(L, idx);
   bool snap_is_idx = (L.si != UNDEF && L.si == idx);
@@ -678,6 +740,7 @@ __device__ __forceinline__ int log_set_last_index(Lane &L, u64 idx) {
  * Returns an RGB_INV_* code; `changed` = last_written moved. */
 
 /* c1 over one range [lo..hi] of the sequence */
+template <class Lane>
 __device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u64 to, u64 &c1) {
   const u64 hi = to < L.li ? to : L.li;
   const u64 lo = from > L.first ? from : L.first;
@@ -692,7 +755,7 @@ __device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u6
 #ifdef RGB_PROFILE
       if (L.prof_noprobe) break;
 #endif
-      const ulonglong2 r = reinterpret_cast<const ulonglong2 *>(L.runs)[k];
+      const ulonglong2 r = ldg16(L.coh, reinterpret_cast<const ulonglong2 *>(L.runs) + k);
 #ifdef RGB_PROFILE
       const_cast<Lane &>(L).prof_nloads += 2;
 #endif
@@ -709,6 +772,7 @@ __device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u6
   return false;
 }
 /* c2 over one range of the sequence */
+template <class Lane>
 __device__ __forceinline__ bool written_c2(const Lane &L, bool in_range, u64 from, u64 to, u64 &c2) {
   if (L.si == UNDEF) return false;
   u64 u = to < L.si ? to : L.si;
@@ -731,6 +795,7 @@ __device__ __forceinline__ bool pend_range_written(u64 ps, u64 pe, u64 c, bool t
   return false;
 }
 
+template <class Lane>
 __device__ __forceinline__ int log_written(Lane &L, u64 term, u64 from, u64 to, bool &changed) {
   changed = false;
   const bool in_range = range_nonempty(L);
@@ -757,7 +822,7 @@ __device__ __forceinline__ int log_written(Lane &L, u64 term, u64 from, u64 to, 
     /* the old ranges as this message has cut them so far (nothing cuts them before a written event, but be exact) */
 #pragma unroll 1
     for (int k = 0; k < 2 && prefix; ++k) {
-      u64 ps = q[QRY_PEND_LO + 2 * k], pe = q[QRY_PEND_LO + 2 * k + 1];
+      u64 ps = ldg8(L.coh, q + QRY_PEND_LO + 2 * k), pe = ldg8(L.coh, q + QRY_PEND_LO + 2 * k + 1);
       if (ps < L.po_floor) ps = L.po_floor;
       if (L.po_cut != UNDEF && pe >= L.po_cut) pe = L.po_cut - 1;
       if (L.po_cut == 0) continue;
@@ -784,6 +849,7 @@ __device__ __forceinline__ int log_written(Lane &L, u64 term, u64 from, u64 to, 
  * only when the range is defined and Idx >= its first index; last_written follows the snapshot
  * when it is not above it; the range is truncated behind the snapshot (ra_range:truncate/2).
  * The run table loses its leading runs right here (no other log edit can share the message). */
+template <class Lane>
 __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term) {
   if (!(range_nonempty(L) && idx >= L.first)) return false;
   bool changed = false;
@@ -802,7 +868,7 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
         u64 rs, rt;                                     /* the newest two runs are in registers */
         if (j == L.n_runs - 1) { rs = L.lrs; rt = L.lrt; }
         else if (j == L.n_runs - 2) { rs = L.prs; rt = L.prt; }
-        else { rs = runs[2 * j]; rt = runs[2 * j + 1]; }
+        else { rs = ldg8(L.coh, runs + 2 * j); rt = ldg8(L.coh, runs + 2 * j + 1); }
         runs[2 * (j - k)] = rs;
         runs[2 * (j - k) + 1] = rt;
       }
@@ -845,7 +911,7 @@ __device__ __forceinline__ u64 agreed_commit(const u64 (&v)[N], const bool (&use
 }
 
 /* match_indexes/1 :3671-3682, increment_commit_index/1 :3648-3657, evaluate_quorum/2 :3633-3646 */
-template <int N, bool PL = false>
+template <int N, bool PL = false, class Lane>
 __device__ __forceinline__ void evaluate_quorum(Lane &L) {
   u64 v[N + 1];
   bool use[N + 1];
@@ -870,7 +936,7 @@ __device__ __forceinline__ void evaluate_quorum(Lane &L) {
  * make_append_entries_rpc/6 :2418-2435.  One pass: peer cursors change in registers and rpc
  * records go to this message's private slots, so when an assertion of the reference fails
  * (non-zero return) nothing has been committed: the decision reports n_rpcs = 0. */
-template <int N, bool EMIT, bool PL = false>
+template <int N, bool EMIT, bool PL = false, class Lane>
 __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, u32 max_batch, bool &more,
                              unsigned &n_out, rgb_rpc *rpcs, u32 slot_base, u32 msg_index) {
   const unsigned self = self_of(L);
@@ -929,7 +995,7 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
 
 /* the leader branch of handle_candidate(#request_vote_result{vote_granted=true}) :1055-1058 with
  * initialise_peers/1 :3234-3242 */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void become_leader(Lane &L) {
   const u64 ni = next_log_index(L);
   load_peers<N>(L);
@@ -948,13 +1014,14 @@ __device__ __forceinline__ void become_leader(Lane &L) {
 }
 
 /* one granted vote for a candidate in its own term (src/ra_server.erl:1045-1061) */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void candidate_vote_granted(Lane &L) {
   unsigned nv = (unsigned)pk_get(L.pk, PK_VOTES_SH, 4) + 1;
   if (nv == required_quorum(L)) become_leader<N>(L);
   else L.pk = pk_set(L.pk, PK_VOTES_SH, 4, nv);
 }
 
+template <class Lane>
 __device__ __forceinline__ void vote_requests(Lane &L, u64 term, bool pre) {
   L.flags &= ~(u32)RGB_F_PRE_VOTE_REQS;
   L.flags |= RGB_F_SEND_VOTE_REQUESTS | (pre ? RGB_F_PRE_VOTE_REQS : 0u);
@@ -964,7 +1031,7 @@ __device__ __forceinline__ void vote_requests(Lane &L, u64 term, bool pre) {
 }
 
 /* call_for_election(candidate,_) (src/ra_server.erl:2880-2899) + the self vote it casts */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void call_for_election_candidate(Lane &L) {
   const u64 new_term = L.ct + 1;
   update_term_and_voted_for(L, new_term, self_of(L));
@@ -976,7 +1043,7 @@ __device__ __forceinline__ void call_for_election_candidate(Lane &L) {
 }
 
 /* call_for_election(pre_vote,_) (src/ra_server.erl:2900-2924) + the self pre-vote (:1229-1246) */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ void call_for_election_pre_vote(Lane &L, u64 token) {
   update_term_and_voted_for(L, L.ct, self_of(L));
   set_leader_id(L, SLOT_NONE4);
@@ -992,6 +1059,7 @@ __device__ __forceinline__ void call_for_election_pre_vote(Lane &L, u64 token) {
 }
 
 /* process_pre_vote/3 (src/ra_server.erl:2926-2983); the server stays in its role */
+template <class Lane>
 __device__ __forceinline__ int process_pre_vote(Lane &L) {
   const u64 token = L.c;
   if (L.term >= L.ct) {
@@ -1018,7 +1086,7 @@ __device__ __forceinline__ int process_pre_vote(Lane &L) {
 
 /* make_all_rpcs/1 :2353-2367 -> make_rpcs_for/2 :2369-2377: one rpc (batch 1) per normal peer,
  * next_index NOT advanced */
-template <int N, bool PL = false>
+template <int N, bool PL = false, class Lane>
 __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *rpcs, u32 slot_base,
                                              u32 msg_index, bool only_stale = false) {
   const unsigned self = self_of(L);
@@ -1028,7 +1096,7 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
   /* make_all_rpcs/1 keeps peers in {snapshot_backoff,_} as well and cancels their retry timers
    * (:2356-2363); stale_peers/1 (the tick) only takes normal ones */
   unsigned backoff = 0;
-  if (!only_stale && pk_get(L.pk, PK_BACKOFF_SH, 1)) backoff = (unsigned)qry_row(L)[QRY_BACKOFF] & 0xFFu;
+  if (!only_stale && pk_get(L.pk, PK_BACKOFF_SH, 1)) backoff = (unsigned)ldg8(L.coh, qry_row(L) + QRY_BACKOFF) & 0xFFu;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if ((unsigned)i == self || !present(L, i)) continue;
@@ -1071,6 +1139,7 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
 /* drop_existing/3 (src/ra_server.erl:3700-3708) run-wise: number of leading entries of the
  * message that already exist with the same term.  Equivalent to the per-entry
  * ra_log:exists loop because run tables are canonical (adjacent runs differ in term). */
+template <class Lane>
 __device__ __forceinline__ u32 drop_existing(const Lane &L) {
   if (L.n_entries == 0) return 0;
   const u64 base = L.a + 1 + (u64)L.gap;
@@ -1098,6 +1167,7 @@ __device__ __forceinline__ u32 drop_existing(const Lane &L) {
 }
 
 /* handle_follower(#append_entries_rpc{}) (src/ra_server.erl:1283-1440) */
+template <class Lane>
 __device__ __forceinline__ int follower_aer(Lane &L) {
   const u64 cur_term = L.ct;
   if (!(L.term >= cur_term)) {
@@ -1175,6 +1245,7 @@ __device__ __forceinline__ int follower_aer(Lane &L) {
 }
 
 /* handle_follower(#request_vote_rpc{}) (src/ra_server.erl:1483-1529) */
+template <class Lane>
 __device__ __forceinline__ int follower_request_vote(Lane &L) {
   if (pk_get(L.pk, PK_NONVOTER_SH, 1)) return 0;
   const unsigned cand4 = slot8to4(L.from);
@@ -1199,7 +1270,7 @@ __device__ __forceinline__ int follower_request_vote(Lane &L) {
   return 0;
 }
 
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ int handle_follower(Lane &L) {
   switch (L.kind) {
     case RGB_MSG_AER:          return follower_aer(L);
@@ -1244,7 +1315,7 @@ __device__ __forceinline__ int handle_follower(Lane &L) {
 }
 
 /* -------------------------------------------------------------------- leader ---- */
-template <int N, bool PL = false>
+template <int N, bool PL = false, class Lane>
 __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb_dev &dev, rgb_rpc *rpcs,
                              u32 slot_base, u32 msg_index, unsigned &n_rpcs) {
   switch (L.kind) {
@@ -1417,7 +1488,7 @@ __device__ __forceinline__ int handle_leader(Lane &L, bool &reprocess, const rgb
 }
 
 /* ----------------------------------------------------------------- candidate ---- */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ int handle_candidate(Lane &L, bool &reprocess) {
   switch (L.kind) {
     case RGB_MSG_VOTE_RESULT: {
@@ -1497,7 +1568,7 @@ __device__ __forceinline__ int handle_candidate(Lane &L, bool &reprocess) {
 }
 
 /* ------------------------------------------------------------------ pre_vote ---- */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ int handle_pre_vote(Lane &L, bool &reprocess) {
   switch (L.kind) {
     case RGB_MSG_AER:
@@ -1569,7 +1640,7 @@ __device__ __forceinline__ int handle_pre_vote(Lane &L, bool &reprocess) {
 }
 
 /* ----------------------------------------------------------- await_condition ---- */
-template <int N>
+template <int N, class Lane>
 __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, const u64 *cond_row) {
   /* wal_down_condition/2 :2232-2233: the predicate is ra_log:can_write/1, which the host knows and passes along */
   const bool wal_down = pk_get(L.pk, PK_COND_SH, 2) == RGB_COND_WAL_DOWN;
@@ -1587,7 +1658,8 @@ __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, 
       /* :1932-1945: predicate false -> stored effects, back to follower */
       L.has_reply = true;
       L.flags |= RGB_F_REPLY | RGB_F_LEADER_MSG;
-      L.r_term = cond_row[0]; L.r_next = cond_row[1]; L.r_last = cond_row[2]; L.r_lterm = cond_row[3];
+      L.r_term = ldg8(L.coh, cond_row); L.r_next = ldg8(L.coh, cond_row + 1);
+      L.r_last = ldg8(L.coh, cond_row + 2); L.r_lterm = ldg8(L.coh, cond_row + 3);
       L.reply_to = slot4to8((unsigned)pk_get(L.pk, PK_CONDLDR_SH, 4));
       set_role(L, RGB_ROLE_FOLLOWER);
       return 0;
@@ -1639,18 +1711,22 @@ __device__ __forceinline__ void make_decision(Dec &d, u32 server, unsigned role,
 
 /* One message against one server: everything between "message words in registers" and
  * "decision words in registers".  State loads/stores go straight to the server's lines. */
-template <int N, int KIND, bool PRE = false>
+/* TR = the multi-tick train launch: state loads bypass the L1 (Lane::coh) and piece 0 of the hot row -- (current_term,
+ * packed word), whose top nibble is the server's train sequence stamp -- is NOT stored here: its final value comes
+ * back in *stamp and the wavefront stores it, stamp advanced, after every other store of the slice has been
+ * acknowledged (rgb_tick_slice).  *stamp is left untouched for a message that addresses no server. */
+template <int N, int KIND, bool PRE = false, bool TR = false>
 __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
                                                 u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr,
                                                 const ulonglong2 *pre = nullptr, unsigned swz = 0,
-                                                const ulonglong2 *prepeers = nullptr) {
-  Lane L;
+                                                const ulonglong2 *prepeers = nullptr, ulonglong2 *stamp = nullptr) {
+  LaneT<TR> L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
-   * (and its registers) remain */
-  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF);
+   * (and its registers) remain.  The kind byte's high nibble is the train sequence stamp (RGB_MSG_SEQ_*). */
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0x0F);
   L.kind = KIND >= 0 ? (unsigned)KIND : wire_kind;
   L.from = (unsigned)((m0.x >> 40) & 0xFF);
   L.mflags = (unsigned)((m0.x >> 48) & 0xFF);
@@ -1679,8 +1755,10 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     h0 = pre[0 ^ swz]; h1 = pre[1 ^ swz]; h2 = pre[2 ^ swz]; h3 = pre[3 ^ swz];
     h4 = pre[4 ^ swz]; h5 = pre[5 ^ swz]; h6 = pre[6 ^ swz]; h7 = pre[7 ^ swz];
   } else {
-    h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5]; h6 = hp[6]; h7 = hp[7];
+    h0 = ldg16(TR, hp + 0); h1 = ldg16(TR, hp + 1); h2 = ldg16(TR, hp + 2); h3 = ldg16(TR, hp + 3);
+    h4 = ldg16(TR, hp + 4); h5 = ldg16(TR, hp + 5); h6 = ldg16(TR, hp + 6); h7 = ldg16(TR, hp + 7);
   }
+  if (TR) *stamp = h0;
 #ifdef RGB_PROFILE
   L.prof_noprobe = RGB_KNOB(dev, 32u); L.prof_nloads = 0;
 #endif
@@ -1734,7 +1812,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   u64 token0 = 0;
   L.token = 0; L.macver = 0;
   if (TM && (L.kind == RGB_MSG_ELECTION_TIMEOUT || L.kind == RGB_MSG_PRE_VOTE_RPC || L.kind == RGB_MSG_PRE_VOTE_RESULT)) {
-    const ulonglong2 tm = *reinterpret_cast<const ulonglong2 *>(qry_row(L) + QRY_TOKEN);
+    const ulonglong2 tm = ldg16(TR, reinterpret_cast<const ulonglong2 *>(qry_row(L) + QRY_TOKEN));
     L.token = token0 = tm.x; L.macver = tm.y;
   }
   L.flags = 0; L.inv = 0; L.has_reply = false; L.reply_to = RGB_NONE;
@@ -1793,15 +1871,16 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
       unsigned shift = nr - L.max_runs;
       unsigned in_mem = nr - L.push_cnt;
       for (unsigned k = shift; k < in_mem; ++k) {
-        runs[2 * (k - shift)] = runs[2 * k];
-        runs[2 * (k - shift) + 1] = runs[2 * k + 1];
+        const u64 rs = ldg8(TR, runs + 2 * k), rt = ldg8(TR, runs + 2 * k + 1);
+        runs[2 * (k - shift)] = rs;
+        runs[2 * (k - shift) + 1] = rt;
       }
       nr = L.max_runs;
       L.flags |= RGB_F_RUNS_OVERFLOW;
       /* new first index = start of the new oldest run */
       u64 nf;
       if (L.push_cnt >= nr) nf = (L.push_cnt == 2 && nr == 2) ? L.prs : L.lrs;
-      else nf = runs[0];
+      else nf = ldg8(TR, runs);
       L.first = nf;
       L.n_runs = nr;
     }
@@ -1845,7 +1924,8 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   /* ---- commit: sparse `pending` (rare: only servers uploaded after a write_sparse) ---- */
   if (((pkhi0 >> (PK_PENDX_SH - 56)) & 1u) && !RGB_KNOB(dev, 1u)) {
     u64 *q = qry_row(L);
-    u64 s0 = q[QRY_PEND_LO], e0 = q[QRY_PEND_LO + 1], s1 = q[QRY_PEND_HI], e1 = q[QRY_PEND_HI + 1];
+    u64 s0 = ldg8(TR, q + QRY_PEND_LO), e0 = ldg8(TR, q + QRY_PEND_LO + 1), s1 = ldg8(TR, q + QRY_PEND_HI),
+        e1 = ldg8(TR, q + QRY_PEND_HI + 1);
     /* cut: keep [po_floor, po_cut) */
     if (s0 < L.po_floor) s0 = L.po_floor;
     if (s1 < L.po_floor) s1 = L.po_floor;
@@ -1869,7 +1949,8 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
   if (!RGB_KNOB(dev, 1u)) {
   if (L.n_runs < 2) { L.prs = 0; L.prt = 0; }         /* canonical: no run n-2 */
-  if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
+  if (TR) *stamp = make_ulonglong2(L.ct, L.pk);
+  else if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
   if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la));
   if (L.li != h2.x || L.lt != h2.y) ST16(ho + 2, make_ulonglong2(L.li, L.lt));
   if (L.lwi != h3.x || L.lwt != h3.y) ST16(ho + 3, make_ulonglong2(L.lwi, L.lwt));
@@ -1909,7 +1990,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1, const ulonglong2 m2,
                                          const ulonglong2 m3, const ulonglong2 *pre, unsigned swz, Dec &out) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
-  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), from = (unsigned)((m0.x >> 40) & 0xFF);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0x0F), from = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF), gap = (unsigned)((m0.x >> 56) & 0xFF);
   const u32 n_entries = (u32)(m2.y & 0xFFFFFFFFull), n_run0 = (u32)(m2.y >> 32);
   if (wire_kind != RGB_MSG_AER || server >= dev.n_servers || gap != 0 || n_entries == 0 || n_run0 < n_entries ||
@@ -1949,7 +2030,7 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
 __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                              const ulonglong2 *pre, unsigned swz, Dec &out) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
-  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), mflags = (unsigned)((m0.x >> 48) & 0xFF);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0x0F), mflags = (unsigned)((m0.x >> 48) & 0xFF);
   if (wire_kind != RGB_MSG_WRITTEN || server >= dev.n_servers || mflags != 0) return false;
   const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h4 = pre[4 ^ swz],
                    h5 = pre[5 ^ swz], h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
@@ -1986,12 +2067,12 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
 /* leader, {Peer, #append_entries_reply{success = true}} of the current term from a member: match / next index of the
  * peer, evaluate_quorum/2, apply (src/ra_server.erl:532-571, 3633-3688); the term of the agreed index must be
  * answerable from the two newest runs (else the general path probes the run table) */
-template <int N>
+template <int N, bool TR = false>
 __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                const ulonglong2 *pre, unsigned swz, Dec &out,
                                                const ulonglong2 *prow = nullptr) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
-  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), peer = (unsigned)((m0.x >> 40) & 0xFF);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0x0F), peer = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF);
   if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || mflags != RGB_MF_SUCCESS || peer >= (unsigned)N)
     return false;
@@ -2011,7 +2092,7 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   } else {
     const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(peers);
 #pragma unroll
-    for (int k = 0; k < (2 * N + 1) / 2; ++k) { const ulonglong2 v = pp[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    for (int k = 0; k < (2 * N + 1) / 2; ++k) { const ulonglong2 v = ldg16(TR, pp + k); w[2 * k] = v.x; w[2 * k + 1] = v.y; }
   }
   /* match_index / next_index of the peer only move forward (:540-547) */
   u64 mi_new = 0, ni_new = 0; bool mi_dirty = false, ni_dirty = false;
@@ -2157,44 +2238,42 @@ __host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLAS
   }
 }
 
-template <int N>
-__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_tick_classes_kernel(
-    rgb_dev dev, const rgb_msg *__restrict__ msgs, rgb_tick_plan plan, const u32 *__restrict__ fam_dev,
-    rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base, u32 msg_index_base) {
-  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];   /* records (5 per slot), then hot rows (9 per slot) */
-  const u32 blk_id = blockIdx.x;
-  u32 q = 0, off, ncls, blk;
-  if (fam_dev != nullptr) {
-    /* per-family totals written by a device-side producer (2 families per class) */
-    u32 n[RGB_N_CLASSES];
-#pragma unroll
-    for (int c = 0; c < RGB_N_CLASSES; ++c) n[c] = fam_dev[2 * c] + fam_dev[2 * c + 1];
-    rgb_tick_plan p;
-    rgb_make_plan(n, p, (unsigned)N);
-    if (blk_id >= p.blk_end[RGB_N_CLASSES - 1]) return;
-    off = p.off[0]; ncls = p.cnt[0]; blk = blk_id;
-#pragma unroll
-    for (int i = 1; i < RGB_N_CLASSES; ++i)
-      if (blk_id >= p.blk_end[i - 1]) { q = (u32)i; off = p.off[i]; ncls = p.cnt[i]; blk = blk_id - p.blk_end[i - 1]; }
-  } else {
-    if (blk_id >= plan.blk_end[RGB_N_CLASSES - 1]) return;
-#pragma unroll
-    for (int i = 0; i < RGB_N_CLASSES - 1; ++i) q += blk_id >= plan.blk_end[i] ? 1u : 0u;
-    off = plan.off[q]; ncls = plan.cnt[q];
-    blk = blk_id - (q ? plan.blk_end[q - 1] : 0u);
-  }
-  const int cls = rgb_class_at(q);
+/* Train launches (rgb_train_kernel): a wavefront whose servers' previous messages have not committed yet polls their
+ * sequence stamps this many times (one L2-served load + s_sleep per try, ~1 us) before it gives up and raises
+ * RGB_TRAIN_ERR_SPIN -- a bound, so that a broken dependency can never hang the device */
+#ifndef RGB_TRAIN_SPIN_LIMIT
+#ifdef RGB_HOST_EMULATION
+#define RGB_TRAIN_SPIN_LIMIT 16u      /* blocks run one after another on the CPU: a dependency is met or never will be */
+#else
+#define RGB_TRAIN_SPIN_LIMIT 40000u
+#endif
+#endif
+
+/* One wavefront's slice of one class: `cnt` (<= SL) consecutive messages starting at msgs[base].  This is the whole
+ * hot path -- record staging, cooperative state fetch, fast paths, clause code, commit, decision store -- shared by
+ * the per-tick class kernel (TR = false) and the multi-tick train kernel (TR = true).
+ *
+ * TR = true adds the dataflow protocol that replaces the kernel boundary between ticks.  A server's hot row carries a
+ * 4-bit sequence stamp (packed word bits 60..63) = the number of messages applied to it (mod 16); every message
+ * carries the stamp it must find (kind byte, high nibble: written by rgb_train_seq_kernel).  The wavefront
+ *   1. polls the packed words of its servers until every stamp matches (the earlier message of each server has
+ *      committed -- by a wavefront of an earlier tick of the SAME launch, on the same XCD: see rgb_train_kernel),
+ *   2. fetches the rows with L2-served loads (sc1: a CU's L1 is never refreshed by another CU's stores),
+ *   3. runs the unchanged clause code, whose state stores are plain (they stay in the XCD's L2),
+ *   4. waits for every store to be acknowledged, then stores piece 0 = (current_term, packed word with the stamp
+ *      advanced): whoever sees the new stamp sees the whole commit. */
+template <int N, bool TR>
+__device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *io, const int cls, const u32 base,
+                                               const u32 cnt, const u32 SL, const rgb_msg *__restrict__ msgs,
+                                               rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs,
+                                               u32 rpc_slot_base, u32 msg_index_base, u32 *__restrict__ ctl) {
   const u32 lane = threadIdx.x;
 #ifdef RGB_PROFILE
   u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl[4] = {0, 0, 0, 0};
-  if (RGB_KNOB(dev, 16u)) t0 = wall_clock64();
+  if (!TR && RGB_KNOB(dev, 16u)) t0 = wall_clock64();
 #endif
   const bool lead_cls = rgb_lead_class(cls);              /* append_entries_reply, append, pipeline_rpcs */
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
-  const u32 SL = (PEERS_LDS && lead_cls) ? 32u : (u32)RGB_TICK_BLOCK;      /* messages of this wavefront's slice */
-  const u32 base = off + blk * SL;                        /* first message of this wavefront */
-  const u32 end = off + ncls;
-  const u32 cnt = end - base < SL ? end - base : SL;
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
   {
     /* four 1 KiB global -> LDS copies in flight (read once: non-temporal), no staging registers and no ds_write
@@ -2209,27 +2288,61 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       const u32 piece = k * RGB_TICK_BLOCK + lane;
       const u32 r = piece >> 2;
       const u32 sp = (r << 2) | ((piece & 3u) ^ ((r >> 2) & 3u));
-      glds16<true>(src + (sp < last ? sp : last), io + k * RGB_TICK_BLOCK);
+      glds16<GLDS_NT>(src + (sp < last ? sp : last), io + k * RGB_TICK_BLOCK);
     }
     glds_wait();
   }
   lds_barrier();
 #ifdef RGB_PROFILE
-  if (RGB_KNOB(dev, 16u)) t1 = wall_clock64();
+  if (!TR && RGB_KNOB(dev, 16u)) t1 = wall_clock64();
 #endif
   const bool active = lane < cnt;
   const u32 mswz = (lane >> 2) & 3u;
   const ulonglong2 m0 = io[lane * 4 + (0 ^ mswz)], m1 = io[lane * 4 + (1 ^ mswz)],
                    m2 = io[lane * 4 + (2 ^ mswz)], m3 = io[lane * 4 + (3 ^ mswz)];
+  const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
+  /* the message addresses a server (a NOP or an out-of-range id touches no state and carries no stamp) */
+  const bool has_srv = TR && active && sv < dev.n_servers && ((m0.x >> 32) & 0x0Full) != RGB_MSG_NOP;
+#ifdef RGB_X_TRAIN_NODEPS
+  /* EXPERIMENT (never in the product; breaks parity): no dependency wait -- the upper bound of what overlapping
+   * ticks can give */
+  if (false) {
+#else
+  if (TR) {
+#endif
+    /* 1. dependencies: this server's previous message -- an earlier tick of this launch -- has committed */
+    const unsigned need = (unsigned)((m0.x >> 36) & 0xFull);
+    const u64 *pkp = dev.hot + (size_t)(has_srv ? sv : 0u) * RGB_HOT_WORDS + HOT_PK;
+    unsigned spins = 0;
+    for (;;) {
+#ifdef RGB_HOST_EMULATION
+      const u64 pk = *pkp;
+#else
+      const u64 pk = __hip_atomic_load(pkp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      const bool late = has_srv && (unsigned)(pk >> PK_SEQ_SH) != need;
+      if (__ballot(late) == 0ull) break;
+      spins += 1;
+      bool give_up = spins > RGB_TRAIN_SPIN_LIMIT;
+#ifndef RGB_HOST_EMULATION
+      if ((spins & 63u) == 0u && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) give_up = true;
+      __builtin_amdgcn_s_sleep(8);
+#endif
+      if (give_up) {                                      /* uniform: the decisions of this slice stay unwritten */
+        if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_SPIN);
+        return;
+      }
+    }
+  }
   /* Cooperative hot-line fetch: 8 lanes read one server's 128-byte line as ONE coalesced access, so
    * an instruction touches 8 lines instead of 64 (the CU's L1 looks up one line per cycle); the lines
    * reach their owners through LDS rows that overlay the record staging area (the messages are in
    * registers by now), and process_message reads its row from LDS piece by piece, when it needs it. */
   constexpr bool PRE = true;
+  constexpr int ROWS = TR ? GLDS_SC1 : GLDS_DEFAULT;
   u64 pf0 = 0, pf1 = 0;
   lds_barrier();
   {
-    const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
     const u32 srv = (active && sv < dev.n_servers) ? sv : 0u;
     /* leader-side classes: one word of the peers row is requested in the same round trip as the hot
      * lines, so the row's line(s) are in the cache when the lane loads the row into registers (a second
@@ -2237,8 +2350,8 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
      * spills on the pipelining paths) */
     if (lead_cls && !PEERS_LDS) {
       const u64 *pp = dev.peers + (size_t)srv * dev.peer_stride;
-      pf0 = pp[0];
-      if (3 * N > 16) pf1 = pp[16];
+      pf0 = ldg8(TR, pp);
+      if (3 * N > 16) pf1 = ldg8(TR, pp + 16);
     }
     /* row r = 8k + lane/8 lands at io[8 r ..] (1 KiB per instruction, lane-linear destination); position q of the
      * row holds piece q ^ ((r >> 1) & 7): the 16 lanes the LDS serves together read 16 different bank groups */
@@ -2247,8 +2360,8 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       if ((u32)k * 8u >= SL) break;
       const u32 r = 8 * k + (lane >> 3);
       const u32 sj = __shfl(srv, (int)r, 64);
-      glds16<false>(reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS) + ((lane & 7u) ^ ((r >> 1) & 7u)),
-                    io + k * RGB_TICK_BLOCK);
+      glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS) + ((lane & 7u) ^ ((r >> 1) & 7u)),
+                   io + k * RGB_TICK_BLOCK);
     }
     if (PEERS_LDS && lead_cls) {
       /* the peers rows (one 128-byte line each) of the slice's 32 servers behind the 32 hot rows, same shape */
@@ -2256,8 +2369,8 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       for (int k = 0; k < 4; ++k) {
         const u32 r = 8 * k + (lane >> 3);
         const u32 sj = __shfl(srv, (int)r, 64);
-        glds16<false>(reinterpret_cast<const ulonglong2 *>(dev.peers + (size_t)sj * 16u) + ((lane & 7u) ^ ((r >> 1) & 7u)),
-                      io + (4 + k) * RGB_TICK_BLOCK);
+        glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.peers + (size_t)sj * 16u) + ((lane & 7u) ^ ((r >> 1) & 7u)),
+                     io + (4 + k) * RGB_TICK_BLOCK);
       }
     }
 #if defined(RGB_X_EXTRA_FETCH) && !defined(RGB_HOST_EMULATION)
@@ -2292,27 +2405,30 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   Dec d;
   u64 *tlp = nullptr;
 #ifdef RGB_PROFILE
-  tlp = tl;
+  if (!TR) tlp = tl;
 #endif
+  /* train: piece 0 as fetched; the fast paths never change it, the clause code returns its new value */
+  ulonglong2 stamp = make_ulonglong2(0, 0);
+  if (TR) stamp = hrow[0 ^ hswz];
   bool done = false;
 #if RGB_X_FAST
   /* the steady-state outcome of the three bulk kinds first; whoever is left takes the general clause code below */
   if (active) {
     if (cls == 0) done = fast_aer(dev, m0, m1, m2, m3, hrow, hswz, d);
-    else if (cls == 1) done = fast_aer_reply<N>(dev, m0, m1, hrow, hswz, d, prow);
+    else if (cls == 1) done = fast_aer_reply<N, TR>(dev, m0, m1, hrow, hswz, d, prow);
     else if (cls == 2) done = fast_written(dev, m0, m1, hrow, hswz, d);
   }
 #endif
 #if defined(RGB_PROFILE) && !defined(RGB_HOST_EMULATION)
   u64 tf = 0; unsigned n_fast = 0;
-  if (RGB_KNOB(dev, 16u)) { tf = wall_clock64(); n_fast = (unsigned)__popcll(__ballot(done)); }   /* fast paths done */
+  if (!TR && RGB_KNOB(dev, 16u)) { tf = wall_clock64(); n_fast = (unsigned)__popcll(__ballot(done)); }   /* fast paths done */
 #endif
   if (active && !done) {
 #define RGB_CASE(RANK, KIND)                                                                            \
   case RANK:                                                                                            \
     RGB_MARK("begin", RANK)                                                                             \
-    process_message<N, KIND, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
-                                  hrow, hswz, prow);                                                    \
+    process_message<N, KIND, PRE, TR>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
+                                      hrow, hswz, prow, TR ? &stamp : nullptr);                         \
     RGB_MARK("end", RANK)                                                                               \
     break;
     switch (cls) {
@@ -2323,13 +2439,14 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
       RGB_CASE(10, RGB_MSG_PRE_VOTE_RESULT) RGB_CASE(11, RGB_MSG_SNAPSHOT_WRITTEN)
       RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
       default:
-        process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                          msg_index_base, d, tlp, hrow, hswz, prow);
+        process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE, TR>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
+                                                              msg_index_base, d, tlp, hrow, hswz, prow,
+                                                              TR ? &stamp : nullptr);
         break;
     }
 #undef RGB_CASE
 #if defined(RGB_PROFILE) && !defined(RGB_HOST_EMULATION)
-    if (RGB_KNOB(dev, 16u)) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
+    if (!TR && RGB_KNOB(dev, 16u)) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
 #endif
   }
 #if defined(RGB_X_EXTRA_STORE) && !defined(RGB_HOST_EMULATION)
@@ -2342,6 +2459,16 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     for (int k = 0; k < RGB_X_EXTRA_STORE / 16; ++k) ST16(xs + k, make_ulonglong2(d.w[0], d.w[1] + (u64)k));
   }
 #endif
+  if (TR) {
+    /* 4. publish: every state store of this wavefront has been acknowledged by the L2 (inline assembly: the
+     * compiler's wait-count pass must not drop or move it), then the stamp -- one 16-byte store per server */
+#ifndef RGB_HOST_EMULATION
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    if (has_srv)
+      ST16(reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)sv * RGB_HOT_WORDS),
+           make_ulonglong2(stamp.x, stamp.y + (1ull << PK_SEQ_SH)));
+  }
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
   if (active) {
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
@@ -2350,7 +2477,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
   }
   lds_barrier();
-  if (RGB_KNOB(dev, 2u)) return;
+  if (!TR && RGB_KNOB(dev, 2u)) return;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -2360,7 +2487,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
     if (j < cnt) store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
   }
 #ifdef RGB_PROFILE
-  if (RGB_KNOB(dev, 16u)) {
+  if (!TR && RGB_KNOB(dev, 16u)) {
     /* run-table words read per lane: wave maximum, sum, lanes that read any */
     unsigned mx = (unsigned)tl[1], sm = (unsigned)tl[1], nz = tl[1] ? 1u : 0u;
 #pragma unroll
@@ -2377,6 +2504,120 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   }
 #endif
 }
+
+template <int N>
+__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_tick_classes_kernel(
+    rgb_dev dev, const rgb_msg *__restrict__ msgs, rgb_tick_plan plan, const u32 *__restrict__ fam_dev,
+    rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base, u32 msg_index_base) {
+  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];   /* records (5 per slot), then hot rows (9 per slot) */
+  const u32 blk_id = blockIdx.x;
+  u32 q = 0, off, ncls, blk;
+  if (fam_dev != nullptr) {
+    /* per-family totals written by a device-side producer (2 families per class) */
+    u32 n[RGB_N_CLASSES];
+#pragma unroll
+    for (int c = 0; c < RGB_N_CLASSES; ++c) n[c] = fam_dev[2 * c] + fam_dev[2 * c + 1];
+    rgb_tick_plan p;
+    rgb_make_plan(n, p, (unsigned)N);
+    if (blk_id >= p.blk_end[RGB_N_CLASSES - 1]) return;
+    off = p.off[0]; ncls = p.cnt[0]; blk = blk_id;
+#pragma unroll
+    for (int i = 1; i < RGB_N_CLASSES; ++i)
+      if (blk_id >= p.blk_end[i - 1]) { q = (u32)i; off = p.off[i]; ncls = p.cnt[i]; blk = blk_id - p.blk_end[i - 1]; }
+  } else {
+    if (blk_id >= plan.blk_end[RGB_N_CLASSES - 1]) return;
+#pragma unroll
+    for (int i = 0; i < RGB_N_CLASSES - 1; ++i) q += blk_id >= plan.blk_end[i] ? 1u : 0u;
+    off = plan.off[q]; ncls = plan.cnt[q];
+    blk = blk_id - (q ? plan.blk_end[q - 1] : 0u);
+  }
+  const int cls = rgb_class_at(q);
+  constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
+  const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;      /* messages of this wavefront's slice */
+  const u32 base = off + blk * SL;                        /* first message of this wavefront */
+  const u32 end = off + ncls;
+  const u32 cnt = end - base < SL ? end - base : SL;
+  rgb_tick_slice<N, false>(dev, io, cls, base, cnt, SL, msgs, dec, rpcs, rpc_slot_base, msg_index_base, nullptr);
+}
+
+/* The TRAIN kernel: n_ticks consecutive ticks in ONE launch.  There is no kernel boundary between the ticks (no
+ * launch gap, no dispatch ramp, no end-of-kernel write-back of the dirty L2 lines per tick, and the wavefronts of
+ * neighbouring ticks drift out of phase, so one tick's memory phases run under the other's clause code); what
+ * orders two messages of one server is the server's sequence stamp (rgb_tick_slice).
+ *
+ * Coherence: the per-XCD L2s are not coherent with each other, so everything that touches a server must run on ONE
+ * XCD for the life of the launch.  Servers are sharded by group (shard = group mod 8), every tick's messages are
+ * ordered by (clause family, shard) -- rgb_synth / the plan carry the per-shard offsets -- and block b of the grid
+ * serves shard b mod 8: the dispatcher places block b on XCD b mod 8 (observed behaviour, not a contract -- so it
+ * is CHECKED: the first block of a shard records the XCC id it runs on, every later one compares, and a mismatch
+ * fails the launch with RGB_TRAIN_ERR_PLACEMENT instead of computing on stale lines).  Within an XCD the L2 is the
+ * coherence point: state stores are plain (write-through L1, line kept in the L2), state loads are L2-served.
+ *
+ * Progress: a wavefront only ever waits for messages of EARLIER ticks, whose blocks come earlier in the grid; blocks
+ * are dispatched in order per XCD, so whatever a resident wavefront waits for is resident or done.  The poll is
+ * bounded all the same (RGB_TRAIN_ERR_SPIN).
+ *
+ * Block b: tick t = b / bpt, j = b mod bpt, shard x = j mod 8, row = j / 8; plan[t] maps the row to a class position
+ * (heaviest classes first, like the per-tick plan) and the (class, shard) pair to its message range.  Surplus blocks
+ * (rows past the tick's last, slices past a shard's count) exit at once. */
+#ifndef RGB_TRAIN_MIN_WAVES
+#define RGB_TRAIN_MIN_WAVES(N) RGB_CLASS_MIN_WAVES(N)
+#endif
+template <int N>
+__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(
+    rgb_dev dev, const rgb_msg *__restrict__ msgs, u32 tick_stride, const rgb_train_tick *__restrict__ plan, u32 bpt,
+    rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_ring, u32 index_base, u32 *__restrict__ ctl) {
+  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];
+  const u32 t = blockIdx.x / bpt, j = blockIdx.x - t * bpt;
+  const u32 x = j & (RGB_TRAIN_SHARDS - 1u), row = j / RGB_TRAIN_SHARDS;
+  const rgb_train_tick *p = plan + t;
+  if (row >= p->row_end[RGB_N_CLASSES - 1]) return;
+  u32 q = 0;
+#pragma unroll
+  for (int i = 0; i < RGB_N_CLASSES - 1; ++i) q += row >= p->row_end[i] ? 1u : 0u;
+  const u32 off = p->off[q][x], ncls = p->cnt[q][x];
+  const int cls = rgb_class_at(q);
+  constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
+  const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
+  const u32 lbase = (row - (q ? p->row_end[q - 1] : 0u)) * SL;
+  if (lbase >= ncls) return;
+  const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
+#ifndef RGB_HOST_EMULATION
+  /* placement check, off the critical path: the atomic's result is only looked at after the slice */
+  u32 xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  u32 seen = 0;
+  if (threadIdx.x == 0) seen = atomicCAS(ctl + 1 + x, 0u, xcc + 1u);
+#endif
+  const size_t toff = (size_t)t * tick_stride;
+  rgb_rpc *rp = rpcs ? rpcs + (size_t)(t % rpc_ring) * tick_stride * (N > 1 ? N - 1 : 1) : nullptr;
+  rgb_tick_slice<N, true>(dev, io, cls, off + lbase, cnt, SL, msgs + toff, dec + toff, rp, 0, index_base + (u32)toff, ctl);
+#ifndef RGB_HOST_EMULATION
+  if (threadIdx.x == 0 && seen != 0u && seen != xcc + 1u) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
+#endif
+}
+
+/* Sequence stamps of a train: seq_cnt[s] = the stamp server s will carry when the next message reaches it.
+ * INIT: seq_cnt := the rows' current stamps.  Then, tick by tick in train order, every message takes its server's
+ * count into the high nibble of its kind byte and advances it (one message per server per tick: no two lanes share
+ * a counter). */
+__global__ void rgb_train_seq_init_kernel(rgb_dev dev, unsigned char *__restrict__ seq_cnt) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= dev.n_servers) return;
+  seq_cnt[s] = (unsigned char)(dev.hot[(size_t)s * RGB_HOT_WORDS + HOT_PK] >> PK_SEQ_SH);
+}
+__global__ void rgb_train_seq_kernel(rgb_dev dev, rgb_msg *__restrict__ msgs, u32 n, unsigned char *__restrict__ seq_cnt) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 *w0 = reinterpret_cast<u64 *>(msgs + i);
+  const u64 w = *w0;
+  const u32 sv = (u32)(w & 0xFFFFFFFFull);
+  if (((w >> 32) & 0x0Full) == RGB_MSG_NOP || sv >= dev.n_servers) return;
+  const unsigned c = seq_cnt[sv] & 0xFu;
+  seq_cnt[sv] = (unsigned char)((c + 1u) & 0xFu);
+  *w0 = (w & ~(0xFull << 36)) | ((u64)c << 36);
+}
+
 
 /* ------------------------------------------------------------ synthetic load ---- */
 /* Device-side load generator (include/ra_gpu_batch_synth.h).  One lane per GROUP reads the hot
@@ -2399,6 +2640,7 @@ __device__ __forceinline__ u64 sm64(u64 &x) {
 struct SynMember { u64 ct, ci, la, li, lt, lwi, lwt, pk, first, lrs, lrt, prs, prt; };
 
 /* a Lane good for fetch_term against member x's log */
+template <class Lane>
 __device__ __forceinline__ void syn_lane(Lane &T, const SynMember &x, const u64 *runs) {
   T.first = x.first; T.li = x.li; T.lrs = x.lrs; T.lrt = x.lrt; T.prs = x.prs; T.prt = x.prt;
   T.push_cnt = 0; T.n_runs = (unsigned)pk_get(x.pk, PK_NRUNS_SH, 5);
@@ -2506,7 +2748,7 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
     const SynMember &x = mb[m];
     const unsigned nr = (unsigned)pk_get(x.pk, PK_NRUNS_SH, 5);
     if (nr < 4 || !(x.first <= x.li) || x.la < x.first || x.la > x.li) continue;
-    Lane T;
+    LaneT<false> T;
     syn_lane(T, x, dev.runs + (size_t)sid(m) * dev.max_runs * 2);
     const u64 t = fetch_term(T, x.la);
     if (t == UNDEF) continue;
@@ -2548,7 +2790,7 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
       const int j = other(l, r >> 16);
       const u64 *pr = dev.peers + (size_t)sid(l) * dev.peer_stride;
       const u64 mi = pr[j];
-      Lane T;                                   /* term lookups against the leader's log */
+      LaneT<false> T;                                   /* term lookups against the leader's log */
       syn_lane(T, ld, dev.runs + (size_t)sid(l) * dev.max_runs * 2);
       if (v < 75) {
         /* what follower j has durably written (its first reply after an election jumps the
@@ -2602,52 +2844,76 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
   }
 }
 
-/* fam_total[f]: messages of family f in this tick (pass 1 output, pass 2 input);
- * fam_fill[f]: running reservation inside family f (pass 2);  both zeroed by the host per tick.
- * d_n: total messages of the tick (written by pass 1's last step on the host side: the sum). */
+/* The tick comes out ordered by BUCKET = (class of the message kind, shard of the group, success flag): class-major,
+ * so every kernel class is one contiguous range (what the per-tick class kernel needs; inside it the failed and the
+ * successful replies still sit in runs), and inside a class the messages of one shard (group mod RGB_TRAIN_SHARDS)
+ * are contiguous -- what a train launch needs (rgb_train_kernel).  Scratch words (zeroed by the launcher per tick):
+ * fam_total[RGB_N_FAMILIES] | bkt_total[RGB_N_BUCKETS] | bkt_fill[RGB_N_BUCKETS] | bkt_base[RGB_N_BUCKETS].
+ * Pass 1 (WRITE = false) counts per bucket, rgb_synth_scan_kernel turns the totals into bases (and the family
+ * totals, the per-kind counts and the tick's size), pass 2 recomputes the messages (same counter-based PRNG) and
+ * writes each one at bucket base + block reservation + rank. */
 template <int N, bool WRITE>
 __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u64 tick, rgb_msg *__restrict__ out,
-                                                       u32 *__restrict__ fam_total, u32 *__restrict__ fam_fill,
-                                                       u32 *__restrict__ kind_counts, u32 *__restrict__ d_n) {
-  __shared__ u32 cnt[SYN_FAMILIES], base[SYN_FAMILIES], rank[SYN_FAMILIES];
-  if (threadIdx.x < SYN_FAMILIES) { cnt[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
+                                                       u32 *__restrict__ scratch) {
+  __shared__ u32 cnt[RGB_N_BUCKETS], base[RGB_N_BUCKETS], rank[RGB_N_BUCKETS];
+  u32 *bkt_total = scratch + RGB_N_FAMILIES, *bkt_fill = bkt_total + RGB_N_BUCKETS, *bkt_base = bkt_fill + RGB_N_BUCKETS;
+  for (u32 b = threadIdx.x; b < RGB_N_BUCKETS; b += blockDim.x) { cnt[b] = 0; rank[b] = 0; }
   __syncthreads();
   const u32 G = dev.n_servers / N;
   const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-  auto family = [](const SynMsg &m) -> unsigned { return rgb_family(m.kind, m.flags); };
-  if (g < G) synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) { atomicAdd(&cnt[family(m)], 1u); });
+  auto bucket = [](const SynMsg &m) -> unsigned { return rgb_bucket(m.kind, m.flags, m.server, (unsigned)N); };
+  if (g < G) synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) { atomicAdd(&cnt[bucket(m)], 1u); });
   __syncthreads();
   if (!WRITE) {
-    if (threadIdx.x < SYN_FAMILIES && cnt[threadIdx.x]) atomicAdd(&fam_total[threadIdx.x], cnt[threadIdx.x]);
+    for (u32 b = threadIdx.x; b < RGB_N_BUCKETS; b += blockDim.x)
+      if (cnt[b]) atomicAdd(&bkt_total[b], cnt[b]);
     return;
   }
-  if (threadIdx.x < SYN_FAMILIES) {
-    /* family base = exclusive scan of the totals; block reservation inside the family */
-    u32 b = 0;
-    for (unsigned f = 0; f < threadIdx.x; ++f) b += fam_total[f];
-    u32 mine = cnt[threadIdx.x];
-    base[threadIdx.x] = b + (mine ? atomicAdd(&fam_fill[threadIdx.x], mine) : 0u);
+  for (u32 b = threadIdx.x; b < RGB_N_BUCKETS; b += blockDim.x) {
+    const u32 mine = cnt[b];
+    base[b] = bkt_base[b] + (mine ? atomicAdd(&bkt_fill[b], mine) : 0u);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  __syncthreads();
+  if (g < G)
+    synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) {
+      const unsigned b = bucket(m);
+      const u32 slot = base[b] + atomicAdd(&rank[b], 1u);
+      syn_store(out + slot, m);
+    });
+}
+
+/* between the passes (one block of RGB_N_BUCKETS threads): bucket bases = exclusive scan of the totals */
+__global__ void rgb_synth_scan_kernel(u32 *__restrict__ scratch, u32 *__restrict__ kind_counts, u32 *__restrict__ d_n,
+                                      u32 *__restrict__ bucket_counts) {
+  __shared__ u32 tot[RGB_N_BUCKETS];
+  u32 *fam_total = scratch, *bkt_total = scratch + RGB_N_FAMILIES, *bkt_base = bkt_total + 2 * RGB_N_BUCKETS;
+  const u32 b = threadIdx.x;
+  tot[b] = bkt_total[b];
+  if (bucket_counts != nullptr) bucket_counts[b] = tot[b];
+  __syncthreads();
+  u32 acc = 0;
+  for (u32 k = 0; k < b; ++k) acc += tot[k];
+  bkt_base[b] = acc;
+  if (b < RGB_N_FAMILIES) {      /* family b = (class b / 2, flag b & 1) */
+    u32 f = 0;
+    for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) f += tot[((b >> 1) * RGB_TRAIN_SHARDS + x) * 2u + (b & 1u)];
+    fam_total[b] = f;
+  }
+  if (b == 0) {
     u32 total = 0;
     const unsigned kind_of_rank[RGB_N_CLASSES + 1] = {
         RGB_MSG_AER, RGB_MSG_AER_REPLY, RGB_MSG_WRITTEN, RGB_MSG_APPEND, RGB_MSG_PIPELINE_RPCS,
         RGB_MSG_REQUEST_VOTE, RGB_MSG_VOTE_RESULT, RGB_MSG_AWAIT_TIMEOUT, RGB_MSG_ELECTION_TIMEOUT,
         RGB_MSG_PRE_VOTE_RPC, RGB_MSG_PRE_VOTE_RESULT, RGB_MSG_SNAPSHOT_WRITTEN, RGB_MSG_HEARTBEAT_RPC,
         RGB_MSG_HEARTBEAT_REPLY, RGB_MSG_CONSISTENT_QUERY, RGB_MSG_NOP};
-    for (unsigned f = 0; f < SYN_FAMILIES; ++f) {
-      total += fam_total[f];
-      if (kind_counts != nullptr && fam_total[f]) kind_counts[kind_of_rank[f >> 1]] += fam_total[f];
+    for (unsigned c = 0; c <= RGB_N_CLASSES; ++c) {
+      u32 ct = 0;
+      for (u32 k = 0; k < 2u * RGB_TRAIN_SHARDS; ++k) ct += tot[c * 2u * RGB_TRAIN_SHARDS + k];
+      total += ct;
+      if (kind_counts != nullptr && ct) kind_counts[kind_of_rank[c]] += ct;
     }
     if (d_n != nullptr) *d_n = total;
   }
-  __syncthreads();
-  if (g < G)
-    synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) {
-      const unsigned f = family(m);
-      const u32 slot = base[f] + atomicAdd(&rank[f], 1u);
-      syn_store(out + slot, m);
-    });
 }
 
 /* ------------------------------------------------------------- support kernels -- */
@@ -2945,25 +3211,83 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
 }
 
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
-                     u32 *d_kind_counts, u32 *d_n, void *stream) {
+                     u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   const u32 G = dev.n_servers / dev.n_members;
   dim3 grid((G + 63) / 64), block(64);
-  u32 *fam_total = d_scratch, *fam_fill = d_scratch + SYN_FAMILIES;
-  hipError_t e = hipMemsetAsync(d_scratch, 0, 2 * SYN_FAMILIES * sizeof(u32), st);
+  hipError_t e = hipMemsetAsync(d_scratch, 0, RGB_SYNTH_SCRATCH_WORDS * sizeof(u32), st);
   if (e != hipSuccess) return (int)e;
 #define LAUNCH(NN)                                                                                     \
   case NN:                                                                                             \
-    hipLaunchKernelGGL((rgb_synth_kernel<NN, false>), grid, block, 0, st, dev, seed, tick, d_msgs,      \
-                       fam_total, fam_fill, d_kind_counts, d_n);                                       \
-    hipLaunchKernelGGL((rgb_synth_kernel<NN, true>), grid, block, 0, st, dev, seed, tick, d_msgs,       \
-                       fam_total, fam_fill, d_kind_counts, d_n);                                       \
+    hipLaunchKernelGGL((rgb_synth_kernel<NN, false>), grid, block, 0, st, dev, seed, tick, d_msgs, d_scratch); \
+    hipLaunchKernelGGL(rgb_synth_scan_kernel, dim3(1), dim3(RGB_N_BUCKETS), 0, st, d_scratch, d_kind_counts, d_n, \
+                       d_bucket_counts);                                                               \
+    hipLaunchKernelGGL((rgb_synth_kernel<NN, true>), grid, block, 0, st, dev, seed, tick, d_msgs, d_scratch); \
     break;
   switch (dev.n_members) {
     RGB_LAUNCH_ALL_N
     default: return -1;
   }
 #undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+/* the plan of one train tick from its bucket counts: class positions heaviest-first (rgb_class_at), rows of
+ * RGB_TRAIN_SHARDS blocks, a class takes as many rows as its fullest shard has slices */
+u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out) {
+  u32 off[RGB_N_CLASSES + 1][RGB_TRAIN_SHARDS], cnt[RGB_N_CLASSES + 1][RGB_TRAIN_SHARDS];
+  u32 acc = 0;
+  for (unsigned c = 0; c <= RGB_N_CLASSES; ++c)
+    for (unsigned x = 0; x < RGB_TRAIN_SHARDS; ++x) {
+      const u32 n = bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u] + bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u + 1u];
+      off[c][x] = acc; cnt[c][x] = n; acc += n;
+    }
+  u32 rows = 0;
+  for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {
+    const int c = rgb_class_at(q);
+    const u32 sl = rgb_class_slice(c, n_members);
+    u32 need = 0;
+    for (unsigned x = 0; x < RGB_TRAIN_SHARDS; ++x) {
+      out->off[q][x] = off[c][x]; out->cnt[q][x] = cnt[c][x];
+      const u32 r = (cnt[c][x] + sl - 1) / sl;
+      if (r > need) need = r;
+    }
+    rows += need;
+    out->row_end[q] = rows;
+  }
+  out->row_end[15] = rows;
+  return rows;
+}
+
+int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, u32 tick_stride, const rgb_train_tick *d_plan,
+                     u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base,
+                     u32 *d_ctl, void *stream) {
+  if (n_ticks == 0 || bpt == 0) return 0;
+  if (bpt % RGB_TRAIN_SHARDS) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  /* the placement map is per launch (the L2s are written back and invalidated between launches); the error word
+   * is sticky until rgb_train_status reads it */
+  hipError_t e = hipMemsetAsync(d_ctl + 1, 0, RGB_TRAIN_SHARDS * sizeof(u32), st);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(n_ticks * bpt), block(RGB_TICK_BLOCK);
+#define LAUNCH(NN)                                                                                      \
+  case NN:                                                                                              \
+    hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, dev, d_msgs, tick_stride, d_plan, bpt, \
+                       d_dec, d_rpcs, rpc_ring ? rpc_ring : 1u, index_base, d_ctl);                     \
+    break;
+  switch (dev.n_members) {
+    RGB_LAUNCH_ALL_N
+    default: return -1;
+  }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_train_seq(const rgb_dev &dev, rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt, bool init, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (init)
+    hipLaunchKernelGGL(rgb_train_seq_init_kernel, dim3((dev.n_servers + 255) / 256), dim3(256), 0, st, dev, d_seq_cnt);
+  if (n) hipLaunchKernelGGL(rgb_train_seq_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dev, d_msgs, n, d_seq_cnt);
   return (int)hipGetLastError();
 }
 

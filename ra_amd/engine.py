@@ -23,8 +23,10 @@ EXPORTS = [
     "rgb_download_state", "rgb_submit", "rgb_collect", "rgb_run_ticks_device", "rgb_snapshot",
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize", "rgb_wait", "rgb_wake", "rgb_in_flight",
     "rgb_route",
+    "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
+    "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status",
 ]
-SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_apply_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
+SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_tick_buckets_device", "rgb_synth_apply_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -101,6 +103,17 @@ def lib():
     L.rgb_route.argtypes = [C.c_uint64, u32]
     L.rgb_route.restype = C.c_uint32
     L.rgb_synth_tick_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
+    L.rgb_synth_tick_buckets_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]
+    L.rgb_train_bucket.restype = C.c_uint32
+    L.rgb_train_bucket.argtypes = [u32, u32, u32, u32]
+    L.rgb_train_plan_create.argtypes = [vp, vp, u32, C.POINTER(vp)]
+    L.rgb_train_plan_destroy.argtypes = [vp]
+    L.rgb_train_plan_destroy.restype = None
+    L.rgb_train_plan_blocks_per_tick.restype = C.c_uint32
+    L.rgb_train_plan_blocks_per_tick.argtypes = [vp]
+    L.rgb_train_stamp_device.argtypes = [vp, vp, u32, vp, u32, vp]
+    L.rgb_train_run_device.argtypes = [vp, vp, u32, u32, vp, u32, vp, vp, u32, vp]
+    L.rgb_train_status.argtypes = [vp, C.POINTER(u32), vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     L.rgb_wal_adler32_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, vp]
     L.rgb_wal_adler32.argtypes = [vp, vp, u32, vp, C.c_uint64, vp]
@@ -275,6 +288,35 @@ class RaGpuBatch:
         self._check(self._L.rgb_synth_tick_device(self._h, seed, tick, d_msgs, d_kind_counts or None,
                                                   d_n or None, stream or None), "rgb_synth_tick_device")
 
+    def synth_tick_buckets_device(self, seed: int, tick: int, d_msgs: int, d_kind_counts: int = 0, d_n: int = 0,
+                                  d_bucket_counts: int = 0, stream: int = 0):
+        """The load generator, also writing uint32[TRAIN_BUCKETS] message counts per train bucket."""
+        self._check(self._L.rgb_synth_tick_buckets_device(self._h, seed & (2**64 - 1), tick, d_msgs, d_kind_counts,
+                                                         d_n, d_bucket_counts, stream), "rgb_synth_tick_buckets_device")
+
+    # ---- train launches: several device-resident ticks in one launch ----
+    def train_plan(self, bucket_counts: np.ndarray) -> "TrainPlan":
+        return TrainPlan(self, bucket_counts)
+
+    def train_stamp_device(self, d_msgs: int, tick_stride: int, tick_counts: np.ndarray, stream: int = 0):
+        tc = np.ascontiguousarray(tick_counts, dtype=np.uint32)
+        self._check(self._L.rgb_train_stamp_device(self._h, d_msgs, tick_stride, tc.ctypes.data, len(tc), stream),
+                    "rgb_train_stamp_device")
+
+    def train_run_device(self, plan: "TrainPlan", first_tick: int, n_ticks: int, d_msgs: int, tick_stride: int,
+                         d_decisions: int, d_rpcs: int = 0, rpc_ring: int = 1, stream: int = 0):
+        self._check(self._L.rgb_train_run_device(self._h, plan.h, first_tick, n_ticks, d_msgs, tick_stride,
+                                                d_decisions, d_rpcs, rpc_ring, stream), "rgb_train_run_device")
+
+    def train_status(self, check: bool = True):
+        """(error flags, XCD of every shard) of the trains run since the last call; the caller has synchronised."""
+        flags = C.c_uint32(0)
+        xcc = np.zeros(8, dtype=np.uint32)
+        rc = self._L.rgb_train_status(self._h, C.byref(flags), xcc.ctypes.data)
+        if check and rc:
+            raise RgbError(rc, f"train launch failed (flags={flags.value}: 1 = placement, 2 = spin bound)")
+        return int(flags.value), xcc
+
     def synth_apply_tick_device(self, d_msgs: int, max_msgs: int, d_decisions: int, d_rpcs: int = 0,
                                 stream: int = 0):
         """Apply the tick just generated by synth_tick_device (class-dispatch kernel sized on-device)."""
@@ -344,6 +386,39 @@ class RaGpuBatch:
 
     def synchronize(self):
         self._check(self._L.rgb_synchronize(self._h), "rgb_synchronize")
+
+
+TRAIN_BUCKETS = 256
+
+
+class TrainPlan:
+    """Device plan of a train (rgb_train_plan): bucket_counts = uint32[n_ticks][TRAIN_BUCKETS]."""
+
+    def __init__(self, eng: "RaGpuBatch", bucket_counts: np.ndarray):
+        bc = np.ascontiguousarray(bucket_counts, dtype=np.uint32).reshape(-1, TRAIN_BUCKETS)
+        self.eng, self.n_ticks = eng, len(bc)
+        h = C.c_void_p()
+        eng._check(eng._L.rgb_train_plan_create(eng._h, bc.ctypes.data, len(bc), C.byref(h)), "rgb_train_plan_create")
+        self.h = h
+        self.blocks_per_tick = int(eng._L.rgb_train_plan_blocks_per_tick(h))
+
+    def close(self):
+        if self.h:
+            self.eng._L.rgb_train_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def train_bucket(kind, flags, server, n_members):
+    """rgb_train_bucket over numpy arrays: (class rank of the kind, group mod 8, success flag)."""
+    rank = np.array([15, 0, 1, 5, 6, 2, 4, 3, 7, 8, 9, 10, 11, 12, 13, 14], dtype=np.uint32)[np.asarray(kind) & 15]
+    shard = (np.asarray(server, dtype=np.uint32) // n_members) & 7
+    return (rank * 8 + shard) * 2 + (np.asarray(flags, dtype=np.uint32) & 1)
 
 
 def wal_layout(records: np.ndarray, base: int = 0) -> int:

@@ -46,6 +46,8 @@ static inline unsigned long long wall_clock64() {
   return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
 }
 template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from ra_amd import abi
+from ra_amd import abi, engine
 import fuzz
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -186,7 +186,8 @@ def _bind_launchers(L):
     L.emu_launch_unpack.argtypes = [vp, u32, u32, vp]
     L.emu_launch_checksum.argtypes = [vp, u32, u32, vp]
     L.emu_launch_leaderboard.argtypes = [vp, vp]
-    L.emu_launch_synth.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
+    L.emu_launch_synth.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]
+    L.emu_synth_scratch_words.restype = u32
     return L
 
 
@@ -279,17 +280,23 @@ def test_load_generator_and_device_sized_dispatch(emu_lib, oracle_lib, n_members
     seen = 0
     for t in range(ticks):
         msgs = np.zeros(S, dtype=abi.MSG_DTYPE)
-        scratch = np.zeros(64, dtype=np.uint32)
+        scratch = np.zeros(emu.L.emu_synth_scratch_words(), dtype=np.uint32)
         kc = np.zeros(abi.N_KINDS, dtype=np.uint32)
         n = np.zeros(1, dtype=np.uint32)
+        bc = np.zeros(engine.TRAIN_BUCKETS, dtype=np.uint32)
         assert emu.L.emu_launch_synth(emu.h, seed, t, msgs.ctypes.data, scratch.ctypes.data, kc.ctypes.data,
-                                      n.ctypes.data) == 0
+                                      n.ctypes.data, bc.ctypes.data) == 0
         nt = int(n[0])
         m = msgs[:nt]
         assert nt > G and not np.any(m["kind"] == abi.MSG_NOP)
         assert len(np.unique(m["server"])) == nt
         assert np.array_equal(np.bincount(m["kind"], minlength=abi.N_KINDS), kc)
-        assert np.all(np.diff(abi.family(m)) >= 0), "tick is not ordered by clause family"
+        # bucket order = (class of the kind, group mod 8, success flag): every class is contiguous (what the class
+        # kernel needs) and so is every (class, shard) pair (what a train launch needs)
+        bk = engine.train_bucket(m["kind"], m["flags"], m["server"], N)
+        assert np.all(np.diff(bk.astype(np.int64)) >= 0), "tick is not in bucket order"
+        assert np.array_equal(np.bincount(bk, minlength=engine.TRAIN_BUCKETS), bc)
+        assert np.all(np.diff(abi.family(m) // 2) >= 0), "classes are not contiguous"
         dec = np.zeros(S, dtype=abi.DECISION_DTYPE)
         assert emu.L.emu_launch_classes_dev(emu.h, msgs.ctypes.data, scratch.ctypes.data, S, dec.ctypes.data) == 0
         want, _ = cpu.step(m)

@@ -1,0 +1,198 @@
+"""Train launches (rgb_train_*, include/ra_gpu_batch.h): several device-resident ticks in ONE launch, ordered per
+server by sequence stamps instead of kernel boundaries.  The claim under test: a train computes exactly what
+rgb_run_ticks_device / the per-tick class kernel compute on the same ticks -- every decision, every rpc record, the
+final state -- and what the oracle computes.
+
+The same test bodies run on the GPU (`-m gpu`, real library, torch device buffers) and on the CPU block emulation
+(tests/native: blocks run one after another in grid order, so every dependency is met on the first poll -- it checks
+the plan, the bucket order, the stamps and the commit protocol's arithmetic, not the races)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ra_amd import abi
+from ra_amd import workload as W
+
+
+class Buf:
+    """`nbytes` of memory the library can use as DEVICE memory: a CUDA tensor on the GPU, numpy on the emulation."""
+
+    def __init__(self, nbytes, on_gpu):
+        self.on_gpu = on_gpu
+        if on_gpu:
+            import torch
+            self.t = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+            self.ptr = self.t.data_ptr()
+        else:
+            self.a = np.zeros(max(nbytes, 16), dtype=np.uint8)
+            self.ptr = self.a.ctypes.data
+
+    def host(self):
+        return self.t.cpu().numpy() if self.on_gpu else self.a
+
+    def sync(self):
+        if self.on_gpu:
+            import torch
+            torch.cuda.synchronize()
+
+
+def _generate(engine, G, N, T, seed, on_gpu, max_runs=16, age=0):
+    """T generator ticks applied one by one with the per-tick class kernel.  Returns everything a train needs."""
+    S = G * N
+    eng = engine.RaGpuBatch(G, N, max_runs=max_runs, ring_slots=1, ring_capacity=64)
+    st0 = W.initial_states(G, N, seed)
+    eng.set_state(0, st0)
+    tb = S * 64
+    msgs, dec = Buf(T * tb, on_gpu), Buf(T * tb, on_gpu)
+    rpcs = Buf(T * S * max(N - 1, 1) * 56, on_gpu)
+    kc, dn = Buf(T * abi.N_KINDS * 4, on_gpu), Buf(T * 4, on_gpu)
+    bc = Buf(T * engine.TRAIN_BUCKETS * 4, on_gpu)
+    scratch_m, scratch_d = Buf(tb, on_gpu), Buf(tb, on_gpu)
+    for t in range(age):                                    # untimed ageing: ticks applied and not kept
+        eng.synth_tick_buckets_device(seed, t, scratch_m.ptr, 0, 0, 0)
+        eng.synth_apply_tick_device(scratch_m.ptr, S, scratch_d.ptr, rpcs.ptr)
+    eng.synchronize()
+    st_start = eng.get_state()
+    rs = S * max(N - 1, 1) * 56
+    for t in range(T):
+        eng.synth_tick_buckets_device(seed, age + t, msgs.ptr + t * tb, kc.ptr + t * abi.N_KINDS * 4, dn.ptr + t * 4,
+                                      bc.ptr + t * engine.TRAIN_BUCKETS * 4)
+        eng.synth_apply_tick_device(msgs.ptr + t * tb, S, dec.ptr + t * tb, rpcs.ptr + t * rs)
+    eng.synchronize()
+    counts = dn.host().view(np.uint32)[:T].copy()
+    buckets = bc.host().view(np.uint32)[:T * engine.TRAIN_BUCKETS].reshape(T, engine.TRAIN_BUCKETS).copy()
+    assert np.array_equal(buckets.sum(axis=1), counts)
+    return dict(eng=eng, S=S, tb=tb, rs=rs, msgs=msgs, dec=dec, rpcs=rpcs, counts=counts, buckets=buckets,
+                st_start=st_start, st_end=eng.get_state(), sum_end=eng.state_checksum())
+
+
+def _tick(buf, t, tb, n, dtype):
+    return buf.host()[t * tb:t * tb + n * 64].view(dtype).copy()
+
+
+def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_gpu, chunks=(None,), age=0):
+    r = _generate(engine, G, N, T, seed, on_gpu, age=age)
+    eng, S, tb, rs = r["eng"], r["S"], r["tb"], r["rs"]
+    want_dec = [_tick(r["dec"], t, tb, int(r["counts"][t]), abi.DECISION_DTYPE) for t in range(T)]
+    want_rpc = r["rpcs"].host()[:T * rs].copy()
+    plain = [_tick(r["msgs"], t, tb, int(r["counts"][t]), abi.MSG_DTYPE) for t in range(T)]
+    for t in range(T):      # the ticks are in bucket order, which keeps every class (and every (class, shard)) contiguous
+        bk = engine.train_bucket(plain[t]["kind"], plain[t]["flags"], plain[t]["server"], N)
+        assert np.all(np.diff(bk.astype(np.int64)) >= 0)
+        assert np.array_equal(np.bincount(bk, minlength=engine.TRAIN_BUCKETS), r["buckets"][t])
+    # the oracle on the same stream (the kind nibble is still clear: stamping comes next)
+    if oracle_lib is not None:
+        cpu = oracle_lib.Oracle(G, N, max_runs=16)
+        cpu.set_state(0, r["st_start"])
+        for t in range(T):
+            want, _ = cpu.step_parallel(plain[t]) if hasattr(cpu, "step_parallel") else cpu.step(plain[t])
+            assert want.tobytes() == want_dec[t].tobytes(), f"per-tick kernel differs from the oracle at tick {t}"
+        assert cpu.get_state().tobytes() == r["st_end"].tobytes()
+        cpu.close()
+    plan = eng.train_plan(r["buckets"])
+    assert plan.blocks_per_tick % 8 == 0 and plan.blocks_per_tick > 0
+    for chunk in chunks:
+        # back to the start state; the train runs in `chunk`-tick launches (None = one launch for all T ticks)
+        eng.set_state(0, r["st_start"])
+        dec2, rpc2 = Buf(T * tb, on_gpu), Buf(T * rs, on_gpu)
+        step = chunk or T
+        t = 0
+        while t < T:
+            n = min(step, T - t)
+            # stamps of this launch's ticks start from what the rows hold now (upload reset them to 0; earlier
+            # launches advanced them)
+            eng.train_stamp_device(r["msgs"].ptr + t * tb, S, r["counts"][t:t + n])
+            eng.train_run_device(plan, t, n, r["msgs"].ptr, S, dec2.ptr, rpc2.ptr + t * rs, rpc_ring=n)
+            t += n
+        eng.synchronize()
+        flags, xcc = eng.train_status()
+        assert flags == 0
+        stamped = [_tick(r["msgs"], t, tb, int(r["counts"][t]), abi.MSG_DTYPE) for t in range(T)]
+        for t in range(T):
+            got = _tick(dec2, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE)
+            if got.tobytes() != want_dec[t].tobytes():
+                bad = int(np.flatnonzero((got.view(np.uint8).reshape(-1, 64) !=
+                                          want_dec[t].view(np.uint8).reshape(-1, 64)).any(axis=1))[0])
+                raise AssertionError(f"chunk {chunk}: tick {t} slot {bad}: msg={stamped[t][bad]}\n train={got[bad]}\n "
+                                     f"per-tick={want_dec[t][bad]}")
+            # the stamp of a message = number of earlier messages of its server since the upload, mod 16
+            assert np.array_equal(stamped[t]["kind"] & 15, plain[t]["kind"])
+        seen = np.zeros(S, dtype=np.int64)
+        for t in range(T):
+            assert np.array_equal(stamped[t]["kind"] >> 4, seen[stamped[t]["server"]] & 15), f"stamps of tick {t}"
+            seen[stamped[t]["server"]] += 1
+        # rpc records: message i of tick t owns slots [i (N-1), (i+1)(N-1)), the first n_rpcs are valid
+        per = max(N - 1, 1)
+        for t in range(T):
+            n_r = want_dec[t]["n_rpcs"].astype(np.int64)
+            a = want_rpc[t * rs:(t + 1) * rs].view(abi.RPC_DTYPE)
+            b = rpc2.host()[t * rs:(t + 1) * rs].view(abi.RPC_DTYPE)
+            for i in np.flatnonzero(n_r):
+                k = int(n_r[i])
+                x, y = a[i * per:i * per + k].copy(), b[i * per:i * per + k].copy()
+                # msg_index is the global index: the per-tick apply numbered from 0, the train from t * stride
+                assert np.array_equal(y["msg_index"].astype(np.int64), x["msg_index"].astype(np.int64) + t * S)
+                x["msg_index"] = 0; y["msg_index"] = 0
+                assert x.tobytes() == y.tobytes(), f"rpc records of tick {t} message {i}"
+        assert eng.get_state().tobytes() == r["st_end"].tobytes(), f"chunk {chunk}: final state differs"
+        assert eng.state_checksum() == r["sum_end"]
+        # restore the stream for the next chunking: clear the stamps
+        for t in range(T):
+            m = r["msgs"].host()
+            if not on_gpu:
+                v = m[t * tb:t * tb + int(r["counts"][t]) * 64].view(abi.MSG_DTYPE)
+                v["kind"] &= 15
+        if on_gpu and chunk is not chunks[-1]:
+            import torch
+            h = r["msgs"].t.cpu().numpy()
+            for t in range(T):
+                v = h[t * tb:t * tb + int(r["counts"][t]) * 64].view(abi.MSG_DTYPE)
+                v["kind"] &= 15
+            r["msgs"].t.copy_(torch.from_numpy(h))
+    plan.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("G,N,T,seed", [(192, 5, 20, 0x5EED0003), (96, 3, 12, 7), (64, 7, 10, 11)])
+def test_train_on_the_block_emulation(emulated_engine, oracle_lib, G, N, T, seed):
+    check_train_equals_per_tick_launches(emulated_engine, oracle_lib, G, N, T, seed, False, chunks=(None, 3))
+
+
+def test_train_with_a_wrong_stamp_fails_in_bounded_time(emulated_engine):
+    """A message whose stamp never comes up: the wavefront gives up (RGB_TRAIN_ERR_SPIN), the launch ends, the host
+    sees the error -- never a hang."""
+    engine = emulated_engine
+    r = _generate(engine, 64, 5, 3, 5, False)
+    eng, S = r["eng"], r["S"]
+    eng.set_state(0, r["st_start"])
+    plan = eng.train_plan(r["buckets"])
+    eng.train_stamp_device(r["msgs"].ptr, S, r["counts"])
+    m = r["msgs"].host()[:int(r["counts"][0]) * 64].view(abi.MSG_DTYPE)
+    m["kind"][0] = (m["kind"][0] & 15) | (5 << 4)          # tick 0 expects stamp 0
+    dec2 = Buf(3 * r["tb"], False)
+    eng.train_run_device(plan, 0, 3, r["msgs"].ptr, S, dec2.ptr)
+    eng.synchronize()
+    flags, _ = eng.train_status(check=False)
+    assert flags & 2
+    assert eng.train_status(check=False)[0] == 0          # reading the status clears it
+    eng.close()
+
+
+def test_train_bucket_matches_the_c_function(emulated_engine):
+    engine = emulated_engine
+    L = engine.lib()
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        kind, flags, n = int(rng.integers(0, 16)), int(rng.integers(0, 32)), int(rng.integers(1, 9))
+        server = int(rng.integers(0, 1 << 20))
+        assert L.rgb_train_bucket(kind, flags, server, n) == int(engine.train_bucket(kind, flags, server, n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,N,T,seed,age", [(2048, 5, 24, 0x5EED0003, 0), (1024, 3, 16, 7, 0), (1024, 7, 12, 11, 0),
+                                            (16384, 5, 48, 0x5EED0003, 64)])
+def test_train_on_the_gpu(oracle_lib, G, N, T, seed, age):
+    """Real races: thousands of wavefronts of neighbouring ticks in flight together, every decision compared."""
+    from ra_amd import engine
+    check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, True, chunks=(None, 16, 5), age=age)
