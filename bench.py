@@ -287,18 +287,19 @@ def main():
 
     # ---- train mode: the plan of every tick (host) and the sequence stamps of the whole stream, counted from
     # the aged state (device, untimed: the order rgb_submit's bucketing would establish on the host path) ----
-    plan = d_dec2 = None
+    plan = d_dec2 = d_stamps = None
     if use_train:
         buckets = d_bc.cpu().numpy().reshape(T, engine.TRAIN_BUCKETS).astype(np.uint32)
         assert np.array_equal(buckets.sum(axis=1), counts)
         plan = eng.train_plan(buckets)
         d_dec2 = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)   # pass 1's decisions stay for comparison
+        d_stamps = torch.zeros(T * S, dtype=torch.uint8, device=dev)          # sequence stamp of every message
 
     def launch_ticks(t, nxt):
         """ticks [t, nxt) on the stream: ONE train launch, or one class-kernel launch per tick"""
         if use_train:
-            eng.train_run_device(plan, t, nxt - t, d_msgs.data_ptr(), S, d_dec2.data_ptr(), d_rpcs.data_ptr(),
-                                 RPC_RING, sptr)
+            eng.train_run_device(plan, t, nxt - t, d_msgs.data_ptr(), d_stamps.data_ptr(), S, d_dec2.data_ptr(),
+                                 d_rpcs.data_ptr(), RPC_RING, sptr)
         else:
             eng.run_ticks_device(d_msgs.data_ptr() + t * tick_bytes, S, nxt - t,
                                  d_dec.data_ptr() + t * tick_bytes, d_rpcs.data_ptr(), sptr,
@@ -320,7 +321,7 @@ def main():
     # ---- pass 2: back to the aged state, warm up, time exactly K ticks ----
     eng.set_state(0, st_aged)
     if use_train:
-        eng.train_stamp_device(d_msgs.data_ptr(), S, counts, sptr)
+        eng.train_stamp_device(d_msgs.data_ptr(), d_stamps.data_ptr(), S, counts, sptr)
     run(0, Wm)
     torch.cuda.synchronize()
 

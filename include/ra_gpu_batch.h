@@ -120,8 +120,7 @@ enum {
  */
 typedef struct rgb_msg {
   uint32_t server;      /* target server id = group * n_members + member slot */
-  uint8_t  kind;        /* RGB_MSG_* (low nibble); high nibble: 0, or the train sequence stamp on device-resident
-                           train ticks (rgb_train_stamp_device) */
+  uint8_t  kind;        /* RGB_MSG_*                                          */
   uint8_t  from;        /* sender member slot or RGB_NONE                     */
   uint8_t  flags;       /* RGB_MF_*                                           */
   uint8_t  gap;         /* AER: first entry index = a + 1 + gap (0 normally)  */
@@ -412,8 +411,8 @@ int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride
 /* ---- Train launches: several device-resident ticks in ONE launch ----
  * rgb_run_ticks_device pays a kernel boundary per tick (launch gap, dispatch ramp, the write-back of every dirty
  * L2 line) and all wavefronts of a tick move through their memory and compute phases in lock step.  A TRAIN runs
- * n_ticks consecutive ticks in one launch: what orders two messages of one server is not the kernel boundary but a
- * 4-bit sequence stamp in the server's device row, which a message waits for and its commit advances; wavefronts of
+ * consecutive ticks in one launch: what orders two messages of one server is not the kernel boundary but a
+ * per-server sequence byte on the device, which a message waits for and its commit advances; wavefronts of
  * neighbouring ticks overlap.  Results are bit-identical to rgb_run_ticks_device on the same ticks.
  *
  * Requirements on the ticks: at most one message per server per tick; every tick ordered by BUCKET =
@@ -421,34 +420,38 @@ int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride
  * tick in that order is also in the clause-family order rgb_run_ticks_device wants.  rgb_synth_tick_buckets_device
  * (ra_gpu_batch_synth.h) writes ticks in this order and their per-bucket counts.
  *
- *   rgb_train_plan_create   bucket_counts = uint32[n_ticks][RGB_TRAIN_BUCKETS] (host): builds and uploads the plan
- *   rgb_train_stamp_device  writes the sequence stamps into the HIGH NIBBLE of every message's kind byte, tick by
- *                           tick (tick_counts[t] messages in tick t), starting from the stamps the device rows hold
- *                           NOW: call it once per train, after the previous train has run (same stream order)
- *                           and before rgb_train_run_device.  Every other entry point ignores that nibble on device-
- *                           resident messages; rgb_submit rejects it (kind > RGB_MSG_KIND_MAX).
- *   rgb_train_run_device    ticks [first_tick, first_tick + n_ticks) of the plan; d_msgs / d_decisions point at tick 0
- *                           of the plan; d_rpcs (may be NULL) holds rpc_ring regions of tick_stride * (n_members-1)
- *                           records, tick k of the launch uses region k mod rpc_ring (ticks of one launch overlap:
- *                           a region must not be reused within the overlap depth -- 4 is plenty)
+ *   rgb_train_plan_create   bucket_counts = uint32[n_ticks][RGB_TRAIN_BUCKETS] (host): builds and uploads the plan.
+ *                           The first call of a context also checks, once, that the device places the blocks of one
+ *                           shard on one XCD (the L2s of different XCDs are not coherent): RGB_E_UNSUPPORTED if not
+ *   rgb_train_stamp_device  d_stamps = uint8[n_ticks * tick_stride], laid out like d_msgs: the sequence value every
+ *                           message must find at its server, counted tick by tick (tick_counts[t] messages in tick
+ *                           t) from what the servers hold at this point of the stream.  Call it after the trains
+ *                           enqueued before (same stream) and before the ones that use the stamps; the messages
+ *                           themselves are not touched.
+ *   rgb_train_run_device    ticks [first_tick, first_tick + n_ticks) of the plan; d_msgs / d_stamps / d_decisions
+ *                           point at tick 0 of the plan; d_rpcs (may be NULL) holds rpc_ring regions of tick_stride *
+ *                           (n_members-1) records, tick k of a launch uses region k mod rpc_ring (ticks of one launch
+ *                           overlap: a region must not be reused within the overlap depth -- 4 is plenty).  More
+ *                           than 255 ticks are split into several launches.
  *   rgb_train_status        after the caller synchronised the stream it used: 0 / RGB_E_STATE with the error flags
- *                           (RGB_TRAIN_ERR_*) and, optionally, the XCD each shard ran on.  An error means the launch
- *                           did not compute the ticks (some decisions are unwritten): the caller restores the state
+ *                           (RGB_TRAIN_ERR_*) and, optionally, the XCD every shard runs on.  An error means the launch
+ *                           did not compute its ticks (some decisions are unwritten): the caller restores the state
  *                           (rgb_upload_state) and falls back to rgb_run_ticks_device.
- * Stamped servers must only be advanced by trains until the next rgb_upload_state (which resets the stamp). */
+ * The per-tick entry points never touch the sequence bytes, so trains and per-tick launches can alternate freely
+ * (re-stamp after every change of the sequence, i.e. after every train). */
 #define RGB_TRAIN_BUCKETS 256u
-#define RGB_TRAIN_ERR_PLACEMENT 1u   /* blocks of one shard ran on different XCDs (the L2s are not coherent)   */
+#define RGB_TRAIN_ERR_PLACEMENT 1u   /* a block ran on another XCD than its shard's (the L2s are not coherent)  */
 #define RGB_TRAIN_ERR_SPIN      2u   /* a wavefront's dependencies did not commit within the spin bound        */
 typedef struct rgb_train_plan rgb_train_plan;
 uint32_t rgb_train_bucket(uint32_t kind, uint32_t flags, uint32_t server, uint32_t n_members);
 int  rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t n_ticks, rgb_train_plan **out);
 void rgb_train_plan_destroy(rgb_train_plan *plan);
 uint32_t rgb_train_plan_blocks_per_tick(const rgb_train_plan *plan);
-int  rgb_train_stamp_device(rgb_ctx *ctx, void *d_msgs, uint32_t tick_stride, const uint32_t *tick_counts,
-                            uint32_t n_ticks, void *stream);
+int  rgb_train_stamp_device(rgb_ctx *ctx, const void *d_msgs, void *d_stamps, uint32_t tick_stride,
+                            const uint32_t *tick_counts, uint32_t n_ticks, void *stream);
 int  rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
-                          const void *d_msgs, uint32_t tick_stride, void *d_decisions, void *d_rpcs,
-                          uint32_t rpc_ring, void *stream);
+                          const void *d_msgs, const void *d_stamps, uint32_t tick_stride, void *d_decisions,
+                          void *d_rpcs, uint32_t rpc_ring, void *stream);
 int  rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard /* [8] or NULL */);
 
 /* leaderboard / metrics snapshot: one row per group */

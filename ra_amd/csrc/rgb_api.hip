@@ -86,8 +86,10 @@ struct rgb_ctx {
   u64 *d_sums = nullptr;
   u32 *d_synth = nullptr;     /* load-generator scratch (family and bucket counters) */
   /* train launches */
-  u32 *d_train_ctl = nullptr;           /* RGB_TRAIN_CTL_WORDS: sticky error flags | XCC id + 1 per shard */
-  unsigned char *d_seq_cnt = nullptr;   /* per-server stamp counters of rgb_train_stamp_device */
+  u32 *d_train_ctl = nullptr;           /* RGB_TRAIN_CTL_WORDS: sticky error flags | calibration scratch */
+  unsigned char *d_seq_cnt = nullptr;   /* running stamp counters of rgb_train_stamp_device (a copy of dev.seq) */
+  u32 xcc_map = 0;                      /* 4 bits per shard: the XCC id blocks b mod 8 = shard run on */
+  int xcc_state = 0;                    /* 0 = not calibrated, 1 = usable, -1 = placement is not one XCD per shard */
 };
 
 /* the device plan of a train: one rgb_train_tick per tick */
@@ -176,6 +178,7 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->dev.runs) (void)hipFree(ctx->dev.runs);
   if (ctx->dev.cond) (void)hipFree(ctx->dev.cond);
   if (ctx->dev.qry) (void)hipFree(ctx->dev.qry);
+  if (ctx->dev.seq) (void)hipFree(ctx->dev.seq);
   if (ctx->d_stage) (void)hipFree(ctx->d_stage);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
@@ -264,6 +267,9 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   HIPCHK(ctx, hipMalloc((void **)&d.cond, (size_t)S * 4 * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.qry, (size_t)S * RGB_QRY_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMemsetAsync(d.runs, 0, (size_t)S * d.max_runs * 2 * sizeof(u64), ctx->stream));
+  d.seq_stride = (((n_groups + RGB_TRAIN_SHARDS - 1u) / RGB_TRAIN_SHARDS) * n_members + 255u) & ~255u;
+  HIPCHK(ctx, hipMalloc((void **)&d.seq, (size_t)d.seq_stride * RGB_TRAIN_SHARDS));
+  HIPCHK(ctx, hipMemsetAsync(d.seq, 0, (size_t)d.seq_stride * RGB_TRAIN_SHARDS, ctx->stream));
   ctx->stage_cap = S < 16384u ? S : 16384u;
   HIPCHK(ctx, hipMalloc((void **)&ctx->d_stage, (size_t)ctx->stage_cap * sizeof(rgb_server_state)));
   HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stage, (size_t)ctx->stage_cap * sizeof(rgb_server_state),
@@ -630,10 +636,41 @@ uint32_t rgb_train_bucket(uint32_t kind, uint32_t flags, uint32_t server, uint32
   return n_members ? rgb_bucket(kind, flags, server, n_members) : 0u;
 }
 
+static int train_scratch(rgb_ctx *ctx) {
+  if (!ctx->d_train_ctl) {
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_train_ctl, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
+    HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
+  }
+  if (!ctx->d_seq_cnt) HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq_cnt, (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS));
+  if (ctx->xcc_state == 0) {
+    /* where do blocks b mod 8 = x run?  A train is only coherent when that is ONE XCD per shard */
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, RGB_TRAIN_SHARDS * sizeof(u32), ctx->stream));
+    for (int rep = 0; rep < 4; ++rep) {
+      int rc = rgb_launch_train_calibrate(ctx->d_train_ctl + 1, ctx->stream);
+      if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
+    }
+    u32 w[RGB_TRAIN_SHARDS];
+    HIPCHK(ctx, hipMemcpyAsync(w, ctx->d_train_ctl + 1, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->xcc_state = 1;
+    ctx->xcc_map = 0;
+    for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) {
+      if (w[x] == 0 || (w[x] & (w[x] - 1u)) != 0 || w[x] > 0x8000u) { ctx->xcc_state = -1; break; }
+      u32 id = 0;
+      while (!((w[x] >> id) & 1u)) ++id;
+      ctx->xcc_map |= id << (4u * x);
+    }
+  }
+  return ctx->xcc_state == 1 ? RGB_OK : RGB_E_UNSUPPORTED;
+}
+
 int rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t n_ticks, rgb_train_plan **out) {
   if (!ctx || !out || (!bucket_counts && n_ticks)) return RGB_E_INVAL;
   *out = nullptr;
   if (!ctx->registered) return RGB_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  int rc = train_scratch(ctx);
+  if (rc) return rc;
   rgb_train_plan *p = new (std::nothrow) rgb_train_plan();
   if (!p) return RGB_E_NOMEM;
   std::vector<rgb_train_tick> ticks(n_ticks);
@@ -667,62 +704,62 @@ void rgb_train_plan_destroy(rgb_train_plan *plan) {
 
 uint32_t rgb_train_plan_blocks_per_tick(const rgb_train_plan *plan) { return plan ? plan->bpt : 0; }
 
-static int train_scratch(rgb_ctx *ctx) {
-  if (!ctx->d_train_ctl) {
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_train_ctl, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
-    HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
-  }
-  if (!ctx->d_seq_cnt) HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq_cnt, ctx->dev.n_servers));
-  return RGB_OK;
-}
-
-int rgb_train_stamp_device(rgb_ctx *ctx, void *d_msgs, uint32_t tick_stride, const uint32_t *tick_counts,
-                           uint32_t n_ticks, void *stream) {
-  if (!ctx || !d_msgs || (!tick_counts && n_ticks)) return RGB_E_INVAL;
+int rgb_train_stamp_device(rgb_ctx *ctx, const void *d_msgs, void *d_stamps, uint32_t tick_stride,
+                           const uint32_t *tick_counts, uint32_t n_ticks, void *stream) {
+  if (!ctx || !d_msgs || !d_stamps || (!tick_counts && n_ticks)) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
-  int rc = train_scratch(ctx);
-  if (rc) return rc;
-  void *st = stream ? stream : (void *)ctx->stream;
-  rgb_msg *m = (rgb_msg *)d_msgs;
+  if (!ctx->d_seq_cnt || ctx->xcc_state != 1) return RGB_E_STATE;      /* rgb_train_plan_create comes first */
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const rgb_msg *m = (const rgb_msg *)d_msgs;
+  unsigned char *sp = (unsigned char *)d_stamps;
+  /* the counters start from what the servers hold now (stream order: after every train enqueued before) */
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_seq_cnt, ctx->dev.seq, (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS,
+                             hipMemcpyDeviceToDevice, st));
   for (u32 t = 0; t < n_ticks; ++t) {
     if (tick_counts[t] > tick_stride) return RGB_E_INVAL;
-    rc = rgb_launch_train_seq(ctx->dev, m + (size_t)t * tick_stride, tick_counts[t], ctx->d_seq_cnt, t == 0, st);
+    int rc = rgb_launch_train_seq(ctx->dev, m + (size_t)t * tick_stride, tick_counts[t], ctx->d_seq_cnt,
+                                  sp + (size_t)t * tick_stride, st);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
   return RGB_OK;
 }
 
 int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
-                         const void *d_msgs, uint32_t tick_stride, void *d_decisions, void *d_rpcs,
-                         uint32_t rpc_ring, void *stream) {
-  if (!ctx || !plan || !d_msgs || !d_decisions) return RGB_E_INVAL;
-  if (!ctx->registered) return RGB_E_STATE;
+                         const void *d_msgs, const void *d_stamps, uint32_t tick_stride, void *d_decisions,
+                         void *d_rpcs, uint32_t rpc_ring, void *stream) {
+  if (!ctx || !plan || !d_msgs || !d_stamps || !d_decisions) return RGB_E_INVAL;
+  if (!ctx->registered || ctx->xcc_state != 1) return RGB_E_STATE;
   if ((uint64_t)first_tick + n_ticks > plan->n_ticks) return RGB_E_INVAL;
   if (n_ticks == 0 || plan->bpt == 0) return RGB_OK;
-  if ((uint64_t)n_ticks * plan->bpt > 0x7FFFFFFFull) return RGB_E_INVAL;
-  int rc = train_scratch(ctx);
-  if (rc) return rc;
   void *st = stream ? stream : (void *)ctx->stream;
-  const size_t off = (size_t)first_tick * tick_stride;
-  rc = rgb_launch_train(ctx->dev, (const rgb_msg *)d_msgs + off, tick_stride, plan->d_ticks + first_tick, n_ticks,
-                        plan->bpt, (rgb_decision *)d_decisions + off, (rgb_rpc *)d_rpcs, rpc_ring, (u32)off,
-                        ctx->d_train_ctl, st);
-  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
+  /* launches of at most RGB_TRAIN_MAX_TICKS ticks (and of a grid the runtime accepts) */
+  u32 per = RGB_TRAIN_MAX_TICKS;
+  if ((uint64_t)per * plan->bpt > 0x7FFFFFFFull) per = (u32)(0x7FFFFFFFull / plan->bpt);
+  if (per == 0) return RGB_E_INVAL;
+  for (u32 t = first_tick; t < first_tick + n_ticks; t += per) {
+    const u32 n = first_tick + n_ticks - t < per ? first_tick + n_ticks - t : per;
+    const size_t off = (size_t)t * tick_stride;
+    int rc = rgb_launch_train(ctx->dev, (const rgb_msg *)d_msgs + off, (const unsigned char *)d_stamps + off,
+                              tick_stride, plan->d_ticks + t, n, plan->bpt, (rgb_decision *)d_decisions + off,
+                              (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->xcc_map, ctx->d_train_ctl, st);
+    if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
+  }
   return RGB_OK;
 }
 
 int rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard) {
   if (!ctx) return RGB_E_INVAL;
   if (flags_out) *flags_out = 0;
+  if (xcc_of_shard)
+    for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x)
+      xcc_of_shard[x] = ctx->xcc_state == 1 ? (ctx->xcc_map >> (4u * x)) & 0xFu : 0xFFFFFFFFu;
   if (!ctx->d_train_ctl) return RGB_OK;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  u32 w[RGB_TRAIN_CTL_WORDS];
-  HIPCHK(ctx, hipMemcpy(w, ctx->d_train_ctl, sizeof w, hipMemcpyDeviceToHost));
-  if (flags_out) *flags_out = w[0];
-  if (xcc_of_shard)
-    for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) xcc_of_shard[x] = w[1 + x] ? w[1 + x] - 1u : 0xFFFFFFFFu;
-  if (w[0]) {
+  u32 w = 0;
+  HIPCHK(ctx, hipMemcpy(&w, ctx->d_train_ctl, sizeof w, hipMemcpyDeviceToHost));
+  if (flags_out) *flags_out = w;
+  if (w) {
     HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, sizeof(u32)));
     return RGB_E_STATE;
   }

@@ -72,9 +72,6 @@ typedef uint32_t u32;
 #define PK_QPEER_SH     57  /* 1: some peer query_index > 0 (reset_query_index has work) */
 #define PK_BACKOFF_SH   58  /* 1: some peer is in {snapshot_backoff,_}: qry row word QRY_BACKOFF holds the mask */
 #define PK_PENDX_SH     59  /* 1: `pending` has ranges below its newest one: qry row words QRY_PEND_LO.. hold them */
-#define PK_SEQ_SH        60  /* 4: train sequence stamp = messages applied to this server, mod 16.  Written only by
-                               the train kernel (rgb_train_kernel); pack sets it to 0, unpack / checksum / the
-                               per-tick kernels neither read nor change it */
 #define QRY_PEND_LO     12  /* (first, last) of the lower old range, (1, 0) when there is only one */
 #define QRY_PEND_HI     14  /* (first, last) of the old range next below the newest range [HOT_PEND .. last_index] */
 #define QRY_BACKOFF     9   /* qry row: word 0 query_index, 1..8 peer query_index, 9 backoff mask */
@@ -118,7 +115,7 @@ static inline unsigned rgb_class_of_kind(unsigned kind) { return rgb_kind_rank(k
 #define RGB_N_BUCKETS ((RGB_N_CLASSES + 1u) * RGB_TRAIN_SHARDS * 2u)   /* 256 */
 #define RGB_TRAIN_ERR_PLACEMENT 1u   /* two blocks of one shard ran on different XCDs                    */
 #define RGB_TRAIN_ERR_SPIN      2u   /* a wavefront's dependencies did not commit within the spin bound */
-#define RGB_TRAIN_CTL_WORDS (1u + RGB_TRAIN_SHARDS)   /* error flags | XCC id + 1 of every shard */
+#define RGB_TRAIN_CTL_WORDS (1u + RGB_TRAIN_SHARDS)   /* sticky error flags | calibration: XCC bit mask of every shard */
 static inline __host__ __device__ unsigned rgb_shard_of_server(unsigned server, unsigned n_members) {
   return (server / n_members) & (RGB_TRAIN_SHARDS - 1u);
 }
@@ -128,6 +125,13 @@ static inline __host__ __device__ unsigned rgb_bucket(unsigned kind, unsigned fl
   return (rgb_kind_rank(kind) * RGB_TRAIN_SHARDS + rgb_shard_of_server(server, n_members)) * 2u +
          ((flags & RGB_MF_SUCCESS) ? 1u : 0u);
 }
+/* position of a server's sequence byte: the bytes of one shard are contiguous, so an XCD's L2 never holds a line of
+ * the array that another XCD writes */
+static inline __host__ __device__ unsigned rgb_seq_index(unsigned server, unsigned n_members, unsigned seq_stride) {
+  const unsigned g = server / n_members, m = server - g * n_members;
+  return (g & (RGB_TRAIN_SHARDS - 1u)) * seq_stride + (g / RGB_TRAIN_SHARDS) * n_members + m;
+}
+#define RGB_TRAIN_MAX_TICKS 255u   /* ticks per launch: the values a sequence byte takes within one launch are distinct */
 /* one tick of a train: rows of RGB_TRAIN_SHARDS blocks; row r of class position q serves slice r of every shard */
 struct rgb_train_tick {
   u32 row_end[16];                              /* cumulative rows of class positions 0..14 ([15] = [14])  */
@@ -154,6 +158,9 @@ struct rgb_dev {
   u32 peer_stride;
   u32 max_pipeline_count;
   u32 max_aer_batch;
+  unsigned char *seq;   /* train launches: per-server sequence byte (messages applied, mod 256), shard-major:
+                           rgb_seq_index().  Only rgb_train_kernel reads or writes it; never reset */
+  u32 seq_stride;       /* bytes per shard of seq */
   u32 dbg;   /* always 0 in the product library.  The -DRGB_PROFILE build (libra_gpu_batch_prof.so, tools/ only)
                 reads RGB_DEBUG: 1 = no state write-back, 2 = no decision store, 8 = no hot-line load (zero
                 state), 16 = per-wave timestamps into dbg_buf; all but 16 break parity */
@@ -176,15 +183,18 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
 /* d_scratch: RGB_SYNTH_SCRATCH_WORDS u32; d_bucket_counts (may be NULL): RGB_N_BUCKETS u32 of this tick */
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
                      u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream);
-/* ticks [0, n_ticks) of d_plan in one launch; bpt = blocks per tick (multiple of RGB_TRAIN_SHARDS); d_rpcs (may be
- * NULL): rpc_ring tick-sized regions, tick t uses region t mod rpc_ring; rgb_rpc.msg_index = index_base + t *
- * tick_stride + i; d_ctl: RGB_TRAIN_CTL_WORDS u32 (word 0 = sticky
- * error flags, never cleared here) */
-int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, u32 tick_stride, const rgb_train_tick *d_plan,
-                     u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base,
-                     u32 *d_ctl, void *stream);
-/* stamp n messages of one tick (ticks must be stamped in train order); init = first tick of a train */
-int rgb_launch_train_seq(const rgb_dev &dev, rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt, bool init, void *stream);
+/* ticks [0, n_ticks) of d_plan in one launch (n_ticks <= RGB_TRAIN_MAX_TICKS); bpt = blocks per tick (multiple of
+ * RGB_TRAIN_SHARDS); d_stamps: one byte per message, laid out like d_msgs; d_rpcs (may be NULL): rpc_ring tick-sized
+ * regions, tick t uses region t mod rpc_ring; rgb_rpc.msg_index = index_base + t * tick_stride + i; xcc_map: 4 bits
+ * per shard = the XCC id its blocks run on (rgb_launch_train_calibrate); d_ctl: word 0 = sticky error flags */
+int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
+                     const rgb_train_tick *d_plan, u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs,
+                     u32 rpc_ring, u32 index_base, u32 xcc_map, u32 *d_ctl, void *stream);
+/* stamps of the n messages of one tick from the running counters d_seq_cnt (ticks in train order) */
+int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt,
+                         unsigned char *d_stamps, void *stream);
+/* d_out: RGB_TRAIN_SHARDS u32, zeroed by the caller: bit k of word x = a block with blockIdx mod 8 = x ran on XCC k */
+int rgb_launch_train_calibrate(u32 *d_out, void *stream);
 /* host: the plan of one tick from its bucket counts (uint32[RGB_N_BUCKETS]); returns the tick's rows */
 u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out);
 int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream);

@@ -1711,22 +1711,19 @@ __device__ __forceinline__ void make_decision(Dec &d, u32 server, unsigned role,
 
 /* One message against one server: everything between "message words in registers" and
  * "decision words in registers".  State loads/stores go straight to the server's lines. */
-/* TR = the multi-tick train launch: state loads bypass the L1 (Lane::coh) and piece 0 of the hot row -- (current_term,
- * packed word), whose top nibble is the server's train sequence stamp -- is NOT stored here: its final value comes
- * back in *stamp and the wavefront stores it, stamp advanced, after every other store of the slice has been
- * acknowledged (rgb_tick_slice).  *stamp is left untouched for a message that addresses no server. */
+/* TR = the multi-tick train launch: state loads bypass the L1 (LaneT<true>::coh, see ldg8). */
 template <int N, int KIND, bool PRE = false, bool TR = false>
 __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
                                                 u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr,
                                                 const ulonglong2 *pre = nullptr, unsigned swz = 0,
-                                                const ulonglong2 *prepeers = nullptr, ulonglong2 *stamp = nullptr) {
+                                                const ulonglong2 *prepeers = nullptr) {
   LaneT<TR> L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
-   * (and its registers) remain.  The kind byte's high nibble is the train sequence stamp (RGB_MSG_SEQ_*). */
-  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0x0F);
+   * (and its registers) remain */
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF);
   L.kind = KIND >= 0 ? (unsigned)KIND : wire_kind;
   L.from = (unsigned)((m0.x >> 40) & 0xFF);
   L.mflags = (unsigned)((m0.x >> 48) & 0xFF);
@@ -1758,7 +1755,6 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
     h0 = ldg16(TR, hp + 0); h1 = ldg16(TR, hp + 1); h2 = ldg16(TR, hp + 2); h3 = ldg16(TR, hp + 3);
     h4 = ldg16(TR, hp + 4); h5 = ldg16(TR, hp + 5); h6 = ldg16(TR, hp + 6); h7 = ldg16(TR, hp + 7);
   }
-  if (TR) *stamp = h0;
 #ifdef RGB_PROFILE
   L.prof_noprobe = RGB_KNOB(dev, 32u); L.prof_nloads = 0;
 #endif
@@ -1949,8 +1945,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
   if (!RGB_KNOB(dev, 1u)) {
   if (L.n_runs < 2) { L.prs = 0; L.prt = 0; }         /* canonical: no run n-2 */
-  if (TR) *stamp = make_ulonglong2(L.ct, L.pk);
-  else if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
+  if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
   if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la));
   if (L.li != h2.x || L.lt != h2.y) ST16(ho + 2, make_ulonglong2(L.li, L.lt));
   if (L.lwi != h3.x || L.lwt != h3.y) ST16(ho + 3, make_ulonglong2(L.lwi, L.lwt));
@@ -1990,7 +1985,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1, const ulonglong2 m2,
                                          const ulonglong2 m3, const ulonglong2 *pre, unsigned swz, Dec &out) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
-  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0x0F), from = (unsigned)((m0.x >> 40) & 0xFF);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), from = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF), gap = (unsigned)((m0.x >> 56) & 0xFF);
   const u32 n_entries = (u32)(m2.y & 0xFFFFFFFFull), n_run0 = (u32)(m2.y >> 32);
   if (wire_kind != RGB_MSG_AER || server >= dev.n_servers || gap != 0 || n_entries == 0 || n_run0 < n_entries ||
@@ -2030,7 +2025,7 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
 __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                              const ulonglong2 *pre, unsigned swz, Dec &out) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
-  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0x0F), mflags = (unsigned)((m0.x >> 48) & 0xFF);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), mflags = (unsigned)((m0.x >> 48) & 0xFF);
   if (wire_kind != RGB_MSG_WRITTEN || server >= dev.n_servers || mflags != 0) return false;
   const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h4 = pre[4 ^ swz],
                    h5 = pre[5 ^ swz], h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
@@ -2072,7 +2067,7 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
                                                const ulonglong2 *pre, unsigned swz, Dec &out,
                                                const ulonglong2 *prow = nullptr) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
-  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0x0F), peer = (unsigned)((m0.x >> 40) & 0xFF);
+  const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), peer = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF);
   if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || mflags != RGB_MF_SUCCESS || peer >= (unsigned)N)
     return false;
@@ -2245,7 +2240,7 @@ __host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLAS
 #ifdef RGB_HOST_EMULATION
 #define RGB_TRAIN_SPIN_LIMIT 16u      /* blocks run one after another on the CPU: a dependency is met or never will be */
 #else
-#define RGB_TRAIN_SPIN_LIMIT 40000u
+#define RGB_TRAIN_SPIN_LIMIT 20000u    /* x ~12 us per try once backed off: a quarter of a second */
 #endif
 #endif
 
@@ -2253,20 +2248,23 @@ __host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLAS
  * hot path -- record staging, cooperative state fetch, fast paths, clause code, commit, decision store -- shared by
  * the per-tick class kernel (TR = false) and the multi-tick train kernel (TR = true).
  *
- * TR = true adds the dataflow protocol that replaces the kernel boundary between ticks.  A server's hot row carries a
- * 4-bit sequence stamp (packed word bits 60..63) = the number of messages applied to it (mod 16); every message
- * carries the stamp it must find (kind byte, high nibble: written by rgb_train_seq_kernel).  The wavefront
- *   1. polls the packed words of its servers until every stamp matches (the earlier message of each server has
+ * TR = true adds the dataflow protocol that replaces the kernel boundary between ticks.  Every server has a sequence
+ * byte in dev.seq (the number of messages applied to it, mod 256; shard-major, so an XCD only ever touches its own
+ * lines of the array, which stay in its L2) and every message of a train carries the value it must find
+ * (stamps[], written by rgb_train_seq_kernel).  The wavefront
+ *   1. polls the sequence bytes of its servers until every one matches (the earlier message of each server has
  *      committed -- by a wavefront of an earlier tick of the SAME launch, on the same XCD: see rgb_train_kernel),
  *   2. fetches the rows with L2-served loads (sc1: a CU's L1 is never refreshed by another CU's stores),
  *   3. runs the unchanged clause code, whose state stores are plain (they stay in the XCD's L2),
- *   4. waits for every store to be acknowledged, then stores piece 0 = (current_term, packed word with the stamp
- *      advanced): whoever sees the new stamp sees the whole commit. */
+ *   4. waits for every store to be acknowledged, then stores the advanced sequence byte: whoever sees the new
+ *      value sees the whole commit.
+ * A launch carries at most 255 ticks, so the values a server goes through within one launch are distinct. */
 template <int N, bool TR>
 __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *io, const int cls, const u32 base,
                                                const u32 cnt, const u32 SL, const rgb_msg *__restrict__ msgs,
                                                rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs,
-                                               u32 rpc_slot_base, u32 msg_index_base, u32 *__restrict__ ctl) {
+                                               u32 rpc_slot_base, u32 msg_index_base, u32 *__restrict__ ctl,
+                                               const unsigned char *__restrict__ stamps) {
   const u32 lane = threadIdx.x;
 #ifdef RGB_PROFILE
   u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl[4] = {0, 0, 0, 0};
@@ -2301,8 +2299,10 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   const ulonglong2 m0 = io[lane * 4 + (0 ^ mswz)], m1 = io[lane * 4 + (1 ^ mswz)],
                    m2 = io[lane * 4 + (2 ^ mswz)], m3 = io[lane * 4 + (3 ^ mswz)];
   const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
-  /* the message addresses a server (a NOP or an out-of-range id touches no state and carries no stamp) */
-  const bool has_srv = TR && active && sv < dev.n_servers && ((m0.x >> 32) & 0x0Full) != RGB_MSG_NOP;
+  /* the message addresses a server (a NOP or an out-of-range id touches no state and has no stamp) */
+  const bool has_srv = TR && active && sv < dev.n_servers && ((m0.x >> 32) & 0xFFull) != RGB_MSG_NOP;
+  unsigned char *seqp = nullptr;
+  unsigned need = 0;
 #ifdef RGB_X_TRAIN_NODEPS
   /* EXPERIMENT (never in the product; breaks parity): no dependency wait -- the upper bound of what overlapping
    * ticks can give */
@@ -2311,22 +2311,29 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   if (TR) {
 #endif
     /* 1. dependencies: this server's previous message -- an earlier tick of this launch -- has committed */
-    const unsigned need = (unsigned)((m0.x >> 36) & 0xFull);
-    const u64 *pkp = dev.hot + (size_t)(has_srv ? sv : 0u) * RGB_HOT_WORDS + HOT_PK;
+    seqp = dev.seq + rgb_seq_index(has_srv ? sv : 0u, dev.n_members, dev.seq_stride);
+    need = has_srv ? (unsigned)stamps[base + lane] : 0u;
     unsigned spins = 0;
+    bool late = has_srv;
     for (;;) {
+      /* only the lanes that are still waiting poll again; a wavefront that has to wait backs off (thousands of
+       * waiting wavefronts polling flat out starve the ones they wait for of L2 bandwidth) */
+      if (late) {
 #ifdef RGB_HOST_EMULATION
-      const u64 pk = *pkp;
+        const unsigned cur = *seqp;
 #else
-      const u64 pk = __hip_atomic_load(pkp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned cur = __hip_atomic_load(seqp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-      const bool late = has_srv && (unsigned)(pk >> PK_SEQ_SH) != need;
+        late = cur != need;
+      }
       if (__ballot(late) == 0ull) break;
       spins += 1;
       bool give_up = spins > RGB_TRAIN_SPIN_LIMIT;
 #ifndef RGB_HOST_EMULATION
-      if ((spins & 63u) == 0u && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) give_up = true;
-      __builtin_amdgcn_s_sleep(8);
+      if ((spins & 15u) == 0u && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) give_up = true;
+      __builtin_amdgcn_s_sleep(32);                       /* ~1 us */
+      if (spins > 4u) __builtin_amdgcn_s_sleep(127);      /* ~4 us more */
+      if (spins > 32u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
 #endif
       if (give_up) {                                      /* uniform: the decisions of this slice stay unwritten */
         if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_SPIN);
@@ -2339,7 +2346,13 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
    * reach their owners through LDS rows that overlay the record staging area (the messages are in
    * registers by now), and process_message reads its row from LDS piece by piece, when it needs it. */
   constexpr bool PRE = true;
+#ifdef RGB_X_TRAIN_PLAINROWS      /* EXPERIMENT (breaks parity): the train's rows through the L1 like the per-tick kernel's */
+  constexpr int ROWS = GLDS_DEFAULT;
+#elif defined(RGB_X_SC1ROWS)        /* EXPERIMENT: the per-tick kernel's rows L2-served too */
+  constexpr int ROWS = GLDS_SC1;
+#else
   constexpr int ROWS = TR ? GLDS_SC1 : GLDS_DEFAULT;
+#endif
   u64 pf0 = 0, pf1 = 0;
   lds_barrier();
   {
@@ -2407,9 +2420,6 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #ifdef RGB_PROFILE
   if (!TR) tlp = tl;
 #endif
-  /* train: piece 0 as fetched; the fast paths never change it, the clause code returns its new value */
-  ulonglong2 stamp = make_ulonglong2(0, 0);
-  if (TR) stamp = hrow[0 ^ hswz];
   bool done = false;
 #if RGB_X_FAST
   /* the steady-state outcome of the three bulk kinds first; whoever is left takes the general clause code below */
@@ -2428,7 +2438,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   case RANK:                                                                                            \
     RGB_MARK("begin", RANK)                                                                             \
     process_message<N, KIND, PRE, TR>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
-                                      hrow, hswz, prow, TR ? &stamp : nullptr);                         \
+                                      hrow, hswz, prow);                                                \
     RGB_MARK("end", RANK)                                                                               \
     break;
     switch (cls) {
@@ -2440,8 +2450,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
       RGB_CASE(12, RGB_MSG_HEARTBEAT_RPC) RGB_CASE(13, RGB_MSG_HEARTBEAT_REPLY)
       default:
         process_message<N, RGB_MSG_CONSISTENT_QUERY, PRE, TR>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base,
-                                                              msg_index_base, d, tlp, hrow, hswz, prow,
-                                                              TR ? &stamp : nullptr);
+                                                              msg_index_base, d, tlp, hrow, hswz, prow);
         break;
     }
 #undef RGB_CASE
@@ -2459,15 +2468,17 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     for (int k = 0; k < RGB_X_EXTRA_STORE / 16; ++k) ST16(xs + k, make_ulonglong2(d.w[0], d.w[1] + (u64)k));
   }
 #endif
+#ifdef RGB_X_TRAIN_NOSTAMP        /* EXPERIMENT (breaks parity): no publish step */
+  if (false) {
+#else
   if (TR) {
+#endif
     /* 4. publish: every state store of this wavefront has been acknowledged by the L2 (inline assembly: the
-     * compiler's wait-count pass must not drop or move it), then the stamp -- one 16-byte store per server */
-#ifndef RGB_HOST_EMULATION
+     * compiler's wait-count pass must not drop or move it), then the advanced sequence byte of every server */
+#if !defined(RGB_HOST_EMULATION) && !defined(RGB_X_TRAIN_NOWAIT)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    if (has_srv)
-      ST16(reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)sv * RGB_HOT_WORDS),
-           make_ulonglong2(stamp.x, stamp.y + (1ull << PK_SEQ_SH)));
+    if (has_srv && seqp != nullptr) *seqp = (unsigned char)(need + 1u);
   }
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
   if (active) {
@@ -2537,20 +2548,22 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
   const u32 base = off + blk * SL;                        /* first message of this wavefront */
   const u32 end = off + ncls;
   const u32 cnt = end - base < SL ? end - base : SL;
-  rgb_tick_slice<N, false>(dev, io, cls, base, cnt, SL, msgs, dec, rpcs, rpc_slot_base, msg_index_base, nullptr);
+  rgb_tick_slice<N, false>(dev, io, cls, base, cnt, SL, msgs, dec, rpcs, rpc_slot_base, msg_index_base, nullptr,
+                           nullptr);
 }
 
 /* The TRAIN kernel: n_ticks consecutive ticks in ONE launch.  There is no kernel boundary between the ticks (no
  * launch gap, no dispatch ramp, no end-of-kernel write-back of the dirty L2 lines per tick, and the wavefronts of
  * neighbouring ticks drift out of phase, so one tick's memory phases run under the other's clause code); what
- * orders two messages of one server is the server's sequence stamp (rgb_tick_slice).
+ * orders two messages of one server is the server's sequence byte (rgb_tick_slice).
  *
  * Coherence: the per-XCD L2s are not coherent with each other, so everything that touches a server must run on ONE
  * XCD for the life of the launch.  Servers are sharded by group (shard = group mod 8), every tick's messages are
- * ordered by (clause family, shard) -- rgb_synth / the plan carry the per-shard offsets -- and block b of the grid
- * serves shard b mod 8: the dispatcher places block b on XCD b mod 8 (observed behaviour, not a contract -- so it
- * is CHECKED: the first block of a shard records the XCC id it runs on, every later one compares, and a mismatch
- * fails the launch with RGB_TRAIN_ERR_PLACEMENT instead of computing on stale lines).  Within an XCD the L2 is the
+ * ordered by (class, shard) -- rgb_synth / the plan carry the per-shard offsets -- and block b of the grid serves
+ * shard b mod 8: the dispatcher places block b on XCD b mod 8 (observed behaviour, not a contract -- so it is
+ * CHECKED: rgb_train_calibrate_kernel records once per context which XCC id blocks b mod 8 = x run on, xcc_map carries
+ * that to every launch, and a block that finds itself elsewhere fails the launch with RGB_TRAIN_ERR_PLACEMENT
+ * instead of computing on stale lines; the check is one s_getreg and a compare).  Within an XCD the L2 is the
  * coherence point: state stores are plain (write-through L1, line kept in the L2), state loads are L2-served.
  *
  * Progress: a wavefront only ever waits for messages of EARLIER ticks, whose blocks come earlier in the grid; blocks
@@ -2563,10 +2576,20 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #ifndef RGB_TRAIN_MIN_WAVES
 #define RGB_TRAIN_MIN_WAVES(N) RGB_CLASS_MIN_WAVES(N)
 #endif
+__device__ __forceinline__ u32 rgb_xcc_id() {
+#ifdef RGB_HOST_EMULATION
+  return 0;
+#else
+  u32 xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  return xcc;
+#endif
+}
 template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(
-    rgb_dev dev, const rgb_msg *__restrict__ msgs, u32 tick_stride, const rgb_train_tick *__restrict__ plan, u32 bpt,
-    rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs, u32 rpc_ring, u32 index_base, u32 *__restrict__ ctl) {
+    rgb_dev dev, const rgb_msg *__restrict__ msgs, const unsigned char *__restrict__ stamps, u32 tick_stride,
+    const rgb_train_tick *__restrict__ plan, u32 bpt, rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs,
+    u32 rpc_ring, u32 index_base, u32 xcc_map, u32 *__restrict__ ctl) {
   __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];
   const u32 t = blockIdx.x / bpt, j = blockIdx.x - t * bpt;
   const u32 x = j & (RGB_TRAIN_SHARDS - 1u), row = j / RGB_TRAIN_SHARDS;
@@ -2583,41 +2606,40 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   if (lbase >= ncls) return;
   const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
 #ifndef RGB_HOST_EMULATION
-  /* placement check, off the critical path: the atomic's result is only looked at after the slice */
-  u32 xcc = 0;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-  u32 seen = 0;
-  if (threadIdx.x == 0) seen = atomicCAS(ctl + 1 + x, 0u, xcc + 1u);
+  if (rgb_xcc_id() != ((xcc_map >> (4u * x)) & 0xFu)) {     /* not where this shard's lines are coherent */
+    if (threadIdx.x == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
+    return;
+  }
 #endif
   const size_t toff = (size_t)t * tick_stride;
   rgb_rpc *rp = rpcs ? rpcs + (size_t)(t % rpc_ring) * tick_stride * (N > 1 ? N - 1 : 1) : nullptr;
-  rgb_tick_slice<N, true>(dev, io, cls, off + lbase, cnt, SL, msgs + toff, dec + toff, rp, 0, index_base + (u32)toff, ctl);
-#ifndef RGB_HOST_EMULATION
-  if (threadIdx.x == 0 && seen != 0u && seen != xcc + 1u) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
-#endif
+  rgb_tick_slice<N, true>(dev, io, cls, off + lbase, cnt, SL, msgs + toff, dec + toff, rp, 0, index_base + (u32)toff,
+                          ctl, stamps + toff);
 }
 
-/* Sequence stamps of a train: seq_cnt[s] = the stamp server s will carry when the next message reaches it.
- * INIT: seq_cnt := the rows' current stamps.  Then, tick by tick in train order, every message takes its server's
- * count into the high nibble of its kind byte and advances it (one message per server per tick: no two lanes share
- * a counter). */
-__global__ void rgb_train_seq_init_kernel(rgb_dev dev, unsigned char *__restrict__ seq_cnt) {
-  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= dev.n_servers) return;
-  seq_cnt[s] = (unsigned char)(dev.hot[(size_t)s * RGB_HOT_WORDS + HOT_PK] >> PK_SEQ_SH);
+/* once per context: out[x] |= 1 << (XCC id of a block with blockIdx mod 8 = x).  The host accepts the map when
+ * every entry has exactly one bit and no two shards share... (sharing an XCD would still be coherent; two XCDs for one
+ * shard is what must not happen) */
+__global__ void rgb_train_calibrate_kernel(u32 *__restrict__ out) {
+  if (threadIdx.x == 0) atomicOr(out + (blockIdx.x & (RGB_TRAIN_SHARDS - 1u)), 1u << rgb_xcc_id());
 }
-__global__ void rgb_train_seq_kernel(rgb_dev dev, rgb_msg *__restrict__ msgs, u32 n, unsigned char *__restrict__ seq_cnt) {
+
+/* Sequence stamps of a train: seq_cnt[i] = the value server (at sequence index i) will hold when the next message
+ * reaches it -- a copy of dev.seq taken by the launcher before the first tick.  Tick by tick in train order, every
+ * message takes its server's count as its stamp and advances it (one message per server per tick: no two lanes
+ * share a counter). */
+__global__ void rgb_train_seq_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs, u32 n, unsigned char *__restrict__ seq_cnt,
+                                     unsigned char *__restrict__ stamps) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  u64 *w0 = reinterpret_cast<u64 *>(msgs + i);
-  const u64 w = *w0;
+  const u64 w = *reinterpret_cast<const u64 *>(msgs + i);
   const u32 sv = (u32)(w & 0xFFFFFFFFull);
-  if (((w >> 32) & 0x0Full) == RGB_MSG_NOP || sv >= dev.n_servers) return;
-  const unsigned c = seq_cnt[sv] & 0xFu;
-  seq_cnt[sv] = (unsigned char)((c + 1u) & 0xFu);
-  *w0 = (w & ~(0xFull << 36)) | ((u64)c << 36);
+  if (((w >> 32) & 0xFFull) == RGB_MSG_NOP || sv >= dev.n_servers) { stamps[i] = 0; return; }
+  const u32 k = rgb_seq_index(sv, dev.n_members, dev.seq_stride);
+  const unsigned char c = seq_cnt[k];
+  seq_cnt[k] = (unsigned char)(c + 1u);
+  stamps[i] = c;
 }
-
 
 /* ------------------------------------------------------------ synthetic load ---- */
 /* Device-side load generator (include/ra_gpu_batch_synth.h).  One lane per GROUP reads the hot
@@ -3259,21 +3281,17 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
   return rows;
 }
 
-int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, u32 tick_stride, const rgb_train_tick *d_plan,
-                     u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base,
-                     u32 *d_ctl, void *stream) {
+int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
+                     const rgb_train_tick *d_plan, u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs,
+                     u32 rpc_ring, u32 index_base, u32 xcc_map, u32 *d_ctl, void *stream) {
   if (n_ticks == 0 || bpt == 0) return 0;
-  if (bpt % RGB_TRAIN_SHARDS) return -1;
+  if (bpt % RGB_TRAIN_SHARDS || n_ticks > RGB_TRAIN_MAX_TICKS) return -1;
   hipStream_t st = (hipStream_t)stream;
-  /* the placement map is per launch (the L2s are written back and invalidated between launches); the error word
-   * is sticky until rgb_train_status reads it */
-  hipError_t e = hipMemsetAsync(d_ctl + 1, 0, RGB_TRAIN_SHARDS * sizeof(u32), st);
-  if (e != hipSuccess) return (int)e;
   dim3 grid(n_ticks * bpt), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                                      \
   case NN:                                                                                              \
-    hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, dev, d_msgs, tick_stride, d_plan, bpt, \
-                       d_dec, d_rpcs, rpc_ring ? rpc_ring : 1u, index_base, d_ctl);                     \
+    hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, dev, d_msgs, d_stamps, tick_stride, d_plan, bpt, \
+                       d_dec, d_rpcs, rpc_ring ? rpc_ring : 1u, index_base, xcc_map, d_ctl);            \
     break;
   switch (dev.n_members) {
     RGB_LAUNCH_ALL_N
@@ -3283,11 +3301,15 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, u32 tick_stride,
   return (int)hipGetLastError();
 }
 
-int rgb_launch_train_seq(const rgb_dev &dev, rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt, bool init, void *stream) {
+int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt,
+                         unsigned char *d_stamps, void *stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (init)
-    hipLaunchKernelGGL(rgb_train_seq_init_kernel, dim3((dev.n_servers + 255) / 256), dim3(256), 0, st, dev, d_seq_cnt);
-  if (n) hipLaunchKernelGGL(rgb_train_seq_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dev, d_msgs, n, d_seq_cnt);
+  if (n) hipLaunchKernelGGL(rgb_train_seq_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dev, d_msgs, n, d_seq_cnt, d_stamps);
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_train_calibrate(u32 *d_out, void *stream) {
+  hipLaunchKernelGGL(rgb_train_calibrate_kernel, dim3(64 * RGB_TRAIN_SHARDS), dim3(64), 0, (hipStream_t)stream, d_out);
   return (int)hipGetLastError();
 }
 

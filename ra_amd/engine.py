@@ -111,8 +111,8 @@ def lib():
     L.rgb_train_plan_destroy.restype = None
     L.rgb_train_plan_blocks_per_tick.restype = C.c_uint32
     L.rgb_train_plan_blocks_per_tick.argtypes = [vp]
-    L.rgb_train_stamp_device.argtypes = [vp, vp, u32, vp, u32, vp]
-    L.rgb_train_run_device.argtypes = [vp, vp, u32, u32, vp, u32, vp, vp, u32, vp]
+    L.rgb_train_stamp_device.argtypes = [vp, vp, vp, u32, vp, u32, vp]
+    L.rgb_train_run_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, u32, vp]
     L.rgb_train_status.argtypes = [vp, C.POINTER(u32), vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     L.rgb_wal_adler32_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, vp]
@@ -298,15 +298,16 @@ class RaGpuBatch:
     def train_plan(self, bucket_counts: np.ndarray) -> "TrainPlan":
         return TrainPlan(self, bucket_counts)
 
-    def train_stamp_device(self, d_msgs: int, tick_stride: int, tick_counts: np.ndarray, stream: int = 0):
+    def train_stamp_device(self, d_msgs: int, d_stamps: int, tick_stride: int, tick_counts: np.ndarray, stream: int = 0):
+        """d_stamps: uint8[n_ticks * tick_stride] on the device, the sequence value every message must find."""
         tc = np.ascontiguousarray(tick_counts, dtype=np.uint32)
-        self._check(self._L.rgb_train_stamp_device(self._h, d_msgs, tick_stride, tc.ctypes.data, len(tc), stream),
-                    "rgb_train_stamp_device")
+        self._check(self._L.rgb_train_stamp_device(self._h, d_msgs, d_stamps, tick_stride, tc.ctypes.data, len(tc),
+                                                   stream), "rgb_train_stamp_device")
 
-    def train_run_device(self, plan: "TrainPlan", first_tick: int, n_ticks: int, d_msgs: int, tick_stride: int,
-                         d_decisions: int, d_rpcs: int = 0, rpc_ring: int = 1, stream: int = 0):
-        self._check(self._L.rgb_train_run_device(self._h, plan.h, first_tick, n_ticks, d_msgs, tick_stride,
-                                                d_decisions, d_rpcs, rpc_ring, stream), "rgb_train_run_device")
+    def train_run_device(self, plan: "TrainPlan", first_tick: int, n_ticks: int, d_msgs: int, d_stamps: int,
+                         tick_stride: int, d_decisions: int, d_rpcs: int = 0, rpc_ring: int = 1, stream: int = 0):
+        self._check(self._L.rgb_train_run_device(self._h, plan.h, first_tick, n_ticks, d_msgs, d_stamps, tick_stride,
+                                                 d_decisions, d_rpcs, rpc_ring, stream), "rgb_train_run_device")
 
     def train_status(self, check: bool = True):
         """(error flags, XCD of every shard) of the trains run since the last call; the caller has synchronised."""

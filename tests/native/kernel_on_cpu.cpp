@@ -135,12 +135,15 @@ void *emu_new(uint32_t n_groups, uint32_t n_members, uint32_t max_runs, uint32_t
   d.runs = (u64 *)calloc(S * max_runs * 2, sizeof(u64));
   d.cond = (u64 *)calloc(S * 4, sizeof(u64));
   d.qry = (u64 *)calloc(S * RGB_QRY_WORDS, sizeof(u64));
+  d.seq_stride = (((n_groups + RGB_TRAIN_SHARDS - 1u) / RGB_TRAIN_SHARDS) * n_members + 255u) & ~255u;
+  d.seq = (unsigned char *)calloc((size_t)d.seq_stride * RGB_TRAIN_SHARDS, 1);
   return e;
 }
 
 void emu_free(void *h) {
   Emu *e = (Emu *)h;
-  free(e->dev.hot); free(e->dev.peers); free(e->dev.runs); free(e->dev.cond); free(e->dev.qry); free(e->slots);
+  free(e->dev.hot); free(e->dev.peers); free(e->dev.runs); free(e->dev.cond); free(e->dev.qry); free(e->dev.seq);
+  free(e->slots);
   free(e);
 }
 

@@ -5,7 +5,8 @@ final state -- and what the oracle computes.
 
 The same test bodies run on the GPU (`-m gpu`, real library, torch device buffers) and on the CPU block emulation
 (tests/native: blocks run one after another in grid order, so every dependency is met on the first poll -- it checks
-the plan, the bucket order, the stamps and the commit protocol's arithmetic, not the races)."""
+the plan, the bucket order, the stamps and the commit protocol's arithmetic, not the races).  The GPU cases include
+trains of more than 16 small ticks, all resident at once: dozens of ticks genuinely in flight together."""
 import ctypes as C
 
 import numpy as np
@@ -81,7 +82,7 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
         bk = engine.train_bucket(plain[t]["kind"], plain[t]["flags"], plain[t]["server"], N)
         assert np.all(np.diff(bk.astype(np.int64)) >= 0)
         assert np.array_equal(np.bincount(bk, minlength=engine.TRAIN_BUCKETS), r["buckets"][t])
-    # the oracle on the same stream (the kind nibble is still clear: stamping comes next)
+    # the oracle on the same stream
     if oracle_lib is not None:
         cpu = oracle_lib.Oracle(G, N, max_runs=16)
         cpu.set_state(0, r["st_start"])
@@ -92,6 +93,8 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
         cpu.close()
     plan = eng.train_plan(r["buckets"])
     assert plan.blocks_per_tick % 8 == 0 and plan.blocks_per_tick > 0
+    stamps = Buf(T * S, on_gpu)
+    seen = np.zeros(S, dtype=np.int64)                      # messages every server has received through trains
     for chunk in chunks:
         # back to the start state; the train runs in `chunk`-tick launches (None = one launch for all T ticks)
         eng.set_state(0, r["st_start"])
@@ -100,28 +103,27 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
         t = 0
         while t < T:
             n = min(step, T - t)
-            # stamps of this launch's ticks start from what the rows hold now (upload reset them to 0; earlier
-            # launches advanced them)
-            eng.train_stamp_device(r["msgs"].ptr + t * tb, S, r["counts"][t:t + n])
-            eng.train_run_device(plan, t, n, r["msgs"].ptr, S, dec2.ptr, rpc2.ptr + t * rs, rpc_ring=n)
+            # the stamps of a launch's ticks count on from what the servers hold now
+            eng.train_stamp_device(r["msgs"].ptr + t * tb, stamps.ptr + t * S, S, r["counts"][t:t + n])
+            eng.train_run_device(plan, t, n, r["msgs"].ptr, stamps.ptr, S, dec2.ptr, rpc2.ptr + t * rs, rpc_ring=n)
             t += n
         eng.synchronize()
         flags, xcc = eng.train_status()
         assert flags == 0
-        stamped = [_tick(r["msgs"], t, tb, int(r["counts"][t]), abi.MSG_DTYPE) for t in range(T)]
+        # the messages are untouched; the stamp of a message = messages its server received through trains before it
+        # (the sequence bytes are never reset: not by rgb_upload_state either)
+        st_h = stamps.host()
         for t in range(T):
             got = _tick(dec2, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE)
             if got.tobytes() != want_dec[t].tobytes():
                 bad = int(np.flatnonzero((got.view(np.uint8).reshape(-1, 64) !=
                                           want_dec[t].view(np.uint8).reshape(-1, 64)).any(axis=1))[0])
-                raise AssertionError(f"chunk {chunk}: tick {t} slot {bad}: msg={stamped[t][bad]}\n train={got[bad]}\n "
+                raise AssertionError(f"chunk {chunk}: tick {t} slot {bad}: msg={plain[t][bad]}\n train={got[bad]}\n "
                                      f"per-tick={want_dec[t][bad]}")
-            # the stamp of a message = number of earlier messages of its server since the upload, mod 16
-            assert np.array_equal(stamped[t]["kind"] & 15, plain[t]["kind"])
-        seen = np.zeros(S, dtype=np.int64)
-        for t in range(T):
-            assert np.array_equal(stamped[t]["kind"] >> 4, seen[stamped[t]["server"]] & 15), f"stamps of tick {t}"
-            seen[stamped[t]["server"]] += 1
+            assert _tick(r["msgs"], t, tb, int(r["counts"][t]), abi.MSG_DTYPE).tobytes() == plain[t].tobytes()
+            n_t = int(r["counts"][t])
+            assert np.array_equal(st_h[t * S:t * S + n_t], (seen[plain[t]["server"]] & 255).astype(np.uint8)), f"stamps of tick {t}"
+            seen[plain[t]["server"]] += 1
         # rpc records: message i of tick t owns slots [i (N-1), (i+1)(N-1)), the first n_rpcs are valid
         per = max(N - 1, 1)
         for t in range(T):
@@ -137,19 +139,6 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
                 assert x.tobytes() == y.tobytes(), f"rpc records of tick {t} message {i}"
         assert eng.get_state().tobytes() == r["st_end"].tobytes(), f"chunk {chunk}: final state differs"
         assert eng.state_checksum() == r["sum_end"]
-        # restore the stream for the next chunking: clear the stamps
-        for t in range(T):
-            m = r["msgs"].host()
-            if not on_gpu:
-                v = m[t * tb:t * tb + int(r["counts"][t]) * 64].view(abi.MSG_DTYPE)
-                v["kind"] &= 15
-        if on_gpu and chunk is not chunks[-1]:
-            import torch
-            h = r["msgs"].t.cpu().numpy()
-            for t in range(T):
-                v = h[t * tb:t * tb + int(r["counts"][t]) * 64].view(abi.MSG_DTYPE)
-                v["kind"] &= 15
-            r["msgs"].t.copy_(torch.from_numpy(h))
     plan.close()
     eng.close()
 
@@ -167,11 +156,11 @@ def test_train_with_a_wrong_stamp_fails_in_bounded_time(emulated_engine):
     eng, S = r["eng"], r["S"]
     eng.set_state(0, r["st_start"])
     plan = eng.train_plan(r["buckets"])
-    eng.train_stamp_device(r["msgs"].ptr, S, r["counts"])
-    m = r["msgs"].host()[:int(r["counts"][0]) * 64].view(abi.MSG_DTYPE)
-    m["kind"][0] = (m["kind"][0] & 15) | (5 << 4)          # tick 0 expects stamp 0
+    stamps = Buf(3 * S, False)
+    eng.train_stamp_device(r["msgs"].ptr, stamps.ptr, S, r["counts"])
+    stamps.host()[0] = 5                                    # the first message of tick 0 must find 0
     dec2 = Buf(3 * r["tb"], False)
-    eng.train_run_device(plan, 0, 3, r["msgs"].ptr, S, dec2.ptr)
+    eng.train_run_device(plan, 0, 3, r["msgs"].ptr, stamps.ptr, S, dec2.ptr)
     eng.synchronize()
     flags, _ = eng.train_status(check=False)
     assert flags & 2
