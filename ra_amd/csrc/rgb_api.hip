@@ -88,7 +88,7 @@ struct rgb_ctx {
   /* train launches */
   u32 *d_train_ctl = nullptr;           /* RGB_TRAIN_CTL_WORDS: sticky error flags | calibration scratch */
   unsigned char *d_seq_cnt = nullptr;   /* running stamp counters of rgb_train_stamp_device (a copy of dev.seq) */
-  u32 xcc_map = 0;                      /* 4 bits per shard: the XCC id blocks b mod 8 = shard run on */
+  u32 xcc_map = 0;                      /* 4 bits per shard: the XCC id blocks b mod 8 = shard ran on in the calibration launch */
   int xcc_state = 0;                    /* 0 = not calibrated, 1 = usable, -1 = placement is not one XCD per shard */
 };
 
@@ -255,6 +255,11 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
     HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
     HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
   }
+#endif
+#ifdef RGB_X_TRAIN_TIMELINE
+  /* EXPERIMENT build (tools/train_timeline.py): 8 words per block of a train launch */
+  HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(1u << 20) * 8 * sizeof(u64)));
+  HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(1u << 20) * 8 * sizeof(u64)));
 #endif
 #ifdef RGB_X_EXTRA_STORE
   /* EXPERIMENT (never in the product): a scratch line per server for the write-side probe of the class kernel */
@@ -645,13 +650,14 @@ static int train_scratch(rgb_ctx *ctx) {
   if (ctx->xcc_state == 0) {
     /* where do blocks b mod 8 = x run?  A train is only coherent when that is ONE XCD per shard */
     HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, RGB_TRAIN_SHARDS * sizeof(u32), ctx->stream));
-    for (int rep = 0; rep < 4; ++rep) {
-      int rc = rgb_launch_train_calibrate(ctx->d_train_ctl + 1, ctx->stream);
+    {
+      int rc = rgb_launch_train_calibrate(ctx->d_train_ctl + 1, ctx->stream);   /* ONE launch: the rotation is per launch */
       if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
     }
     u32 w[RGB_TRAIN_SHARDS];
     HIPCHK(ctx, hipMemcpyAsync(w, ctx->d_train_ctl + 1, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, RGB_TRAIN_SHARDS * sizeof(u32), ctx->stream));
     ctx->xcc_state = 1;
     ctx->xcc_map = 0;
     for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) {
@@ -741,7 +747,7 @@ int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t firs
     const size_t off = (size_t)t * tick_stride;
     int rc = rgb_launch_train(ctx->dev, (const rgb_msg *)d_msgs + off, (const unsigned char *)d_stamps + off,
                               tick_stride, plan->d_ticks + t, n, plan->bpt, (rgb_decision *)d_decisions + off,
-                              (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->xcc_map, ctx->d_train_ctl, st);
+                              (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, st);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
   return RGB_OK;

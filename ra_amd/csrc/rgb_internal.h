@@ -185,11 +185,11 @@ int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u3
                      u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream);
 /* ticks [0, n_ticks) of d_plan in one launch (n_ticks <= RGB_TRAIN_MAX_TICKS); bpt = blocks per tick (multiple of
  * RGB_TRAIN_SHARDS); d_stamps: one byte per message, laid out like d_msgs; d_rpcs (may be NULL): rpc_ring tick-sized
- * regions, tick t uses region t mod rpc_ring; rgb_rpc.msg_index = index_base + t * tick_stride + i; xcc_map: 4 bits
- * per shard = the XCC id its blocks run on (rgb_launch_train_calibrate); d_ctl: word 0 = sticky error flags */
+ * regions, tick t uses region t mod rpc_ring; rgb_rpc.msg_index = index_base + t * tick_stride + i; d_ctl: word 0 =
+ * sticky error flags, word 1 = this launch's placement rotation mask (zeroed here) */
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs,
-                     u32 rpc_ring, u32 index_base, u32 xcc_map, u32 *d_ctl, void *stream);
+                     u32 rpc_ring, u32 index_base, u32 *d_ctl, void *stream);
 /* stamps of the n messages of one tick from the running counters d_seq_cnt (ticks in train order) */
 int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt,
                          unsigned char *d_stamps, void *stream);

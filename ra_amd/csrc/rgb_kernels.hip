@@ -2233,6 +2233,16 @@ __host__ __device__ __forceinline__ void rgb_make_plan(const u32 (&n)[RGB_N_CLAS
   }
 }
 
+__device__ __forceinline__ u32 rgb_xcc_id() {
+#ifdef RGB_HOST_EMULATION
+  return 0;
+#else
+  u32 xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  return xcc;
+#endif
+}
+
 /* Train launches (rgb_train_kernel): a wavefront whose servers' previous messages have not committed yet polls their
  * sequence stamps this many times (one L2-served load + s_sleep per try, ~1 us) before it gives up and raises
  * RGB_TRAIN_ERR_SPIN -- a bound, so that a broken dependency can never hang the device */
@@ -2272,6 +2282,15 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #endif
   const bool lead_cls = rgb_lead_class(cls);              /* append_entries_reply, append, pipeline_rpcs */
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
+#if defined(RGB_X_TRAIN_TIMELINE) && !defined(RGB_HOST_EMULATION)
+  /* EXPERIMENT build (tools/train_timeline.py): per-wavefront wall-clock stamps of a train launch */
+  u64 tt[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned tt_spins = 0;
+#define RGB_TT(k) do { if (TR) tt[k] = wall_clock64(); } while (0)
+#else
+#define RGB_TT(k) do { } while (0)
+#endif
+  RGB_TT(0);
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
   {
     /* four 1 KiB global -> LDS copies in flight (read once: non-temporal), no staging registers and no ds_write
@@ -2298,6 +2317,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   const u32 mswz = (lane >> 2) & 3u;
   const ulonglong2 m0 = io[lane * 4 + (0 ^ mswz)], m1 = io[lane * 4 + (1 ^ mswz)],
                    m2 = io[lane * 4 + (2 ^ mswz)], m3 = io[lane * 4 + (3 ^ mswz)];
+  RGB_TT(1);
   const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
   /* the message addresses a server (a NOP or an out-of-range id touches no state and has no stamp) */
   const bool has_srv = TR && active && sv < dev.n_servers && ((m0.x >> 32) & 0xFFull) != RGB_MSG_NOP;
@@ -2328,12 +2348,21 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
       }
       if (__ballot(late) == 0ull) break;
       spins += 1;
+#if defined(RGB_X_TRAIN_TIMELINE) && !defined(RGB_HOST_EMULATION)
+      tt_spins = spins;
+#endif
       bool give_up = spins > RGB_TRAIN_SPIN_LIMIT;
 #ifndef RGB_HOST_EMULATION
       if ((spins & 15u) == 0u && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) give_up = true;
-      __builtin_amdgcn_s_sleep(32);                       /* ~1 us */
-      if (spins > 4u) __builtin_amdgcn_s_sleep(127);      /* ~4 us more */
-      if (spins > 32u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+#ifndef RGB_TRAIN_SLEEP
+#define RGB_TRAIN_SLEEP 32                                /* x 64 clocks: ~1 us */
+#endif
+#ifndef RGB_TRAIN_BACKOFF
+#define RGB_TRAIN_BACKOFF 1
+#endif
+      __builtin_amdgcn_s_sleep(RGB_TRAIN_SLEEP);
+      if (RGB_TRAIN_BACKOFF && spins > 4u) __builtin_amdgcn_s_sleep(127);      /* ~4 us more */
+      if (RGB_TRAIN_BACKOFF && spins > 32u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
 #endif
       if (give_up) {                                      /* uniform: the decisions of this slice stay unwritten */
         if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_SPIN);
@@ -2345,6 +2374,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
    * an instruction touches 8 lines instead of 64 (the CU's L1 looks up one line per cycle); the lines
    * reach their owners through LDS rows that overlay the record staging area (the messages are in
    * registers by now), and process_message reads its row from LDS piece by piece, when it needs it. */
+  RGB_TT(2);
   constexpr bool PRE = true;
 #ifdef RGB_X_TRAIN_PLAINROWS      /* EXPERIMENT (breaks parity): the train's rows through the L1 like the per-tick kernel's */
   constexpr int ROWS = GLDS_DEFAULT;
@@ -2409,6 +2439,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     glds_wait();
   }
   lds_barrier();
+  RGB_TT(3);
   const ulonglong2 *hrow = io + lane * 8;
   const unsigned hswz = (lane >> 1) & 7u;
   const ulonglong2 *prow = (PEERS_LDS && lead_cls) ? io + 4 * RGB_TICK_BLOCK + lane * 8 : nullptr;
@@ -2468,6 +2499,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     for (int k = 0; k < RGB_X_EXTRA_STORE / 16; ++k) ST16(xs + k, make_ulonglong2(d.w[0], d.w[1] + (u64)k));
   }
 #endif
+  RGB_TT(4);
 #ifdef RGB_X_TRAIN_NOSTAMP        /* EXPERIMENT (breaks parity): no publish step */
   if (false) {
 #else
@@ -2480,6 +2512,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #endif
     if (has_srv && seqp != nullptr) *seqp = (unsigned char)(need + 1u);
   }
+  RGB_TT(5);
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
   if (active) {
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
@@ -2497,6 +2530,14 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     /* decisions are never re-read on the device: non-temporal (measured -5 % per tick) */
     if (j < cnt) store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
   }
+#if defined(RGB_X_TRAIN_TIMELINE) && !defined(RGB_HOST_EMULATION)
+  if (TR && dev.dbg_buf != nullptr && lane == 0 && blockIdx.x < (1u << 20)) {
+    u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 8;
+    tt[6] = wall_clock64();
+    for (int k = 0; k < 7; ++k) o[k] = tt[k];
+    o[7] = (u64)(unsigned)cls | ((u64)cnt << 8) | ((u64)tt_spins << 32) | ((u64)rgb_xcc_id() << 56);
+  }
+#endif
 #ifdef RGB_PROFILE
   if (!TR && RGB_KNOB(dev, 16u)) {
     /* run-table words read per lane: wave maximum, sum, lanes that read any */
@@ -2560,10 +2601,11 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
  * Coherence: the per-XCD L2s are not coherent with each other, so everything that touches a server must run on ONE
  * XCD for the life of the launch.  Servers are sharded by group (shard = group mod 8), every tick's messages are
  * ordered by (class, shard) -- rgb_synth / the plan carry the per-shard offsets -- and block b of the grid serves
- * shard b mod 8: the dispatcher places block b on XCD b mod 8 (observed behaviour, not a contract -- so it is
- * CHECKED: rgb_train_calibrate_kernel records once per context which XCC id blocks b mod 8 = x run on, xcc_map carries
- * that to every launch, and a block that finds itself elsewhere fails the launch with RGB_TRAIN_ERR_PLACEMENT
- * instead of computing on stale lines; the check is one s_getreg and a compare).  Within an XCD the L2 is the
+ * shard b mod 8: the dispatcher deals the blocks of a launch round robin over the XCDs, block b on XCD (b + r) mod 8
+ * with r fixed per launch (observed behaviour, not a contract -- so it is CHECKED: rgb_train_calibrate_kernel tells
+ * once per context whether the device behaves like that at all, and in every launch one block in 64 per shard
+ * records (XCC id - shard) mod 8 and fails the launch with RGB_TRAIN_ERR_PLACEMENT when it is not the value the others
+ * saw, instead of computing on stale lines).  Within an XCD the L2 is the
  * coherence point: state stores are plain (write-through L1, line kept in the L2), state loads are L2-served.
  *
  * Progress: a wavefront only ever waits for messages of EARLIER ticks, whose blocks come earlier in the grid; blocks
@@ -2576,20 +2618,11 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #ifndef RGB_TRAIN_MIN_WAVES
 #define RGB_TRAIN_MIN_WAVES(N) RGB_CLASS_MIN_WAVES(N)
 #endif
-__device__ __forceinline__ u32 rgb_xcc_id() {
-#ifdef RGB_HOST_EMULATION
-  return 0;
-#else
-  u32 xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-  return xcc;
-#endif
-}
 template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(
     rgb_dev dev, const rgb_msg *__restrict__ msgs, const unsigned char *__restrict__ stamps, u32 tick_stride,
     const rgb_train_tick *__restrict__ plan, u32 bpt, rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs,
-    u32 rpc_ring, u32 index_base, u32 xcc_map, u32 *__restrict__ ctl) {
+    u32 rpc_ring, u32 index_base, u32 *__restrict__ ctl) {
   __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];
   const u32 t = blockIdx.x / bpt, j = blockIdx.x - t * bpt;
   const u32 x = j & (RGB_TRAIN_SHARDS - 1u), row = j / RGB_TRAIN_SHARDS;
@@ -2606,20 +2639,26 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   if (lbase >= ncls) return;
   const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
 #ifndef RGB_HOST_EMULATION
-  if (rgb_xcc_id() != ((xcc_map >> (4u * x)) & 0xFu)) {     /* not where this shard's lines are coherent */
-    if (threadIdx.x == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
-    return;
-  }
+  /* placement check, sampled (one block in 64 per shard: an atomic per block costs more than the tick) and off the
+   * critical path: (XCC id - shard) mod 8 -- the rotation of this launch's round robin -- must be ONE value */
+  u32 rot_seen = 0, rot_bit = 0;
+  const bool sampled = (row & 63u) == 0u && threadIdx.x == 0;
+  if (sampled) { rot_bit = 1u << ((rgb_xcc_id() - x) & (RGB_TRAIN_SHARDS - 1u)); rot_seen = atomicOr(ctl + 1, rot_bit); }
+#endif
+#if defined(RGB_X_TRAIN_PRIO) && !defined(RGB_HOST_EMULATION)
+  if (rgb_lead_class(cls)) __builtin_amdgcn_s_setprio(3);   /* EXPERIMENT: the leader-side chain first */
 #endif
   const size_t toff = (size_t)t * tick_stride;
   rgb_rpc *rp = rpcs ? rpcs + (size_t)(t % rpc_ring) * tick_stride * (N > 1 ? N - 1 : 1) : nullptr;
   rgb_tick_slice<N, true>(dev, io, cls, off + lbase, cnt, SL, msgs + toff, dec + toff, rp, 0, index_base + (u32)toff,
                           ctl, stamps + toff);
+#ifndef RGB_HOST_EMULATION
+  if (sampled && ((rot_seen | rot_bit) & ((rot_seen | rot_bit) - 1u)) != 0u) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
+#endif
 }
 
-/* once per context: out[x] |= 1 << (XCC id of a block with blockIdx mod 8 = x).  The host accepts the map when
- * every entry has exactly one bit and no two shards share... (sharing an XCD would still be coherent; two XCDs for one
- * shard is what must not happen) */
+/* once per context: out[x] |= 1 << (XCC id of a block with blockIdx mod 8 = x) over one launch.  The host accepts
+ * the device when every entry has exactly one bit (two XCDs for one shard is what must not happen) */
 __global__ void rgb_train_calibrate_kernel(u32 *__restrict__ out) {
   if (threadIdx.x == 0) atomicOr(out + (blockIdx.x & (RGB_TRAIN_SHARDS - 1u)), 1u << rgb_xcc_id());
 }
@@ -3283,15 +3322,18 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
 
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs,
-                     u32 rpc_ring, u32 index_base, u32 xcc_map, u32 *d_ctl, void *stream) {
+                     u32 rpc_ring, u32 index_base, u32 *d_ctl, void *stream) {
   if (n_ticks == 0 || bpt == 0) return 0;
   if (bpt % RGB_TRAIN_SHARDS || n_ticks > RGB_TRAIN_MAX_TICKS) return -1;
   hipStream_t st = (hipStream_t)stream;
+  /* the rotation mask is per launch; the error word (d_ctl[0]) is sticky until rgb_train_status reads it */
+  hipError_t e = hipMemsetAsync(d_ctl + 1, 0, sizeof(u32), st);
+  if (e != hipSuccess) return (int)e;
   dim3 grid(n_ticks * bpt), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                                      \
   case NN:                                                                                              \
     hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, dev, d_msgs, d_stamps, tick_stride, d_plan, bpt, \
-                       d_dec, d_rpcs, rpc_ring ? rpc_ring : 1u, index_base, xcc_map, d_ctl);            \
+                       d_dec, d_rpcs, rpc_ring ? rpc_ring : 1u, index_base, d_ctl);                     \
     break;
   switch (dev.n_members) {
     RGB_LAUNCH_ALL_N

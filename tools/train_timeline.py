@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Per-wavefront timeline of ONE train launch (variant built with -DRGB_X_TRAIN_TIMELINE, tools/build_variants.sh):
+where a wavefront's life goes -- message load, dependency wait, row fetch, clause code, publish, decision store --
+per class, and the cadence of the ticks.   usage (GPU box): RGB_LIB=.../variants/timeline.so python tools/train_timeline.py"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ra_amd import abi, engine, workload as W
+G, N = int(os.environ.get("TL_GROUPS", "65536")), 5
+T, AGE = int(os.environ.get("TL_TICKS", "16")), int(os.environ.get("TL_AGE", "128"))
+S = G * N; tb = S * 64
+eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
+eng.set_state(0, W.initial_states(G, N, 0x5EED0003))
+stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); sp = stream.cuda_stream
+dm = torch.empty(T * tb, dtype=torch.uint8, device="cuda"); dd = torch.empty(T * tb, dtype=torch.uint8, device="cuda")
+dr = torch.empty(4 * S * 4 * 56, dtype=torch.uint8, device="cuda")
+dn = torch.zeros(T, dtype=torch.int32, device="cuda"); bc = torch.zeros(T * 256, dtype=torch.int32, device="cuda")
+for t in range(AGE):
+    eng.synth_tick_buckets_device(0x5EED0003, t, dm.data_ptr(), 0, 0, 0, sp)
+    eng.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), sp)
+torch.cuda.synchronize()
+st = eng.get_state()
+for t in range(T):
+    eng.synth_tick_buckets_device(0x5EED0003, AGE + t, dm.data_ptr() + t * tb, 0, dn.data_ptr() + t * 4, bc.data_ptr() + t * 1024, sp)
+    eng.synth_apply_tick_device(dm.data_ptr() + t * tb, S, dd.data_ptr() + t * tb, dr.data_ptr(), sp)
+torch.cuda.synchronize()
+counts = dn.cpu().numpy().astype(np.uint32)
+plan = eng.train_plan(bc.cpu().numpy().reshape(T, 256).astype(np.uint32))
+ds = torch.zeros(T * S, dtype=torch.uint8, device="cuda")
+for rep in range(2):                      # the second run is the one read back (warm instruction caches)
+    eng.set_state(0, st)
+    eng.train_stamp_device(dm.data_ptr(), ds.data_ptr(), S, counts, sp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    eng.train_run_device(plan, 0, T, dm.data_ptr(), ds.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), 4, sp)
+    e1.record(stream)
+    torch.cuda.synchronize()
+print("train of", T, "ticks:", round(e0.elapsed_time(e1) * 1e3 / T, 2), "us per tick; flags", eng.train_status(check=False)[0],
+      "blocks per tick", plan.blocks_per_tick)
+nblk = T * plan.blocks_per_tick
+buf = np.zeros(nblk * 8, dtype=np.uint64)
+L = engine.lib(); L.rgb_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+assert L.rgb_debug_read(eng._h, buf.ctypes.data, len(buf)) == 0
+b = buf.reshape(nblk, 8)
+tick_of = np.arange(nblk) // plan.blocks_per_tick
+ok = b[:, 0] > 0
+b, tick_of = b[ok], tick_of[ok]
+ts = b[:, :7].astype(np.int64); z = ts[:, 0].min()
+us = (ts - z) * 0.01                                    # wall_clock64 = 100 MHz
+cls = (b[:, 7] & np.uint64(0xFF)).astype(int); spins = ((b[:, 7] >> np.uint64(32)) & np.uint64(0xFFFFFF)).astype(int)
+names = {0: "aer", 1: "aer_reply", 2: "written", 3: "append", 4: "pipeline", 5: "req_vote", 6: "vote_res", 8: "el_timeout",
+         10: "pre_vote_res", 11: "snap_written", 12: "hb_rpc", 13: "hb_reply", 14: "query"}
+print("span of the launch: %.1f us; wavefronts %d" % (us[:, 6].max(), len(b)))
+print("per tick: first start / median publish / last end (us), per-tick cadence of the median publish")
+prev = None
+for t in range(T):
+    m = tick_of == t
+    mp = np.median(us[m, 5])
+    print(f"  tick {t:2d}: start {us[m,0].min():7.1f}  publish p50 {mp:7.1f} p99 {np.percentile(us[m,5],99):7.1f}  end {us[m,6].max():7.1f}"
+          + (f"  cadence {mp-prev:5.1f}" if prev is not None else ""))
+    prev = mp
+mid = (tick_of >= 4) & (tick_of < T - 2)
+print("steady ticks (4..T-3), per class: waves | msg load | dep wait (spins p50/p90) | row fetch | clause | publish | dec store | life  (medians, us)")
+for c in sorted(set(cls)):
+    m = mid & (cls == c)
+    if not m.any(): continue
+    d = np.diff(us[m], axis=1)
+    md = np.median(d, axis=0); p9 = np.percentile(d, 90, axis=0)
+    print(f"  {names.get(c, c):>12}: {m.sum():6d} | {md[0]:5.2f} | {md[1]:5.2f} p90 {p9[1]:5.2f} ({np.median(spins[m]):.0f}/{np.percentile(spins[m],90):.0f}) | {md[2]:5.2f} | "
+          f"{md[3]:5.2f} p90 {p9[3]:5.2f} | {md[4]:5.2f} | {md[5]:5.2f} | {np.median(us[m,6]-us[m,0]):5.2f}")
+# resident wavefronts over time
+print("wavefronts in flight / waiting on dependencies, every 10 us:")
+for x in np.arange(0, us[:, 6].max(), 10.0):
+    infl = ((us[:, 0] <= x) & (us[:, 6] > x)).sum(); wait = ((us[:, 1] <= x) & (us[:, 2] > x)).sum()
+    print(f"  t={x:6.0f}  in flight {infl:5d}  waiting {wait:5d}")
