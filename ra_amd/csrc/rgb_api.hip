@@ -95,6 +95,7 @@ struct rgb_ctx {
 /* the device plan of a train: one rgb_train_tick per tick */
 struct rgb_train_plan {
   rgb_train_tick *d_ticks = nullptr;
+  u32 *d_rows = nullptr;  /* [n_ticks][bpt / RGB_TRAIN_SHARDS]: class << 24 | row of the class */
   u32 n_ticks = 0;
   u32 bpt = 0;            /* blocks per tick: RGB_TRAIN_SHARDS x the longest tick's rows */
 };
@@ -624,7 +625,8 @@ int rgb_synth_tick_buckets_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, vo
   if (!ctx || !d_msgs) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   void *st = stream ? stream : (void *)ctx->stream;
-  if (!ctx->d_synth) HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth, RGB_SYNTH_SCRATCH_WORDS * sizeof(u32)));
+  if (!ctx->d_synth)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth, (size_t)rgb_synth_scratch_words(ctx->dev.n_servers / ctx->dev.n_members) * sizeof(u32)));
   int rc = rgb_launch_synth(ctx->dev, seed, tick, (rgb_msg *)d_msgs, ctx->d_synth, (u32 *)d_kind_counts,
                             (u32 *)d_n, (u32 *)d_bucket_counts, st);
   if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
@@ -682,18 +684,24 @@ int rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t 
   std::vector<rgb_train_tick> ticks(n_ticks);
   u32 rows = 0;
   for (u32 t = 0; t < n_ticks; ++t) {
-    const u32 r = rgb_train_make_tick(bucket_counts + (size_t)t * RGB_N_BUCKETS, ctx->dev.n_members, &ticks[t]);
+    const u32 r = rgb_train_make_tick(bucket_counts + (size_t)t * RGB_N_BUCKETS, ctx->dev.n_members, &ticks[t], nullptr, 0);
     if (r > rows) rows = r;
   }
+  std::vector<u32> tab((size_t)n_ticks * rows, 0xFFFFFFFFu);
+  for (u32 t = 0; t < n_ticks; ++t)
+    rgb_train_make_tick(bucket_counts + (size_t)t * RGB_N_BUCKETS, ctx->dev.n_members, &ticks[t], tab.data() + (size_t)t * rows, rows);
   p->n_ticks = n_ticks;
   p->bpt = rows * RGB_TRAIN_SHARDS;
-  if (n_ticks) {
+  if (n_ticks && rows) {
     hipError_t e = hipMalloc((void **)&p->d_ticks, (size_t)n_ticks * sizeof(rgb_train_tick));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_rows, tab.size() * sizeof(u32));
     if (e == hipSuccess)
       e = hipMemcpy(p->d_ticks, ticks.data(), (size_t)n_ticks * sizeof(rgb_train_tick), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_rows, tab.data(), tab.size() * sizeof(u32), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       ctx->last_hip.store((int)e, std::memory_order_relaxed);
       if (p->d_ticks) (void)hipFree(p->d_ticks);
+      if (p->d_rows) (void)hipFree(p->d_rows);
       delete p;
       return RGB_E_HIP;
     }
@@ -705,6 +713,7 @@ int rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t 
 void rgb_train_plan_destroy(rgb_train_plan *plan) {
   if (!plan) return;
   if (plan->d_ticks) (void)hipFree(plan->d_ticks);
+  if (plan->d_rows) (void)hipFree(plan->d_rows);
   delete plan;
 }
 
@@ -746,7 +755,8 @@ int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t firs
     const u32 n = first_tick + n_ticks - t < per ? first_tick + n_ticks - t : per;
     const size_t off = (size_t)t * tick_stride;
     int rc = rgb_launch_train(ctx->dev, (const rgb_msg *)d_msgs + off, (const unsigned char *)d_stamps + off,
-                              tick_stride, plan->d_ticks + t, n, plan->bpt, (rgb_decision *)d_decisions + off,
+                              tick_stride, plan->d_ticks + t, plan->d_rows + (size_t)t * (plan->bpt / RGB_TRAIN_SHARDS), n,
+                              plan->bpt, (rgb_decision *)d_decisions + off,
                               (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, st);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }

@@ -132,15 +132,18 @@ static inline __host__ __device__ unsigned rgb_seq_index(unsigned server, unsign
   return (g & (RGB_TRAIN_SHARDS - 1u)) * seq_stride + (g / RGB_TRAIN_SHARDS) * n_members + m;
 }
 #define RGB_TRAIN_MAX_TICKS 255u   /* ticks per launch: the values a sequence byte takes within one launch are distinct */
-/* one tick of a train: rows of RGB_TRAIN_SHARDS blocks; row r of class position q serves slice r of every shard */
+/* one tick of a train: rows of RGB_TRAIN_SHARDS blocks; row r of class c serves slice r of every shard (the row table
+ * of rgb_train_make_tick says which (class, row) a block row of the tick is) */
 struct rgb_train_tick {
-  u32 row_end[16];                              /* cumulative rows of class positions 0..14 ([15] = [14])  */
-  u32 off[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* first message of (class at position q, shard)           */
-  u32 cnt[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* its message count                                       */
+  u32 n_rows;
+  u32 pad[15];
+  u32 off[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* first message of (class, shard)  */
+  u32 cnt[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* its message count                */
 };
-/* words of the load generator's scratch: family totals (what rgb_tick_classes_kernel reads) | bucket totals |
- * bucket fill | bucket bases */
-#define RGB_SYNTH_SCRATCH_WORDS (RGB_N_FAMILIES + 3u * RGB_N_BUCKETS)
+/* the load generator's scratch: RGB_SYNTH_FIXED_WORDS (family totals -- what rgb_tick_classes_kernel reads -- |
+ * bucket totals | bucket bases) + RGB_N_BUCKETS words per generator block (64 groups): rgb_synth_scratch_words() */
+#define RGB_SYNTH_FIXED_WORDS (RGB_N_FAMILIES + 2u * RGB_N_BUCKETS)
+u32 rgb_synth_scratch_words(u32 n_groups);
 
 static inline __host__ __device__ unsigned rgb_peer_stride(unsigned n_members) {
   return (3u * n_members + 7u) & ~7u;
@@ -180,23 +183,24 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
                             const u32 *d_family_totals, u32 max_msgs, rgb_decision *d_dec, rgb_rpc *d_rpcs,
                             u32 rpc_slot_base, u32 msg_index_base, void *stream);
 /* d_scratch: 2*RGB_N_FAMILIES u32 of device scratch */
-/* d_scratch: RGB_SYNTH_SCRATCH_WORDS u32; d_bucket_counts (may be NULL): RGB_N_BUCKETS u32 of this tick */
+/* d_scratch: rgb_synth_scratch_words(groups) u32; d_bucket_counts (may be NULL): RGB_N_BUCKETS u32 of this tick */
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
                      u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream);
 /* ticks [0, n_ticks) of d_plan in one launch (n_ticks <= RGB_TRAIN_MAX_TICKS); bpt = blocks per tick (multiple of
- * RGB_TRAIN_SHARDS); d_stamps: one byte per message, laid out like d_msgs; d_rpcs (may be NULL): rpc_ring tick-sized
+ * RGB_TRAIN_SHARDS); d_row_tab: bpt / RGB_TRAIN_SHARDS words per tick; d_stamps: one byte per message, laid out like d_msgs; d_rpcs (may be NULL): rpc_ring tick-sized
  * regions, tick t uses region t mod rpc_ring; rgb_rpc.msg_index = index_base + t * tick_stride + i; d_ctl: word 0 =
  * sticky error flags, word 1 = this launch's placement rotation mask (zeroed here) */
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
-                     const rgb_train_tick *d_plan, u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs,
-                     u32 rpc_ring, u32 index_base, u32 *d_ctl, void *stream);
+                     const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
+                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, void *stream);
 /* stamps of the n messages of one tick from the running counters d_seq_cnt (ticks in train order) */
 int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt,
                          unsigned char *d_stamps, void *stream);
 /* d_out: RGB_TRAIN_SHARDS u32, zeroed by the caller: bit k of word x = a block with blockIdx mod 8 = x ran on XCC k */
 int rgb_launch_train_calibrate(u32 *d_out, void *stream);
-/* host: the plan of one tick from its bucket counts (uint32[RGB_N_BUCKETS]); returns the tick's rows */
-u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out);
+/* host: the plan of one tick from its bucket counts (uint32[RGB_N_BUCKETS]); returns the tick's rows; row_tab (may be
+ * NULL: count only) receives them when they fit row_cap */
+u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap);
 int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream);
 int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u32 n, void *stream);
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream);

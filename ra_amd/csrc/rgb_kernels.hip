@@ -2612,37 +2612,39 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
  * are dispatched in order per XCD, so whatever a resident wavefront waits for is resident or done.  The poll is
  * bounded all the same (RGB_TRAIN_ERR_SPIN).
  *
- * Block b: tick t = b / bpt, j = b mod bpt, shard x = j mod 8, row = j / 8; plan[t] maps the row to a class position
- * (heaviest classes first, like the per-tick plan) and the (class, shard) pair to its message range.  Surplus blocks
- * (rows past the tick's last, slices past a shard's count) exit at once. */
+ * Block b: tick t = b / bpt, j = b mod bpt, shard x = j mod 8, row = j / 8; row_tab maps the row to (class, slice of
+ * the class) -- the classes interleaved by relative position, rgb_train_make_tick -- and plan[t] the (class, shard)
+ * pair to its message range.  Surplus blocks (rows past the tick's last, slices past a shard's count) exit at once. */
 #ifndef RGB_TRAIN_MIN_WAVES
 #define RGB_TRAIN_MIN_WAVES(N) RGB_CLASS_MIN_WAVES(N)
 #endif
 template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(
     rgb_dev dev, const rgb_msg *__restrict__ msgs, const unsigned char *__restrict__ stamps, u32 tick_stride,
-    const rgb_train_tick *__restrict__ plan, u32 bpt, rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs,
-    u32 rpc_ring, u32 index_base, u32 *__restrict__ ctl) {
+    const rgb_train_tick *__restrict__ plan, const u32 *__restrict__ row_tab, u32 bpt, rgb_decision *__restrict__ dec,
+    rgb_rpc *__restrict__ rpcs, u32 rpc_ring, u32 index_base, u32 *__restrict__ ctl) {
   __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];
   const u32 t = blockIdx.x / bpt, j = blockIdx.x - t * bpt;
   const u32 x = j & (RGB_TRAIN_SHARDS - 1u), row = j / RGB_TRAIN_SHARDS;
   const rgb_train_tick *p = plan + t;
-  if (row >= p->row_end[RGB_N_CLASSES - 1]) return;
-  u32 q = 0;
-#pragma unroll
-  for (int i = 0; i < RGB_N_CLASSES - 1; ++i) q += row >= p->row_end[i] ? 1u : 0u;
-  const u32 off = p->off[q][x], ncls = p->cnt[q][x];
-  const int cls = rgb_class_at(q);
+  if (row >= p->n_rows) return;
+  const u32 e = row_tab[(size_t)t * (bpt / RGB_TRAIN_SHARDS) + row];
+  const int cls = (int)(e >> 24);
+  const u32 off = p->off[cls][x], ncls = p->cnt[cls][x];
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
   const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
-  const u32 lbase = (row - (q ? p->row_end[q - 1] : 0u)) * SL;
+  const u32 lbase = (e & 0xFFFFFFu) * SL;
   if (lbase >= ncls) return;
   const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
 #ifndef RGB_HOST_EMULATION
   /* placement check, sampled (one block in 64 per shard: an atomic per block costs more than the tick) and off the
    * critical path: (XCC id - shard) mod 8 -- the rotation of this launch's round robin -- must be ONE value */
   u32 rot_seen = 0, rot_bit = 0;
+#ifdef RGB_X_TRAIN_NOCAS
+  const bool sampled = false;                 /* EXPERIMENT: no placement check */
+#else
   const bool sampled = (row & 63u) == 0u && threadIdx.x == 0;
+#endif
   if (sampled) { rot_bit = 1u << ((rgb_xcc_id() - x) & (RGB_TRAIN_SHARDS - 1u)); rot_seen = atomicOr(ctl + 1, rot_bit); }
 #endif
 #if defined(RGB_X_TRAIN_PRIO) && !defined(RGB_HOST_EMULATION)
@@ -2908,53 +2910,59 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
 /* The tick comes out ordered by BUCKET = (class of the message kind, shard of the group, success flag): class-major,
  * so every kernel class is one contiguous range (what the per-tick class kernel needs; inside it the failed and the
  * successful replies still sit in runs), and inside a class the messages of one shard (group mod RGB_TRAIN_SHARDS)
- * are contiguous -- what a train launch needs (rgb_train_kernel).  Scratch words (zeroed by the launcher per tick):
- * fam_total[RGB_N_FAMILIES] | bkt_total[RGB_N_BUCKETS] | bkt_fill[RGB_N_BUCKETS] | bkt_base[RGB_N_BUCKETS].
- * Pass 1 (WRITE = false) counts per bucket, rgb_synth_scan_kernel turns the totals into bases (and the family
- * totals, the per-kind counts and the tick's size), pass 2 recomputes the messages (same counter-based PRNG) and
- * writes each one at bucket base + block reservation + rank. */
+ * are contiguous -- what a train launch needs (rgb_train_kernel).  Inside a bucket the messages are in GROUP order
+ * (by generator block = 64 consecutive groups), the same in every tick: a server's messages sit at the same relative
+ * position of their buckets tick after tick, which is what lets a train's ticks follow each other at a constant lag.
+ * Scratch words (zeroed by the launcher per tick): fam_total[RGB_N_FAMILIES] | bkt_total[RGB_N_BUCKETS] |
+ * bkt_base[RGB_N_BUCKETS] | blk_cnt[blocks][RGB_N_BUCKETS] (pass 1: per-block counts; after the scan: per-block bases).
+ * Pass 1 (WRITE = false) counts per block and bucket, rgb_synth_scan_kernel turns the counts into bases (and the
+ * family totals, the per-kind counts and the tick's size), pass 2 recomputes the messages (same counter-based PRNG)
+ * and writes each one at its block's base + rank. */
 template <int N, bool WRITE>
 __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u64 tick, rgb_msg *__restrict__ out,
                                                        u32 *__restrict__ scratch) {
-  __shared__ u32 cnt[RGB_N_BUCKETS], base[RGB_N_BUCKETS], rank[RGB_N_BUCKETS];
-  u32 *bkt_total = scratch + RGB_N_FAMILIES, *bkt_fill = bkt_total + RGB_N_BUCKETS, *bkt_base = bkt_fill + RGB_N_BUCKETS;
+  __shared__ u32 cnt[RGB_N_BUCKETS], rank[RGB_N_BUCKETS];
+  u32 *blk = scratch + RGB_SYNTH_FIXED_WORDS + (size_t)blockIdx.x * RGB_N_BUCKETS;
   for (u32 b = threadIdx.x; b < RGB_N_BUCKETS; b += blockDim.x) { cnt[b] = 0; rank[b] = 0; }
   __syncthreads();
   const u32 G = dev.n_servers / N;
   const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
   auto bucket = [](const SynMsg &m) -> unsigned { return rgb_bucket(m.kind, m.flags, m.server, (unsigned)N); };
-  if (g < G) synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) { atomicAdd(&cnt[bucket(m)], 1u); });
-  __syncthreads();
   if (!WRITE) {
-    for (u32 b = threadIdx.x; b < RGB_N_BUCKETS; b += blockDim.x)
-      if (cnt[b]) atomicAdd(&bkt_total[b], cnt[b]);
+    if (g < G) synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) { atomicAdd(&cnt[bucket(m)], 1u); });
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < RGB_N_BUCKETS; b += blockDim.x) blk[b] = cnt[b];
     return;
   }
-  for (u32 b = threadIdx.x; b < RGB_N_BUCKETS; b += blockDim.x) {
-    const u32 mine = cnt[b];
-    base[b] = bkt_base[b] + (mine ? atomicAdd(&bkt_fill[b], mine) : 0u);
-  }
-  __syncthreads();
   if (g < G)
     synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) {
       const unsigned b = bucket(m);
-      const u32 slot = base[b] + atomicAdd(&rank[b], 1u);
+      const u32 slot = blk[b] + atomicAdd(&rank[b], 1u);
       syn_store(out + slot, m);
     });
 }
 
-/* between the passes (one block of RGB_N_BUCKETS threads): bucket bases = exclusive scan of the totals */
-__global__ void rgb_synth_scan_kernel(u32 *__restrict__ scratch, u32 *__restrict__ kind_counts, u32 *__restrict__ d_n,
-                                      u32 *__restrict__ bucket_counts) {
+/* between the passes (one block of RGB_N_BUCKETS threads): per-block counts -> per-block bases, bucket by bucket */
+__global__ void rgb_synth_scan_kernel(u32 *__restrict__ scratch, u32 n_blocks, u32 *__restrict__ kind_counts,
+                                      u32 *__restrict__ d_n, u32 *__restrict__ bucket_counts) {
   __shared__ u32 tot[RGB_N_BUCKETS];
-  u32 *fam_total = scratch, *bkt_total = scratch + RGB_N_FAMILIES, *bkt_base = bkt_total + 2 * RGB_N_BUCKETS;
+  u32 *fam_total = scratch, *bkt_total = scratch + RGB_N_FAMILIES, *bkt_base = bkt_total + RGB_N_BUCKETS;
+  u32 *blk = scratch + RGB_SYNTH_FIXED_WORDS;
   const u32 b = threadIdx.x;
-  tot[b] = bkt_total[b];
-  if (bucket_counts != nullptr) bucket_counts[b] = tot[b];
+  u32 sum = 0;
+  for (u32 k = 0; k < n_blocks; ++k) sum += blk[(size_t)k * RGB_N_BUCKETS + b];
+  tot[b] = sum;
+  bkt_total[b] = sum;
+  if (bucket_counts != nullptr) bucket_counts[b] = sum;
   __syncthreads();
   u32 acc = 0;
   for (u32 k = 0; k < b; ++k) acc += tot[k];
   bkt_base[b] = acc;
+  for (u32 k = 0; k < n_blocks; ++k) {
+    const u32 c = blk[(size_t)k * RGB_N_BUCKETS + b];
+    blk[(size_t)k * RGB_N_BUCKETS + b] = acc;
+    acc += c;
+  }
   if (b < RGB_N_FAMILIES) {      /* family b = (class b / 2, flag b & 1) */
     u32 f = 0;
     for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) f += tot[((b >> 1) * RGB_TRAIN_SHARDS + x) * 2u + (b & 1u)];
@@ -3271,18 +3279,21 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
   return (int)hipGetLastError();
 }
 
+u32 rgb_synth_scratch_words(u32 n_groups) { return RGB_SYNTH_FIXED_WORDS + ((n_groups + 63u) / 64u) * RGB_N_BUCKETS; }
+
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
                      u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   const u32 G = dev.n_servers / dev.n_members;
-  dim3 grid((G + 63) / 64), block(64);
-  hipError_t e = hipMemsetAsync(d_scratch, 0, RGB_SYNTH_SCRATCH_WORDS * sizeof(u32), st);
+  const u32 nblk = (G + 63) / 64;
+  dim3 grid(nblk), block(64);
+  hipError_t e = hipMemsetAsync(d_scratch, 0, RGB_SYNTH_FIXED_WORDS * sizeof(u32), st);
   if (e != hipSuccess) return (int)e;
 #define LAUNCH(NN)                                                                                     \
   case NN:                                                                                             \
     hipLaunchKernelGGL((rgb_synth_kernel<NN, false>), grid, block, 0, st, dev, seed, tick, d_msgs, d_scratch); \
-    hipLaunchKernelGGL(rgb_synth_scan_kernel, dim3(1), dim3(RGB_N_BUCKETS), 0, st, d_scratch, d_kind_counts, d_n, \
-                       d_bucket_counts);                                                               \
+    hipLaunchKernelGGL(rgb_synth_scan_kernel, dim3(1), dim3(RGB_N_BUCKETS), 0, st, d_scratch, nblk, d_kind_counts, \
+                       d_n, d_bucket_counts);                                                          \
     hipLaunchKernelGGL((rgb_synth_kernel<NN, true>), grid, block, 0, st, dev, seed, tick, d_msgs, d_scratch); \
     break;
   switch (dev.n_members) {
@@ -3293,36 +3304,54 @@ int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u3
   return (int)hipGetLastError();
 }
 
-/* the plan of one train tick from its bucket counts: class positions heaviest-first (rgb_class_at), rows of
- * RGB_TRAIN_SHARDS blocks, a class takes as many rows as its fullest shard has slices */
-u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out) {
-  u32 off[RGB_N_CLASSES + 1][RGB_TRAIN_SHARDS], cnt[RGB_N_CLASSES + 1][RGB_TRAIN_SHARDS];
+/* The plan of one train tick from its bucket counts.  A class takes as many ROWS (of RGB_TRAIN_SHARDS blocks) as its
+ * fullest shard has slices; row j of class c serves slice j of every shard.  The rows of all classes are interleaved
+ * by RELATIVE POSITION (j + 1/2) / rows(c): buckets are in group order, so the messages of one group range sit at the
+ * same place of the block order whatever their class -- and a server's next message, whatever ITS class, comes one
+ * whole tick of blocks after the previous one: the wavefront that serves it finds its dependencies committed instead of
+ * holding a slot while it waits.  row_tab[k] = class << 24 | row of the class; returns the number of rows. */
+u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap) {
   u32 acc = 0;
-  for (unsigned c = 0; c <= RGB_N_CLASSES; ++c)
-    for (unsigned x = 0; x < RGB_TRAIN_SHARDS; ++x) {
-      const u32 n = bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u] + bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u + 1u];
-      off[c][x] = acc; cnt[c][x] = n; acc += n;
-    }
-  u32 rows = 0;
-  for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {
-    const int c = rgb_class_at(q);
-    const u32 sl = rgb_class_slice(c, n_members);
+  u32 rows_of[RGB_N_CLASSES];
+  for (unsigned c = 0; c <= RGB_N_CLASSES; ++c) {
     u32 need = 0;
     for (unsigned x = 0; x < RGB_TRAIN_SHARDS; ++x) {
-      out->off[q][x] = off[c][x]; out->cnt[q][x] = cnt[c][x];
-      const u32 r = (cnt[c][x] + sl - 1) / sl;
-      if (r > need) need = r;
+      const u32 n = bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u] + bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u + 1u];
+      if (c < RGB_N_CLASSES) {
+        out->off[c][x] = acc; out->cnt[c][x] = n;
+        const u32 sl = rgb_class_slice((int)c, n_members);
+        const u32 r = (n + sl - 1) / sl;
+        if (r > need) need = r;
+      }
+      acc += n;
     }
-    rows += need;
-    out->row_end[q] = rows;
+    if (c < RGB_N_CLASSES) rows_of[c] = need;
   }
-  out->row_end[15] = rows;
-  return rows;
+  u32 total = 0;
+  for (unsigned c = 0; c < RGB_N_CLASSES; ++c) total += rows_of[c];
+  out->n_rows = total;
+  if (row_tab == nullptr || total > row_cap) return total;
+  /* merge by key (j + 1/2) / rows(c) = (2j + 1) / (2 rows(c)), compared exactly as cross products */
+  u32 next[RGB_N_CLASSES] = {0};
+  for (u32 k = 0; k < total; ++k) {
+    int best = -1;
+    for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {       /* ties: the heavier class (rgb_class_at order) first */
+      const int c = rgb_class_at(q);
+      if (next[c] >= rows_of[c]) continue;
+      if (best < 0) { best = c; continue; }
+      const unsigned long long a = (2ull * next[c] + 1ull) * (2ull * rows_of[best]);
+      const unsigned long long b = (2ull * next[best] + 1ull) * (2ull * rows_of[c]);
+      if (a < b) best = c;
+    }
+    row_tab[k] = ((u32)best << 24) | next[best];
+    next[best] += 1;
+  }
+  return total;
 }
 
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
-                     const rgb_train_tick *d_plan, u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs,
-                     u32 rpc_ring, u32 index_base, u32 *d_ctl, void *stream) {
+                     const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
+                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, void *stream) {
   if (n_ticks == 0 || bpt == 0) return 0;
   if (bpt % RGB_TRAIN_SHARDS || n_ticks > RGB_TRAIN_MAX_TICKS) return -1;
   hipStream_t st = (hipStream_t)stream;
@@ -3332,8 +3361,8 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
   dim3 grid(n_ticks * bpt), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                                      \
   case NN:                                                                                              \
-    hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, dev, d_msgs, d_stamps, tick_stride, d_plan, bpt, \
-                       d_dec, d_rpcs, rpc_ring ? rpc_ring : 1u, index_base, d_ctl);                     \
+    hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, dev, d_msgs, d_stamps, tick_stride, d_plan,      \
+                       d_row_tab, bpt, d_dec, d_rpcs, rpc_ring ? rpc_ring : 1u, index_base, d_ctl);     \
     break;
   switch (dev.n_members) {
     RGB_LAUNCH_ALL_N

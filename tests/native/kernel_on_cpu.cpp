@@ -251,9 +251,9 @@ int emu_launch_checksum(void *h, uint32_t first, uint32_t n, uint64_t *out) {
 int emu_launch_leaderboard(void *h, rgb_leaderboard_row *rows) {
   return rgb_launch_leaderboard(((Emu *)h)->dev, rows, nullptr);
 }
-/* the load generator: scratch = RGB_SYNTH_SCRATCH_WORDS u32 (emu_synth_scratch_words), kind_counts =
- * RGB_MSG_KIND_MAX + 1 u32, bucket_counts (may be NULL) = RGB_N_BUCKETS u32 */
-uint32_t emu_synth_scratch_words(void) { return RGB_SYNTH_SCRATCH_WORDS; }
+/* the load generator: scratch = emu_synth_scratch_words(h) u32, kind_counts = RGB_MSG_KIND_MAX + 1 u32,
+ * bucket_counts (may be NULL) = RGB_N_BUCKETS u32 */
+uint32_t emu_synth_scratch_words(void *h) { const rgb_dev &d = ((Emu *)h)->dev; return rgb_synth_scratch_words(d.n_servers / d.n_members); }
 int emu_launch_synth(void *h, uint64_t seed, uint64_t tick, rgb_msg *msgs, uint32_t *scratch, uint32_t *kind_counts,
                      uint32_t *n_out, uint32_t *bucket_counts) {
   return rgb_launch_synth(((Emu *)h)->dev, seed, tick, msgs, scratch, kind_counts, n_out, bucket_counts, nullptr);

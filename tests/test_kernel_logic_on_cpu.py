@@ -188,6 +188,7 @@ def _bind_launchers(L):
     L.emu_launch_leaderboard.argtypes = [vp, vp]
     L.emu_launch_synth.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]
     L.emu_synth_scratch_words.restype = u32
+    L.emu_synth_scratch_words.argtypes = [vp]
     return L
 
 
@@ -280,7 +281,7 @@ def test_load_generator_and_device_sized_dispatch(emu_lib, oracle_lib, n_members
     seen = 0
     for t in range(ticks):
         msgs = np.zeros(S, dtype=abi.MSG_DTYPE)
-        scratch = np.zeros(emu.L.emu_synth_scratch_words(), dtype=np.uint32)
+        scratch = np.zeros(emu.L.emu_synth_scratch_words(emu.h), dtype=np.uint32)
         kc = np.zeros(abi.N_KINDS, dtype=np.uint32)
         n = np.zeros(1, dtype=np.uint32)
         bc = np.zeros(engine.TRAIN_BUCKETS, dtype=np.uint32)
@@ -297,6 +298,9 @@ def test_load_generator_and_device_sized_dispatch(emu_lib, oracle_lib, n_members
         assert np.all(np.diff(bk.astype(np.int64)) >= 0), "tick is not in bucket order"
         assert np.array_equal(np.bincount(bk, minlength=engine.TRAIN_BUCKETS), bc)
         assert np.all(np.diff(abi.family(m) // 2) >= 0), "classes are not contiguous"
+        # inside a bucket: group order at the generator's block granularity (64 groups), the same every tick
+        key = bk.astype(np.int64) * (1 << 32) + (m["server"] // N) // 64
+        assert np.all(np.diff(key) >= 0), "a bucket is not in group order"
         dec = np.zeros(S, dtype=abi.DECISION_DTYPE)
         assert emu.L.emu_launch_classes_dev(emu.h, msgs.ctypes.data, scratch.ctypes.data, S, dec.ctypes.data) == 0
         want, _ = cpu.step(m)

@@ -9,6 +9,7 @@ from collections import Counter, OrderedDict
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flags = [a for a in sys.argv[1:] if a.startswith("-")]
 N = os.environ.get("ONLY_N", "5")
+KERNEL = os.environ.get("KERNEL", "rgb_tick_classes_kernel")   # or rgb_train_kernel
 names = ["aer", "aer_reply", "written", "append", "pipeline_rpcs", "request_vote", "vote_result", "await_timeout",
          "election_timeout", "pre_vote_rpc", "pre_vote_result", "snapshot_written", "heartbeat_rpc", "heartbeat_reply",
          "consistent_query"]
@@ -22,7 +23,7 @@ inside, cur = False, "prologue"
 per = OrderedDict()
 meta = {}
 for l in lines:
-    if re.match(rf"^_ZN\S*rgb_tick_classes_kernelILi{N}E\S*:", l):
+    if re.match(rf"^_ZN\S*{KERNEL}ILi{N}E\S*:", l):
         inside = True; cur = "prologue"; continue
     if not inside:
         continue
