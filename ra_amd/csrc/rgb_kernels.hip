@@ -1945,6 +1945,29 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(hot);
   if (!RGB_KNOB(dev, 1u)) {
   if (L.n_runs < 2) { L.prs = 0; L.prt = 0; }         /* canonical: no run n-2 */
+#ifndef RGB_X_REREAD
+#define RGB_X_REREAD 0
+#endif
+  if (RGB_X_REREAD && PRE) {
+    /* what the row held: re-read from the LDS row (still intact) instead of kept in sixteen registers across the
+     * clause code */
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const ulonglong2 o = pre[(unsigned)k ^ swz];
+      ulonglong2 n;
+      switch (k) {
+        case 0: n = make_ulonglong2(L.ct, L.pk); break;
+        case 1: n = make_ulonglong2(L.ci, L.la); break;
+        case 2: n = make_ulonglong2(L.li, L.lt); break;
+        case 3: n = make_ulonglong2(L.lwi, L.lwt); break;
+        case 4: n = make_ulonglong2(L.si, L.st); break;
+        case 5: n = make_ulonglong2(L.first, L.lrs); break;
+        case 6: n = make_ulonglong2(L.lrt, L.prs); break;
+        default: n = make_ulonglong2(L.prt, L.pend); break;
+      }
+      if (n.x != o.x || n.y != o.y) ST16(ho + k, n);
+    }
+  } else {
   if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
   if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la));
   if (L.li != h2.x || L.lt != h2.y) ST16(ho + 2, make_ulonglong2(L.li, L.lt));
@@ -1953,6 +1976,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs));
   if (L.lrt != h6.x || L.prs != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.prs));
   if (L.prt != h7.x || L.pend != h7.y) ST16(ho + 7, make_ulonglong2(L.prt, L.pend));
+  }
   if (TM && L.token != token0) ST8(qry_row(L) + QRY_TOKEN, L.token);
   }
 
@@ -2250,7 +2274,7 @@ __device__ __forceinline__ u32 rgb_xcc_id() {
 #ifdef RGB_HOST_EMULATION
 #define RGB_TRAIN_SPIN_LIMIT 16u      /* blocks run one after another on the CPU: a dependency is met or never will be */
 #else
-#define RGB_TRAIN_SPIN_LIMIT 20000u    /* x ~12 us per try once backed off: a quarter of a second */
+#define RGB_TRAIN_SPIN_LIMIT 20000u    /* x ~4 us per try once backed off: ~80 ms */
 #endif
 #endif
 
@@ -2355,14 +2379,10 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #ifndef RGB_HOST_EMULATION
       if ((spins & 15u) == 0u && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) give_up = true;
 #ifndef RGB_TRAIN_SLEEP
-#define RGB_TRAIN_SLEEP 32                                /* x 64 clocks: ~1 us */
-#endif
-#ifndef RGB_TRAIN_BACKOFF
-#define RGB_TRAIN_BACKOFF 1
+#define RGB_TRAIN_SLEEP 8                                 /* x 64 clocks: ~0.2 us between polls (measured best: 2..32) */
 #endif
       __builtin_amdgcn_s_sleep(RGB_TRAIN_SLEEP);
-      if (RGB_TRAIN_BACKOFF && spins > 4u) __builtin_amdgcn_s_sleep(127);      /* ~4 us more */
-      if (RGB_TRAIN_BACKOFF && spins > 32u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+      if (spins > 64u) __builtin_amdgcn_s_sleep(127);     /* a long wait (> ~15 us) is not the steady state: back off */
 #endif
       if (give_up) {                                      /* uniform: the decisions of this slice stay unwritten */
         if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_SPIN);
@@ -2615,8 +2635,11 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
  * Block b: tick t = b / bpt, j = b mod bpt, shard x = j mod 8, row = j / 8; row_tab maps the row to (class, slice of
  * the class) -- the classes interleaved by relative position, rgb_train_make_tick -- and plan[t] the (class, shard)
  * pair to its message range.  Surplus blocks (rows past the tick's last, slices past a shard's count) exit at once. */
+/* Three wavefronts per SIMD (168 registers: no spills; four need 128 and spill ~120): a train's throughput is
+ * resident wavefronts / wavefront life, and the spills' scratch round trips sit on the clause code's dependency chain
+ * -- 4 x 128 measured 24-25 us per tick, 3 x 168 19-20 */
 #ifndef RGB_TRAIN_MIN_WAVES
-#define RGB_TRAIN_MIN_WAVES(N) RGB_CLASS_MIN_WAVES(N)
+#define RGB_TRAIN_MIN_WAVES(N) 3
 #endif
 template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(
