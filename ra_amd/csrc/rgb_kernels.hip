@@ -2528,7 +2528,12 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     /* 4. publish: every state store of this wavefront has been acknowledged by the L2 (inline assembly: the
      * compiler's wait-count pass must not drop or move it), then the advanced sequence byte of every server */
 #if !defined(RGB_HOST_EMULATION) && !defined(RGB_X_TRAIN_NOWAIT)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    /* the BUILTIN, like glds_wait(): behind an inline-assembly wait the compiler's wait-count pass no longer knows
+     * that the LDS-DMA copies have landed and puts a vmcnt(0) -- i.e. a wait for the previous store's acknowledgement
+     * -- in front of every later LDS access: the four decision stores then leave one round trip apart (1.5 us of a
+     * 10 us wavefront life).  tools/check_train_isa.py asserts the wait is in the binary, right before the byte store */
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
 #endif
     if (has_srv && seqp != nullptr) *seqp = (unsigned char)(need + 1u);
   }
