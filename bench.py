@@ -291,6 +291,12 @@ def main():
     if use_train:
         buckets = d_bc.cpu().numpy().reshape(T, engine.TRAIN_BUCKETS).astype(np.uint32)
         assert np.array_equal(buckets.sum(axis=1), counts)
+        if os.environ.get("RGB_TRAIN_LEAD"):     # tuning probe: "class:lead,..." in ticks (tools/gpu_ab.sh)
+            import ctypes as C
+            lead = np.zeros(15, dtype=np.float32)
+            for kv in os.environ["RGB_TRAIN_LEAD"].split(","):
+                c, v = kv.split(":"); lead[int(c)] = float(v)
+            engine.lib().rgb_train_set_lead(lead.ctypes.data_as(C.c_void_p))
         plan = eng.train_plan(buckets)
         d_dec2 = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)   # pass 1's decisions stay for comparison
         d_stamps = torch.zeros(T * S, dtype=torch.uint8, device=dev)          # sequence stamp of every message

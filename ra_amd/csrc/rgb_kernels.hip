@@ -303,6 +303,23 @@ __device__ __forceinline__ int run_search(const Lane &L, u64 idx, u64 &term) {
   const ulonglong2 *rt = reinterpret_cast<const ulonglong2 *>(L.runs);
   int k = (int)L.n_runs - 3;
   if (k < 0) return -1;
+#ifndef RGB_X_TRAIN_WALK4
+#define RGB_X_TRAIN_WALK4 0   /* measured: 23.2 vs 19.96 us per tick (tools/gpu_ab.sh r03o): off */
+#endif
+  if (RGB_X_TRAIN_WALK4 && L.coh) {
+    /* train launches: every load of the table is an L2 round trip (~1 us, no L1), and the wavefront's life IS the
+     * throughput there -- four runs per round trip (168 registers: room for the eight words) */
+#pragma unroll 1
+    for (; k >= 0; k -= 4) {
+      ulonglong2 r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = ldg16(true, rt + (k - j >= 0 ? k - j : 0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k - j >= 0 && idx >= r[j].x) { term = r[j].y; return k - j; }
+    }
+    return -1;
+  }
   ulonglong2 cur = ldg16(L.coh, rt + k);
 #pragma unroll 1
   for (; k >= 0; --k) {
@@ -747,6 +764,8 @@ __device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u6
   if (hi < lo) return false;
   /* walk runs from the newest: run k covers [start_k, end_k] */
   u64 end = L.li;
+  ulonglong2 pre4[4];                     /* train launches: the in-memory runs four per round trip (see run_search) */
+  int pre_top = -1;
   for (int k = (int)L.n_runs - 1; k >= 0; --k) {
     u64 s, t;
     if ((unsigned)k == L.n_runs - 1) { s = L.lrs; t = L.lrt; }
@@ -755,7 +774,20 @@ __device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u6
 #ifdef RGB_PROFILE
       if (L.prof_noprobe) break;
 #endif
-      const ulonglong2 r = ldg16(L.coh, reinterpret_cast<const ulonglong2 *>(L.runs) + k);
+      ulonglong2 r;
+      if (RGB_X_TRAIN_WALK4 && L.coh) {
+        if (pre_top < 0 || k <= pre_top - 4) {
+          pre_top = k;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            pre4[j] = ldg16(true, reinterpret_cast<const ulonglong2 *>(L.runs) + (k - j >= 0 ? k - j : 0));
+        }
+        r = pre4[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) r = (pre_top - k == j) ? pre4[j] : r;
+      } else {
+        r = ldg16(false, reinterpret_cast<const ulonglong2 *>(L.runs) + k);
+      }
 #ifdef RGB_PROFILE
       const_cast<Lane &>(L).prof_nloads += 2;
 #endif
@@ -863,7 +895,36 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
     const u64 nf = idx + 1;
     const int k = find_run(L, nf);
     u64 *runs = const_cast<u64 *>(L.runs);
+#ifndef RGB_X_TRAIN_SNAP4
+#define RGB_X_TRAIN_SNAP4 0
+#endif
     if (k > 0) {
+      if (RGB_X_TRAIN_SNAP4 && L.coh) {
+        /* train launches: a load of the table is an L2 round trip and, behind the stores of the same array, the
+         * compiler keeps them in order -- four runs per round trip (loads of a batch first, then its stores: a
+         * batch only ever writes below what the NEXT batches read) */
+#pragma unroll 1
+        for (unsigned j0 = (unsigned)k; j0 < L.n_runs; j0 += 4) {
+          u64 rs[4], rt[4];
+#pragma unroll
+          for (unsigned q = 0; q < 4; ++q) {
+            const unsigned j = j0 + q;
+            const unsigned jl = j < L.n_runs ? j : L.n_runs - 1;
+            rs[q] = 0; rt[q] = 0;
+            if (jl + 2 < L.n_runs) { rs[q] = ldg8(true, runs + 2 * jl); rt[q] = ldg8(true, runs + 2 * jl + 1); }
+          }
+#pragma unroll
+          for (unsigned q = 0; q < 4; ++q) {
+            const unsigned j = j0 + q;
+            if (j >= L.n_runs) break;
+            u64 a = rs[q], b = rt[q];
+            if (j == L.n_runs - 1) { a = L.lrs; b = L.lrt; }
+            else if (j == L.n_runs - 2) { a = L.prs; b = L.prt; }
+            runs[2 * (j - k)] = a;
+            runs[2 * (j - k) + 1] = b;
+          }
+        }
+      } else {
       for (unsigned j = (unsigned)k; j < L.n_runs; ++j) {
         u64 rs, rt;                                     /* the newest two runs are in registers */
         if (j == L.n_runs - 1) { rs = L.lrs; rt = L.lrt; }
@@ -871,6 +932,7 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
         else { rs = ldg8(L.coh, runs + 2 * j); rt = ldg8(L.coh, runs + 2 * j + 1); }
         runs[2 * (j - k)] = rs;
         runs[2 * (j - k) + 1] = rt;
+      }
       }
       L.n_runs -= (unsigned)k;
     }
@@ -3338,6 +3400,13 @@ int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u3
  * same place of the block order whatever their class -- and a server's next message, whatever ITS class, comes one
  * whole tick of blocks after the previous one: the wavefront that serves it finds its dependencies committed instead of
  * holding a slot while it waits.  row_tab[k] = class << 24 | row of the class; returns the number of rows. */
+/* how much earlier than its group range's place in the tick a class's rows start, in ticks (measured wavefront
+ * lives, tools/train_timeline.py, relative to the append_entries_rpc class; index = class rank) */
+float rgb_train_lead[RGB_N_CLASSES] = {0.0f, 0.15f, 0.10f, 0.08f, 0.08f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.25f, 0.0f, 0.0f, 0.0f};
+extern "C" void rgb_train_set_lead(const float *lead) {      /* tuning hook of tools/ (not part of the boundary) */
+  for (int c = 0; c < RGB_N_CLASSES; ++c) rgb_train_lead[c] = lead[c];
+}
+
 u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap) {
   u32 acc = 0;
   u32 rows_of[RGB_N_CLASSES];
@@ -3359,17 +3428,21 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
   for (unsigned c = 0; c < RGB_N_CLASSES; ++c) total += rows_of[c];
   out->n_rows = total;
   if (row_tab == nullptr || total > row_cap) return total;
-  /* merge by key (j + 1/2) / rows(c) = (2j + 1) / (2 rows(c)), compared exactly as cross products */
+  /* merge by key (j + 1/2) / rows(c) - lead(c): a class whose wavefronts live longer starts that much earlier, so
+   * that what lines up from tick to tick is the time a group range's messages COMMIT, not the time they start: a
+   * wavefront's dependencies then have the slack of (cadence - its own life) whatever class committed them
+   * (without the leads the slowest classes -- snapshot_written, the leader-side ones -- commit later than one tick
+   * after their predecessors start, the wavefronts that depend on them wait holding their slots, live longer
+   * themselves, and the waits cascade).  rgb_train_lead[] is in ticks; ties: the heavier class first. */
   u32 next[RGB_N_CLASSES] = {0};
   for (u32 k = 0; k < total; ++k) {
     int best = -1;
-    for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {       /* ties: the heavier class (rgb_class_at order) first */
+    double best_key = 0.0;
+    for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {
       const int c = rgb_class_at(q);
       if (next[c] >= rows_of[c]) continue;
-      if (best < 0) { best = c; continue; }
-      const unsigned long long a = (2ull * next[c] + 1ull) * (2ull * rows_of[best]);
-      const unsigned long long b = (2ull * next[best] + 1ull) * (2ull * rows_of[c]);
-      if (a < b) best = c;
+      const double key = (2.0 * next[c] + 1.0) / (2.0 * rows_of[c]) - (double)rgb_train_lead[c];
+      if (best < 0 || key < best_key) { best = c; best_key = key; }
     }
     row_tab[k] = ((u32)best << 24) | next[best];
     next[best] += 1;
