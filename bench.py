@@ -615,8 +615,9 @@ def main():
                 "workload": "configs[2] closed loop: 65536 groups x 5 members per GPU, mixed append_entries + "
                             "request_vote (5% of the groups per tick see a request_vote with term+1 and re-elect), "
                             "every server may get a message every tick (device-side generator), device-resident "
-                            "message batches, one kernel launch per tick; the literal one-message-per-group form "
-                            "of SURVEY 8(d) is under literal_configs.config3",
+                            "message batches; the ticks of one leaderboard period run as ONE train launch (per-server "
+                            "sequence bytes order the ticks, --launch tick = one kernel launch per tick); the literal "
+                            "one-message-per-group form of SURVEY 8(d) is under literal_configs.config3",
                 "aged_ticks": A, "n_runs_histogram_at_start": n_runs_hist,
                 "groups_per_gpu": G, "members": N, "decisions_per_tick": float(n_dec[Wm:].mean()),
                 "message_mix": mix,
