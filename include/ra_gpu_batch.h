@@ -314,6 +314,7 @@ typedef struct rgb_leaderboard_row {
   uint64_t last_applied;  /* the leader's last_applied (max over members when no leader)       */
 } rgb_leaderboard_row;
 
+#define RGB_CFG_ROUNDS_PER_LAUNCH 1u   /* rgb_submit: one kernel launch per sub-tick round, never a train (A/B measurements) */
 typedef struct rgb_config {
   uint32_t abi_version;          /* RGB_ABI_VERSION                                             */
   int32_t  device;               /* HIP device ordinal                                          */
@@ -322,7 +323,7 @@ typedef struct rgb_config {
   uint32_t ring_capacity;        /* messages per ring slot                                      */
   uint32_t max_pipeline_count;   /* cfg.max_pipeline_count                                      */
   uint32_t max_aer_batch;        /* cfg.max_append_entries_rpc_batch_size                       */
-  uint32_t flags;                /* reserved, 0                                                 */
+  uint32_t flags;                /* RGB_CFG_*                                                   */
 } rgb_config;
 
 typedef struct rgb_ctx rgb_ctx;
@@ -379,6 +380,11 @@ int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
  * was called (both RGB_E_EMPTY): a collector thread blocks here instead of polling rgb_collect.
  * rgb_upload_state / rgb_download_state / rgb_snapshot / rgb_state_checksum use the context's stream and are
  * ordered after the batches submitted before them; they may run beside submit/collect. */
+/* Sub-tick rounds: a batch that holds several messages for one server is applied in rounds (round r = every server's
+ * r-th message).  A batch of at least 4096 messages with 2..16 rounds and no NOP padding runs its rounds as ONE train
+ * launch (see "Train launches" below: the per-server sequence bytes order a server's messages) instead of one launch
+ * per round; rgb_submit_trains counts the batches that did.  Results are identical either way. */
+uint32_t rgb_submit_trains(const rgb_ctx *ctx);
 int      rgb_wait(rgb_ctx *ctx, uint32_t timeout_ms);
 void     rgb_wake(rgb_ctx *ctx);
 uint32_t rgb_in_flight(const rgb_ctx *ctx);

@@ -40,6 +40,12 @@ struct rgb_slot {
   rgb_rpc *d_rpcs = nullptr;
   rgb_rpc *h_rpcs = nullptr;        /* pinned: the fixed rpc slots of device positions [rpc_lo, rpc_lo+rpc_cnt) */
   u32 rpc_lo = 0, rpc_cnt = 0;
+  /* sub-tick rounds as ONE train launch: stamps, per-round plan and row table (pinned staging + device) */
+  unsigned char *h_stamps = nullptr, *d_stamps = nullptr;
+  rgb_train_tick *h_plan = nullptr, *d_plan = nullptr;
+  u32 *h_rows = nullptr, *d_rows = nullptr;
+  u32 rows_cap = 0;                 /* words of h_rows / d_rows */
+  bool used_train = false;
   std::vector<u32> perm;            /* device position -> submission index */
   u32 n = 0;
   uint64_t tick = 0;
@@ -55,6 +61,9 @@ struct rgb_slot {
  * event is recorded, collect acquires it, and gives the slot back with a release decrement that the next
  * submit's full-check acquires.  head belongs to the producers' lock, tail to the consumers'.  rgb_wait parks
  * a consumer on the condition variable until a batch is in flight (no polling). */
+#define RGB_SUBMIT_TRAIN_ROUNDS 16u    /* a batch with more sub-tick rounds than this takes one launch per round */
+#define RGB_SUBMIT_TRAIN_MIN 4096u     /* and so does a small one: a train's fixed costs are those of a big launch */
+
 struct rgb_ctx {
   rgb_config cfg;
   rgb_dev dev;
@@ -88,6 +97,9 @@ struct rgb_ctx {
   /* train launches */
   u32 *d_train_ctl = nullptr;           /* RGB_TRAIN_CTL_WORDS: sticky error flags | calibration scratch */
   unsigned char *d_seq_cnt = nullptr;   /* running stamp counters of rgb_train_stamp_device (a copy of dev.seq) */
+  std::vector<unsigned char> seq_host;  /* host mirror of dev.seq (by server), valid while only rgb_submit ran trains */
+  bool seq_host_valid = false;
+  std::atomic<u32> n_submit_trains{0};  /* batches whose sub-tick rounds ran as one train launch */
   u32 xcc_map = 0;                      /* 4 bits per shard: the XCC id blocks b mod 8 = shard ran on in the calibration launch */
   int xcc_state = 0;                    /* 0 = not calibrated, 1 = usable, -1 = placement is not one XCD per shard */
 };
@@ -164,6 +176,12 @@ static void free_slot(rgb_slot &s) {
   if (s.d_dec) (void)hipFree(s.d_dec);
   if (s.d_rpcs) (void)hipFree(s.d_rpcs);
   if (s.h_rpcs) (void)hipHostFree(s.h_rpcs);
+  if (s.h_stamps) (void)hipHostFree(s.h_stamps);
+  if (s.d_stamps) (void)hipFree(s.d_stamps);
+  if (s.h_plan) (void)hipHostFree(s.h_plan);
+  if (s.d_plan) (void)hipFree(s.d_plan);
+  if (s.h_rows) (void)hipHostFree(s.h_rows);
+  if (s.d_rows) (void)hipFree(s.d_rows);
   if (s.done) (void)hipEventDestroy(s.done);
   s = rgb_slot();
 }
@@ -230,6 +248,14 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   HIPCHK(ctx, hipMalloc((void **)&s.d_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc)));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc), hipHostMallocDefault));
   HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  /* fused sub-tick rounds (at most RGB_SUBMIT_TRAIN_ROUNDS of them per batch) */
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_stamps, cap, hipHostMallocDefault));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_stamps, cap));
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_plan, RGB_SUBMIT_TRAIN_ROUNDS * sizeof(rgb_train_tick), hipHostMallocDefault));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_plan, RGB_SUBMIT_TRAIN_ROUNDS * sizeof(rgb_train_tick)));
+  s.rows_cap = (cap / 32u + 2u * RGB_N_CLASSES * RGB_SUBMIT_TRAIN_ROUNDS + 64u);   /* every row holds >= 32 x 8 messages or closes a class */
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_rows, (size_t)s.rows_cap * RGB_SUBMIT_TRAIN_ROUNDS * sizeof(u32), hipHostMallocDefault));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_rows, (size_t)s.rows_cap * RGB_SUBMIT_TRAIN_ROUNDS * sizeof(u32)));
   return RGB_OK;
 }
 
@@ -391,6 +417,48 @@ static int validate_msg(const rgb_ctx *ctx, const rgb_msg &m) {
   return RGB_OK;
 }
 
+static int train_scratch(rgb_ctx *ctx);
+
+/* The sub-tick rounds of one batch as ONE train launch (reference: the mailbox of a member is FIFO,
+ * src/ra_server_proc.erl:1356-1397 -- a leader's N-1 replies land in one batch, so rounds > 1 are the normal shape):
+ * round r = tick r of the train, every round in bucket order, the per-server sequence bytes order a server's
+ * messages instead of a kernel boundary per round.  The slot's messages are already in device order. */
+static int submit_rounds_as_train(rgb_ctx *ctx, rgb_slot &s, u32 n, u32 n_rounds, const std::vector<u32> &start,
+                                  const std::vector<u32> &bucket_counts) {
+  const unsigned N = ctx->dev.n_members;
+  u32 rows_max = 0;
+  for (u32 r = 0; r < n_rounds; ++r) {
+    const u32 rows = rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, N, &s.h_plan[r], nullptr, 0);
+    if (rows > rows_max) rows_max = rows;
+  }
+  if (rows_max == 0 || rows_max > s.rows_cap) return RGB_E_UNSUPPORTED;
+  for (u32 r = 0; r < n_rounds; ++r) {
+    for (u32 k = 0; k < rows_max; ++k) s.h_rows[(size_t)r * rows_max + k] = 0xFFFFFFFFu;
+    rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, N, &s.h_plan[r], s.h_rows + (size_t)r * rows_max, rows_max);
+    s.h_plan[r].msg_base = start[r];
+  }
+  /* stamps from the host mirror of the sequence bytes (refreshed from the device after a device-side train) */
+  if (!ctx->seq_host_valid) {
+    const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
+    std::vector<unsigned char> raw(bytes);
+    HIPCHK(ctx, hipMemcpyAsync(raw.data(), ctx->dev.seq, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->seq_host.resize(ctx->dev.n_servers);
+    for (u32 sv = 0; sv < ctx->dev.n_servers; ++sv) ctx->seq_host[sv] = raw[rgb_seq_index(sv, N, ctx->dev.seq_stride)];
+    ctx->seq_host_valid = true;
+  }
+  for (u32 p = 0; p < n; ++p) s.h_stamps[p] = ctx->seq_host[s.h_msgs[p].server]++;
+  HIPCHK(ctx, hipMemcpyAsync(s.d_stamps, s.h_stamps, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(s.d_plan, s.h_plan, (size_t)n_rounds * sizeof(rgb_train_tick), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(s.d_rows, s.h_rows, (size_t)n_rounds * rows_max * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  int rc = rgb_launch_train(ctx->dev, s.d_msgs, s.d_stamps, 0, s.d_plan, s.d_rows, n_rounds, rows_max * RGB_TRAIN_SHARDS,
+                            s.d_dec, s.d_rpcs, 1, 0, ctx->d_train_ctl, ctx->stream);
+  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
+  s.used_train = true;
+  ctx->n_submit_trains.fetch_add(1, std::memory_order_relaxed);
+  return RGB_OK;
+}
+
 int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   if (!ctx || (!msgs && n)) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
@@ -421,11 +489,21 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     if (r + 1 > n_rounds) n_rounds = r + 1;
   }
   for (u32 t : ctx->touched) ctx->seen[t] = 0;
+  /* several rounds, a batch worth a big launch, no NOP padding, a device that keeps a shard on one XCD: the rounds
+   * run as ONE train launch, in bucket order (class, shard, success flag) -- a finer key of the same family order */
+  bool as_train = n_rounds >= 2 && n_rounds <= RGB_SUBMIT_TRAIN_ROUNDS && n >= RGB_SUBMIT_TRAIN_MIN &&
+                  !(ctx->cfg.flags & RGB_CFG_ROUNDS_PER_LAUNCH);
+  for (u32 i = 0; as_train && i < n; ++i) as_train = msgs[i].kind != RGB_MSG_NOP;
+  if (as_train) as_train = train_scratch(ctx) == RGB_OK;
   /* device order: by round, then by clause family = (message kind, success flag) (a round holds
    * at most one message per server, so its order is free; family-homogeneous wavefronts do not
    * diverge across clause families), stable inside a bucket */
-  const u32 NK = RGB_N_FAMILIES;
-  auto family = [](const rgb_msg &m) -> u32 { return rgb_family(m.kind, m.flags); };
+  const u32 NK = as_train ? (u32)RGB_N_BUCKETS : (u32)RGB_N_FAMILIES;
+  const unsigned n_members = ctx->dev.n_members;
+  auto family = [as_train, n_members](const rgb_msg &m) -> u32 {
+    return as_train ? rgb_bucket(m.kind, m.flags, m.server, n_members) : rgb_family(m.kind, m.flags);
+  };
+  std::vector<u32> bucket_counts;
   std::vector<u32> start(n_rounds + 1, 0);
   std::vector<u32> bucket((size_t)n_rounds * NK + 1, 0);
   for (u32 i = 0; i < n; ++i) {
@@ -433,6 +511,7 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     bucket[(size_t)ctx->round_of[i] * NK + family(msgs[i]) + 1]++;
   }
   for (u32 r = 0; r < n_rounds; ++r) start[r + 1] += start[r];
+  if (as_train) bucket_counts.assign(bucket.begin() + 1, bucket.end());      /* per (round, bucket), before the scan */
   for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) bucket[b + 1] += bucket[b];
   s.perm.resize(n);
   for (u32 i = 0; i < n; ++i) {
@@ -441,10 +520,16 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     s.h_msgs[p] = msgs[i];
   }
   s.n = n; s.tick = tick;
+  s.used_train = false;
   if (n) {
     HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice,
                                ctx->stream));
-    for (u32 r = 0; r < n_rounds; ++r) {
+    if (as_train) {
+      int rc = submit_rounds_as_train(ctx, s, n, n_rounds, start, bucket_counts);
+      if (rc == RGB_E_UNSUPPORTED) as_train = false;       /* more rows than the slot's table holds: one launch per round */
+      else if (rc) return rc;
+    }
+    for (u32 r = 0; r < n_rounds && !s.used_train; ++r) {
       u32 off = start[r], cnt = start[r + 1] - start[r];
       int rc;
       if (cnt >= 4096) {
@@ -509,6 +594,21 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
   rgb_slot &s = ctx->ring[ctx->tail];
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   HIPCHK(ctx, hipEventSynchronize(s.done));
+  if (s.used_train) {
+    /* a train that hit its spin bound or found a block on the wrong XCD did not compute the batch: consumed,
+     * reported once, the caller re-uploads the servers and resubmits (exceptional: the placement is checked when
+     * the first train of a context is set up) */
+    u32 flags = 0;
+    HIPCHK(ctx, hipMemcpy(&flags, ctx->d_train_ctl, sizeof flags, hipMemcpyDeviceToHost));
+    if (flags) {
+      HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, sizeof(u32)));
+      ctx->seq_host_valid = false;
+      s.busy = false; s.used_train = false;
+      ctx->tail = (ctx->tail + 1) % (u32)ctx->ring.size();
+      ctx->in_flight.fetch_sub(1, std::memory_order_release);
+      return RGB_E_STATE;
+    }
+  }
   u32 n_rpc = 0;
   for (u32 p = 0; p < s.n; ++p) n_rpc += s.h_dec[p].n_rpcs;
   /* a buffer that is too small leaves the batch in the ring: the sizes it needs are reported and the
@@ -569,6 +669,8 @@ void rgb_wake(rgb_ctx *ctx) {
   { std::lock_guard<std::mutex> wl(ctx->wait_mu); }
   ctx->wait_cv.notify_all();
 }
+
+uint32_t rgb_submit_trains(const rgb_ctx *ctx) { return ctx ? ctx->n_submit_trains.load(std::memory_order_relaxed) : 0; }
 
 uint32_t rgb_in_flight(const rgb_ctx *ctx) { return ctx ? ctx->in_flight.load(std::memory_order_acquire) : 0; }
 
@@ -747,6 +849,7 @@ int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t firs
   if ((uint64_t)first_tick + n_ticks > plan->n_ticks) return RGB_E_INVAL;
   if (n_ticks == 0 || plan->bpt == 0) return RGB_OK;
   void *st = stream ? stream : (void *)ctx->stream;
+  ctx->seq_host_valid = false;          /* rgb_submit's host mirror of the sequence bytes is stale from here on */
   /* launches of at most RGB_TRAIN_MAX_TICKS ticks (and of a grid the runtime accepts) */
   u32 per = RGB_TRAIN_MAX_TICKS;
   if ((uint64_t)per * plan->bpt > 0x7FFFFFFFull) per = (u32)(0x7FFFFFFFull / plan->bpt);

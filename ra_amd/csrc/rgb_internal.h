@@ -136,7 +136,8 @@ static inline __host__ __device__ unsigned rgb_seq_index(unsigned server, unsign
  * of rgb_train_make_tick says which (class, row) a block row of the tick is) */
 struct rgb_train_tick {
   u32 n_rows;
-  u32 pad[15];
+  u32 msg_base;                                  /* first message of the tick when the launch has no tick stride (rgb_submit) */
+  u32 pad[14];
   u32 off[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* first message of (class, shard)  */
   u32 cnt[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* its message count                */
 };
@@ -187,7 +188,9 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
                      u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream);
 /* ticks [0, n_ticks) of d_plan in one launch (n_ticks <= RGB_TRAIN_MAX_TICKS); bpt = blocks per tick (multiple of
- * RGB_TRAIN_SHARDS); d_row_tab: bpt / RGB_TRAIN_SHARDS words per tick; d_stamps: one byte per message, laid out like d_msgs; d_rpcs (may be NULL): rpc_ring tick-sized
+ * RGB_TRAIN_SHARDS); tick_stride = 0: tick t starts at d_plan[t].msg_base and a message's rpc slots follow its index
+ * in the whole buffer (the sub-tick rounds of one rgb_submit); d_row_tab: bpt / RGB_TRAIN_SHARDS words per tick;
+ * d_stamps: one byte per message, laid out like d_msgs; d_rpcs (may be NULL): rpc_ring tick-sized
  * regions, tick t uses region t mod rpc_ring; rgb_rpc.msg_index = index_base + t * tick_stride + i; d_ctl: word 0 =
  * sticky error flags, word 1 = this launch's placement rotation mask (zeroed here) */
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,

@@ -2740,8 +2740,10 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
 #if defined(RGB_X_TRAIN_PRIO) && !defined(RGB_HOST_EMULATION)
   if (rgb_lead_class(cls)) __builtin_amdgcn_s_setprio(3);   /* EXPERIMENT: the leader-side chain first */
 #endif
-  const size_t toff = (size_t)t * tick_stride;
-  rgb_rpc *rp = rpcs ? rpcs + (size_t)(t % rpc_ring) * tick_stride * (N > 1 ? N - 1 : 1) : nullptr;
+  /* ticks a fixed stride apart with a ring of rpc regions (device-resident streams), or -- tick_stride = 0 -- packed
+   * one behind the other, every message owning the rpc slots of its index in the whole buffer (rgb_submit's rounds) */
+  const size_t toff = tick_stride ? (size_t)t * tick_stride : (size_t)p->msg_base;
+  rgb_rpc *rp = rpcs ? rpcs + (tick_stride ? (size_t)(t % rpc_ring) * tick_stride : toff) * (N > 1 ? N - 1 : 1) : nullptr;
   rgb_tick_slice<N, true>(dev, io, cls, off + lbase, cnt, SL, msgs + toff, dec + toff, rp, 0, index_base + (u32)toff,
                           ctl, stamps + toff);
 #ifndef RGB_HOST_EMULATION
@@ -3427,6 +3429,7 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
   u32 total = 0;
   for (unsigned c = 0; c < RGB_N_CLASSES; ++c) total += rows_of[c];
   out->n_rows = total;
+  out->msg_base = 0;
   if (row_tab == nullptr || total > row_cap) return total;
   /* merge by key (j + 1/2) / rows(c) - lead(c): a class whose wavefronts live longer starts that much earlier, so
    * that what lines up from tick to tick is the time a group range's messages COMMIT, not the time they start: a

@@ -22,7 +22,7 @@ EXPORTS = [
     "rgb_close", "rgb_last_hip_error", "rgb_register_groups", "rgb_n_servers", "rgb_upload_state",
     "rgb_download_state", "rgb_submit", "rgb_collect", "rgb_run_ticks_device", "rgb_snapshot",
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize", "rgb_wait", "rgb_wake", "rgb_in_flight",
-    "rgb_route",
+    "rgb_route", "rgb_submit_trains",
     "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status",
 ]
@@ -99,6 +99,8 @@ def lib():
     L.rgb_wake.argtypes = [vp]
     L.rgb_wake.restype = None
     L.rgb_in_flight.argtypes = [vp]
+    L.rgb_submit_trains.restype = C.c_uint32
+    L.rgb_submit_trains.argtypes = [vp]
     L.rgb_in_flight.restype = C.c_uint32
     L.rgb_route.argtypes = [C.c_uint64, u32]
     L.rgb_route.restype = C.c_uint32
@@ -150,7 +152,7 @@ class RaGpuBatch:
 
     def __init__(self, n_groups: int, n_members: int, device: int = 0, max_runs: int = 8,
                  ring_slots: int = 4, ring_capacity: int = 65536, max_pipeline_count: int = 0,
-                 max_aer_batch: int = 0):
+                 max_aer_batch: int = 0, flags: int = 0):
         self._L = lib()
         cfg = default_config()
         cfg["device"] = device
@@ -161,6 +163,7 @@ class RaGpuBatch:
             cfg["max_pipeline_count"] = max_pipeline_count
         if max_aer_batch:
             cfg["max_aer_batch"] = max_aer_batch
+        cfg["flags"] = flags                    # abi.CFG_ROUNDS_PER_LAUNCH: never fuse sub-tick rounds into a train
         h = C.c_void_p()
         rc = self._L.rgb_open(cfg.ctypes.data, C.byref(h))
         if rc:
@@ -239,6 +242,10 @@ class RaGpuBatch:
 
     def wake(self):
         self._L.rgb_wake(self._h)
+
+    def submit_trains(self) -> int:
+        """Batches whose sub-tick rounds ran as one train launch (rgb_submit_trains)."""
+        return int(self._L.rgb_submit_trains(self._h))
 
     @property
     def in_flight(self) -> int:

@@ -35,6 +35,11 @@ def test_sub_ticks_ring_and_overflow(emulated_engine, oracle_lib):
         G.test_write_below_first_index_keeps_the_range_start(emulated_engine, oracle_lib, n_run0)
 
 
+def test_rounds_as_one_train_launch_through_the_c_abi(emulated_engine, oracle_lib):
+    G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, G=1200, N=5, batches=2)
+    G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, G=1400, N=3, batches=1)
+
+
 def test_sparse_pending_through_the_c_abi(emulated_engine, oracle_lib):
     for seed in range(8):
         G.test_sparse_pending_and_two_range_written_events(emulated_engine, oracle_lib, seed)

@@ -105,6 +105,34 @@ def test_same_server_messages_are_serialised_in_submission_order(engine_mod, ora
             assert_same(f"round {rnd}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
 
 
+def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, G=1500, N=5, batches=3):
+    """The normal shape of a real batch: a leader's N-1 replies arrive together, so does a follower's append and its
+    written event -- four messages per leader, two or three per follower in ONE rgb_submit.  Rounds 2..16 of a big
+    batch run as one train launch (rgb_submit_trains counts them); the result is the sequential checker's."""
+    rng = np.random.default_rng(21)
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        fused = 0
+        for b in range(batches):
+            parts = [fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.9) for _ in range(4)]
+            msgs = np.concatenate(parts)
+            msgs = msgs[msgs["kind"] != abi.MSG_NOP]
+            rng.shuffle(msgs)
+            assert len(msgs) >= 4096
+            do, ro = cpu.step(msgs)
+            dg, rg = gpu.step(msgs)
+            assert_same(f"batch {b}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+            fused = gpu.submit_trains()
+        assert fused == batches, f"{fused} of {batches} batches took the train path"
+        # a device-side train in between makes the host's copy of the sequence bytes stale: it is refreshed
+        small = fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.2)
+        do, ro = cpu.step(small); dg, rg = gpu.step(small)
+        assert_same("small batch (one launch per round)", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+
+
 def test_pipelined_ring_keeps_batches_in_order(engine_mod, oracle_lib):
     """submit/submit/submit then collect x3: the staging ring returns batches oldest first."""
     rng = np.random.default_rng(9)

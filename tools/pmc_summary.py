@@ -10,5 +10,5 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), r
             acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
     print("==", os.path.relpath(f, root))
     for (kn, cn), (s, n) in sorted(acc.items()):
-        if "tick" in kn or "leaderboard" in kn or "wal" in kn:
+        if "tick" in kn or "train" in kn or "leaderboard" in kn or "wal" in kn:
             print(f"  {kn:60s} {cn:16s} mean={s/n:14.1f} n={n}")
