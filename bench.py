@@ -369,17 +369,26 @@ def main():
             print(f"[bench] hipGraph capture failed ({e!r}); eager launches", file=sys.stderr)
             graphs = None
 
+    ag_events = []      # (before, after) of every leaderboard all-gather of the timed region, on the launch stream
+
+    def allgather():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        dist.all_gather_into_tensor(lb_all, lb_local)
+        e1.record(stream)
+        ag_events.append((e0, e1))
+
     def timed():
         if graphs is not None:
             for g, nxt in graphs:
                 g.replay()
                 if use_dist and nxt % SNAPSHOT_EVERY == 0:
-                    dist.all_gather_into_tensor(lb_all, lb_local)
+                    allgather()
         else:
             for t, nxt in segments(Wm, T):
                 run_segment(t, nxt)
                 if use_dist and nxt % SNAPSHOT_EVERY == 0:
-                    dist.all_gather_into_tensor(lb_all, lb_local)
+                    allgather()
 
     if use_dist:
         dist.barrier()
@@ -411,7 +420,20 @@ def main():
                       "xcd_of_shard": [int(v) for v in xcc], "decisions_compared_with_per_tick_launches": int(n_dec.sum())}
     checksum_pass2 = eng.state_checksum()
     assert checksum_pass2 == checksum_pass1 or os.environ.get("RGB_BENCH_NOCHECK"), "replay diverged from the generation pass"
+    per_rank = None
     if use_dist:
+        # every rank's own clock and its all-gathers' own time: the scaling curve can be read rank by rank
+        ag_us = sum(a.elapsed_time(b) for a, b in ag_events) * 1e3
+        mine = torch.tensor([elapsed * 1e3 / K, ev_ms / K, ag_us / max(len(ag_events), 1), float(len(ag_events))],
+                            dtype=torch.float64, device=dev)
+        allr = torch.empty(world * 4, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        rr = allr.cpu().numpy().reshape(world, 4)
+        per_rank = {"ms_per_step_wall": [round(float(v), 6) for v in rr[:, 0]],
+                    "ms_per_step_hip_events": [round(float(v), 6) for v in rr[:, 1]],
+                    "allgather_us_per_call": [round(float(v), 2) for v in rr[:, 2]],
+                    "allgathers_in_timed_region": int(rr[0, 3]),
+                    "allgather_bytes_per_rank": int(G * 32)}
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -661,6 +683,7 @@ def main():
                 "launch": ("train: one rgb_train_kernel launch per leaderboard period" if use_train
                            else "one rgb_tick_classes_kernel launch per tick"),
                 "train": train_info,
+                "per_rank": per_rank,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
