@@ -14,7 +14,7 @@
 %%     commit_index:64, last_applied:64
 -module(ra_gpu_batch).
 
--export([init/0, open/4, register_groups/3, upload_state/3, download_state/3, register_owner/4, route/2,
+-export([init/0, open/4, register_groups/3, upload_state/3, download_state/3, register_owner/4, unregister_owner/2, owner_slots/1, fan_back_stats/1, route/2,
          submit/3, collect/1, start_collector/2, stop_collector/1, snapshot/2, wal_checksums/3]).
 -export([wal_batch_checksums/2, wal_frame/4, wal_recover_check/2, wal_frame_batch/3, wal_recover/2]).
 -export([encode_msg/3, decode_decision/1, decision_to_effects/3]).
@@ -74,6 +74,17 @@ route(_GroupUId, _NContexts) -> erlang:nif_error(not_loaded).
 %% process's decisions, submission order; rpc msg_index = position inside DecisionsBin).  A ra_server_proc
 %% registers itself for its one server in init/1; unregistered servers go to the start_collector/2 pid.
 register_owner(_Ctx, _FirstServer, _N, _Pid) -> erlang:nif_error(not_loaded).
+
+%% unregister_owner(Ctx, Pid): Pid owns nothing any more (its servers go back to the default owner of
+%% start_collector/2) and its slot of the owner table is free for the next register_owner/4 -- call it from
+%% ra_server_proc:terminate/3, so that restarts do not grow the table (src/ra_server_proc.erl terminate/3).
+unregister_owner(_Ctx, _Pid) -> erlang:nif_error(not_loaded).
+
+%% owner_slots(Ctx) -> {Slots, Live}: diagnostics of the owner table.
+owner_slots(_Ctx) -> erlang:nif_error(not_loaded).
+
+%% fan_back_stats(Ctx) -> {Batches, Decisions, Nanoseconds} spent by the collector thread fanning batches back.
+fan_back_stats(_Ctx) -> erlang:nif_error(not_loaded).
 %% submit/3 may be called from any process; batches above 2048 messages run on a dirty CPU scheduler.
 submit(_Ctx, _MsgsBin, _Tick) -> erlang:nif_error(not_loaded).
 collect(_Ctx) -> erlang:nif_error(not_loaded).

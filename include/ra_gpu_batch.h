@@ -385,6 +385,9 @@ int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
  * launch (see "Train launches" below: the per-server sequence bytes order a server's messages) instead of one launch
  * per round; rgb_submit_trains counts the batches that did.  Results are identical either way. */
 uint32_t rgb_submit_trains(const rgb_ctx *ctx);
+/* sizes of the oldest batch in flight (waits for it, consumes nothing): decisions and rpc records rgb_collect will
+ * hand out next -- a caller that allocates per batch (the NIF's binaries) sizes them from this */
+int      rgb_peek(rgb_ctx *ctx, uint32_t *n_out, uint32_t *n_rpc_out);
 int      rgb_wait(rgb_ctx *ctx, uint32_t timeout_ms);
 void     rgb_wake(rgb_ctx *ctx);
 uint32_t rgb_in_flight(const rgb_ctx *ctx);

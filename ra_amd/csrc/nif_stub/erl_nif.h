@@ -60,6 +60,9 @@ void enif_clear_env(ErlNifEnv *);
 int enif_send(ErlNifEnv *, const ErlNifPid *, ErlNifEnv *, ERL_NIF_TERM);
 int enif_thread_create(char *, ErlNifTid *, void *(*)(void *), void *, ErlNifThreadOpts *);
 int enif_thread_join(ErlNifTid, void **);
+ErlNifTid enif_thread_self(void);
+int enif_equal_tids(ErlNifTid, ErlNifTid);
+int enif_compare_pids(const ErlNifPid *, const ErlNifPid *);
 typedef struct ErlNifMutex_ ErlNifMutex;
 ErlNifMutex *enif_mutex_create(char *name);
 void enif_mutex_destroy(ErlNifMutex *);

@@ -28,6 +28,7 @@
  */
 #include <stdatomic.h>
 #include <string.h>
+#include <time.h>
 
 #include "erl_nif.h"
 #include "ra_gpu_batch.h"
@@ -44,7 +45,10 @@ typedef struct {
   ErlNifMutex *own_mu;
   ErlNifPid *pids;
   uint32_t n_pids, cap_pids;
+  unsigned char *live;          /* live[k]: slot k of pids holds a registered owner (unregister_owner/2 frees it) */
   uint32_t *owner_of;
+  atomic_ullong fb_ns, fb_decisions, fb_batches;   /* time the collector thread spent in fan_back (fan_back_stats/1) */
+  uint32_t *tix; uint32_t tix_cap, tix_gen;   /* fan_back scratch: per-slot position in the batch's owner list, generation-stamped */
   atomic_int collector_on, stop;
 } nif_ctx;
 
@@ -65,11 +69,18 @@ static void ctx_dtor(ErlNifEnv *env, void *obj) {
   nif_ctx *c = (nif_ctx *)obj;
   (void)env;
   atomic_store(&c->stop, 1);
-  if (atomic_load(&c->collector_on)) { rgb_wake(c->ctx); enif_thread_join(c->tid, NULL); }
+  /* the collector thread drops its reference when it ends: if that was the last one this destructor runs ON that
+   * thread, and a thread cannot join itself (EDEADLK) */
+  if (atomic_load(&c->collector_on) && !enif_equal_tids(enif_thread_self(), c->tid)) {
+    rgb_wake(c->ctx);
+    enif_thread_join(c->tid, NULL);
+  }
   if (c->ctx) rgb_close(c->ctx);
   c->ctx = NULL;
   if (c->own_mu) enif_mutex_destroy(c->own_mu);
   if (c->pids) enif_free(c->pids);
+  if (c->live) enif_free(c->live);
+  if (c->tix) enif_free(c->tix);
   if (c->owner_of) enif_free(c->owner_of);
 }
 
@@ -114,7 +125,30 @@ static ERL_NIF_TERM nif_register_groups(ErlNifEnv *env, int argc, const ERL_NIF_
 }
 
 /* register_owner(Ctx, FirstServer, N, Pid) -> ok: the gen_statem Pid owns servers [FirstServer, FirstServer+N)
- * (a ra_server_proc registers the one server it is; a batching process may own a range) */
+ * (a ra_server_proc registers the one server it is; a batching process may own a range).  A pid that is already in
+ * the table keeps its slot, a slot freed by unregister_owner/2 is reused: the table is bounded by the number of LIVE
+ * owners, not by the number of restarts. */
+static uint32_t owner_slot(nif_ctx *c, const ErlNifPid *pid) {      /* own_mu held; 0 = no memory */
+  uint32_t free_at = 0;
+  for (uint32_t k = 0; k < c->n_pids; ++k) {
+    if (c->live[k] && enif_compare_pids(&c->pids[k], pid) == 0) return k + 1;
+    if (!c->live[k] && !free_at) free_at = k + 1;
+  }
+  if (free_at) { c->pids[free_at - 1] = *pid; c->live[free_at - 1] = 1; return free_at; }
+  if (c->n_pids == c->cap_pids) {
+    uint32_t cap = c->cap_pids ? c->cap_pids * 2 : 64;
+    ErlNifPid *p = (ErlNifPid *)enif_alloc((size_t)cap * sizeof(ErlNifPid));
+    unsigned char *l = (unsigned char *)enif_alloc(cap);
+    if (!p || !l) { if (p) enif_free(p); if (l) enif_free(l); return 0; }
+    if (c->n_pids) { memcpy(p, c->pids, (size_t)c->n_pids * sizeof(ErlNifPid)); memcpy(l, c->live, c->n_pids); }
+    if (c->pids) enif_free(c->pids);
+    if (c->live) enif_free(c->live);
+    c->pids = p; c->live = l; c->cap_pids = cap;
+  }
+  c->pids[c->n_pids] = *pid; c->live[c->n_pids] = 1;
+  return ++c->n_pids;
+}
+
 static ERL_NIF_TERM nif_register_owner(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c; unsigned first, n; ErlNifPid pid;
   (void)argc;
@@ -122,19 +156,53 @@ static ERL_NIF_TERM nif_register_owner(ErlNifEnv *env, int argc, const ERL_NIF_T
       !enif_get_local_pid(env, argv[3], &pid) || !c->owner_of || (uint64_t)first + n > c->n_servers)
     return enif_make_badarg(env);
   enif_mutex_lock(c->own_mu);
-  if (c->n_pids == c->cap_pids) {
-    uint32_t cap = c->cap_pids ? c->cap_pids * 2 : 64;
-    ErlNifPid *p = (ErlNifPid *)enif_alloc((size_t)cap * sizeof(ErlNifPid));
-    if (!p) { enif_mutex_unlock(c->own_mu); return mk_error(env, c, RGB_E_NOMEM); }
-    if (c->n_pids) memcpy(p, c->pids, (size_t)c->n_pids * sizeof(ErlNifPid));
-    if (c->pids) enif_free(c->pids);
-    c->pids = p; c->cap_pids = cap;
-  }
-  c->pids[c->n_pids] = pid;
-  const uint32_t idx = ++c->n_pids;
+  const uint32_t idx = owner_slot(c, &pid);
+  if (!idx) { enif_mutex_unlock(c->own_mu); return mk_error(env, c, RGB_E_NOMEM); }
   for (unsigned k = 0; k < n; ++k) c->owner_of[first + k] = idx;
   enif_mutex_unlock(c->own_mu);
   return enif_make_atom(env, "ok");
+}
+
+/* unregister_owner(Ctx, Pid) -> ok: Pid owns nothing any more (its servers fall back to the default owner of
+ * start_collector/2) and its slot is free for the next register_owner/4 -- what a terminating or restarting
+ * ra_server_proc calls (src/ra_server_proc.erl terminate/3) */
+static ERL_NIF_TERM nif_unregister_owner(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c; ErlNifPid pid;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c) || !enif_get_local_pid(env, argv[1], &pid) || !c->owner_of) return enif_make_badarg(env);
+  enif_mutex_lock(c->own_mu);
+  for (uint32_t k = 0; k < c->n_pids; ++k) {
+    if (!c->live[k] || enif_compare_pids(&c->pids[k], &pid) != 0) continue;
+    for (uint32_t sv = 0; sv < c->n_servers; ++sv)
+      if (c->owner_of[sv] == k + 1) c->owner_of[sv] = 0;
+    c->live[k] = 0;
+  }
+  enif_mutex_unlock(c->own_mu);
+  return enif_make_atom(env, "ok");
+}
+
+/* owner_slots(Ctx) -> {Slots, Live}: size of the owner table and how many of its slots hold a registered process
+ * (diagnostics: Slots stays bounded by the peak number of live owners whatever the number of restarts) */
+static ERL_NIF_TERM nif_owner_slots(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c)) return enif_make_badarg(env);
+  enif_mutex_lock(c->own_mu);
+  unsigned live = 0;
+  for (uint32_t k = 0; k < c->n_pids; ++k) live += c->live[k] ? 1u : 0u;
+  const unsigned slots = c->n_pids;
+  enif_mutex_unlock(c->own_mu);
+  return enif_make_tuple2(env, enif_make_uint(env, slots), enif_make_uint(env, live));
+}
+
+/* fan_back_stats(Ctx) -> {Batches, Decisions, Nanoseconds}: what the collector thread has spent splitting batches
+ * per owner and sending them (allocation of the per-owner binaries + enif_send included) */
+static ERL_NIF_TERM nif_fan_back_stats(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c)) return enif_make_badarg(env);
+  return enif_make_tuple3(env, enif_make_uint64(env, atomic_load(&c->fb_batches)),
+                          enif_make_uint64(env, atomic_load(&c->fb_decisions)), enif_make_uint64(env, atomic_load(&c->fb_ns)));
 }
 
 /* upload_state(Ctx, FirstServer, <<rgb_server_state x N>>) */
@@ -178,15 +246,15 @@ static ERL_NIF_TERM nif_submit(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv
 }
 
 static int do_collect(nif_ctx *c, ErlNifBinary *dec, ErlNifBinary *rpc, uint32_t *n, uint32_t *nr, uint64_t *tick) {
-  uint32_t rcap = c->ring_capacity * (c->n_members > 1 ? c->n_members - 1 : 1);
-  if (!enif_alloc_binary((size_t)c->ring_capacity * sizeof(rgb_decision), dec)) return RGB_E_NOMEM;
-  if (!enif_alloc_binary((size_t)rcap * sizeof(rgb_rpc), rpc)) { enif_release_binary(dec); return RGB_E_NOMEM; }
-  int rc = rgb_collect(c->ctx, (rgb_decision *)dec->data, c->ring_capacity, n, (rgb_rpc *)rpc->data, rcap, nr, tick);
+  /* the binaries are sized from the batch itself (rgb_peek waits for it): exactly byte_size(DecisionsBin) div 64
+   * decisions and byte_size(RpcsBin) div 56 rpc records, no ring-capacity-sized allocation per batch */
+  uint32_t want = 0, want_r = 0;
+  int rc = rgb_peek(c->ctx, &want, &want_r);
+  if (rc) return rc;
+  if (!enif_alloc_binary((size_t)want * sizeof(rgb_decision), dec)) return RGB_E_NOMEM;
+  if (!enif_alloc_binary((size_t)want_r * sizeof(rgb_rpc), rpc)) { enif_release_binary(dec); return RGB_E_NOMEM; }
+  rc = rgb_collect(c->ctx, (rgb_decision *)dec->data, want, n, (rgb_rpc *)rpc->data, want_r, nr, tick);
   if (rc) { enif_release_binary(dec); enif_release_binary(rpc); return rc; }
-  /* the binaries carry exactly the records that were produced: byte_size(DecisionsBin) div 64 decisions,
-   * byte_size(RpcsBin) div 56 rpc records */
-  enif_realloc_binary(dec, (size_t)*n * sizeof(rgb_decision));
-  enif_realloc_binary(rpc, (size_t)*nr * sizeof(rgb_rpc));
   return rc;
 }
 
@@ -195,7 +263,7 @@ static ERL_NIF_TERM nif_collect(ErlNifEnv *env, int argc, const ERL_NIF_TERM arg
   nif_ctx *c; ErlNifBinary dec, rpc; uint32_t n = 0, nr = 0; uint64_t tick = 0;
   (void)argc;
   if (!get_ctx(env, argv[0], &c)) return enif_make_badarg(env);
-  if (atomic_load(&c->collector_on))     /* one consumer: the collector thread owns rgb_collect while it runs */
+  if (atomic_load(&c->collector_on) == 1)     /* one consumer: the collector thread owns rgb_collect while it runs */
     return enif_make_tuple2(env, enif_make_atom(env, "error"), enif_make_atom(env, "collector_running"));
   int rc = do_collect(c, &dec, &rpc, &n, &nr, &tick);
   if (rc) return mk_error(env, c, rc);
@@ -224,22 +292,42 @@ static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint3
     send_batch(env, &c->owner, tick, n, dec, rpc);
     return RGB_OK;
   }
+  /* Under the lock only what depends on the owner table: owner of every decision and the pids involved (copied).
+   * The binaries are filled and sent after it is released -- register_owner/4 runs on a normal scheduler and must
+   * not wait for a 64k-decision fan-out.  tix[] (one word per table slot, generation-stamped: no memset per batch)
+   * lives in the context; the per-batch scratch is bounded by the batch. */
   const uint32_t n_own = c->n_pids + 1;                       /* bucket 0 = default owner */
-  /* tix[o] = 1 + position of owner o in the first-appearance list (0 = not seen in this batch) */
-  uint32_t *tix = (uint32_t *)enif_alloc((size_t)n_own * sizeof(uint32_t));
-  uint32_t *own = (uint32_t *)enif_alloc((size_t)(n + 1) * 5 * sizeof(uint32_t));
+  if (c->tix_cap < n_own) {
+    uint32_t *t2 = (uint32_t *)enif_alloc((size_t)n_own * 2 * sizeof(uint32_t));
+    if (!t2) { enif_mutex_unlock(c->own_mu); enif_release_binary(dec); enif_release_binary(rpc); return RGB_E_NOMEM; }
+    memset(t2, 0, (size_t)n_own * 2 * sizeof(uint32_t));
+    if (c->tix) enif_free(c->tix);
+    c->tix = t2; c->tix_cap = n_own; c->tix_gen = 0;
+  }
+  if (++c->tix_gen == 0) { memset(c->tix, 0, (size_t)c->tix_cap * 2 * sizeof(uint32_t)); c->tix_gen = 1; }
+  uint32_t *tix = c->tix, *tgen = c->tix + c->tix_cap;       /* tix[o] valid iff tgen[o] == tix_gen */
+  uint32_t *own = (uint32_t *)enif_alloc((size_t)(n + 1) * 6 * sizeof(uint32_t));
+  ErlNifPid *to = NULL;
   ErlNifBinary *bins = NULL;
   int rc = RGB_OK;
-  if (!tix || !own) rc = RGB_E_NOMEM;
+  if (!own) rc = RGB_E_NOMEM;
   uint32_t n_t = 0;
+  uint32_t *cnt_d = NULL, *cnt_r = NULL, *fill_d = NULL, *fill_r = NULL, *slot_of = NULL;
   if (rc == RGB_OK) {
-    uint32_t *cnt_d = own + (n + 1), *cnt_r = cnt_d + (n + 1), *fill_d = cnt_r + (n + 1), *fill_r = fill_d + (n + 1);
-    memset(tix, 0, (size_t)n_own * sizeof(uint32_t));
+    cnt_d = own + (n + 1); cnt_r = cnt_d + (n + 1); fill_d = cnt_r + (n + 1); fill_r = fill_d + (n + 1);
+    slot_of = fill_r + (n + 1);                               /* decision i -> position of its owner in the list */
     for (uint32_t i = 0; i < n; ++i) {
       const uint32_t o = d[i].server < c->n_servers ? c->owner_of[d[i].server] : 0;
-      if (!tix[o]) { own[n_t] = o; cnt_d[n_t] = cnt_r[n_t] = fill_d[n_t] = fill_r[n_t] = 0; tix[o] = ++n_t; }
+      if (tgen[o] != c->tix_gen) { tgen[o] = c->tix_gen; own[n_t] = o; cnt_d[n_t] = cnt_r[n_t] = fill_d[n_t] = fill_r[n_t] = 0; tix[o] = ++n_t; }
+      slot_of[i] = tix[o] - 1;
       cnt_d[tix[o] - 1] += 1; cnt_r[tix[o] - 1] += d[i].n_rpcs;
     }
+    to = (ErlNifPid *)enif_alloc((size_t)(n_t ? n_t : 1) * sizeof(ErlNifPid));
+    if (!to) rc = RGB_E_NOMEM;
+    for (uint32_t t = 0; rc == RGB_OK && t < n_t; ++t) to[t] = (own[t] && c->live[own[t] - 1]) ? c->pids[own[t] - 1] : c->owner;
+  }
+  enif_mutex_unlock(c->own_mu);
+  if (rc == RGB_OK) {
     bins = (ErlNifBinary *)enif_alloc((size_t)(n_t ? n_t : 1) * 2 * sizeof(ErlNifBinary));
     uint32_t made = 0;
     if (!bins) rc = RGB_E_NOMEM;
@@ -254,8 +342,7 @@ static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint3
     } else {
       uint32_t k = 0;                                          /* cursor into the rpc records */
       for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t o = d[i].server < c->n_servers ? c->owner_of[d[i].server] : 0;
-        const uint32_t t = tix[o] - 1;
+        const uint32_t t = slot_of[i];
         const uint32_t at = fill_d[t]++;
         ((rgb_decision *)bins[2 * t].data)[at] = d[i];
         for (uint32_t q = 0; q < d[i].n_rpcs; ++q) {
@@ -264,14 +351,10 @@ static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint3
           ((rgb_rpc *)bins[2 * t + 1].data)[fill_r[t]++] = x;
         }
       }
-      for (uint32_t t = 0; t < n_t; ++t) {
-        const ErlNifPid to = own[t] ? c->pids[own[t] - 1] : c->owner;
-        send_batch(env, &to, tick, cnt_d[t], &bins[2 * t], &bins[2 * t + 1]);
-      }
+      for (uint32_t t = 0; t < n_t; ++t) send_batch(env, &to[t], tick, cnt_d[t], &bins[2 * t], &bins[2 * t + 1]);
     }
   }
-  enif_mutex_unlock(c->own_mu);
-  if (tix) enif_free(tix);
+  if (to) enif_free(to);
   if (own) enif_free(own);
   if (bins) enif_free(bins);
   enif_release_binary(dec); enif_release_binary(rpc);
@@ -287,7 +370,15 @@ static void *collector_main(void *arg) {
     ErlNifBinary dec, rpc; uint32_t n = 0, nr = 0; uint64_t tick = 0;
     int rc = do_collect(c, &dec, &rpc, &n, &nr, &tick);
     if (rc == RGB_E_EMPTY) continue;
-    if (rc == RGB_OK) rc = fan_back(c, env, tick, n, nr, &dec, &rpc);
+    if (rc == RGB_OK) {
+      struct timespec a, b;
+      clock_gettime(CLOCK_MONOTONIC, &a);
+      rc = fan_back(c, env, tick, n, nr, &dec, &rpc);
+      clock_gettime(CLOCK_MONOTONIC, &b);
+      atomic_fetch_add(&c->fb_ns, (unsigned long long)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec)));
+      atomic_fetch_add(&c->fb_decisions, (unsigned long long)n);
+      atomic_fetch_add(&c->fb_batches, 1ull);
+    }
     if (rc != RGB_OK) {
       /* a persistent error is reported ONCE to the default owner and ends the thread (the owner falls back to
        * ra_server and may start a new collector): no hot error loop */
@@ -297,7 +388,9 @@ static void *collector_main(void *arg) {
     }
   }
   enif_free_env(env);
-  atomic_store(&c->collector_on, 2);                          /* finished: stop_collector/1 joins it */
+  /* finished by itself (2): collect/1 works again at once, and the next start_collector/2 -- or stop_collector/1, or
+   * the destructor -- joins this thread */
+  atomic_store(&c->collector_on, 2);
   enif_release_resource(c);
   return NULL;
 }
@@ -305,16 +398,26 @@ static void *collector_main(void *arg) {
 static ERL_NIF_TERM nif_start_collector(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c;
   (void)argc;
-  if (!get_ctx(env, argv[0], &c) || atomic_load(&c->collector_on) || !enif_get_local_pid(env, argv[1], &c->owner))
-    return enif_make_badarg(env);
+  ErlNifPid owner;
+  if (!get_ctx(env, argv[0], &c) || !enif_get_local_pid(env, argv[1], &owner)) return enif_make_badarg(env);
+  /* exactly one caller wins the right to start it: 0 -> 3 (starting), or 2 -> 3 when the previous thread ended by
+   * itself after an error (joined here).  A running (1) or starting (3) collector: badarg */
+  int was = 0;
+  if (!atomic_compare_exchange_strong(&c->collector_on, &was, 3)) {
+    was = 2;
+    if (!atomic_compare_exchange_strong(&c->collector_on, &was, 3)) return enif_make_badarg(env);
+    enif_thread_join(c->tid, NULL);
+  }
+  c->owner = owner;
   enif_keep_resource(c);
   atomic_store(&c->stop, 0);
-  atomic_store(&c->collector_on, 1);
   if (enif_thread_create((char *)"rgb_collector", &c->tid, collector_main, c, NULL)) {
     atomic_store(&c->collector_on, 0);
     enif_release_resource(c);
     return mk_error(env, c, RGB_E_NOMEM);
   }
+  was = 3;
+  atomic_compare_exchange_strong(&c->collector_on, &was, 1);   /* (a thread that already ended left 2) */
   return enif_make_atom(env, "ok");
 }
 
@@ -323,7 +426,8 @@ static ERL_NIF_TERM nif_start_collector(ErlNifEnv *env, int argc, const ERL_NIF_
 static ERL_NIF_TERM nif_stop_collector(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c;
   (void)argc;
-  if (!get_ctx(env, argv[0], &c) || !atomic_load(&c->collector_on)) return enif_make_badarg(env);
+  if (!get_ctx(env, argv[0], &c) || (atomic_load(&c->collector_on) != 1 && atomic_load(&c->collector_on) != 2))
+    return enif_make_badarg(env);
   atomic_store(&c->stop, 1);
   rgb_wake(c->ctx);                                            /* the thread may be parked in rgb_wait */
   enif_thread_join(c->tid, NULL);
@@ -429,6 +533,9 @@ static ErlNifFunc nif_funcs[] = {
   {"download_state", 3, nif_download_state, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"route", 2, nif_route, 0},
   {"register_owner", 4, nif_register_owner, 0},
+  {"unregister_owner", 2, nif_unregister_owner, ERL_NIF_DIRTY_JOB_CPU_BOUND},   /* scans owner_of: O(servers) */
+  {"owner_slots", 1, nif_owner_slots, 0},
+  {"fan_back_stats", 1, nif_fan_back_stats, 0},
   {"submit", 3, nif_submit, 0},
   {"collect", 1, nif_collect, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"start_collector", 2, nif_start_collector, 0},

@@ -651,6 +651,24 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
   return rc_out;
 }
 
+/* Sizes of the OLDEST batch in flight (waits for it like rgb_collect, consumes nothing): what a caller needs to
+ * allocate exactly the buffers rgb_collect will fill. */
+int rgb_peek(rgb_ctx *ctx, uint32_t *n_out, uint32_t *n_rpc_out) {
+  if (!ctx) return RGB_E_INVAL;
+  if (n_out) *n_out = 0;
+  if (n_rpc_out) *n_rpc_out = 0;
+  std::lock_guard<std::mutex> lk(ctx->collect_mu);
+  if (ctx->in_flight.load(std::memory_order_acquire) == 0) return RGB_E_EMPTY;
+  rgb_slot &s = ctx->ring[ctx->tail];
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  HIPCHK(ctx, hipEventSynchronize(s.done));
+  u32 n_rpc = 0;
+  for (u32 p = 0; p < s.n; ++p) n_rpc += s.h_dec[p].n_rpcs;
+  if (n_out) *n_out = s.n;
+  if (n_rpc_out) *n_rpc_out = n_rpc;
+  return RGB_OK;
+}
+
 /* Park until a batch is in flight (RGB_OK), the timeout passes or rgb_wake is called (RGB_E_EMPTY). */
 int rgb_wait(rgb_ctx *ctx, uint32_t timeout_ms) {
   if (!ctx) return RGB_E_INVAL;

@@ -22,7 +22,7 @@ EXPORTS = [
     "rgb_close", "rgb_last_hip_error", "rgb_register_groups", "rgb_n_servers", "rgb_upload_state",
     "rgb_download_state", "rgb_submit", "rgb_collect", "rgb_run_ticks_device", "rgb_snapshot",
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize", "rgb_wait", "rgb_wake", "rgb_in_flight",
-    "rgb_route", "rgb_submit_trains",
+    "rgb_route", "rgb_submit_trains", "rgb_peek",
     "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status",
 ]
@@ -99,6 +99,7 @@ def lib():
     L.rgb_wake.argtypes = [vp]
     L.rgb_wake.restype = None
     L.rgb_in_flight.argtypes = [vp]
+    L.rgb_peek.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.rgb_submit_trains.restype = C.c_uint32
     L.rgb_submit_trains.argtypes = [vp]
     L.rgb_in_flight.restype = C.c_uint32

@@ -86,7 +86,7 @@ int enif_get_resource(ErlNifEnv *e, ERL_NIF_TERM x, ErlNifResourceType *ty, void
 ErlNifEnv *enif_alloc_env(void) { return (ErlNifEnv *)calloc(1, sizeof(ErlNifEnv)); }
 void enif_free_env(ErlNifEnv *e) { free(e); }
 void enif_clear_env(ErlNifEnv *e) {}
-#define QCAP 1024
+#define QCAP (1 << 20)   /* one owner per server at 65 536 x 5 sends 327 680 messages per batch */
 static term *queue[QCAP]; static uint64_t queue_to[QCAP];
 static int q_head = 0, q_tail = 0;
 static pthread_mutex_t q_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -98,12 +98,21 @@ int enif_send(ErlNifEnv *caller, const ErlNifPid *to, ErlNifEnv *msg_env, ERL_NI
   pthread_mutex_unlock(&q_mu);
   return ok;
 }
-struct ErlNifTid_ { pthread_t th; };
+struct ErlNifTid_ { pthread_t th; void *(*fn)(void *); void *arg; };
+static __thread ErlNifTid tls_self = NULL;               /* threads the "BEAM" did not create have no tid */
+static void *thread_tramp(void *p) { ErlNifTid t = (ErlNifTid)p; tls_self = t; return t->fn(t->arg); }
 int enif_thread_create(char *name, ErlNifTid *tid, void *(*fn)(void *), void *arg, ErlNifThreadOpts *o) {
   *tid = (ErlNifTid)calloc(1, sizeof(struct ErlNifTid_));
-  return pthread_create(&(*tid)->th, NULL, fn, arg);
+  (*tid)->fn = fn; (*tid)->arg = arg;
+  return pthread_create(&(*tid)->th, NULL, thread_tramp, *tid);
 }
 int enif_thread_join(ErlNifTid tid, void **ret) { int rc = pthread_join(tid->th, ret); free(tid); return rc; }
+ErlNifTid enif_thread_self(void) { return tls_self; }
+int enif_equal_tids(ErlNifTid a, ErlNifTid b) { return a == b; }
+int enif_compare_pids(const ErlNifPid *a, const ErlNifPid *b) {
+  const uint64_t x = TT(a->pid)->u, y = TT(b->pid)->u;
+  return x < y ? -1 : x > y;
+}
 
 struct ErlNifMutex_ { pthread_mutex_t mu; };
 ErlNifMutex *enif_mutex_create(char *name) { ErlNifMutex *m = (ErlNifMutex *)calloc(1, sizeof *m); pthread_mutex_init(&m->mu, NULL); return m; }

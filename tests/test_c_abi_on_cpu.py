@@ -40,6 +40,10 @@ def test_rounds_as_one_train_launch_through_the_c_abi(emulated_engine, oracle_li
     G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, G=1400, N=3, batches=1)
 
 
+def test_wal_down_host_recipe_through_the_c_abi(emulated_engine, oracle_lib):
+    G.test_wal_down_host_recipe_keeps_last_applied_and_the_log(emulated_engine, oracle_lib)
+
+
 def test_sparse_pending_through_the_c_abi(emulated_engine, oracle_lib):
     for seed in range(8):
         G.test_sparse_pending_and_two_range_written_events(emulated_engine, oracle_lib, seed)

@@ -133,6 +133,64 @@ def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, G=1
         assert_same("small batch (one launch per round)", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
 
 
+def wal_down_reupload(before: np.ndarray, dec: np.ndarray) -> np.ndarray:
+    """INTEGRATION.md's host recipe for `ra_log:write/2 -> {error, wal_down}` (src/ra_server.erl:1377-1385): the state
+    to re-upload for ONE server, from its state before the append_entries_rpc and the decision that carried WROTE.
+    The reference keeps State1 (term, leader_id, commit_index := LeaderCommit) and returns await_condition WITHOUT
+    evaluate_commit_index_follower/2: the log cursors, `pending` and last_applied are what they were before the
+    message, and the APPLIED / AUX_EVAL flags of that decision are ignored (its entries are not in the log)."""
+    new = before.copy()
+    new["current_term"] = dec["reply_term"] if dec["flags"] & abi.F_REPLY else max(int(before["current_term"]), 0)
+    new["commit_index"] = dec["commit_index"]
+    new["role"] = abi.ROLE_AWAIT_CONDITION
+    new["cond_reason"] = abi.COND_WAL_DOWN
+    return new
+
+
+def test_wal_down_host_recipe_keeps_last_applied_and_the_log(engine_mod, oracle_lib):
+    """the append_entries_rpc decision may carry APPLIED together with WROTE (the device applied up to
+    min(last_index, leader_commit), entries included that the WAL then refused).  The host recipe drops that: the
+    re-uploaded server has the OLD last_applied and log, the new term / leader / commit_index, role await_condition
+    (wal_down) -- and from there engine and checker agree on what the next messages do (W1 pins the state itself)."""
+    rng = np.random.default_rng(33)
+    G, N = 8, 3
+    st = fuzz.random_states(rng, G, N, max_runs=4)
+    # a follower whose leader is member 0, log [1..10] in term 3, everything written and applied up to 6
+    s = 1
+    f = st[s:s + 1].copy()
+    f["role"] = abi.ROLE_FOLLOWER; f["cond_reason"] = abi.COND_NONE; f["current_term"] = 3; f["leader_id"] = 0
+    f["voted_for"] = 0; f["first_index"] = 1; f["last_index"] = 10; f["last_term"] = 3
+    f["last_written_index"] = 10; f["last_written_term"] = 3; f["commit_index"] = 6; f["last_applied"] = 6
+    f["snapshot_index"] = abi.UNDEF; f["snapshot_term"] = abi.UNDEF
+    f["n_runs"] = 1; f["run_start"][0][0] = 1; f["run_term"][0][0] = 3; f["pending_first"] = 11; f["n_pending_old"] = 0
+    st[s] = f[0]
+    cpu = oracle_lib.Oracle(G, N); cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=64, ring_slots=2, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        m = np.zeros(1, dtype=abi.MSG_DTYPE)
+        m["server"] = s; m["kind"] = abi.MSG_AER; m["from"] = 0; m["term"] = 3
+        m["a"] = 10; m["b"] = 3; m["c"] = 12; m["n_entries"] = 2; m["n_run0"] = 2; m["run0_term"] = 3
+        dg, _ = gpu.step(m); do, _ = cpu.step(m)
+        assert dg.tobytes() == do.tobytes()
+        d = dg[0]
+        assert d["flags"] & abi.F_WROTE and d["flags"] & abi.F_APPLIED and d["last_applied"] == 12
+        # ra_log:write/2 answered {error, wal_down}: the host recipe
+        new = wal_down_reupload(st[s], d)
+        assert new["last_applied"] == 6 and new["last_index"] == 10 and new["commit_index"] == 12
+        for target in (gpu, cpu):
+            target.set_state(s, new.reshape(1))
+        assert gpu.get_state(s, 1).tobytes() == cpu.get_state(s, 1).tobytes()
+        # while the WAL is down the resend is dropped; once ra_log:can_write/1 is true it is re-processed as a follower
+        for flags, wrote in ((0, False), (abi.MF_CAN_WRITE, True)):
+            m["flags"] = flags
+            dg, _ = gpu.step(m); do, _ = cpu.step(m)
+            assert dg.tobytes() == do.tobytes()
+            assert bool(dg[0]["flags"] & abi.F_WROTE) == wrote
+            assert gpu.get_state(s, 1).tobytes() == cpu.get_state(s, 1).tobytes()
+        assert gpu.get_state(s, 1)["last_applied"][0] == 12 and gpu.get_state(s, 1)["role"][0] == abi.ROLE_FOLLOWER
+    cpu.close()
+
+
 def test_pipelined_ring_keeps_batches_in_order(engine_mod, oracle_lib):
     """submit/submit/submit then collect x3: the staging ring returns batches oldest first."""
     rng = np.random.default_rng(9)

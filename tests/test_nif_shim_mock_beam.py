@@ -261,6 +261,110 @@ def test_collector_fans_decisions_back_to_the_owning_processes(beam, oracle_lib)
     cpu.close()
 
 
+def test_owner_table_is_bounded_and_the_collector_starts_once(beam, oracle_lib):
+    """(1) a pid that registers again keeps its slot, unregister_owner/2 frees a slot for the next process: a thousand
+    restarts leave the table as big as the live owners; the servers of an unregistered process go to the default
+    owner.  (2) start_collector/2 from many threads at once: exactly one starts a thread (compare-exchange)."""
+    import threading
+    G, N = 16, 5
+    rng = np.random.default_rng(83)
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    ok, ctx = beam.call("open", 0, 16, 4, 512)
+    assert ok == "ok" and beam.call("register_groups", ctx, G, N) == "ok"
+    assert beam.call("upload_state", ctx, 0, st.tobytes()) == "ok"
+    for g in range(G):
+        assert beam.call("register_owner", ctx, g * N, N, Opaque(beam.L.mock_pid(2000 + g))) == "ok"
+    assert beam.call("owner_slots", ctx) == (G, G)
+    for g in range(G):                                          # the same processes again: no growth
+        assert beam.call("register_owner", ctx, g * N, N, Opaque(beam.L.mock_pid(2000 + g))) == "ok"
+    assert beam.call("owner_slots", ctx) == (G, G)
+    for restart in range(1000):                                 # group 3's process dies and comes back under a new pid
+        assert beam.call("unregister_owner", ctx, Opaque(beam.L.mock_pid(2003 if restart == 0 else 50000 + restart - 1))) == "ok"
+        assert beam.call("register_owner", ctx, 3 * N, N, Opaque(beam.L.mock_pid(50000 + restart))) == "ok"
+    assert beam.call("owner_slots", ctx) == (G, G)
+    assert beam.call("unregister_owner", ctx, Opaque(beam.L.mock_pid(2005))) == "ok"     # group 5: nobody takes over
+    assert beam.call("owner_slots", ctx) == (G, G - 1)
+    results = []
+    def start():
+        results.append(beam.call("start_collector", ctx, Opaque(beam.L.mock_pid(4242))))
+    ths = [threading.Thread(target=start) for _ in range(8)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert sorted(results) == ["badarg"] * 7 + ["ok"], results
+    msgs = fuzz.random_msgs(rng, cpu.get_state(), N, frac=1.0)
+    want_d, _ = cpu.step(msgs)
+    assert beam.call("submit", ctx, msgs.tobytes(), 1) == "ok"
+    owner_of = lambda srv: 4242 if srv // N == 5 else (50999 if srv // N == 3 else 2000 + srv // N)
+    expect = {}
+    for d in want_d:
+        expect.setdefault(owner_of(int(d["server"])), []).append(d)
+    got = {}
+    for _ in expect:
+        to, msg = beam.recv()
+        assert msg is not None and msg[0] == "ra_gpu_batch"
+        got[to] = msg
+    assert sorted(got) == sorted(expect)
+    for o, ds in expect.items():
+        assert got[o][3] == np.array(ds, dtype=abi.DECISION_DTYPE).tobytes(), f"owner {o}"
+        assert len(got[o][3]) == 64 * got[o][2]                 # the binary is exactly the batch's decisions
+    assert beam.call("stop_collector", ctx) == "ok"
+    assert beam.call("start_collector", ctx, Opaque(beam.L.mock_pid(4242))) == "ok"      # and again
+    assert beam.call("stop_collector", ctx) == "ok"
+    beam.L.mock_gc_resource_term(ctx.t)
+    cpu.close()
+
+
+@pytest.mark.skipif(not os.environ.get("RGB_FANBACK_REPORT"), reason="a 12-minute measurement: RGB_FANBACK_REPORT=1 pytest -s -k fan_back_rate")
+@pytest.mark.parametrize("G,owners", [(8192, 1), (8192, 4096), (65536, 327680)])
+def test_fan_back_rate_report(beam, G, owners, capsys):
+    """What an Erlang caller pays for the per-process fan-back (reference interception point: one gen_statem per
+    server, src/ra_server_proc.erl:1382-1397): wall time from submit/3 until every owner has its message, for ONE
+    default owner (one send per batch), 4 096 owners and one owner PER SERVER (327 680: two binaries + one send per
+    decision).  The kernels run on the CPU emulation here, so the single-owner time is the baseline that the others
+    are read against; the numbers go to DESIGN.md section 5 (run with -s).  Asserts only that everything arrives."""
+    import time
+    N = 5
+    S = G * N
+    rng = np.random.default_rng(91)
+    from ra_amd import workload as W
+    st = W.initial_states(G, N, 91)
+    ok, ctx = beam.call("open", 0, 16, 2, S)
+    assert ok == "ok" and beam.call("register_groups", ctx, G, N) == "ok"
+    assert beam.call("upload_state", ctx, 0, st.tobytes()) == "ok"
+    per = max(S // owners, 1)
+    n_own = 0
+    if owners > 1:
+        for k in range(0, S, per):
+            assert beam.call("register_owner", ctx, k, min(per, S - k), Opaque(beam.L.mock_pid(10000 + k // per))) == "ok"
+            n_own += 1
+    assert beam.call("start_collector", ctx, Opaque(beam.L.mock_pid(4242))) == "ok"
+    msgs = W.gen_tick(st, N, 0, 91)
+    best = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        assert beam.call("submit", ctx, msgs.tobytes(), rep + 1) == "ok"
+        want = len(np.unique(msgs["server"] // per)) if owners > 1 else 1
+        got, n_dec = 0, 0
+        while got < want:
+            to, msg = beam.recv(timeout_ms=120000)
+            assert msg is not None, f"{got} of {want} owner messages arrived"
+            got += 1; n_dec += msg[2]
+        dt = time.perf_counter() - t0
+        assert n_dec == len(msgs)
+        best = dt if best is None else min(best, dt)
+    nb, nd, ns = beam.call("fan_back_stats", ctx)
+    with capsys.disabled():
+        print(f"\n[fan-back] in the collector thread: {nb} batches, {nd} decisions, {ns / max(nd, 1):.0f} ns per decision "
+              f"({nd / max(ns, 1) * 1e3:.1f} M decisions/s) with {max(n_own, 1)} owners")
+        print(f"[fan-back] {len(msgs)} decisions, {max(n_own, 1)} registered owners -> {want} messages per batch: "
+              f"{best * 1e3:.1f} ms per batch (CPU-emulated kernels + collector + fan_back + mock enif_send + Python recv), "
+              f"{len(msgs) / best / 1e6:.2f} M decisions/s")
+    assert beam.call("stop_collector", ctx) == "ok"
+    beam.L.mock_gc_resource_term(ctx.t)
+
+
 def test_concurrent_producers_and_the_collector_thread(beam, oracle_lib):
     """Several processes submit at once (submit is thread-safe) while the collector thread consumes:
     every batch comes back exactly once and whole, per-producer order is kept, the engine ends in the state the
@@ -369,8 +473,10 @@ def test_nif_table_matches_the_erlang_stub(beam):
         arity = len([a for a in args.split(",") if a.strip()])
         flags = beam.L.mock_func_flags(name.encode(), arity)
         assert flags != 0xFFFFFFFF, f"{name}/{arity} is not in the NIF table"
-        if name in ("submit", "open", "start_collector", "register_owner", "route"):
+        if name in ("submit", "open", "start_collector", "register_owner", "route", "owner_slots", "fan_back_stats"):
             assert flags == 0, f"{name} must not be a dirty NIF (non-blocking)"
+        elif name == "unregister_owner":
+            assert flags == 1, "unregister_owner scans the owner map: dirty CPU-bound"
         else:
             assert flags == 2, f"{name} waits on the GPU / copies: dirty IO-bound"
 
