@@ -26,6 +26,9 @@
  *   cc -O2 -fPIC -shared -I$ERL_INCLUDE -Iinclude ra_amd/csrc/ra_gpu_batch_nif.c \
  *      -Lra_amd/csrc -lra_gpu_batch -o priv/ra_gpu_batch_nif.so
  */
+#ifndef _POSIX_C_SOURCE
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime under -std=c11 */
+#endif
 #include <stdatomic.h>
 #include <string.h>
 #include <time.h>
