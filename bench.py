@@ -522,6 +522,60 @@ def main():
         host_path = {"value": best, "unit": "decisions/s", "batch": BATCH,
                      "note": "first 12 ticks through rgb_submit/rgb_collect (ctypes caller, pinned ring, "
                              "PCIe both ways, 64-B message in / 64-B decision + rpc records out), best of 3"}
+        # four producer threads and two consumer threads on one context (the boundary's threading contract: producers
+        # prepare their batches in parallel, the stream's work is enqueued in ticket order, consumers copy different
+        # batches at once).  The batches of the first 12 ticks are dealt round robin to the producers, so the order
+        # in which they reach the device is not the sequential one: a throughput figure, not a parity run
+        try:
+            import threading
+            P_THREADS, C_THREADS = 4, 2
+            eng_p = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=8, ring_capacity=BATCH)
+            chunks = [m[i:i + BATCH] for m in first_ticks[:12] for i in range(0, len(m), BATCH)]
+            best_p = 0.0
+            for rep in range(3):
+                eng_p.set_state(0, st_aged)
+                todo = len(chunks)
+                got = [0] * C_THREADS
+                lock = threading.Lock()
+                taken = [0]
+
+                def producer(k):
+                    for c in chunks[k::P_THREADS]:
+                        while True:
+                            try:
+                                eng_p.submit(c); break
+                            except engine.RgbError as e:
+                                if e.code != abi.E_FULL: raise
+                                time.sleep(0.0002)
+
+                def consumer(k):
+                    bufs_c = (np.empty(BATCH, dtype=abi.DECISION_DTYPE), np.empty(BATCH * max(N - 1, 1), dtype=abi.RPC_DTYPE))
+                    while True:
+                        with lock:
+                            if taken[0] >= todo: return
+                            taken[0] += 1
+                        while True:
+                            try:
+                                d, _r, _t = eng_p.collect(out=bufs_c); got[k] += len(d); break
+                            except engine.RgbError as e:
+                                if e.code != abi.E_EMPTY: raise
+                                eng_p.wait(50)
+
+                ths = [threading.Thread(target=producer, args=(k,)) for k in range(P_THREADS)] + \
+                      [threading.Thread(target=consumer, args=(k,)) for k in range(C_THREADS)]
+                t0 = time.perf_counter()
+                for t in ths: t.start()
+                for t in ths: t.join()
+                dt = time.perf_counter() - t0
+                assert sum(got) == sum(len(c) for c in chunks)
+                best_p = max(best_p, sum(got) / dt)
+            eng_p.close()
+            host_path["threads4"] = {"value": best_p, "unit": "decisions/s", "producer_threads": P_THREADS,
+                                     "consumer_threads": C_THREADS, "batch": BATCH, "ring_slots": 8,
+                                     "note": "the same 12 ticks in 131072-message batches, dealt round robin to 4 Python "
+                                             "threads calling rgb_submit (ctypes releases the GIL), 2 threads in rgb_collect; best of 3"}
+        except Exception as e:                                              # noqa: BLE001 - reported, not raised
+            host_path["threads4"] = {"error": f"{type(e).__name__}: {e}"}
         # the normal shape of a real batch: several messages per server in ONE submit (a leader's N-1 replies arrive
         # together).  Four consecutive ticks per batch = four sub-tick rounds: fused into one train launch, and -- same
         # batches, RGB_CFG_ROUNDS_PER_LAUNCH -- one launch per round

@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -46,21 +47,27 @@ struct rgb_slot {
   u32 *h_rows = nullptr, *d_rows = nullptr;
   u32 rows_cap = 0;                 /* words of h_rows / d_rows */
   bool used_train = false;
+  int enqueue_error = 0;            /* the enqueue of this batch failed (RGB_E_*): rgb_collect reports it once */
+  /* 0 free | 1 reserved by a producer (being filled) | 2 in flight (published) | 3 reserved by a consumer (being
+   * copied out).  Producers take slots in ring order and consumers hand them back in any order, so fullness is the
+   * state of the NEXT slot, not a count. */
+  std::atomic<int> state{0};
   std::vector<u32> perm;            /* device position -> submission index */
   u32 n = 0;
   uint64_t tick = 0;
   hipEvent_t done = nullptr;
-  bool busy = false;
 };
 
-/* Threading contract of the staging ring: any number of threads may call rgb_submit
- * (they serialise on submit_mu: the ring slot, the sub-tick scratch and the order of the stream's work are
- * one critical section -- batches reach the device in the order their submits acquired the lock), any number
- * may call rgb_collect (serialised on collect_mu; every batch is handed out exactly once, oldest first), and
- * the two sides only meet in `in_flight`: submit publishes a filled slot with a release increment after its
- * event is recorded, collect acquires it, and gives the slot back with a release decrement that the next
- * submit's full-check acquires.  head belongs to the producers' lock, tail to the consumers'.  rgb_wait parks
- * a consumer on the condition variable until a batch is in flight (no polling). */
+/* Threading contract of the staging ring: any number of threads may call rgb_submit -- they
+ * prepare their batches in parallel (validation, rounds, the bucket sort into the slot's pinned buffer) and meet in
+ * two short critical sections: submit_mu hands out the next ring slot and a ticket, enqueue_mu lets the tickets
+ * through in order for the stream's work and the publication (batches reach the device in the order their submits
+ * took their slots).  Any number may call rgb_collect: collect_mu covers waiting for the oldest batch, the size check
+ * and taking the slot; the copy back to submission order runs outside it, so consumers copy different batches at
+ * once; every batch is handed out exactly once.  The two sides meet in the slots' atomic states (release on publish,
+ * acquire on collect; release when the slot is given back, acquire by the producer whose turn it is) and in
+ * `in_flight` = published and not yet taken, on which rgb_wait parks a consumer (no polling).  head belongs to the
+ * producers' lock, tail to the consumers'. */
 #define RGB_SUBMIT_TRAIN_ROUNDS 16u    /* a batch with more sub-tick rounds than this takes one launch per round */
 #define RGB_SUBMIT_TRAIN_MIN 4096u     /* and so does a small one: a train's fixed costs are those of a big launch */
 
@@ -75,10 +82,16 @@ struct rgb_ctx {
   rgb_server_state *h_stage = nullptr;   /* pinned */
   u32 stage_cap = 0;
   /* ring */
-  std::vector<rgb_slot> ring;
+  std::unique_ptr<rgb_slot[]> ring_mem;   /* rgb_slot holds an atomic: not movable */
+  u32 ring_size = 0;
   u32 head = 0;                          /* guarded by submit_mu  */
   u32 tail = 0;                          /* guarded by collect_mu */
-  std::atomic<u32> in_flight{0};
+  std::atomic<u32> in_flight{0};         /* published and not yet taken by a consumer */
+  /* producers prepare their batches in parallel; the stream's work is enqueued in the order the slots were taken */
+  uint64_t next_ticket = 0;              /* guarded by submit_mu  */
+  uint64_t enqueue_turn = 0;             /* guarded by enqueue_mu */
+  std::mutex enqueue_mu, train_mu;
+  std::condition_variable enqueue_cv;
   std::mutex submit_mu, collect_mu, state_mu;   /* state_mu: the h_stage / d_stage transfer staging */
   std::mutex wait_mu;
   std::condition_variable wait_cv;
@@ -86,10 +99,6 @@ struct rgb_ctx {
   u32 rpc_cap = 0;      /* records per ring slot = ring_capacity * rpc_stride */
   u32 rpc_stride = 1;   /* fixed rpc slots per message = max(n_members-1, 1) */
 
-  /* sub-tick scheduling scratch (submit_mu) */
-  std::vector<uint16_t> seen;
-  std::vector<u32> touched;
-  std::vector<u32> round_of;
   /* snapshot / checksum scratch */
   rgb_leaderboard_row *d_rows = nullptr;
   u64 *d_sums = nullptr;
@@ -183,14 +192,15 @@ static void free_slot(rgb_slot &s) {
   if (s.h_rows) (void)hipHostFree(s.h_rows);
   if (s.d_rows) (void)hipFree(s.d_rows);
   if (s.done) (void)hipEventDestroy(s.done);
-  s = rgb_slot();
+  s.h_msgs = nullptr; s.h_dec = nullptr; s.d_msgs = nullptr; s.d_dec = nullptr; s.d_rpcs = nullptr; s.h_rpcs = nullptr;
+  s.h_stamps = s.d_stamps = nullptr; s.h_plan = s.d_plan = nullptr; s.h_rows = s.d_rows = nullptr; s.done = nullptr;
 }
 
 void rgb_close(rgb_ctx *ctx) {
   if (!ctx) return;
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   rgb_wal_release(ctx);
-  for (auto &s : ctx->ring) free_slot(s);
+  for (u32 k = 0; k < ctx->ring_size; ++k) free_slot(ctx->ring_mem[k]);
   if (ctx->dev.dbg_buf) (void)hipFree(ctx->dev.dbg_buf);
   if (ctx->dev.hot) (void)hipFree(ctx->dev.hot);
   if (ctx->dev.peers) (void)hipFree(ctx->dev.peers);
@@ -310,12 +320,14 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   HIPCHK(ctx, hipMalloc((void **)&ctx->d_sums, (size_t)S * sizeof(u64)));
   ctx->rpc_stride = n_members > 1 ? n_members - 1 : 1;
   ctx->rpc_cap = ctx->cfg.ring_capacity * ctx->rpc_stride;
-  ctx->ring.resize(ctx->cfg.ring_slots);
-  for (auto &s : ctx->ring) {
+  ctx->ring_mem.reset(new (std::nothrow) rgb_slot[ctx->cfg.ring_slots]);
+  if (!ctx->ring_mem) return RGB_E_NOMEM;
+  ctx->ring_size = ctx->cfg.ring_slots;
+  for (u32 k = 0; k < ctx->ring_size; ++k) {
+    rgb_slot &s = ctx->ring_mem[k];
     int rc = alloc_slot(ctx, s);
     if (rc) return rc;
   }
-  ctx->seen.assign(S, 0);
   ctx->registered = true;
   /* every server starts as ra_server:init/1 on an empty log (empty_state of the reference
    * tests, test/ra_server_SUITE.erl:4139-4149; new_peer/0 src/ra_server.erl:2990-2995) */
@@ -419,82 +431,56 @@ static int validate_msg(const rgb_ctx *ctx, const rgb_msg &m) {
 
 static int train_scratch(rgb_ctx *ctx);
 
-/* The sub-tick rounds of one batch as ONE train launch (reference: the mailbox of a member is FIFO,
+/* The sub-tick rounds of one batch run as ONE train launch (reference: the mailbox of a member is FIFO,
  * src/ra_server_proc.erl:1356-1397 -- a leader's N-1 replies land in one batch, so rounds > 1 are the normal shape):
  * round r = tick r of the train, every round in bucket order, the per-server sequence bytes order a server's
- * messages instead of a kernel boundary per round.  The slot's messages are already in device order. */
-static int submit_rounds_as_train(rgb_ctx *ctx, rgb_slot &s, u32 n, u32 n_rounds, const std::vector<u32> &start,
-                                  const std::vector<u32> &bucket_counts) {
-  const unsigned N = ctx->dev.n_members;
-  u32 rows_max = 0;
-  for (u32 r = 0; r < n_rounds; ++r) {
-    const u32 rows = rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, N, &s.h_plan[r], nullptr, 0);
-    if (rows > rows_max) rows_max = rows;
-  }
-  if (rows_max == 0 || rows_max > s.rows_cap) return RGB_E_UNSUPPORTED;
-  for (u32 r = 0; r < n_rounds; ++r) {
-    for (u32 k = 0; k < rows_max; ++k) s.h_rows[(size_t)r * rows_max + k] = 0xFFFFFFFFu;
-    rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, N, &s.h_plan[r], s.h_rows + (size_t)r * rows_max, rows_max);
-    s.h_plan[r].msg_base = start[r];
-  }
-  /* stamps from the host mirror of the sequence bytes (refreshed from the device after a device-side train) */
-  if (!ctx->seq_host_valid) {
-    const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
-    std::vector<unsigned char> raw(bytes);
-    HIPCHK(ctx, hipMemcpyAsync(raw.data(), ctx->dev.seq, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->seq_host.resize(ctx->dev.n_servers);
-    for (u32 sv = 0; sv < ctx->dev.n_servers; ++sv) ctx->seq_host[sv] = raw[rgb_seq_index(sv, N, ctx->dev.seq_stride)];
-    ctx->seq_host_valid = true;
-  }
-  for (u32 p = 0; p < n; ++p) s.h_stamps[p] = ctx->seq_host[s.h_msgs[p].server]++;
-  HIPCHK(ctx, hipMemcpyAsync(s.d_stamps, s.h_stamps, n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(s.d_plan, s.h_plan, (size_t)n_rounds * sizeof(rgb_train_tick), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(s.d_rows, s.h_rows, (size_t)n_rounds * rows_max * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-  int rc = rgb_launch_train(ctx->dev, s.d_msgs, s.d_stamps, 0, s.d_plan, s.d_rows, n_rounds, rows_max * RGB_TRAIN_SHARDS,
-                            s.d_dec, s.d_rpcs, 1, 0, ctx->d_train_ctl, ctx->stream);
-  if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
-  s.used_train = true;
-  ctx->n_submit_trains.fetch_add(1, std::memory_order_relaxed);
-  return RGB_OK;
-}
-
+ * messages instead of a kernel boundary per round. */
+/* rgb_submit in three steps, so that any number of producers prepare their batches IN PARALLEL:
+ *   1. no lock: validation, the sub-tick rounds (thread-local scratch), the bucket counts;
+ *   2. submit_mu, O(1): take the next ring slot and a ticket -- RGB_E_FULL when that slot is not free;
+ *      then, no lock: the bucket sort of the batch into the slot's pinned buffer, the train plan;
+ *   3. enqueue_mu, in ticket order: the stream's work (H2D, kernels, D2H, event), the train stamps (they count on from
+ *      the previous batch), publication.  Batches reach the device in the order their submits took their slots.
+ * Everything that can fail because of the INPUT fails before step 2; a HIP error in step 3 publishes the batch as
+ * failed (rgb_collect returns the error once and the ring moves on). */
 int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   if (!ctx || (!msgs && n)) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   if (n > ctx->cfg.ring_capacity) return RGB_E_INVAL;
-  for (u32 i = 0; i < n; ++i) {                  /* validation needs no lock: it reads the batch only */
+  for (u32 i = 0; i < n; ++i) {
     int rc = validate_msg(ctx, msgs[i]);
     if (rc) return rc;
   }
-  std::lock_guard<std::mutex> lk(ctx->submit_mu);
-  /* acquire: a slot the consumer gave back (release decrement in rgb_collect) is really free */
-  if (ctx->in_flight.load(std::memory_order_acquire) == ctx->ring.size()) return RGB_E_FULL;
-  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-  rgb_slot &s = ctx->ring[ctx->head];
-  /* sub-tick rounds: round r = every server's r-th message of this batch, in order */
-  ctx->round_of.resize(n);
-  ctx->touched.clear();
+  /* ---- 1. rounds: round r = every server's r-th message of this batch, in order (per-thread scratch) ---- */
+  thread_local std::vector<uint16_t> seen;
+  thread_local std::vector<u32> touched, round_of;
+  if (seen.size() < ctx->dev.n_servers) seen.assign(ctx->dev.n_servers, 0);
+  round_of.resize(n);
+  touched.clear();
   u32 n_rounds = n ? 1 : 0;
+  bool any_nop = false, too_many = false;
   for (u32 i = 0; i < n; ++i) {
     u32 r = 0;
     if (msgs[i].kind != RGB_MSG_NOP) {
-      uint16_t &c = ctx->seen[msgs[i].server];
-      if (c == 0) ctx->touched.push_back(msgs[i].server);
+      uint16_t &c = seen[msgs[i].server];
+      if (c == 0) touched.push_back(msgs[i].server);
       r = c;
-      if (c == 0xFFFF) { for (u32 t : ctx->touched) ctx->seen[t] = 0; return RGB_E_UNSUPPORTED; }
+      if (c == 0xFFFF) { too_many = true; break; }
       c++;
-    }
-    ctx->round_of[i] = r;
+    } else any_nop = true;
+    round_of[i] = r;
     if (r + 1 > n_rounds) n_rounds = r + 1;
   }
-  for (u32 t : ctx->touched) ctx->seen[t] = 0;
+  for (u32 t : touched) seen[t] = 0;
+  if (too_many) return RGB_E_UNSUPPORTED;
   /* several rounds, a batch worth a big launch, no NOP padding, a device that keeps a shard on one XCD: the rounds
    * run as ONE train launch, in bucket order (class, shard, success flag) -- a finer key of the same family order */
-  bool as_train = n_rounds >= 2 && n_rounds <= RGB_SUBMIT_TRAIN_ROUNDS && n >= RGB_SUBMIT_TRAIN_MIN &&
+  bool as_train = n_rounds >= 2 && n_rounds <= RGB_SUBMIT_TRAIN_ROUNDS && n >= RGB_SUBMIT_TRAIN_MIN && !any_nop &&
                   !(ctx->cfg.flags & RGB_CFG_ROUNDS_PER_LAUNCH);
-  for (u32 i = 0; as_train && i < n; ++i) as_train = msgs[i].kind != RGB_MSG_NOP;
-  if (as_train) as_train = train_scratch(ctx) == RGB_OK;
+  if (as_train) {
+    std::lock_guard<std::mutex> tl(ctx->train_mu);          /* the one-off calibration uses the stream */
+    as_train = train_scratch(ctx) == RGB_OK;
+  }
   /* device order: by round, then by clause family = (message kind, success flag) (a round holds
    * at most one message per server, so its order is free; family-homogeneous wavefronts do not
    * diverge across clause families), stable inside a bucket */
@@ -507,56 +493,49 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   std::vector<u32> start(n_rounds + 1, 0);
   std::vector<u32> bucket((size_t)n_rounds * NK + 1, 0);
   for (u32 i = 0; i < n; ++i) {
-    start[ctx->round_of[i] + 1]++;
-    bucket[(size_t)ctx->round_of[i] * NK + family(msgs[i]) + 1]++;
+    start[round_of[i] + 1]++;
+    bucket[(size_t)round_of[i] * NK + family(msgs[i]) + 1]++;
   }
   for (u32 r = 0; r < n_rounds; ++r) start[r + 1] += start[r];
   if (as_train) bucket_counts.assign(bucket.begin() + 1, bucket.end());      /* per (round, bucket), before the scan */
   for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) bucket[b + 1] += bucket[b];
+
+  /* ---- 2. the slot and the ticket ---- */
+  rgb_slot *sp;
+  uint64_t ticket;
+  {
+    std::lock_guard<std::mutex> lk(ctx->submit_mu);
+    sp = &ctx->ring_mem[ctx->head];
+    int free_state = 0;
+    /* acquire: a slot a consumer gave back (release store in rgb_collect) is really free */
+    if (!sp->state.compare_exchange_strong(free_state, 1, std::memory_order_acquire)) return RGB_E_FULL;
+    ctx->head = (ctx->head + 1) % ctx->ring_size;
+    ticket = ctx->next_ticket++;
+  }
+  rgb_slot &s = *sp;
   s.perm.resize(n);
   for (u32 i = 0; i < n; ++i) {
-    u32 p = bucket[(size_t)ctx->round_of[i] * NK + family(msgs[i])]++;
+    u32 p = bucket[(size_t)round_of[i] * NK + family(msgs[i])]++;
     s.perm[p] = i;
     s.h_msgs[p] = msgs[i];
   }
   s.n = n; s.tick = tick;
-  s.used_train = false;
-  if (n) {
-    HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice,
-                               ctx->stream));
-    if (as_train) {
-      int rc = submit_rounds_as_train(ctx, s, n, n_rounds, start, bucket_counts);
-      if (rc == RGB_E_UNSUPPORTED) as_train = false;       /* more rows than the slot's table holds: one launch per round */
-      else if (rc) return rc;
+  s.used_train = false; s.enqueue_error = 0;
+  u32 rows_max = 0;
+  if (as_train) {                                            /* the plan of every round: slot-local, no lock */
+    for (u32 r = 0; r < n_rounds; ++r) {
+      const u32 rows = rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, n_members, &s.h_plan[r], nullptr, 0);
+      if (rows > rows_max) rows_max = rows;
     }
-    for (u32 r = 0; r < n_rounds && !s.used_train; ++r) {
-      u32 off = start[r], cnt = start[r + 1] - start[r];
-      int rc;
-      if (cnt >= 4096) {
-        /* big round: the class-dispatch kernel (specialised path per message kind) */
-        u32 cc[RGB_N_CLASSES] = {0};
-        for (u32 p = off; p < off + cnt; ++p)
-          if (s.h_msgs[p].kind != RGB_MSG_NOP) cc[rgb_class_of_kind(s.h_msgs[p].kind)]++;
-        rc = launch_tick_classes(ctx, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
-        if (rc) return rc;
-        u32 real = 0;
-        for (int c = 0; c < RGB_N_CLASSES; ++c) real += cc[c];
-        if (real < cnt) {      /* NOP slots sort last: the generic kernel writes their empty decisions */
-          rc = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
-                               s.d_rpcs, off + real, off + real, ctx->stream);
-          if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
-        }
-      } else {
-        rc = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off,
-                             ctx->stream);
-        if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
-      }
+    if (rows_max == 0 || rows_max > s.rows_cap) as_train = false;   /* more rows than the slot's table holds */
+    for (u32 r = 0; as_train && r < n_rounds; ++r) {
+      for (u32 k = 0; k < rows_max; ++k) s.h_rows[(size_t)r * rows_max + k] = 0xFFFFFFFFu;
+      rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, n_members, &s.h_plan[r], s.h_rows + (size_t)r * rows_max, rows_max);
+      s.h_plan[r].msg_base = start[r];
     }
-    HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost,
-                               ctx->stream));
-    /* the fixed rpc slots come back with the decisions, but only the span of device positions whose
-     * message kind can emit rpcs (the batch is in family order, so the append_entries_rpc / written
-     * bulk in front of and behind that span is never copied) */
+  }
+  /* the rpc slots that come back: the span of device positions whose message kind can emit rpcs */
+  {
     u32 lo = n, hi = 0;
     for (u32 p = 0; p < n; ++p) {
       const unsigned k = s.h_msgs[p].kind;
@@ -567,57 +546,129 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
       }
     }
     s.rpc_lo = lo < n ? lo : 0; s.rpc_cnt = lo < n ? hi - lo + 1 : 0;
-    if (s.rpc_cnt)
-      HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
-                                 (size_t)s.rpc_cnt * ctx->rpc_stride * sizeof(rgb_rpc), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-  } else {
-    s.rpc_lo = s.rpc_cnt = 0;
   }
-  HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
-  s.busy = true;
-  ctx->head = (ctx->head + 1) % (u32)ctx->ring.size();
-  /* publish: everything written to the slot above happens-before the consumer's acquire load */
-  ctx->in_flight.fetch_add(1, std::memory_order_release);
+
+  /* ---- 3. the stream's work, in ticket order ---- */
+  int rc = RGB_OK;
+  {
+    std::unique_lock<std::mutex> el(ctx->enqueue_mu);
+    ctx->enqueue_cv.wait(el, [&] { return ctx->enqueue_turn == ticket; });
+    rc = [&]() -> int {
+      HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+      if (!n) { HIPCHK(ctx, hipEventRecord(s.done, ctx->stream)); return RGB_OK; }
+      HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice, ctx->stream));
+      if (as_train) {
+        /* stamps from the host mirror of the sequence bytes (refreshed from the device after a device-side train) */
+        if (!ctx->seq_host_valid) {
+          const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
+          std::vector<unsigned char> raw(bytes);
+          HIPCHK(ctx, hipMemcpyAsync(raw.data(), ctx->dev.seq, bytes, hipMemcpyDeviceToHost, ctx->stream));
+          HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+          ctx->seq_host.resize(ctx->dev.n_servers);
+          for (u32 sv = 0; sv < ctx->dev.n_servers; ++sv) ctx->seq_host[sv] = raw[rgb_seq_index(sv, n_members, ctx->dev.seq_stride)];
+          ctx->seq_host_valid = true;
+        }
+        for (u32 p = 0; p < n; ++p) s.h_stamps[p] = ctx->seq_host[s.h_msgs[p].server]++;
+        HIPCHK(ctx, hipMemcpyAsync(s.d_stamps, s.h_stamps, n, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(s.d_plan, s.h_plan, (size_t)n_rounds * sizeof(rgb_train_tick), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(s.d_rows, s.h_rows, (size_t)n_rounds * rows_max * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+        int lr = rgb_launch_train(ctx->dev, s.d_msgs, s.d_stamps, 0, s.d_plan, s.d_rows, n_rounds, rows_max * RGB_TRAIN_SHARDS,
+                                  s.d_dec, s.d_rpcs, 1, 0, ctx->d_train_ctl, ctx->stream);
+        if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+        s.used_train = true;
+        ctx->n_submit_trains.fetch_add(1, std::memory_order_relaxed);
+      }
+      for (u32 r = 0; r < n_rounds && !s.used_train; ++r) {
+        u32 off = start[r], cnt = start[r + 1] - start[r];
+        int lr;
+        if (cnt >= 4096) {
+          /* big round: the class-dispatch kernel (specialised path per message kind) */
+          u32 cc[RGB_N_CLASSES] = {0};
+          for (u32 p = off; p < off + cnt; ++p)
+            if (s.h_msgs[p].kind != RGB_MSG_NOP) cc[rgb_class_of_kind(s.h_msgs[p].kind)]++;
+          lr = launch_tick_classes(ctx, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
+          if (lr) return lr;
+          u32 real = 0;
+          for (int c = 0; c < RGB_N_CLASSES; ++c) real += cc[c];
+          if (real < cnt) {      /* NOP slots sort last: the generic kernel writes their empty decisions */
+            lr = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
+                                 s.d_rpcs, off + real, off + real, ctx->stream);
+            if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+          }
+        } else {
+          lr = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off, ctx->stream);
+          if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+        }
+      }
+      HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost, ctx->stream));
+      if (s.rpc_cnt)
+        HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
+                                   (size_t)s.rpc_cnt * ctx->rpc_stride * sizeof(rgb_rpc), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
+      return RGB_OK;
+    }();
+    if (rc != RGB_OK) { s.enqueue_error = rc; s.n = 0; s.rpc_cnt = 0; (void)hipEventRecord(s.done, ctx->stream); }
+    /* publish: everything written to the slot above happens-before the consumer's acquire load */
+    s.state.store(2, std::memory_order_release);
+    ctx->in_flight.fetch_add(1, std::memory_order_release);
+    ctx->enqueue_turn += 1;
+  }
+  ctx->enqueue_cv.notify_all();
   { std::lock_guard<std::mutex> wl(ctx->wait_mu); }
   ctx->wait_cv.notify_one();
-  return RGB_OK;
+  return rc;
 }
 
+/* rgb_collect: the oldest published batch.  Under collect_mu only: wait for the batch, size check, take the slot;
+ * the copy back to submission order runs outside the lock, so several consumers copy different batches at once. */
 int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, rgb_rpc *rpc_out,
                 uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out) {
   if (!ctx) return RGB_E_INVAL;
   if (n_out) *n_out = 0;
   if (n_rpc_out) *n_rpc_out = 0;
-  std::lock_guard<std::mutex> lk(ctx->collect_mu);
-  if (ctx->in_flight.load(std::memory_order_acquire) == 0) return RGB_E_EMPTY;
-  rgb_slot &s = ctx->ring[ctx->tail];
-  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-  HIPCHK(ctx, hipEventSynchronize(s.done));
-  if (s.used_train) {
-    /* a train that hit its spin bound or found a block on the wrong XCD did not compute the batch: consumed,
-     * reported once, the caller re-uploads the servers and resubmits (exceptional: the placement is checked when
-     * the first train of a context is set up) */
-    u32 flags = 0;
-    HIPCHK(ctx, hipMemcpy(&flags, ctx->d_train_ctl, sizeof flags, hipMemcpyDeviceToHost));
-    if (flags) {
-      HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, sizeof(u32)));
-      ctx->seq_host_valid = false;
-      s.busy = false; s.used_train = false;
-      ctx->tail = (ctx->tail + 1) % (u32)ctx->ring.size();
-      ctx->in_flight.fetch_sub(1, std::memory_order_release);
-      return RGB_E_STATE;
-    }
-  }
+  rgb_slot *sp;
   u32 n_rpc = 0;
-  for (u32 p = 0; p < s.n; ++p) n_rpc += s.h_dec[p].n_rpcs;
-  /* a buffer that is too small leaves the batch in the ring: the sizes it needs are reported and the
-   * caller retries (nothing is dropped, the ring is not wedged) */
-  if (s.n > cap || (s.n && !out) || (rpc_out && n_rpc > rpc_cap)) {
-    if (n_out) *n_out = s.n;
-    if (n_rpc_out) *n_rpc_out = n_rpc;
-    return (s.n > cap || (s.n && !out)) ? RGB_E_INVAL : RGB_E_FULL;
+  {
+    std::lock_guard<std::mutex> lk(ctx->collect_mu);
+    if (ctx->in_flight.load(std::memory_order_acquire) == 0) return RGB_E_EMPTY;
+    sp = &ctx->ring_mem[ctx->tail];
+    rgb_slot &s = *sp;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipEventSynchronize(s.done));
+    int fail = s.enqueue_error;
+    if (!fail && s.used_train) {
+      /* a train that hit its spin bound or found a block on the wrong XCD did not compute the batch: consumed,
+       * reported once, the caller re-uploads the servers and resubmits (exceptional: the placement is checked when
+       * the first train of a context is set up) */
+      u32 flags = 0;
+      HIPCHK(ctx, hipMemcpy(&flags, ctx->d_train_ctl, sizeof flags, hipMemcpyDeviceToHost));
+      if (flags) {
+        HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, sizeof(u32)));
+        std::lock_guard<std::mutex> el(ctx->enqueue_mu);
+        ctx->seq_host_valid = false;
+        fail = RGB_E_STATE;
+      }
+    }
+    if (fail) {
+      s.used_train = false; s.enqueue_error = 0;
+      ctx->tail = (ctx->tail + 1) % ctx->ring_size;
+      ctx->in_flight.fetch_sub(1, std::memory_order_release);
+      s.state.store(0, std::memory_order_release);
+      return fail;
+    }
+    for (u32 p = 0; p < s.n; ++p) n_rpc += s.h_dec[p].n_rpcs;
+    /* a buffer that is too small leaves the batch in the ring: the sizes it needs are reported and the
+     * caller retries (nothing is dropped, the ring is not wedged) */
+    if (s.n > cap || (s.n && !out) || (rpc_out && n_rpc > rpc_cap)) {
+      if (n_out) *n_out = s.n;
+      if (n_rpc_out) *n_rpc_out = n_rpc;
+      return (s.n > cap || (s.n && !out)) ? RGB_E_INVAL : RGB_E_FULL;
+    }
+    s.state.store(3, std::memory_order_relaxed);            /* mine: the next consumer takes the next slot */
+    ctx->tail = (ctx->tail + 1) % ctx->ring_size;
+    ctx->in_flight.fetch_sub(1, std::memory_order_release);
   }
+  rgb_slot &s = *sp;
   /* decisions back in submission order; remember where each one ran on the device */
   std::vector<u32> pos_of(s.n);
   for (u32 p = 0; p < s.n; ++p) {
@@ -644,10 +695,8 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
   if (n_out) *n_out = s.n;
   if (n_rpc_out) *n_rpc_out = n_rpc;
   if (tick_out) *tick_out = s.tick;
-  s.busy = false;
-  ctx->tail = (ctx->tail + 1) % (u32)ctx->ring.size();
-  /* release: the slot's buffers are free for the next submit that observes the lower count */
-  ctx->in_flight.fetch_sub(1, std::memory_order_release);
+  /* release: the slot's buffers are free for the producer whose turn it is */
+  s.state.store(0, std::memory_order_release);
   return rc_out;
 }
 
@@ -659,7 +708,7 @@ int rgb_peek(rgb_ctx *ctx, uint32_t *n_out, uint32_t *n_rpc_out) {
   if (n_rpc_out) *n_rpc_out = 0;
   std::lock_guard<std::mutex> lk(ctx->collect_mu);
   if (ctx->in_flight.load(std::memory_order_acquire) == 0) return RGB_E_EMPTY;
-  rgb_slot &s = ctx->ring[ctx->tail];
+  rgb_slot &s = ctx->ring_mem[ctx->tail];
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   HIPCHK(ctx, hipEventSynchronize(s.done));
   u32 n_rpc = 0;

@@ -2636,7 +2636,9 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     }
     if (lane == 0) {
       u64 *o = dev.dbg_buf + (size_t)blockIdx.x * 8;
-      o[0] = t0; o[1] = t1 | ((tl[0] - t1) << 40); o[2] = t2 | ((t2b - t2) << 40) | ((u64)cls << 60); o[3] = wall_clock64();
+      /* a wavefront whose lanes all took a fast path never stamped tl[0] / t2: zeros, not wrapped differences */
+      o[0] = t0; o[1] = t1 | ((tl[0] > t1 ? tl[0] - t1 : 0) << 40);
+      o[2] = t2 | ((t2b > t2 ? t2b - t2 : 0) << 40) | ((u64)cls << 60); o[3] = wall_clock64();
       o[4] = mx; o[5] = sm | ((tl[2] > t1 ? tl[2] - t1 : 0) << 24); o[6] = nz | ((tl[3] > t1 ? tl[3] - t1 : 0) << 24);
       o[7] = cnt | ((u64)n_fast << 8) | ((tf > t1 ? tf - t1 : 0) << 24);   /* lanes, lanes the fast paths took, fast paths done */
     }

@@ -32,6 +32,13 @@ cls = (b[:, 2] >> np.uint64(60)).astype(int)
 M40 = np.uint64((1 << 40) - 1)
 t0 = b[:, 0].astype(np.int64); t1 = (b[:, 1] & M40).astype(np.int64); dl = (b[:, 1] >> np.uint64(40)).astype(np.int64)
 t2 = (b[:, 2] & M40).astype(np.int64); dst = ((b[:, 2] >> np.uint64(40)) & np.uint64(0xFFFFF)).astype(np.int64); t3 = (b[:, 3] & M40).astype(np.int64)
+# wavefronts whose lanes all took a fast path never ran the general clause code: t2 (its end) is unset.  Their
+# "process" phase ends where the fast paths ended (o[7] >> 24, relative to the messages-in-registers stamp) and
+# their state-load figure (stamped inside the general path) does not exist
+tfast_all = (b[:, 7] >> np.uint64(24)).astype(np.int64)
+only_fast = t2 == 0
+t2 = np.where(only_fast, (t1 & ((1 << 40) - 1)) + tfast_all, t2)
+dl = np.where(only_fast, 0, dl)
 t0 = t0 & ((1 << 40) - 1)
 z = t0.min()
 tick = 10.0  # ns per wall_clock64 tick (100 MHz)
@@ -40,7 +47,7 @@ for c in range(12):
     m = cls == c
     if not m.any(): continue
     print(f"class {c}: waves {m.sum():5d} start {((t0[m]-z).min()*tick/1e3):6.1f}..{((t0[m]-z).max()*tick/1e3):6.1f} us | "
-          f"msg-load {np.median(t1[m]-t0[m])*tick/1e3:5.2f} | state-load {np.median(dl[m])*tick/1e3:5.2f} | store-drain {np.median(dst[m])*tick/1e3:5.2f} | process {np.median(t2[m]-t1[m])*tick/1e3:5.2f} (p90 {np.percentile(t2[m]-t1[m],90)*tick/1e3:5.2f}) | "
+          f"msg-load {np.median(t1[m]-t0[m])*tick/1e3:5.2f} | state-load {(f'{np.median(dl[m][dl[m] > 0])*tick/1e3:5.2f}' if (dl[m] > 0).any() else '  n/a')} ({int((dl[m] > 0).sum())} of {int(m.sum())} waves ran the general path) | store-drain {np.median(dst[m])*tick/1e3:5.2f} | process {np.median(t2[m]-t1[m])*tick/1e3:5.2f} (p90 {np.percentile(t2[m]-t1[m],90)*tick/1e3:5.2f}) | "
           f"dec-store {np.median(t3[m]-t2[m])*tick/1e3:5.2f} | wave life {np.median(t3[m]-t0[m])*tick/1e3:5.2f} us")
     M24 = (1 << 24) - 1
     d_disp, d_comm = (b[m, 5] >> np.uint64(24)).astype(np.int64), (b[m, 6] >> np.uint64(24)).astype(np.int64)
