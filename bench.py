@@ -528,7 +528,7 @@ def main():
         # in which they reach the device is not the sequential one: a throughput figure, not a parity run
         try:
             import threading
-            P_THREADS, C_THREADS = 4, 2
+            P_THREADS, C_THREADS = 4, 3
             eng_p = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=8, ring_capacity=BATCH)
             chunks = [m[i:i + BATCH] for m in first_ticks[:12] for i in range(0, len(m), BATCH)]
             best_p = 0.0
@@ -573,7 +573,7 @@ def main():
             host_path["threads4"] = {"value": best_p, "unit": "decisions/s", "producer_threads": P_THREADS,
                                      "consumer_threads": C_THREADS, "batch": BATCH, "ring_slots": 8,
                                      "note": "the same 12 ticks in 131072-message batches, dealt round robin to 4 Python "
-                                             "threads calling rgb_submit (ctypes releases the GIL), 2 threads in rgb_collect; best of 3"}
+                                             "threads calling rgb_submit (ctypes releases the GIL), 3 threads in rgb_collect; best of 3"}
         except Exception as e:                                              # noqa: BLE001 - reported, not raised
             host_path["threads4"] = {"error": f"{type(e).__name__}: {e}"}
         # the normal shape of a real batch: several messages per server in ONE submit (a leader's N-1 replies arrive

@@ -58,6 +58,7 @@ ErlNifEnv *enif_alloc_env(void);
 void enif_free_env(ErlNifEnv *);
 void enif_clear_env(ErlNifEnv *);
 int enif_send(ErlNifEnv *, const ErlNifPid *, ErlNifEnv *, ERL_NIF_TERM);
+ERL_NIF_TERM enif_make_sub_binary(ErlNifEnv *, ERL_NIF_TERM, size_t, size_t);
 int enif_thread_create(char *, ErlNifTid *, void *(*)(void *), void *, ErlNifThreadOpts *);
 int enif_thread_join(ErlNifTid, void **);
 ErlNifTid enif_thread_self(void);

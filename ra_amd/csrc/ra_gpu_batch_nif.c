@@ -311,7 +311,6 @@ static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint3
   uint32_t *tix = c->tix, *tgen = c->tix + c->tix_cap;       /* tix[o] valid iff tgen[o] == tix_gen */
   uint32_t *own = (uint32_t *)enif_alloc((size_t)(n + 1) * 6 * sizeof(uint32_t));
   ErlNifPid *to = NULL;
-  ErlNifBinary *bins = NULL;
   int rc = RGB_OK;
   if (!own) rc = RGB_E_NOMEM;
   uint32_t n_t = 0;
@@ -331,35 +330,50 @@ static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint3
   }
   enif_mutex_unlock(c->own_mu);
   if (rc == RGB_OK) {
-    bins = (ErlNifBinary *)enif_alloc((size_t)(n_t ? n_t : 1) * 2 * sizeof(ErlNifBinary));
-    uint32_t made = 0;
-    if (!bins) rc = RGB_E_NOMEM;
-    for (; rc == RGB_OK && made < n_t; ++made) {
-      if (!enif_alloc_binary((size_t)cnt_d[made] * sizeof(rgb_decision), &bins[2 * made])) { rc = RGB_E_NOMEM; break; }
-      if (!enif_alloc_binary((size_t)cnt_r[made] * sizeof(rgb_rpc), &bins[2 * made + 1])) {
-        enif_release_binary(&bins[2 * made]); rc = RGB_E_NOMEM; break;
-      }
-    }
-    if (rc != RGB_OK) {
-      for (uint32_t t = 0; t < made; ++t) { enif_release_binary(&bins[2 * t]); enif_release_binary(&bins[2 * t + 1]); }
-    } else {
-      uint32_t k = 0;                                          /* cursor into the rpc records */
-      for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t t = slot_of[i];
-        const uint32_t at = fill_d[t]++;
-        ((rgb_decision *)bins[2 * t].data)[at] = d[i];
-        for (uint32_t q = 0; q < d[i].n_rpcs; ++q) {
-          rgb_rpc x = r[k++];
-          x.msg_index = at;
-          ((rgb_rpc *)bins[2 * t + 1].data)[fill_r[t]++] = x;
+    /* ONE decisions binary and ONE rpc binary per batch, grouped by owner in first-appearance order; every owner
+     * gets SUB-BINARIES of them (no allocation and no copy per owner: with one gen_statem per server that is per
+     * decision -- the mock BEAM measured 263 ns per decision at 4 096 owners with two binaries allocated per owner).
+     * The messages are sent with msg_env = NULL (copied: the two parent terms stay valid until the env is cleared). */
+    ErlNifBinary all_d, all_r;
+    uint32_t tot_r = 0;
+    for (uint32_t t = 0; t < n_t; ++t) tot_r += cnt_r[t];
+    if (!enif_alloc_binary((size_t)n * sizeof(rgb_decision), &all_d)) rc = RGB_E_NOMEM;
+    else if (!enif_alloc_binary((size_t)tot_r * sizeof(rgb_rpc), &all_r)) { enif_release_binary(&all_d); rc = RGB_E_NOMEM; }
+    if (rc == RGB_OK) {
+      /* fill_d / fill_r become the owners' running cursors: start at their offsets */
+      uint32_t od = 0, orr = 0;
+      for (uint32_t t = 0; t < n_t; ++t) { fill_d[t] = od; fill_r[t] = orr; od += cnt_d[t]; orr += cnt_r[t]; }
+      uint32_t *first_d = (uint32_t *)enif_alloc((size_t)(n_t ? n_t : 1) * 2 * sizeof(uint32_t));
+      if (!first_d) { enif_release_binary(&all_d); enif_release_binary(&all_r); rc = RGB_E_NOMEM; }
+      else {
+        uint32_t *first_r = first_d + (n_t ? n_t : 1);
+        for (uint32_t t = 0; t < n_t; ++t) { first_d[t] = fill_d[t]; first_r[t] = fill_r[t]; }
+        uint32_t k = 0;                                        /* cursor into the rpc records */
+        for (uint32_t i = 0; i < n; ++i) {
+          const uint32_t t = slot_of[i];
+          const uint32_t at = fill_d[t]++;
+          ((rgb_decision *)all_d.data)[at] = d[i];
+          for (uint32_t q = 0; q < d[i].n_rpcs; ++q) {
+            rgb_rpc x = r[k++];
+            x.msg_index = at - first_d[t];                     /* position inside that owner's DecisionsBin */
+            ((rgb_rpc *)all_r.data)[fill_r[t]++] = x;
+          }
         }
+        ERL_NIF_TERM td = enif_make_binary(env, &all_d), tr = enif_make_binary(env, &all_r);
+        for (uint32_t t = 0; t < n_t; ++t) {
+          ERL_NIF_TERM msg = enif_make_tuple5(env, enif_make_atom(env, "ra_gpu_batch"), enif_make_uint64(env, tick),
+                                              enif_make_uint64(env, cnt_d[t]),
+                                              enif_make_sub_binary(env, td, (size_t)first_d[t] * sizeof(rgb_decision), (size_t)cnt_d[t] * sizeof(rgb_decision)),
+                                              enif_make_sub_binary(env, tr, (size_t)first_r[t] * sizeof(rgb_rpc), (size_t)cnt_r[t] * sizeof(rgb_rpc)));
+          enif_send(NULL, &to[t], NULL, msg);
+        }
+        enif_clear_env(env);
+        enif_free(first_d);
       }
-      for (uint32_t t = 0; t < n_t; ++t) send_batch(env, &to[t], tick, cnt_d[t], &bins[2 * t], &bins[2 * t + 1]);
     }
   }
   if (to) enif_free(to);
   if (own) enif_free(own);
-  if (bins) enif_free(bins);
   enif_release_binary(dec); enif_release_binary(rpc);
   return rc;
 }

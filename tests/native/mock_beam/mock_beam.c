@@ -44,6 +44,10 @@ int enif_realloc_binary(ErlNifBinary *b, size_t n) {
   b->data = p; b->ref_bin = p; b->size = n; return 1;
 }
 ERL_NIF_TERM enif_make_binary(ErlNifEnv *e, ErlNifBinary *b) { term *t = mk(T_BIN); t->data = b->data; t->size = b->size; b->ref_bin = NULL; return (ERL_NIF_TERM)t; }
+/* a view into the parent's bytes (terms are never freed in the mock, so the parent outlives it) */
+ERL_NIF_TERM enif_make_sub_binary(ErlNifEnv *e, ERL_NIF_TERM parent, size_t pos, size_t size) {
+  term *t = mk(T_BIN); t->data = TT(parent)->data + pos; t->size = size; return (ERL_NIF_TERM)t;
+}
 int enif_inspect_binary(ErlNifEnv *e, ERL_NIF_TERM x, ErlNifBinary *b) {
   if (TT(x)->tag != T_BIN) return 0;
   b->data = TT(x)->data; b->size = TT(x)->size; b->ref_bin = NULL; return 1;
