@@ -40,6 +40,10 @@ def test_rounds_as_one_train_launch_through_the_c_abi(emulated_engine, oracle_li
     G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, G=1400, N=3, batches=1)
 
 
+def test_concurrent_producers_and_consumers_through_the_c_abi(emulated_engine, oracle_lib):
+    G.test_concurrent_producers_and_consumers_on_one_context(emulated_engine, oracle_lib, G=64, N=5, P=4, C_=2, per=5)
+
+
 def test_wal_down_host_recipe_through_the_c_abi(emulated_engine, oracle_lib):
     G.test_wal_down_host_recipe_keeps_last_applied_and_the_log(emulated_engine, oracle_lib)
 

@@ -191,6 +191,78 @@ def test_wal_down_host_recipe_keeps_last_applied_and_the_log(engine_mod, oracle_
     cpu.close()
 
 
+def test_concurrent_producers_and_consumers_on_one_context(engine_mod, oracle_lib, G=256, N=5, P=4, C_=2, per=6):
+    """The boundary's threading contract (include/ra_gpu_batch.h): P threads in rgb_submit and C_ threads in rgb_collect
+    on ONE context.  Every producer owns a disjoint range of groups, so the order in which the producers' batches
+    interleave does not matter: each server sees its own producer's batches in that producer's order, and the result
+    must be the checker's -- every batch's decisions (identified by its tick number) and the final state."""
+    import threading
+    rng = np.random.default_rng(57)
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    gp = G // P
+    batches, want = {}, {}
+    for k in range(P):                                          # producer k: groups [k gp, (k+1) gp)
+        for b in range(per):
+            cur = cpu.get_state()
+            m = fuzz.random_msgs(rng, cur[k * gp * N:(k + 1) * gp * N], N, frac=0.8)
+            m["server"] += k * gp * N
+            parts = [m]
+            if b % 2:                                           # every other batch carries a second round
+                m2 = fuzz.random_msgs(rng, cur[k * gp * N:(k + 1) * gp * N], N, frac=0.3)
+                m2["server"] += k * gp * N
+                parts.append(m2)
+            msgs = np.concatenate(parts)
+            d, r = cpu.step(msgs)
+            batches[(k, b)] = msgs; want[1000 * k + b] = (d, r)
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=8192, ring_slots=3, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        total = P * per
+        got, errs = {}, []
+        lock = threading.Lock()
+        taken = [0]
+
+        def producer(k):
+            try:
+                for b in range(per):
+                    while True:
+                        try:
+                            gpu.submit(batches[(k, b)], tick=1000 * k + b); break
+                        except engine_mod.RgbError as e:
+                            if e.code != abi.E_FULL: raise
+            except Exception as e:                               # noqa: BLE001
+                errs.append(e)
+
+        def consumer():
+            try:
+                while True:
+                    with lock:
+                        if taken[0] >= total: return
+                        taken[0] += 1
+                    while True:
+                        try:
+                            d, r, tick = gpu.collect(); break
+                        except engine_mod.RgbError as e:
+                            if e.code != abi.E_EMPTY: raise
+                            gpu.wait(20)
+                    with lock:
+                        got[tick] = (d.copy(), r.copy())
+            except Exception as e:                               # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=producer, args=(k,)) for k in range(P)] + [threading.Thread(target=consumer) for _ in range(C_)]
+        for t in ths: t.start()
+        for t in ths: t.join()
+        assert not errs, errs
+        assert sorted(got) == sorted(want)
+        for tick, (d, r) in want.items():
+            assert got[tick][0].tobytes() == d.tobytes(), f"batch {tick}: decisions"
+            assert fuzz.sort_rpcs(got[tick][1].copy()).tobytes() == fuzz.sort_rpcs(r.copy()).tobytes(), f"batch {tick}: rpcs"
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes()
+    cpu.close()
+
+
 def test_pipelined_ring_keeps_batches_in_order(engine_mod, oracle_lib):
     """submit/submit/submit then collect x3: the staging ring returns batches oldest first."""
     rng = np.random.default_rng(9)
