@@ -41,6 +41,7 @@ struct rgb_slot {
   rgb_rpc *d_rpcs = nullptr;
   rgb_rpc *h_rpcs = nullptr;        /* pinned: the fixed rpc slots of device positions [rpc_lo, rpc_lo+rpc_cnt) */
   u32 rpc_lo = 0, rpc_cnt = 0;
+  u32 *h_nrpc = nullptr, *d_nrpc = nullptr;   /* pinned / device: the batch's rpc record count (rgb_count_rpcs_kernel) */
   /* sub-tick rounds as ONE train launch: stamps, per-round plan and row table (pinned staging + device) */
   unsigned char *h_stamps = nullptr, *d_stamps = nullptr;
   rgb_train_tick *h_plan = nullptr, *d_plan = nullptr;
@@ -185,6 +186,8 @@ static void free_slot(rgb_slot &s) {
   if (s.d_dec) (void)hipFree(s.d_dec);
   if (s.d_rpcs) (void)hipFree(s.d_rpcs);
   if (s.h_rpcs) (void)hipHostFree(s.h_rpcs);
+  if (s.h_nrpc) (void)hipHostFree(s.h_nrpc);
+  if (s.d_nrpc) (void)hipFree(s.d_nrpc);
   if (s.h_stamps) (void)hipHostFree(s.h_stamps);
   if (s.d_stamps) (void)hipFree(s.d_stamps);
   if (s.h_plan) (void)hipHostFree(s.h_plan);
@@ -193,6 +196,7 @@ static void free_slot(rgb_slot &s) {
   if (s.d_rows) (void)hipFree(s.d_rows);
   if (s.done) (void)hipEventDestroy(s.done);
   s.h_msgs = nullptr; s.h_dec = nullptr; s.d_msgs = nullptr; s.d_dec = nullptr; s.d_rpcs = nullptr; s.h_rpcs = nullptr;
+  s.h_nrpc = s.d_nrpc = nullptr;
   s.h_stamps = s.d_stamps = nullptr; s.h_plan = s.d_plan = nullptr; s.h_rows = s.d_rows = nullptr; s.done = nullptr;
 }
 
@@ -258,6 +262,8 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   HIPCHK(ctx, hipMalloc((void **)&s.d_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc)));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc), hipHostMallocDefault));
   HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_nrpc, 64, hipHostMallocDefault));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_nrpc, 64));
   /* fused sub-tick rounds (at most RGB_SUBMIT_TRAIN_ROUNDS of them per batch) */
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_stamps, cap, hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_stamps, cap));
@@ -534,15 +540,21 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
       s.h_plan[r].msg_base = start[r];
     }
   }
-  /* the rpc slots that come back: the span of device positions whose message kind can emit rpcs */
+  /* the rpc slots that come back: the span of device positions whose message kind can emit rpcs.  A bucket holds
+   * one kind, so the span follows from the buckets' ends (bucket[b] is now the END of bucket b) */
+  std::vector<u32> class_counts;                              /* per round, for the class-dispatch kernel */
+  if (!as_train) class_counts.assign((size_t)n_rounds * RGB_N_CLASSES, 0);
   {
     u32 lo = n, hi = 0;
-    for (u32 p = 0; p < n; ++p) {
-      const unsigned k = s.h_msgs[p].kind;
+    for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) {
+      const u32 b0 = b ? bucket[b - 1] : 0u, b1 = bucket[b];
+      if (b1 == b0) continue;
+      const unsigned k = s.h_msgs[b0].kind;
+      if (!as_train && k != RGB_MSG_NOP) class_counts[(b / NK) * RGB_N_CLASSES + rgb_class_of_kind(k)] += b1 - b0;
       if (k == RGB_MSG_AER_REPLY || k == RGB_MSG_APPEND || k == RGB_MSG_PIPELINE_RPCS ||
           k == RGB_MSG_VOTE_RESULT || k == RGB_MSG_PRE_VOTE_RPC) {
-        if (p < lo) lo = p;
-        hi = p;
+        if (b0 < lo) lo = b0;
+        hi = b1 - 1;
       }
     }
     s.rpc_lo = lo < n ? lo : 0; s.rpc_cnt = lo < n ? hi - lo + 1 : 0;
@@ -555,6 +567,7 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     ctx->enqueue_cv.wait(el, [&] { return ctx->enqueue_turn == ticket; });
     rc = [&]() -> int {
       HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+      s.h_nrpc[0] = 0;
       if (!n) { HIPCHK(ctx, hipEventRecord(s.done, ctx->stream)); return RGB_OK; }
       HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice, ctx->stream));
       if (as_train) {
@@ -583,9 +596,8 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
         int lr;
         if (cnt >= 4096) {
           /* big round: the class-dispatch kernel (specialised path per message kind) */
-          u32 cc[RGB_N_CLASSES] = {0};
-          for (u32 p = off; p < off + cnt; ++p)
-            if (s.h_msgs[p].kind != RGB_MSG_NOP) cc[rgb_class_of_kind(s.h_msgs[p].kind)]++;
+          u32 cc[RGB_N_CLASSES];
+          for (int c = 0; c < RGB_N_CLASSES; ++c) cc[c] = class_counts[(size_t)r * RGB_N_CLASSES + c];
           lr = launch_tick_classes(ctx, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
           if (lr) return lr;
           u32 real = 0;
@@ -600,6 +612,11 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
           if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
         }
       }
+      {
+        int lr = rgb_launch_count_rpcs(s.d_dec, n, s.d_nrpc, ctx->stream);
+        if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+      }
+      HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc, s.d_nrpc, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost, ctx->stream));
       if (s.rpc_cnt)
         HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
@@ -656,7 +673,7 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
       s.state.store(0, std::memory_order_release);
       return fail;
     }
-    for (u32 p = 0; p < s.n; ++p) n_rpc += s.h_dec[p].n_rpcs;
+    n_rpc = s.n ? s.h_nrpc[0] : 0u;                        /* counted on the device */
     /* a buffer that is too small leaves the batch in the ring: the sizes it needs are reported and the
      * caller retries (nothing is dropped, the ring is not wedged) */
     if (s.n > cap || (s.n && !out) || (rpc_out && n_rpc > rpc_cap)) {
@@ -711,8 +728,7 @@ int rgb_peek(rgb_ctx *ctx, uint32_t *n_out, uint32_t *n_rpc_out) {
   rgb_slot &s = ctx->ring_mem[ctx->tail];
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   HIPCHK(ctx, hipEventSynchronize(s.done));
-  u32 n_rpc = 0;
-  for (u32 p = 0; p < s.n; ++p) n_rpc += s.h_dec[p].n_rpcs;
+  const u32 n_rpc = (s.n && !s.enqueue_error) ? s.h_nrpc[0] : 0u;
   if (n_out) *n_out = s.n;
   if (n_rpc_out) *n_rpc_out = n_rpc;
   return RGB_OK;

@@ -3502,6 +3502,23 @@ int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u3
   return (int)hipGetLastError();
 }
 
+/* sum of rgb_decision.n_rpcs over a batch (byte 6 of the record's first word): rgb_collect sizes the rpc buffer from
+ * four bytes instead of walking the batch's decisions under its lock */
+__global__ void rgb_count_rpcs_kernel(const rgb_decision *__restrict__ dec, u32 n, u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 v = i < n ? (u32)((reinterpret_cast<const u64 *>(dec + i)[0] >> 48) & 0xFFull) : 0u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out, v);
+}
+
+int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream) {
+  hipError_t e = hipMemsetAsync(d_out, 0, sizeof(u32), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (n) hipLaunchKernelGGL(rgb_count_rpcs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_dec, n, d_out);
+  return (int)hipGetLastError();
+}
+
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream) {
   u32 g = dev.n_servers / dev.n_members;
   if (g == 0) return 0;
