@@ -453,31 +453,36 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   if (!ctx || (!msgs && n)) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   if (n > ctx->cfg.ring_capacity) return RGB_E_INVAL;
-  for (u32 i = 0; i < n; ++i) {
-    int rc = validate_msg(ctx, msgs[i]);
-    if (rc) return rc;
-  }
-  /* ---- 1. rounds: round r = every server's r-th message of this batch, in order (per-thread scratch) ---- */
-  thread_local std::vector<uint16_t> seen;
+  /* ---- 1. ONE pass over the batch: validation, the rounds (round r = every server's r-th message of this batch,
+   * in order; per-thread scratch) and every message's bucket key -- the later passes read 6 bytes per message, not 64 */
+  thread_local std::vector<uint16_t> seen, key_of;
   thread_local std::vector<u32> touched, round_of;
   if (seen.size() < ctx->dev.n_servers) seen.assign(ctx->dev.n_servers, 0);
   round_of.resize(n);
+  key_of.resize(n);
   touched.clear();
   u32 n_rounds = n ? 1 : 0;
   bool any_nop = false, too_many = false;
+  int bad = RGB_OK;
+  const unsigned n_members = ctx->dev.n_members;
   for (u32 i = 0; i < n; ++i) {
+    const rgb_msg &m = msgs[i];
+    bad = validate_msg(ctx, m);
+    if (bad) break;
     u32 r = 0;
-    if (msgs[i].kind != RGB_MSG_NOP) {
-      uint16_t &c = seen[msgs[i].server];
-      if (c == 0) touched.push_back(msgs[i].server);
+    if (m.kind != RGB_MSG_NOP) {
+      uint16_t &c = seen[m.server];
+      if (c == 0) touched.push_back(m.server);
       r = c;
       if (c == 0xFFFF) { too_many = true; break; }
       c++;
     } else any_nop = true;
     round_of[i] = r;
+    key_of[i] = (uint16_t)rgb_bucket(m.kind, m.flags, m.kind != RGB_MSG_NOP ? m.server : 0u, n_members);
     if (r + 1 > n_rounds) n_rounds = r + 1;
   }
   for (u32 t : touched) seen[t] = 0;
+  if (bad) return bad;
   if (too_many) return RGB_E_UNSUPPORTED;
   /* several rounds, a batch worth a big launch, no NOP padding, a device that keeps a shard on one XCD: the rounds
    * run as ONE train launch, in bucket order (class, shard, success flag) -- a finer key of the same family order */
@@ -491,16 +496,14 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
    * at most one message per server, so its order is free; family-homogeneous wavefronts do not
    * diverge across clause families), stable inside a bucket */
   const u32 NK = as_train ? (u32)RGB_N_BUCKETS : (u32)RGB_N_FAMILIES;
-  const unsigned n_members = ctx->dev.n_members;
-  auto family = [as_train, n_members](const rgb_msg &m) -> u32 {
-    return as_train ? rgb_bucket(m.kind, m.flags, m.server, n_members) : rgb_family(m.kind, m.flags);
-  };
+  /* the family (kind rank, success flag) is the bucket key without its shard bits */
+  auto family = [as_train](uint16_t key) -> u32 { return as_train ? (u32)key : (((u32)key >> 4) << 1) | ((u32)key & 1u); };
   std::vector<u32> bucket_counts;
   std::vector<u32> start(n_rounds + 1, 0);
   std::vector<u32> bucket((size_t)n_rounds * NK + 1, 0);
   for (u32 i = 0; i < n; ++i) {
     start[round_of[i] + 1]++;
-    bucket[(size_t)round_of[i] * NK + family(msgs[i]) + 1]++;
+    bucket[(size_t)round_of[i] * NK + family(key_of[i]) + 1]++;
   }
   for (u32 r = 0; r < n_rounds; ++r) start[r + 1] += start[r];
   if (as_train) bucket_counts.assign(bucket.begin() + 1, bucket.end());      /* per (round, bucket), before the scan */
@@ -521,7 +524,7 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   rgb_slot &s = *sp;
   s.perm.resize(n);
   for (u32 i = 0; i < n; ++i) {
-    u32 p = bucket[(size_t)round_of[i] * NK + family(msgs[i])]++;
+    u32 p = bucket[(size_t)round_of[i] * NK + family(key_of[i])]++;
     s.perm[p] = i;
     s.h_msgs[p] = msgs[i];
   }
