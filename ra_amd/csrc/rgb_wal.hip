@@ -194,13 +194,19 @@ __device__ __forceinline__ void store_sub16(unsigned char *base, const uint4 w, 
   if (p + 1u <= hi) { base[p] = (unsigned char)sub(p); }
 }
 
-/* whole aligned chunk, written once and not read again by the device: non-temporal */
+/* whole aligned chunk, written once and not read again by the device.  STREAM (one record per wavefront, KiB-sized
+ * payloads): non-temporal.  Small records: a plain store -- every other 128-byte line of the output holds a record
+ * boundary whose bytes (prefix, partial chunks) arrive from other instructions, and a line the non-temporal store
+ * pushed out early is written to memory twice (256-byte payloads, same box: 396 -> 360 us per 2 M records; 4 KiB
+ * payloads the other way round, 418 -> 441 us) */
+template <bool STREAM>
 __device__ __forceinline__ void store16_stream(unsigned char *p, const uint4 w) {
   v4u t; t.x = w.x; t.y = w.y; t.z = w.z; t.w = w.w;
-#ifdef RGB_HOST_EMULATION
+#if defined(RGB_HOST_EMULATION)
   *reinterpret_cast<v4u *>(p) = t;
 #else
-  __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(p));
+  if (STREAM) __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(p));
+  else *reinterpret_cast<v4u *>(p) = t;
 #endif
 }
 
@@ -214,14 +220,30 @@ __device__ __forceinline__ u32 rot1(u32 v) {
   const int t = (int)(threadIdx.x & 63u);
   return __shfl(v, (t & ~(GROUP - 1)) | ((t - 1) & (GROUP - 1)), 64);
 #else
-  static_assert(GROUP == 16 || GROUP == 64, "a DPP row is 16 lanes, a wavefront 64");
-  if (GROUP == 16) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
+  static_assert(GROUP == 8 || GROUP == 16 || GROUP == 64, "a DPP row is 16 lanes, a wavefront 64");
+  /* 8-lane groups: right for every lane but the group's first (rot_last serves that one) */
+  if (GROUP <= 16) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
   return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
 #endif
 }
 template <int GROUP>
 __device__ __forceinline__ uint4 rot1(const uint4 v) {
   return make_uint4(rot1<GROUP>(v.x), rot1<GROUP>(v.y), rot1<GROUP>(v.z), rot1<GROUP>(v.w));
+}
+/* the group's FIRST lane receives the value of the group's last lane (the other lanes: unspecified) */
+template <int GROUP>
+__device__ __forceinline__ u32 rot_last(u32 v) {
+#if defined(RGB_HOST_EMULATION) || defined(WAL_X_NODPP)
+  return rot1<GROUP>(v);
+#else
+  if (GROUP == 8) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x129 /* row_ror:9 */, 0xF, 0xF, false);
+  return rot1<GROUP>(v);
+#endif
+}
+template <int GROUP>
+__device__ __forceinline__ uint4 rot_last(const uint4 v) {
+  if (GROUP != 8) return rot1<GROUP>(v);
+  return make_uint4(rot_last<GROUP>(v.x), rot_last<GROUP>(v.y), rot_last<GROUP>(v.z), rot_last<GROUP>(v.w));
 }
 /* ({hi, lo} >> 8 sb) & 0xFFFFFFFF, sb = 0..3: v_alignbyte_b32 */
 __device__ __forceinline__ u32 alignbyte(u32 hi, u32 lo, u32 sb) {
@@ -266,24 +288,29 @@ __device__ __forceinline__ uint4 window16(const uint4 p, const uint4 c, u32 o) {
 /* destination chunk at stream position dpos (a multiple of 16) of the record whose payload sits at stream positions
  * [ps, pe) = f: a whole chunk is streamed, the chunks that hold the payload's first / last byte go as aligned
  * power-of-two stores.  Everything by value (see halves16). */
+template <bool STREAM>
 __device__ __forceinline__ void emit_chunk(unsigned char *rec_al, u32 ps, u32 pe, u32 dpos, const uint4 f) {
   if (dpos + 16u > ps && dpos < pe) {                   /* the chunk holds payload bytes */
     unsigned char *to = rec_al + dpos;
     const bool head = dpos < ps, tail = dpos + 16u > pe;
-    if (!head && !tail) store16_stream(to, f);
+    if (!head && !tail) store16_stream<STREAM>(to, f);
     else if (!head) store_tail16(to, f, pe - dpos);
     else if (!tail) store_head16(to, f, ps - dpos);
     else store_sub16(to, f, ps - dpos, pe - dpos);
   }
 }
 
+/* mean payload up to which a batch is framed with eight lanes per record (then sixteen up to 1 KiB, then a wavefront) */
+#ifndef WAL_FRAME_EIGHT_MAX
+#define WAL_FRAME_EIGHT_MAX 320u
+#endif
 template <int GROUP>
 __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel(
     const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data,
     unsigned char *__restrict__ out, u32 *__restrict__ sums_out, u32 flags) {
   constexpr u32 PER_BLOCK = WAL_WAVES_PER_BLOCK * 64 / GROUP;
   constexpr bool UNI = GROUP == 64;                     /* one record per wavefront: its shifts are wave-uniform */
-  constexpr int UNROLL = GROUP == 64 ? WAL_UNROLL : 2;  /* small records: 512 bytes per round and group */
+  constexpr int UNROLL = GROUP == 64 ? WAL_UNROLL : 2;  /* small records: 512 / 256 bytes per round and group */
   const u32 lane = threadIdx.x & (GROUP - 1);
   u32 e = blockIdx.x * PER_BLOCK + threadIdx.x / GROUP;
 #ifndef RGB_HOST_EMULATION
@@ -327,7 +354,11 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel
     for (int k = 0; k < UNROLL; ++k) {
       const u32 i = c0 + (u32)k * GROUP + lane;
       v[k] = make_uint4(0, 0, 0, 0);
+#ifdef WAL_X_NOREAD           /* EXPERIMENT (breaks the output): the write side alone */
+      if (i < n_src) v[k] = make_uint4(i, lane, e, len);
+#else
       if (i < n_src) { const v4u t = __builtin_nontemporal_load(src + i); v[k] = make_uint4(t.x, t.y, t.z, t.w); }
+#endif
     }
 #pragma unroll
     for (int k = 0; k < UNROLL; ++k) {
@@ -356,9 +387,13 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel
       /* every lane of the group takes part in the exchange, whatever it loaded */
       const uint4 rot = rot1<GROUP>(v[k]);
       const uint4 prev = lane == 0u ? carry : rot;
-      carry = rot;
+      carry = rot_last<GROUP>(v[k]);
       const uint4 f = window16<UNI>(prev, v[k], 16u - dm);
-      if (i < n_fun) emit_chunk(rec_al, ps, pe, (i + qd) << 4, f);
+#ifdef WAL_X_NOWRITE          /* EXPERIMENT (breaks the output): the read + compute side alone */
+      if (i < n_fun && f.x == 0x12345678u && f.y == 0x9ABCDEF0u) emit_chunk<UNI>(rec_al, ps, pe, (i + qd) << 4, f);
+#else
+      if (i < n_fun) emit_chunk<UNI>(rec_al, ps, pe, (i + qd) << 4, f);
+#endif
     }
   }
   const u32 a_sum = group_sum<GROUP>(a_acc % ADLER_MOD);
@@ -423,7 +458,14 @@ extern "C" int rgb_wal_frame_device(rgb_ctx *ctx, const void *d_records, uint32_
   if (n == 0) return RGB_OK;
   if (out_bytes < 27ull * n) return RGB_E_INVAL;       /* the shortest record is 3 + 24 bytes */
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)rgb_ctx_stream(ctx);
-  if (data_bytes / n < 1024u) {
+  if (data_bytes / n <= WAL_FRAME_EIGHT_MAX) {
+    /* the smallest payloads: eight lanes per record, eight records per wavefront (the per-record work that does not
+     * shrink with the payload -- descriptor, reduction, prefix -- is paid per WAVEFRONT instruction) */
+    const u32 per = WAL_WAVES_PER_BLOCK * 64 / 8;
+    hipLaunchKernelGGL(rgb_wal_frame_kernel<8>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
+                       (unsigned char *)d_out, (u32 *)d_checksums, flags);
+  } else if (data_bytes / n < 1024u) {
     const u32 per = WAL_WAVES_PER_BLOCK * 64 / 16;
     hipLaunchKernelGGL(rgb_wal_frame_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
                        (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,

@@ -103,6 +103,7 @@ def check_phase_sweep(framed: bytes, want, out_bytes):
 
 
 SWEEP_SMALL = [0, 1, 2, 3, 5, 8, 13, 15, 16, 17, 31, 32, 33, 47, 48, 49, 240, 255, 256, 257, 272]
+SWEEP_MID = [321, 400, 496, 511, 512, 513, 527, 528, 529, 767, 768, 769, 1000]     # sixteen lanes per record
 SWEEP_LARGE = [1007, 1008, 1023, 1024, 1025, 1040, 2047, 2048, 2049, 4096]
 
 
@@ -290,13 +291,15 @@ def _open():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+@pytest.mark.parametrize("small", [0, 1, 2], ids=["wave_per_record", "four_per_wave", "eight_per_wave"])
 @pytest.mark.parametrize("flags", [0, abi.WAL_NO_CHECKSUMS])
 def test_gpu_frame_matches_oracle_bytes(small, flags):
     import torch
     rng = np.random.default_rng(20 + small)
-    if small:
+    if small == 2:
         lens = [0, 1, 2, 15, 16, 17, 31, 32, 33, 255, 256, 257] + [int(x) for x in rng.integers(0, 600, size=1000)]
+    elif small == 1:
+        lens = [0, 1, 16, 255, 256, 257, 511, 512, 513, 1023] + [int(x) for x in rng.integers(300, 1000, size=1000)]
     else:
         lens = [0, 1, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 4097, 65535, 65536, 70001, 1 << 20] + \
                [int(x) for x in rng.integers(0, 20000, size=300)]
@@ -304,7 +307,7 @@ def test_gpu_frame_matches_oracle_bytes(small, flags):
     recs, data, payloads = make_batch(rng, specs)
     base = int(rng.integers(0, 16))                                 # the batch continues a file at any offset
     total = engine.wal_layout(recs, base)
-    assert (len(data) / len(lens) < 1024) == small
+    assert (len(data) / len(lens) < 1024) == bool(small) and (len(data) / len(lens) <= 320) == (small == 2)
     want = O.wal_frame(recs, data, total, compute_checksums=not flags)
     assert want[base:].tobytes() == python_frame(specs, payloads, not flags)
     eng = _open()
@@ -455,14 +458,14 @@ def test_gpu_frame_full_size_batch_round_trips_through_the_recovery_path():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+@pytest.mark.parametrize("small", [0, 1, 2], ids=["wave_per_record", "four_per_wave", "eight_per_wave"])
 def test_gpu_frame_every_source_and_destination_phase(small):
     """Payload lengths around the 16-byte chunk and the lane-group boundaries at every source phase x destination
     phase: the chunk that spills over behind the last source chunk is written by the lane that holds that chunk."""
     rng = np.random.default_rng(95 + small)
-    lens = SWEEP_SMALL if small else SWEEP_LARGE
+    lens = (SWEEP_LARGE, SWEEP_MID, SWEEP_SMALL)[small]
     recs, data, out_bytes, want = phase_sweep_batch(rng, lens, range(16), range(16) if small else (0, 1, 5, 8, 11, 15))
-    assert (len(data) / len(recs) < 1024) == small
+    assert (len(data) / len(recs) < 1024) == bool(small) and (len(data) / len(recs) <= 320) == (small == 2)
     eng = _open()
     try:
         check_phase_sweep(eng.wal_frame(recs, data, out_bytes).tobytes(), want, out_bytes)

@@ -12,7 +12,7 @@ import pytest
 from ra_amd import abi
 from oracle import oracle as O
 from test_wal_framing import (make_batch as make_records, python_frame, random_specs, scanned_as_tuples,
-                               phase_sweep_batch, check_phase_sweep, SWEEP_SMALL, SWEEP_LARGE)
+                               phase_sweep_batch, check_phase_sweep, SWEEP_SMALL, SWEEP_MID, SWEEP_LARGE)
 from test_wal_checksum import make_batch as make_entries, zlib_checksums
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,19 +67,21 @@ def test_checksum_kernel_matches_zlib(wal, small):
     assert len(bad) == 0, f"entry {bad[0]} len {lens[bad[0]]}: kernel {got[bad[0]]:#x} zlib {want[bad[0]]:#x}"
 
 
-@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+@pytest.mark.parametrize("small", [0, 1, 2], ids=["wave_per_record", "four_per_wave", "eight_per_wave"])
 @pytest.mark.parametrize("flags", [0, abi.WAL_NO_CHECKSUMS])
 def test_framing_kernel_matches_struct_pack(wal, small, flags):
     rng = np.random.default_rng(60 + small)
-    if small:
+    if small == 2:
         lens = [0, 1, 2, 15, 16, 17, 31, 32, 33, 255, 256, 257] + [int(x) for x in rng.integers(0, 600, size=150)]
+    elif small == 1:
+        lens = [0, 1, 16, 255, 256, 257, 511, 512, 513, 1023] + [int(x) for x in rng.integers(300, 1000, size=80)]
     else:
         lens = [0, 1, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 4097, 65535, 65536, 70001] + \
                [int(x) for x in rng.integers(0, 20000, size=40)]
     specs = random_specs(rng, len(lens), lens, n_writers=7)
     recs, data, payloads = make_records(rng, specs)
     total = wal.wal_layout(recs, 0)
-    assert (len(data) / len(lens) < 1024) == small
+    assert (len(data) / len(lens) < 1024) == bool(small) and (len(data) / len(lens) <= 320) == (small == 2)
     rc, out = wal.wal_frame(recs, data, total, flags)
     assert rc == 0
     want = python_frame(specs, payloads, not flags)
@@ -165,16 +167,18 @@ def test_descriptors_whose_offset_plus_length_wraps_are_refused(wal):
     assert e.value.code == abi.E_INVAL
 
 
-@pytest.mark.parametrize("small", [False, True], ids=["wave_per_record", "four_per_wave"])
+@pytest.mark.parametrize("small", [0, 1, 2], ids=["wave_per_record", "four_per_wave", "eight_per_wave"])
 def test_framing_kernel_at_every_source_and_destination_phase(wal, small):
-    """The -m gpu test of the same name on the emulated kernel (fewer phases for the large records: the fiber
+    """The -m gpu test of the same name on the emulated kernel (fewer phases for the larger records: the fiber
     emulation runs them at a few MB/s)."""
     rng = np.random.default_rng(95 + small)
-    if small:
+    if small == 2:
         recs, data, out_bytes, want = phase_sweep_batch(rng, SWEEP_SMALL)
+    elif small == 1:
+        recs, data, out_bytes, want = phase_sweep_batch(rng, SWEEP_MID, (0, 1, 5, 9, 15), (0, 3, 5, 8, 13))
     else:
         recs, data, out_bytes, want = phase_sweep_batch(rng, SWEEP_LARGE, (0, 5, 15), (0, 3, 8, 13))
-    assert (len(data) / len(recs) < 1024) == small
+    assert (len(data) / len(recs) < 1024) == bool(small) and (len(data) / len(recs) <= 320) == (small == 2)
     rc, out = wal.wal_frame(recs, data, out_bytes)
     assert rc == 0
     check_phase_sweep(out.tobytes(), want, out_bytes)
