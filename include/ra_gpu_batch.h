@@ -369,17 +369,26 @@ int  rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick);
 int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
                  rgb_rpc *rpc_out, uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out);
 /* Threading (the interception point is per gen_statem, reference src/ra_server_proc.erl:1356-1397, so many
- * scheduler threads reach the boundary at once): rgb_submit may be called from any number of threads --
- * callers serialise on an internal lock and their batches reach the device in lock order; RGB_E_FULL when
- * every ring slot is in flight (nothing was enqueued).  rgb_collect may be called from any thread,
- * concurrently with submits; concurrent collectors serialise and each batch is handed out exactly once,
- * oldest first.  A buffer that is too small leaves the batch in the ring: RGB_E_INVAL (cap) or RGB_E_FULL
- * (rpc_cap) with the needed counts in *n_out / *n_rpc_out, the caller retries with larger buffers.
- * RGB_E_STATE from rgb_collect (a batch whose records are inconsistent) consumes the batch.
+ * scheduler threads reach the boundary at once).
+ * rgb_submit may be called from any number of threads.  Callers prepare their batches IN PARALLEL (validation, the
+ * sub-tick rounds, the bucket sort into the slot's pinned buffer); they meet in two short critical sections: one
+ * hands out the next ring slot and a ticket, the other lets the tickets through in order for the stream's work.
+ * Batches reach the device in the order their submits took their slots; every batch is enqueued as a whole (all its
+ * rounds).  RGB_E_FULL when the next ring slot is not free (nothing was enqueued).
+ * rgb_collect may be called from any number of threads, concurrently with submits: waiting for the oldest batch,
+ * the size check and taking the slot are serialised, the copy back to submission order is not, so consumers copy
+ * different batches at once; each batch is handed out exactly once, oldest first.  A buffer that is too small
+ * leaves the batch in the ring: RGB_E_INVAL (cap) or RGB_E_FULL (rpc_cap) with the needed counts in *n_out /
+ * *n_rpc_out, the caller retries with larger buffers (or asks rgb_peek first).  RGB_E_STATE from rgb_collect (a
+ * batch whose records are inconsistent, or whose train launch failed) consumes the batch.
  * rgb_wait parks the calling thread until a batch is in flight (RGB_OK), timeout_ms have passed or rgb_wake
  * was called (both RGB_E_EMPTY): a collector thread blocks here instead of polling rgb_collect.
- * rgb_upload_state / rgb_download_state / rgb_snapshot / rgb_state_checksum use the context's stream and are
- * ordered after the batches submitted before them; they may run beside submit/collect. */
+ * rgb_upload_state / rgb_download_state / rgb_snapshot / rgb_state_checksum may run beside submit / collect from
+ * any thread.  They serialise among themselves (shared staging buffers) and against the enqueue of batches: their
+ * work is ordered against WHOLE batches -- never between the rounds of one -- and after every rgb_submit that
+ * returned before the call.  A submit that is still preparing its batch in another thread may be enqueued before
+ * or after; a caller that needs "after batch X" lets that rgb_submit return (or collects X) first.  The *_device
+ * entry points take the CALLER's stream and are ordered by it alone. */
 /* Sub-tick rounds: a batch that holds several messages for one server is applied in rounds (round r = every server's
  * r-th message).  A batch of at least 4096 messages with 2..16 rounds and no NOP padding runs its rounds as ONE train
  * launch (see "Train launches" below: the per-server sequence bytes order a server's messages) instead of one launch

@@ -179,6 +179,16 @@ void rgb_default_config(rgb_config *cfg) {
 
 int rgb_last_hip_error(const rgb_ctx *ctx) { return ctx ? ctx->last_hip.load(std::memory_order_relaxed) : 0; }
 
+/* The host-buffer state calls (upload / download / snapshot / checksum) share staging buffers (state_mu) and put
+ * work on the context's stream: they take the enqueue lock as well, so their work never lands between the rounds of
+ * a batch another thread is enqueuing -- it is ordered against WHOLE batches, after every rgb_submit that has
+ * returned.  Lock order: state_mu, then enqueue_mu (rgb_submit holds enqueue_mu alone, rgb_collect collect_mu then
+ * enqueue_mu). */
+struct rgb_stream_turn {
+  std::lock_guard<std::mutex> a, b;
+  explicit rgb_stream_turn(rgb_ctx *ctx) : a(ctx->state_mu), b(ctx->enqueue_mu) {}
+};
+
 static void free_slot(rgb_slot &s) {
   if (s.h_msgs) (void)hipHostFree(s.h_msgs);
   if (s.h_dec) (void)hipHostFree(s.h_dec);
@@ -392,7 +402,7 @@ int rgb_upload_state(rgb_ctx *ctx, uint32_t first, uint32_t n, const rgb_server_
     if (rc) return rc;
   }
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-  std::lock_guard<std::mutex> lk(ctx->state_mu);
+  rgb_stream_turn turn(ctx);
   for (u32 base = 0; base < n; base += ctx->stage_cap) {
     u32 cnt = n - base < ctx->stage_cap ? n - base : ctx->stage_cap;
     memcpy(ctx->h_stage, in + base, (size_t)cnt * sizeof(rgb_server_state));
@@ -410,7 +420,7 @@ int rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_stat
   if (!ctx->registered) return RGB_E_STATE;
   if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-  std::lock_guard<std::mutex> lk(ctx->state_mu);
+  rgb_stream_turn turn(ctx);
   for (u32 base = 0; base < n; base += ctx->stage_cap) {
     u32 cnt = n - base < ctx->stage_cap ? n - base : ctx->stage_cap;
     int rc = rgb_launch_unpack(ctx->dev, ctx->d_stage, first + base, cnt, ctx->stream);
@@ -995,6 +1005,7 @@ int rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out) {
   if (!ctx || !out) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  rgb_stream_turn turn(ctx);                               /* d_rows is shared */
   int rc = rgb_snapshot_device(ctx, ctx->d_rows, ctx->stream);
   if (rc) return rc;
   u32 g = ctx->dev.n_servers / ctx->dev.n_members;
@@ -1009,6 +1020,7 @@ int rgb_state_checksum(rgb_ctx *ctx, uint32_t first, uint32_t n, uint64_t *out) 
   if (!ctx->registered) return RGB_E_STATE;
   if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  rgb_stream_turn turn(ctx);                               /* d_sums is shared */
   int rc = rgb_launch_checksum(ctx->dev, first, n, ctx->d_sums, ctx->stream);
   if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   std::vector<u64> sums(n);
