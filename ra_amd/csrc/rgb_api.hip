@@ -314,11 +314,6 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(1u << 20) * 8 * sizeof(u64)));
   HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(1u << 20) * 8 * sizeof(u64)));
 #endif
-#ifdef RGB_X_EXTRA_STORE
-  /* EXPERIMENT (never in the product): a scratch line per server for the write-side probe of the class kernel */
-  HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)S * 16 * sizeof(u64)));
-  HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)S * 16 * sizeof(u64)));
-#endif
   HIPCHK(ctx, hipMalloc((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.runs, (size_t)S * d.max_runs * 2 * sizeof(u64)));

@@ -303,23 +303,6 @@ __device__ __forceinline__ int run_search(const Lane &L, u64 idx, u64 &term) {
   const ulonglong2 *rt = reinterpret_cast<const ulonglong2 *>(L.runs);
   int k = (int)L.n_runs - 3;
   if (k < 0) return -1;
-#ifndef RGB_X_TRAIN_WALK4
-#define RGB_X_TRAIN_WALK4 0   /* measured: 23.2 vs 19.96 us per tick (tools/gpu_ab.sh r03o): off */
-#endif
-  if (RGB_X_TRAIN_WALK4 && L.coh) {
-    /* train launches: every load of the table is an L2 round trip (~1 us, no L1), and the wavefront's life IS the
-     * throughput there -- four runs per round trip (168 registers: room for the eight words) */
-#pragma unroll 1
-    for (; k >= 0; k -= 4) {
-      ulonglong2 r[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = ldg16(true, rt + (k - j >= 0 ? k - j : 0));
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (k - j >= 0 && idx >= r[j].x) { term = r[j].y; return k - j; }
-    }
-    return -1;
-  }
   ulonglong2 cur = ldg16(L.coh, rt + k);
 #pragma unroll 1
   for (; k >= 0; --k) {
@@ -764,8 +747,6 @@ __device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u6
   if (hi < lo) return false;
   /* walk runs from the newest: run k covers [start_k, end_k] */
   u64 end = L.li;
-  ulonglong2 pre4[4];                     /* train launches: the in-memory runs four per round trip (see run_search) */
-  int pre_top = -1;
   for (int k = (int)L.n_runs - 1; k >= 0; --k) {
     u64 s, t;
     if ((unsigned)k == L.n_runs - 1) { s = L.lrs; t = L.lrt; }
@@ -774,20 +755,8 @@ __device__ __forceinline__ bool written_c1(const Lane &L, u64 term, u64 from, u6
 #ifdef RGB_PROFILE
       if (L.prof_noprobe) break;
 #endif
-      ulonglong2 r;
-      if (RGB_X_TRAIN_WALK4 && L.coh) {
-        if (pre_top < 0 || k <= pre_top - 4) {
-          pre_top = k;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            pre4[j] = ldg16(true, reinterpret_cast<const ulonglong2 *>(L.runs) + (k - j >= 0 ? k - j : 0));
-        }
-        r = pre4[0];
-#pragma unroll
-        for (int j = 1; j < 4; ++j) r = (pre_top - k == j) ? pre4[j] : r;
-      } else {
-        r = ldg16(false, reinterpret_cast<const ulonglong2 *>(L.runs) + k);
-      }
+      /* L2-served in a train launch: the table's older runs were pushed there by an earlier tick of the same launch */
+      const ulonglong2 r = ldg16(L.coh, reinterpret_cast<const ulonglong2 *>(L.runs) + k);
 #ifdef RGB_PROFILE
       const_cast<Lane &>(L).prof_nloads += 2;
 #endif
@@ -895,36 +864,7 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
     const u64 nf = idx + 1;
     const int k = find_run(L, nf);
     u64 *runs = const_cast<u64 *>(L.runs);
-#ifndef RGB_X_TRAIN_SNAP4
-#define RGB_X_TRAIN_SNAP4 0
-#endif
     if (k > 0) {
-      if (RGB_X_TRAIN_SNAP4 && L.coh) {
-        /* train launches: a load of the table is an L2 round trip and, behind the stores of the same array, the
-         * compiler keeps them in order -- four runs per round trip (loads of a batch first, then its stores: a
-         * batch only ever writes below what the NEXT batches read) */
-#pragma unroll 1
-        for (unsigned j0 = (unsigned)k; j0 < L.n_runs; j0 += 4) {
-          u64 rs[4], rt[4];
-#pragma unroll
-          for (unsigned q = 0; q < 4; ++q) {
-            const unsigned j = j0 + q;
-            const unsigned jl = j < L.n_runs ? j : L.n_runs - 1;
-            rs[q] = 0; rt[q] = 0;
-            if (jl + 2 < L.n_runs) { rs[q] = ldg8(true, runs + 2 * jl); rt[q] = ldg8(true, runs + 2 * jl + 1); }
-          }
-#pragma unroll
-          for (unsigned q = 0; q < 4; ++q) {
-            const unsigned j = j0 + q;
-            if (j >= L.n_runs) break;
-            u64 a = rs[q], b = rt[q];
-            if (j == L.n_runs - 1) { a = L.lrs; b = L.lrt; }
-            else if (j == L.n_runs - 2) { a = L.prs; b = L.prt; }
-            runs[2 * (j - k)] = a;
-            runs[2 * (j - k) + 1] = b;
-          }
-        }
-      } else {
       for (unsigned j = (unsigned)k; j < L.n_runs; ++j) {
         u64 rs, rt;                                     /* the newest two runs are in registers */
         if (j == L.n_runs - 1) { rs = L.lrs; rt = L.lrt; }
@@ -932,7 +872,6 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
         else { rs = ldg8(L.coh, runs + 2 * j); rt = ldg8(L.coh, runs + 2 * j + 1); }
         runs[2 * (j - k)] = rs;
         runs[2 * (j - k) + 1] = rt;
-      }
       }
       L.n_runs -= (unsigned)k;
     }
@@ -2458,13 +2397,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
    * registers by now), and process_message reads its row from LDS piece by piece, when it needs it. */
   RGB_TT(2);
   constexpr bool PRE = true;
-#ifdef RGB_X_TRAIN_PLAINROWS      /* EXPERIMENT (breaks parity): the train's rows through the L1 like the per-tick kernel's */
-  constexpr int ROWS = GLDS_DEFAULT;
-#elif defined(RGB_X_SC1ROWS)        /* EXPERIMENT: the per-tick kernel's rows L2-served too */
-  constexpr int ROWS = GLDS_SC1;
-#else
-  constexpr int ROWS = TR ? GLDS_SC1 : GLDS_DEFAULT;
-#endif
+  constexpr int ROWS = TR ? GLDS_SC1 : GLDS_DEFAULT;      /* a train's rows are L2-served (see above) */
   u64 pf0 = 0, pf1 = 0;
   lds_barrier();
   {
@@ -2498,26 +2431,6 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
                      io + (4 + k) * RGB_TICK_BLOCK);
       }
     }
-#if defined(RGB_X_EXTRA_FETCH) && !defined(RGB_HOST_EMULATION)
-    /* EXPERIMENT (never in the product): RGB_X_EXTRA_FETCH x 64 more bytes per message, gathered like the hot rows
-     * (coalesced per row) from the cold qry rows in the same round trip and thrown away -- the slope of the state
-     * round trip against the bytes it gathers, i.e. what a 64-byte hot row would buy */
-    {
-      constexpr u32 LPR = 4u * RGB_X_EXTRA_FETCH;           /* lanes per row (16 bytes each) */
-      constexpr u32 RPI = 64u / LPR;                        /* rows per instruction */
-      ulonglong2 xf[64u / RPI];
-#pragma unroll
-      for (u32 k = 0; k < 64u / RPI; ++k) {
-        xf[k] = make_ulonglong2(0, 0);
-        if (k * RPI >= SL) break;
-        const u32 r = RPI * k + lane / LPR;
-        const u32 sj = __shfl(srv, (int)r, 64);
-        xf[k] = ld16<false>(reinterpret_cast<const ulonglong2 *>(dev.qry + (size_t)sj * 16u) + (lane % LPR));
-      }
-#pragma unroll
-      for (u32 k = 0; k < 64u / RPI; ++k) asm volatile("" ::"v"(xf[k].x), "v"(xf[k].y));
-    }
-#endif
     glds_wait();
   }
   lds_barrier();
@@ -2571,22 +2484,8 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     if (!TR && RGB_KNOB(dev, 16u)) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
 #endif
   }
-#if defined(RGB_X_EXTRA_STORE) && !defined(RGB_HOST_EMULATION)
-  /* EXPERIMENT (never in the product): RGB_X_EXTRA_STORE more dirty bytes (16 or 64) per message in a line of its own
-   * (a scratch line per server), stored like the state write-back: is the end-of-kernel write-back priced per line or
-   * per byte -- the twin of RGB_X_EXTRA_FETCH */
-  if (active && (u32)(m0.x & 0xFFFFFFFFull) < dev.n_servers) {
-    ulonglong2 *xs = reinterpret_cast<ulonglong2 *>(dev.dbg_buf + (size_t)(u32)(m0.x & 0xFFFFFFFFull) * 16);
-#pragma unroll
-    for (int k = 0; k < RGB_X_EXTRA_STORE / 16; ++k) ST16(xs + k, make_ulonglong2(d.w[0], d.w[1] + (u64)k));
-  }
-#endif
   RGB_TT(4);
-#ifdef RGB_X_TRAIN_NOSTAMP        /* EXPERIMENT (breaks parity): no publish step */
-  if (false) {
-#else
   if (TR) {
-#endif
     /* 4. publish: every state store of this wavefront has been acknowledged by the L2 (inline assembly: the
      * compiler's wait-count pass must not drop or move it), then the advanced sequence byte of every server */
 #if !defined(RGB_HOST_EMULATION) && !defined(RGB_X_TRAIN_NOWAIT)
@@ -2732,15 +2631,8 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   /* placement check, sampled (one block in 64 per shard: an atomic per block costs more than the tick) and off the
    * critical path: (XCC id - shard) mod 8 -- the rotation of this launch's round robin -- must be ONE value */
   u32 rot_seen = 0, rot_bit = 0;
-#ifdef RGB_X_TRAIN_NOCAS
-  const bool sampled = false;                 /* EXPERIMENT: no placement check */
-#else
   const bool sampled = (row & 63u) == 0u && threadIdx.x == 0;
-#endif
   if (sampled) { rot_bit = 1u << ((rgb_xcc_id() - x) & (RGB_TRAIN_SHARDS - 1u)); rot_seen = atomicOr(ctl + 1, rot_bit); }
-#endif
-#if defined(RGB_X_TRAIN_PRIO) && !defined(RGB_HOST_EMULATION)
-  if (rgb_lead_class(cls)) __builtin_amdgcn_s_setprio(3);   /* EXPERIMENT: the leader-side chain first */
 #endif
   /* ticks a fixed stride apart with a ring of rpc regions (device-resident streams), or -- tick_stride = 0 -- packed
    * one behind the other, every message owning the rpc slots of its index in the whole buffer (rgb_submit's rounds) */
