@@ -761,6 +761,9 @@ def main():
         try:   # PMC passes cannot run inside this process: the newest committed per-launch figure, if any
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            same_call = os.environ.get("RGB_TRAFFIC_JSON")         # written by the PMC passes of the same gpurun call
+            if same_call and os.path.exists(same_call):
+                cands = [same_call]
             if cands:
                 traffic_src = os.path.relpath(cands[-1], ROOT)
                 with open(cands[-1]) as f:
@@ -803,7 +806,9 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_note": f"HBM bytes per launch from {traffic_src} (rocprofv3 PMC passes, FETCH_SIZE with the "
-                                "guide's gfx950 x2 correction + WRITE_SIZE); not re-measured in this run",
+                                "guide's gfx950 x2 correction + WRITE_SIZE)" +
+                                ("; PMC passes of the same gpurun call, in front of this run" if os.environ.get("RGB_TRAFFIC_JSON")
+                                 else "; not re-measured in this run"),
                 "kernel": (f"rgb_train_kernel<{N}>" if use_train else f"rgb_tick_classes_kernel<{N}>")
                           if not args.generic_kernel else f"rgb_tick_kernel<{N},generic>",
                 "ticks_per_launch": SNAPSHOT_EVERY if use_train else 1,

@@ -8,9 +8,6 @@ TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench_driver_form.err
-python bench.py --steps 20 --warmup 5 --launch tick --no-cpu-baseline --no-host-path --literal-ticks 0 > $OUT/bench_driver_form_tick.json 2> $OUT/bench_driver_form_tick.err
 cd /tmp && export TMPDIR=/tmp
 Q="--no-cpu-baseline --no-host-path --check-ticks 0"
 # kernel trace + stats of the driver's command (trains of 11 + 9 ticks in the timed region, 5 warm-up ticks)
@@ -21,6 +18,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_l
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- $CMDS > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- $CMDS > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -o $TAG -- $CMDS > $OUT/pmc_sq.log 2>&1
+# the traffic figure the bench lines carry comes from the PMC passes above (same box, same call)
+python $R/tools/make_traffic_json.py $OUT 16 > $OUT/traffic.json 2> $OUT/traffic.err
+export RGB_TRAFFIC_JSON=$OUT/traffic.json
+cd $R
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench_driver_form.err
+python bench.py --steps 20 --warmup 5 --launch tick --no-cpu-baseline --no-host-path --literal-ticks 0 > $OUT/bench_driver_form_tick.json 2> $OUT/bench_driver_form_tick.err
+cd /tmp
 # the literal configurations (per-tick class kernels: <5> for configs 2/3, <7> for config 5), headline skipped quickly
 LIT="python $R/bench.py --steps 4 --warmup 2 --age 0 $Q --literal-ticks 32 --no-graph"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lit_stats -o $TAG -- $LIT > $OUT/lit_stats.log 2>&1

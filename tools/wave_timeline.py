@@ -8,19 +8,47 @@ os.environ.setdefault("RGB_LIB", os.path.join(os.path.dirname(os.path.dirname(os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ra_amd import abi, engine, workload as W
-G, N = int(os.environ.get('TL_GROUPS', '65536')), 5
-S = G * N
-eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
-eng.set_state(0, W.initial_states(G, N, 0x5EED0003))
+CFG = os.environ.get("TL_CONFIG")                     # "5" / "3": the literal SURVEY 8(d) configuration (bench.LITERAL)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); sp = stream.cuda_stream
-dm = torch.empty(S * 64, dtype=torch.uint8, device="cuda"); dd = torch.empty(S * 64, dtype=torch.uint8, device="cuda")
-dr = torch.empty(S * 4 * 56, dtype=torch.uint8, device="cuda")
-kc = torch.zeros(abi.N_KINDS, dtype=torch.int32, device="cuda"); dn = torch.zeros(1, dtype=torch.int32, device="cuda")
-for t in range(int(os.environ.get("TL_TICKS", "24"))):
-    eng.synth_tick_device(0x5EED0003, t, dm.data_ptr(), kc.data_ptr(), dn.data_ptr(), sp)
-    torch.cuda.synchronize()
-    eng.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), sp)
-    torch.cuda.synchronize()
+if CFG:
+    import bench
+    from oracle import oracle as O
+    c = bench.LITERAL[CFG]
+    G, N, seed = c["groups"], c["members"], c["seed"]
+    S = G * N
+    st0 = W.initial_states(G, N, seed, **c["init"])
+    cpu = O.Oracle(G, N, max_runs=16); cpu.set_state(0, st0)
+    ticks = []
+    for t in range(int(os.environ.get("TL_TICKS", "8"))):
+        m = W.gen_tick(cpu.get_state(), N, t, seed, getattr(W, c["mix"]), **c["gen"])
+        cpu.step_parallel(m); ticks.append(m)
+    cpu.close()
+    eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
+    eng.set_state(0, st0)
+    stride = max(len(m) for m in ticks)
+    dd = torch.empty(stride * 64, dtype=torch.uint8, device="cuda")
+    dr = torch.empty(stride * max(N - 1, 1) * 56, dtype=torch.uint8, device="cuda")
+    dn = torch.tensor([len(ticks[-1])], dtype=torch.int32, device="cuda")
+    kc = torch.from_numpy(np.bincount(ticks[-1]["kind"], minlength=abi.N_KINDS)[:abi.N_KINDS].astype(np.int32)).cuda()
+    for m in ticks:
+        dm = torch.from_numpy(m.view(np.uint8)).cuda()
+        k1 = np.bincount(m["kind"], minlength=abi.N_KINDS)[:abi.N_KINDS].astype(np.uint32).reshape(1, -1)
+        eng.run_ticks_device(dm.data_ptr(), len(m), 1, dd.data_ptr(), dr.data_ptr(), sp,
+                             tick_counts=np.array([len(m)], dtype=np.uint32), kind_counts=k1)
+        torch.cuda.synchronize()
+else:
+    G, N = int(os.environ.get('TL_GROUPS', '65536')), 5
+    S = G * N
+    eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
+    eng.set_state(0, W.initial_states(G, N, 0x5EED0003))
+    dm = torch.empty(S * 64, dtype=torch.uint8, device="cuda"); dd = torch.empty(S * 64, dtype=torch.uint8, device="cuda")
+    dr = torch.empty(S * 4 * 56, dtype=torch.uint8, device="cuda")
+    kc = torch.zeros(abi.N_KINDS, dtype=torch.int32, device="cuda"); dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for t in range(int(os.environ.get("TL_TICKS", "24"))):
+        eng.synth_tick_device(0x5EED0003, t, dm.data_ptr(), kc.data_ptr(), dn.data_ptr(), sp)
+        torch.cuda.synchronize()
+        eng.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), sp)
+        torch.cuda.synchronize()
 nblk = S // 64 + 16
 buf = np.zeros(nblk * 8, dtype=np.uint64)
 L = engine.lib(); L.rgb_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
