@@ -173,6 +173,8 @@ struct LaneT {
   u64 *peers;            /* this server's peers row                    */
   const ulonglong2 *peers_lds;   /* the same row in LDS (class kernel, leader-side classes, 128-byte rows), or null */
   unsigned peers_swz;            /* piece p of that row sits at position p ^ peers_swz */
+  const ulonglong2 *runs_lds;    /* runs 0..RGB_RUNS_LDS-1 of the run table in LDS (train launches, leader-side classes:
+                                  * fetched with the hot row; run k at position k ^ peers_swz), or null */
   u32 max_runs;
   /* effects */
   u32 flags;
@@ -285,12 +287,32 @@ template <int N, bool PL, class Lane> __device__ __forceinline__ void ni_put(Lan
 template <class Lane>
 __device__ __forceinline__ bool range_nonempty(const Lane &L) { return L.first <= L.li; }
 
+/* Runs of the table a leader-side train wavefront fetched into LDS with its hot rows (the first 128-byte line of the
+ * row = the eight OLDEST runs: every in-memory run of a table of up to ten).  In a train every load of the table is an
+ * L2 round trip (no L1, see ldg8) and the reply / {commands} wavefronts walk it in 99 % of the wavefronts (27.8 % of
+ * their lanes, wave maximum 5 runs at the median, 8 at p90: profiles/r02_wave_timeline.txt) -- one round trip per
+ * run, on the critical path of the wavefront's life.  The table is read-only for these kinds (a leader never truncates
+ * its own log; a pushed run stays in registers until the commit). */
+#define RGB_RUNS_LDS 8
+#ifndef RGB_TRAIN_RUNS_LDS
+#define RGB_TRAIN_RUNS_LDS 1
+#endif
+/* (start, term) of in-memory run k */
+template <class Lane>
+__device__ __forceinline__ ulonglong2 run_pair(const Lane &L, int k) {
+  if (L.runs_lds != nullptr && k < RGB_RUNS_LDS) return L.runs_lds[(unsigned)k ^ L.peers_swz];
+  return ldg16(L.coh, reinterpret_cast<const ulonglong2 *>(L.runs) + k);
+}
 /* word i of this server's in-memory run table: (start, term) of run k at words 2k, 2k+1 */
 template <class Lane>
 __device__ __forceinline__ u64 run_word(const Lane &L, int i) {
 #ifdef RGB_PROFILE
   const_cast<Lane &>(L).prof_nloads += 1;
 #endif
+  if (L.runs_lds != nullptr && i < 2 * RGB_RUNS_LDS) {
+    const ulonglong2 v = L.runs_lds[(unsigned)(i >> 1) ^ L.peers_swz];
+    return (i & 1) ? v.y : v.x;
+  }
   return ldg8(L.coh, L.runs + i);
 }
 
@@ -300,13 +322,12 @@ __device__ __forceinline__ u64 run_word(const Lane &L, int i) {
  * time measured 15 % slower per tick: the extra live registers spilled in the clause code around every call site). */
 template <class Lane>
 __device__ __forceinline__ int run_search(const Lane &L, u64 idx, u64 &term) {
-  const ulonglong2 *rt = reinterpret_cast<const ulonglong2 *>(L.runs);
   int k = (int)L.n_runs - 3;
   if (k < 0) return -1;
-  ulonglong2 cur = ldg16(L.coh, rt + k);
+  ulonglong2 cur = run_pair(L, k);
 #pragma unroll 1
   for (; k >= 0; --k) {
-    const ulonglong2 nxt = ldg16(L.coh, rt + (k > 0 ? k - 1 : 0));
+    const ulonglong2 nxt = run_pair(L, k > 0 ? k - 1 : 0);
 #ifdef RGB_PROFILE
     const_cast<Lane &>(L).prof_nloads += 2u;
 #endif
@@ -1719,7 +1740,8 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
                                                 u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr,
                                                 const ulonglong2 *pre = nullptr, unsigned swz = 0,
-                                                const ulonglong2 *prepeers = nullptr) {
+                                                const ulonglong2 *prepeers = nullptr,
+                                                const ulonglong2 *preruns = nullptr) {
   LaneT<TR> L;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -1771,6 +1793,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   /* leader-side kinds: fetch the peers row in the same round trip as the hot line (the address
    * only depends on the message); kinds that need it rarely load it lazily */
   L.peers_lds = prepeers; L.peers_swz = swz; L.pdirty = 0;
+  L.runs_lds = preruns;
   /* PL: the class kernel fetched this leader-side message's peers row into LDS with the hot row (128-byte rows:
    * 3..5 members): the clause code reads and writes it there, no register copy */
 #ifndef RGB_X_COMMIT_WAIT
@@ -2307,6 +2330,8 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #endif
   const bool lead_cls = rgb_lead_class(cls);              /* append_entries_reply, append, pipeline_rpcs */
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
+  /* a table row of max_runs >= 8 runs holds the whole 128-byte line that is fetched (wave-uniform) */
+  const bool RUNS_LDS = TR && RGB_TRAIN_RUNS_LDS && PEERS_LDS && dev.max_runs >= (u32)RGB_RUNS_LDS;
 #if defined(RGB_X_TRAIN_TIMELINE) && !defined(RGB_HOST_EMULATION)
   /* EXPERIMENT build (tools/train_timeline.py): per-wavefront wall-clock stamps of a train launch */
   u64 tt[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -2430,6 +2455,16 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
         glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.peers + (size_t)sj * 16u) + ((lane & 7u) ^ ((r >> 1) & 7u)),
                      io + (4 + k) * RGB_TICK_BLOCK);
       }
+      if (RUNS_LDS) {
+        /* train launches: the first line of the 32 run tables behind the peers rows (see run_pair) */
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32 r = 8 * k + (lane >> 3);
+          const u32 sj = __shfl(srv, (int)r, 64);
+          glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.runs + (size_t)sj * dev.max_runs * 2u) + ((lane & 7u) ^ ((r >> 1) & 7u)),
+                       io + (8 + k) * RGB_TICK_BLOCK);
+        }
+      }
     }
     glds_wait();
   }
@@ -2438,6 +2473,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   const ulonglong2 *hrow = io + lane * 8;
   const unsigned hswz = (lane >> 1) & 7u;
   const ulonglong2 *prow = (PEERS_LDS && lead_cls) ? io + 4 * RGB_TICK_BLOCK + lane * 8 : nullptr;
+  const ulonglong2 *rrow = (RUNS_LDS && PEERS_LDS && lead_cls) ? io + 8 * RGB_TICK_BLOCK + lane * 8 : nullptr;
 #ifndef RGB_HOST_EMULATION
   asm volatile("" ::"v"(pf0), "v"(pf1));   /* the touch loads above stay in the program */
 #endif
@@ -2464,7 +2500,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   case RANK:                                                                                            \
     RGB_MARK("begin", RANK)                                                                             \
     process_message<N, KIND, PRE, TR>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
-                                      hrow, hswz, prow);                                                \
+                                      hrow, hswz, prow, rrow);                                          \
     RGB_MARK("end", RANK)                                                                               \
     break;
     switch (cls) {
@@ -2614,7 +2650,10 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
     rgb_dev dev, const rgb_msg *__restrict__ msgs, const unsigned char *__restrict__ stamps, u32 tick_stride,
     const rgb_train_tick *__restrict__ plan, const u32 *__restrict__ row_tab, u32 bpt, rgb_decision *__restrict__ dec,
     rgb_rpc *__restrict__ rpcs, u32 rpc_ring, u32 index_base, u32 *__restrict__ ctl) {
-  __shared__ ulonglong2 io[RGB_TICK_BLOCK * RGB_HOT_SLOT];
+  /* records, then hot rows; a leader-side slice: 32 hot rows | 32 peers rows | the first line of 32 run tables
+   * (12 KiB: twelve wavefronts per CU -- three per SIMD, what the registers allow -- hold 144 of the 160 KiB) */
+  __shared__ ulonglong2 io[(RGB_TRAIN_RUNS_LDS && rgb_class_slice(1, (unsigned)N) == 32u) ? 12 * RGB_TICK_BLOCK
+                                                                                         : RGB_TICK_BLOCK * RGB_HOT_SLOT];
   const u32 t = blockIdx.x / bpt, j = blockIdx.x - t * bpt;
   const u32 x = j & (RGB_TRAIN_SHARDS - 1u), row = j / RGB_TRAIN_SHARDS;
   const rgb_train_tick *p = plan + t;
@@ -2693,7 +2732,7 @@ template <class Lane>
 __device__ __forceinline__ void syn_lane(Lane &T, const SynMember &x, const u64 *runs) {
   T.first = x.first; T.li = x.li; T.lrs = x.lrs; T.lrt = x.lrt; T.prs = x.prs; T.prt = x.prt;
   T.push_cnt = 0; T.n_runs = (unsigned)pk_get(x.pk, PK_NRUNS_SH, 5);
-  T.runs = runs;
+  T.runs = runs; T.runs_lds = nullptr;
 #ifdef RGB_PROFILE
   T.prof_noprobe = false; T.prof_nloads = 0;
 #endif
