@@ -36,8 +36,9 @@ def test_sub_ticks_ring_and_overflow(emulated_engine, oracle_lib):
 
 
 def test_rounds_as_one_train_launch_through_the_c_abi(emulated_engine, oracle_lib):
-    G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, G=1200, N=5, batches=2)
-    G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, G=1400, N=3, batches=1)
+    G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, 6, G=1200, N=5, batches=2)
+    G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, 16, G=1200, N=5, batches=1)
+    G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, 6, G=1400, N=3, batches=1)
 
 
 def test_concurrent_producers_and_consumers_through_the_c_abi(emulated_engine, oracle_lib):

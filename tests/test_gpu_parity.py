@@ -105,12 +105,15 @@ def test_same_server_messages_are_serialised_in_submission_order(engine_mod, ora
             assert_same(f"round {rnd}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
 
 
-def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, G=1500, N=5, batches=3):
+@pytest.mark.parametrize("table_runs", [6, 16], ids=["shallow_run_tables", "deep_run_tables"])
+def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, table_runs, G=1500, N=5, batches=3):
     """The normal shape of a real batch: a leader's N-1 replies arrive together, so does a follower's append and its
     written event -- four messages per leader, two or three per follower in ONE rgb_submit.  Rounds 2..16 of a big
     batch run as one train launch (rgb_submit_trains counts them); the result is the sequential checker's."""
-    rng = np.random.default_rng(21)
-    st = fuzz.random_states(rng, G, N, max_runs=6)
+    rng = np.random.default_rng(21 + table_runs)
+    # deep tables (up to 13 in-memory runs): a leader-side train wavefront serves runs 0..7 from LDS and the rest from
+    # memory (run_pair in rgb_kernels.hip) -- both sides of that border are walked
+    st = fuzz.random_states(rng, G, N, max_runs=table_runs, backlog=24 if table_runs <= 8 else 60)
     cpu = oracle_lib.Oracle(G, N)
     cpu.set_state(0, st)
     with engine_mod.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16) as gpu:
