@@ -220,6 +220,11 @@ static int log_write(olog *l, const rgb_msg *m, uint32_t k0) {
   if (l->has_range && !(fst <= l->last + 1))              /* guard :557-559 */
     return RGB_INV_WRITE_INTEGRITY;
   if (fst == 0) return RGB_INV_WRITE_INTEGRITY;            /* index 0 is never rewritten */
+  /* NewRange = ra_range:new(Start, LastIdx) :1617-1622, and new/2 with Start > End is `undefined`
+   * (src/ra_range.erl:41-50): a write that ends below the start of a sparse range leaves NO range.  What follows
+   * reads last_index_term/1 :831-835 -- the snapshot's -- so a log without a snapshot cannot go there */
+  const int range_lost = l->has_range && l->first > lst;
+  if (range_lost && l->snap_idx == UNDEF) return RGB_INV_WRITE_INTEGRITY;
   /* overwrite lowers last_written, :565-581 */
   uint64_t lwi = fst - 1 < l->lw_idx ? fst - 1 : l->lw_idx;
   uint64_t lwt;
@@ -239,6 +244,7 @@ static int log_write(olog *l, const rgb_msg *m, uint32_t k0) {
   if (!l->has_range) { l->has_range = 1; l->first = fst; }
   l->last = lst;
   l->last_term = msg_entry_term(m, m->n_entries - 1);
+  if (range_lost) l->has_range = 0;
   l->lw_idx = lwi; l->lw_term = lwt;
   /* Pend = ra_seq:limit(FstIdx - 1, Pend0) :583, then ra_seq:append per entry :1610 */
   if (l->pend_idx) {

@@ -680,6 +680,11 @@ __device__ __forceinline__ int log_write(Lane &L, u32 k0) {
   const bool had_range = range_nonempty(L);
   if (had_range && !(fst <= L.li + 1)) return RGB_INV_WRITE_INTEGRITY;
   if (fst == 0) return RGB_INV_WRITE_INTEGRITY;
+  /* NewRange = ra_range:new(Start, LastIdx) (src/ra_log.erl:1617-1622), and new/2 with Start > End is `undefined`
+   * (src/ra_range.erl:41-50): a write that ends below the start of a sparse range leaves NO range; last_index_term/1
+   * (:831-835) is the snapshot's from then on */
+  const bool range_lost = had_range && L.first > lst;
+  if (range_lost && L.si == UNDEF) return RGB_INV_WRITE_INTEGRITY;
   u64 lwi = fst - 1 < L.lwi ? fst - 1 : L.lwi;
   u64 lwt;
   if (lwi == L.lwi) lwt = L.lwt;
@@ -700,15 +705,21 @@ __device__ __forceinline__ int log_write(Lane &L, u32 k0) {
   /* the range keeps its Start (src/ra_log.erl:1617-1622): indexes written below first_index stay
    * invisible, so the runs begin at max(fst, first_index) */
   const u64 lo = (had_range && L.first > fst) ? L.first : fst;
-  if (k0 < L.n_run0) {
-    const u64 s1 = base + L.n_run0;
-    if (L.n_run0 == L.n_entries || lo < s1) push_segment(L, lo, L.run0_term);
-    if (L.n_run0 < L.n_entries) push_segment(L, s1 > lo ? s1 : lo, L.run1_term);
+  if (range_lost) {
+    /* the canonical undefined range behind a snapshot: (last index, last term) = the snapshot's, no runs */
+    L.n_runs = 0; L.push_cnt = 0;
+    L.li = L.si; L.lt = L.st; L.first = L.si + 1;
   } else {
-    push_segment(L, lo, L.run1_term);
+    if (k0 < L.n_run0) {
+      const u64 s1 = base + L.n_run0;
+      if (L.n_run0 == L.n_entries || lo < s1) push_segment(L, lo, L.run0_term);
+      if (L.n_run0 < L.n_entries) push_segment(L, s1 > lo ? s1 : lo, L.run1_term);
+    } else {
+      push_segment(L, lo, L.run1_term);
+    }
+    L.li = lst;
+    L.lt = (L.n_entries - 1) < L.n_run0 ? L.run0_term : L.run1_term;
   }
-  L.li = lst;
-  L.lt = (L.n_entries - 1) < L.n_run0 ? L.run0_term : L.run1_term;
   L.lwi = lwi; L.lwt = lwt;
   if (fst < L.pend) L.pend = fst;      /* ra_seq:limit(FstIdx-1, Pend0) :583 + ra_seq:append per entry :1610 */
   pend_old_limit(L, fst);
@@ -1240,7 +1251,7 @@ __device__ __forceinline__ int follower_aer(Lane &L) {
     int rc = log_write(L, k);
     if (rc) return rc;
     L.flags |= RGB_F_WROTE | RGB_F_LEADER_MSG;
-    L.w_first = fst; L.w_last = L.li;
+    L.w_first = fst; L.w_last = L.a + (u64)L.gap + L.n_entries;   /* what went to the WAL (the range may be gone) */
     evaluate_commit_index_follower(L);
     return 0;                                                       /* reply comes on written */
   }

@@ -33,6 +33,7 @@ def test_sub_ticks_ring_and_overflow(emulated_engine, oracle_lib):
     G.test_leaderboard_snapshot(emulated_engine)
     for n_run0 in (3, 1, 2):
         G.test_write_below_first_index_keeps_the_range_start(emulated_engine, oracle_lib, n_run0)
+    G.test_write_that_ends_below_a_sparse_range_leaves_no_range(emulated_engine, oracle_lib)
 
 
 def test_rounds_as_one_train_launch_through_the_c_abi(emulated_engine, oracle_lib):

@@ -405,6 +405,44 @@ def test_write_below_first_index_keeps_the_range_start(engine_mod, oracle_lib, n
         assert int(so["first_index"][1]) == 47 == int(so["run_start"][1][0]) and int(so["last_index"][1]) == 47
 
 
+def test_write_that_ends_below_a_sparse_range_leaves_no_range(engine_mod, oracle_lib):
+    """A sparse range [47..48] behind a snapshot at 44, overwritten by ONE entry at 45: the reference computes
+    `ra_range:new(Start = 47, LastIdx = 45)` (src/ra_log.erl:1617-1622) and new/2 with Start > End is `undefined`
+    (src/ra_range.erl:41-50) -- no range is left, last_index_term/1 (:831-835) is the snapshot's again, nothing above
+    the snapshot is applied, and the decision still names the entry that went to the WAL.  (Found by the fused-rounds
+    fuzz test; device and checker both kept a half-defined range here.)"""
+    st = abi.empty_server_states(1, 3)
+    for i in range(3):
+        st["current_term"][i] = 3
+        st["role"][i] = abi.ROLE_FOLLOWER
+        abi.set_log(st, i, [(47, 2), (48, 2)], last_written=(44, 2), snapshot=(44, 2))
+        st["commit_index"][i] = st["last_applied"][i] = 44
+        st["pending_first"][i] = 45
+    m = np.zeros(1, dtype=abi.MSG_DTYPE)
+    m["server"], m["kind"], m["from"], m["term"] = 1, abi.MSG_AER, 0, 3
+    m["a"], m["b"], m["c"] = 44, 2, 49
+    m["n_entries"], m["n_run0"], m["run0_term"], m["run1_term"] = 1, 1, 3, 3
+    cpu = oracle_lib.Oracle(1, 3)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(1, 3, ring_capacity=16, ring_slots=1) as gpu:
+        gpu.set_state(0, st)
+        do, ro = cpu.step(m)
+        dg, rg = gpu.step(m)
+        so = cpu.get_state()
+        assert_same("write below a sparse range", dg, rg, gpu.get_state(), do, ro, so)
+        assert int(do["flags"][0]) & abi.F_WROTE and not int(do["flags"][0]) & abi.F_APPLIED
+        assert (int(do["reply_next_index"][0]), int(do["reply_last_index"][0])) == (45, 45)      # written range
+        s1 = so[1]
+        assert (int(s1["last_index"]), int(s1["last_term"]), int(s1["first_index"]), int(s1["n_runs"])) == (44, 2, 45, 0)
+        assert int(s1["last_applied"]) == 44 and int(s1["commit_index"]) == 49
+        # the next append_entries_rpc continues from the snapshot
+        m2 = m.copy()
+        m2["n_entries"], m2["n_run0"] = 2, 2
+        do, ro = cpu.step(m2); dg, rg = gpu.step(m2)
+        assert_same("append after the range was lost", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+        assert int(cpu.get_state()["last_index"][1]) == 46
+
+
 def _reply_ok(server, peer, term, next_index, last_index):
     m = np.zeros(1, dtype=abi.MSG_DTYPE)
     m["server"], m["kind"], m["from"], m["term"], m["flags"] = server, abi.MSG_AER_REPLY, peer, term, abi.MF_SUCCESS
