@@ -1,0 +1,24 @@
+import numpy as np, pytest
+import fuzz
+from ra_amd import abi
+from test_gpu_parity import assert_same
+
+
+@pytest.mark.parametrize("seed", list(range(300, 312)))
+def test_more_seeds(emulated_engine, oracle_lib, seed):
+    G, N = 1100, 5
+    rng = np.random.default_rng(seed)
+    deep = seed % 2 == 1
+    st = fuzz.random_states(rng, G, N, max_runs=16 if deep else 6, backlog=60 if deep else 24)
+    cpu = oracle_lib.Oracle(G, N, max_runs=16)
+    cpu.set_state(0, st)
+    with emulated_engine.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        for b in range(2):
+            parts = [fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.9) for _ in range(4)]
+            msgs = np.concatenate(parts)
+            msgs = msgs[msgs["kind"] != abi.MSG_NOP]
+            rng.shuffle(msgs)
+            do, ro = cpu.step(msgs)
+            dg, rg = gpu.step(msgs)
+            assert_same(f"seed {seed} batch {b}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
