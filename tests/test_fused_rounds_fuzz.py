@@ -1,11 +1,28 @@
-import numpy as np, pytest
+"""Differential fuzz of the host path's normal shape -- several messages per server in ONE rgb_submit, the rounds
+fused into one train launch -- on the CPU emulation: random states (shallow and deep run tables), random messages of
+every kind, 3 / 5 / 7 members, the checker bounded like the device.  Four seeds run with the suite; more with
+RGB_FUZZ_SEEDS=lo:hi (round 3 ran 312:432 clean after seed 27 of the GPU twin had found the range-lost corner of
+ra_log:write)."""
+import os
+
+import numpy as np
+import pytest
+
 import fuzz
 from ra_amd import abi
 from test_gpu_parity import assert_same
 
 
-@pytest.mark.parametrize("seed", list(range(312, 432)))
-def test_more_seeds(emulated_engine, oracle_lib, seed):
+def _seeds():
+    spec = os.environ.get("RGB_FUZZ_SEEDS")
+    if spec:
+        lo, hi = (int(x) for x in spec.split(":"))
+        return list(range(lo, hi))
+    return [300, 301, 302, 307]
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fused_rounds_equal_the_sequential_checker(emulated_engine, oracle_lib, seed):
     N = (5, 3, 7, 5)[seed % 4]
     G = {3: 1800, 5: 1100, 7: 800}[N]
     rng = np.random.default_rng(seed)
@@ -23,3 +40,4 @@ def test_more_seeds(emulated_engine, oracle_lib, seed):
             do, ro = cpu.step(msgs)
             dg, rg = gpu.step(msgs)
             assert_same(f"seed {seed} batch {b}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+        assert gpu.submit_trains() >= 1
