@@ -110,7 +110,7 @@ def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, tab
     """The normal shape of a real batch: a leader's N-1 replies arrive together, so does a follower's append and its
     written event -- four messages per leader, two or three per follower in ONE rgb_submit.  Rounds 2..16 of a big
     batch run as one train launch (rgb_submit_trains counts them); the result is the sequential checker's."""
-    rng = np.random.default_rng(21 + table_runs)
+    rng = np.random.default_rng(21 + table_runs + 1000 * int(os.environ.get("RGB_FUZZ_SEED_OFFSET", "0")))   # more seeds: tools/gpu_fuzz_rounds.py
     # deep tables (up to 13 in-memory runs): a leader-side train wavefront serves runs 0..7 from LDS and the rest from
     # memory (run_pair in rgb_kernels.hip) -- both sides of that border are walked
     st = fuzz.random_states(rng, G, N, max_runs=table_runs, backlog=24 if table_runs <= 8 else 60)
