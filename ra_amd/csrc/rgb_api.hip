@@ -47,6 +47,15 @@ struct rgb_slot {
   rgb_train_tick *h_plan = nullptr, *d_plan = nullptr;
   u32 *h_rows = nullptr, *d_rows = nullptr;
   u32 rows_cap = 0;                 /* words of h_rows / d_rows */
+  u32 *d_ctl = nullptr;             /* RGB_TRAIN_CTL_WORDS: this slot's train error word + per-launch counters */
+  /* fail-safe: the servers this batch touches and their rows as they were before it (saved while a train is in flight) */
+  u32 *h_touched = nullptr, *d_touched = nullptr;   /* pinned / device: ring_capacity ids */
+  u32 n_touched = 0;
+  void *d_undo = nullptr;           /* allocated with the first batch that needs it */
+  bool has_undo = false;
+  u32 n_rounds = 0;
+  std::vector<u32> round_start;     /* n_rounds + 1: first device position of every round            */
+  std::vector<u32> round_cc;        /* n_rounds x RGB_N_CLASSES: class sizes (one launch per round)  */
   bool used_train = false;
   int enqueue_error = 0;            /* the enqueue of this batch failed (RGB_E_*): rgb_collect reports it once */
   /* 0 free | 1 reserved by a producer (being filled) | 2 in flight (published) | 3 reserved by a consumer (being
@@ -110,8 +119,13 @@ struct rgb_ctx {
   std::vector<unsigned char> seq_host;  /* host mirror of dev.seq (by server), valid while only rgb_submit ran trains */
   bool seq_host_valid = false;
   std::atomic<u32> n_submit_trains{0};  /* batches whose sub-tick rounds ran as one train launch */
-  u32 xcc_map = 0;                      /* 4 bits per shard: the XCC id blocks b mod 8 = shard ran on in the calibration launch */
-  int xcc_state = 0;                    /* 0 = not calibrated, 1 = usable, -1 = placement is not one XCD per shard */
+  std::atomic<u32> trains_in_flight{0}; /* such batches enqueued and not yet verified by rgb_collect: while there are
+                                           any, every batch saves an undo log (settle_trains) */
+  std::atomic<u32> n_train_recoveries{0};
+  std::atomic<u32> inject_fault{0};     /* tests: RGB_FAULT_* applied to the next train batch (rgb_debug_inject_train_fault) */
+  u32 n_xcc = 0;                        /* XCCs of the device (calibration launch): a train block serves the shard of its XCC */
+  u32 train_blocks = 0;                 /* blocks of a persistent train launch: every wavefront slot of the device */
+  int xcc_state = 0;                    /* 0 = not calibrated, 1 = usable, -1 = the XCC ids are not 0 .. n-1 with n | 8 */
 };
 
 /* the device plan of a train: one rgb_train_tick per tick */
@@ -182,11 +196,13 @@ int rgb_last_hip_error(const rgb_ctx *ctx) { return ctx ? ctx->last_hip.load(std
 /* The host-buffer state calls (upload / download / snapshot / checksum) share staging buffers (state_mu) and put
  * work on the context's stream: they take the enqueue lock as well, so their work never lands between the rounds of
  * a batch another thread is enqueuing -- it is ordered against WHOLE batches, after every rgb_submit that has
- * returned.  Lock order: state_mu, then enqueue_mu (rgb_submit holds enqueue_mu alone, rgb_collect collect_mu then
- * enqueue_mu). */
+ * returned.  Lock order: state_mu, collect_mu, enqueue_mu (rgb_submit holds enqueue_mu alone, rgb_collect collect_mu
+ * then enqueue_mu). */
+static int settle_trains(rgb_ctx *ctx);
 struct rgb_stream_turn {
-  std::lock_guard<std::mutex> a, b;
-  explicit rgb_stream_turn(rgb_ctx *ctx) : a(ctx->state_mu), b(ctx->enqueue_mu) {}
+  std::lock_guard<std::mutex> a, c, b;
+  int rc;      /* a failed train launch among the batches in flight is repaired first (settle_trains) */
+  explicit rgb_stream_turn(rgb_ctx *ctx) : a(ctx->state_mu), c(ctx->collect_mu), b(ctx->enqueue_mu), rc(settle_trains(ctx)) {}
 };
 
 static void free_slot(rgb_slot &s) {
@@ -204,10 +220,15 @@ static void free_slot(rgb_slot &s) {
   if (s.d_plan) (void)hipFree(s.d_plan);
   if (s.h_rows) (void)hipHostFree(s.h_rows);
   if (s.d_rows) (void)hipFree(s.d_rows);
+  if (s.d_ctl) (void)hipFree(s.d_ctl);
+  if (s.h_touched) (void)hipHostFree(s.h_touched);
+  if (s.d_touched) (void)hipFree(s.d_touched);
+  if (s.d_undo) (void)hipFree(s.d_undo);
   if (s.done) (void)hipEventDestroy(s.done);
   s.h_msgs = nullptr; s.h_dec = nullptr; s.d_msgs = nullptr; s.d_dec = nullptr; s.d_rpcs = nullptr; s.h_rpcs = nullptr;
   s.h_nrpc = s.d_nrpc = nullptr;
   s.h_stamps = s.d_stamps = nullptr; s.h_plan = s.d_plan = nullptr; s.h_rows = s.d_rows = nullptr; s.done = nullptr;
+  s.d_ctl = nullptr; s.h_touched = s.d_touched = nullptr; s.d_undo = nullptr;
 }
 
 void rgb_close(rgb_ctx *ctx) {
@@ -282,6 +303,11 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   s.rows_cap = (cap / 32u + 2u * RGB_N_CLASSES * RGB_SUBMIT_TRAIN_ROUNDS + 64u);   /* every row holds >= 32 x 8 messages or closes a class */
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_rows, (size_t)s.rows_cap * RGB_SUBMIT_TRAIN_ROUNDS * sizeof(u32), hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_rows, (size_t)s.rows_cap * RGB_SUBMIT_TRAIN_ROUNDS * sizeof(u32)));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_ctl, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
+  HIPCHK(ctx, hipMemset(s.d_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_touched, (size_t)cap * sizeof(u32), hipHostMallocDefault));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_touched, (size_t)cap * sizeof(u32)));
+  s.perm.reserve(cap);              /* nothing allocates between taking the ticket and publishing the slot */
   return RGB_OK;
 }
 
@@ -398,6 +424,7 @@ int rgb_upload_state(rgb_ctx *ctx, uint32_t first, uint32_t n, const rgb_server_
   }
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   rgb_stream_turn turn(ctx);
+  if (turn.rc) return turn.rc;
   for (u32 base = 0; base < n; base += ctx->stage_cap) {
     u32 cnt = n - base < ctx->stage_cap ? n - base : ctx->stage_cap;
     memcpy(ctx->h_stage, in + base, (size_t)cnt * sizeof(rgb_server_state));
@@ -416,6 +443,7 @@ int rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_stat
   if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   rgb_stream_turn turn(ctx);
+  if (turn.rc) return turn.rc;
   for (u32 base = 0; base < n; base += ctx->stage_cap) {
     u32 cnt = n - base < ctx->stage_cap ? n - base : ctx->stage_cap;
     int rc = rgb_launch_unpack(ctx->dev, ctx->d_stage, first + base, cnt, ctx->stream);
@@ -442,6 +470,126 @@ static int validate_msg(const rgb_ctx *ctx, const rgb_msg &m) {
 
 static int train_scratch(rgb_ctx *ctx);
 
+/* fault injection for the fail-safe tests (rgb_debug_inject_train_fault): applied to the next train batch */
+#define RGB_FAULT_STAMP 1u   /* its first message carries a stamp that never comes up: RGB_TRAIN_ERR_SPIN            */
+#define RGB_FAULT_SHARD 2u   /* two messages of one class and round swap shards: RGB_TRAIN_ERR_PLACEMENT            */
+
+/* the rounds of a batch with one launch per round (the shape of every batch that is not a train, and the replay of
+ * one whose train launch failed) */
+static int enqueue_rounds(rgb_ctx *ctx, rgb_slot &s) {
+  for (u32 r = 0; r < s.n_rounds; ++r) {
+    const u32 off = s.round_start[r], cnt = s.round_start[r + 1] - s.round_start[r];
+    int lr;
+    if (cnt >= 4096) {
+      /* big round: the class-dispatch kernel (specialised path per message kind) */
+      u32 cc[RGB_N_CLASSES];
+      for (int c = 0; c < RGB_N_CLASSES; ++c) cc[c] = s.round_cc[(size_t)r * RGB_N_CLASSES + c];
+      lr = launch_tick_classes(ctx, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
+      if (lr) return lr;
+      u32 real = 0;
+      for (int c = 0; c < RGB_N_CLASSES; ++c) real += cc[c];
+      if (real < cnt) {      /* NOP slots sort last: the generic kernel writes their empty decisions */
+        lr = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
+                             s.d_rpcs, off + real, off + real, ctx->stream);
+        if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+      }
+    } else {
+      lr = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off, ctx->stream);
+      if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+    }
+  }
+  return RGB_OK;
+}
+
+/* what comes back: the rpc count, the decisions, the span of rpc slots, a train's error word; then the slot's event */
+static int enqueue_results(rgb_ctx *ctx, rgb_slot &s) {
+  {
+    int lr = rgb_launch_count_rpcs(s.d_dec, s.n, s.d_nrpc, ctx->stream);
+    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+  }
+  HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc, s.d_nrpc, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  if (s.used_train)
+    HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc + 1, s.d_ctl, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)s.n * sizeof(rgb_decision), hipMemcpyDeviceToHost, ctx->stream));
+  if (s.rpc_cnt)
+    HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
+                               (size_t)s.rpc_cnt * ctx->rpc_stride * sizeof(rgb_rpc), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
+  return RGB_OK;
+}
+
+/* step 3 of rgb_submit (under enqueue_mu, in ticket order): everything the batch puts on the stream */
+static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max) {
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  const u32 n = s.n;
+  s.h_nrpc[0] = 0; s.h_nrpc[1] = 0;
+  if (!n) { HIPCHK(ctx, hipEventRecord(s.done, ctx->stream)); return RGB_OK; }
+  u32 fault = 0;
+  if (as_train) {
+    /* stamps from the host mirror of the sequence bytes (refreshed from the device after a device-side train or a
+     * repaired one) */
+    if (!ctx->seq_host_valid) {
+      const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
+      std::vector<unsigned char> raw(bytes);
+      HIPCHK(ctx, hipMemcpyAsync(raw.data(), ctx->dev.seq, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->seq_host.resize(ctx->dev.n_servers);
+      for (u32 sv = 0; sv < ctx->dev.n_servers; ++sv)
+        ctx->seq_host[sv] = raw[rgb_seq_index(sv, ctx->dev.n_members, ctx->dev.seq_stride)];
+      ctx->seq_host_valid = true;
+    }
+    for (u32 p = 0; p < n; ++p) s.h_stamps[p] = ctx->seq_host[s.h_msgs[p].server]++;
+    fault = ctx->inject_fault.exchange(0u, std::memory_order_relaxed);
+    if (fault == RGB_FAULT_STAMP) s.h_stamps[0] = (unsigned char)(s.h_stamps[0] + 7u);
+    if (fault == RGB_FAULT_SHARD) {
+      /* the first messages of two shards of one (round, class) change places (with their stamps and their places in
+       * the permutation): the tick is still class-ordered, so the per-round replay computes it */
+      bool done = false;
+      for (u32 c = 0; c < RGB_N_CLASSES && !done; ++c)
+        for (u32 x = 0; x + 1 < RGB_TRAIN_SHARDS && !done; ++x) {
+          const rgb_train_tick &t0 = s.h_plan[0];
+          if (t0.cnt[c][x] == 0 || t0.cnt[c][x + 1] == 0) continue;
+          const u32 a = t0.msg_base + t0.off[c][x], b = t0.msg_base + t0.off[c][x + 1];
+          std::swap(s.h_msgs[a], s.h_msgs[b]); std::swap(s.h_stamps[a], s.h_stamps[b]); std::swap(s.perm[a], s.perm[b]);
+          done = true;
+        }
+    }
+  }
+  HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice, ctx->stream));
+  /* the undo log: the rows of the touched servers as they are before this batch -- while a train is in flight
+   * (this batch included) a failed launch must be repairable */
+  if (as_train || ctx->trains_in_flight.load(std::memory_order_acquire) != 0) {
+    if (s.n_touched) {
+      if (!s.d_undo) {
+        const size_t servers = ctx->cfg.ring_capacity < ctx->dev.n_servers ? ctx->cfg.ring_capacity : ctx->dev.n_servers;
+        HIPCHK(ctx, hipMalloc(&s.d_undo, servers * rgb_undo_pieces(ctx->dev) * 16u));
+      }
+      HIPCHK(ctx, hipMemcpyAsync(s.d_touched, s.h_touched, (size_t)s.n_touched * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+      int lr = rgb_launch_undo(ctx->dev, s.d_touched, s.n_touched, s.d_undo, 0, ctx->stream);
+      if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+    }
+    s.has_undo = true;
+  }
+  if (as_train) {
+    HIPCHK(ctx, hipMemcpyAsync(s.d_stamps, s.h_stamps, n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(s.d_plan, s.h_plan, (size_t)s.n_rounds * sizeof(rgb_train_tick), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(s.d_rows, s.h_rows, (size_t)s.n_rounds * rows_max * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(s.d_ctl, 0, sizeof(u32), ctx->stream));    /* this slot's own error word */
+    int lr = rgb_launch_train(ctx->dev, s.d_msgs, s.d_stamps, 0, s.d_plan, s.d_rows, s.n_rounds, rows_max * RGB_TRAIN_SHARDS,
+                              s.d_dec, s.d_rpcs, 1, 0, s.d_ctl, ctx->n_xcc, ctx->train_blocks, ctx->stream);
+    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+    s.used_train = true;
+    ctx->trains_in_flight.fetch_add(1, std::memory_order_release);
+    ctx->n_submit_trains.fetch_add(1, std::memory_order_relaxed);
+  } else {
+    int rc = enqueue_rounds(ctx, s);
+    if (rc) return rc;
+  }
+  int rc = enqueue_results(ctx, s);
+  if (rc && s.used_train) { s.used_train = false; ctx->trains_in_flight.fetch_sub(1, std::memory_order_release); }
+  return rc;
+}
+
 /* The sub-tick rounds of one batch run as ONE train launch (reference: the mailbox of a member is FIFO,
  * src/ra_server_proc.erl:1356-1397 -- a leader's N-1 replies land in one batch, so rounds > 1 are the normal shape):
  * round r = tick r of the train, every round in bucket order, the per-server sequence bytes order a server's
@@ -458,6 +606,9 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   if (!ctx || (!msgs && n)) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   if (n > ctx->cfg.ring_capacity) return RGB_E_INVAL;
+  /* the calling thread's current device may be any (one context per GPU, scheduler threads default to device 0):
+   * everything below -- the one-off train calibration included -- runs on the context's */
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   /* ---- 1. ONE pass over the batch: validation, the rounds (round r = every server's r-th message of this batch,
    * in order; per-thread scratch) and every message's bucket key -- the later passes read 6 bytes per message, not 64 */
   thread_local std::vector<uint16_t> seen, key_of;
@@ -514,7 +665,25 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   if (as_train) bucket_counts.assign(bucket.begin() + 1, bucket.end());      /* per (round, bucket), before the scan */
   for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) bucket[b + 1] += bucket[b];
 
-  /* ---- 2. the slot and the ticket ---- */
+  /* per round: the class sizes (what one launch per round needs -- the fall-back of a train and its replay after a
+   * failed launch) and the span of device positions whose kind can emit rpc records.  A bucket holds one class, so
+   * both follow from the bucket bounds (bucket[b] .. bucket[b + 1] before the scatter below moves them) */
+  std::vector<u32> class_counts((size_t)n_rounds * RGB_N_CLASSES, 0);
+  u32 rpc_lo = n, rpc_hi = 0;
+  for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) {
+    const u32 b0 = bucket[b], b1 = bucket[b + 1];
+    if (b1 == b0) continue;
+    const u32 cls = (u32)(b % NK) / (as_train ? 2u * RGB_TRAIN_SHARDS : 2u);      /* kind rank; 15 = NOP */
+    if (cls < RGB_N_CLASSES) class_counts[(b / NK) * RGB_N_CLASSES + cls] += b1 - b0;
+    /* append_entries_reply, {commands}, pipeline_rpcs, request_vote_result, pre_vote_rpc */
+    if (cls == 1 || cls == 3 || cls == 4 || cls == 6 || cls == 9) {
+      if (b0 < rpc_lo) rpc_lo = b0;
+      rpc_hi = b1 - 1;
+    }
+  }
+  /* ---- 2. the slot and the ticket.  From here to the publication nothing returns early and whatever throws is
+   * caught: the ticket must be honoured (enqueue_turn advances, the slot is published -- as failed if need be) or
+   * every later rgb_submit would block for ever ---- */
   rgb_slot *sp;
   uint64_t ticket;
   {
@@ -527,112 +696,57 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     ticket = ctx->next_ticket++;
   }
   rgb_slot &s = *sp;
-  s.perm.resize(n);
-  for (u32 i = 0; i < n; ++i) {
-    u32 p = bucket[(size_t)round_of[i] * NK + family(key_of[i])]++;
-    s.perm[p] = i;
-    s.h_msgs[p] = msgs[i];
-  }
-  s.n = n; s.tick = tick;
-  s.used_train = false; s.enqueue_error = 0;
+  int rc = RGB_OK;
   u32 rows_max = 0;
-  if (as_train) {                                            /* the plan of every round: slot-local, no lock */
-    for (u32 r = 0; r < n_rounds; ++r) {
-      const u32 rows = rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, n_members, &s.h_plan[r], nullptr, 0);
-      if (rows > rows_max) rows_max = rows;
+  try {
+    s.perm.resize(n);                                           /* within the capacity reserved by alloc_slot */
+    for (u32 i = 0; i < n; ++i) {
+      u32 p = bucket[(size_t)round_of[i] * NK + family(key_of[i])]++;
+      s.perm[p] = i;
+      s.h_msgs[p] = msgs[i];
     }
-    if (rows_max == 0 || rows_max > s.rows_cap) as_train = false;   /* more rows than the slot's table holds */
-    for (u32 r = 0; as_train && r < n_rounds; ++r) {
-      for (u32 k = 0; k < rows_max; ++k) s.h_rows[(size_t)r * rows_max + k] = 0xFFFFFFFFu;
-      rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, n_members, &s.h_plan[r], s.h_rows + (size_t)r * rows_max, rows_max);
-      s.h_plan[r].msg_base = start[r];
-    }
-  }
-  /* the rpc slots that come back: the span of device positions whose message kind can emit rpcs.  A bucket holds
-   * one kind, so the span follows from the buckets' ends (bucket[b] is now the END of bucket b) */
-  std::vector<u32> class_counts;                              /* per round, for the class-dispatch kernel */
-  if (!as_train) class_counts.assign((size_t)n_rounds * RGB_N_CLASSES, 0);
-  {
-    u32 lo = n, hi = 0;
-    for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) {
-      const u32 b0 = b ? bucket[b - 1] : 0u, b1 = bucket[b];
-      if (b1 == b0) continue;
-      const unsigned k = s.h_msgs[b0].kind;
-      if (!as_train && k != RGB_MSG_NOP) class_counts[(b / NK) * RGB_N_CLASSES + rgb_class_of_kind(k)] += b1 - b0;
-      if (k == RGB_MSG_AER_REPLY || k == RGB_MSG_APPEND || k == RGB_MSG_PIPELINE_RPCS ||
-          k == RGB_MSG_VOTE_RESULT || k == RGB_MSG_PRE_VOTE_RPC) {
-        if (b0 < lo) lo = b0;
-        hi = b1 - 1;
+    s.n = n; s.tick = tick;
+    s.used_train = false; s.enqueue_error = 0; s.has_undo = false;
+    s.n_rounds = n_rounds;
+    s.round_start.swap(start);                                  /* no allocation: the vectors change hands */
+    s.round_cc.swap(class_counts);
+    s.n_touched = (u32)touched.size();
+    if (s.n_touched) memcpy(s.h_touched, touched.data(), (size_t)s.n_touched * sizeof(u32));
+    s.rpc_lo = rpc_lo < n ? rpc_lo : 0; s.rpc_cnt = rpc_lo < n ? rpc_hi - rpc_lo + 1 : 0;
+    if (as_train) {                                            /* the plan of every round: slot-local, no lock */
+      for (u32 r = 0; r < n_rounds; ++r) {
+        const u32 rows = rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, n_members, &s.h_plan[r], nullptr, 0);
+        if (rows > rows_max) rows_max = rows;
+      }
+      if (rows_max == 0 || rows_max > s.rows_cap) as_train = false;   /* more rows than the slot's table holds */
+      for (u32 r = 0; as_train && r < n_rounds; ++r) {
+        for (u32 k = 0; k < rows_max; ++k) s.h_rows[(size_t)r * rows_max + k] = 0xFFFFFFFFu;
+        rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, n_members, &s.h_plan[r], s.h_rows + (size_t)r * rows_max, rows_max);
+        s.h_plan[r].msg_base = s.round_start[r];
       }
     }
-    s.rpc_lo = lo < n ? lo : 0; s.rpc_cnt = lo < n ? hi - lo + 1 : 0;
+  } catch (...) {
+    rc = RGB_E_NOMEM;
   }
 
   /* ---- 3. the stream's work, in ticket order ---- */
-  int rc = RGB_OK;
   {
     std::unique_lock<std::mutex> el(ctx->enqueue_mu);
     ctx->enqueue_cv.wait(el, [&] { return ctx->enqueue_turn == ticket; });
-    rc = [&]() -> int {
-      HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-      s.h_nrpc[0] = 0;
-      if (!n) { HIPCHK(ctx, hipEventRecord(s.done, ctx->stream)); return RGB_OK; }
-      HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice, ctx->stream));
-      if (as_train) {
-        /* stamps from the host mirror of the sequence bytes (refreshed from the device after a device-side train) */
-        if (!ctx->seq_host_valid) {
-          const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
-          std::vector<unsigned char> raw(bytes);
-          HIPCHK(ctx, hipMemcpyAsync(raw.data(), ctx->dev.seq, bytes, hipMemcpyDeviceToHost, ctx->stream));
-          HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-          ctx->seq_host.resize(ctx->dev.n_servers);
-          for (u32 sv = 0; sv < ctx->dev.n_servers; ++sv) ctx->seq_host[sv] = raw[rgb_seq_index(sv, n_members, ctx->dev.seq_stride)];
-          ctx->seq_host_valid = true;
-        }
-        for (u32 p = 0; p < n; ++p) s.h_stamps[p] = ctx->seq_host[s.h_msgs[p].server]++;
-        HIPCHK(ctx, hipMemcpyAsync(s.d_stamps, s.h_stamps, n, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(s.d_plan, s.h_plan, (size_t)n_rounds * sizeof(rgb_train_tick), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(s.d_rows, s.h_rows, (size_t)n_rounds * rows_max * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-        int lr = rgb_launch_train(ctx->dev, s.d_msgs, s.d_stamps, 0, s.d_plan, s.d_rows, n_rounds, rows_max * RGB_TRAIN_SHARDS,
-                                  s.d_dec, s.d_rpcs, 1, 0, ctx->d_train_ctl, ctx->stream);
-        if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
-        s.used_train = true;
-        ctx->n_submit_trains.fetch_add(1, std::memory_order_relaxed);
+    if (rc == RGB_OK) {
+      try {
+        rc = enqueue_batch(ctx, s, as_train, rows_max);
+      } catch (...) {
+        rc = RGB_E_NOMEM;
       }
-      for (u32 r = 0; r < n_rounds && !s.used_train; ++r) {
-        u32 off = start[r], cnt = start[r + 1] - start[r];
-        int lr;
-        if (cnt >= 4096) {
-          /* big round: the class-dispatch kernel (specialised path per message kind) */
-          u32 cc[RGB_N_CLASSES];
-          for (int c = 0; c < RGB_N_CLASSES; ++c) cc[c] = class_counts[(size_t)r * RGB_N_CLASSES + c];
-          lr = launch_tick_classes(ctx, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
-          if (lr) return lr;
-          u32 real = 0;
-          for (int c = 0; c < RGB_N_CLASSES; ++c) real += cc[c];
-          if (real < cnt) {      /* NOP slots sort last: the generic kernel writes their empty decisions */
-            lr = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
-                                 s.d_rpcs, off + real, off + real, ctx->stream);
-            if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
-          }
-        } else {
-          lr = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off, ctx->stream);
-          if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
-        }
-      }
-      {
-        int lr = rgb_launch_count_rpcs(s.d_dec, n, s.d_nrpc, ctx->stream);
-        if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
-      }
-      HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc, s.d_nrpc, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)n * sizeof(rgb_decision), hipMemcpyDeviceToHost, ctx->stream));
-      if (s.rpc_cnt)
-        HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
-                                   (size_t)s.rpc_cnt * ctx->rpc_stride * sizeof(rgb_rpc), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
-      return RGB_OK;
-    }();
-    if (rc != RGB_OK) { s.enqueue_error = rc; s.n = 0; s.rpc_cnt = 0; (void)hipEventRecord(s.done, ctx->stream); }
+    }
+    if (rc != RGB_OK) {
+      /* published as failed: rgb_collect reports the error once and the ring moves on.  The host mirror of the
+       * sequence bytes may have been advanced for stamps that never reached the device */
+      s.enqueue_error = rc; s.n = 0; s.rpc_cnt = 0; s.used_train = false; s.has_undo = false;
+      ctx->seq_host_valid = false;
+      (void)hipEventRecord(s.done, ctx->stream);
+    }
     /* publish: everything written to the slot above happens-before the consumer's acquire load */
     s.state.store(2, std::memory_order_release);
     ctx->in_flight.fetch_add(1, std::memory_order_release);
@@ -642,6 +756,48 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   { std::lock_guard<std::mutex> wl(ctx->wait_mu); }
   ctx->wait_cv.notify_one();
   return rc;
+}
+
+/* A train launch that failed (RGB_TRAIN_ERR_*: a dependency that never committed, a tick out of bucket order) has
+ * applied SOME of its batch's messages, and every batch enqueued behind it ran on that state.  The engine repairs this
+ * itself (reference semantics to keep: a member's messages apply in order, exactly once,
+ * src/ra_server_proc.erl:1356-1397): the undo logs of the in-flight batches go back newest first -- every batch that
+ * was enqueued while a train was in flight carries one -- which is the state before the failed batch, and the batches
+ * run again, oldest first, with one launch per round.  Caller holds collect_mu and enqueue_mu. */
+static int settle_trains(rgb_ctx *ctx) {
+  if (ctx->trains_in_flight.load(std::memory_order_acquire) == 0) return RGB_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  /* the published batches, oldest first (producers take slots in ring order) */
+  u32 idx[64], m = 0, first_bad = 0xFFFFFFFFu;
+  for (u32 k = 0; k < ctx->ring_size; ++k) {
+    const u32 j = (ctx->tail + k) % ctx->ring_size;
+    rgb_slot &s = ctx->ring_mem[j];
+    if (s.state.load(std::memory_order_acquire) != 2) break;
+    if (first_bad == 0xFFFFFFFFu && s.used_train && !s.enqueue_error && s.h_nrpc[1] != 0) first_bad = m;
+    idx[m++] = j;
+  }
+  if (first_bad == 0xFFFFFFFFu) return RGB_OK;
+  ctx->n_train_recoveries.fetch_add(1, std::memory_order_relaxed);
+  for (u32 k = m; k-- > first_bad;) {
+    rgb_slot &s = ctx->ring_mem[idx[k]];
+    if (s.enqueue_error || !s.n) continue;
+    if (!s.has_undo) return RGB_E_STATE;                    /* cannot happen: enqueued behind a train in flight */
+    int lr = rgb_launch_undo(ctx->dev, s.d_touched, s.n_touched, s.d_undo, 1, ctx->stream);
+    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+  }
+  for (u32 k = first_bad; k < m; ++k) {
+    rgb_slot &s = ctx->ring_mem[idx[k]];
+    if (s.enqueue_error || !s.n) continue;
+    if (s.used_train) { s.used_train = false; ctx->trains_in_flight.fetch_sub(1, std::memory_order_release); }
+    s.h_nrpc[1] = 0;
+    int rc = enqueue_rounds(ctx, s);
+    if (rc == RGB_OK) rc = enqueue_results(ctx, s);
+    if (rc) return rc;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->seq_host_valid = false;                              /* the sequence bytes went back with the rows */
+  return RGB_OK;
 }
 
 /* rgb_collect: the oldest published batch.  Under collect_mu only: wait for the batch, size check, take the slot;
@@ -661,21 +817,19 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     HIPCHK(ctx, hipEventSynchronize(s.done));
     int fail = s.enqueue_error;
+    if (!fail && s.used_train && s.h_nrpc[1] != 0) {
+      /* the train launch of this batch failed (its error word came back with the results): repair the device
+       * state and run this batch and everything enqueued behind it again, one launch per round */
+      std::lock_guard<std::mutex> el(ctx->enqueue_mu);
+      fail = settle_trains(ctx);
+    }
     if (!fail && s.used_train) {
-      /* a train that hit its spin bound or found a block on the wrong XCD did not compute the batch: consumed,
-       * reported once, the caller re-uploads the servers and resubmits (exceptional: the placement is checked when
-       * the first train of a context is set up) */
-      u32 flags = 0;
-      HIPCHK(ctx, hipMemcpy(&flags, ctx->d_train_ctl, sizeof flags, hipMemcpyDeviceToHost));
-      if (flags) {
-        HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, sizeof(u32)));
-        std::lock_guard<std::mutex> el(ctx->enqueue_mu);
-        ctx->seq_host_valid = false;
-        fail = RGB_E_STATE;
-      }
+      s.used_train = false;
+      ctx->trains_in_flight.fetch_sub(1, std::memory_order_release);
     }
     if (fail) {
-      s.used_train = false; s.enqueue_error = 0;
+      if (s.used_train) { s.used_train = false; ctx->trains_in_flight.fetch_sub(1, std::memory_order_release); }
+      s.enqueue_error = 0;
       ctx->tail = (ctx->tail + 1) % ctx->ring_size;
       ctx->in_flight.fetch_sub(1, std::memory_order_release);
       s.state.store(0, std::memory_order_release);
@@ -736,6 +890,11 @@ int rgb_peek(rgb_ctx *ctx, uint32_t *n_out, uint32_t *n_rpc_out) {
   rgb_slot &s = ctx->ring_mem[ctx->tail];
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   HIPCHK(ctx, hipEventSynchronize(s.done));
+  if (!s.enqueue_error && s.used_train && s.h_nrpc[1] != 0) {   /* a failed train launch: repaired before it is sized */
+    std::lock_guard<std::mutex> el(ctx->enqueue_mu);
+    int rc = settle_trains(ctx);
+    if (rc) return rc;
+  }
   const u32 n_rpc = (s.n && !s.enqueue_error) ? s.h_nrpc[0] : 0u;
   if (n_out) *n_out = s.n;
   if (n_rpc_out) *n_rpc_out = n_rpc;
@@ -837,30 +996,30 @@ uint32_t rgb_train_bucket(uint32_t kind, uint32_t flags, uint32_t server, uint32
 }
 
 static int train_scratch(rgb_ctx *ctx) {
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   if (!ctx->d_train_ctl) {
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_train_ctl, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
     HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
   }
   if (!ctx->d_seq_cnt) HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq_cnt, (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS));
   if (ctx->xcc_state == 0) {
-    /* where do blocks b mod 8 = x run?  A train is only coherent when that is ONE XCD per shard */
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, RGB_TRAIN_SHARDS * sizeof(u32), ctx->stream));
+    /* which XCCs does the device have?  A train block serves the shard(s) of the XCC it runs on (placement by
+     * construction); the ids must be 0 .. n-1 with n dividing the 8 shards */
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, sizeof(u32), ctx->stream));
     {
-      int rc = rgb_launch_train_calibrate(ctx->d_train_ctl + 1, ctx->stream);   /* ONE launch: the rotation is per launch */
+      int rc = rgb_launch_train_calibrate(ctx->d_train_ctl + 1, ctx->stream);
       if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
     }
-    u32 w[RGB_TRAIN_SHARDS];
-    HIPCHK(ctx, hipMemcpyAsync(w, ctx->d_train_ctl + 1, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+    u32 w = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&w, ctx->d_train_ctl + 1, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, RGB_TRAIN_SHARDS * sizeof(u32), ctx->stream));
-    ctx->xcc_state = 1;
-    ctx->xcc_map = 0;
-    for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) {
-      if (w[x] == 0 || (w[x] & (w[x] - 1u)) != 0 || w[x] > 0x8000u) { ctx->xcc_state = -1; break; }
-      u32 id = 0;
-      while (!((w[x] >> id) & 1u)) ++id;
-      ctx->xcc_map |= id << (4u * x);
-    }
+    u32 n = 0;
+    while ((w >> n) & 1u) ++n;
+    ctx->train_blocks = rgb_train_resident_blocks(ctx->dev.n_members);
+    const bool ok = n >= 1 && n <= RGB_TRAIN_SHARDS && (n & (n - 1u)) == 0 && (w >> n) == 0 &&
+                    ctx->train_blocks >= RGB_TRAIN_SHARDS;
+    ctx->n_xcc = ok ? n : 0;
+    ctx->xcc_state = ok ? 1 : -1;
   }
   return ctx->xcc_state == 1 ? RGB_OK : RGB_E_UNSUPPORTED;
 }
@@ -869,8 +1028,11 @@ int rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t 
   if (!ctx || !out || (!bucket_counts && n_ticks)) return RGB_E_INVAL;
   *out = nullptr;
   if (!ctx->registered) return RGB_E_STATE;
-  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-  int rc = train_scratch(ctx);
+  int rc;
+  {
+    std::lock_guard<std::mutex> tl(ctx->train_mu);          /* the one-off calibration uses the stream */
+    rc = train_scratch(ctx);
+  }
   if (rc) return rc;
   rgb_train_plan *p = new (std::nothrow) rgb_train_plan();
   if (!p) return RGB_E_NOMEM;
@@ -951,7 +1113,7 @@ int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t firs
     int rc = rgb_launch_train(ctx->dev, (const rgb_msg *)d_msgs + off, (const unsigned char *)d_stamps + off,
                               tick_stride, plan->d_ticks + t, plan->d_rows + (size_t)t * (plan->bpt / RGB_TRAIN_SHARDS), n,
                               plan->bpt, (rgb_decision *)d_decisions + off,
-                              (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, st);
+                              (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, ctx->n_xcc, ctx->train_blocks, st);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
   return RGB_OK;
@@ -962,7 +1124,7 @@ int rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard) 
   if (flags_out) *flags_out = 0;
   if (xcc_of_shard)
     for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x)
-      xcc_of_shard[x] = ctx->xcc_state == 1 ? (ctx->xcc_map >> (4u * x)) & 0xFu : 0xFFFFFFFFu;
+      xcc_of_shard[x] = ctx->xcc_state == 1 ? x % ctx->n_xcc : 0xFFFFFFFFu;
   if (!ctx->d_train_ctl) return RGB_OK;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1001,6 +1163,7 @@ int rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out) {
   if (!ctx->registered) return RGB_E_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   rgb_stream_turn turn(ctx);                               /* d_rows is shared */
+  if (turn.rc) return turn.rc;
   int rc = rgb_snapshot_device(ctx, ctx->d_rows, ctx->stream);
   if (rc) return rc;
   u32 g = ctx->dev.n_servers / ctx->dev.n_members;
@@ -1016,6 +1179,7 @@ int rgb_state_checksum(rgb_ctx *ctx, uint32_t first, uint32_t n, uint64_t *out) 
   if ((uint64_t)first + n > ctx->dev.n_servers) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   rgb_stream_turn turn(ctx);                               /* d_sums is shared */
+  if (turn.rc) return turn.rc;
   int rc = rgb_launch_checksum(ctx->dev, first, n, ctx->d_sums, ctx->stream);
   if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   std::vector<u64> sums(n);
@@ -1036,6 +1200,14 @@ int rgb_debug_read(rgb_ctx *ctx, uint64_t *out, uint32_t n_words) {
   HIPCHK(ctx, hipMemcpy(out, ctx->dev.dbg_buf, (size_t)n_words * sizeof(u64), hipMemcpyDeviceToHost));
   return RGB_OK;
 }
+
+/* fail-safe tests and diagnostics (not part of the boundary): the next train batch of rgb_submit gets a fault
+ * (1 = a stamp that never comes up, 2 = two messages bucketed under each other's shard); the batches whose failed
+ * train launch the engine repaired so far */
+void rgb_debug_inject_train_fault(rgb_ctx *ctx, uint32_t fault) {
+  if (ctx) ctx->inject_fault.store(fault, std::memory_order_relaxed);
+}
+uint32_t rgb_train_recoveries(const rgb_ctx *ctx) { return ctx ? ctx->n_train_recoveries.load(std::memory_order_relaxed) : 0; }
 
 int rgb_synchronize(rgb_ctx *ctx) {
   if (!ctx) return RGB_E_INVAL;

@@ -115,7 +115,9 @@ static inline unsigned rgb_class_of_kind(unsigned kind) { return rgb_kind_rank(k
 #define RGB_N_BUCKETS ((RGB_N_CLASSES + 1u) * RGB_TRAIN_SHARDS * 2u)   /* 256 */
 #define RGB_TRAIN_ERR_PLACEMENT 1u   /* two blocks of one shard ran on different XCDs                    */
 #define RGB_TRAIN_ERR_SPIN      2u   /* a wavefront's dependencies did not commit within the spin bound */
-#define RGB_TRAIN_CTL_WORDS (1u + RGB_TRAIN_SHARDS)   /* sticky error flags | calibration: XCC bit mask of every shard */
+/* control words of a train launch: 0 sticky error flags | 1..7 calibration scratch | 8..15 blocks arrived per XCC |
+ * 32 (1 + x): the ticket counter of shard x, one 128-byte line each (rgb_train_kernel) */
+#define RGB_TRAIN_CTL_WORDS (32u * (1u + RGB_TRAIN_SHARDS))
 static inline __host__ __device__ unsigned rgb_shard_of_server(unsigned server, unsigned n_members) {
   return (server / n_members) & (RGB_TRAIN_SHARDS - 1u);
 }
@@ -187,19 +189,21 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
 /* d_scratch: rgb_synth_scratch_words(groups) u32; d_bucket_counts (may be NULL): RGB_N_BUCKETS u32 of this tick */
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
                      u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream);
-/* ticks [0, n_ticks) of d_plan in one launch (n_ticks <= RGB_TRAIN_MAX_TICKS); bpt = blocks per tick (multiple of
- * RGB_TRAIN_SHARDS); tick_stride = 0: tick t starts at d_plan[t].msg_base and a message's rpc slots follow its index
- * in the whole buffer (the sub-tick rounds of one rgb_submit); d_row_tab: bpt / RGB_TRAIN_SHARDS words per tick;
- * d_stamps: one byte per message, laid out like d_msgs; d_rpcs (may be NULL): rpc_ring tick-sized
- * regions, tick t uses region t mod rpc_ring; rgb_rpc.msg_index = index_base + t * tick_stride + i; d_ctl: word 0 =
- * sticky error flags, word 1 = this launch's placement rotation mask (zeroed here) */
+/* ticks [0, n_ticks) of d_plan in one launch (n_ticks <= RGB_TRAIN_MAX_TICKS) of n_blocks persistent blocks
+ * (rgb_train_resident_blocks) on a device of n_xcc XCCs (1, 2, 4 or 8: a block serves the shard of the XCC it runs
+ * on); bpt = RGB_TRAIN_SHARDS x the rows per tick of d_row_tab; tick_stride = 0: tick t starts at d_plan[t].msg_base
+ * and a message's rpc slots follow its index in the whole buffer (the sub-tick rounds of one rgb_submit); d_stamps:
+ * one byte per message, laid out like d_msgs; d_rpcs (may be NULL): rpc_ring tick-sized regions, tick t uses region
+ * t mod rpc_ring; rgb_rpc.msg_index = index_base + t * tick_stride + i; d_ctl: RGB_TRAIN_CTL_WORDS words, word 0 =
+ * sticky error flags, the rest per-launch counters (zeroed here) */
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
-                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, void *stream);
+                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream);
+u32 rgb_train_resident_blocks(unsigned n_members);
 /* stamps of the n messages of one tick from the running counters d_seq_cnt (ticks in train order) */
 int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt,
                          unsigned char *d_stamps, void *stream);
-/* d_out: RGB_TRAIN_SHARDS u32, zeroed by the caller: bit k of word x = a block with blockIdx mod 8 = x ran on XCC k */
+/* d_out: one u32, zeroed by the caller: bit k = a block of the launch ran on XCC k */
 int rgb_launch_train_calibrate(u32 *d_out, void *stream);
 /* host: the plan of one tick from its bucket counts (uint32[RGB_N_BUCKETS]); returns the tick's rows; row_tab (may be
  * NULL: count only) receives them when they fit row_cap */
@@ -209,5 +213,9 @@ int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u3
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream);
 int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream);
 int rgb_launch_checksum(const rgb_dev &dev, u32 first, u32 n, u64 *d_out, void *stream);
+/* undo log: rgb_undo_pieces(dev) 16-byte pieces per server (every row + the sequence byte) of the n servers d_ids
+ * name, saved to (restore = 0) or written back from (restore = 1) d_undo */
+u32 rgb_undo_pieces(const rgb_dev &dev);
+int rgb_launch_undo(const rgb_dev &dev, const u32 *d_ids, u32 n, void *d_undo, u32 restore, void *stream);
 
 #endif

@@ -2313,6 +2313,37 @@ __device__ __forceinline__ u32 rgb_xcc_id() {
 #endif
 #endif
 
+/* Persistent train launches: a wavefront takes the next row of its shard from the shard's ticket counter: one
+ * returning atomic by lane 0.  rgb_take_ticket only ISSUES it (the raw value is valid in lane 0); rgb_ticket_value
+ * brings it to the whole wavefront where it is consumed, so the atomic's round trip overlaps whatever is issued in
+ * between.  The counters of different shards are 128 bytes apart and each is only ever touched from one XCD. */
+__device__ __forceinline__ u32 rgb_take_ticket(u32 *ctr, const u32 *err) {
+  u32 v = 0;
+#ifdef RGB_HOST_EMULATION
+  if (threadIdx.x == 0) v = atomicAdd(ctr, 1u);
+  if (threadIdx.x == 1) v = *err;
+#else
+  if (threadIdx.x == 0) v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  /* lane 1 of the same register: the launch's error word (a failed launch drains instead of computing on) */
+  if (threadIdx.x == 1) v = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  return v;
+}
+__device__ __forceinline__ u32 rgb_ticket_value(u32 raw) {
+#ifdef RGB_HOST_EMULATION
+  return __shfl(raw, 0, 64);
+#else
+  return (u32)__builtin_amdgcn_readfirstlane((int)raw);
+#endif
+}
+__device__ __forceinline__ u32 rgb_ticket_err(u32 raw) {
+#ifdef RGB_HOST_EMULATION
+  return __shfl(raw, 1, 64);
+#else
+  return (u32)__builtin_amdgcn_readlane((int)raw, 1);
+#endif
+}
+
 /* One wavefront's slice of one class: `cnt` (<= SL) consecutive messages starting at msgs[base].  This is the whole
  * hot path -- record staging, cooperative state fetch, fast paths, clause code, commit, decision store -- shared by
  * the per-tick class kernel (TR = false) and the multi-tick train kernel (TR = true).
@@ -2329,12 +2360,14 @@ __device__ __forceinline__ u32 rgb_xcc_id() {
  *      value sees the whole commit.
  * A launch carries at most 255 ticks, so the values a server goes through within one launch are distinct. */
 template <int N, bool TR>
-__device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *io, const int cls, const u32 base,
+__device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *io, const int cls, const u32 base,
                                                const u32 cnt, const u32 SL, const rgb_msg *__restrict__ msgs,
                                                rgb_decision *__restrict__ dec, rgb_rpc *__restrict__ rpcs,
                                                u32 rpc_slot_base, u32 msg_index_base, u32 *__restrict__ ctl,
-                                               const unsigned char *__restrict__ stamps) {
-  const u32 lane = threadIdx.x;
+                                               const unsigned char *__restrict__ stamps,
+                                               u32 *__restrict__ ticket_ctr = nullptr, u32 *next_ticket = nullptr,
+                                               u32 shard = 0, u32 lane_in = 0) {
+  const u32 lane = TR ? lane_in : (u32)threadIdx.x;     /* the persistent loop hands in an opaque copy */
 #ifdef RGB_PROFILE
   u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl[4] = {0, 0, 0, 0};
   if (!TR && RGB_KNOB(dev, 16u)) t0 = wall_clock64();
@@ -2391,6 +2424,12 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #else
   if (TR) {
 #endif
+    /* 0. every message of the slice belongs to the shard (= the XCD) this wavefront serves: a tick that is not in
+     * bucket order must not be computed on another XCD's lines */
+    if (__ballot(has_srv && rgb_shard_of_server(sv, (unsigned)N) != shard) != 0ull) {
+      if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
+      return false;
+    }
     /* 1. dependencies: this server's previous message -- an earlier tick of this launch -- has committed */
     seqp = dev.seq + rgb_seq_index(has_srv ? sv : 0u, dev.n_members, dev.seq_stride);
     need = has_srv ? (unsigned)stamps[base + lane] : 0u;
@@ -2423,7 +2462,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #endif
       if (give_up) {                                      /* uniform: the decisions of this slice stay unwritten */
         if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_SPIN);
-        return;
+        return false;
       }
     }
   }
@@ -2544,6 +2583,11 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     asm volatile("" ::: "memory");
 #endif
     if (has_srv && seqp != nullptr) *seqp = (unsigned char)(need + 1u);
+    /* persistent train: the wavefront's NEXT row is requested now -- behind the publish (the atomic's return must not
+     * sit in front of the sequence bytes) and under the decision stores; rgb_train_kernel consumes it at the top of
+     * its loop.  Not earlier: a ticket held while this slice runs would start its row a whole wavefront life late,
+     * and the rows that depend on it one tick later would find it uncommitted */
+    if (ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
   }
   RGB_TT(5);
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
@@ -2554,7 +2598,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
   }
   lds_barrier();
-  if (!TR && RGB_KNOB(dev, 2u)) return;
+  if (!TR && RGB_KNOB(dev, 2u)) return true;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -2590,6 +2634,7 @@ __device__ __forceinline__ void rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     }
   }
 #endif
+  return true;
 }
 
 template <int N>
@@ -2634,71 +2679,123 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
  * orders two messages of one server is the server's sequence byte (rgb_tick_slice).
  *
  * Coherence: the per-XCD L2s are not coherent with each other, so everything that touches a server must run on ONE
- * XCD for the life of the launch.  Servers are sharded by group (shard = group mod 8), every tick's messages are
- * ordered by (class, shard) -- rgb_synth / the plan carry the per-shard offsets -- and block b of the grid serves
- * shard b mod 8: the dispatcher deals the blocks of a launch round robin over the XCDs, block b on XCD (b + r) mod 8
- * with r fixed per launch (observed behaviour, not a contract -- so it is CHECKED: rgb_train_calibrate_kernel tells
- * once per context whether the device behaves like that at all, and in every launch one block in 64 per shard
- * records (XCC id - shard) mod 8 and fails the launch with RGB_TRAIN_ERR_PLACEMENT when it is not the value the others
- * saw, instead of computing on stale lines).  Within an XCD the L2 is the
+ * XCD for the life of the launch.  Servers are sharded by group (shard = group mod 8) and every tick's messages are
+ * ordered by (class, shard) -- rgb_synth / the plan carry the per-shard offsets.  Within an XCD the L2 is the
  * coherence point: state stores are plain (write-through L1, line kept in the L2), state loads are L2-served.
  *
- * Progress: a wavefront only ever waits for messages of EARLIER ticks, whose blocks come earlier in the grid; blocks
- * are dispatched in order per XCD, so whatever a resident wavefront waits for is resident or done.  The poll is
- * bounded all the same (RGB_TRAIN_ERR_SPIN).
+ * PERSISTENT wavefronts, placement by construction (round 4).  The grid is as many blocks as the device holds at
+ * once; a block reads the id of the XCD it runs on (HW_REG_XCC_ID) and serves THAT shard for its whole life: it takes
+ * the rows of its shard one by one from the shard's ticket counter (ctl) until they run out.  Nothing depends on how
+ * the dispatcher deals blocks to XCDs any more (round 3 assumed round robin and checked one block in 64), every
+ * wavefront slot is in use until the launch drains (the in-order round-robin dispatch of one block per slice left
+ * ~15 % of the slots empty whenever one XCD was full), and a slice costs no block start.  Every lane checks that its
+ * message's server belongs to the block's shard (RGB_TRAIN_ERR_PLACEMENT otherwise: a mis-bucketed tick must not be
+ * computed on another XCD's lines).
  *
- * Block b: tick t = b / bpt, j = b mod bpt, shard x = j mod 8, row = j / 8; row_tab maps the row to (class, slice of
- * the class) -- the classes interleaved by relative position, rgb_train_make_tick -- and plan[t] the (class, shard)
- * pair to its message range.  Surplus blocks (rows past the tick's last, slices past a shard's count) exit at once. */
+ * Progress: rows are numbered tick-major per shard and tickets are handed out in order, so a wavefront only ever
+ * waits for rows with SMALLER tickets -- taken by wavefronts that are running (a wavefront holds one ticket at a
+ * time and takes the next only after it has published).  The poll is bounded all the same (RGB_TRAIN_ERR_SPIN), and
+ * after any error the wavefronts stop taking rows (the error word travels with every ticket).
+ *
+ * Ticket k of shard x: tick t = the tick whose rows contain k (n_rows per tick in the plan), row = k - rows before;
+ * row_tab maps the row to (class, slice of the class) -- the classes interleaved by relative position,
+ * rgb_train_make_tick -- and plan[t] the (class, shard) pair to its message range.  A slice past the shard's count
+ * (the fullest shard sets a class's rows) costs one more ticket. */
 /* Three wavefronts per SIMD (168 registers: no spills; four need 128 and spill ~120): a train's throughput is
  * resident wavefronts / wavefront life, and the spills' scratch round trips sit on the clause code's dependency chain
  * -- 4 x 128 measured 24-25 us per tick, 3 x 168 19-20 */
 #ifndef RGB_TRAIN_MIN_WAVES
 #define RGB_TRAIN_MIN_WAVES(N) 3
 #endif
+#define RGB_TRAIN_CTL_ARRIVE 8u     /* ctl words 8..15: blocks arrived per XCC (devices with fewer XCCs than shards) */
+#define RGB_TRAIN_CTL_TICKET 32u    /* ctl word 32 (1 + x): next row of shard x (one 128-byte line per shard)         */
+/* the kernel's one argument.  The persistent loop re-reads it from the kernarg segment through a pointer the compiler
+ * cannot see through, every iteration: hoisted out of the loop, the fields (and everything derived from them and
+ * from the lane id, for fifteen class paths) stay live across the whole slice -- 370 spilled SGPRs and 209 spilled
+ * VGPRs at first try */
+struct rgb_train_args {
+  rgb_dev dev;
+  const rgb_msg *msgs;
+  const unsigned char *stamps;
+  const rgb_train_tick *plan;
+  const u32 *row_tab;
+  rgb_decision *dec;
+  rgb_rpc *rpcs;
+  u32 *ctl;
+  u32 tick_stride, rpt, n_ticks, rpc_ring, index_base, n_xcc;
+};
 template <int N>
-__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(
-    rgb_dev dev, const rgb_msg *__restrict__ msgs, const unsigned char *__restrict__ stamps, u32 tick_stride,
-    const rgb_train_tick *__restrict__ plan, const u32 *__restrict__ row_tab, u32 bpt, rgb_decision *__restrict__ dec,
-    rgb_rpc *__restrict__ rpcs, u32 rpc_ring, u32 index_base, u32 *__restrict__ ctl) {
+__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(rgb_train_args args) {
   /* records, then hot rows; a leader-side slice: 32 hot rows | 32 peers rows | the first line of 32 run tables
    * (12 KiB: twelve wavefronts per CU -- three per SIMD, what the registers allow -- hold 144 of the 160 KiB) */
   __shared__ ulonglong2 io[(RGB_TRAIN_RUNS_LDS && rgb_class_slice(1, (unsigned)N) == 32u) ? 12 * RGB_TICK_BLOCK
                                                                                          : RGB_TICK_BLOCK * RGB_HOT_SLOT];
-  const u32 t = blockIdx.x / bpt, j = blockIdx.x - t * bpt;
-  const u32 x = j & (RGB_TRAIN_SHARDS - 1u), row = j / RGB_TRAIN_SHARDS;
-  const rgb_train_tick *p = plan + t;
-  if (row >= p->n_rows) return;
-  const u32 e = row_tab[(size_t)t * (bpt / RGB_TRAIN_SHARDS) + row];
-  const int cls = (int)(e >> 24);
-  const u32 off = p->off[cls][x], ncls = p->cnt[cls][x];
+  /* the shard this block serves: the XCD it runs on */
+  u32 x;
+  {
+    const u32 n_xcc = args.n_xcc;
+    const u32 xcc = rgb_xcc_id() & (RGB_TRAIN_SHARDS - 1u);
+    if (n_xcc >= RGB_TRAIN_SHARDS) x = xcc;
+    else {
+      /* fewer XCCs than shards (a partitioned device; the CPU emulation has one): the blocks of an XCC take its
+       * shards xcc, xcc + n_xcc, .. in arrival order -- the grid holds at least 8 / n_xcc blocks per XCC */
+      u32 a = 0;
+      if (threadIdx.x == 0) a = atomicAdd(args.ctl + RGB_TRAIN_CTL_ARRIVE + (xcc & (n_xcc - 1u)), 1u);
+      a = rgb_ticket_value(a);
+      x = (xcc & (n_xcc - 1u)) + n_xcc * (a % (RGB_TRAIN_SHARDS / n_xcc));
+    }
+  }
+  u32 raw = rgb_take_ticket(args.ctl + RGB_TRAIN_CTL_TICKET * (1u + x), args.ctl);
+  u32 t = 0, cum = 0;
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
-  const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
-  const u32 lbase = (e & 0xFFFFFFu) * SL;
-  if (lbase >= ncls) return;
-  const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
-#ifndef RGB_HOST_EMULATION
-  /* placement check, sampled (one block in 64 per shard: an atomic per block costs more than the tick) and off the
-   * critical path: (XCC id - shard) mod 8 -- the rotation of this launch's round robin -- must be ONE value */
-  u32 rot_seen = 0, rot_bit = 0;
-  const bool sampled = (row & 63u) == 0u && threadIdx.x == 0;
-  if (sampled) { rot_bit = 1u << ((rgb_xcc_id() - x) & (RGB_TRAIN_SHARDS - 1u)); rot_seen = atomicOr(ctl + 1, rot_bit); }
+  for (;;) {
+#ifdef RGB_HOST_EMULATION
+    const rgb_train_args *A = &args;
+    u32 lane = threadIdx.x;
+#else
+    const rgb_train_args *A = (const rgb_train_args *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(A));
+    u32 lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
 #endif
-  /* ticks a fixed stride apart with a ring of rpc regions (device-resident streams), or -- tick_stride = 0 -- packed
-   * one behind the other, every message owning the rpc slots of its index in the whole buffer (rgb_submit's rounds) */
-  const size_t toff = tick_stride ? (size_t)t * tick_stride : (size_t)p->msg_base;
-  rgb_rpc *rp = rpcs ? rpcs + (tick_stride ? (size_t)(t % rpc_ring) * tick_stride : toff) * (N > 1 ? N - 1 : 1) : nullptr;
-  rgb_tick_slice<N, true>(dev, io, cls, off + lbase, cnt, SL, msgs + toff, dec + toff, rp, 0, index_base + (u32)toff,
-                          ctl, stamps + toff);
-#ifndef RGB_HOST_EMULATION
-  if (sampled && ((rot_seen | rot_bit) & ((rot_seen | rot_bit) - 1u)) != 0u) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
-#endif
+    const u32 k = rgb_ticket_value(raw);
+    if (rgb_ticket_err(raw) != 0u) break;                 /* the launch has failed: drain */
+    /* the tick of row k (tickets only grow: t and the rows before it are carried along) */
+    const rgb_train_tick *plan = A->plan;
+    const u32 n_ticks = A->n_ticks;
+    u32 nr = 0;
+    while (t < n_ticks) {
+      nr = plan[t].n_rows;
+      if (k - cum < nr) break;
+      cum += nr; ++t;
+    }
+    if (t >= n_ticks) break;
+    const rgb_train_tick *p = plan + t;
+    const u32 e = A->row_tab[(size_t)t * A->rpt + (k - cum)];
+    const int cls = (int)(e >> 24);
+    const u32 off = p->off[cls][x], ncls = p->cnt[cls][x];
+    const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
+    const u32 lbase = (e & 0xFFFFFFu) * SL;
+    u32 *const tk = A->ctl + RGB_TRAIN_CTL_TICKET * (1u + x);
+    if (lbase >= ncls) { raw = rgb_take_ticket(tk, A->ctl); continue; }
+    const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
+    /* ticks a fixed stride apart with a ring of rpc regions (device-resident streams), or -- tick_stride = 0 -- packed
+     * one behind the other, every message owning the rpc slots of its index in the whole buffer (rgb_submit's rounds) */
+    const u32 tick_stride = A->tick_stride;
+    const size_t toff = tick_stride ? (size_t)t * tick_stride : (size_t)p->msg_base;
+    rgb_rpc *rp = A->rpcs ? A->rpcs + (tick_stride ? (size_t)(t % A->rpc_ring) * tick_stride : toff) * (N > 1 ? N - 1 : 1) : nullptr;
+    lds_barrier();                                        /* the previous slice is done with the staging area */
+    raw = 0;
+    if (!rgb_tick_slice<N, true>(A->dev, io, cls, off + lbase, cnt, SL, A->msgs + toff, A->dec + toff, rp, 0,
+                                 A->index_base + (u32)toff, A->ctl, A->stamps + toff, tk, &raw, x, lane))
+      break;
+  }
 }
 
-/* once per context: out[x] |= 1 << (XCC id of a block with blockIdx mod 8 = x) over one launch.  The host accepts
- * the device when every entry has exactly one bit (two XCDs for one shard is what must not happen) */
+/* once per context: out[0] |= 1 << (XCC id) over one launch that fills the device: the set of XCC ids blocks run on.
+ * The host accepts ids 0 .. n-1 with n = 1, 2, 4 or 8 (a block serves the shards congruent to its XCC id mod n) */
 __global__ void rgb_train_calibrate_kernel(u32 *__restrict__ out) {
-  if (threadIdx.x == 0) atomicOr(out + (blockIdx.x & (RGB_TRAIN_SHARDS - 1u)), 1u << rgb_xcc_id());
+  if (threadIdx.x == 0) atomicOr(out, 1u << rgb_xcc_id());
 }
 
 /* Sequence stamps of a train: seq_cnt[i] = the value server (at sequence index i) will hold when the next message
@@ -3248,6 +3345,34 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   out[k] = x;
 }
 
+/* Undo log of a batch (rgb_submit's fail-safe, rgb_api.hip): every row of the servers ids[0..n) -- hot, peers, run
+ * table, cond, qry, sequence byte -- copied to undo (restore = 0) or back (restore = 1), one lane per 16-byte piece */
+__host__ __device__ __forceinline__ u32 rgb_undo_pieces_of(const rgb_dev &dev) {
+  return RGB_HOT_WORDS / 2u + dev.peer_stride / 2u + dev.max_runs + 2u + RGB_QRY_WORDS / 2u + 1u;
+}
+__global__ void rgb_undo_kernel(rgb_dev dev, const u32 *__restrict__ ids, u32 n, ulonglong2 *__restrict__ undo, u32 restore) {
+  const u32 P = rgb_undo_pieces_of(dev);
+  const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 i = (u32)(idx / P), p = (u32)(idx - (u64)i * P);
+  if (i >= n) return;
+  const u32 sv = ids[i];
+  if (sv >= dev.n_servers) return;
+  ulonglong2 *slot = undo + (size_t)i * P + p;
+  u32 q = p;
+  ulonglong2 *row;
+  if (q < RGB_HOT_WORDS / 2u) row = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)sv * RGB_HOT_WORDS) + q;
+  else if ((q -= RGB_HOT_WORDS / 2u) < dev.peer_stride / 2u) row = reinterpret_cast<ulonglong2 *>(dev.peers + (size_t)sv * dev.peer_stride) + q;
+  else if ((q -= dev.peer_stride / 2u) < dev.max_runs) row = reinterpret_cast<ulonglong2 *>(dev.runs + (size_t)sv * dev.max_runs * 2u) + q;
+  else if ((q -= dev.max_runs) < 2u) row = reinterpret_cast<ulonglong2 *>(dev.cond + (size_t)sv * 4u) + q;
+  else if ((q -= 2u) < RGB_QRY_WORDS / 2u) row = reinterpret_cast<ulonglong2 *>(dev.qry + (size_t)sv * RGB_QRY_WORDS) + q;
+  else {
+    unsigned char *b = dev.seq + rgb_seq_index(sv, dev.n_members, dev.seq_stride);
+    if (restore) *b = (unsigned char)slot->x; else *slot = make_ulonglong2((u64)*b, 0);
+    return;
+  }
+  if (restore) *row = *slot; else *slot = *row;
+}
+
 }  // namespace
 
 #define RGB_BLOCK 256
@@ -3397,20 +3522,52 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
   return total;
 }
 
+/* blocks a persistent train launch should have: every wavefront slot of the device (occupancy x compute units) */
+u32 rgb_train_resident_blocks(unsigned n_members) {
+#ifdef RGB_HOST_EMULATION
+  (void)n_members;
+  return RGB_TRAIN_SHARDS;
+#else
+  int device = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&device) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 0;
+  hipError_t e = hipErrorInvalidValue;
+#define LAUNCH(NN)                                                                                          \
+  case NN:                                                                                                  \
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rgb_train_kernel<NN>, RGB_TICK_BLOCK, 0);     \
+    break;
+  switch (n_members) {
+    RGB_LAUNCH_ALL_N
+    default: return 0;
+  }
+#undef LAUNCH
+  if (e != hipSuccess || per_cu <= 0) return 0;
+  return (u32)per_cu * (u32)cus;
+#endif
+}
+
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
-                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, void *stream) {
+                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream) {
   if (n_ticks == 0 || bpt == 0) return 0;
   if (bpt % RGB_TRAIN_SHARDS || n_ticks > RGB_TRAIN_MAX_TICKS) return -1;
+  if (n_xcc == 0 || n_xcc > RGB_TRAIN_SHARDS || (n_xcc & (n_xcc - 1u)) != 0 || n_blocks < RGB_TRAIN_SHARDS) return -1;
   hipStream_t st = (hipStream_t)stream;
-  /* the rotation mask is per launch; the error word (d_ctl[0]) is sticky until rgb_train_status reads it */
-  hipError_t e = hipMemsetAsync(d_ctl + 1, 0, sizeof(u32), st);
+  /* the arrival and ticket counters are per launch; the error word (d_ctl[0]) is sticky until it is read */
+  hipError_t e = hipMemsetAsync(d_ctl + 1, 0, (RGB_TRAIN_CTL_WORDS - 1u) * sizeof(u32), st);
   if (e != hipSuccess) return (int)e;
-  dim3 grid(n_ticks * bpt), block(RGB_TICK_BLOCK);
+  /* never more blocks than rows: a block without a row only costs its ticket */
+  const uint64_t rows = (uint64_t)n_ticks * bpt;
+  dim3 grid((u32)(rows < n_blocks ? rows : n_blocks)), block(RGB_TICK_BLOCK);
+  if (grid.x < RGB_TRAIN_SHARDS) grid.x = RGB_TRAIN_SHARDS;
+  rgb_train_args args;
+  args.dev = dev; args.msgs = d_msgs; args.stamps = d_stamps; args.plan = d_plan; args.row_tab = d_row_tab;
+  args.dec = d_dec; args.rpcs = d_rpcs; args.ctl = d_ctl; args.tick_stride = tick_stride;
+  args.rpt = bpt / RGB_TRAIN_SHARDS; args.n_ticks = n_ticks; args.rpc_ring = rpc_ring ? rpc_ring : 1u;
+  args.index_base = index_base; args.n_xcc = n_xcc;
 #define LAUNCH(NN)                                                                                      \
   case NN:                                                                                              \
-    hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, dev, d_msgs, d_stamps, tick_stride, d_plan,      \
-                       d_row_tab, bpt, d_dec, d_rpcs, rpc_ring ? rpc_ring : 1u, index_base, d_ctl);     \
+    hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, args);                                 \
     break;
   switch (dev.n_members) {
     RGB_LAUNCH_ALL_N
@@ -3428,7 +3585,7 @@ int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsig
 }
 
 int rgb_launch_train_calibrate(u32 *d_out, void *stream) {
-  hipLaunchKernelGGL(rgb_train_calibrate_kernel, dim3(64 * RGB_TRAIN_SHARDS), dim3(64), 0, (hipStream_t)stream, d_out);
+  hipLaunchKernelGGL(rgb_train_calibrate_kernel, dim3(4096), dim3(64), 0, (hipStream_t)stream, d_out);
   return (int)hipGetLastError();
 }
 
@@ -3471,5 +3628,15 @@ int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void
 int rgb_launch_checksum(const rgb_dev &dev, u32 first, u32 n, u64 *d_out, void *stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(rgb_checksum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev, first, n, d_out);
+  return (int)hipGetLastError();
+}
+
+u32 rgb_undo_pieces(const rgb_dev &dev) { return rgb_undo_pieces_of(dev); }
+
+int rgb_launch_undo(const rgb_dev &dev, const u32 *d_ids, u32 n, void *d_undo, u32 restore, void *stream) {
+  if (n == 0) return 0;
+  const u64 lanes = (u64)n * rgb_undo_pieces_of(dev);
+  hipLaunchKernelGGL(rgb_undo_kernel, dim3((u32)((lanes + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream, dev, d_ids, n,
+                     (ulonglong2 *)d_undo, restore);
   return (int)hipGetLastError();
 }
