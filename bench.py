@@ -145,10 +145,18 @@ def run_literal(name, ticks, torch, engine, W, abi, dev, local_rank, reps=3):
                 eng.train_run_device(plan, 0, ticks, d_msgs_t.data_ptr(), d_stamps.data_ptr(), stride, d_dec_t.data_ptr(),
                                      d_rpcs_t.data_ptr(), RING, sptr)
             best_t = None
+            # the train stamps are the PRODUCER's: the host that generated and bucket-sorted the ticks counts the
+            # messages it has sent to every server (what rgb_submit does for a host batch); the sequence bytes of this
+            # fresh engine start at 0 and only trains move them
+            sent = np.zeros(S, dtype=np.uint8)
             for rep in range(reps + 1):                                 # rep 0: the parity pass
                 eng.set_state(0, st0)
-                # the stamps count on from what the servers' sequence bytes hold now (they are never reset)
-                eng.train_stamp_device(d_msgs_t.data_ptr(), d_stamps.data_ptr(), stride, counts, sptr)
+                h_st = np.zeros(ticks * stride, dtype=np.uint8)
+                for t, m in enumerate(msgs):
+                    srv = m["server"][perms[t]]
+                    h_st[t * stride:t * stride + len(m)] = sent[srv]
+                    sent[srv] += 1                                       # one message per server per tick; wraps mod 256
+                d_stamps.copy_(torch.from_numpy(h_st))
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
@@ -226,6 +234,11 @@ def main():
                          "sequence stamps instead of kernel boundaries); tick: one class-kernel launch per tick")
     ap.add_argument("--snapshot-every", type=int, default=0,
                     help="leaderboard period in ticks (default 16 = SURVEY 8(d) config 4); a train covers one period")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE configs[3] as written: 262 144 groups x 5 in TOTAL, hashed (rgb_route / splitmix64) over "
+                         "the --gpus ranks -- strong scaling, N=1 holds all of them; the leaderboard all-gather every 16 "
+                         "ticks goes through the C entry point (rgb_leaderboard_allgather)")
+    ap.add_argument("--total-groups", type=int, default=262144, help="--config4: groups over all ranks")
     ap.add_argument("--literal-ticks", type=int, default=32,
                     help="ticks of each literal SURVEY 8(d) configuration (configs 2, 3 and 5; host-generated, every "
                          "tick oracle-checked, then replayed and timed on the device); 0 = skip (rank 0, N=1 only)")
@@ -265,12 +278,21 @@ def main():
         SNAPSHOT_EVERY = args.snapshot_every
     use_train = args.launch == "train" and not args.generic_kernel
     G, N = args.groups, args.members
+    if args.config4 and args.steps == 1000:
+        args.steps, args.warmup = 192, 16          # 1.3 M servers: 84 MB per tick of messages, as much of decisions
+    if args.config4:
+        # configs[3]: a FIXED population hashed over the ranks (strong scaling); this rank's share of the global ids
+        my_groups = shard.local_group_ids(args.total_groups, world, rank)
+        G = len(my_groups)
+        args.no_cpu_baseline = args.no_host_path = True
+        args.literal_ticks = 0
+    else:
+        # this rank's shard of the global group-id space (hash partition), 65 536 per rank
+        my_groups = shard.local_group_ids(G * world, world, rank, per_rank=G)
     S = G * N
     K, Wm = args.steps, args.warmup
     T = Wm + K
     NK = abi.N_KINDS
-    # this rank's shard of the global group-id space (hash partition)
-    my_groups = shard.local_group_ids(G * world, world, rank, per_rank=G)
     seed = (args.seed ^ (rank * 0x9E3779B97F4A7C15)) & ((1 << 64) - 1)
 
     eng = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=2, ring_capacity=1024)
@@ -303,10 +325,20 @@ def main():
     torch.cuda.synchronize()
     d_kc.zero_()
     st_aged = eng.get_state() if A else st0
-    # ---- pass 1 (untimed): generate tick A+t from the device state, then apply it ----
+    # ---- pass 1 (untimed): generate tick A+t from the device state, then apply it.  The generator is the PRODUCER
+    # of the stream: it writes every tick in bucket order and, beside every message, the train stamp -- its own count
+    # of the messages it has addressed to that server (what rgb_submit's bucketing pass does for a host batch).  No
+    # pass over the finished stream is needed before the timed replay ----
+    d_stamps = torch.zeros(T * S, dtype=torch.uint8, device=dev) if use_train else None
+    old_build = not hasattr(engine.lib(), "rgb_synth_tick_stamped_device")     # RGB_LIB=<round-3 build>: A/B timing only
     for t in range(T):
-        eng.synth_tick_buckets_device(seed, A + t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
-                                      d_n.data_ptr() + t * 4, d_bc.data_ptr() + t * engine.TRAIN_BUCKETS * 4, sptr)
+        if old_build:
+            eng.synth_tick_buckets_device(seed, A + t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
+                                          d_n.data_ptr() + t * 4, d_bc.data_ptr() + t * engine.TRAIN_BUCKETS * 4, sptr)
+        else:
+            eng.synth_tick_stamped_device(seed, A + t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
+                                          d_n.data_ptr() + t * 4, d_bc.data_ptr() + t * engine.TRAIN_BUCKETS * 4,
+                                          d_stamps.data_ptr() + t * S if use_train else 0, sptr)
         eng.synth_apply_tick_device(d_msgs.data_ptr() + t * tick_bytes, S, d_dec.data_ptr() + t * tick_bytes,
                                     d_rpcs.data_ptr(), sptr)
     torch.cuda.synchronize()
@@ -347,7 +379,8 @@ def main():
 
     # ---- train mode: the plan of every tick (host) and the sequence stamps of the whole stream, counted from
     # the aged state (device, untimed: the order rgb_submit's bucketing would establish on the host path) ----
-    plan = d_dec2 = d_stamps = None
+    plan = d_dec2 = None
+    plan_host_ms = None
     if use_train:
         buckets = d_bc.cpu().numpy().reshape(T, engine.TRAIN_BUCKETS).astype(np.uint32)
         assert np.array_equal(buckets.sum(axis=1), counts)
@@ -357,9 +390,10 @@ def main():
             for kv in os.environ["RGB_TRAIN_LEAD"].split(","):
                 c, v = kv.split(":"); lead[int(c)] = float(v)
             engine.lib().rgb_train_set_lead(lead.ctypes.data_as(C.c_void_p))
-        plan = eng.train_plan(buckets)
+        t_plan = time.perf_counter()
+        plan = eng.train_plan(buckets)                                        # host: 256 bucket counts per tick -> row order
+        plan_host_ms = (time.perf_counter() - t_plan) * 1e3
         d_dec2 = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)   # pass 1's decisions stay for comparison
-        d_stamps = torch.zeros(T * S, dtype=torch.uint8, device=dev)          # sequence stamp of every message
 
     def launch_ticks(t, nxt):
         """ticks [t, nxt) on the stream: ONE train launch, or one class-kernel launch per tick"""
@@ -385,8 +419,10 @@ def main():
             t = nxt
 
     # ---- pass 2: back to the aged state, warm up, time exactly K ticks ----
+    # (rgb_upload_state and the per-tick launches of pass 1 leave the servers' sequence bytes where they were when the
+    # generator started counting, so the stream's stamps are the ones this replay needs)
     eng.set_state(0, st_aged)
-    if use_train:
+    if use_train and old_build:
         eng.train_stamp_device(d_msgs.data_ptr(), d_stamps.data_ptr(), S, counts, sptr)
     run(0, Wm)
     torch.cuda.synchronize()
@@ -477,6 +513,10 @@ def main():
             if not torch.equal(d_dec2[t * tick_bytes:t * tick_bytes + nb], d_dec[t * tick_bytes:t * tick_bytes + nb]):
                 raise SystemExit(f"PARITY FAILURE: train decisions of tick {t} differ from the per-tick launches")
         train_info = {"ticks_per_launch": SNAPSHOT_EVERY, "blocks_per_tick": plan.blocks_per_tick,
+                      "stamps": "written by the stream's producer (rgb_synth_tick_stamped_device) with the messages: "
+                                "nothing of the train's input preparation is outside the timed region except the host's "
+                                "row plan (256 bucket counts per tick)",
+                      "plan_host_ms_total": round(plan_host_ms, 3), "plan_host_us_per_tick": round(plan_host_ms * 1e3 / T, 2),
                       "xcd_of_shard": [int(v) for v in xcc], "decisions_compared_with_per_tick_launches": int(n_dec.sum())}
     checksum_pass2 = eng.state_checksum()
     assert checksum_pass2 == checksum_pass1 or os.environ.get("RGB_BENCH_NOCHECK"), "replay diverged from the generation pass"
@@ -781,10 +821,14 @@ def main():
             "unit": "decisions/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed * 1e3 / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.config4 else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {
-                "workload": "configs[2] closed loop: 65536 groups x 5 members per GPU, mixed append_entries + "
+                "workload": (f"configs[3] as written: {args.total_groups} groups x {N} members in TOTAL, hashed "
+                             f"(splitmix64(group) mod {world} = rgb_route) over {world} GPU(s), rank 0 holds {G}; the "
+                             "configs[2] closed-loop mix per GPU; leaderboard all-gather every 16 ticks through the C "
+                             "entry point; strong scaling (the population is fixed)") if args.config4 else
+                            "configs[2] closed loop: 65536 groups x 5 members per GPU, mixed append_entries + "
                             "request_vote (5% of the groups per tick see a request_vote with term+1 and re-elect), "
                             "every server may get a message every tick (device-side generator), device-resident "
                             "message batches; the ticks of one leaderboard period run as ONE train launch (per-server "
@@ -804,7 +848,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_note": f"HBM bytes per launch from {traffic_src} (rocprofv3 PMC passes, FETCH_SIZE with the "
                                 "guide's gfx950 x2 correction + WRITE_SIZE)" +
                                 ("; PMC passes of the same gpurun call, in front of this run" if os.environ.get("RGB_TRAFFIC_JSON")

@@ -44,6 +44,19 @@ int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_ms
 int rgb_synth_tick_buckets_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs,
                                   void *d_kind_counts, void *d_n, void *d_bucket_counts, void *stream);
 
+/* the same, plus the TRAIN STAMPS of the tick: d_stamps (uint8 per message slot, laid out like d_msgs) = the value of
+ * the server's sequence byte every message must find in a train launch (ra_gpu_batch.h, "Train launches").  A producer
+ * knows how many messages it has addressed to a server: the generator keeps that count per server (mod 256, device
+ * memory of the context) and stamps as it writes -- no pass over the stream afterwards (rgb_train_stamp_device is
+ * that pass, for streams whose producer does not stamp).  The count starts from what the servers' sequence bytes
+ * hold when the first stamped tick is generated; rgb_synth_stamps_resync_device re-reads them (after trains of a
+ * stream the generator did not produce, or none of its own: the stamps of a stream are valid for a replay that
+ * starts from the same sequence bytes -- per-tick launches and rgb_upload_state do not move them). */
+int rgb_synth_tick_stamped_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs,
+                                  void *d_kind_counts, void *d_n, void *d_bucket_counts, void *d_stamps,
+                                  void *stream);
+int rgb_synth_stamps_resync_device(rgb_ctx *ctx, void *stream);
+
 /* Apply the tick that rgb_synth_tick_device just wrote (same stream): one launch of the
  * class-dispatch kernel sized from the family totals the generator left in device memory, so no
  * host round trip is needed between generating a tick and applying it. */

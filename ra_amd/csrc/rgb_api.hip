@@ -113,6 +113,7 @@ struct rgb_ctx {
   rgb_leaderboard_row *d_rows = nullptr;
   u64 *d_sums = nullptr;
   u32 *d_synth = nullptr;     /* load-generator scratch (family and bucket counters) */
+  unsigned char *d_synth_sent = nullptr;   /* load generator: messages addressed to every server so far, mod 256 (its stamps) */
   /* train launches */
   u32 *d_train_ctl = nullptr;           /* RGB_TRAIN_CTL_WORDS: sticky error flags | calibration scratch */
   unsigned char *d_seq_cnt = nullptr;   /* running stamp counters of rgb_train_stamp_device (a copy of dev.seq) */
@@ -248,6 +249,7 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->d_synth) (void)hipFree(ctx->d_synth);
+  if (ctx->d_synth_sent) (void)hipFree(ctx->d_synth_sent);
   if (ctx->d_train_ctl) (void)hipFree(ctx->d_train_ctl);
   if (ctx->d_seq_cnt) (void)hipFree(ctx->d_seq_cnt);
 
@@ -334,6 +336,11 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
     HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
     HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
   }
+#endif
+#ifdef RGB_X_DECLINE_HIST
+  /* EXPERIMENT build (tools/decline_hist.py): 3 classes x 32 reason counters */
+  HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, 128 * sizeof(u64)));
+  HIPCHK(ctx, hipMemset(d.dbg_buf, 0, 128 * sizeof(u64)));
 #endif
 #ifdef RGB_X_TRAIN_TIMELINE
   /* EXPERIMENT build (tools/train_timeline.py): 8 words per block of a train launch */
@@ -972,22 +979,46 @@ int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
 void *rgb_ctx_stream(rgb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rgb_ctx_device(rgb_ctx *ctx) { return ctx ? ctx->cfg.device : 0; }
 
-int rgb_synth_tick_buckets_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
-                                  void *d_n, void *d_bucket_counts, void *stream) {
+int rgb_synth_tick_stamped_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
+                                  void *d_n, void *d_bucket_counts, void *d_stamps, void *stream) {
   if (!ctx || !d_msgs) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   void *st = stream ? stream : (void *)ctx->stream;
   if (!ctx->d_synth)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth, (size_t)rgb_synth_scratch_words(ctx->dev.n_servers / ctx->dev.n_members) * sizeof(u32)));
+  if (d_stamps && !ctx->d_synth_sent) {
+    /* first stamped tick: the generator counts on from what the servers hold now */
+    const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth_sent, bytes));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_synth_sent, ctx->dev.seq, bytes, hipMemcpyDeviceToDevice, (hipStream_t)st));
+  }
   int rc = rgb_launch_synth(ctx->dev, seed, tick, (rgb_msg *)d_msgs, ctx->d_synth, (u32 *)d_kind_counts,
-                            (u32 *)d_n, (u32 *)d_bucket_counts, st);
+                            (u32 *)d_n, (u32 *)d_bucket_counts, (unsigned char *)d_stamps,
+                            d_stamps ? ctx->d_synth_sent : nullptr, st);
   if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   return RGB_OK;
 }
 
+int rgb_synth_stamps_resync_device(rgb_ctx *ctx, void *stream) {
+  if (!ctx) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
+  if (!ctx->d_synth_sent) HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth_sent, bytes));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_synth_sent, ctx->dev.seq, bytes, hipMemcpyDeviceToDevice, st));
+  return RGB_OK;
+}
+
+int rgb_synth_tick_buckets_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
+                                  void *d_n, void *d_bucket_counts, void *stream) {
+  return rgb_synth_tick_stamped_device(ctx, seed, tick, d_msgs, d_kind_counts, d_n, d_bucket_counts, nullptr, stream);
+}
+
 int rgb_synth_tick_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
                           void *d_n, void *stream) {
-  return rgb_synth_tick_buckets_device(ctx, seed, tick, d_msgs, d_kind_counts, d_n, nullptr, stream);
+  return rgb_synth_tick_stamped_device(ctx, seed, tick, d_msgs, d_kind_counts, d_n, nullptr, nullptr, stream);
 }
 
 /* ---- train launches (include/ra_gpu_batch.h) ---- */

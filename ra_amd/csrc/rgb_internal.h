@@ -187,8 +187,11 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
                             u32 rpc_slot_base, u32 msg_index_base, void *stream);
 /* d_scratch: 2*RGB_N_FAMILIES u32 of device scratch */
 /* d_scratch: rgb_synth_scratch_words(groups) u32; d_bucket_counts (may be NULL): RGB_N_BUCKETS u32 of this tick */
+/* d_stamps (may be NULL): one byte per message slot = the generator's count d_sent[] (one byte per server, laid out
+ * like dev.seq, advanced here) of the messages it addressed to that server before: a train's sequence stamps */
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
-                     u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream);
+                     u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, unsigned char *d_stamps, unsigned char *d_sent,
+                     void *stream);
 /* ticks [0, n_ticks) of d_plan in one launch (n_ticks <= RGB_TRAIN_MAX_TICKS) of n_blocks persistent blocks
  * (rgb_train_resident_blocks) on a device of n_xcc XCCs (1, 2, 4 or 8: a block serves the shard of the XCC it runs
  * on); bpt = RGB_TRAIN_SHARDS x the rows per tick of d_row_tab; tick_stride = 0: tick t starts at d_plan[t].msg_base

@@ -2037,6 +2037,15 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 #ifndef RGB_X_FAST
 #define RGB_X_FAST 1
 #endif
+/* -DRGB_X_DECLINE_HIST (tools/decline_hist.py): why a lane declined its fast path, counted per class and reason in
+ * dev.dbg_buf (word 0 of every class = lanes that took the fast path) */
+#if defined(RGB_X_DECLINE_HIST) && !defined(RGB_HOST_EMULATION)
+#define FP_DECLINE(cls, code) do { atomicAdd(dev.dbg_buf + (cls) * 32 + (code), 1ull); return false; } while (0)
+#define FP_TAKEN(cls) atomicAdd(dev.dbg_buf + (cls) * 32, 1ull)
+#else
+#define FP_DECLINE(cls, code) return false
+#define FP_TAKEN(cls) do { } while (0)
+#endif
 
 /* follower, append_entries_rpc from the known leader in the current term, appended right after the last index with
  * entries of the last run's term: ra_log:write of the tail (src/ra_server.erl:1283-1303, 1365-1389; ra_log:write/2
@@ -2047,32 +2056,46 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
   const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), from = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF), gap = (unsigned)((m0.x >> 56) & 0xFF);
   const u32 n_entries = (u32)(m2.y & 0xFFFFFFFFull), n_run0 = (u32)(m2.y >> 32);
-  if (wire_kind != RGB_MSG_AER || server >= dev.n_servers || gap != 0 || n_entries == 0 || n_run0 < n_entries ||
-      from >= 8u || mflags != 0)
-    return false;
+  if (wire_kind != RGB_MSG_AER || server >= dev.n_servers || from >= 8u || mflags != 0) FP_DECLINE(0, 1);
+  if (gap != 0) FP_DECLINE(0, 2);
+  if (n_run0 < n_entries) FP_DECLINE(0, 4);                          /* entries of two terms */
   const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h5 = pre[5 ^ swz],
                    h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
   const u64 ct = h0.x, pk = h0.y, la = h1.y, li = h2.x, lt = h2.y, lwi = h3.x, first = h5.x, lrs = h5.y, lrt = h6.x,
             pend = h7.y;
   /* follower (role 0, no condition), the sender is the leader we know, nothing sparse pending, a run table */
-  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER || pk_get(pk, PK_LEADER_SH, 4) != from ||
-      pk_get(pk, PK_PENDX_SH, 1) || pk_get(pk, PK_NRUNS_SH, 5) == 0)
-    return false;
+  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER) FP_DECLINE(0, 5);
+  if (pk_get(pk, PK_LEADER_SH, 4) != from) FP_DECLINE(0, 6);
+  if (pk_get(pk, PK_PENDX_SH, 1) || pk_get(pk, PK_NRUNS_SH, 5) == 0) FP_DECLINE(0, 7);
   const u64 term = m0.y, pli = m1.x, plt = m1.y, leader_commit = m2.x, eterm = m3.x;
-  if (term != ct || !(first <= li) || li == UNDEF || pli != li || li < lrs || plt != lrt || lt != lrt ||
-      eterm != lrt || la > li + 1 || lwi > li || pend > li + 1)
-    return false;
-  if (pk_get(pk, PK_NRUNS_SH, 5) < 2 && (h6.y | h7.x) != 0) return false;   /* the commit would canonicalise the row */
+  if (term != ct) FP_DECLINE(0, 8);
+  if (!(first <= li) || li == UNDEF) FP_DECLINE(0, 9);
+  if (pli != li) FP_DECLINE(0, 10);                                  /* not at the tail: gap, resend, overlap */
+  if (li < lrs) FP_DECLINE(0, 11);
+  if (plt != lrt) FP_DECLINE(0, 12);                                 /* wrong prev_log_term */
+  if (lt != lrt) FP_DECLINE(0, 13);
+  if (n_entries != 0 && eterm != lrt) FP_DECLINE(0, 14);             /* entries of a new term: a run is pushed */
+  if (la > li + 1 || lwi > li || pend > li + 1) FP_DECLINE(0, 15);
+  if (pk_get(pk, PK_NRUNS_SH, 5) < 2 && (h6.y | h7.x) != 0) FP_DECLINE(0, 16);   /* the commit would canonicalise the row */
+  FP_TAKEN(0);
   /* has_log_entry_or_snapshot: entry_ok; drop_existing: nothing exists above the last index; ra_log:write extends
    * the last run: last_index moves, last_written and pending keep their words ([pend..] simply grows) */
   const u64 fst = li + 1, lst = li + n_entries;
-  u32 flags = RGB_F_WROTE | RGB_F_LEADER_MSG;
+  u32 flags = RGB_F_LEADER_MSG;
   const u64 ci = leader_commit;
   u64 nla = la;
   const u64 at = lst < ci ? lst : ci;
   if (at > la) { nla = at; flags |= RGB_F_APPLIED | RGB_F_AUX_EVAL; }     /* apply_to/5: at >= la + 1 */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS);
   if (ci != h1.x || nla != la) ST16(ho + 1, make_ulonglong2(ci, nla));
+  if (n_entries == 0) {
+    /* the empty rpc at the tail (nothing new to write, :1304-1343): validated, the commit index is the leader's, the
+     * success reply carries what is written (append_entries_reply/3 :3624-3631) */
+    make_decision(out, server, RGB_ROLE_FOLLOWER, from, 0, RGB_MSG_AER, flags | RGB_F_REPLY | RGB_F_REPLY_SUCCESS, 0, term,
+                  li + 1, lwi, h3.y, ci, nla);
+    return true;
+  }
+  flags |= RGB_F_WROTE;
   ST16(ho + 2, make_ulonglong2(lst, lt));
   make_decision(out, server, RGB_ROLE_FOLLOWER, RGB_NONE, 0, RGB_MSG_AER, flags, 0, 0, fst, lst, 0, ci, nla);
   return true;
@@ -2085,22 +2108,27 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
                                              const ulonglong2 *pre, unsigned swz, Dec &out) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
   const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), mflags = (unsigned)((m0.x >> 48) & 0xFF);
-  if (wire_kind != RGB_MSG_WRITTEN || server >= dev.n_servers || mflags != 0) return false;
+  if (wire_kind != RGB_MSG_WRITTEN || server >= dev.n_servers || mflags != 0) FP_DECLINE(2, 1);
   const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h4 = pre[4 ^ swz],
                    h5 = pre[5 ^ swz], h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
   const u64 ct = h0.x, pk = h0.y, li = h2.x, si = h4.x, first = h5.x, lrs = h5.y, lrt = h6.x, pend = h7.y;
   const unsigned l4 = (unsigned)pk_get(pk, PK_LEADER_SH, 4);
-  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER || l4 == SLOT_NONE4 || pk_get(pk, PK_PENDX_SH, 1) ||
-      pk_get(pk, PK_NRUNS_SH, 5) == 0)
-    return false;
+  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER) FP_DECLINE(2, 2);   /* the leader's own written event */
+  if (l4 == SLOT_NONE4) FP_DECLINE(2, 3);
+  if (pk_get(pk, PK_PENDX_SH, 1) || pk_get(pk, PK_NRUNS_SH, 5) == 0) FP_DECLINE(2, 4);
   const u64 term = m0.y, from = m1.x, to = m1.y;
   /* the whole of [from..to] ends inside the last run, which has the event's term; the snapshot lies below the range */
-  if (!(first <= li) || li == UNDEF || from > to || to > li || to < lrs || to < first || lrt != term ||
-      (si != UNDEF && si >= first) || pend > li + 1)
-    return false;
-  if (pk_get(pk, PK_NRUNS_SH, 5) < 2 && (h6.y | h7.x) != 0) return false;   /* the commit would canonicalise the row */
+  if (!(first <= li) || li == UNDEF || from > to) FP_DECLINE(2, 5);
+  if (to > li) FP_DECLINE(2, 6);
+  if (to < lrs) FP_DECLINE(2, 7);                                     /* ends below the last run */
+  if (to < first) FP_DECLINE(2, 8);
+  if (lrt != term) FP_DECLINE(2, 9);                                  /* a stale event */
+  if (si != UNDEF && si >= first) FP_DECLINE(2, 10);
+  if (pend > li + 1) FP_DECLINE(2, 11);
+  if (pk_get(pk, PK_NRUNS_SH, 5) < 2 && (h6.y | h7.x) != 0) FP_DECLINE(2, 12);   /* the commit would canonicalise the row */
   /* ra_seq:remove_prefix: the pending tail [pend..li] up to `to` must start inside [from..to] */
-  if (pend <= li && pend <= to && pend < from) return false;         /* not a prefix: the resend path */
+  if (pend <= li && pend <= to && pend < from) FP_DECLINE(2, 13);    /* not a prefix: the resend path */
+  FP_TAKEN(2);
   u64 npend = pend;
   if (pend <= li && to + 1 > pend) npend = to + 1;                    /* == li + 1 when everything is confirmed */
   const bool changed = !(h3.x == to && h3.y == term);
@@ -2124,20 +2152,23 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
 template <int N, bool TR = false>
 __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                const ulonglong2 *pre, unsigned swz, Dec &out,
-                                               const ulonglong2 *prow = nullptr) {
+                                               const ulonglong2 *prow = nullptr,
+                                               const ulonglong2 *rrow = nullptr) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
   const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), peer = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF);
-  if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || mflags != RGB_MF_SUCCESS || peer >= (unsigned)N)
-    return false;
+  if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || peer >= (unsigned)N) FP_DECLINE(1, 1);
+  if (mflags != RGB_MF_SUCCESS) FP_DECLINE(1, 2);                    /* a failed reply */
   const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h4 = pre[4 ^ swz],
                    h5 = pre[5 ^ swz], h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
   const u64 ct = h0.x, pk = h0.y, ci0 = h1.x, la = h1.y, li = h2.x, lwi = h3.x, si = h4.x, st = h4.y, first = h5.x,
             lrs = h5.y, lrt = h6.x, prs = h6.y, prt = h7.x;
   const unsigned present = (unsigned)pk_get(pk, PK_PRESENT_SH, 8), voters = (unsigned)pk_get(pk, PK_VOTER_SH, 8);
   const unsigned self = (unsigned)pk_get(pk, PK_SELF_SH, 4), n_runs = (unsigned)pk_get(pk, PK_NRUNS_SH, 5);
-  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_LEADER || m0.y != ct || !((present >> peer) & 1u)) return false;
-  if (n_runs < 2 && (h6.y | h7.x) != 0) return false;
+  if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_LEADER) FP_DECLINE(1, 3);
+  if (m0.y != ct) FP_DECLINE(1, 4);
+  if (!((present >> peer) & 1u)) FP_DECLINE(1, 5);
+  if (n_runs < 2 && (h6.y | h7.x) != 0) FP_DECLINE(1, 6);
   u64 *peers = dev.peers + (size_t)server * dev.peer_stride;
   u64 w[2 * N + (N & 1)];
   if (prow != nullptr) {
@@ -2171,8 +2202,22 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   if (first <= li && p >= first && p <= li) {
     if (p >= lrs) t = lrt;
     else if (n_runs >= 2 && p >= prs) t = prt;
-    else return false;                                               /* older than the mirrored runs: probe */
+    else if (rrow != nullptr && n_runs <= (unsigned)RGB_RUNS_LDS + 2u) {
+      /* older than the mirrored runs: the in-memory runs (0 .. n_runs-3) are all in the table line the wavefront
+       * fetched into LDS with the rows (train launches; run k at rrow[k ^ swz]) -- the newest one that starts at or
+       * below p holds it (ra_log:fetch_term/2 inside the range, src/ra_log.erl:1186-1200) */
+      bool found = false;
+#pragma unroll
+      for (int k = RGB_RUNS_LDS - 1; k >= 0; --k) {
+        if (!found && (unsigned)k + 3u <= n_runs) {
+          const ulonglong2 r = rrow[(unsigned)k ^ swz];
+          if (p >= r.x) { t = r.y; found = true; }
+        }
+      }
+      if (!found) FP_DECLINE(1, 8);
+    } else FP_DECLINE(1, 7);                                         /* more in-memory runs than the line holds: probe */
   }
+  FP_TAKEN(1);
   if (t == UNDEF && si != UNDEF && si == p) t = st;
   u64 ci = ci0, nla = la;
   u32 flags = RGB_F_PIPELINE;
@@ -2323,7 +2368,11 @@ __device__ __forceinline__ u32 rgb_take_ticket(u32 *ctr, const u32 *err) {
   if (threadIdx.x == 0) v = atomicAdd(ctr, 1u);
   if (threadIdx.x == 1) v = *err;
 #else
+#ifdef RGB_X_TICKET_WG   /* EXPERIMENT: no sc1 on the atomic (all users of a counter share one XCD's L2) */
+  if (threadIdx.x == 0) v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
   if (threadIdx.x == 0) v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   /* lane 1 of the same register: the launch's error word (a failed launch drains instead of computing on) */
   if (threadIdx.x == 1) v = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -2537,7 +2586,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   /* the steady-state outcome of the three bulk kinds first; whoever is left takes the general clause code below */
   if (active) {
     if (cls == 0) done = fast_aer(dev, m0, m1, m2, m3, hrow, hswz, d);
-    else if (cls == 1) done = fast_aer_reply<N, TR>(dev, m0, m1, hrow, hswz, d, prow);
+    else if (cls == 1) done = fast_aer_reply<N, TR>(dev, m0, m1, hrow, hswz, d, prow, rrow);
     else if (cls == 2) done = fast_written(dev, m0, m1, hrow, hswz, d);
   }
 #endif
@@ -2707,6 +2756,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #ifndef RGB_TRAIN_MIN_WAVES
 #define RGB_TRAIN_MIN_WAVES(N) 3
 #endif
+#ifndef RGB_X_TRAIN_BLOCKS
+#define RGB_X_TRAIN_BLOCKS 0
+#endif
 #define RGB_TRAIN_CTL_ARRIVE 8u     /* ctl words 8..15: blocks arrived per XCC (devices with fewer XCCs than shards) */
 #define RGB_TRAIN_CTL_TICKET 32u    /* ctl word 32 (1 + x): next row of shard x (one 128-byte line per shard)         */
 /* the kernel's one argument.  The persistent loop re-reads it from the kernarg segment through a pointer the compiler
@@ -2745,19 +2797,30 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
       x = (xcc & (n_xcc - 1u)) + n_xcc * (a % (RGB_TRAIN_SHARDS / n_xcc));
     }
   }
+#if RGB_X_TRAIN_BLOCKS
+  /* EXPERIMENT (A/B only): the round-3 dispatch -- one block per row, block b serves shard b mod 8 and RELIES on the
+   * dispatcher dealing blocks round robin over the XCDs; the launcher sizes the grid accordingly */
+  x = blockIdx.x & (RGB_TRAIN_SHARDS - 1u);
+  u32 raw = (threadIdx.x == 0) ? blockIdx.x / RGB_TRAIN_SHARDS : 0u;
+#else
   u32 raw = rgb_take_ticket(args.ctl + RGB_TRAIN_CTL_TICKET * (1u + x), args.ctl);
+#endif
   u32 t = 0, cum = 0;
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
   for (;;) {
-#ifdef RGB_HOST_EMULATION
+#if defined(RGB_HOST_EMULATION) || !defined(__HIP_DEVICE_COMPILE__)   /* (the host pass only parses the kernel) */
     const rgb_train_args *A = &args;
     u32 lane = threadIdx.x;
 #else
-    const rgb_train_args *A = (const rgb_train_args *)__builtin_amdgcn_kernarg_segment_ptr();
+    /* the constant address space stays on the pointer: loads through it are invariant scalar loads (through a generic
+     * pointer every state store could alias the arguments and each use would re-load them behind a wait) */
+    typedef const __attribute__((address_space(4))) rgb_train_args *args_ptr;
+    args_ptr A = (args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(A));
     u32 lane = threadIdx.x;
     asm volatile("" : "+v"(lane));
 #endif
+    const rgb_dev dev = A->dev;
     const u32 k = rgb_ticket_value(raw);
     if (rgb_ticket_err(raw) != 0u) break;                 /* the launch has failed: drain */
     /* the tick of row k (tickets only grow: t and the rows before it are carried along) */
@@ -2777,7 +2840,11 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
     const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
     const u32 lbase = (e & 0xFFFFFFu) * SL;
     u32 *const tk = A->ctl + RGB_TRAIN_CTL_TICKET * (1u + x);
+#if RGB_X_TRAIN_BLOCKS
+    if (lbase >= ncls) break;
+#else
     if (lbase >= ncls) { raw = rgb_take_ticket(tk, A->ctl); continue; }
+#endif
     const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
     /* ticks a fixed stride apart with a ring of rpc regions (device-resident streams), or -- tick_stride = 0 -- packed
      * one behind the other, every message owning the rpc slots of its index in the whole buffer (rgb_submit's rounds) */
@@ -2786,9 +2853,13 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
     rgb_rpc *rp = A->rpcs ? A->rpcs + (tick_stride ? (size_t)(t % A->rpc_ring) * tick_stride : toff) * (N > 1 ? N - 1 : 1) : nullptr;
     lds_barrier();                                        /* the previous slice is done with the staging area */
     raw = 0;
-    if (!rgb_tick_slice<N, true>(A->dev, io, cls, off + lbase, cnt, SL, A->msgs + toff, A->dec + toff, rp, 0,
-                                 A->index_base + (u32)toff, A->ctl, A->stamps + toff, tk, &raw, x, lane))
+    if (!rgb_tick_slice<N, true>(dev, io, cls, off + lbase, cnt, SL, A->msgs + toff, A->dec + toff, rp, 0,
+                                 A->index_base + (u32)toff, A->ctl, A->stamps + toff,
+                                 RGB_X_TRAIN_BLOCKS ? nullptr : tk, &raw, x, lane))
       break;
+#if RGB_X_TRAIN_BLOCKS
+    break;
+#endif
   }
 }
 
@@ -3053,7 +3124,8 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
  * and writes each one at its block's base + rank. */
 template <int N, bool WRITE>
 __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u64 tick, rgb_msg *__restrict__ out,
-                                                       u32 *__restrict__ scratch) {
+                                                       u32 *__restrict__ scratch, unsigned char *__restrict__ stamps,
+                                                       unsigned char *__restrict__ sent) {
   __shared__ u32 cnt[RGB_N_BUCKETS], rank[RGB_N_BUCKETS];
   u32 *blk = scratch + RGB_SYNTH_FIXED_WORDS + (size_t)blockIdx.x * RGB_N_BUCKETS;
   for (u32 b = threadIdx.x; b < RGB_N_BUCKETS; b += blockDim.x) { cnt[b] = 0; rank[b] = 0; }
@@ -3072,6 +3144,15 @@ __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u6
       const unsigned b = bucket(m);
       const u32 slot = blk[b] + atomicAdd(&rank[b], 1u);
       syn_store(out + slot, m);
+      /* the producer's own count of the messages it has addressed to the server = the value of the server's
+       * sequence byte the message must find in a train launch (one lane per group, one message per server and
+       * tick: nobody else touches the counter) */
+      if (stamps != nullptr) {
+        const u32 q = rgb_seq_index(m.server, (unsigned)N, dev.seq_stride);
+        const unsigned char c = sent[q];
+        sent[q] = (unsigned char)(c + 1u);
+        stamps[slot] = c;
+      }
     });
 }
 
@@ -3443,7 +3524,8 @@ int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32
 u32 rgb_synth_scratch_words(u32 n_groups) { return RGB_SYNTH_FIXED_WORDS + ((n_groups + 63u) / 64u) * RGB_N_BUCKETS; }
 
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
-                     u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, void *stream) {
+                     u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, unsigned char *d_stamps, unsigned char *d_sent,
+                     void *stream) {
   hipStream_t st = (hipStream_t)stream;
   const u32 G = dev.n_servers / dev.n_members;
   const u32 nblk = (G + 63) / 64;
@@ -3452,10 +3534,12 @@ int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u3
   if (e != hipSuccess) return (int)e;
 #define LAUNCH(NN)                                                                                     \
   case NN:                                                                                             \
-    hipLaunchKernelGGL((rgb_synth_kernel<NN, false>), grid, block, 0, st, dev, seed, tick, d_msgs, d_scratch); \
+    hipLaunchKernelGGL((rgb_synth_kernel<NN, false>), grid, block, 0, st, dev, seed, tick, d_msgs, d_scratch, \
+                       (unsigned char *)nullptr, (unsigned char *)nullptr);                             \
     hipLaunchKernelGGL(rgb_synth_scan_kernel, dim3(1), dim3(RGB_N_BUCKETS), 0, st, d_scratch, nblk, d_kind_counts, \
                        d_n, d_bucket_counts);                                                          \
-    hipLaunchKernelGGL((rgb_synth_kernel<NN, true>), grid, block, 0, st, dev, seed, tick, d_msgs, d_scratch); \
+    hipLaunchKernelGGL((rgb_synth_kernel<NN, true>), grid, block, 0, st, dev, seed, tick, d_msgs, d_scratch, \
+                       d_stamps, d_sent);                                                              \
     break;
   switch (dev.n_members) {
     RGB_LAUNCH_ALL_N
@@ -3542,6 +3626,9 @@ u32 rgb_train_resident_blocks(unsigned n_members) {
   }
 #undef LAUNCH
   if (e != hipSuccess || per_cu <= 0) return 0;
+#ifdef RGB_X_TRAIN_GRID_PCT      /* EXPERIMENT: a share of the device's wavefront slots */
+  return (u32)((u64)per_cu * (u32)cus * RGB_X_TRAIN_GRID_PCT / 100u);
+#endif
   return (u32)per_cu * (u32)cus;
 #endif
 }
@@ -3560,6 +3647,9 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
   const uint64_t rows = (uint64_t)n_ticks * bpt;
   dim3 grid((u32)(rows < n_blocks ? rows : n_blocks)), block(RGB_TICK_BLOCK);
   if (grid.x < RGB_TRAIN_SHARDS) grid.x = RGB_TRAIN_SHARDS;
+#if RGB_X_TRAIN_BLOCKS
+  grid.x = (u32)rows;        /* one block per row of the longest tick, every tick */
+#endif
   rgb_train_args args;
   args.dev = dev; args.msgs = d_msgs; args.stamps = d_stamps; args.plan = d_plan; args.row_tab = d_row_tab;
   args.dec = d_dec; args.rpcs = d_rpcs; args.ctl = d_ctl; args.tick_stride = tick_stride;

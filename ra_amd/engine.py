@@ -26,7 +26,9 @@ EXPORTS = [
     "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status",
 ]
-SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_tick_buckets_device", "rgb_synth_apply_tick_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
+SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_tick_buckets_device", "rgb_synth_apply_tick_device",
+                 "rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
+OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device"}
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -72,6 +74,9 @@ def lib():
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS + SYNTH_EXPORTS + WAL_EXPORTS:
         if not hasattr(L, name):
+            # tools/ only: RGB_LIB=<an older build> for same-box A/B timing of bench.py (tools/gpu_ab.sh --variants)
+            if os.environ.get("RGB_LIB") and name in OPTIONAL_IN_OLD_BUILDS:
+                continue
             raise RuntimeError(f"libra_gpu_batch.so does not export {name}")
     vp, u32, u64p = C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)
     L.rgb_abi_version.restype = C.c_uint32
@@ -107,6 +112,14 @@ def lib():
     L.rgb_route.restype = C.c_uint32
     L.rgb_synth_tick_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]
     L.rgb_synth_tick_buckets_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]
+    if hasattr(L, "rgb_synth_tick_stamped_device"):
+        L.rgb_synth_tick_stamped_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp, vp]
+        L.rgb_synth_stamps_resync_device.argtypes = [vp, vp]
+    if hasattr(L, "rgb_debug_inject_train_fault"):
+        L.rgb_debug_inject_train_fault.argtypes = [vp, u32]
+        L.rgb_debug_inject_train_fault.restype = None
+        L.rgb_train_recoveries.argtypes = [vp]
+        L.rgb_train_recoveries.restype = C.c_uint32
     L.rgb_train_bucket.restype = C.c_uint32
     L.rgb_train_bucket.argtypes = [u32, u32, u32, u32]
     L.rgb_train_plan_create.argtypes = [vp, vp, u32, C.POINTER(vp)]
@@ -302,6 +315,18 @@ class RaGpuBatch:
         self._check(self._L.rgb_synth_tick_buckets_device(self._h, seed & (2**64 - 1), tick, d_msgs, d_kind_counts,
                                                          d_n, d_bucket_counts, stream), "rgb_synth_tick_buckets_device")
 
+    def synth_tick_stamped_device(self, seed: int, tick: int, d_msgs: int, d_kind_counts: int = 0, d_n: int = 0,
+                                  d_bucket_counts: int = 0, d_stamps: int = 0, stream: int = 0):
+        """The load generator, also writing the tick's train stamps (uint8 per message slot): the producer's own
+        count of the messages it has addressed to each server."""
+        self._check(self._L.rgb_synth_tick_stamped_device(self._h, seed & (2**64 - 1), tick, d_msgs, d_kind_counts,
+                                                         d_n, d_bucket_counts, d_stamps, stream),
+                    "rgb_synth_tick_stamped_device")
+
+    def synth_stamps_resync_device(self, stream: int = 0):
+        """The generator's per-server message counts := the servers' sequence bytes as they are now."""
+        self._check(self._L.rgb_synth_stamps_resync_device(self._h, stream), "rgb_synth_stamps_resync_device")
+
     # ---- train launches: several device-resident ticks in one launch ----
     def train_plan(self, bucket_counts: np.ndarray) -> "TrainPlan":
         return TrainPlan(self, bucket_counts)
@@ -325,6 +350,14 @@ class RaGpuBatch:
         if check and rc:
             raise RgbError(rc, f"train launch failed (flags={flags.value}: 1 = placement, 2 = spin bound)")
         return int(flags.value), xcc
+
+    def inject_train_fault(self, fault: int):
+        """Fail-safe tests: the next train batch of submit() gets a fault (1 = a stamp that never comes up,
+        2 = two messages bucketed under each other's shard).  The engine must repair the failed launch itself."""
+        self._L.rgb_debug_inject_train_fault(self._h, fault)
+
+    def train_recoveries(self) -> int:
+        return int(self._L.rgb_train_recoveries(self._h))
 
     def synth_apply_tick_device(self, d_msgs: int, max_msgs: int, d_decisions: int, d_rpcs: int = 0,
                                 stream: int = 0):

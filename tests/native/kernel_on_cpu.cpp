@@ -256,7 +256,7 @@ int emu_launch_leaderboard(void *h, rgb_leaderboard_row *rows) {
 uint32_t emu_synth_scratch_words(void *h) { const rgb_dev &d = ((Emu *)h)->dev; return rgb_synth_scratch_words(d.n_servers / d.n_members); }
 int emu_launch_synth(void *h, uint64_t seed, uint64_t tick, rgb_msg *msgs, uint32_t *scratch, uint32_t *kind_counts,
                      uint32_t *n_out, uint32_t *bucket_counts) {
-  return rgb_launch_synth(((Emu *)h)->dev, seed, tick, msgs, scratch, kind_counts, n_out, bucket_counts, nullptr);
+  return rgb_launch_synth(((Emu *)h)->dev, seed, tick, msgs, scratch, kind_counts, n_out, bucket_counts, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -128,3 +128,60 @@ def test_config5_repair_backlogs_at_16384_groups(engine_mod, oracle_lib):
     assert (cpu.get_state()["role"] == abi.ROLE_AWAIT_CONDITION).sum() > G // 4
     assert seen & abi.F_REPLY and seen & abi.F_PIPELINE and n_dec > ticks * 20_000
     cpu.close()
+
+
+def test_config3_trains_against_the_oracle_at_full_size(engine_mod, oracle_lib):
+    """VERDICT round 3, "What's weak" 1: rgb_train_kernel at 65 536 x 5 against the ORACLE itself (not through the
+    per-tick launches): 64 ageing ticks, then 64 ticks generated by the stamping load generator and replayed from the
+    aged state as four 16-tick train launches -- every decision of every tick and the whole final state compared with
+    Oracle.step_parallel on the same stream."""
+    import torch
+    from ra_amd import workload as W
+    G, N, seed, age, T, per = 65536, 5, 0x5EED0003, 64, 64, 16
+    S, tb = G * N, G * N * 64
+    stream = torch.cuda.Stream()
+    sp = stream.cuda_stream
+    with engine_mod.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64) as gpu:
+        gpu.set_state(0, W.initial_states(G, N, seed))
+        dm = torch.zeros(T * tb, dtype=torch.uint8, device="cuda")
+        dd = torch.zeros(T * tb, dtype=torch.uint8, device="cuda")
+        ds = torch.zeros(T * S, dtype=torch.uint8, device="cuda")
+        dr = torch.zeros(4 * S * (N - 1) * 56, dtype=torch.uint8, device="cuda")
+        dn = torch.zeros(T, dtype=torch.int32, device="cuda")
+        bc = torch.zeros(T * engine_mod.TRAIN_BUCKETS, dtype=torch.int32, device="cuda")
+        for t in range(age):                                 # ageing: applied, not kept
+            gpu.synth_tick_device(seed, t, dm.data_ptr(), 0, 0, sp)
+            gpu.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), sp)
+        stream.synchronize()
+        st_aged = gpu.get_state()
+        for t in range(T):                                   # the stream: generated (and stamped) tick by tick
+            gpu.synth_tick_stamped_device(seed, age + t, dm.data_ptr() + t * tb, 0, dn.data_ptr() + t * 4,
+                                          bc.data_ptr() + t * engine_mod.TRAIN_BUCKETS * 4, ds.data_ptr() + t * S, sp)
+            gpu.synth_apply_tick_device(dm.data_ptr() + t * tb, S, dd.data_ptr(), dr.data_ptr(), sp)
+        stream.synchronize()
+        counts = dn.cpu().numpy().astype(np.int64)
+        buckets = bc.cpu().numpy().reshape(T, engine_mod.TRAIN_BUCKETS).astype(np.uint32)
+        plan = gpu.train_plan(buckets)
+        gpu.set_state(0, st_aged)
+        dd.zero_()
+        for t in range(0, T, per):
+            gpu.train_run_device(plan, t, per, dm.data_ptr(), ds.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), 4, sp)
+        stream.synchronize()
+        assert gpu.train_status()[0] == 0
+        cpu = oracle_lib.Oracle(G, N, max_runs=16)
+        cpu.set_state(0, st_aged)
+        n_dec = 0
+        for t in range(T):
+            n = int(counts[t])
+            msgs = dm[t * tb:t * tb + n * 64].cpu().numpy().view(abi.MSG_DTYPE)
+            got = dd[t * tb:t * tb + n * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+            want, _ = cpu.step_parallel(msgs)
+            if got.tobytes() != want.tobytes():
+                bad = int(np.flatnonzero((got.view(np.uint8).reshape(n, 64) != want.view(np.uint8).reshape(n, 64)).any(axis=1))[0])
+                raise AssertionError(f"train, tick {t} slot {bad}: msg={msgs[bad]}\n gpu={got[bad]}\n cpu={want[bad]}")
+            n_dec += n
+        assert n_dec > T * 180_000
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes(), "final state differs from the oracle's"
+        assert gpu.state_checksum() == checksum_of_checksums(oracle_lib.server_checksums(cpu.get_state()))
+        plan.close()
+        cpu.close()

@@ -168,6 +168,102 @@ def test_train_with_a_wrong_stamp_fails_in_bounded_time(emulated_engine):
     eng.close()
 
 
+def check_generator_stamps(engine, G, N, T, seed, on_gpu):
+    """The stamps the load generator writes with its ticks = what rgb_train_stamp_device counts over the same stream,
+    and a replay from the same sequence bytes accepts them."""
+    S, tb = G * N, G * N * 64
+    eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
+    eng.set_state(0, W.initial_states(G, N, seed))
+    st0 = eng.get_state()
+    msgs, dec, dec2 = Buf(T * tb, on_gpu), Buf(T * tb, on_gpu), Buf(T * tb, on_gpu)
+    rpcs = Buf(4 * S * max(N - 1, 1) * 56, on_gpu)
+    dn, bc = Buf(T * 4, on_gpu), Buf(T * engine.TRAIN_BUCKETS * 4, on_gpu)
+    stamps, stamps2 = Buf(T * S, on_gpu), Buf(T * S, on_gpu)
+    for t in range(T):
+        eng.synth_tick_stamped_device(seed, t, msgs.ptr + t * tb, 0, dn.ptr + t * 4, bc.ptr + t * engine.TRAIN_BUCKETS * 4,
+                                      stamps.ptr + t * S)
+        eng.synth_apply_tick_device(msgs.ptr + t * tb, S, dec.ptr + t * tb, rpcs.ptr)
+    eng.synchronize()
+    counts = dn.host().view(np.uint32)[:T].copy()
+    buckets = bc.host().view(np.uint32)[:T * engine.TRAIN_BUCKETS].reshape(T, engine.TRAIN_BUCKETS).copy()
+    sum_end = eng.state_checksum()
+    plan = eng.train_plan(buckets)
+    eng.train_stamp_device(msgs.ptr, stamps2.ptr, S, counts)
+    eng.synchronize()
+    a, b = stamps.host(), stamps2.host()
+    for t in range(T):
+        n = int(counts[t])
+        assert np.array_equal(a[t * S:t * S + n], b[t * S:t * S + n]), f"generator stamps of tick {t}"
+    eng.set_state(0, st0)
+    eng.train_run_device(plan, 0, T, msgs.ptr, stamps.ptr, S, dec2.ptr, rpcs.ptr, rpc_ring=4)
+    eng.synchronize()
+    assert eng.train_status()[0] == 0
+    for t in range(T):
+        n = int(counts[t])
+        assert _tick(dec2, t, tb, n, abi.DECISION_DTYPE).tobytes() == _tick(dec, t, tb, n, abi.DECISION_DTYPE).tobytes()
+    assert eng.state_checksum() == sum_end
+    plan.close()
+    eng.close()
+
+
+def test_generator_stamps_on_the_block_emulation(emulated_engine):
+    check_generator_stamps(emulated_engine, 192, 5, 12, 0x5EED0003, False)
+
+
+@pytest.mark.gpu
+def test_generator_stamps_on_the_gpu():
+    from ra_amd import engine
+    check_generator_stamps(engine, 4096, 5, 24, 0x5EED0003, True)
+
+
+def check_failed_train_is_repaired(engine, oracle_lib, G, N, seed, faults):
+    """A train launch of rgb_submit that fails -- a stamp that never comes up, a message bucketed under another
+    shard -- is repaired by the engine: the undo logs of the batches in flight go back, the batches run again with one
+    launch per round, rgb_collect hands out exactly what the oracle computes, the batch submitted BEHIND the failed
+    one included (reference: a member's messages apply in order, exactly once, src/ra_server_proc.erl:1356-1397)."""
+    import fuzz
+    from test_gpu_parity import assert_same
+    rng = np.random.default_rng(seed)
+    st = fuzz.random_states(rng, G, N, max_runs=6, backlog=24)
+    cpu = oracle_lib.Oracle(G, N, max_runs=16)
+    cpu.set_state(0, st)
+    with engine.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=4, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        for fault in faults:
+            batches, want = [], []
+            for b in range(3):                              # the faulty batch, then two more behind it in the ring
+                parts = [fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.9) for _ in range(3 if b != 1 else 1)]
+                msgs = np.concatenate(parts)
+                msgs = msgs[msgs["kind"] != abi.MSG_NOP]
+                rng.shuffle(msgs)
+                batches.append(msgs)
+                want.append(cpu.step(msgs))
+            before = gpu.train_recoveries()
+            gpu.inject_train_fault(fault)
+            for b, msgs in enumerate(batches):
+                gpu.submit(msgs, tick=b)
+            for b in range(3):
+                dg, rg, tick = gpu.collect()
+                assert tick == b
+                do, ro = want[b]
+                assert dg.tobytes() == do.tobytes(), f"fault {fault}: decisions of batch {b}"
+                assert fuzz.sort_rpcs(rg).tobytes() == fuzz.sort_rpcs(ro).tobytes(), f"fault {fault}: rpcs of batch {b}"
+            assert gpu.train_recoveries() == before + (1 if fault else 0)
+            assert gpu.get_state().tobytes() == cpu.get_state().tobytes(), f"fault {fault}: state"
+        assert gpu.submit_trains() >= len(faults)
+    cpu.close()
+
+
+def test_failed_train_is_repaired_on_the_block_emulation(emulated_engine, oracle_lib):
+    check_failed_train_is_repaired(emulated_engine, oracle_lib, 1100, 5, 41, faults=(1, 0, 2))
+
+
+@pytest.mark.gpu
+def test_failed_train_is_repaired_on_the_gpu(oracle_lib):
+    from ra_amd import engine
+    check_failed_train_is_repaired(engine, oracle_lib, 4096, 5, 43, faults=(1, 0, 2))
+
+
 def test_train_bucket_matches_the_c_function(emulated_engine):
     engine = emulated_engine
     L = engine.lib()
