@@ -232,6 +232,9 @@ def main():
     ap.add_argument("--launch", choices=("train", "tick"), default="train",
                     help="train: the ticks of one leaderboard period run in ONE launch (rgb_train_run_device: per-server "
                          "sequence stamps instead of kernel boundaries); tick: one class-kernel launch per tick")
+    ap.add_argument("--train-form", choices=("auto", "persistent"), default="auto",
+                    help="auto: the dealt form where the calibration launch shows round-robin dispatch (every block "
+                         "verifies it), else persistent; persistent: RGB_CFG_TRAIN_PERSISTENT")
     ap.add_argument("--snapshot-every", type=int, default=0,
                     help="leaderboard period in ticks (default 16 = SURVEY 8(d) config 4); a train covers one period")
     ap.add_argument("--config4", action="store_true",
@@ -295,7 +298,8 @@ def main():
     NK = abi.N_KINDS
     seed = (args.seed ^ (rank * 0x9E3779B97F4A7C15)) & ((1 << 64) - 1)
 
-    eng = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=2, ring_capacity=1024)
+    eng = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=2, ring_capacity=1024,
+                            flags=abi.CFG_TRAIN_PERSISTENT if args.train_form == "persistent" else 0)
     st0 = W.initial_states(G, N, seed)
     eng.set_state(0, st0)
 
@@ -512,7 +516,7 @@ def main():
             nb = int(n_dec[t]) * 64
             if not torch.equal(d_dec2[t * tick_bytes:t * tick_bytes + nb], d_dec[t * tick_bytes:t * tick_bytes + nb]):
                 raise SystemExit(f"PARITY FAILURE: train decisions of tick {t} differ from the per-tick launches")
-        train_info = {"ticks_per_launch": SNAPSHOT_EVERY, "blocks_per_tick": plan.blocks_per_tick,
+        train_info = {"ticks_per_launch": SNAPSHOT_EVERY, "blocks_per_tick": plan.blocks_per_tick, "form": eng.train_form(),
                       "stamps": "written by the stream's producer (rgb_synth_tick_stamped_device) with the messages: "
                                 "nothing of the train's input preparation is outside the timed region except the host's "
                                 "row plan (256 bucket counts per tick)",

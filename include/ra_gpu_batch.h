@@ -315,6 +315,8 @@ typedef struct rgb_leaderboard_row {
 } rgb_leaderboard_row;
 
 #define RGB_CFG_ROUNDS_PER_LAUNCH 1u   /* rgb_submit: one kernel launch per sub-tick round, never a train (A/B measurements) */
+#define RGB_CFG_TRAIN_PERSISTENT 2u   /* trains always in the persistent form (placement by construction), also on a device
+                                         whose dispatcher deals blocks round robin (see "Train launches") */
 typedef struct rgb_config {
   uint32_t abi_version;          /* RGB_ABI_VERSION                                             */
   int32_t  device;               /* HIP device ordinal                                          */
@@ -435,14 +437,37 @@ int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride
  *
  * Requirements on the ticks: at most one message per server per tick; every tick ordered by BUCKET =
  * rgb_train_bucket(kind, flags, server, n_members) ascending -- (class of the kind, group mod 8, success flag); a
- * tick in that order is also in the clause-family order rgb_run_ticks_device wants.  rgb_synth_tick_buckets_device
- * (ra_gpu_batch_synth.h) writes ticks in this order and their per-bucket counts.
+ * tick in that order is also in the clause-family order rgb_run_ticks_device wants.  The kernel checks the order
+ * (RGB_TRAIN_ERR_ORDER).  Every message carries a STAMP = the value its server's sequence byte must hold when the
+ * message is applied = the number of messages applied to that server before it, mod 256: a producer that counts what
+ * it sends stamps as it writes (rgb_submit does, from its host mirror; rgb_synth_tick_stamped_device does, on the
+ * device); rgb_train_stamp_device is the pass for streams whose producer did not.
+ *
+ * Coherence and the two forms of a launch.  The L2 caches of the XCDs are not coherent with each other, so all
+ * messages of a server must be applied on ONE XCD during a launch: servers are sharded by group mod 8 and a shard's
+ * messages only ever run on one XCD.  PERSISTENT form: the grid is the device's wavefront slots, a block serves the
+ * shard of the XCD it runs on (HW_REG_XCC_ID; shards xcc, xcc + n, .. on a device of n < 8 XCCs) and takes that
+ * shard's rows from a ticket counter -- placement by construction, no assumption about the dispatcher.  DEALT form:
+ * one block per row, block b serves shard b mod 8 -- correct when the dispatcher deals the blocks of a launch round
+ * robin over eight XCDs, 7 % faster where that holds (no ticket in front of every slice).  A context uses the dealt
+ * form only if its calibration launch was dealt that way, EVERY block of every dealt launch verifies its placement
+ * (RGB_TRAIN_ERR_PLACEMENT), and after one failure the context stays with the persistent form;
+ * RGB_CFG_TRAIN_PERSISTENT asks for it from the start; rgb_train_form tells.
+ *
+ * Fail-safe.  A launch that fails (RGB_TRAIN_ERR_*) has applied SOME of its messages.  On the host path the engine
+ * repairs that itself: every batch enqueued while a train is in flight saves the rows of the servers it touches
+ * first (an undo log on the device); when rgb_collect (or any state call) finds a failed launch, the logs of the
+ * batches in flight go back newest first, the batches run again oldest first with one launch per round, and
+ * rgb_collect hands out what a faultless run would have -- every message applied in order, exactly once
+ * (reference: src/ra_server_proc.erl:1356-1397); rgb_train_recoveries counts.  On the device-resident path the
+ * caller owns the streams: rgb_train_status reports the error, the caller restores the state (rgb_upload_state) and
+ * falls back to rgb_run_ticks_device.
  *
  *   rgb_train_plan_create   bucket_counts = uint32[n_ticks][RGB_TRAIN_BUCKETS] (host): builds and uploads the plan.
- *                           The first call of a context also checks, once, that the device places the blocks of one
- *                           shard on one XCD (the L2s of different XCDs are not coherent): RGB_E_UNSUPPORTED if not
- *   rgb_train_stamp_device  d_stamps = uint8[n_ticks * tick_stride], laid out like d_msgs: the sequence value every
- *                           message must find at its server, counted tick by tick (tick_counts[t] messages in tick
+ *                           The first call of a context runs the calibration launch (which XCCs, dealt round robin
+ *                           or not): RGB_E_UNSUPPORTED if the XCC ids are not 0 .. n-1 with n = 1, 2, 4 or 8
+ *   rgb_train_stamp_device  d_stamps = uint8[n_ticks * tick_stride], laid out like d_msgs: the stamps of a stream
+ *                           whose producer did not write them, counted tick by tick (tick_counts[t] messages in tick
  *                           t) from what the servers hold at this point of the stream.  Call it after the trains
  *                           enqueued before (same stream) and before the ones that use the stamps; the messages
  *                           themselves are not touched.
@@ -452,14 +477,15 @@ int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride
  *                           overlap: a region must not be reused within the overlap depth -- 4 is plenty).  More
  *                           than 255 ticks are split into several launches.
  *   rgb_train_status        after the caller synchronised the stream it used: 0 / RGB_E_STATE with the error flags
- *                           (RGB_TRAIN_ERR_*) and, optionally, the XCD every shard runs on.  An error means the launch
- *                           did not compute its ticks (some decisions are unwritten): the caller restores the state
- *                           (rgb_upload_state) and falls back to rgb_run_ticks_device.
- * The per-tick entry points never touch the sequence bytes, so trains and per-tick launches can alternate freely
- * (re-stamp after every change of the sequence, i.e. after every train). */
+ *                           (RGB_TRAIN_ERR_*) and, optionally, the XCD every shard runs on.
+ * The per-tick entry points never touch the sequence bytes, so trains and per-tick launches can alternate freely. */
 #define RGB_TRAIN_BUCKETS 256u
-#define RGB_TRAIN_ERR_PLACEMENT 1u   /* a block ran on another XCD than its shard's (the L2s are not coherent)  */
+#define RGB_TRAIN_ERR_PLACEMENT 1u   /* dealt form: a block ran on another XCD than its shard's (the L2s are not coherent) */
 #define RGB_TRAIN_ERR_SPIN      2u   /* a wavefront's dependencies did not commit within the spin bound        */
+#define RGB_TRAIN_ERR_ORDER     4u   /* a message sits in another shard's bucket: the tick is not in bucket order */
+#define RGB_TRAIN_FORM_NONE       0u /* no train has been set up yet (or the device cannot run them)            */
+#define RGB_TRAIN_FORM_DEALT      1u
+#define RGB_TRAIN_FORM_PERSISTENT 2u
 typedef struct rgb_train_plan rgb_train_plan;
 uint32_t rgb_train_bucket(uint32_t kind, uint32_t flags, uint32_t server, uint32_t n_members);
 int  rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t n_ticks, rgb_train_plan **out);
@@ -471,6 +497,8 @@ int  rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t fir
                           const void *d_msgs, const void *d_stamps, uint32_t tick_stride, void *d_decisions,
                           void *d_rpcs, uint32_t rpc_ring, void *stream);
 int  rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard /* [8] or NULL */);
+uint32_t rgb_train_form(const rgb_ctx *ctx);          /* RGB_TRAIN_FORM_*: how the next train launch will run */
+uint32_t rgb_train_recoveries(const rgb_ctx *ctx);    /* failed train launches of rgb_submit the engine repaired */
 
 /* leaderboard / metrics snapshot: one row per group */
 int  rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out);

@@ -126,6 +126,8 @@ struct rgb_ctx {
   std::atomic<u32> inject_fault{0};     /* tests: RGB_FAULT_* applied to the next train batch (rgb_debug_inject_train_fault) */
   u32 n_xcc = 0;                        /* XCCs of the device (calibration launch): a train block serves the shard of its XCC */
   u32 train_blocks = 0;                 /* blocks of a persistent train launch: every wavefront slot of the device */
+  std::atomic<bool> train_dealt{false}; /* trains run in the dealt form (one block per row): the calibration launch was dealt
+                                           round robin over 8 XCCs and no launch has failed its placement check since */
   int xcc_state = 0;                    /* 0 = not calibrated, 1 = usable, -1 = the XCC ids are not 0 .. n-1 with n | 8 */
 };
 
@@ -515,8 +517,11 @@ static int enqueue_results(rgb_ctx *ctx, rgb_slot &s) {
     if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
   }
   HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc, s.d_nrpc, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-  if (s.used_train)
+  if (s.used_train) {
+    int lr = rgb_launch_train_verify(s.d_ctl, ctx->stream);    /* the launch's placement marks -> the error word */
+    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
     HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc + 1, s.d_ctl, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)s.n * sizeof(rgb_decision), hipMemcpyDeviceToHost, ctx->stream));
   if (s.rpc_cnt)
     HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
@@ -583,7 +588,8 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
     HIPCHK(ctx, hipMemcpyAsync(s.d_rows, s.h_rows, (size_t)s.n_rounds * rows_max * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(s.d_ctl, 0, sizeof(u32), ctx->stream));    /* this slot's own error word */
     int lr = rgb_launch_train(ctx->dev, s.d_msgs, s.d_stamps, 0, s.d_plan, s.d_rows, s.n_rounds, rows_max * RGB_TRAIN_SHARDS,
-                              s.d_dec, s.d_rpcs, 1, 0, s.d_ctl, ctx->n_xcc, ctx->train_blocks, ctx->stream);
+                              s.d_dec, s.d_rpcs, 1, 0, s.d_ctl, ctx->n_xcc,
+                              ctx->train_dealt.load(std::memory_order_relaxed) ? 0u : ctx->train_blocks, ctx->stream);
     if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
     s.used_train = true;
     ctx->trains_in_flight.fetch_add(1, std::memory_order_release);
@@ -786,6 +792,8 @@ static int settle_trains(rgb_ctx *ctx) {
   }
   if (first_bad == 0xFFFFFFFFu) return RGB_OK;
   ctx->n_train_recoveries.fetch_add(1, std::memory_order_relaxed);
+  /* a block on the wrong XCD: this device does not (always) deal round robin -- persistent trains from now on */
+  if (ctx->ring_mem[idx[first_bad]].h_nrpc[1] & RGB_TRAIN_ERR_PLACEMENT) ctx->train_dealt.store(false, std::memory_order_relaxed);
   for (u32 k = m; k-- > first_bad;) {
     rgb_slot &s = ctx->ring_mem[idx[k]];
     if (s.enqueue_error || !s.n) continue;
@@ -1036,14 +1044,16 @@ static int train_scratch(rgb_ctx *ctx) {
   if (ctx->xcc_state == 0) {
     /* which XCCs does the device have?  A train block serves the shard(s) of the XCC it runs on (placement by
      * construction); the ids must be 0 .. n-1 with n dividing the 8 shards */
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, sizeof(u32), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, 2 * sizeof(u32), ctx->stream));
     {
       int rc = rgb_launch_train_calibrate(ctx->d_train_ctl + 1, ctx->stream);
       if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
     }
-    u32 w = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&w, ctx->d_train_ctl + 1, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+    u32 cal[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(cal, ctx->d_train_ctl + 1, sizeof cal, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl + 1, 0, 2 * sizeof(u32), ctx->stream));
+    const u32 w = cal[0];
     u32 n = 0;
     while ((w >> n) & 1u) ++n;
     ctx->train_blocks = rgb_train_resident_blocks(ctx->dev.n_members);
@@ -1051,6 +1061,9 @@ static int train_scratch(rgb_ctx *ctx) {
                     ctx->train_blocks >= RGB_TRAIN_SHARDS;
     ctx->n_xcc = ok ? n : 0;
     ctx->xcc_state = ok ? 1 : -1;
+    /* the dealt form only where the calibration launch was dealt round robin over eight XCCs (one rotation seen) */
+    ctx->train_dealt.store(ok && n == RGB_TRAIN_SHARDS && cal[1] != 0 && (cal[1] & (cal[1] - 1u)) == 0 &&
+                           !(ctx->cfg.flags & RGB_CFG_TRAIN_PERSISTENT), std::memory_order_relaxed);
   }
   return ctx->xcc_state == 1 ? RGB_OK : RGB_E_UNSUPPORTED;
 }
@@ -1144,7 +1157,8 @@ int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t firs
     int rc = rgb_launch_train(ctx->dev, (const rgb_msg *)d_msgs + off, (const unsigned char *)d_stamps + off,
                               tick_stride, plan->d_ticks + t, plan->d_rows + (size_t)t * (plan->bpt / RGB_TRAIN_SHARDS), n,
                               plan->bpt, (rgb_decision *)d_decisions + off,
-                              (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, ctx->n_xcc, ctx->train_blocks, st);
+                              (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, ctx->n_xcc,
+                              ctx->train_dealt.load(std::memory_order_relaxed) ? 0u : ctx->train_blocks, st);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
   return RGB_OK;
@@ -1158,10 +1172,15 @@ int rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard) 
       xcc_of_shard[x] = ctx->xcc_state == 1 ? x % ctx->n_xcc : 0xFFFFFFFFu;
   if (!ctx->d_train_ctl) return RGB_OK;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  {
+    int lr = rgb_launch_train_verify(ctx->d_train_ctl, ctx->stream);   /* the last launch's placement marks */
+    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   u32 w = 0;
   HIPCHK(ctx, hipMemcpy(&w, ctx->d_train_ctl, sizeof w, hipMemcpyDeviceToHost));
   if (flags_out) *flags_out = w;
+  if (w & RGB_TRAIN_ERR_PLACEMENT) ctx->train_dealt.store(false, std::memory_order_relaxed);
   if (w) {
     HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, sizeof(u32)));
     return RGB_E_STATE;
@@ -1237,6 +1256,10 @@ int rgb_debug_read(rgb_ctx *ctx, uint64_t *out, uint32_t n_words) {
  * train launch the engine repaired so far */
 void rgb_debug_inject_train_fault(rgb_ctx *ctx, uint32_t fault) {
   if (ctx) ctx->inject_fault.store(fault, std::memory_order_relaxed);
+}
+uint32_t rgb_train_form(const rgb_ctx *ctx) {
+  if (!ctx || ctx->xcc_state != 1) return RGB_TRAIN_FORM_NONE;
+  return ctx->train_dealt.load(std::memory_order_relaxed) ? RGB_TRAIN_FORM_DEALT : RGB_TRAIN_FORM_PERSISTENT;
 }
 uint32_t rgb_train_recoveries(const rgb_ctx *ctx) { return ctx ? ctx->n_train_recoveries.load(std::memory_order_relaxed) : 0; }
 

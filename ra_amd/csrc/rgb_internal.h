@@ -113,11 +113,10 @@ static inline unsigned rgb_class_of_kind(unsigned kind) { return rgb_kind_rank(k
  * ordered by (class, shard, success flag): see rgb_bucket. */
 #define RGB_TRAIN_SHARDS 8u
 #define RGB_N_BUCKETS ((RGB_N_CLASSES + 1u) * RGB_TRAIN_SHARDS * 2u)   /* 256 */
-#define RGB_TRAIN_ERR_PLACEMENT 1u   /* two blocks of one shard ran on different XCDs                    */
-#define RGB_TRAIN_ERR_SPIN      2u   /* a wavefront's dependencies did not commit within the spin bound */
+/* RGB_TRAIN_ERR_*: include/ra_gpu_batch.h */
 /* control words of a train launch: 0 sticky error flags | 1..7 calibration scratch | 8..15 blocks arrived per XCC |
  * 32 (1 + x): the ticket counter of shard x, one 128-byte line each (rgb_train_kernel) */
-#define RGB_TRAIN_CTL_WORDS (32u * (1u + RGB_TRAIN_SHARDS))
+#define RGB_TRAIN_CTL_WORDS (320u + 32u * 64u)   /* .. | 320 + 32 j, j < 64: the rotation marks of a dealt launch */
 static inline __host__ __device__ unsigned rgb_shard_of_server(unsigned server, unsigned n_members) {
   return (server / n_members) & (RGB_TRAIN_SHARDS - 1u);
 }
@@ -203,6 +202,9 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
                      rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream);
 u32 rgb_train_resident_blocks(unsigned n_members);
+/* the placement marks of the last dealt launch on d_ctl -> RGB_TRAIN_ERR_PLACEMENT in d_ctl[0] (the next launch does
+ * this by itself; the host calls it before it reads the error word) */
+int rgb_launch_train_verify(u32 *d_ctl, void *stream);
 /* stamps of the n messages of one tick from the running counters d_seq_cnt (ticks in train order) */
 int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt,
                          unsigned char *d_stamps, void *stream);

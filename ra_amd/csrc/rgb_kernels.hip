@@ -2358,6 +2358,10 @@ __device__ __forceinline__ u32 rgb_xcc_id() {
 #endif
 #endif
 
+#ifndef RGB_X_TICKET_AT
+#define RGB_X_TICKET_AT 0   /* where a persistent wavefront requests its next row: 0 behind its publish, 1 in front of its
+                               clause code (the rows have arrived), 2 at the start of its slice */
+#endif
 /* Persistent train launches: a wavefront takes the next row of its shard from the shard's ticket counter: one
  * returning atomic by lane 0.  rgb_take_ticket only ISSUES it (the raw value is valid in lane 0); rgb_ticket_value
  * brings it to the whole wavefront where it is consumed, so the atomic's round trip overlaps whatever is issued in
@@ -2415,7 +2419,8 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
                                                u32 rpc_slot_base, u32 msg_index_base, u32 *__restrict__ ctl,
                                                const unsigned char *__restrict__ stamps,
                                                u32 *__restrict__ ticket_ctr = nullptr, u32 *next_ticket = nullptr,
-                                               u32 shard = 0, u32 lane_in = 0) {
+                                               u32 shard = 0, u32 lane_in = 0, const u32 *place_word = nullptr,
+                                               u32 place_bit = 0) {
   const u32 lane = TR ? lane_in : (u32)threadIdx.x;     /* the persistent loop hands in an opaque copy */
 #ifdef RGB_PROFILE
   u64 t0 = 0, t1 = 0, t2 = 0, t2b = 0, tl[4] = {0, 0, 0, 0};
@@ -2434,6 +2439,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #define RGB_TT(k) do { } while (0)
 #endif
   RGB_TT(0);
+  if (TR && RGB_X_TICKET_AT == 2 && ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
   {
     /* four 1 KiB global -> LDS copies in flight (read once: non-temporal), no staging registers and no ds_write
@@ -2476,7 +2482,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     /* 0. every message of the slice belongs to the shard (= the XCD) this wavefront serves: a tick that is not in
      * bucket order must not be computed on another XCD's lines */
     if (__ballot(has_srv && rgb_shard_of_server(sv, (unsigned)N) != shard) != 0ull) {
-      if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
+      if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_ORDER);
       return false;
     }
     /* 1. dependencies: this server's previous message -- an earlier tick of this launch -- has committed */
@@ -2569,6 +2575,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   }
   lds_barrier();
   RGB_TT(3);
+  if (TR && RGB_X_TICKET_AT == 1 && ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
   const ulonglong2 *hrow = io + lane * 8;
   const unsigned hswz = (lane >> 1) & 7u;
   const ulonglong2 *prow = (PEERS_LDS && lead_cls) ? io + 4 * RGB_TICK_BLOCK + lane * 8 : nullptr;
@@ -2636,7 +2643,16 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
      * sit in front of the sequence bytes) and under the decision stores; rgb_train_kernel consumes it at the top of
      * its loop.  Not earlier: a ticket held while this slice runs would start its row a whole wavefront life late,
      * and the rows that depend on it one tick later would find it uncommitted */
-    if (ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
+    if (RGB_X_TICKET_AT == 0 && ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
+    /* dealt trains: this block's rotation mark, fire and forget (no value comes back, nothing waits for it; behind
+     * the publish, so the sequence bytes do not wait for its acknowledgement either) */
+    if (place_word != nullptr && lane == 0) {
+#ifdef RGB_HOST_EMULATION
+      *const_cast<u32 *>(place_word) |= place_bit;
+#else
+      (void)__hip_atomic_fetch_or(const_cast<u32 *>(place_word), place_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
   }
   RGB_TT(5);
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
@@ -2738,7 +2754,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
  * the dispatcher deals blocks to XCDs any more (round 3 assumed round robin and checked one block in 64), every
  * wavefront slot is in use until the launch drains (the in-order round-robin dispatch of one block per slice left
  * ~15 % of the slots empty whenever one XCD was full), and a slice costs no block start.  Every lane checks that its
- * message's server belongs to the block's shard (RGB_TRAIN_ERR_PLACEMENT otherwise: a mis-bucketed tick must not be
+ * message's server belongs to the block's shard (RGB_TRAIN_ERR_ORDER otherwise: a mis-bucketed tick must not be
  * computed on another XCD's lines).
  *
  * Progress: rows are numbered tick-major per shard and tickets are handed out in order, so a wavefront only ever
@@ -2755,9 +2771,6 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
  * -- 4 x 128 measured 24-25 us per tick, 3 x 168 19-20 */
 #ifndef RGB_TRAIN_MIN_WAVES
 #define RGB_TRAIN_MIN_WAVES(N) 3
-#endif
-#ifndef RGB_X_TRAIN_BLOCKS
-#define RGB_X_TRAIN_BLOCKS 0
 #endif
 #define RGB_TRAIN_CTL_ARRIVE 8u     /* ctl words 8..15: blocks arrived per XCC (devices with fewer XCCs than shards) */
 #define RGB_TRAIN_CTL_TICKET 32u    /* ctl word 32 (1 + x): next row of shard x (one 128-byte line per shard)         */
@@ -2776,6 +2789,63 @@ struct rgb_train_args {
   u32 *ctl;
   u32 tick_stride, rpt, n_ticks, rpc_ring, index_base, n_xcc;
 };
+/* DEALT trains (one block per row, block b serves shard b mod 8): the round-3 dispatch, which needs the dispatcher to
+ * deal the blocks of a launch round robin over the XCDs -- block b on XCD (b + r) mod 8, r fixed per launch (what
+ * /opt/skills/guides/cdna_hip_programming.md, "XCD-aware blockIdx swizzle", describes as the default and every
+ * XCD-aware tiling relies on).  It is still VERIFIED, in every launch and for every block: (1) a context only uses
+ * this form when its calibration launch was dealt that way; (2) every block ORs the bit of its rotation
+ * (XCC id - shard) mod 8 into one of RGB_TRAIN_MARK_WORDS control words (a fire-and-forget atomic behind its publish:
+ * no value returns, nothing waits -- a returning atomic or an agent-scope load per block cost 1-5 % of the tick), and
+ * rgb_train_prolog_kernel -- in front of the NEXT launch on the same control words, and behind the last one when the
+ * host asks (rgb_train_status, rgb_submit) -- raises RGB_TRAIN_ERR_PLACEMENT unless all marks of the launch are ONE bit.  rgb_submit then repairs the batch (undo log + one launch per round) and the context goes over
+ * to the persistent form for good.  Measured 2-7 % faster than the persistent form on the 65 536 x 5 closed loop (a
+ * ticket and its row look-up stand ~2 us in front of every slice, and the device is not short of wavefront slots),
+ * which is why it is the default where it holds. */
+#define RGB_TRAIN_MARK_WORDS 64u    /* ctl words 320 + 32 j (one 128-byte line each), j = row mod 64 */
+#define RGB_TRAIN_CTL_MARK 320u
+template <int N>
+__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_dealt_kernel(rgb_train_args args) {
+  __shared__ ulonglong2 io[(RGB_TRAIN_RUNS_LDS && rgb_class_slice(1, (unsigned)N) == 32u) ? 12 * RGB_TICK_BLOCK
+                                                                                         : RGB_TICK_BLOCK * RGB_HOT_SLOT];
+  const u32 x = blockIdx.x & (RGB_TRAIN_SHARDS - 1u), k = blockIdx.x / RGB_TRAIN_SHARDS;
+  const u32 t = k / args.rpt, row = k - t * args.rpt;
+  if (t >= args.n_ticks) return;
+  const rgb_train_tick *p = args.plan + t;
+  if (row >= p->n_rows) return;
+  const u32 e = args.row_tab[(size_t)t * args.rpt + row];
+  const int cls = (int)(e >> 24);
+  const u32 off = p->off[cls][x], ncls = p->cnt[cls][x];
+  constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
+  const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
+  const u32 lbase = (e & 0xFFFFFFu) * SL;
+  if (lbase >= ncls) return;
+  const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
+  const u32 tick_stride = args.tick_stride;
+  const size_t toff = tick_stride ? (size_t)t * tick_stride : (size_t)p->msg_base;
+  rgb_rpc *rp = args.rpcs ? args.rpcs + (tick_stride ? (size_t)(t % args.rpc_ring) * tick_stride : toff) * (N > 1 ? N - 1 : 1) : nullptr;
+  u32 unused = 0;
+  (void)rgb_tick_slice<N, true>(args.dev, io, cls, off + lbase, cnt, SL, args.msgs + toff, args.dec + toff, rp, 0,
+                                args.index_base + (u32)toff, args.ctl, args.stamps + toff, nullptr, &unused, x,
+                                threadIdx.x, args.ctl + RGB_TRAIN_CTL_MARK + 32u * (k & (RGB_TRAIN_MARK_WORDS - 1u)),
+                                1u << ((rgb_xcc_id() - x) & (RGB_TRAIN_SHARDS - 1u)));
+}
+
+/* In FRONT of every train launch (where round 3 had a memset node): the rotation marks the previous dealt launch on
+ * these control words left must be one bit -- all of them have landed, the launches are ordered by the stream --
+ * else RGB_TRAIN_ERR_PLACEMENT (sticky, word 0); then every per-launch word is cleared.  clear = 0: verify only
+ * (rgb_train_status and rgb_submit check the LAST launch this way). */
+__global__ void rgb_train_prolog_kernel(u32 *__restrict__ ctl, u32 clear) {
+  if (threadIdx.x < RGB_TRAIN_MARK_WORDS) {
+    u32 v = ctl[RGB_TRAIN_CTL_MARK + 32u * threadIdx.x];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o, 64);
+    if (threadIdx.x == 0 && (v & (v - 1u)) != 0u) atomicOr(ctl, (u32)RGB_TRAIN_ERR_PLACEMENT);
+  }
+  __syncthreads();
+  if (clear)
+    for (u32 w = 1u + threadIdx.x; w < RGB_TRAIN_CTL_WORDS; w += blockDim.x) ctl[w] = 0u;
+}
+
 template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(rgb_train_args args) {
   /* records, then hot rows; a leader-side slice: 32 hot rows | 32 peers rows | the first line of 32 run tables
@@ -2797,14 +2867,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
       x = (xcc & (n_xcc - 1u)) + n_xcc * (a % (RGB_TRAIN_SHARDS / n_xcc));
     }
   }
-#if RGB_X_TRAIN_BLOCKS
-  /* EXPERIMENT (A/B only): the round-3 dispatch -- one block per row, block b serves shard b mod 8 and RELIES on the
-   * dispatcher dealing blocks round robin over the XCDs; the launcher sizes the grid accordingly */
-  x = blockIdx.x & (RGB_TRAIN_SHARDS - 1u);
-  u32 raw = (threadIdx.x == 0) ? blockIdx.x / RGB_TRAIN_SHARDS : 0u;
-#else
   u32 raw = rgb_take_ticket(args.ctl + RGB_TRAIN_CTL_TICKET * (1u + x), args.ctl);
-#endif
   u32 t = 0, cum = 0;
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
   for (;;) {
@@ -2840,11 +2903,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
     const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
     const u32 lbase = (e & 0xFFFFFFu) * SL;
     u32 *const tk = A->ctl + RGB_TRAIN_CTL_TICKET * (1u + x);
-#if RGB_X_TRAIN_BLOCKS
-    if (lbase >= ncls) break;
-#else
     if (lbase >= ncls) { raw = rgb_take_ticket(tk, A->ctl); continue; }
-#endif
     const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
     /* ticks a fixed stride apart with a ring of rpc regions (device-resident streams), or -- tick_stride = 0 -- packed
      * one behind the other, every message owning the rpc slots of its index in the whole buffer (rgb_submit's rounds) */
@@ -2854,19 +2913,21 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
     lds_barrier();                                        /* the previous slice is done with the staging area */
     raw = 0;
     if (!rgb_tick_slice<N, true>(dev, io, cls, off + lbase, cnt, SL, A->msgs + toff, A->dec + toff, rp, 0,
-                                 A->index_base + (u32)toff, A->ctl, A->stamps + toff,
-                                 RGB_X_TRAIN_BLOCKS ? nullptr : tk, &raw, x, lane))
+                                 A->index_base + (u32)toff, A->ctl, A->stamps + toff, tk, &raw, x, lane))
       break;
-#if RGB_X_TRAIN_BLOCKS
-    break;
-#endif
   }
 }
 
 /* once per context: out[0] |= 1 << (XCC id) over one launch that fills the device: the set of XCC ids blocks run on.
  * The host accepts ids 0 .. n-1 with n = 1, 2, 4 or 8 (a block serves the shards congruent to its XCC id mod n) */
+/* out[1] |= 1 << ((XCC id - blockIdx) mod 8): one bit = the dispatcher dealt this launch round robin (what the
+ * dealt form of a train needs, and checks again in every block of every launch) */
 __global__ void rgb_train_calibrate_kernel(u32 *__restrict__ out) {
-  if (threadIdx.x == 0) atomicOr(out, 1u << rgb_xcc_id());
+  if (threadIdx.x == 0) {
+    const u32 xcc = rgb_xcc_id();
+    atomicOr(out, 1u << xcc);
+    atomicOr(out + 1, 1u << ((xcc - blockIdx.x) & (RGB_TRAIN_SHARDS - 1u)));
+  }
 }
 
 /* Sequence stamps of a train: seq_cnt[i] = the value server (at sequence index i) will hold when the next message
@@ -3636,20 +3697,24 @@ u32 rgb_train_resident_blocks(unsigned n_members) {
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
                      rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream) {
+  /* n_blocks = 0: the DEALT form (one block per row; the caller's calibration showed round-robin dispatch) */
+  const bool dealt = n_blocks == 0;
+  if (dealt) { n_blocks = RGB_TRAIN_SHARDS; n_xcc = RGB_TRAIN_SHARDS; }
   if (n_ticks == 0 || bpt == 0) return 0;
   if (bpt % RGB_TRAIN_SHARDS || n_ticks > RGB_TRAIN_MAX_TICKS) return -1;
   if (n_xcc == 0 || n_xcc > RGB_TRAIN_SHARDS || (n_xcc & (n_xcc - 1u)) != 0 || n_blocks < RGB_TRAIN_SHARDS) return -1;
   hipStream_t st = (hipStream_t)stream;
-  /* the arrival and ticket counters are per launch; the error word (d_ctl[0]) is sticky until it is read */
-  hipError_t e = hipMemsetAsync(d_ctl + 1, 0, (RGB_TRAIN_CTL_WORDS - 1u) * sizeof(u32), st);
-  if (e != hipSuccess) return (int)e;
+  /* the previous launch's rotation marks are verified, then every per-launch word (arrival and ticket counters, the
+   * marks) is cleared; the error word (d_ctl[0]) is sticky until it is read */
+  hipLaunchKernelGGL(rgb_train_prolog_kernel, dim3(1), dim3(256), 0, st, d_ctl, 1u);
   /* never more blocks than rows: a block without a row only costs its ticket */
   const uint64_t rows = (uint64_t)n_ticks * bpt;
   dim3 grid((u32)(rows < n_blocks ? rows : n_blocks)), block(RGB_TICK_BLOCK);
   if (grid.x < RGB_TRAIN_SHARDS) grid.x = RGB_TRAIN_SHARDS;
-#if RGB_X_TRAIN_BLOCKS
-  grid.x = (u32)rows;        /* one block per row of the longest tick, every tick */
-#endif
+  if (dealt) {
+    if (rows > 0x7FFFFFFFull) return -1;
+    grid.x = (u32)rows;      /* one block per row of the longest tick, every tick; surplus blocks exit at once */
+  }
   rgb_train_args args;
   args.dev = dev; args.msgs = d_msgs; args.stamps = d_stamps; args.plan = d_plan; args.row_tab = d_row_tab;
   args.dec = d_dec; args.rpcs = d_rpcs; args.ctl = d_ctl; args.tick_stride = tick_stride;
@@ -3657,13 +3722,19 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
   args.index_base = index_base; args.n_xcc = n_xcc;
 #define LAUNCH(NN)                                                                                      \
   case NN:                                                                                              \
-    hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, args);                                 \
+    if (dealt) hipLaunchKernelGGL(rgb_train_dealt_kernel<NN>, grid, block, 0, st, args);                \
+    else hipLaunchKernelGGL(rgb_train_kernel<NN>, grid, block, 0, st, args);                            \
     break;
   switch (dev.n_members) {
     RGB_LAUNCH_ALL_N
     default: return -1;
   }
 #undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_train_verify(u32 *d_ctl, void *stream) {
+  hipLaunchKernelGGL(rgb_train_prolog_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_ctl, 0u);
   return (int)hipGetLastError();
 }
 

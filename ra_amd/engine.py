@@ -24,11 +24,12 @@ EXPORTS = [
     "rgb_snapshot_device", "rgb_state_checksum", "rgb_synchronize", "rgb_wait", "rgb_wake", "rgb_in_flight",
     "rgb_route", "rgb_submit_trains", "rgb_peek",
     "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
-    "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status",
+    "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status", "rgb_train_form", "rgb_train_recoveries",
 ]
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_tick_buckets_device", "rgb_synth_apply_tick_device",
                  "rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
-OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device"}
+OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device", "rgb_train_form",
+                          "rgb_train_recoveries"}
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -120,6 +121,8 @@ def lib():
         L.rgb_debug_inject_train_fault.restype = None
         L.rgb_train_recoveries.argtypes = [vp]
         L.rgb_train_recoveries.restype = C.c_uint32
+        L.rgb_train_form.argtypes = [vp]
+        L.rgb_train_form.restype = C.c_uint32
     L.rgb_train_bucket.restype = C.c_uint32
     L.rgb_train_bucket.argtypes = [u32, u32, u32, u32]
     L.rgb_train_plan_create.argtypes = [vp, vp, u32, C.POINTER(vp)]
@@ -355,6 +358,9 @@ class RaGpuBatch:
         """Fail-safe tests: the next train batch of submit() gets a fault (1 = a stamp that never comes up,
         2 = two messages bucketed under each other's shard).  The engine must repair the failed launch itself."""
         self._L.rgb_debug_inject_train_fault(self._h, fault)
+
+    def train_form(self) -> str:
+        return {0: "none", 1: "dealt", 2: "persistent"}[int(self._L.rgb_train_form(self._h))] if hasattr(self._L, "rgb_train_form") else "round-3 build"
 
     def train_recoveries(self) -> int:
         return int(self._L.rgb_train_recoveries(self._h))
