@@ -303,6 +303,13 @@ def main():
     st0 = W.initial_states(G, N, seed)
     eng.set_state(0, st0)
 
+    comm = None
+    if use_dist:
+        idt = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).to(dev)
+        dist.broadcast(idt, 0)            # the id travels by the host's own means (here torch.distributed)
+        comm = engine.Comm(eng, idt.cpu().numpy().tobytes(), world, rank)
     # a real (non-default) stream: the kernels, the HIP events and RCCL all run on it
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -316,8 +323,16 @@ def main():
     d_bc = torch.zeros(T * engine.TRAIN_BUCKETS, dtype=torch.int32, device=dev)     # messages per train bucket
     d_kc = torch.zeros(T * NK, dtype=torch.int32, device=dev)
     d_n = torch.zeros(T, dtype=torch.int32, device=dev)           # real size of every tick
-    lb_local = torch.empty(G * 32, dtype=torch.uint8, device=dev)
-    lb_all = torch.empty(world * G * 32, dtype=torch.uint8, device=dev) if use_dist else None
+    # the leaderboard all-gather goes through the C entry point (rgb_leaderboard_allgather: ncclAllGather behind the
+    # boundary, on the launch stream).  Every rank contributes the same number of rows: hash sharding leaves the shards
+    # unequal (--config4), so the rows are padded to the largest shard
+    lb_rows = G
+    if use_dist:
+        gm = torch.tensor([G], dtype=torch.int64, device=dev)
+        dist.all_reduce(gm, op=dist.ReduceOp.MAX)
+        lb_rows = int(gm.item())
+    lb_local = torch.zeros(lb_rows * 32, dtype=torch.uint8, device=dev)
+    lb_all = torch.empty(world * lb_rows * 32, dtype=torch.uint8, device=dev) if use_dist else None
 
     # ---- pass 0 (untimed): age the state.  `age` generator ticks are applied without being kept; the aged
     # state is the starting point of both the generation pass and the timed replay ----
@@ -419,7 +434,7 @@ def main():
             if with_snapshots and nxt % SNAPSHOT_EVERY == 0:
                 eng.snapshot_device(lb_local.data_ptr(), sptr)
                 if use_dist:
-                    dist.all_gather_into_tensor(lb_all, lb_local)
+                    comm.allgather_leaderboard(lb_local.data_ptr(), lb_rows, lb_all.data_ptr(), sptr)
             t = nxt
 
     # ---- pass 2: back to the aged state, warm up, time exactly K ticks ----
@@ -474,7 +489,7 @@ def main():
     def allgather():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        dist.all_gather_into_tensor(lb_all, lb_local)
+        comm.allgather_leaderboard(lb_local.data_ptr(), lb_rows, lb_all.data_ptr(), sptr)
         e1.record(stream)
         ag_events.append((e0, e1))
 
@@ -537,7 +552,8 @@ def main():
                     "ms_per_step_hip_events": [round(float(v), 6) for v in rr[:, 1]],
                     "allgather_us_per_call": [round(float(v), 2) for v in rr[:, 2]],
                     "allgathers_in_timed_region": int(rr[0, 3]),
-                    "allgather_bytes_per_rank": int(G * 32)}
+                    "allgather_bytes_per_rank": int(lb_rows * 32),
+                    "allgather": "rgb_leaderboard_allgather (C ABI; ncclAllGather over xGMI on the launch stream)"}
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())

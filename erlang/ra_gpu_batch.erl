@@ -15,7 +15,8 @@
 -module(ra_gpu_batch).
 
 -export([init/0, open/4, register_groups/3, upload_state/3, download_state/3, register_owner/4, unregister_owner/2, owner_slots/1, fan_back_stats/1, route/2,
-         submit/3, collect/1, start_collector/2, stop_collector/1, snapshot/2, wal_checksums/3]).
+         submit/3, collect/1, start_collector/2, stop_collector/1, snapshot/2, wal_checksums/3,
+         comm_unique_id/0, comm_init/4, allgather_leaderboard/2, node_leaderboard/3]).
 -export([wal_batch_checksums/2, wal_frame/4, wal_recover_check/2, wal_frame_batch/3, wal_recover/2]).
 -export([encode_msg/3, decode_decision/1, decision_to_effects/3]).
 
@@ -91,6 +92,32 @@ collect(_Ctx) -> erlang:nif_error(not_loaded).
 start_collector(_Ctx, _Pid) -> erlang:nif_error(not_loaded).
 stop_collector(_Ctx) -> erlang:nif_error(not_loaded).
 snapshot(_Ctx, _NGroups) -> erlang:nif_error(not_loaded).
+%% The node-wide leaderboard over the GPUs of one node (one context per GPU, groups routed by route/2; the reference's
+%% ra_leaderboard is one ETS table per node, src/ra_leaderboard.erl:18-26): RCCL all-gather behind the C ABI.
+%% comm_unique_id() -> {ok, <<Id:128/binary>>} on ONE context's owner, Id sent to the others as a plain message;
+%% comm_init(Ctx, Id, NRanks, Rank) -> ok and allgather_leaderboard(Ctx, NRows) -> {ok, RowsBin} are collective: the
+%% owner process of every context calls them (dirty scheduler), NRows = the largest group count of any context.
+comm_unique_id() -> erlang:nif_error(not_loaded).
+comm_init(_Ctx, _Id, _NRanks, _Rank) -> erlang:nif_error(not_loaded).
+allgather_leaderboard(_Ctx, _NRows) -> erlang:nif_error(not_loaded).
+
+%% node_leaderboard(Ctx, NRows, GroupsOfRank) -> [{GroupUId, LeaderSlot | undefined, Term, CommitIndex, LastApplied}]
+%% for EVERY group of the node, from this context's side of the collective: GroupsOfRank(Rank) -> [GroupUId] ascending
+%% (the groups with route(GroupUId, NRanks) =:= Rank, in local-id order).  What ra_leaderboard:lookup_leader/1 and the
+%% commit_index / last_applied gauges of ra:key_metrics/1 (src/ra.erl:1242-1270) read, for all GPUs at once.
+node_leaderboard(Ctx, NRows, GroupsOfRank) ->
+    {ok, Bin} = allgather_leaderboard(Ctx, NRows),
+    RowBytes = 32,
+    NRanks = byte_size(Bin) div (NRows * RowBytes),
+    lists:append(
+      [begin
+           Shard = binary:part(Bin, Rank * NRows * RowBytes, NRows * RowBytes),
+           [begin
+                <<Leader:32/little, _NLeaders:32/little, Term:64/little, CI:64/little, LA:64/little>> =
+                    binary:part(Shard, K * RowBytes, RowBytes),
+                {UId, case Leader of 255 -> undefined; _ -> Leader end, Term, CI, LA}
+            end || {K, UId} <- lists:zip(lists:seq(0, length(GroupsOfRank(Rank)) - 1), GroupsOfRank(Rank))]
+       end || Rank <- lists:seq(0, NRanks - 1)]).
 wal_checksums(_Ctx, _EntriesBin, _DataBin) -> erlang:nif_error(not_loaded).
 
 wal_frame(_Ctx, _RecordsBin, _DataBin, _Flags) -> erlang:nif_error(not_loaded).

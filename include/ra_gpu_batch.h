@@ -340,7 +340,8 @@ enum {
   RGB_E_FULL        = -5,  /* staging ring full: collect first        */
   RGB_E_EMPTY       = -6,  /* nothing submitted                       */
   RGB_E_UNSUPPORTED = -7,
-  RGB_E_NODEVICE    = -8   /* no HIP device: there is no CPU fallback */
+  RGB_E_NODEVICE    = -8,  /* no HIP device: there is no CPU fallback */
+  RGB_E_COMM        = -9   /* RCCL failed: rgb_comm_last_error()      */
 };
 
 uint32_t    rgb_abi_version(void);
@@ -407,6 +408,31 @@ uint32_t rgb_in_flight(const rgb_ctx *ctx);
  * ra_leaderboard / the ra_directory lookup give the reference, src/ra_leaderboard.erl:18-26): the context
  * (one per GPU) that owns a Raft group = splitmix64(group_uid) mod n_contexts.  Pure function. */
 uint32_t rgb_route(uint64_t group_uid, uint32_t n_contexts);
+
+/* ---- Multi-GPU: the one collective of the path ----
+ * Groups are independent, so the decision path has no exchange step; what a node-wide view needs is the gathered
+ * leaderboard / key-metrics snapshot (ra_leaderboard is a node-wide ETS table, src/ra_leaderboard.erl:18-26; the
+ * gauges of src/ra.erl:1242-1270 are read per server): every context (one per GPU) produces one rgb_leaderboard_row per
+ * LOCAL group (rgb_snapshot_device) and rgb_leaderboard_allgather gathers the shards of all ranks with RCCL
+ * (ncclAllGather over xGMI) on the stream the caller gives -- the train launches' stream: ordered behind the snapshot
+ * kernel, no event.  One rank creates the id (rgb_comm_unique_id) and hands its RGB_COMM_ID_BYTES to the others by
+ * whatever the host has (Erlang distribution for the NIF: INTEGRATION.md); rgb_comm_init_rank is collective.  Every
+ * rank contributes the SAME n_rows (hash sharding leaves the shards unequal: pad to the largest); rank r's rows land at
+ * d_rows_all + r * n_rows.  RCCL is bound at run time (dlopen; a copy already in the process is used):
+ * RGB_E_UNSUPPORTED when there is none, RGB_E_COMM with rgb_comm_last_error() for an RCCL failure. */
+#define RGB_COMM_ID_BYTES 128u
+typedef struct rgb_comm rgb_comm;
+int  rgb_comm_unique_id(void *id_out /* RGB_COMM_ID_BYTES */);
+int  rgb_comm_init_rank(rgb_ctx *ctx, const void *id, uint32_t n_ranks, uint32_t rank, rgb_comm **out);
+void rgb_comm_destroy(rgb_comm *comm);
+uint32_t rgb_comm_n_ranks(const rgb_comm *comm);
+uint32_t rgb_comm_rank(const rgb_comm *comm);
+int  rgb_leaderboard_allgather(rgb_ctx *ctx, rgb_comm *comm, const void *d_rows_local, uint32_t n_rows,
+                               void *d_rows_all /* n_ranks * n_rows rows */, void *stream);
+/* the same with host buffers (the NIF's form): this context's rows are produced, padded to n_rows >= its group
+ * count, gathered and copied to rows_all (n_ranks * n_rows rows); synchronous */
+int  rgb_leaderboard_allgather_host(rgb_ctx *ctx, rgb_comm *comm, uint32_t n_rows, rgb_leaderboard_row *rows_all);
+const char *rgb_comm_last_error(void);
 
 /* Device-resident path (benchmarks, device-side producers): d_msgs holds n_ticks ticks laid out
  * tick_stride messages apart; tick t carries tick_counts[t] messages (host array; NULL = every

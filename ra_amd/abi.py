@@ -75,8 +75,9 @@ F_CANCEL_SNAPSHOT_RETRY = 1 << 27
 
 RPC_AER, RPC_SNAPSHOT = 1, 2
 
-OK, E_INVAL, E_NOMEM, E_HIP, E_STATE, E_FULL, E_EMPTY, E_UNSUPPORTED, E_NODEVICE = (
-    0, -1, -2, -3, -4, -5, -6, -7, -8)
+OK, E_INVAL, E_NOMEM, E_HIP, E_STATE, E_FULL, E_EMPTY, E_UNSUPPORTED, E_NODEVICE, E_COMM = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9)
+COMM_ID_BYTES = 128
 
 u8, u16, u32, u64, i32 = np.uint8, np.uint16, np.uint32, np.uint64, np.int32
 

@@ -53,6 +53,7 @@ typedef struct {
   atomic_ullong fb_ns, fb_decisions, fb_batches;   /* time the collector thread spent in fan_back (fan_back_stats/1) */
   uint32_t *tix; uint32_t tix_cap, tix_gen;   /* fan_back scratch: per-slot position in the batch's owner list, generation-stamped */
   atomic_int collector_on, stop;
+  rgb_comm *comm;                  /* this context's rank in the node's leaderboard all-gather (comm_init/4), or NULL */
 } nif_ctx;
 
 static ErlNifResourceType *CTX_TYPE;
@@ -62,10 +63,10 @@ static ERL_NIF_TERM mk_error(ErlNifEnv *env, nif_ctx *c, int rc) {
     return enif_make_tuple2(env, enif_make_atom(env, "error"),
                             enif_make_tuple2(env, enif_make_atom(env, "hip"),
                                              enif_make_int(env, c ? rgb_last_hip_error(c->ctx) : 0)));
-  static const char *names[] = {"ok", "invalid", "nomem", "hip", "state", "full", "empty", "unsupported", "nodevice"};
+  static const char *names[] = {"ok", "invalid", "nomem", "hip", "state", "full", "empty", "unsupported", "nodevice", "comm"};
   int k = -rc;
   return enif_make_tuple2(env, enif_make_atom(env, "error"),
-                          enif_make_atom(env, (k >= 0 && k <= 8) ? names[k] : "unknown"));
+                          enif_make_atom(env, (k >= 0 && k <= 9) ? names[k] : "unknown"));
 }
 
 static void ctx_dtor(ErlNifEnv *env, void *obj) {
@@ -78,6 +79,8 @@ static void ctx_dtor(ErlNifEnv *env, void *obj) {
     rgb_wake(c->ctx);
     enif_thread_join(c->tid, NULL);
   }
+  if (c->comm) rgb_comm_destroy(c->comm);
+  c->comm = NULL;
   if (c->ctx) rgb_close(c->ctx);
   c->ctx = NULL;
   if (c->own_mu) enif_mutex_destroy(c->own_mu);
@@ -476,6 +479,44 @@ static ERL_NIF_TERM nif_route(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[
   return enif_make_uint(env, rgb_route(uid, n));
 }
 
+/* ---- the node's leaderboard all-gather (one context per GPU; include/ra_gpu_batch.h "Multi-GPU") ----
+ * comm_unique_id() -> {ok, <<Id:128/binary>>}: one context's owner creates the id and sends it to the owners of the
+ * others (plain Erlang messages); comm_init(Ctx, Id, NRanks, Rank) -> ok is collective -- every owner calls it, on a
+ * dirty scheduler, before any of them returns; allgather_leaderboard(Ctx, NRows) -> {ok, <<rgb_leaderboard_row x NRanks
+ * x NRows>>}: collective as well, NRows = the largest group count of any context (rank r's rows start at r * NRows;
+ * the rows beyond a context's own groups are zero) */
+static ERL_NIF_TERM nif_comm_unique_id(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  ErlNifBinary b;
+  (void)argc; (void)argv;
+  if (!enif_alloc_binary(RGB_COMM_ID_BYTES, &b)) return mk_error(env, NULL, RGB_E_NOMEM);
+  int rc = rgb_comm_unique_id(b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, NULL, rc); }
+  return enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_binary(env, &b));
+}
+
+static ERL_NIF_TERM nif_comm_init(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c; ErlNifBinary id; unsigned n, rank;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &id) || id.size != RGB_COMM_ID_BYTES ||
+      !enif_get_uint(env, argv[2], &n) || !enif_get_uint(env, argv[3], &rank) || c->comm != NULL)
+    return enif_make_badarg(env);
+  int rc = rgb_comm_init_rank(c->ctx, id.data, n, rank, &c->comm);
+  if (rc) return mk_error(env, c, rc);
+  return enif_make_atom(env, "ok");
+}
+
+static ERL_NIF_TERM nif_allgather_leaderboard(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
+  nif_ctx *c; unsigned n_rows; ErlNifBinary b;
+  (void)argc;
+  if (!get_ctx(env, argv[0], &c) || !enif_get_uint(env, argv[1], &n_rows) || c->comm == NULL || n_rows < c->n_groups)
+    return enif_make_badarg(env);
+  const size_t rows = (size_t)n_rows * rgb_comm_n_ranks(c->comm);
+  if (!enif_alloc_binary(rows * sizeof(rgb_leaderboard_row), &b)) return mk_error(env, c, RGB_E_NOMEM);
+  int rc = rgb_leaderboard_allgather_host(c->ctx, c->comm, n_rows, (rgb_leaderboard_row *)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, c, rc); }
+  return enif_make_tuple2(env, enif_make_atom(env, "ok"), enif_make_binary(env, &b));
+}
+
 static int on_load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info) {
   (void)priv; (void)info;
   CTX_TYPE = enif_open_resource_type(env, NULL, "ra_gpu_batch_ctx", ctx_dtor, ERL_NIF_RT_CREATE, NULL);
@@ -558,6 +599,9 @@ static ErlNifFunc nif_funcs[] = {
   {"start_collector", 2, nif_start_collector, 0},
   {"stop_collector", 1, nif_stop_collector, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"snapshot", 2, nif_snapshot, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"comm_unique_id", 0, nif_comm_unique_id, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"comm_init", 4, nif_comm_init, ERL_NIF_DIRTY_JOB_IO_BOUND},
+  {"allgather_leaderboard", 2, nif_allgather_leaderboard, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"wal_checksums", 3, nif_wal_checksums, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"wal_frame", 4, nif_wal_frame, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"wal_recover_check", 2, nif_wal_recover_check, ERL_NIF_DIRTY_JOB_IO_BOUND},

@@ -112,6 +112,8 @@ struct rgb_ctx {
   /* snapshot / checksum scratch */
   rgb_leaderboard_row *d_rows = nullptr;
   u64 *d_sums = nullptr;
+  void *d_lb_gather = nullptr;      /* rgb_leaderboard_allgather_host: this rank's padded rows | the gathered rows */
+  size_t lb_gather_bytes = 0;
   u32 *d_synth = nullptr;     /* load-generator scratch (family and bucket counters) */
   unsigned char *d_synth_sent = nullptr;   /* load generator: messages addressed to every server so far, mod 256 (its stamps) */
   /* train launches */
@@ -177,6 +179,7 @@ const char *rgb_strerror(int code) {
     case RGB_E_EMPTY: return "nothing submitted";
     case RGB_E_UNSUPPORTED: return "unsupported";
     case RGB_E_NODEVICE: return "no HIP device (there is no CPU fallback)";
+    case RGB_E_COMM: return "RCCL error (see rgb_comm_last_error)";
     default: return "unknown error";
   }
 }
@@ -250,6 +253,7 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+  if (ctx->d_lb_gather) (void)hipFree(ctx->d_lb_gather);
   if (ctx->d_synth) (void)hipFree(ctx->d_synth);
   if (ctx->d_synth_sent) (void)hipFree(ctx->d_synth_sent);
   if (ctx->d_train_ctl) (void)hipFree(ctx->d_train_ctl);
@@ -986,6 +990,11 @@ int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
 /* internal: the context's default stream (rgb_wal.hip) */
 void *rgb_ctx_stream(rgb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rgb_ctx_device(rgb_ctx *ctx) { return ctx ? ctx->cfg.device : 0; }
+int rgb_ctx_set_device(rgb_ctx *ctx) {
+  if (!ctx) return RGB_E_INVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  return RGB_OK;
+}
 
 int rgb_synth_tick_stamped_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
                                   void *d_n, void *d_bucket_counts, void *d_stamps, void *stream) {
@@ -1218,6 +1227,36 @@ int rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out) {
   if (rc) return rc;
   u32 g = ctx->dev.n_servers / ctx->dev.n_members;
   HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_rows, (size_t)g * sizeof(rgb_leaderboard_row), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return RGB_OK;
+}
+
+/* host-buffer form of the leaderboard all-gather (what the NIF hands out as a binary): this context's rows are
+ * produced on the device, padded to n_rows, gathered with rgb_leaderboard_allgather on the context's stream and
+ * copied to rows_all (n_ranks * n_rows rows) */
+int rgb_leaderboard_allgather_host(rgb_ctx *ctx, rgb_comm *comm, uint32_t n_rows, rgb_leaderboard_row *rows_all) {
+  if (!ctx || !comm || !rows_all) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  const u32 g = ctx->dev.n_servers / ctx->dev.n_members, world = rgb_comm_n_ranks(comm);
+  if (n_rows < g || world == 0) return RGB_E_INVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  rgb_stream_turn turn(ctx);
+  if (turn.rc) return turn.rc;
+  const size_t need = (size_t)n_rows * (world + 1u) * sizeof(rgb_leaderboard_row);
+  if (ctx->lb_gather_bytes < need) {
+    if (ctx->d_lb_gather) (void)hipFree(ctx->d_lb_gather);
+    ctx->d_lb_gather = nullptr; ctx->lb_gather_bytes = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_lb_gather, need));
+    ctx->lb_gather_bytes = need;
+  }
+  rgb_leaderboard_row *d_local = (rgb_leaderboard_row *)ctx->d_lb_gather, *d_all = d_local + n_rows;
+  HIPCHK(ctx, hipMemsetAsync(d_local, 0, (size_t)n_rows * sizeof(rgb_leaderboard_row), ctx->stream));
+  int rc = rgb_snapshot_device(ctx, d_local, ctx->stream);
+  if (rc) return rc;
+  rc = rgb_leaderboard_allgather(ctx, comm, d_local, n_rows, d_all, ctx->stream);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(rows_all, d_all, (size_t)n_rows * world * sizeof(rgb_leaderboard_row), hipMemcpyDeviceToHost,
                              ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return RGB_OK;

@@ -26,10 +26,12 @@ EXPORTS = [
     "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status", "rgb_train_form", "rgb_train_recoveries",
 ]
+COMM_EXPORTS = ["rgb_comm_unique_id", "rgb_comm_init_rank", "rgb_comm_destroy", "rgb_comm_n_ranks", "rgb_comm_rank",
+                "rgb_leaderboard_allgather", "rgb_comm_last_error"]        # the one collective of the path (RCCL)
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_tick_buckets_device", "rgb_synth_apply_tick_device",
                  "rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
 OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device", "rgb_train_form",
-                          "rgb_train_recoveries"}
+                          "rgb_train_recoveries"} | set(COMM_EXPORTS)
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -42,7 +44,7 @@ class RgbError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("rgb_kernels.hip", "rgb_api.hip", "rgb_wal.hip", "rgb_wal_host.cpp", "rgb_internal.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("rgb_kernels.hip", "rgb_api.hip", "rgb_wal.hip", "rgb_wal_host.cpp", "rgb_comm.cpp", "rgb_internal.h")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "ra_gpu_wal.h"))
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "ra_gpu_batch.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
@@ -73,7 +75,7 @@ def lib():
     except Exception:  # pragma: no cover - torch is optional for the binding
         pass
     L = C.CDLL(LIB_PATH)
-    for name in EXPORTS + SYNTH_EXPORTS + WAL_EXPORTS:
+    for name in EXPORTS + COMM_EXPORTS + SYNTH_EXPORTS + WAL_EXPORTS:
         if not hasattr(L, name):
             # tools/ only: RGB_LIB=<an older build> for same-box A/B timing of bench.py (tools/gpu_ab.sh --variants)
             if os.environ.get("RGB_LIB") and name in OPTIONAL_IN_OLD_BUILDS:
@@ -116,6 +118,17 @@ def lib():
     if hasattr(L, "rgb_synth_tick_stamped_device"):
         L.rgb_synth_tick_stamped_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp, vp]
         L.rgb_synth_stamps_resync_device.argtypes = [vp, vp]
+    if hasattr(L, "rgb_comm_init_rank"):
+        L.rgb_comm_unique_id.argtypes = [vp]
+        L.rgb_comm_init_rank.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+        L.rgb_comm_destroy.argtypes = [vp]
+        L.rgb_comm_destroy.restype = None
+        L.rgb_comm_n_ranks.argtypes = [vp]
+        L.rgb_comm_n_ranks.restype = C.c_uint32
+        L.rgb_comm_rank.argtypes = [vp]
+        L.rgb_comm_rank.restype = C.c_uint32
+        L.rgb_leaderboard_allgather.argtypes = [vp, vp, vp, u32, vp, vp]
+        L.rgb_comm_last_error.restype = C.c_char_p
     if hasattr(L, "rgb_debug_inject_train_fault"):
         L.rgb_debug_inject_train_fault.argtypes = [vp, u32]
         L.rgb_debug_inject_train_fault.restype = None
@@ -437,6 +450,45 @@ class RaGpuBatch:
 
 
 TRAIN_BUCKETS = 256
+
+
+def comm_unique_id() -> bytes:
+    """RGB_COMM_ID_BYTES of a fresh communicator id (one rank creates it, the others receive it from the host)."""
+    buf = C.create_string_buffer(abi.COMM_ID_BYTES)
+    rc = lib().rgb_comm_unique_id(buf)
+    if rc:
+        raise RgbError(rc, "rgb_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """rgb_comm: this context's rank in the leaderboard all-gather (RCCL behind the C ABI)."""
+
+    def __init__(self, eng: "RaGpuBatch", comm_id: bytes, n_ranks: int, rank: int):
+        assert len(comm_id) == abi.COMM_ID_BYTES
+        self.eng, self.n_ranks, self.rank = eng, n_ranks, rank
+        h = C.c_void_p()
+        rc = eng._L.rgb_comm_init_rank(eng._h, comm_id, n_ranks, rank, C.byref(h))
+        if rc:
+            raise RgbError(rc, f"rgb_comm_init_rank: {eng._L.rgb_comm_last_error().decode()}")
+        self.h = h
+
+    def allgather_leaderboard(self, d_rows_local: int, n_rows: int, d_rows_all: int, stream: int = 0):
+        """Every rank's n_rows leaderboard rows (device memory) -> d_rows_all[rank * n_rows ..], on `stream`."""
+        rc = self.eng._L.rgb_leaderboard_allgather(self.eng._h, self.h, d_rows_local, n_rows, d_rows_all, stream or None)
+        if rc:
+            raise RgbError(rc, f"rgb_leaderboard_allgather: {self.eng._L.rgb_comm_last_error().decode()}")
+
+    def close(self):
+        if self.h:
+            self.eng._L.rgb_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class TrainPlan:

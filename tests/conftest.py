@@ -36,7 +36,7 @@ def emulated_kernels_so(tmp_path_factory):
            "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-function", "-Wno-unused-variable",
            "-I", os.path.join(nat, "fake_hip"), "-I", os.path.join(ROOT, "include"), "-o", str(out),
            os.path.join(nat, "api_on_cpu.cpp"), os.path.join(nat, "kernel_on_cpu.cpp"),
-           os.path.join(nat, "wal_on_cpu.cpp")]
+           os.path.join(nat, "wal_on_cpu.cpp"), os.path.join(nat, "comm_on_cpu.cpp")]
     # opt-in: compile-time experiment switches of the kernels (tools/build_variants.sh) through the emulation,
     # e.g. RGB_EMU_CXXFLAGS="-DRGB_X_COOPWB=2 -DRGB_X_RPC16=2"
     extra = os.environ.get("RGB_EMU_CXXFLAGS")

@@ -1,6 +1,6 @@
 """The N>1 path on REAL GPUs (BASELINE configs[3]): one process and one rgb_ctx per GPU over its hash
-shard (rgb_route), no data-path collective, the leaderboard shards all-gathered with RCCL (`nccl` backend) exactly as
-bench.py does between trains.  Skipped unless the box has at least two GPUs -- the pool's test boxes have one, the
+shard (rgb_route), no data-path collective, the leaderboard shards all-gathered with RCCL through the C entry point
+(rgb_leaderboard_allgather) exactly as bench.py does between trains.  Skipped unless the box has at least two GPUs -- the pool's test boxes have one, the
 driver's scaling node has eight: the first multi-GPU contact is then a PARITY run, not only a timing.
 
 What is compared: (i) the RCCL-gathered leaderboard of every rank against ONE process that computes every group with
@@ -84,7 +84,14 @@ def _rccl_worker(rank, world, port, out_dir, g_global):
         ids[:G] = torch.from_numpy(mine.astype(np.int64)).to(dev)
         lb_all = torch.empty(world * m * 32, dtype=torch.uint8, device=dev)
         id_all = torch.empty(world * m, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(lb_all, lb)
+        # the leaderboard shards through the C entry point (rgb_leaderboard_allgather = ncclAllGather behind the
+        # boundary, what the NIF calls); the communicator id travels from rank 0 by the host's own means
+        idt = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).to(dev)
+        dist.broadcast(idt, 0)
+        comm = engine.Comm(eng, idt.cpu().numpy().tobytes(), world, rank)
+        comm.allgather_leaderboard(lb.data_ptr(), m, lb_all.data_ptr(), stream.cuda_stream)
         dist.all_gather_into_tensor(id_all, ids)
         torch.cuda.synchronize()
         ids_h = id_all.cpu().numpy()
@@ -94,6 +101,7 @@ def _rccl_worker(rank, world, port, out_dir, g_global):
         np.save(os.path.join(out_dir, f"uids_{world}_{rank}.npy"), ids_h[keep][order].astype(np.uint64))
         np.save(os.path.join(out_dir, f"rows_{world}_{rank}.npy"), rows_h[keep][order].view(np.uint8))
         np.save(os.path.join(out_dir, f"sum_{world}_{rank}.npy"), np.array([eng.state_checksum()], dtype=np.uint64))
+        comm.close()
     dist.destroy_process_group()
 
 
@@ -146,3 +154,24 @@ def test_checker_side_of_the_multi_gpu_test(oracle_lib):
                 rows[int(g)] = row
         got = np.array([rows[g] for g in range(g_global)], dtype=abi.LEADERBOARD_DTYPE)
         assert got.tobytes() == ref_rows.tobytes()
+
+
+@pytest.mark.gpu
+def test_c_allgather_with_one_rank_on_the_gpu():
+    """The RCCL binding behind the C ABI on the pool's one-GPU boxes: a communicator of one rank (ncclCommInitRank from a
+    C-created id), rgb_leaderboard_allgather on the launch stream = the rank's own rows, bit for bit."""
+    import torch
+    from ra_amd import engine
+    G = 1024
+    with engine.RaGpuBatch(G, N, max_runs=16, ring_capacity=64, ring_slots=1) as eng:
+        eng.set_state(0, W.initial_states(G, N, SEED))
+        comm = engine.Comm(eng, engine.comm_unique_id(), 1, 0)
+        stream = torch.cuda.Stream()
+        lb = torch.zeros(G * 32, dtype=torch.uint8, device="cuda")
+        lb_all = torch.zeros(G * 32, dtype=torch.uint8, device="cuda")
+        eng.snapshot_device(lb.data_ptr(), stream.cuda_stream)
+        comm.allgather_leaderboard(lb.data_ptr(), G, lb_all.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        want = eng.snapshot()
+        assert lb_all.cpu().numpy().tobytes() == want.tobytes()
+        comm.close()

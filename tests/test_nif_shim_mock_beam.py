@@ -153,6 +153,18 @@ def test_shim_round_trip_against_the_checker(beam, oracle_lib):
     assert beam.call("snapshot", ctx, G + 1) == "badarg"
     # an error code from the library comes back as {error, Atom}
     assert beam.call("download_state", ctx, G * N, 8) == ("error", "invalid")
+    # the node's leaderboard all-gather through the shim (one rank here): the gathered binary = this context's rows,
+    # padded to NRows; before comm_init/4 and with too few rows it is badarg
+    assert beam.call("allgather_leaderboard", ctx, G) == "badarg"
+    ok, comm_id = beam.call("comm_unique_id")
+    assert ok == "ok" and len(comm_id) == abi.COMM_ID_BYTES
+    assert beam.call("comm_init", ctx, comm_id[:-1], 1, 0) == "badarg"
+    assert beam.call("comm_init", ctx, comm_id, 1, 0) == "ok"
+    assert beam.call("comm_init", ctx, comm_id, 1, 0) == "badarg"          # once per context
+    assert beam.call("allgather_leaderboard", ctx, G - 1) == "badarg"
+    ok, gathered = beam.call("allgather_leaderboard", ctx, G + 3)
+    assert ok == "ok" and len(gathered) == (G + 3) * 32
+    assert gathered[:G * 32] == lb and gathered[G * 32:] == b"\0" * (3 * 32)
 
     # the last reference goes away: the destructor runs rgb_close exactly once
     beam.L.mock_gc_resource_term(ctx.t)

@@ -98,8 +98,37 @@ def _engine_worker(rank, world, port, out_dir, emu_so, g_global):
                 m["server"] += k * N
                 msgs.append(m)
             eng.step(np.concatenate(msgs))
-        rows = eng.snapshot()
-    uids, allrows = shard.all_gather_leaderboard(rows, mine, dist)
+        # the all-gather through the C entry point (rgb_leaderboard_allgather): the id travels from rank 0 by the
+        # host's own means (here gloo), every rank pads its shard to the largest one, rank r's rows land at
+        # r * n_rows.  In the emulated library the transport under the entry point is a callback (here gloo); in the
+        # product it is ncclAllGather over xGMI (tests/test_multi_gpu.py on a box with two GPUs).
+        import ctypes as C
+        counts = [len(shard.local_group_ids(g_global, world, r)) for r in range(world)]
+        n_rows = max(counts)
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32)
+        def transport(local, nbytes, allp, n_ranks, rk):
+            src = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(local)).copy())
+            out = torch.empty(nbytes * n_ranks, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, src)
+            C.memmove(allp, out.numpy().ctypes.data, nbytes * n_ranks)
+            return 0
+        L.emu_comm_set_transport(transport)
+        idt = torch.zeros(abi.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(idt, 0)
+        comm = engine.Comm(eng, bytes(idt.numpy().tobytes()), world, rank)
+        local = np.zeros(n_rows, dtype=abi.LEADERBOARD_DTYPE)
+        eng.snapshot_device(local.ctypes.data)                  # "device" memory of the emulation is host memory
+        eng.synchronize()
+        gathered = np.zeros(world * n_rows, dtype=abi.LEADERBOARD_DTYPE)
+        comm.allgather_leaderboard(local.ctypes.data, n_rows, gathered.ctypes.data)
+        comm.close()
+    uids = np.concatenate([shard.local_group_ids(g_global, world, r) for r in range(world)])
+    allrows = np.concatenate([gathered[r * n_rows:r * n_rows + counts[r]] for r in range(world)])
+    order = np.argsort(uids, kind="stable")
+    uids, allrows = uids[order], allrows[order]
     np.save(os.path.join(out_dir, f"e_uids_{rank}.npy"), uids)
     np.save(os.path.join(out_dir, f"e_rows_{rank}.npy"), allrows.view(np.uint8))
     dist.destroy_process_group()

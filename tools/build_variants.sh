@@ -10,7 +10,7 @@ pids=()
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-parameter -mllvm -disable-machine-licm -DRGB_X_ONLY_N=${ONLY_N:-5} $flags -shared \
-      -o variants/$name.so rgb_kernels.hip rgb_api.hip rgb_wal.hip rgb_wal_host.cpp > variants/$name.log 2>&1 \
+      -o variants/$name.so rgb_kernels.hip rgb_api.hip rgb_wal.hip rgb_wal_host.cpp rgb_comm.cpp -ldl > variants/$name.log 2>&1 \
       && echo "built $name ($flags)" || { echo "FAILED $name"; tail -5 variants/$name.log; } ) &
   pids+=($!)
   if [ ${#pids[@]} -ge ${JOBS:-6} ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); fi
