@@ -27,7 +27,8 @@ EXPORTS = [
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status", "rgb_train_form", "rgb_train_recoveries",
 ]
 COMM_EXPORTS = ["rgb_comm_unique_id", "rgb_comm_init_rank", "rgb_comm_destroy", "rgb_comm_n_ranks", "rgb_comm_rank",
-                "rgb_leaderboard_allgather", "rgb_comm_last_error"]        # the one collective of the path (RCCL)
+                "rgb_leaderboard_allgather", "rgb_leaderboard_allgather_host", "rgb_comm_last_error"]   # the one collective of the path (RCCL)
+EXPORTS += COMM_EXPORTS
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_tick_buckets_device", "rgb_synth_apply_tick_device",
                  "rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
 OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device", "rgb_train_form",
@@ -75,7 +76,7 @@ def lib():
     except Exception:  # pragma: no cover - torch is optional for the binding
         pass
     L = C.CDLL(LIB_PATH)
-    for name in EXPORTS + COMM_EXPORTS + SYNTH_EXPORTS + WAL_EXPORTS:
+    for name in EXPORTS + SYNTH_EXPORTS + WAL_EXPORTS:
         if not hasattr(L, name):
             # tools/ only: RGB_LIB=<an older build> for same-box A/B timing of bench.py (tools/gpu_ab.sh --variants)
             if os.environ.get("RGB_LIB") and name in OPTIONAL_IN_OLD_BUILDS:
