@@ -885,7 +885,14 @@ def main():
             "host_path": host_path,
             "aux_kernels": {"wal_adler32": wal, "wal_frame": wal_frame},
         }
-        print(json.dumps(out))
+        try:                                   # RCCL prints its version banner through C stdio: out before the line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()

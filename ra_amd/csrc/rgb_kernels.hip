@@ -1814,7 +1814,15 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 #define RGB_X_PL 0     /* measured 1 % slower than the register arrays on the aged stream (23.6 vs 23.4 us), although it
                           removes every spill of the leader-side classes: kept as an option */
 #endif
-  constexpr bool PL = RGB_X_PL && PRE && rgb_class_slice(1, (unsigned)N) == 32u &&
+#ifndef RGB_X_PL_TICK
+#define RGB_X_PL_TICK 1   /* the per-tick class kernel (4 wavefronts per SIMD, 128 registers): the peers row stays in LDS and
+                             the commit re-reads the hot row from LDS (RGB_X_REREAD_TICK) -- no spills, where the register
+                             arrays spilled 34 VGPRs (40 bytes of scratch per lane) */
+#endif
+#ifndef RGB_X_REREAD_TICK
+#define RGB_X_REREAD_TICK 1
+#endif
+  constexpr bool PL = (TR ? RGB_X_PL : RGB_X_PL_TICK) && PRE && rgb_class_slice(1, (unsigned)N) == 32u &&
                       (KIND == RGB_MSG_AER_REPLY || KIND == RGB_MSG_APPEND || KIND == RGB_MSG_PIPELINE_RPCS);
   if (!PL && (L.kind == RGB_MSG_AER_REPLY || L.kind == RGB_MSG_APPEND || L.kind == RGB_MSG_PIPELINE_RPCS) &&
       !RGB_KNOB(dev, 64u)) {
@@ -1983,7 +1991,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 #ifndef RGB_X_REREAD
 #define RGB_X_REREAD 0
 #endif
-  if (RGB_X_REREAD && PRE) {
+  if ((TR ? RGB_X_REREAD : RGB_X_REREAD_TICK) && PRE) {
     /* what the row held: re-read from the LDS row (still intact) instead of kept in sixteen registers across the
      * clause code */
 #pragma unroll
@@ -3651,18 +3659,26 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
    * (without the leads the slowest classes -- snapshot_written, the leader-side ones -- commit later than one tick
    * after their predecessors start, the wavefronts that depend on them wait holding their slots, live longer
    * themselves, and the waits cascade).  rgb_train_lead[] is in ticks; ties: the heavier class first. */
-  u32 next[RGB_N_CLASSES] = {0};
+  /* a merge of the non-empty classes in heaviest-first order (the tie break), keys advanced by addition: this runs
+   * on the host once per tick of every plan (~4 us for the 65 536 x 5 closed loop) */
+  int act[RGB_N_CLASSES]; u32 next[RGB_N_CLASSES]; double key[RGB_N_CLASSES], step[RGB_N_CLASSES];
+  unsigned n_act = 0;
+  for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {
+    const int c = rgb_class_at(q);
+    if (rows_of[c] == 0) continue;
+    act[n_act] = c; next[n_act] = 0;
+    step[n_act] = 1.0 / (double)rows_of[c];
+    key[n_act] = 0.5 * step[n_act] - (double)rgb_train_lead[c];
+    n_act += 1;
+  }
   for (u32 k = 0; k < total; ++k) {
-    int best = -1;
-    double best_key = 0.0;
-    for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {
-      const int c = rgb_class_at(q);
-      if (next[c] >= rows_of[c]) continue;
-      const double key = (2.0 * next[c] + 1.0) / (2.0 * rows_of[c]) - (double)rgb_train_lead[c];
-      if (best < 0 || key < best_key) { best = c; best_key = key; }
-    }
-    row_tab[k] = ((u32)best << 24) | next[best];
+    unsigned best = 0;
+    for (unsigned a = 1; a < n_act; ++a)
+      if (key[a] < key[best]) best = a;
+    row_tab[k] = ((u32)act[best] << 24) | next[best];
     next[best] += 1;
+    if (next[best] >= rows_of[act[best]]) key[best] = 1e300;     /* exhausted */
+    else key[best] = (2.0 * next[best] + 1.0) * 0.5 * step[best] - (double)rgb_train_lead[act[best]];
   }
   return total;
 }
