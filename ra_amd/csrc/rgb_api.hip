@@ -14,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -38,6 +39,8 @@ struct rgb_slot {
   rgb_decision *h_dec = nullptr;    /* pinned */
   rgb_msg *d_msgs = nullptr;
   rgb_decision *d_dec = nullptr;
+  rgb_decision *d_dec_sub = nullptr;   /* the decisions in submission order (rgb_unpermute_kernel), what goes to h_dec */
+  u32 *h_pos = nullptr, *d_pos = nullptr;   /* pinned / device: device position of submitted message i */
   rgb_rpc *d_rpcs = nullptr;
   rgb_rpc *h_rpcs = nullptr;        /* pinned: the fixed rpc slots of device positions [rpc_lo, rpc_lo+rpc_cnt) */
   u32 rpc_lo = 0, rpc_cnt = 0;
@@ -119,8 +122,6 @@ struct rgb_ctx {
   /* train launches */
   u32 *d_train_ctl = nullptr;           /* RGB_TRAIN_CTL_WORDS: sticky error flags | calibration scratch */
   unsigned char *d_seq_cnt = nullptr;   /* running stamp counters of rgb_train_stamp_device (a copy of dev.seq) */
-  std::vector<unsigned char> seq_host;  /* host mirror of dev.seq (by server), valid while only rgb_submit ran trains */
-  bool seq_host_valid = false;
   std::atomic<u32> n_submit_trains{0};  /* batches whose sub-tick rounds ran as one train launch */
   std::atomic<u32> trains_in_flight{0}; /* such batches enqueued and not yet verified by rgb_collect: while there are
                                            any, every batch saves an undo log (settle_trains) */
@@ -216,6 +217,9 @@ static void free_slot(rgb_slot &s) {
   if (s.h_dec) (void)hipHostFree(s.h_dec);
   if (s.d_msgs) (void)hipFree(s.d_msgs);
   if (s.d_dec) (void)hipFree(s.d_dec);
+  if (s.d_dec_sub) (void)hipFree(s.d_dec_sub);
+  if (s.h_pos) (void)hipHostFree(s.h_pos);
+  if (s.d_pos) (void)hipFree(s.d_pos);
   if (s.d_rpcs) (void)hipFree(s.d_rpcs);
   if (s.h_rpcs) (void)hipHostFree(s.h_rpcs);
   if (s.h_nrpc) (void)hipHostFree(s.h_nrpc);
@@ -235,6 +239,7 @@ static void free_slot(rgb_slot &s) {
   s.h_nrpc = s.d_nrpc = nullptr;
   s.h_stamps = s.d_stamps = nullptr; s.h_plan = s.d_plan = nullptr; s.h_rows = s.d_rows = nullptr; s.done = nullptr;
   s.d_ctl = nullptr; s.h_touched = s.d_touched = nullptr; s.d_undo = nullptr;
+  s.d_dec_sub = nullptr; s.h_pos = s.d_pos = nullptr;
 }
 
 void rgb_close(rgb_ctx *ctx) {
@@ -298,6 +303,9 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_dec, (size_t)cap * sizeof(rgb_decision), hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_msgs, (size_t)cap * sizeof(rgb_msg)));
   HIPCHK(ctx, hipMalloc((void **)&s.d_dec, (size_t)cap * sizeof(rgb_decision)));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_dec_sub, (size_t)cap * sizeof(rgb_decision)));
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_pos, (size_t)cap * sizeof(u32), hipHostMallocDefault));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_pos, (size_t)cap * sizeof(u32)));
   HIPCHK(ctx, hipMalloc((void **)&s.d_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc)));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc), hipHostMallocDefault));
   HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -312,7 +320,8 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_rows, (size_t)s.rows_cap * RGB_SUBMIT_TRAIN_ROUNDS * sizeof(u32), hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_rows, (size_t)s.rows_cap * RGB_SUBMIT_TRAIN_ROUNDS * sizeof(u32)));
   HIPCHK(ctx, hipMalloc((void **)&s.d_ctl, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
-  HIPCHK(ctx, hipMemset(s.d_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
+  /* on the context's stream: it is a non-blocking stream, which the null stream's memset would not be ordered with */
+  HIPCHK(ctx, hipMemsetAsync(s.d_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32), ctx->stream));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_touched, (size_t)cap * sizeof(u32), hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_touched, (size_t)cap * sizeof(u32)));
   s.perm.reserve(cap);              /* nothing allocates between taking the ticket and publishing the slot */
@@ -340,18 +349,18 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   { const char *e = getenv("RGB_DEBUG"); d.dbg = e ? (u32)atoi(e) : 0u; }
   if (d.dbg & 16u) {
     HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
-    HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 8 * sizeof(u64)));
+    HIPCHK(ctx, hipMemsetAsync(d.dbg_buf, 0, (size_t)(S / 64 + 16) * 8 * sizeof(u64), ctx->stream));
   }
 #endif
 #ifdef RGB_X_DECLINE_HIST
   /* EXPERIMENT build (tools/decline_hist.py): 3 classes x 32 reason counters */
   HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, 128 * sizeof(u64)));
-  HIPCHK(ctx, hipMemset(d.dbg_buf, 0, 128 * sizeof(u64)));
+  HIPCHK(ctx, hipMemsetAsync(d.dbg_buf, 0, 128 * sizeof(u64), ctx->stream));
 #endif
 #ifdef RGB_X_TRAIN_TIMELINE
   /* EXPERIMENT build (tools/train_timeline.py): 8 words per block of a train launch */
   HIPCHK(ctx, hipMalloc((void **)&d.dbg_buf, (size_t)(1u << 20) * 8 * sizeof(u64)));
-  HIPCHK(ctx, hipMemset(d.dbg_buf, 0, (size_t)(1u << 20) * 8 * sizeof(u64)));
+  HIPCHK(ctx, hipMemsetAsync(d.dbg_buf, 0, (size_t)(1u << 20) * 8 * sizeof(u64), ctx->stream));
 #endif
   HIPCHK(ctx, hipMalloc((void **)&d.hot, (size_t)S * RGB_HOT_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.peers, (size_t)S * d.peer_stride * sizeof(u64)));
@@ -526,7 +535,11 @@ static int enqueue_results(rgb_ctx *ctx, rgb_slot &s) {
     if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
     HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc + 1, s.d_ctl, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   }
-  HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec, (size_t)s.n * sizeof(rgb_decision), hipMemcpyDeviceToHost, ctx->stream));
+  {
+    int lr = rgb_launch_unpermute(s.d_dec, s.d_pos, s.n, s.d_dec_sub, ctx->stream);    /* back to submission order */
+    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+  }
+  HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec_sub, (size_t)s.n * sizeof(rgb_decision), hipMemcpyDeviceToHost, ctx->stream));
   if (s.rpc_cnt)
     HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
                                (size_t)s.rpc_cnt * ctx->rpc_stride * sizeof(rgb_rpc), hipMemcpyDeviceToHost, ctx->stream));
@@ -542,21 +555,8 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
   if (!n) { HIPCHK(ctx, hipEventRecord(s.done, ctx->stream)); return RGB_OK; }
   u32 fault = 0;
   if (as_train) {
-    /* stamps from the host mirror of the sequence bytes (refreshed from the device after a device-side train or a
-     * repaired one) */
-    if (!ctx->seq_host_valid) {
-      const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
-      std::vector<unsigned char> raw(bytes);
-      HIPCHK(ctx, hipMemcpyAsync(raw.data(), ctx->dev.seq, bytes, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      ctx->seq_host.resize(ctx->dev.n_servers);
-      for (u32 sv = 0; sv < ctx->dev.n_servers; ++sv)
-        ctx->seq_host[sv] = raw[rgb_seq_index(sv, ctx->dev.n_members, ctx->dev.seq_stride)];
-      ctx->seq_host_valid = true;
-    }
-    for (u32 p = 0; p < n; ++p) s.h_stamps[p] = ctx->seq_host[s.h_msgs[p].server]++;
     fault = ctx->inject_fault.exchange(0u, std::memory_order_relaxed);
-    if (fault == RGB_FAULT_STAMP) s.h_stamps[0] = (unsigned char)(s.h_stamps[0] + 7u);
+    if (fault == RGB_FAULT_STAMP) s.h_stamps[0] = (unsigned char)(s.h_stamps[0] + 7u);   /* (round + 7: never comes up) */
     if (fault == RGB_FAULT_SHARD) {
       /* the first messages of two shards of one (round, class) change places (with their stamps and their places in
        * the permutation): the tick is still class-ordered, so the per-round replay computes it */
@@ -567,11 +567,13 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
           if (t0.cnt[c][x] == 0 || t0.cnt[c][x + 1] == 0) continue;
           const u32 a = t0.msg_base + t0.off[c][x], b = t0.msg_base + t0.off[c][x + 1];
           std::swap(s.h_msgs[a], s.h_msgs[b]); std::swap(s.h_stamps[a], s.h_stamps[b]); std::swap(s.perm[a], s.perm[b]);
+          s.h_pos[s.perm[a]] = a; s.h_pos[s.perm[b]] = b;
           done = true;
         }
     }
   }
   HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(s.d_pos, s.h_pos, (size_t)n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
   /* the undo log: the rows of the touched servers as they are before this batch -- while a train is in flight
    * (this batch included) a failed launch must be repairable */
   if (as_train || ctx->trains_in_flight.load(std::memory_order_acquire) != 0) {
@@ -588,6 +590,10 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
   }
   if (as_train) {
     HIPCHK(ctx, hipMemcpyAsync(s.d_stamps, s.h_stamps, n, hipMemcpyHostToDevice, ctx->stream));
+    {
+      int lr = rgb_launch_stamp_rounds(ctx->dev, s.d_msgs, n, s.d_stamps, ctx->stream);
+      if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+    }
     HIPCHK(ctx, hipMemcpyAsync(s.d_plan, s.h_plan, (size_t)s.n_rounds * sizeof(rgb_train_tick), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(s.d_rows, s.h_rows, (size_t)s.n_rounds * rows_max * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(s.d_ctl, 0, sizeof(u32), ctx->stream));    /* this slot's own error word */
@@ -663,7 +669,12 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
                   !(ctx->cfg.flags & RGB_CFG_ROUNDS_PER_LAUNCH);
   if (as_train) {
     std::lock_guard<std::mutex> tl(ctx->train_mu);          /* the one-off calibration uses the stream */
-    as_train = train_scratch(ctx) == RGB_OK;
+    const int ts = train_scratch(ctx);
+    as_train = ts == RGB_OK;
+    if (!as_train && getenv("RGB_TRACE_TRAIN_SETUP"))
+      fprintf(stderr, "[rgb] rgb_submit: no train (setup rc %d, hip %d)\n", ts, ctx->last_hip.load());
+  } else if (getenv("RGB_TRACE_TRAIN_SETUP")) {
+    fprintf(stderr, "[rgb] rgb_submit: n %u rounds %u nop %d -> launch per round\n", n, n_rounds, (int)any_nop);
   }
   /* device order: by round, then by clause family = (message kind, success flag) (a round holds
    * at most one message per server, so its order is free; family-homogeneous wavefronts do not
@@ -720,7 +731,9 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     for (u32 i = 0; i < n; ++i) {
       u32 p = bucket[(size_t)round_of[i] * NK + family(key_of[i])]++;
       s.perm[p] = i;
+      s.h_pos[i] = p;
       s.h_msgs[p] = msgs[i];
+      s.h_stamps[p] = (unsigned char)round_of[i];        /* a train's stamps: the device adds the sequence bytes */
     }
     s.n = n; s.tick = tick;
     s.used_train = false; s.enqueue_error = 0; s.has_undo = false;
@@ -758,10 +771,8 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
       }
     }
     if (rc != RGB_OK) {
-      /* published as failed: rgb_collect reports the error once and the ring moves on.  The host mirror of the
-       * sequence bytes may have been advanced for stamps that never reached the device */
+      /* published as failed: rgb_collect reports the error once and the ring moves on */
       s.enqueue_error = rc; s.n = 0; s.rpc_cnt = 0; s.used_train = false; s.has_undo = false;
-      ctx->seq_host_valid = false;
       (void)hipEventRecord(s.done, ctx->stream);
     }
     /* publish: everything written to the slot above happens-before the consumer's acquire load */
@@ -814,8 +825,7 @@ static int settle_trains(rgb_ctx *ctx) {
     if (rc == RGB_OK) rc = enqueue_results(ctx, s);
     if (rc) return rc;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->seq_host_valid = false;                              /* the sequence bytes went back with the rows */
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   /* (the sequence bytes went back with the rows) */
   return RGB_OK;
 }
 
@@ -867,18 +877,14 @@ int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, 
     ctx->in_flight.fetch_sub(1, std::memory_order_release);
   }
   rgb_slot &s = *sp;
-  /* decisions back in submission order; remember where each one ran on the device */
-  std::vector<u32> pos_of(s.n);
-  for (u32 p = 0; p < s.n; ++p) {
-    out[s.perm[p]] = s.h_dec[p];
-    pos_of[s.perm[p]] = p;
-  }
+  /* the decisions came back in submission order (rgb_unpermute_kernel): one sequential copy */
+  if (s.n) memcpy(out, s.h_dec, (size_t)s.n * sizeof(rgb_decision));
   int rc_out = RGB_OK;
   if (n_rpc && rpc_out) {
     u32 k = 0;
     for (u32 i = 0; i < s.n && rc_out == RGB_OK; ++i) {      /* ordered by (msg_index, peer) */
-      const u32 p = pos_of[i];
-      const u32 nr = s.h_dec[p].n_rpcs;
+      const u32 p = s.h_pos[i];                              /* where the message ran on the device */
+      const u32 nr = s.h_dec[i].n_rpcs;
       if (!nr) continue;
       /* a kind that cannot emit rpcs did: unrecoverable for this batch -- it is consumed all the same, so
        * the ring moves on and the caller sees the error once */
@@ -1047,7 +1053,9 @@ static int train_scratch(rgb_ctx *ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   if (!ctx->d_train_ctl) {
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_train_ctl, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
-    HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32)));
+    /* (on the context's non-blocking stream: a null-stream memset is not ordered with the calibration launch below and
+     * wiped some of its marks -- found by the fail-safe test running behind other tests of one process) */
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32), ctx->stream));
   }
   if (!ctx->d_seq_cnt) HIPCHK(ctx, hipMalloc((void **)&ctx->d_seq_cnt, (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS));
   if (ctx->xcc_state == 0) {
@@ -1070,6 +1078,9 @@ static int train_scratch(rgb_ctx *ctx) {
                     ctx->train_blocks >= RGB_TRAIN_SHARDS;
     ctx->n_xcc = ok ? n : 0;
     ctx->xcc_state = ok ? 1 : -1;
+    if (getenv("RGB_TRACE_TRAIN_SETUP"))
+      fprintf(stderr, "[rgb] train setup: xcc mask %#x rotations %#x resident blocks %u -> %s\n", cal[0], cal[1],
+              ctx->train_blocks, ok ? "ok" : "unsupported");
     /* the dealt form only where the calibration launch was dealt round robin over eight XCCs (one rotation seen) */
     ctx->train_dealt.store(ok && n == RGB_TRAIN_SHARDS && cal[1] != 0 && (cal[1] & (cal[1] - 1u)) == 0 &&
                            !(ctx->cfg.flags & RGB_CFG_TRAIN_PERSISTENT), std::memory_order_relaxed);
@@ -1155,7 +1166,6 @@ int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t firs
   if ((uint64_t)first_tick + n_ticks > plan->n_ticks) return RGB_E_INVAL;
   if (n_ticks == 0 || plan->bpt == 0) return RGB_OK;
   void *st = stream ? stream : (void *)ctx->stream;
-  ctx->seq_host_valid = false;          /* rgb_submit's host mirror of the sequence bytes is stale from here on */
   /* launches of at most RGB_TRAIN_MAX_TICKS ticks (and of a grid the runtime accepts) */
   u32 per = RGB_TRAIN_MAX_TICKS;
   if ((uint64_t)per * plan->bpt > 0x7FFFFFFFull) per = (u32)(0x7FFFFFFFull / plan->bpt);
@@ -1191,7 +1201,8 @@ int rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard) 
   if (flags_out) *flags_out = w;
   if (w & RGB_TRAIN_ERR_PLACEMENT) ctx->train_dealt.store(false, std::memory_order_relaxed);
   if (w) {
-    HIPCHK(ctx, hipMemset(ctx->d_train_ctl, 0, sizeof(u32)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_train_ctl, 0, sizeof(u32), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RGB_E_STATE;
   }
   return RGB_OK;

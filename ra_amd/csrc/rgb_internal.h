@@ -218,6 +218,10 @@ int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u3
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream);
 int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream);
 int rgb_launch_checksum(const rgb_dev &dev, u32 first, u32 n, u64 *d_out, void *stream);
+/* rgb_submit: stamps = sequence byte before the launch + the round the host wrote into d_stamps; decisions from device
+ * order to submission order (d_pos[i] = device position of submitted message i) */
+int rgb_launch_stamp_rounds(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_stamps, void *stream);
+int rgb_launch_unpermute(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream);
 /* undo log: rgb_undo_pieces(dev) 16-byte pieces per server (every row + the sequence byte) of the n servers d_ids
  * name, saved to (restore = 0) or written back from (restore = 1) d_undo */
 u32 rgb_undo_pieces(const rgb_dev &dev);

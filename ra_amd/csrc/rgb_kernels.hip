@@ -3495,6 +3495,29 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   out[k] = x;
 }
 
+/* rgb_submit's host side made lighter (two tiny kernels around a batch's launches):
+ * rgb_stamp_rounds_kernel   a train's stamps from what the device knows: in = the round of every message (the host's
+ *                           sub-tick round, one byte), out = the server's sequence byte as it stands before the launch +
+ *                           the round (a server's rounds in one batch are 0, 1, 2, ..: its r-th message finds exactly
+ *                           that) -- no host mirror of the sequence bytes, no per-message random access on the host
+ * rgb_unpermute_kernel      decisions from device order (round, bucket) back to submission order before the copy to the
+ *                           host: rgb_collect hands them out with one sequential memcpy */
+__global__ void rgb_stamp_rounds_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs, u32 n, unsigned char *__restrict__ stamps) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 w = *reinterpret_cast<const u64 *>(msgs + i);
+  const u32 sv = (u32)(w & 0xFFFFFFFFull);
+  if (((w >> 32) & 0xFFull) == RGB_MSG_NOP || sv >= dev.n_servers) { stamps[i] = 0; return; }
+  stamps[i] = (unsigned char)(dev.seq[rgb_seq_index(sv, dev.n_members, dev.seq_stride)] + stamps[i]);
+}
+__global__ void rgb_unpermute_kernel(const ulonglong2 *__restrict__ dec, const u32 *__restrict__ pos, u32 n,
+                                     ulonglong2 *__restrict__ out) {
+  const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 i = idx >> 2, part = idx & 3u;
+  if (i >= n) return;
+  out[(size_t)i * 4u + part] = dec[(size_t)pos[i] * 4u + part];
+}
+
 /* Undo log of a batch (rgb_submit's fail-safe, rgb_api.hip): every row of the servers ids[0..n) -- hot, peers, run
  * table, cond, qry, sequence byte -- copied to undo (restore = 0) or back (restore = 1), one lane per 16-byte piece */
 __host__ __device__ __forceinline__ u32 rgb_undo_pieces_of(const rgb_dev &dev) {
@@ -3553,6 +3576,7 @@ static int launch_tick_kind(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, co
 
 int rgb_launch_tick(const rgb_dev &dev, int cls, const rgb_msg *d_msgs, u32 n, const u32 *d_n,
                     rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_slot_base, u32 msg_index_base, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   switch (cls) {
@@ -3567,6 +3591,7 @@ int rgb_launch_tick(const rgb_dev &dev, int cls, const rgb_msg *d_msgs, u32 n, c
 int rgb_launch_tick_classes(const rgb_dev &dev, const rgb_msg *d_msgs, const u32 counts[RGB_N_CLASSES],
                             const u32 *d_family_totals, u32 max_msgs, rgb_decision *d_dec, rgb_rpc *d_rpcs,
                             u32 rpc_slot_base, u32 msg_index_base, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   hipStream_t st = (hipStream_t)stream;
   u32 n[RGB_N_CLASSES];
   for (int c = 0; c < RGB_N_CLASSES; ++c) n[c] = counts ? counts[c] : 0;
@@ -3595,6 +3620,7 @@ u32 rgb_synth_scratch_words(u32 n_groups) { return RGB_SYNTH_FIXED_WORDS + ((n_g
 int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u32 *d_scratch,
                      u32 *d_kind_counts, u32 *d_n, u32 *d_bucket_counts, unsigned char *d_stamps, unsigned char *d_sent,
                      void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   hipStream_t st = (hipStream_t)stream;
   const u32 G = dev.n_servers / dev.n_members;
   const u32 nblk = (G + 63) / 64;
@@ -3713,6 +3739,7 @@ u32 rgb_train_resident_blocks(unsigned n_members) {
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
                      rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   /* n_blocks = 0: the DEALT form (one block per row; the caller's calibration showed round-robin dispatch) */
   const bool dealt = n_blocks == 0;
   if (dealt) { n_blocks = RGB_TRAIN_SHARDS; n_xcc = RGB_TRAIN_SHARDS; }
@@ -3750,29 +3777,34 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
 }
 
 int rgb_launch_train_verify(u32 *d_ctl, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   hipLaunchKernelGGL(rgb_train_prolog_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_ctl, 0u);
   return (int)hipGetLastError();
 }
 
 int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_seq_cnt,
                          unsigned char *d_stamps, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   hipStream_t st = (hipStream_t)stream;
   if (n) hipLaunchKernelGGL(rgb_train_seq_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dev, d_msgs, n, d_seq_cnt, d_stamps);
   return (int)hipGetLastError();
 }
 
 int rgb_launch_train_calibrate(u32 *d_out, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   hipLaunchKernelGGL(rgb_train_calibrate_kernel, dim3(4096), dim3(64), 0, (hipStream_t)stream, d_out);
   return (int)hipGetLastError();
 }
 
 int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   if (n == 0) return 0;
   hipLaunchKernelGGL(rgb_pack_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dev, d_in, first, n);
   return (int)hipGetLastError();
 }
 
 int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u32 n, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   if (n == 0) return 0;
   hipLaunchKernelGGL(rgb_unpack_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dev, d_out, first, n);
   return (int)hipGetLastError();
@@ -3789,6 +3821,7 @@ __global__ void rgb_count_rpcs_kernel(const rgb_decision *__restrict__ dec, u32 
 }
 
 int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   hipError_t e = hipMemsetAsync(d_out, 0, sizeof(u32), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   if (n) hipLaunchKernelGGL(rgb_count_rpcs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_dec, n, d_out);
@@ -3796,6 +3829,7 @@ int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *st
 }
 
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   u32 g = dev.n_servers / dev.n_members;
   if (g == 0) return 0;
   hipLaunchKernelGGL(rgb_leaderboard_kernel, dim3((g + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev, d_rows, g);
@@ -3803,6 +3837,7 @@ int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void
 }
 
 int rgb_launch_checksum(const rgb_dev &dev, u32 first, u32 n, u64 *d_out, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   if (n == 0) return 0;
   hipLaunchKernelGGL(rgb_checksum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev, first, n, d_out);
   return (int)hipGetLastError();
@@ -3811,9 +3846,23 @@ int rgb_launch_checksum(const rgb_dev &dev, u32 first, u32 n, u64 *d_out, void *
 u32 rgb_undo_pieces(const rgb_dev &dev) { return rgb_undo_pieces_of(dev); }
 
 int rgb_launch_undo(const rgb_dev &dev, const u32 *d_ids, u32 n, void *d_undo, u32 restore, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   if (n == 0) return 0;
   const u64 lanes = (u64)n * rgb_undo_pieces_of(dev);
   hipLaunchKernelGGL(rgb_undo_kernel, dim3((u32)((lanes + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream, dev, d_ids, n,
                      (ulonglong2 *)d_undo, restore);
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_stamp_rounds(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_stamps, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
+  if (n) hipLaunchKernelGGL(rgb_stamp_rounds_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev, d_msgs, n, d_stamps);
+  return (int)hipGetLastError();
+}
+
+int rgb_launch_unpermute(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
+  if (n) hipLaunchKernelGGL(rgb_unpermute_kernel, dim3((u32)(((u64)n * 4u + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream,
+                            reinterpret_cast<const ulonglong2 *>(d_dec), d_pos, n, reinterpret_cast<ulonglong2 *>(d_out));
   return (int)hipGetLastError();
 }

@@ -438,6 +438,7 @@ extern "C" int rgb_wal_adler32_device(rgb_ctx *ctx, const void *d_entries, uint3
   if (!ctx || (n && (!d_entries || !d_checksums))) return RGB_E_INVAL;
   if (n == 0) return RGB_OK;
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)rgb_ctx_stream(ctx);
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   /* lanes per entry by the batch's mean payload: four entries per wavefront below 1 KiB */
   if (data_bytes / n < 1024u) {
     const u32 per = WAL_WAVES_PER_BLOCK * 64 / 16;
@@ -458,6 +459,7 @@ extern "C" int rgb_wal_frame_device(rgb_ctx *ctx, const void *d_records, uint32_
   if (n == 0) return RGB_OK;
   if (out_bytes < 27ull * n) return RGB_E_INVAL;       /* the shortest record is 3 + 24 bytes */
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)rgb_ctx_stream(ctx);
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   if (data_bytes / n <= WAL_FRAME_EIGHT_MAX) {
     /* the smallest payloads: eight lanes per record, eight records per wavefront (the per-record work that does not
      * shrink with the payload -- descriptor, reduction, prefix -- is paid per WAVEFRONT instruction) */

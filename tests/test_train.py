@@ -248,7 +248,10 @@ def check_failed_train_is_repaired(engine, oracle_lib, G, N, seed, faults):
                 do, ro = want[b]
                 assert dg.tobytes() == do.tobytes(), f"fault {fault}: decisions of batch {b}"
                 assert fuzz.sort_rpcs(rg).tobytes() == fuzz.sort_rpcs(ro).tobytes(), f"fault {fault}: rpcs of batch {b}"
-            assert gpu.train_recoveries() == before + (1 if fault else 0)
+            assert gpu.train_recoveries() == before + (1 if fault else 0), \
+                f"fault {fault}: recoveries {gpu.train_recoveries()} (before {before}), batches as trains so far " \
+                f"{gpu.submit_trains()}, form {gpu.train_form()}"
+
             assert gpu.get_state().tobytes() == cpu.get_state().tobytes(), f"fault {fault}: state"
         assert gpu.submit_trains() >= len(faults)
     cpu.close()
