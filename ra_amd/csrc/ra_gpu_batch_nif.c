@@ -49,6 +49,8 @@ typedef struct {
   ErlNifPid *pids;
   uint32_t n_pids, cap_pids;
   unsigned char *live;          /* live[k]: slot k of pids holds a registered owner (unregister_owner/2 frees it) */
+  uint32_t *ht; uint32_t ht_cap, ht_used;      /* pid -> slot + 1 (open addressing; 0 empty, 0xFFFFFFFF a released entry) */
+  uint32_t *free_slots; uint32_t n_free;       /* slots released by unregister_owner/2 */
   uint32_t *owner_of;
   atomic_ullong fb_ns, fb_decisions, fb_batches;   /* time the collector thread spent in fan_back (fan_back_stats/1) */
   uint32_t *tix; uint32_t tix_cap, tix_gen;   /* fan_back scratch: per-slot position in the batch's owner list, generation-stamped */
@@ -86,6 +88,8 @@ static void ctx_dtor(ErlNifEnv *env, void *obj) {
   if (c->own_mu) enif_mutex_destroy(c->own_mu);
   if (c->pids) enif_free(c->pids);
   if (c->live) enif_free(c->live);
+  if (c->ht) enif_free(c->ht);
+  if (c->free_slots) enif_free(c->free_slots);
   if (c->tix) enif_free(c->tix);
   if (c->owner_of) enif_free(c->owner_of);
 }
@@ -134,25 +138,66 @@ static ERL_NIF_TERM nif_register_groups(ErlNifEnv *env, int argc, const ERL_NIF_
  * (a ra_server_proc registers the one server it is; a batching process may own a range).  A pid that is already in
  * the table keeps its slot, a slot freed by unregister_owner/2 is reused: the table is bounded by the number of LIVE
  * owners, not by the number of restarts. */
-static uint32_t owner_slot(nif_ctx *c, const ErlNifPid *pid) {      /* own_mu held; 0 = no memory */
-  uint32_t free_at = 0;
+/* O(1): a pid -> slot hash (open addressing over enif_hash of the pid, compared with enif_compare_pids) and a free
+ * list of the slots unregister_owner/2 released -- one ra_server_proc per server registers itself, so a linear scan of
+ * the table made the registration of S owners O(S^2) and held own_mu (which fan_back needs) all the while */
+static uint64_t pid_hash(const ErlNifPid *pid) {
+  uint64_t x = enif_hash(ERL_NIF_INTERNAL_HASH, pid->pid, 0);    /* (the term's bits are opaque: enif_hash, OTP 20+) */
+  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+  return x;
+}
+static int owner_ht_grow(nif_ctx *c) {                              /* own_mu held */
+  const uint32_t cap = c->ht_cap ? c->ht_cap * 2 : 256;
+  uint32_t *ht = (uint32_t *)enif_alloc((size_t)cap * sizeof(uint32_t));
+  if (!ht) return 0;
+  memset(ht, 0, (size_t)cap * sizeof(uint32_t));
   for (uint32_t k = 0; k < c->n_pids; ++k) {
-    if (c->live[k] && enif_compare_pids(&c->pids[k], pid) == 0) return k + 1;
-    if (!c->live[k] && !free_at) free_at = k + 1;
+    if (!c->live[k]) continue;
+    uint32_t h = (uint32_t)(pid_hash(&c->pids[k]) & (cap - 1));
+    while (ht[h]) h = (h + 1) & (cap - 1);
+    ht[h] = k + 1;
   }
-  if (free_at) { c->pids[free_at - 1] = *pid; c->live[free_at - 1] = 1; return free_at; }
-  if (c->n_pids == c->cap_pids) {
-    uint32_t cap = c->cap_pids ? c->cap_pids * 2 : 64;
-    ErlNifPid *p = (ErlNifPid *)enif_alloc((size_t)cap * sizeof(ErlNifPid));
-    unsigned char *l = (unsigned char *)enif_alloc(cap);
-    if (!p || !l) { if (p) enif_free(p); if (l) enif_free(l); return 0; }
-    if (c->n_pids) { memcpy(p, c->pids, (size_t)c->n_pids * sizeof(ErlNifPid)); memcpy(l, c->live, c->n_pids); }
-    if (c->pids) enif_free(c->pids);
-    if (c->live) enif_free(c->live);
-    c->pids = p; c->live = l; c->cap_pids = cap;
+  if (c->ht) enif_free(c->ht);
+  c->ht = ht; c->ht_cap = cap; c->ht_used = 0;
+  for (uint32_t k = 0; k < c->n_pids; ++k) c->ht_used += c->live[k] ? 1u : 0u;
+  return 1;
+}
+static uint32_t owner_find(nif_ctx *c, const ErlNifPid *pid) {      /* own_mu held; slot + 1, 0 = not registered */
+  if (!c->ht_cap) return 0;
+  uint32_t h = (uint32_t)(pid_hash(pid) & (c->ht_cap - 1));
+  while (c->ht[h]) {
+    const uint32_t k = c->ht[h] - 1;
+    if (k != 0xFFFFFFFEu && c->live[k] && enif_compare_pids(&c->pids[k], pid) == 0) return k + 1;
+    h = (h + 1) & (c->ht_cap - 1);
   }
-  c->pids[c->n_pids] = *pid; c->live[c->n_pids] = 1;
-  return ++c->n_pids;
+  return 0;
+}
+static uint32_t owner_slot(nif_ctx *c, const ErlNifPid *pid) {      /* own_mu held; 0 = no memory */
+  uint32_t idx = owner_find(c, pid);
+  if (idx) return idx;
+  if ((c->ht_used + 1) * 2 > c->ht_cap && !owner_ht_grow(c)) return 0;   /* (also clears the tombstones) */
+  if (c->n_free) idx = c->free_slots[--c->n_free] + 1;
+  else {
+    if (c->n_pids == c->cap_pids) {
+      uint32_t cap = c->cap_pids ? c->cap_pids * 2 : 64;
+      ErlNifPid *p = (ErlNifPid *)enif_alloc((size_t)cap * sizeof(ErlNifPid));
+      unsigned char *l = (unsigned char *)enif_alloc(cap);
+      uint32_t *f = (uint32_t *)enif_alloc((size_t)cap * sizeof(uint32_t));
+      if (!p || !l || !f) { if (p) enif_free(p); if (l) enif_free(l); if (f) enif_free(f); return 0; }
+      if (c->n_pids) { memcpy(p, c->pids, (size_t)c->n_pids * sizeof(ErlNifPid)); memcpy(l, c->live, c->n_pids); }
+      if (c->n_free) memcpy(f, c->free_slots, (size_t)c->n_free * sizeof(uint32_t));
+      if (c->pids) enif_free(c->pids);
+      if (c->live) enif_free(c->live);
+      if (c->free_slots) enif_free(c->free_slots);
+      c->pids = p; c->live = l; c->free_slots = f; c->cap_pids = cap;
+    }
+    idx = ++c->n_pids;
+  }
+  c->pids[idx - 1] = *pid; c->live[idx - 1] = 1;
+  uint32_t h = (uint32_t)(pid_hash(pid) & (c->ht_cap - 1));
+  while (c->ht[h] && c->ht[h] != 0xFFFFFFFFu) h = (h + 1) & (c->ht_cap - 1);
+  c->ht[h] = idx; c->ht_used += 1;
+  return idx;
 }
 
 static ERL_NIF_TERM nif_register_owner(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
@@ -177,11 +222,15 @@ static ERL_NIF_TERM nif_unregister_owner(ErlNifEnv *env, int argc, const ERL_NIF
   (void)argc;
   if (!get_ctx(env, argv[0], &c) || !enif_get_local_pid(env, argv[1], &pid) || !c->owner_of) return enif_make_badarg(env);
   enif_mutex_lock(c->own_mu);
-  for (uint32_t k = 0; k < c->n_pids; ++k) {
-    if (!c->live[k] || enif_compare_pids(&c->pids[k], &pid) != 0) continue;
-    for (uint32_t sv = 0; sv < c->n_servers; ++sv)
-      if (c->owner_of[sv] == k + 1) c->owner_of[sv] = 0;
-    c->live[k] = 0;
+  const uint32_t idx = owner_find(c, &pid);
+  if (idx) {
+    for (uint32_t sv = 0; sv < c->n_servers; ++sv)          /* (dirty CPU scheduler: the one O(servers) walk left) */
+      if (c->owner_of[sv] == idx) c->owner_of[sv] = 0;
+    c->live[idx - 1] = 0;
+    uint32_t h = (uint32_t)(pid_hash(&pid) & (c->ht_cap - 1));
+    while (c->ht[h] != idx) h = (h + 1) & (c->ht_cap - 1);
+    c->ht[h] = 0xFFFFFFFFu;                                  /* released: probes walk over it, inserts reuse it */
+    c->free_slots[c->n_free++] = idx - 1;
   }
   enif_mutex_unlock(c->own_mu);
   return enif_make_atom(env, "ok");
@@ -410,7 +459,7 @@ static void *collector_main(void *arg) {
   enif_free_env(env);
   /* finished by itself (2): collect/1 works again at once, and the next start_collector/2 -- or stop_collector/1, or
    * the destructor -- joins this thread */
-  atomic_store(&c->collector_on, 2);
+  { int running = 1; atomic_compare_exchange_strong(&c->collector_on, &running, 2); }   /* (a stopper's 4 stays) */
   enif_release_resource(c);
   return NULL;
 }
@@ -446,8 +495,13 @@ static ERL_NIF_TERM nif_start_collector(ErlNifEnv *env, int argc, const ERL_NIF_
 static ERL_NIF_TERM nif_stop_collector(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
   nif_ctx *c;
   (void)argc;
-  if (!get_ctx(env, argv[0], &c) || (atomic_load(&c->collector_on) != 1 && atomic_load(&c->collector_on) != 2))
-    return enif_make_badarg(env);
+  if (!get_ctx(env, argv[0], &c)) return enif_make_badarg(env);
+  /* exactly one caller joins the thread: running (1) or already ended (2) -> stopping (4) */
+  int was = 1;
+  if (!atomic_compare_exchange_strong(&c->collector_on, &was, 4)) {
+    was = 2;
+    if (!atomic_compare_exchange_strong(&c->collector_on, &was, 4)) return enif_make_badarg(env);
+  }
   atomic_store(&c->stop, 1);
   rgb_wake(c->ctx);                                            /* the thread may be parked in rgb_wait */
   enif_thread_join(c->tid, NULL);

@@ -64,6 +64,8 @@ int enif_thread_join(ErlNifTid, void **);
 ErlNifTid enif_thread_self(void);
 int enif_equal_tids(ErlNifTid, ErlNifTid);
 int enif_compare_pids(const ErlNifPid *, const ErlNifPid *);
+typedef enum { ERL_NIF_INTERNAL_HASH = 1, ERL_NIF_PHASH2 = 2 } ErlNifHash;
+uint64_t enif_hash(ErlNifHash, ERL_NIF_TERM, uint64_t salt);
 typedef struct ErlNifMutex_ ErlNifMutex;
 ErlNifMutex *enif_mutex_create(char *name);
 void enif_mutex_destroy(ErlNifMutex *);

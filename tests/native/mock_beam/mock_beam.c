@@ -113,6 +113,12 @@ int enif_thread_create(char *name, ErlNifTid *tid, void *(*fn)(void *), void *ar
 int enif_thread_join(ErlNifTid tid, void **ret) { int rc = pthread_join(tid->th, ret); free(tid); return rc; }
 ErlNifTid enif_thread_self(void) { return tls_self; }
 int enif_equal_tids(ErlNifTid a, ErlNifTid b) { return a == b; }
+uint64_t enif_hash(ErlNifHash type, ERL_NIF_TERM t, uint64_t salt) {
+  uint64_t x = TT(t)->u ^ salt;                          /* (the mock hashes pids only: what the shim asks for) */
+  (void)type;
+  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33;
+  return x;
+}
 int enif_compare_pids(const ErlNifPid *a, const ErlNifPid *b) {
   const uint64_t x = TT(a->pid)->u, y = TT(b->pid)->u;
   return x < y ? -1 : x > y;
