@@ -728,7 +728,7 @@ def main():
     # ---- second kernel of the path's neighbourhood, rank 0, N=1: batched WAL entry
     # checksums, 262 144 entries x 4 KiB = 1 GiB resident in HBM (four times the Infinity Cache); reported
     # beside the headline, never as `value` ----
-    wal = wal_frame = None
+    wal = wal_frame = wal_frame_256 = None
     if rank == 0 and world == 1 and not args.no_host_path:
         import zlib
         n_e, ln = 262144, 4096
@@ -794,6 +794,44 @@ def main():
             del d_rec, d_out
         except Exception as e:                                              # noqa: BLE001 - reported, not raised
             wal_frame = {"error": f"{type(e).__name__}: {e}"}
+        # the weak case of the framing kernel, in the driver-run record as well: 256-byte payloads (2 M records,
+        # 512 MiB of payload; eight lanes per record) -- the per-record work that does not shrink with the payload
+        try:
+            import struct
+            n_s, ln_s = 1 << 21, 256
+            hdr = ((1 << 22) | 9).to_bytes(3, "big")
+            d_pay_s = torch.randint(0, 256, (n_s * ln_s + 16,), dtype=torch.uint8, device=dev)
+            d_pay_s[n_s * ln_s:n_s * ln_s + 3] = torch.tensor(list(hdr), dtype=torch.uint8, device=dev)
+            recs = np.zeros(n_s, dtype=abi.WAL_RECORD_DTYPE)
+            recs["index"] = np.arange(n_s); recs["term"] = 3
+            recs["data_offset"] = np.arange(n_s, dtype=np.uint64) * ln_s; recs["data_len"] = ln_s
+            recs["hdr_offset"] = n_s * ln_s; recs["hdr_len"] = 3
+            out_bytes = engine.wal_layout(recs, 5)
+            d_rec = torch.from_numpy(recs.view(np.uint8)).to(dev)
+            d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                eng.wal_frame_device(d_rec.data_ptr(), n_s, d_pay_s.data_ptr(), n_s * ln_s + 16, d_out.data_ptr(), out_bytes, 0, 0, sptr)
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(stream)
+            for _ in range(20):
+                eng.wal_frame_device(d_rec.data_ptr(), n_s, d_pay_s.data_ptr(), n_s * ln_s + 16, d_out.data_ptr(), out_bytes, 0, 0, sptr)
+            f1.record(stream)
+            torch.cuda.synchronize()
+            f_us = f0.elapsed_time(f1) * 1e3 / 20
+            host_s = d_pay_s[:8 * ln_s].cpu().numpy()
+            got = d_out[5:5 + 8 * (27 + ln_s)].cpu().numpy().tobytes()
+            exp = b"".join(hdr + struct.pack(">II", zlib.adler32(struct.pack(">QQ", i, 3) + host_s[i * ln_s:(i + 1) * ln_s].tobytes()), ln_s) +
+                           struct.pack(">QQ", i, 3) + host_s[i * ln_s:(i + 1) * ln_s].tobytes() for i in range(8))
+            assert got == exp, "framed 256-byte records differ from struct.pack + zlib"
+            f_bytes = n_s * (2 * ln_s + 48 + 3 + 27)
+            wal_frame_256 = {"kernel": "rgb_wal_frame_kernel<8>", "records": n_s, "payload_bytes_each": ln_s,
+                             "us_per_launch": f_us, "achieved": f_bytes / (f_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": f_bytes / (f_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                             "note": "the framing kernel's weak case: 256-byte payloads; first 8 records checked"}
+            del d_rec, d_out, d_pay_s
+        except Exception as e:                                              # noqa: BLE001 - reported, not raised
+            wal_frame_256 = {"error": f"{type(e).__name__}: {e}"}
         del d_pay, d_ent, d_sum
 
     # ---- the literal SURVEY 8(d) configurations (rank 0, N=1 only): reported beside the headline ----
@@ -883,7 +921,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "literal_configs": literal,
             "host_path": host_path,
-            "aux_kernels": {"wal_adler32": wal, "wal_frame": wal_frame},
+            "aux_kernels": {"wal_adler32": wal, "wal_frame": wal_frame, "wal_frame_256": wal_frame_256},
         }
         try:                                   # RCCL prints its version banner through C stdio: out before the line
             import ctypes

@@ -157,9 +157,19 @@ __device__ __forceinline__ unsigned slot4to8(unsigned s) { return s >= 8u ? (uns
 
 /* Everything one lane needs for one message: the server's hot line in registers, the message,
  * the effects being accumulated and the pending (uncommitted) log-table edits. */
-template <bool COH>
+template <bool COH, bool WC = false>
 struct LaneT {
   static constexpr bool coh = COH;   /* state loads must bypass the CU's L1 (train launch), see ldg8 */
+  /* WC (groups of six and more members: the kernels that have the registers): the run a table walk ended in is
+   * remembered -- number, start, term, start of the next run -- and the next look-up of the same message tries it
+   * first.  One append_entries_rpc asks has_log_entry_or_snapshot(prev), drop_existing (run of the first entry, its
+   * term, its end), fetch_term(last_applied): on the log-matching repair workload (configs[4]: 1 024-entry backlogs
+   * over 3-6 term boundaries, every prev_log_index inside the backlog) each of them walked the table again from its
+   * newest run, 7.6 dependent round trips per lane.  The table rows a walk reads are never written before the commit,
+   * so what is remembered stays true for the whole message. */
+  static constexpr bool walk_cache = WC;
+  int wc_k;
+  u64 wc_start, wc_term, wc_next;
   /* hot line */
   u64 ct, ci, la, li, lt, lwi, lwt, pk, si, st, first, lrs, lrt, prs, prt, pend;
   /* cold words (qry row), loaded only by the election kinds */
@@ -324,14 +334,27 @@ template <class Lane>
 __device__ __forceinline__ int run_search(const Lane &L, u64 idx, u64 &term) {
   int k = (int)L.n_runs - 3;
   if (k < 0) return -1;
+  if (Lane::walk_cache && L.wc_k >= 0 && L.wc_k <= k && idx >= L.wc_start && idx < L.wc_next) {
+    term = L.wc_term;                                   /* the run the previous walk of this message ended in */
+    return L.wc_k;
+  }
   ulonglong2 cur = run_pair(L, k);
+  u64 upper = L.prs;                                    /* start of run k + 1 (run n_runs - 2 is mirrored in the row) */
 #pragma unroll 1
   for (; k >= 0; --k) {
     const ulonglong2 nxt = run_pair(L, k > 0 ? k - 1 : 0);
 #ifdef RGB_PROFILE
     const_cast<Lane &>(L).prof_nloads += 2u;
 #endif
-    if (idx >= cur.x) { term = cur.y; return k; }
+    if (idx >= cur.x) {
+      term = cur.y;
+      if (Lane::walk_cache) {
+        Lane &M = const_cast<Lane &>(L);
+        M.wc_k = k; M.wc_start = cur.x; M.wc_term = cur.y; M.wc_next = upper;
+      }
+      return k;
+    }
+    upper = cur.x;
     cur = nxt;
   }
   return -1;
@@ -1188,10 +1211,12 @@ __device__ __forceinline__ u32 drop_existing(const Lane &L) {
     if (s > L.li) return k;
     int r = find_run(L, s);
     if (r < 0) return k;
-    u64 rterm = ((unsigned)r == L.n_runs - 1) ? L.lrt : ((unsigned)r == L.n_runs - 2) ? L.prt : run_word(L, 2 * r + 1);
+    const bool cached = Lane::walk_cache && r == L.wc_k;      /* find_run's walk just ended in it */
+    u64 rterm = ((unsigned)r == L.n_runs - 1) ? L.lrt : ((unsigned)r == L.n_runs - 2) ? L.prt :
+                cached ? L.wc_term : run_word(L, 2 * r + 1);
     if (rterm != t) return k;
     u64 rend = ((unsigned)r == L.n_runs - 1) ? L.li : ((unsigned)r == L.n_runs - 2) ? L.lrs - 1 :
-               ((unsigned)r == L.n_runs - 3) ? L.prs - 1 : run_word(L, 2 * (r + 1)) - 1;
+               ((unsigned)r == L.n_runs - 3) ? L.prs - 1 : cached ? L.wc_next - 1 : run_word(L, 2 * (r + 1)) - 1;
     if (rend >= e) { k += cnt; continue; }
     k += (u32)(rend - s + 1);
     return k;
@@ -1753,7 +1778,8 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
                                                 const ulonglong2 *pre = nullptr, unsigned swz = 0,
                                                 const ulonglong2 *prepeers = nullptr,
                                                 const ulonglong2 *preruns = nullptr) {
-  LaneT<TR> L;
+  LaneT<TR, (N >= 6 && KIND == RGB_MSG_AER)> L;   /* (the walk cache costs seven registers: only where it pays) */
+  L.wc_k = -1; L.wc_start = L.wc_term = L.wc_next = 0;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
    * (and its registers) remain */
