@@ -93,7 +93,7 @@ def run_literal(name, ticks, torch, engine, W, abi, dev, local_rank, reps=3):
         eng.set_state(0, st0)
         enqueue()
         torch.cuda.synchronize()
-        got = d_dec.cpu().numpy().view(abi.DECISION_DTYPE)
+        got = abi.expand_decisions(d_dec.cpu().numpy().view(abi.DECISION_DTYPE))    # (device streams hold compact records)
         checked = 0
         for t in range(ticks):
             g = got[t * stride:t * stride + len(msgs[t])]
@@ -165,7 +165,7 @@ def run_literal(name, ticks, torch, engine, W, abi, dev, local_rank, reps=3):
                 torch.cuda.synchronize()
                 eng.train_status()
                 if rep == 0:
-                    got_t = d_dec_t.cpu().numpy().view(abi.DECISION_DTYPE)
+                    got_t = abi.expand_decisions(d_dec_t.cpu().numpy().view(abi.DECISION_DTYPE))
                     for t in range(ticks):
                         gt = got_t[t * stride:t * stride + len(msgs[t])]
                         if gt.tobytes() != decs[t][perms[t]].tobytes():
@@ -317,7 +317,8 @@ def main():
     assert sptr != 0
     tick_bytes = S * 64
     d_msgs = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)
-    d_dec = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)
+    d_dec = torch.zeros(T * tick_bytes, dtype=torch.uint8, device=dev)     # zeroed: the unwritten half of a compact
+                                                                           # record compares equal between the two passes
     RPC_RING = 4 if use_train else 1       # ticks of one train overlap: tick k of a launch writes region k mod 4
     d_rpcs = torch.empty(RPC_RING * S * max(N - 1, 1) * 56, dtype=torch.uint8, device=dev)   # rewritten every tick
     d_bc = torch.zeros(T * engine.TRAIN_BUCKETS, dtype=torch.int32, device=dev)     # messages per train bucket
@@ -343,6 +344,7 @@ def main():
         eng.synth_apply_tick_device(d_msgs.data_ptr(), S, d_dec.data_ptr(), d_rpcs.data_ptr(), sptr)
     torch.cuda.synchronize()
     d_kc.zero_()
+    d_dec.zero_()            # (the ageing ticks wrote here: the unwritten half of a compact record must compare equal)
     st_aged = eng.get_state() if A else st0
     # ---- pass 1 (untimed): generate tick A+t from the device state, then apply it.  The generator is the PRODUCER
     # of the stream: it writes every tick in bucket order and, beside every message, the train stamp -- its own count
@@ -387,7 +389,7 @@ def main():
             for t in range(min(args.check_ticks, T)):
                 want, _ = cpu.step_parallel(first_ticks[t])
                 nt = int(n_dec[t])
-                got = d_dec[t * tick_bytes:t * tick_bytes + nt * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+                got = abi.expand_decisions(d_dec[t * tick_bytes:t * tick_bytes + nt * 64].cpu().numpy().view(abi.DECISION_DTYPE))
                 if got.tobytes() != want.tobytes():
                     bad = int(np.flatnonzero((got.view(np.uint8).reshape(nt, 64) !=
                                               want.view(np.uint8).reshape(nt, 64)).any(axis=1))[0])
@@ -412,7 +414,7 @@ def main():
         t_plan = time.perf_counter()
         plan = eng.train_plan(buckets)                                        # host: 256 bucket counts per tick -> row order
         plan_host_ms = (time.perf_counter() - t_plan) * 1e3
-        d_dec2 = torch.empty(T * tick_bytes, dtype=torch.uint8, device=dev)   # pass 1's decisions stay for comparison
+        d_dec2 = torch.zeros(T * tick_bytes, dtype=torch.uint8, device=dev)   # pass 1's decisions stay for comparison
 
     def launch_ticks(t, nxt):
         """ticks [t, nxt) on the stream: ONE train launch, or one class-kernel launch per tick"""

@@ -67,6 +67,7 @@ F_SEND_HEARTBEATS = 1 << 24
 F_QUERY_QUORUM = 1 << 25
 F_QUERY_APPLY = 1 << 26
 F_CANCEL_SNAPSHOT_RETRY = 1 << 27
+F_COMPACT = 1 << 28   # device-resident decision streams: the 32-byte compact form (expand_decisions)
 
 (INV_NONE, INV_LEADER_SAW_AER_SAME_TERM, INV_TRUNCATE_BELOW_APPLIED, INV_WRITE_BELOW_APPLIED,
  INV_MISMATCH_TERM_UNDEFINED, INV_WRITE_INTEGRITY, INV_SET_LAST_INDEX_NOT_FOUND,
@@ -231,3 +232,39 @@ def log_entries(st_row) -> list:
         t = int(st_row["run_term"][r])
         out.extend((i, t) for i in range(a, b + 1))
     return out
+
+
+def expand_decisions(dec: np.ndarray) -> np.ndarray:
+    """rgb_decision_expand (include/ra_gpu_batch.h) over an array read from a DEVICE-RESIDENT decision stream: records
+    with F_COMPACT were written as 32 bytes; the full records come back (a copy), the flag cleared."""
+    d = np.array(dec, dtype=DECISION_DTYPE, copy=True)
+    c = (d["flags"] & F_COMPACT) != 0
+    if not c.any():
+        return d
+    w = d.view(np.uint64).reshape(-1, 8)
+    aux = (w[:, 1] >> np.uint64(32)).astype(np.uint64)
+    A, B = w[:, 2].copy(), w[:, 3].copy()
+    flags = d["flags"] & ~np.uint32(F_COMPACT)
+    reply = c & ((flags & F_REPLY) != 0)
+    wrote = c & ~reply & ((flags & F_WROTE) != 0)
+    counted = c & ~reply & ~wrote
+    with np.errstate(over="ignore"):
+        d["flags"] = flags
+        for f in ("invariant", "heartbeat_to", "cancel_backoff"):
+            d[f][c] = 0
+        for f in ("reply_term", "reply_next_index", "reply_last_index", "reply_last_term"):
+            d[f][c] = 0
+        u = np.uint64
+        d["reply_next_index"][reply] = (A + u(1))[reply]
+        d["reply_term"][reply] = B[reply]
+        d["reply_last_index"][reply] = (A - (aux & u(0xFF)))[reply]
+        d["reply_last_term"][reply] = (B - ((aux >> u(8)) & u(0xF)))[reply]
+        d["commit_index"][reply] = (A + ((aux >> u(12)) & u(0x3FF)) - u(512))[reply]
+        d["last_applied"][reply] = (A + u(1) - ((aux >> u(22)) & u(0x3FF)))[reply]
+        d["reply_last_index"][wrote] = A[wrote]
+        d["reply_next_index"][wrote] = (A - (aux & u(0xFFFF)))[wrote]
+        d["commit_index"][wrote] = B[wrote]
+        d["last_applied"][wrote] = (A - (aux >> u(16)))[wrote]
+        d["commit_index"][counted] = A[counted]
+        d["last_applied"][counted] = B[counted]
+    return d

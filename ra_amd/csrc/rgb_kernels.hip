@@ -1767,6 +1767,44 @@ __device__ __forceinline__ void make_decision(Dec &d, u32 server, unsigned role,
   d.w[2] = w2; d.w[3] = w3; d.w[4] = w4; d.w[5] = w5; d.w[6] = ci; d.w[7] = la;
 }
 
+/* The compact form of a decision (include/ra_gpu_batch.h, "Compact decisions"): applied where a decision is staged for
+ * its store, whatever path computed it; returns whether the record became 32 bytes.  Three shapes, each tested value
+ * by value -- what does not fit stays a full record. */
+#ifndef RGB_X_COMPACT
+#define RGB_X_COMPACT 1
+#endif
+__device__ __forceinline__ bool compact_decision(Dec &d) {
+  if (!RGB_X_COMPACT) return false;
+  const u32 flags = (u32)d.w[1];
+  const unsigned kind = (unsigned)(d.w[0] >> 56);
+  if ((d.w[1] >> 32) != 0ull || (flags & RGB_F_COMPACT)) return false;             /* invariant / masks in use */
+  const u32 plain = RGB_F_LEADER_MSG | RGB_F_APPLIED | RGB_F_AUX_EVAL | RGB_F_PIPELINE;     /* flags that carry no words */
+  u64 A, B; u32 aux = 0;
+  if ((flags & ~plain) == 0u && (kind == RGB_MSG_AER_REPLY || kind == RGB_MSG_WRITTEN)) {
+    if ((d.w[2] | d.w[3] | d.w[4] | d.w[5]) != 0ull) return false;
+    A = d.w[6]; B = d.w[7];                                                         /* counted */
+  } else if ((flags & ~plain) == RGB_F_WROTE && kind == RGB_MSG_AER) {
+    const u64 fst = d.w[3], lst = d.w[4], la = d.w[7];
+    if ((d.w[2] | d.w[5]) != 0ull || fst > lst || lst - fst > 0xFFFFull || la > lst || lst - la > 0xFFFFull) return false;
+    A = lst; B = d.w[6];
+    aux = (u32)(lst - fst) | ((u32)(lst - la) << 16);                               /* wrote */
+  } else if ((flags & ~plain) == (RGB_F_REPLY | RGB_F_REPLY_SUCCESS) && (kind == RGB_MSG_AER || kind == RGB_MSG_WRITTEN)) {
+    const u64 term = d.w[2], next = d.w[3], last = d.w[4], lterm = d.w[5], ci = d.w[6], la = d.w[7];
+    if (next == 0ull) return false;
+    A = next - 1ull; B = term;
+    const u64 d1 = A - last, d2 = term - lterm, d3 = ci + 512ull - A, d4 = A + 1ull - la;
+    if (last > A || d1 > 0xFFull || lterm > term || d2 > 0xFull || ci + 512ull < A || d3 > 0x3FFull || la > A + 1ull ||
+        d4 > 0x3FFull)
+      return false;
+    aux = (u32)d1 | ((u32)d2 << 8) | ((u32)d3 << 12) | ((u32)d4 << 22);            /* confirmed */
+  } else {
+    return false;
+  }
+  d.w[1] = (u64)(flags | RGB_F_COMPACT) | ((u64)aux << 32);
+  d.w[2] = A; d.w[3] = B;
+  return true;
+}
+
 /* One message against one server: everything between "message words in registers" and
  * "decision words in registers".  State loads/stores go straight to the server's lines. */
 /* TR = the multi-tick train launch: state loads bypass the L1 (LaneT<true>::coh, see ldg8). */
@@ -2168,7 +2206,9 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
   const bool changed = !(h3.x == to && h3.y == term);
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS);
   if (changed) ST16(ho + 3, make_ulonglong2(to, term));
+#ifndef RGB_X_NOPEND      /* EXPERIMENT (breaks parity): what is the second dirty sector of a written event worth? */
   if (npend != pend) ST16(ho + 7, make_ulonglong2(h7.x, npend));
+#endif
   u32 flags = 0;
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
   unsigned reply_to = RGB_NONE;
@@ -2259,7 +2299,9 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   if (ci > ci0) flags |= RGB_F_AUX_EVAL;
   if (ci > la) { const u64 to = li < ci ? li : ci; if (to >= la + 1) { nla = to; flags |= RGB_F_APPLIED; } }
   if (mi_dirty) ST8(peers + peer, mi_new);
+#ifndef RGB_X_NONIW       /* EXPERIMENT (breaks parity): the reply's next_index store (a second sector of the peers row) */
   if (ni_dirty) ST8(peers + N + peer, ni_new);
+#endif
   if (ci != ci0 || nla != la)
     ST16(reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS) + 1, make_ulonglong2(ci, nla));
   make_decision(out, server, RGB_ROLE_LEADER, RGB_NONE, 0, RGB_MSG_AER_REPLY, flags, 0, 0, 0, 0, 0, ci, nla);
@@ -2310,6 +2352,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
     const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
                      m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
     process_message<N, KIND>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d);
+    (void)compact_decision(d);
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
     io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
@@ -2322,7 +2365,8 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
-    if (j < cnt) store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+    if (j < cnt && (part < 2u || !((u32)io[j * RGB_IO_SLOT].y & RGB_F_COMPACT)))
+      store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
   }
 }
 
@@ -2691,6 +2735,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   RGB_TT(5);
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
   if (active) {
+    (void)compact_decision(d);       /* 32 bytes where the outcome allows: the storing lanes read the flag from the slot */
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
     io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
@@ -2704,7 +2749,13 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
     /* decisions are never re-read on the device: non-temporal (measured -5 % per tick) */
-    if (j < cnt) store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+#ifdef RGB_X_HALFDEC      /* EXPERIMENT (breaks the output): 32-byte decisions -- what would compact records be worth? */
+    if (j < cnt && part < 2u) store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+#else
+    /* the upper half of a compact record is not written */
+    if (j < cnt && (part < 2u || !((u32)io[j * RGB_IO_SLOT].y & RGB_F_COMPACT)))
+      store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+#endif
   }
 #if defined(RGB_X_TRAIN_TIMELINE) && !defined(RGB_HOST_EMULATION)
   if (TR && dev.dbg_buf != nullptr && lane == 0 && blockIdx.x < (1u << 20)) {
@@ -3538,10 +3589,27 @@ __global__ void rgb_stamp_rounds_kernel(rgb_dev dev, const rgb_msg *__restrict__
 }
 __global__ void rgb_unpermute_kernel(const ulonglong2 *__restrict__ dec, const u32 *__restrict__ pos, u32 n,
                                      ulonglong2 *__restrict__ out) {
-  const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 i = idx >> 2, part = idx & 3u;
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out[(size_t)i * 4u + part] = dec[(size_t)pos[i] * 4u + part];
+  const ulonglong2 *src = dec + (size_t)pos[i] * 4u;
+  ulonglong2 a = src[0], b = src[1], c, e;
+  const u32 flags = (u32)a.y;
+  if (flags & RGB_F_COMPACT) {
+    /* rgb_decision_expand (include/ra_gpu_batch.h): the host path always hands out full records */
+    const u32 aux = (u32)(a.y >> 32), f = flags & ~(u32)RGB_F_COMPACT;
+    const u64 A = b.x, B = b.y;
+    u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0, ci, la;
+    if (f & RGB_F_REPLY) {
+      w3 = A + 1ull; w2 = B; w4 = A - (u64)(aux & 0xFFu); w5 = B - (u64)((aux >> 8) & 0xFu);
+      ci = A + (u64)((aux >> 12) & 0x3FFu) - 512ull; la = A + 1ull - (u64)((aux >> 22) & 0x3FFu);
+    } else if (f & RGB_F_WROTE) {
+      w4 = A; w3 = A - (u64)(aux & 0xFFFFu); ci = B; la = A - (u64)(aux >> 16);
+    } else { ci = A; la = B; }
+    a.y = (u64)f;
+    b = make_ulonglong2(w2, w3); c = make_ulonglong2(w4, w5); e = make_ulonglong2(ci, la);
+  } else { c = src[2]; e = src[3]; }
+  ulonglong2 *dst = out + (size_t)i * 4u;
+  dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = e;
 }
 
 /* Undo log of a batch (rgb_submit's fail-safe, rgb_api.hip): every row of the servers ids[0..n) -- hot, peers, run
@@ -3888,7 +3956,7 @@ int rgb_launch_stamp_rounds(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, un
 
 int rgb_launch_unpermute(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream) {
   (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
-  if (n) hipLaunchKernelGGL(rgb_unpermute_kernel, dim3((u32)(((u64)n * 4u + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream,
+  if (n) hipLaunchKernelGGL(rgb_unpermute_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
                             reinterpret_cast<const ulonglong2 *>(d_dec), d_pos, n, reinterpret_cast<ulonglong2 *>(d_out));
   return (int)hipGetLastError();
 }

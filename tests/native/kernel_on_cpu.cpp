@@ -218,6 +218,7 @@ int emu_launch_tick(void *h, int cls, const rgb_msg *msgs, uint32_t n, rgb_decis
   need_slots(e, n);
   int rc = rgb_launch_tick(e->dev, cls, msgs, n, nullptr, dec, e->slots, 0, 0, nullptr);
   if (rc) return rc;
+  for (uint32_t i = 0; i < n; ++i) rgb_decision_expand(&dec[i]);     /* device streams hold compact records */
   return compact_rpcs(e, dec, n, rpcs, rpc_cap, n_rpcs_out);
 }
 
@@ -228,6 +229,7 @@ int emu_launch_classes(void *h, const rgb_msg *msgs, const uint32_t *counts, uin
   need_slots(e, n);
   int rc = rgb_launch_tick_classes(e->dev, msgs, counts, nullptr, n, dec, e->slots, 0, 0, nullptr);
   if (rc) return rc;
+  for (uint32_t i = 0; i < n; ++i) rgb_decision_expand(&dec[i]);
   return compact_rpcs(e, dec, n, rpcs, rpc_cap, n_rpcs_out);
 }
 
@@ -236,7 +238,12 @@ int emu_launch_classes_dev(void *h, const rgb_msg *msgs, const uint32_t *family_
                            rgb_decision *dec) {
   Emu *e = (Emu *)h;
   need_slots(e, max_msgs);
-  return rgb_launch_tick_classes(e->dev, msgs, nullptr, family_totals, max_msgs, dec, e->slots, 0, 0, nullptr);
+  int rc = rgb_launch_tick_classes(e->dev, msgs, nullptr, family_totals, max_msgs, dec, e->slots, 0, 0, nullptr);
+  if (rc) return rc;
+  u32 total = 0;
+  for (unsigned f = 0; f < RGB_N_FAMILIES; ++f) total += family_totals[f];
+  for (uint32_t i = 0; i < total && i < max_msgs; ++i) rgb_decision_expand(&dec[i]);
+  return 0;
 }
 
 int emu_launch_pack(void *h, uint32_t first, uint32_t n, const rgb_server_state *in) {

@@ -58,7 +58,7 @@ def replay_device_stream(engine_mod, oracle_lib, G, N, seed, ticks, checksum_eve
             n = int(dn.item())
             assert 0 < n <= S
             msgs = dm[:n * 64].cpu().numpy().view(abi.MSG_DTYPE)
-            got = dd[:n * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+            got = abi.expand_decisions(dd[:n * 64].cpu().numpy().view(abi.DECISION_DTYPE))
             srv = msgs["server"]
             assert len(np.unique(srv)) == n, f"tick {t}: two messages for one server"
             want, _ = cpu.step_parallel(msgs)
@@ -174,7 +174,7 @@ def test_config3_trains_against_the_oracle_at_full_size(engine_mod, oracle_lib):
         for t in range(T):
             n = int(counts[t])
             msgs = dm[t * tb:t * tb + n * 64].cpu().numpy().view(abi.MSG_DTYPE)
-            got = dd[t * tb:t * tb + n * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+            got = abi.expand_decisions(dd[t * tb:t * tb + n * 64].cpu().numpy().view(abi.DECISION_DTYPE))
             want, _ = cpu.step_parallel(msgs)
             if got.tobytes() != want.tobytes():
                 bad = int(np.flatnonzero((got.view(np.uint8).reshape(n, 64) != want.view(np.uint8).reshape(n, 64)).any(axis=1))[0])

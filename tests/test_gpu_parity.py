@@ -326,7 +326,7 @@ def test_device_resident_ticks_match_host_path(engine_mod, oracle_lib):
                                + [np.zeros(0, dtype=abi.RPC_DTYPE)])
         assert int(last["n_rpcs"].sum()) == len(got_r)
         assert np.all(got_r["msg_index"] >= 3 * G * N)
-        got = dd.cpu().numpy().view(abi.DECISION_DTYPE)
+        got = abi.expand_decisions(dd.cpu().numpy().view(abi.DECISION_DTYPE))
         want = np.concatenate(decs)
         assert got.tobytes() == want.tobytes()
         assert gpu.get_state().tobytes() == cpu.get_state().tobytes()
@@ -572,7 +572,7 @@ def test_device_generated_stream_matches_oracle(engine_mod, oracle_lib, n_member
                                          dr.data_ptr(), stream.cuda_stream, d_tick_counts=dn.data_ptr() + t * 4)
         torch.cuda.synchronize()
         msgs = dm.cpu().numpy().view(abi.MSG_DTYPE).reshape(ticks, S)
-        decs = dd.cpu().numpy().view(abi.DECISION_DTYPE).reshape(ticks, S)
+        decs = abi.expand_decisions(dd.cpu().numpy().view(abi.DECISION_DTYPE)).reshape(ticks, S)
         counts = kc.cpu().numpy().reshape(ticks, abi.N_KINDS)
         ns = dn.cpu().numpy()
         flags_seen = 0
@@ -679,7 +679,7 @@ def test_full_size_properties_config3(engine_mod):
             torch.cuda.synchronize()
             n = int(dn.item())
             msgs = dm[:n * 64].cpu().numpy().view(abi.MSG_DTYPE)
-            dec_a = dd[:n * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+            dec_a = abi.expand_decisions(dd[:n * 64].cpu().numpy().view(abi.DECISION_DTYPE))
             assert len(np.unique(msgs["server"])) == n
             assert not np.any(dec_a["flags"] & abi.F_INVARIANT)
             # the same messages, shuffled, through the host path in 65536-message chunks

@@ -69,7 +69,8 @@ def _generate(engine, G, N, T, seed, on_gpu, max_runs=16, age=0):
 
 
 def _tick(buf, t, tb, n, dtype):
-    return buf.host()[t * tb:t * tb + n * 64].view(dtype).copy()
+    a = buf.host()[t * tb:t * tb + n * 64].view(dtype).copy()
+    return abi.expand_decisions(a) if dtype is abi.DECISION_DTYPE else a      # device streams hold compact records
 
 
 def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_gpu, chunks=(None,), age=0):

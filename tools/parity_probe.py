@@ -21,7 +21,7 @@ for t in range(T):
     stream.synchronize(); torch.cuda.synchronize()
     n = int(dn.item())
     msgs = dm[:n * 64].cpu().numpy().view(abi.MSG_DTYPE)
-    got = dd[:n * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+    got = abi.expand_decisions(dd[:n * 64].cpu().numpy().view(abi.DECISION_DTYPE))
     want, _ = cpu.step_parallel(msgs)
     bad = np.flatnonzero((got.view(np.uint8).reshape(n, 64) != want.view(np.uint8).reshape(n, 64)).any(axis=1))
     kinds = np.bincount(msgs["kind"], minlength=16)
