@@ -533,7 +533,16 @@ def main():
             nb = int(n_dec[t]) * 64
             if not torch.equal(d_dec2[t * tick_bytes:t * tick_bytes + nb], d_dec[t * tick_bytes:t * tick_bytes + nb]):
                 raise SystemExit(f"PARITY FAILURE: train decisions of tick {t} differ from the per-tick launches")
+        # how many decisions of a timed tick went out in the 32-byte compact form, and which kinds stayed full
+        tW = min(Wm, T - 1)
+        rawW = d_dec2[tW * tick_bytes:tW * tick_bytes + int(n_dec[tW]) * 64].cpu().numpy().view(abi.DECISION_DTYPE)
+        isc = (rawW["flags"] & abi.F_COMPACT) != 0
+        full_by_kind = np.bincount(rawW["kind"][~isc], minlength=NK)[:NK]
+        compact_info = {"fraction": round(float(isc.mean()), 4),
+                        "decision_bytes_per_tick": int(isc.sum()) * 32 + int((~isc).sum()) * 64,
+                        "full_records_by_kind": {str(k): int(v) for k, v in enumerate(full_by_kind) if v}}
         train_info = {"ticks_per_launch": SNAPSHOT_EVERY, "blocks_per_tick": plan.blocks_per_tick, "form": eng.train_form(),
+                      "compact_decisions": compact_info,
                       "stamps": "written by the stream's producer (rgb_synth_tick_stamped_device) with the messages: "
                                 "nothing of the train's input preparation is outside the timed region except the host's "
                                 "row plan (256 bucket counts per tick)",

@@ -6,14 +6,13 @@
  *
  *   hot  [S][16] u64   128 B  every message reads it, most write it back
  *        0 current_term   1 packed (role, condition, slots, masks -- see PK_*)
- *        2 commit_index   3 last_applied     4 last_index       5 last_term
- *        6 last_written_index               7 last_written_term
- *        8 snapshot_index 9 snapshot_term  10 first_index
- *        11 last-run start index           12 last-run term
- *        13 start, 14 term of the run before the last (mirrors of the run table: a term lookup
- *           touches memory only below the newest two runs)
- *        15 first pending index (ra_log `pending` = [this .. last_index])
- *   peers[S][PS] u64   PS = roundup(3*N, 8): match_index[N] | next_index[N] | commit_index_sent[N]
+ *        2 last-run term  3 start of the run before the last (mirrors of the run table: a term lookup touches
+ *          memory only below the newest two runs)
+ *        4 commit_index   5 last_applied     6 last_index       7 last_term
+ *        8 snapshot_index 9 snapshot_term  10 first_index      11 last-run start index
+ *        12 last_written_index             13 last_written_term
+ *        14 term of the run before the last 15 first pending index (ra_log `pending` = [this .. last_index])
+ *   peers[S][PS] u64   PS = roundup(3*N, 8): (match_index, next_index) x N | commit_index_sent[N]
  *        only leader-side messages touch it
  *   runs [S][K][2] u64 (start, term) of each term run of the ra_log range; only probed when an
  *        index older than the last run is looked up (log-matching repair)
@@ -38,22 +37,41 @@ typedef uint32_t u32;
  * (term, packed) votes/roles | (commit, applied) every commit advance | (last index, last term)
  * appends | (last written index, term) written events | snapshot | range start, last-run start |
  * last-run term, pre-vote token | machine versions, first pending index */
+/* Word order chosen by what a steady-state message WRITES: a follower appending dirties (commit_index, last_applied)
+ * and (last_index, last_term) -- pieces 2 and 3, ONE aligned 32-byte sector; a written event dirties (last written
+ * index, term) and the first pending index -- pieces 6 and 7, one sector; the write-back of a dirty line goes out in
+ * 32-byte sectors and a tick's time follows its written bytes (round 4: the earlier order -- commit / last index in
+ * pieces 1 and 2, last written in piece 3 -- made each of them two sectors). */
 #define HOT_CT    0
 #define HOT_PK    1
-#define HOT_CI    2
-#define HOT_LA    3
-#define HOT_LI    4
-#define HOT_LT    5
-#define HOT_LWI   6
-#define HOT_LWT   7
+#define HOT_LRT   2    /* last-run term | (start of run n_runs-2: a mirror of the run table, like HOT_LRS of the last run) */
+#define HOT_PRS   3
+#define HOT_CI    4
+#define HOT_LA    5
+#define HOT_LI    6
+#define HOT_LT    7
 #define HOT_SI    8
 #define HOT_ST    9
 #define HOT_FIRST 10
 #define HOT_LRS   11
-#define HOT_LRT   12
-#define HOT_PRS   13   /* (start, term) of run n_runs-2: a mirror of the run table, like 11/12 of the last run */
-#define HOT_PRT   14
+#define HOT_LWI   12
+#define HOT_LWT   13
+#define HOT_PRT   14   /* term of run n_runs-2 */
 #define HOT_PEND  15
+/* the 16-byte piece (pair of words) that holds ..: the explicit piece code of the kernels goes through these */
+#define HOT_P_TERM  0  /* (current_term, packed)          */
+#define HOT_P_LRT   1  /* (last-run term, prev-run start) */
+#define HOT_P_CI    2  /* (commit_index, last_applied)    */
+#define HOT_P_LI    3  /* (last_index, last_term)         */
+#define HOT_P_SI    4  /* (snapshot index, term)          */
+#define HOT_P_FIRST 5  /* (first_index, last-run start)   */
+#define HOT_P_LW    6  /* (last written index, term)      */
+#define HOT_P_PEND  7  /* (prev-run term, first pending)  */
+/* peers row: (match_index, next_index) of member i side by side -- a counted reply dirties one 16-byte piece -- then
+ * the commit_index_sent words */
+#define PEER_MI(i, N) (2u * (unsigned)(i))
+#define PEER_NI(i, N) (2u * (unsigned)(i) + 1u)
+#define PEER_CS(i, N) (2u * (unsigned)(N) + (unsigned)(i))
 
 /* packed word: bit offset / width */
 #define PK_ROLE_SH      0   /* 3 */

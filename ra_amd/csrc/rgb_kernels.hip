@@ -52,6 +52,16 @@ namespace {
 #define RGB_X_LEAD32 1
 #endif
 __host__ __device__ constexpr bool rgb_lead_class(int c) { return c == 1 || c == 3 || c == 4; }
+/* classes whose kinds only use the first 32 bytes of their message records (include/ra_gpu_batch.h, "Field use by
+ * kind": term, a, b at most; the two-range form of a written event re-reads its record): written, pipeline_rpcs,
+ * request_vote, vote_result, await_timeout, snapshot_written, heartbeat_rpc, heartbeat_reply, consistent_query.
+ * Their wavefronts request half of every record -- a third of a tick's messages, and a tick's time follows its bytes */
+#ifndef RGB_X_HALFMSG
+#define RGB_X_HALFMSG 1
+#endif
+__host__ __device__ constexpr bool rgb_half_msg_class(int c) {
+  return RGB_X_HALFMSG && (c == 2 || c == 4 || c == 5 || c == 6 || c == 7 || c == 11 || c == 12 || c == 13 || c == 14);
+}
 __host__ __device__ constexpr u32 rgb_class_slice(int c, unsigned n_members) {
   return (RGB_X_LEAD32 && rgb_lead_class(c) && ((3u * n_members + 7u) & ~7u) == 16u) ? 32u : (u32)RGB_TICK_BLOCK;
 }
@@ -246,7 +256,7 @@ __device__ __forceinline__ void load_peers(Lane &L) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < N; ++i) { L.pmi[i] = w[i]; L.pni[i] = w[N + i]; L.pcs[i] = w[2 * N + i]; }
+  for (int i = 0; i < N; ++i) { L.pmi[i] = w[PEER_MI(i, N)]; L.pni[i] = w[PEER_NI(i, N)]; L.pcs[i] = w[PEER_CS(i, N)]; }
   L.peers_loaded = true;
 }
 
@@ -278,20 +288,20 @@ __device__ __forceinline__ void prow_set(Lane &L, unsigned w, u64 v) {
   const_cast<u64 *>(reinterpret_cast<const u64 *>(L.peers_lds))[prow_at(L, w)] = v;
   L.pdirty |= 1u << w;
 }
-template <int N, bool PL, class Lane> __device__ __forceinline__ u64 mi_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)i) : L.pmi[i]; }
-template <int N, bool PL, class Lane> __device__ __forceinline__ u64 ni_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)(N + i)) : L.pni[i]; }
-template <int N, bool PL, class Lane> __device__ __forceinline__ u64 cs_get(const Lane &L, int i) { return PL ? prow_get(L, (unsigned)(2 * N + i)) : L.pcs[i]; }
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 mi_get(const Lane &L, int i) { return PL ? prow_get(L, PEER_MI(i, N)) : L.pmi[i]; }
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 ni_get(const Lane &L, int i) { return PL ? prow_get(L, PEER_NI(i, N)) : L.pni[i]; }
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 cs_get(const Lane &L, int i) { return PL ? prow_get(L, PEER_CS(i, N)) : L.pcs[i]; }
 template <int N, bool PL, class Lane> __device__ __forceinline__ void ni_set(Lane &L, int i, u64 v) {
-  if (PL) prow_set(L, (unsigned)(N + i), v); else { L.pni[i] = v; L.dni |= 1u << i; }
+  if (PL) prow_set(L, PEER_NI(i, N), v); else { L.pni[i] = v; L.dni |= 1u << i; }
 }
 /* run-time peer index (the sender of a reply) */
-template <int N, bool PL, class Lane> __device__ __forceinline__ u64 mi_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, p) : 0) : peer_get<N>(L.pmi, p); }
-template <int N, bool PL, class Lane> __device__ __forceinline__ u64 ni_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, (unsigned)N + p) : 0) : peer_get<N>(L.pni, p); }
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 mi_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, PEER_MI(p, N)) : 0) : peer_get<N>(L.pmi, p); }
+template <int N, bool PL, class Lane> __device__ __forceinline__ u64 ni_of(const Lane &L, unsigned p) { return PL ? (p < (unsigned)N ? prow_get(L, PEER_NI(p, N)) : 0) : peer_get<N>(L.pni, p); }
 template <int N, bool PL, class Lane> __device__ __forceinline__ void mi_put(Lane &L, unsigned p, u64 v) {
-  if (PL) { if (p < (unsigned)N) prow_set(L, p, v); } else peer_set<N>(L.pmi, L.dmi, p, v);
+  if (PL) { if (p < (unsigned)N) prow_set(L, PEER_MI(p, N), v); } else peer_set<N>(L.pmi, L.dmi, p, v);
 }
 template <int N, bool PL, class Lane> __device__ __forceinline__ void ni_put(Lane &L, unsigned p, u64 v) {
-  if (PL) { if (p < (unsigned)N) prow_set(L, (unsigned)N + p, v); } else peer_set<N>(L.pni, L.dni, p, v);
+  if (PL) { if (p < (unsigned)N) prow_set(L, PEER_NI(p, N), v); } else peer_set<N>(L.pni, L.dni, p, v);
 }
 
 template <class Lane>
@@ -1847,11 +1857,13 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   if (RGB_KNOB(dev, 8u)) { h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_ulonglong2(0, 0); h0.y = 0x1Full << PK_PRESENT_SH; }
   else if (PRE) {     /* the wavefront fetched the lines cooperatively into LDS: pre = this lane's row */
     /* unpadded 128-byte rows: piece p sits at position p ^ swz (conflict-free 16-byte LDS reads, see the fetch) */
-    h0 = pre[0 ^ swz]; h1 = pre[1 ^ swz]; h2 = pre[2 ^ swz]; h3 = pre[3 ^ swz];
-    h4 = pre[4 ^ swz]; h5 = pre[5 ^ swz]; h6 = pre[6 ^ swz]; h7 = pre[7 ^ swz];
+    /* h0 (term, packed) h1 (commit, applied) h2 (last index, term) h3 (last written) h4 (snapshot) h5 (first, last-run
+     * start) h6 (last-run term, prev-run start) h7 (prev-run term, pending): by meaning, wherever the piece sits */
+    h0 = pre[HOT_P_TERM ^ swz]; h1 = pre[HOT_P_CI ^ swz]; h2 = pre[HOT_P_LI ^ swz]; h3 = pre[HOT_P_LW ^ swz];
+    h4 = pre[HOT_P_SI ^ swz]; h5 = pre[HOT_P_FIRST ^ swz]; h6 = pre[HOT_P_LRT ^ swz]; h7 = pre[HOT_P_PEND ^ swz];
   } else {
-    h0 = ldg16(TR, hp + 0); h1 = ldg16(TR, hp + 1); h2 = ldg16(TR, hp + 2); h3 = ldg16(TR, hp + 3);
-    h4 = ldg16(TR, hp + 4); h5 = ldg16(TR, hp + 5); h6 = ldg16(TR, hp + 6); h7 = ldg16(TR, hp + 7);
+    h0 = ldg16(TR, hp + HOT_P_TERM); h1 = ldg16(TR, hp + HOT_P_CI); h2 = ldg16(TR, hp + HOT_P_LI); h3 = ldg16(TR, hp + HOT_P_LW);
+    h4 = ldg16(TR, hp + HOT_P_SI); h5 = ldg16(TR, hp + HOT_P_FIRST); h6 = ldg16(TR, hp + HOT_P_LRT); h7 = ldg16(TR, hp + HOT_P_PEND);
   }
 #ifdef RGB_PROFILE
   L.prof_noprobe = RGB_KNOB(dev, 32u); L.prof_nloads = 0;
@@ -2013,15 +2025,15 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
         if (L.pdirty & (1u << w)) ST8(L.peers + w, prow_get(L, (unsigned)w));
 #pragma unroll
       for (int k = 0; k < N; ++k)
-        if (L.dcs_ci & (1u << k)) ST8(L.peers + 2 * N + k, L.ci);
+        if (L.dcs_ci & (1u << k)) ST8(L.peers + PEER_CS(k, N), L.ci);
     }
   } else if (L.dmi | L.dni | L.dcs | L.dcs_ci) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      if (L.dmi & (1u << k)) ST8(L.peers + k, L.pmi[k]);
-      if (L.dni & (1u << k)) ST8(L.peers + N + k, L.pni[k]);
-      if (L.dcs & (1u << k)) ST8(L.peers + 2 * N + k, L.pcs[k]);
-      else if (L.dcs_ci & (1u << k)) ST8(L.peers + 2 * N + k, L.ci);
+      if (L.dmi & (1u << k)) ST8(L.peers + PEER_MI(k, N), L.pmi[k]);
+      if (L.dni & (1u << k)) ST8(L.peers + PEER_NI(k, N), L.pni[k]);
+      if (L.dcs & (1u << k)) ST8(L.peers + PEER_CS(k, N), L.pcs[k]);
+      else if (L.dcs_ci & (1u << k)) ST8(L.peers + PEER_CS(k, N), L.ci);
     }
   }
   /* ---- commit: sparse `pending` (rare: only servers uploaded after a write_sparse) ---- */
@@ -2063,26 +2075,26 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
       const ulonglong2 o = pre[(unsigned)k ^ swz];
       ulonglong2 n;
       switch (k) {
-        case 0: n = make_ulonglong2(L.ct, L.pk); break;
-        case 1: n = make_ulonglong2(L.ci, L.la); break;
-        case 2: n = make_ulonglong2(L.li, L.lt); break;
-        case 3: n = make_ulonglong2(L.lwi, L.lwt); break;
-        case 4: n = make_ulonglong2(L.si, L.st); break;
-        case 5: n = make_ulonglong2(L.first, L.lrs); break;
-        case 6: n = make_ulonglong2(L.lrt, L.prs); break;
+        case HOT_P_TERM: n = make_ulonglong2(L.ct, L.pk); break;
+        case HOT_P_CI: n = make_ulonglong2(L.ci, L.la); break;
+        case HOT_P_LI: n = make_ulonglong2(L.li, L.lt); break;
+        case HOT_P_LW: n = make_ulonglong2(L.lwi, L.lwt); break;
+        case HOT_P_SI: n = make_ulonglong2(L.si, L.st); break;
+        case HOT_P_FIRST: n = make_ulonglong2(L.first, L.lrs); break;
+        case HOT_P_LRT: n = make_ulonglong2(L.lrt, L.prs); break;
         default: n = make_ulonglong2(L.prt, L.pend); break;
       }
       if (n.x != o.x || n.y != o.y) ST16(ho + k, n);
     }
   } else {
-  if (L.ct != h0.x || L.pk != h0.y) ST16(ho + 0, make_ulonglong2(L.ct, L.pk));
-  if (L.ci != h1.x || L.la != h1.y) ST16(ho + 1, make_ulonglong2(L.ci, L.la));
-  if (L.li != h2.x || L.lt != h2.y) ST16(ho + 2, make_ulonglong2(L.li, L.lt));
-  if (L.lwi != h3.x || L.lwt != h3.y) ST16(ho + 3, make_ulonglong2(L.lwi, L.lwt));
-  if (L.si != h4.x || L.st != h4.y) ST16(ho + 4, make_ulonglong2(L.si, L.st));
-  if (L.first != h5.x || L.lrs != h5.y) ST16(ho + 5, make_ulonglong2(L.first, L.lrs));
-  if (L.lrt != h6.x || L.prs != h6.y) ST16(ho + 6, make_ulonglong2(L.lrt, L.prs));
-  if (L.prt != h7.x || L.pend != h7.y) ST16(ho + 7, make_ulonglong2(L.prt, L.pend));
+  if (L.ct != h0.x || L.pk != h0.y) ST16(ho + HOT_P_TERM, make_ulonglong2(L.ct, L.pk));
+  if (L.ci != h1.x || L.la != h1.y) ST16(ho + HOT_P_CI, make_ulonglong2(L.ci, L.la));
+  if (L.li != h2.x || L.lt != h2.y) ST16(ho + HOT_P_LI, make_ulonglong2(L.li, L.lt));
+  if (L.lwi != h3.x || L.lwt != h3.y) ST16(ho + HOT_P_LW, make_ulonglong2(L.lwi, L.lwt));
+  if (L.si != h4.x || L.st != h4.y) ST16(ho + HOT_P_SI, make_ulonglong2(L.si, L.st));
+  if (L.first != h5.x || L.lrs != h5.y) ST16(ho + HOT_P_FIRST, make_ulonglong2(L.first, L.lrs));
+  if (L.lrt != h6.x || L.prs != h6.y) ST16(ho + HOT_P_LRT, make_ulonglong2(L.lrt, L.prs));
+  if (L.prt != h7.x || L.pend != h7.y) ST16(ho + HOT_P_PEND, make_ulonglong2(L.prt, L.pend));
   }
   if (TM && L.token != token0) ST8(qry_row(L) + QRY_TOKEN, L.token);
   }
@@ -2131,8 +2143,8 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
   if (wire_kind != RGB_MSG_AER || server >= dev.n_servers || from >= 8u || mflags != 0) FP_DECLINE(0, 1);
   if (gap != 0) FP_DECLINE(0, 2);
   if (n_run0 < n_entries) FP_DECLINE(0, 4);                          /* entries of two terms */
-  const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h5 = pre[5 ^ swz],
-                   h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
+  const ulonglong2 h0 = pre[HOT_P_TERM ^ swz], h1 = pre[HOT_P_CI ^ swz], h2 = pre[HOT_P_LI ^ swz], h3 = pre[HOT_P_LW ^ swz],
+                   h5 = pre[HOT_P_FIRST ^ swz], h6 = pre[HOT_P_LRT ^ swz], h7 = pre[HOT_P_PEND ^ swz];
   const u64 ct = h0.x, pk = h0.y, la = h1.y, li = h2.x, lt = h2.y, lwi = h3.x, first = h5.x, lrs = h5.y, lrt = h6.x,
             pend = h7.y;
   /* follower (role 0, no condition), the sender is the leader we know, nothing sparse pending, a run table */
@@ -2159,7 +2171,7 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
   const u64 at = lst < ci ? lst : ci;
   if (at > la) { nla = at; flags |= RGB_F_APPLIED | RGB_F_AUX_EVAL; }     /* apply_to/5: at >= la + 1 */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS);
-  if (ci != h1.x || nla != la) ST16(ho + 1, make_ulonglong2(ci, nla));
+  if (ci != h1.x || nla != la) ST16(ho + HOT_P_CI, make_ulonglong2(ci, nla));
   if (n_entries == 0) {
     /* the empty rpc at the tail (nothing new to write, :1304-1343): validated, the commit index is the leader's, the
      * success reply carries what is written (append_entries_reply/3 :3624-3631) */
@@ -2168,7 +2180,7 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
     return true;
   }
   flags |= RGB_F_WROTE;
-  ST16(ho + 2, make_ulonglong2(lst, lt));
+  ST16(ho + HOT_P_LI, make_ulonglong2(lst, lt));
   make_decision(out, server, RGB_ROLE_FOLLOWER, RGB_NONE, 0, RGB_MSG_AER, flags, 0, 0, fst, lst, 0, ci, nla);
   return true;
 }
@@ -2181,8 +2193,8 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
   const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), mflags = (unsigned)((m0.x >> 48) & 0xFF);
   if (wire_kind != RGB_MSG_WRITTEN || server >= dev.n_servers || mflags != 0) FP_DECLINE(2, 1);
-  const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h4 = pre[4 ^ swz],
-                   h5 = pre[5 ^ swz], h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
+  const ulonglong2 h0 = pre[HOT_P_TERM ^ swz], h1 = pre[HOT_P_CI ^ swz], h2 = pre[HOT_P_LI ^ swz], h3 = pre[HOT_P_LW ^ swz],
+                   h4 = pre[HOT_P_SI ^ swz], h5 = pre[HOT_P_FIRST ^ swz], h6 = pre[HOT_P_LRT ^ swz], h7 = pre[HOT_P_PEND ^ swz];
   const u64 ct = h0.x, pk = h0.y, li = h2.x, si = h4.x, first = h5.x, lrs = h5.y, lrt = h6.x, pend = h7.y;
   const unsigned l4 = (unsigned)pk_get(pk, PK_LEADER_SH, 4);
   if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER) FP_DECLINE(2, 2);   /* the leader's own written event */
@@ -2205,9 +2217,9 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
   if (pend <= li && to + 1 > pend) npend = to + 1;                    /* == li + 1 when everything is confirmed */
   const bool changed = !(h3.x == to && h3.y == term);
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS);
-  if (changed) ST16(ho + 3, make_ulonglong2(to, term));
+  if (changed) ST16(ho + HOT_P_LW, make_ulonglong2(to, term));
 #ifndef RGB_X_NOPEND      /* EXPERIMENT (breaks parity): what is the second dirty sector of a written event worth? */
-  if (npend != pend) ST16(ho + 7, make_ulonglong2(h7.x, npend));
+  if (npend != pend) ST16(ho + HOT_P_PEND, make_ulonglong2(h7.x, npend));
 #endif
   u32 flags = 0;
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
@@ -2233,8 +2245,8 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF);
   if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || peer >= (unsigned)N) FP_DECLINE(1, 1);
   if (mflags != RGB_MF_SUCCESS) FP_DECLINE(1, 2);                    /* a failed reply */
-  const ulonglong2 h0 = pre[0 ^ swz], h1 = pre[1 ^ swz], h2 = pre[2 ^ swz], h3 = pre[3 ^ swz], h4 = pre[4 ^ swz],
-                   h5 = pre[5 ^ swz], h6 = pre[6 ^ swz], h7 = pre[7 ^ swz];
+  const ulonglong2 h0 = pre[HOT_P_TERM ^ swz], h1 = pre[HOT_P_CI ^ swz], h2 = pre[HOT_P_LI ^ swz], h3 = pre[HOT_P_LW ^ swz],
+                   h4 = pre[HOT_P_SI ^ swz], h5 = pre[HOT_P_FIRST ^ swz], h6 = pre[HOT_P_LRT ^ swz], h7 = pre[HOT_P_PEND ^ swz];
   const u64 ct = h0.x, pk = h0.y, ci0 = h1.x, la = h1.y, li = h2.x, lwi = h3.x, si = h4.x, st = h4.y, first = h5.x,
             lrs = h5.y, lrt = h6.x, prs = h6.y, prt = h7.x;
   const unsigned present = (unsigned)pk_get(pk, PK_PRESENT_SH, 8), voters = (unsigned)pk_get(pk, PK_VOTER_SH, 8);
@@ -2244,23 +2256,24 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   if (!((present >> peer) & 1u)) FP_DECLINE(1, 5);
   if (n_runs < 2 && (h6.y | h7.x) != 0) FP_DECLINE(1, 6);
   u64 *peers = dev.peers + (size_t)server * dev.peer_stride;
-  u64 w[2 * N + (N & 1)];
+  /* piece i of the peers row = (match_index, next_index) of member i */
+  u64 wm[N], wn[N];
   if (prow != nullptr) {
 #pragma unroll
-    for (int k = 0; k < (2 * N + 1) / 2; ++k) { const ulonglong2 v = prow[(unsigned)k ^ swz]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    for (int k = 0; k < N; ++k) { const ulonglong2 v = prow[(unsigned)k ^ swz]; wm[k] = v.x; wn[k] = v.y; }
   } else {
     const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(peers);
 #pragma unroll
-    for (int k = 0; k < (2 * N + 1) / 2; ++k) { const ulonglong2 v = ldg16(TR, pp + k); w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+    for (int k = 0; k < N; ++k) { const ulonglong2 v = ldg16(TR, pp + k); wm[k] = v.x; wn[k] = v.y; }
   }
   /* match_index / next_index of the peer only move forward (:540-547) */
   u64 mi_new = 0, ni_new = 0; bool mi_dirty = false, ni_dirty = false;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if ((unsigned)i != peer) continue;
-    mi_new = w[i]; ni_new = w[N + i];
-    if (m1.y > w[i]) { mi_new = m1.y; mi_dirty = true; w[i] = m1.y; }
-    if (m1.x > w[N + i]) { ni_new = m1.x; ni_dirty = true; }
+    mi_new = wm[i]; ni_new = wn[i];
+    if (m1.y > wm[i]) { mi_new = m1.y; mi_dirty = true; wm[i] = m1.y; }
+    if (m1.x > wn[i]) { ni_new = m1.x; ni_dirty = true; }
   }
   /* agreed_commit/1 over the voters' match indexes and the leader's last written index: descending order statistic
    * n/2 + 1 by rank counting */
@@ -2269,7 +2282,7 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const bool u = ((unsigned)i != self) && ((present >> i) & 1u) && ((voters >> i) & 1u);
-    v[i] = w[i]; use[i] = u; n += u ? 1 : 0;
+    v[i] = wm[i]; use[i] = u; n += u ? 1 : 0;
   }
   const u64 p = agreed_commit<N + 1>(v, use, n);
   u64 t = UNDEF;
@@ -2298,12 +2311,12 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   if (t != UNDEF && t == ct) ci = p;                                 /* Raft 5.4.2; NO max() */
   if (ci > ci0) flags |= RGB_F_AUX_EVAL;
   if (ci > la) { const u64 to = li < ci ? li : ci; if (to >= la + 1) { nla = to; flags |= RGB_F_APPLIED; } }
-  if (mi_dirty) ST8(peers + peer, mi_new);
-#ifndef RGB_X_NONIW       /* EXPERIMENT (breaks parity): the reply's next_index store (a second sector of the peers row) */
-  if (ni_dirty) ST8(peers + N + peer, ni_new);
-#endif
+  /* the two words are one 16-byte piece of the row */
+  if (mi_dirty && ni_dirty) ST16(reinterpret_cast<ulonglong2 *>(peers) + peer, make_ulonglong2(mi_new, ni_new));
+  else if (mi_dirty) ST8(peers + PEER_MI(peer, N), mi_new);
+  else if (ni_dirty) ST8(peers + PEER_NI(peer, N), ni_new);
   if (ci != ci0 || nla != la)
-    ST16(reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS) + 1, make_ulonglong2(ci, nla));
+    ST16(reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS) + HOT_P_CI, make_ulonglong2(ci, nla));
   make_decision(out, server, RGB_ROLE_LEADER, RGB_NONE, 0, RGB_MSG_AER_REPLY, flags, 0, 0, 0, 0, 0, ci, nla);
   return true;
 }
@@ -2526,13 +2539,14 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
      * conflict-free 16-byte LDS reads without padding.  Pieces past the slice's end re-read its last piece, their
      * LDS slots are never consumed. */
     const u32 last = cnt * 4u - 1u;
+    const bool half = rgb_half_msg_class(cls);            /* only pieces 0, 1 of every record are asked for */
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if ((u32)k * 16u >= SL) break;                      /* a 32-message slice is two copies */
       const u32 piece = k * RGB_TICK_BLOCK + lane;
       const u32 r = piece >> 2;
       const u32 sp = (r << 2) | ((piece & 3u) ^ ((r >> 2) & 3u));
-      glds16<GLDS_NT>(src + (sp < last ? sp : last), io + k * RGB_TICK_BLOCK);
+      if (!half || (sp & 2u) == 0u) glds16<GLDS_NT>(src + (sp < last ? sp : last), io + k * RGB_TICK_BLOCK);
     }
     glds_wait();
   }
@@ -2542,8 +2556,14 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #endif
   const bool active = lane < cnt;
   const u32 mswz = (lane >> 2) & 3u;
-  const ulonglong2 m0 = io[lane * 4 + (0 ^ mswz)], m1 = io[lane * 4 + (1 ^ mswz)],
-                   m2 = io[lane * 4 + (2 ^ mswz)], m3 = io[lane * 4 + (3 ^ mswz)];
+  const ulonglong2 m0 = io[lane * 4 + (0 ^ mswz)], m1 = io[lane * 4 + (1 ^ mswz)];
+  ulonglong2 m2 = io[lane * 4 + (2 ^ mswz)], m3 = io[lane * 4 + (3 ^ mswz)];
+  if (rgb_half_msg_class(cls)) {
+    /* the upper half was not loaded: zeros, as the field list of these kinds says -- but for a written event that
+     * carries two ranges (RGB_MF_SEQ2: the lower one rides in the record's last piece), which re-reads its record */
+    m2 = make_ulonglong2(0, 0); m3 = make_ulonglong2(0, 0);
+    if (cls == 2 && active && (((m0.x >> 48) & 0xFFull) & RGB_MF_SEQ2)) m3 = ld16<true>(src + lane * 4u + 3u);
+  }
   RGB_TT(1);
   const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
   /* the message addresses a server (a NOP or an out-of-range id touches no state and has no stamp) */
@@ -3095,7 +3115,8 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
 #pragma unroll
   for (int m = 0; m < N; ++m) {
     const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(dev.hot + ((size_t)g * N + m) * RGB_HOT_WORDS);
-    const ulonglong2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h5 = hp[5], h6 = hp[6], h7 = hp[7];
+    const ulonglong2 h0 = hp[HOT_P_TERM], h1 = hp[HOT_P_CI], h2 = hp[HOT_P_LI], h3 = hp[HOT_P_LW], h5 = hp[HOT_P_FIRST],
+                     h6 = hp[HOT_P_LRT], h7 = hp[HOT_P_PEND];
     mb[m].ct = h0.x; mb[m].pk = h0.y; mb[m].ci = h1.x; mb[m].la = h1.y; mb[m].li = h2.x;
     mb[m].lt = h2.y; mb[m].lwi = h3.x; mb[m].lwt = h3.y; mb[m].first = h5.x; mb[m].lrs = h5.y;
     mb[m].lrt = h6.x; mb[m].prs = h6.y; mb[m].prt = h7.x;
@@ -3202,7 +3223,7 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
       if (RGB_KNOB(dev, 128u) && v >= 75 && v < 80) v = 0;   /* profiling: no failed replies */
       const int j = other(l, r >> 16);
       const u64 *pr = dev.peers + (size_t)sid(l) * dev.peer_stride;
-      const u64 mi = pr[j];
+      const u64 mi = pr[PEER_MI(j, N)];
       LaneT<false> T;                                   /* term lookups against the leader's log */
       syn_lane(T, ld, dev.runs + (size_t)sid(l) * dev.max_runs * 2);
       if (v < 75) {
@@ -3425,7 +3446,7 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
   u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < dev.peer_stride; ++i) pr[i] = 0;
   for (unsigned i = 0; i < N; ++i) {
-    pr[i] = h.match_index[i]; pr[N + i] = h.next_index[i]; pr[2 * N + i] = h.commit_index_sent[i];
+    pr[PEER_MI(i, N)] = h.match_index[i]; pr[PEER_NI(i, N)] = h.next_index[i]; pr[PEER_CS(i, N)] = h.commit_index_sent[i];
   }
   u64 *cd = dev.cond + (size_t)s * 4;
   for (int i = 0; i < 4; ++i) cd[i] = h.cond_reply[i];
@@ -3449,7 +3470,7 @@ __global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ ou
   for (int i = 0; i < 4; ++i) h.cond_reply[i] = cd[i];
   const u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < N; ++i) {
-    h.match_index[i] = pr[i]; h.next_index[i] = pr[N + i]; h.commit_index_sent[i] = pr[2 * N + i];
+    h.match_index[i] = pr[PEER_MI(i, N)]; h.next_index[i] = pr[PEER_NI(i, N)]; h.commit_index_sent[i] = pr[PEER_CS(i, N)];
   }
   unsigned nr = (unsigned)pk_get(pk, PK_NRUNS_SH, 5);
   const u64 *runs = dev.runs + (size_t)s * dev.max_runs * 2;
@@ -3499,8 +3520,8 @@ __global__ void rgb_leaderboard_kernel(rgb_dev dev, rgb_leaderboard_row *__restr
   u64 term = 0, lead_term = 0, ci = 0, la = 0, max_ci = 0, max_la = 0;
   for (unsigned m = 0; m < N; ++m) {
     const u64 *hot = dev.hot + ((size_t)g * N + m) * RGB_HOT_WORDS;
-    const ulonglong2 h0 = reinterpret_cast<const ulonglong2 *>(hot)[0];
-    const ulonglong2 h1 = reinterpret_cast<const ulonglong2 *>(hot)[1];
+    const ulonglong2 h0 = reinterpret_cast<const ulonglong2 *>(hot)[HOT_P_TERM];
+    const ulonglong2 h1 = reinterpret_cast<const ulonglong2 *>(hot)[HOT_P_CI];
     const u64 pk = hot[HOT_PK];
     const u64 ct = h0.x;
     if (ct > term) term = ct;
@@ -3565,7 +3586,7 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   x = fnv_word(x, (dev.qry + (size_t)s * RGB_QRY_WORDS)[QRY_MACVER]);
   const u64 *pr = dev.peers + (size_t)s * dev.peer_stride;
   for (unsigned i = 0; i < N; ++i) {
-    x = fnv_word(x, pr[i]); x = fnv_word(x, pr[N + i]); x = fnv_word(x, pr[2 * N + i]);
+    x = fnv_word(x, pr[PEER_MI(i, N)]); x = fnv_word(x, pr[PEER_NI(i, N)]); x = fnv_word(x, pr[PEER_CS(i, N)]);
   }
   const u64 *runs = dev.runs + (size_t)s * dev.max_runs * 2;
   for (unsigned r = 0; r < nr; ++r) { x = fnv_word(x, runs[2 * r]); x = fnv_word(x, runs[2 * r + 1]); }
