@@ -2532,6 +2532,10 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   RGB_TT(0);
   if (TR && RGB_X_TICKET_AT == 2 && ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
+  /* a train's stamp byte travels with the record copies: requested here, it arrives under their round trip (behind
+   * the records' barrier it was a second memory round trip in front of the first poll) */
+  unsigned need_raw = 0;
+  if (TR && lane < cnt) need_raw = (unsigned)stamps[base + lane];
   {
     /* four 1 KiB global -> LDS copies in flight (read once: non-temporal), no staging registers and no ds_write
      * pass: record r lands at io[4 r ..], its piece p at position p ^ ((r >> 2) & 3).  The permutation is applied to
@@ -2585,7 +2589,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     }
     /* 1. dependencies: this server's previous message -- an earlier tick of this launch -- has committed */
     seqp = dev.seq + rgb_seq_index(has_srv ? sv : 0u, dev.n_members, dev.seq_stride);
-    need = has_srv ? (unsigned)stamps[base + lane] : 0u;
+    need = has_srv ? need_raw : 0u;
     unsigned spins = 0;
     bool late = has_srv;
     for (;;) {

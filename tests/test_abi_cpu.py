@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions(header="ra_gpu_batch.h"):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rgb_[a-z0-9_]+)\s*\(", src)))
+    # `static inline` helpers (rgb_decision_expand) are header code, not exports
+    inline = set(re.findall(r"static\s+inline\s+[a-z_0-9 ]*?\b(rgb_[a-z0-9_]+)\s*\(", src))
+    return sorted(set(re.findall(r"\b(rgb_[a-z0-9_]+)\s*\(", src)) - inline)
 
 
 @pytest.fixture(scope="module")
