@@ -561,7 +561,7 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
       /* the first messages of two shards of one (round, class) change places (with their stamps and their places in
        * the permutation): the tick is still class-ordered, so the per-round replay computes it */
       bool done = false;
-      for (u32 c = 0; c < RGB_N_CLASSES && !done; ++c)
+      for (u32 c = 0; c < RGB_N_PCLASSES && !done; ++c)
         for (u32 x = 0; x + 1 < RGB_TRAIN_SHARDS && !done; ++x) {
           const rgb_train_tick &t0 = s.h_plan[0];
           if (t0.cnt[c][x] == 0 || t0.cnt[c][x + 1] == 0) continue;

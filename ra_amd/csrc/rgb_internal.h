@@ -144,6 +144,17 @@ static inline __host__ __device__ unsigned rgb_bucket(unsigned kind, unsigned fl
   return (rgb_kind_rank(kind) * RGB_TRAIN_SHARDS + rgb_shard_of_server(server, n_members)) * 2u +
          ((flags & RGB_MF_SUCCESS) ? 1u : 0u);
 }
+/* The same with the producer's HINT for the kinds that carry no success flag: off_steady = "the owning gen_statem is
+ * not in the state this kind's steady-state outcome needs" (a written event of a server that is leader, an
+ * append_entries_rpc for a server that is not follower -- ra_server_proc knows its own state name, the device-side
+ * generator reads the role).  The hint only ORDERS the tick: hinted messages sit in sub-bucket 1 of their (class,
+ * shard), so the wavefronts of sub-bucket 0 are steady-state lanes only and skip the general clause code.  A wrong or
+ * absent hint costs time, never a result: nothing in the kernels reads the sub-bucket. */
+static inline __host__ __device__ unsigned rgb_bucket_hinted(unsigned kind, unsigned flags, unsigned server,
+                                                             unsigned n_members, bool off_steady) {
+  const bool hinted_kind = kind == RGB_MSG_WRITTEN || kind == RGB_MSG_AER;
+  return rgb_bucket(kind, flags, server, n_members) | ((hinted_kind && off_steady) ? 1u : 0u);
+}
 /* position of a server's sequence byte: the bytes of one shard are contiguous, so an XCD's L2 never holds a line of
  * the array that another XCD writes */
 static inline __host__ __device__ unsigned rgb_seq_index(unsigned server, unsigned n_members, unsigned seq_stride) {
@@ -153,12 +164,17 @@ static inline __host__ __device__ unsigned rgb_seq_index(unsigned server, unsign
 #define RGB_TRAIN_MAX_TICKS 255u   /* ticks per launch: the values a sequence byte takes within one launch are distinct */
 /* one tick of a train: rows of RGB_TRAIN_SHARDS blocks; row r of class c serves slice r of every shard (the row table
  * of rgb_train_make_tick says which (class, row) a block row of the tick is) */
+/* A class's two sub-buckets (bucket bit 0: the success flag of a reply, the producer's steady-state hint for the other
+ * kinds -- rgb_bucket_hinted) are separate row sets, "plan classes" pc = 2 x class + sub: a slice never straddles them,
+ * and each is spread over the tick by its own group order (a sub-bucket that simply sat behind the other one inside
+ * the class's rows would meet its servers' next messages less than a tick later). */
+#define RGB_N_PCLASSES (2u * RGB_N_CLASSES)
 struct rgb_train_tick {
   u32 n_rows;
   u32 msg_base;                                  /* first message of the tick when the launch has no tick stride (rgb_submit) */
   u32 pad[14];
-  u32 off[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* first message of (class, shard)  */
-  u32 cnt[RGB_N_CLASSES][RGB_TRAIN_SHARDS];     /* its message count                */
+  u32 off[RGB_N_PCLASSES][RGB_TRAIN_SHARDS];    /* first message of (plan class, shard)  */
+  u32 cnt[RGB_N_PCLASSES][RGB_TRAIN_SHARDS];    /* its message count                     */
 };
 /* the load generator's scratch: RGB_SYNTH_FIXED_WORDS (family totals -- what rgb_tick_classes_kernel reads -- |
  * bucket totals | bucket bases) + RGB_N_BUCKETS words per generator block (64 groups): rgb_synth_scratch_words() */

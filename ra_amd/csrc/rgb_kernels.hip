@@ -56,6 +56,9 @@ __host__ __device__ constexpr bool rgb_lead_class(int c) { return c == 1 || c ==
  * kind": term, a, b at most; the two-range form of a written event re-reads its record): written, pipeline_rpcs,
  * request_vote, vote_result, await_timeout, snapshot_written, heartbeat_rpc, heartbeat_reply, consistent_query.
  * Their wavefronts request half of every record -- a third of a tick's messages, and a tick's time follows its bytes */
+#ifndef RGB_X_HINT
+#define RGB_X_HINT 1        /* the generator's steady-state bucketing hint (rgb_bucket_hinted); 0: A/B timing only */
+#endif
 #ifndef RGB_X_HALFMSG
 #define RGB_X_HALFMSG 1
 #endif
@@ -2728,6 +2731,11 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     if (!TR && RGB_KNOB(dev, 16u)) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
 #endif
   }
+  /* the 32-byte form of the decision where its shape allows -- register arithmetic, done HERE so that in a train it
+   * runs under the acknowledgements the publish step waits for (behind the publish it kept the wavefront's slot
+   * for ~0.8 us longer); the storing lanes learn the record sizes from the ballot, not from the LDS slots */
+  const bool is_compact = active && compact_decision(d);
+  const u64 cmask = __ballot(is_compact);
   RGB_TT(4);
   if (TR) {
     /* 4. publish: every state store of this wavefront has been acknowledged by the L2 (inline assembly: the
@@ -2759,11 +2767,12 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   RGB_TT(5);
   lds_barrier();      /* every lane is done with its hot row before the decisions overlay the rows */
   if (active) {
-    (void)compact_decision(d);       /* 32 bytes where the outcome allows: the storing lanes read the flag from the slot */
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
-    io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
-    io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
+    if (!is_compact) {
+      io[lane * RGB_IO_SLOT + 2] = make_ulonglong2(d.w[4], d.w[5]);
+      io[lane * RGB_IO_SLOT + 3] = make_ulonglong2(d.w[6], d.w[7]);
+    }
   }
   lds_barrier();
   if (!TR && RGB_KNOB(dev, 2u)) return true;
@@ -2777,7 +2786,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     if (j < cnt && part < 2u) store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
 #else
     /* the upper half of a compact record is not written */
-    if (j < cnt && (part < 2u || !((u32)io[j * RGB_IO_SLOT].y & RGB_F_COMPACT)))
+    if (j < cnt && (part < 2u || !((cmask >> j) & 1ull)))
       store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
 #endif
   }
@@ -2922,8 +2931,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   const rgb_train_tick *p = args.plan + t;
   if (row >= p->n_rows) return;
   const u32 e = args.row_tab[(size_t)t * args.rpt + row];
-  const int cls = (int)(e >> 24);
-  const u32 off = p->off[cls][x], ncls = p->cnt[cls][x];
+  const u32 pc = e >> 24;                                  /* plan class = 2 x class + sub-bucket */
+  const int cls = (int)(pc >> 1);
+  const u32 off = p->off[pc][x], ncls = p->cnt[pc][x];
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
   const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
   const u32 lbase = (e & 0xFFFFFFu) * SL;
@@ -3007,8 +3017,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
     if (t >= n_ticks) break;
     const rgb_train_tick *p = plan + t;
     const u32 e = A->row_tab[(size_t)t * A->rpt + (k - cum)];
-    const int cls = (int)(e >> 24);
-    const u32 off = p->off[cls][x], ncls = p->cnt[cls][x];
+    const u32 pc = e >> 24;                                /* plan class = 2 x class + sub-bucket */
+    const int cls = (int)(pc >> 1);
+    const u32 off = p->off[pc][x], ncls = p->cnt[pc][x];
     const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
     const u32 lbase = (e & 0xFFFFFFu) * SL;
     u32 *const tk = A->ctl + RGB_TRAIN_CTL_TICKET * (1u + x);
@@ -3089,6 +3100,7 @@ __device__ __forceinline__ void syn_lane(Lane &T, const SynMember &x, const u64 
 
 struct SynMsg {
   u32 server; unsigned kind, from, flags, gap; u64 term, a, b, c; u32 n_entries, n_run0; u64 run0, run1;
+  bool off_steady;      /* the producer's bucketing hint (rgb_bucket_hinted): never part of the record */
 };
 
 __device__ __forceinline__ void syn_store(rgb_msg *slot, const SynMsg &m) {
@@ -3106,6 +3118,7 @@ __device__ __forceinline__ SynMsg syn_msg(u32 server, unsigned kind, unsigned fr
   SynMsg m;
   m.server = server; m.kind = kind; m.from = from; m.flags = flags; m.gap = 0; m.term = term;
   m.a = a; m.b = b; m.c = c; m.n_entries = n_entries; m.n_run0 = n_run0; m.run0 = run0; m.run1 = 0;
+  m.off_steady = false;
   return m;
 }
 
@@ -3216,7 +3229,9 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
       emit(syn_msg(sid(l), RGB_MSG_APPEND, RGB_NONE, RGB_MF_FORCE, 0, 0, 0, 0, 1));
     } else if (ld.lwi < ld.li && (r & 3) == 0) {
       const u64 a = ld.lwi + 1 > ld.first ? ld.lwi + 1 : ld.first;
-      emit(syn_msg(sid(l), RGB_MSG_WRITTEN, RGB_NONE, 0, ld.lt, a, ld.li, 0));
+      SynMsg w = syn_msg(sid(l), RGB_MSG_WRITTEN, RGB_NONE, 0, ld.lt, a, ld.li, 0);
+      w.off_steady = RGB_X_HINT;                          /* the owner is in state leader (ra_server_proc knows) */
+      emit(w);
     } else if (hb_lag >= 0 && (r >> 40) % 3 == 0) {
       /* a follower that has not confirmed the current query index answers the heartbeat */
       emit(syn_msg(sid(l), RGB_MSG_HEARTBEAT_REPLY, hb_lag, 0, ld.ct, lq, 0, 0));
@@ -3274,10 +3289,14 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
           prev_i = f.li - back; prev_t = f.lt; n_ent = (u32)back; run0 = f.lt;
         }
       }
-      emit(syn_msg(sid(j), RGB_MSG_AER, l, 0, ld.ct, prev_i, prev_t, ld.ci, n_ent, n_ent, run0));
+      SynMsg w = syn_msg(sid(j), RGB_MSG_AER, l, 0, ld.ct, prev_i, prev_t, ld.ci, n_ent, n_ent, run0);
+      w.off_steady = RGB_X_HINT && pk_get(f.pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER;     /* the receiver's own state name */
+      emit(w);
     } else if (f.lwi < f.li && f.first <= f.li && (r >> 8) % 10 < 8) {
       const u64 a = f.lwi + 1 > f.first ? f.lwi + 1 : f.first;
-      emit(syn_msg(sid(j), RGB_MSG_WRITTEN, RGB_NONE, 0, f.lt, a, f.li, 0));
+      SynMsg w = syn_msg(sid(j), RGB_MSG_WRITTEN, RGB_NONE, 0, f.lt, a, f.li, 0);
+      w.off_steady = RGB_X_HINT && pk_get(f.pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER;
+      emit(w);
     }
   }
 }
@@ -3303,7 +3322,7 @@ __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u6
   __syncthreads();
   const u32 G = dev.n_servers / N;
   const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-  auto bucket = [](const SynMsg &m) -> unsigned { return rgb_bucket(m.kind, m.flags, m.server, (unsigned)N); };
+  auto bucket = [](const SynMsg &m) -> unsigned { return rgb_bucket_hinted(m.kind, m.flags, m.server, (unsigned)N, m.off_steady); };
   if (!WRITE) {
     if (g < G) synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) { atomicAdd(&cnt[bucket(m)], 1u); });
     __syncthreads();
@@ -3768,7 +3787,8 @@ int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u3
  * by RELATIVE POSITION (j + 1/2) / rows(c): buckets are in group order, so the messages of one group range sit at the
  * same place of the block order whatever their class -- and a server's next message, whatever ITS class, comes one
  * whole tick of blocks after the previous one: the wavefront that serves it finds its dependencies committed instead of
- * holding a slot while it waits.  row_tab[k] = class << 24 | row of the class; returns the number of rows. */
+ * holding a slot while it waits.  row_tab[k] = plan class << 24 | row of the plan class (plan class = 2 x class + sub-bucket,
+ * rgb_internal.h); returns the number of rows. */
 /* how much earlier than its group range's place in the tick a class's rows start, in ticks (measured wavefront
  * lives, tools/train_timeline.py, relative to the append_entries_rpc class; index = class rank) */
 float rgb_train_lead[RGB_N_CLASSES] = {0.0f, 0.15f, 0.10f, 0.08f, 0.08f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.25f, 0.0f, 0.0f, 0.0f};
@@ -3778,43 +3798,55 @@ extern "C" void rgb_train_set_lead(const float *lead) {      /* tuning hook of t
 
 u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap) {
   u32 acc = 0;
-  u32 rows_of[RGB_N_CLASSES];
-  for (unsigned c = 0; c <= RGB_N_CLASSES; ++c) {
+  u32 rows_of[RGB_N_PCLASSES];
+  for (unsigned pc = 0; pc < RGB_N_PCLASSES + 2u; ++pc) {      /* (the two sub-buckets of the NOP class only advance acc) */
+    const unsigned c = pc >> 1, sub = pc & 1u;
     u32 need = 0;
     for (unsigned x = 0; x < RGB_TRAIN_SHARDS; ++x) {
-      const u32 n = bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u] + bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u + 1u];
-      if (c < RGB_N_CLASSES) {
-        out->off[c][x] = acc; out->cnt[c][x] = n;
+      /* the stream is bucket-major: (class, shard, sub) -- the two sub-buckets of one shard are neighbours */
+      const u32 n = bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u + sub];
+      if (pc < RGB_N_PCLASSES) {
+        u32 before = 0;                                          /* messages of the class in front of (shard x, sub) */
+        for (unsigned y = 0; y < RGB_TRAIN_SHARDS; ++y)
+          before += (y < x ? bucket_counts[(c * RGB_TRAIN_SHARDS + y) * 2u] + bucket_counts[(c * RGB_TRAIN_SHARDS + y) * 2u + 1u] : 0u);
+        if (sub) before += bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u];
+        out->off[pc][x] = acc + before; out->cnt[pc][x] = n;
         const u32 sl = rgb_class_slice((int)c, n_members);
         const u32 r = (n + sl - 1) / sl;
         if (r > need) need = r;
       }
-      acc += n;
     }
-    if (c < RGB_N_CLASSES) rows_of[c] = need;
+    if (pc < RGB_N_PCLASSES) rows_of[pc] = need;
+    if (sub) {                                                   /* the class is done: its messages are behind us */
+      for (unsigned x = 0; x < RGB_TRAIN_SHARDS; ++x)
+        acc += bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u] + bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u + 1u];
+    }
   }
   u32 total = 0;
-  for (unsigned c = 0; c < RGB_N_CLASSES; ++c) total += rows_of[c];
+  for (unsigned pc = 0; pc < RGB_N_PCLASSES; ++pc) total += rows_of[pc];
   out->n_rows = total;
   out->msg_base = 0;
   if (row_tab == nullptr || total > row_cap) return total;
-  /* merge by key (j + 1/2) / rows(c) - lead(c): a class whose wavefronts live longer starts that much earlier, so
+  /* merge by key (j + 1/2) / rows(pc) - lead(class): a class whose wavefronts live longer starts that much earlier, so
    * that what lines up from tick to tick is the time a group range's messages COMMIT, not the time they start: a
    * wavefront's dependencies then have the slack of (cadence - its own life) whatever class committed them
    * (without the leads the slowest classes -- snapshot_written, the leader-side ones -- commit later than one tick
    * after their predecessors start, the wavefronts that depend on them wait holding their slots, live longer
    * themselves, and the waits cascade).  rgb_train_lead[] is in ticks; ties: the heavier class first. */
-  /* a merge of the non-empty classes in heaviest-first order (the tie break), keys advanced by addition: this runs
+  /* a merge of the non-empty plan classes in heaviest-first order (the tie break), keys advanced by addition: this runs
    * on the host once per tick of every plan (~4 us for the 65 536 x 5 closed loop) */
-  int act[RGB_N_CLASSES]; u32 next[RGB_N_CLASSES]; double key[RGB_N_CLASSES], step[RGB_N_CLASSES];
+  int act[RGB_N_PCLASSES]; u32 next[RGB_N_PCLASSES]; double key[RGB_N_PCLASSES], step[RGB_N_PCLASSES];
   unsigned n_act = 0;
   for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {
     const int c = rgb_class_at(q);
-    if (rows_of[c] == 0) continue;
-    act[n_act] = c; next[n_act] = 0;
-    step[n_act] = 1.0 / (double)rows_of[c];
-    key[n_act] = 0.5 * step[n_act] - (double)rgb_train_lead[c];
-    n_act += 1;
+    for (int sub = 0; sub < 2; ++sub) {
+      const int pc = 2 * c + sub;
+      if (rows_of[pc] == 0) continue;
+      act[n_act] = pc; next[n_act] = 0;
+      step[n_act] = 1.0 / (double)rows_of[pc];
+      key[n_act] = 0.5 * step[n_act] - (double)rgb_train_lead[c];
+      n_act += 1;
+    }
   }
   for (u32 k = 0; k < total; ++k) {
     unsigned best = 0;
@@ -3823,7 +3855,7 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
     row_tab[k] = ((u32)act[best] << 24) | next[best];
     next[best] += 1;
     if (next[best] >= rows_of[act[best]]) key[best] = 1e300;     /* exhausted */
-    else key[best] = (2.0 * next[best] + 1.0) * 0.5 * step[best] - (double)rgb_train_lead[act[best]];
+    else key[best] = (2.0 * next[best] + 1.0) * 0.5 * step[best] - (double)rgb_train_lead[act[best] >> 1];
   }
   return total;
 }

@@ -294,12 +294,18 @@ def test_load_generator_and_device_sized_dispatch(emu_lib, oracle_lib, n_members
         assert np.array_equal(np.bincount(m["kind"], minlength=abi.N_KINDS), kc)
         # bucket order = (class of the kind, group mod 8, success flag): every class is contiguous (what the class
         # kernel needs) and so is every (class, shard) pair (what a train launch needs)
+        # (the sub-bucket -- bit 0 -- is the success flag for the replies and the producer's steady-state HINT for
+        # append_entries_rpc / written: the generator's own counts say where a sub-bucket ends)
         bk = engine.train_bucket(m["kind"], m["flags"], m["server"], N)
-        assert np.all(np.diff(bk.astype(np.int64)) >= 0), "tick is not in bucket order"
-        assert np.array_equal(np.bincount(bk, minlength=engine.TRAIN_BUCKETS), bc)
+        assert np.all(np.diff((bk >> 1).astype(np.int64)) >= 0), "tick is not in (class, shard) order"
+        assert np.array_equal(np.bincount(bk >> 1, minlength=engine.TRAIN_BUCKETS // 2), bc.reshape(-1, 2).sum(axis=1))
+        hinted = (m["kind"] == abi.MSG_AER) | (m["kind"] == abi.MSG_WRITTEN)
+        gen_bucket = np.repeat(np.arange(engine.TRAIN_BUCKETS), bc)
+        assert np.array_equal(gen_bucket[~hinted], bk[~hinted]), "a sub-bucket of an unhinted kind is not its success flag"
+        assert np.array_equal(gen_bucket >> 1, bk >> 1)
         assert np.all(np.diff(abi.family(m) // 2) >= 0), "classes are not contiguous"
         # inside a bucket: group order at the generator's block granularity (64 groups), the same every tick
-        key = bk.astype(np.int64) * (1 << 32) + (m["server"] // N) // 64
+        key = gen_bucket.astype(np.int64) * (1 << 32) + (m["server"] // N) // 64
         assert np.all(np.diff(key) >= 0), "a bucket is not in group order"
         dec = np.zeros(S, dtype=abi.DECISION_DTYPE)
         assert emu.L.emu_launch_classes_dev(emu.h, msgs.ctypes.data, scratch.ctypes.data, S, dec.ctypes.data) == 0
