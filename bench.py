@@ -235,6 +235,9 @@ def main():
     ap.add_argument("--train-form", choices=("auto", "persistent"), default="auto",
                     help="auto: the dealt form where the calibration launch shows round-robin dispatch (every block "
                          "verifies it), else persistent; persistent: RGB_CFG_TRAIN_PERSISTENT")
+    ap.add_argument("--snapshot-kernel", action="store_true",
+                    help="train: one launch per leaderboard period with the snapshot KERNEL between the launches (the "
+                         "round-3 form; default: the snapshots run as rows of launches of up to 255 ticks)")
     ap.add_argument("--snapshot-every", type=int, default=0,
                     help="leaderboard period in ticks (default 16 = SURVEY 8(d) config 4); a train covers one period")
     ap.add_argument("--config4", action="store_true",
@@ -352,7 +355,21 @@ def main():
     # pass over the finished stream is needed before the timed replay ----
     d_stamps = torch.zeros(T * S, dtype=torch.uint8, device=dev) if use_train else None
     old_build = not hasattr(engine.lib(), "rgb_synth_tick_stamped_device")     # RGB_LIB=<round-3 build>: A/B timing only
+    # Leaderboard snapshots INSIDE the train (one rank: nothing happens between two leaderboard periods, so a launch
+    # covers several of them -- the snapshot's rows run as rows of the launch, ordered like one more message to every
+    # server).  With --gpus N the periods stay one launch each: the all-gather sits between them.
+    snap_in_train = (use_train and not use_dist and not args.snapshot_kernel
+                     and hasattr(engine.lib(), "rgb_train_run_snap_device"))
+    n_bound = T // SNAPSHOT_EVERY                                   # boundaries k = 0.. in front of tick (k + 1) * every
+    seqb = eng.train_seq_bytes() if snap_in_train else 0
+    d_snap_stamps = torch.zeros(max(n_bound, 1) * max(seqb, 1), dtype=torch.uint8, device=dev) if snap_in_train else None
+    lb_ref = torch.zeros(max(n_bound, 1) * G * 32, dtype=torch.uint8, device=dev) if snap_in_train else None
+    lb_got = torch.zeros(max(n_bound, 1) * G * 32, dtype=torch.uint8, device=dev) if snap_in_train else None
     for t in range(T):
+        if snap_in_train and t and t % SNAPSHOT_EVERY == 0:
+            k = t // SNAPSHOT_EVERY - 1
+            eng.synth_snapshot_mark_device(d_snap_stamps.data_ptr() + k * seqb, sptr)     # the producer's side of it
+            eng.snapshot_device(lb_ref.data_ptr() + k * G * 32, sptr)                     # what the rows must be
         if old_build:
             eng.synth_tick_buckets_device(seed, A + t, d_msgs.data_ptr() + t * tick_bytes, d_kc.data_ptr() + t * NK * 4,
                                           d_n.data_ptr() + t * 4, d_bc.data_ptr() + t * engine.TRAIN_BUCKETS * 4, sptr)
@@ -412,13 +429,17 @@ def main():
                 c, v = kv.split(":"); lead[int(c)] = float(v)
             engine.lib().rgb_train_set_lead(lead.ctypes.data_as(C.c_void_p))
         t_plan = time.perf_counter()
-        plan = eng.train_plan(buckets)                                        # host: 256 bucket counts per tick -> row order
+        plan = (eng.train_plan_snap(buckets, SNAPSHOT_EVERY) if snap_in_train
+                else eng.train_plan(buckets))                                 # host: 256 bucket counts per tick -> row order
         plan_host_ms = (time.perf_counter() - t_plan) * 1e3
         d_dec2 = torch.zeros(T * tick_bytes, dtype=torch.uint8, device=dev)   # pass 1's decisions stay for comparison
 
     def launch_ticks(t, nxt):
         """ticks [t, nxt) on the stream: ONE train launch, or one class-kernel launch per tick"""
-        if use_train:
+        if snap_in_train:
+            eng.train_run_snap_device(plan, t, nxt - t, d_msgs.data_ptr(), d_stamps.data_ptr(), S, d_dec2.data_ptr(),
+                                      d_rpcs.data_ptr(), RPC_RING, d_snap_stamps.data_ptr(), lb_got.data_ptr(), sptr)
+        elif use_train:
             eng.train_run_device(plan, t, nxt - t, d_msgs.data_ptr(), d_stamps.data_ptr(), S, d_dec2.data_ptr(),
                                  d_rpcs.data_ptr(), RPC_RING, sptr)
         else:
@@ -427,17 +448,35 @@ def main():
                                  tick_counts=counts[t:nxt],
                                  kind_counts=None if args.generic_kernel else kc[t:nxt].astype(np.uint32))
 
-    def run(t0, t1, with_snapshots=True):
-        """Enqueue ticks [t0, t1) on the stream."""
+    # a launch: one leaderboard period -- or, with the snapshots inside the train, as many whole periods as a launch
+    # holds (255 ticks); a boundary that ends a launch is taken behind it (rgb_snapshot_train_device: the snapshot
+    # kernel + the sequence bytes advanced, what the rows inside a launch do group by group)
+    # (a server's sequence byte must not come round within one launch: ticks + snapshots inside it <= 255)
+    WIN = (255 * SNAPSHOT_EVERY // (SNAPSHOT_EVERY + 1)) // SNAPSHOT_EVERY * SNAPSHOT_EVERY if snap_in_train else SNAPSHOT_EVERY
+    if snap_in_train and WIN == 0:
+        raise SystemExit("--snapshot-every > 254 needs --snapshot-kernel")
+
+    def segments(t0, t1):
         t = t0
         while t < t1:
-            nxt = min(t1, (t // SNAPSHOT_EVERY + 1) * SNAPSHOT_EVERY)
-            launch_ticks(t, nxt)
-            if with_snapshots and nxt % SNAPSHOT_EVERY == 0:
-                eng.snapshot_device(lb_local.data_ptr(), sptr)
-                if use_dist:
-                    comm.allgather_leaderboard(lb_local.data_ptr(), lb_rows, lb_all.data_ptr(), sptr)
+            nxt = min(t1, (t // WIN + 1) * WIN)
+            yield t, nxt
             t = nxt
+
+    def run_segment(t, nxt):
+        launch_ticks(t, nxt)
+        if nxt % SNAPSHOT_EVERY == 0:
+            if snap_in_train:
+                eng.snapshot_train_device(lb_got.data_ptr() + (nxt // SNAPSHOT_EVERY - 1) * G * 32, sptr)
+            else:
+                eng.snapshot_device(lb_local.data_ptr(), sptr)
+
+    def run(t0, t1):
+        """Enqueue ticks [t0, t1) on the stream."""
+        for t, nxt in segments(t0, t1):
+            run_segment(t, nxt)
+            if use_dist and nxt % SNAPSHOT_EVERY == 0:
+                comm.allgather_leaderboard(lb_local.data_ptr(), lb_rows, lb_all.data_ptr(), sptr)
 
     # ---- pass 2: back to the aged state, warm up, time exactly K ticks ----
     # (rgb_upload_state and the per-tick launches of pass 1 leave the servers' sequence bytes where they were when the
@@ -451,18 +490,6 @@ def main():
     # The timed ticks are captured into hipGraphs, one per leaderboard period (16 ticks + the
     # snapshot kernel): the inner loop is launch-bound (the eager host launch rate is ~3.7 us per
     # kernel on this box).  The RCCL all-gather stays outside the graphs, on the same stream.
-    def segments(t0, t1):
-        t = t0
-        while t < t1:
-            nxt = min(t1, (t // SNAPSHOT_EVERY + 1) * SNAPSHOT_EVERY)
-            yield t, nxt
-            t = nxt
-
-    def run_segment(t, nxt):
-        launch_ticks(t, nxt)
-        if nxt % SNAPSHOT_EVERY == 0:
-            eng.snapshot_device(lb_local.data_ptr(), sptr)
-
     graphs = None
     if not args.no_graph:
         try:
@@ -507,6 +534,7 @@ def main():
                 if use_dist and nxt % SNAPSHOT_EVERY == 0:
                     allgather()
 
+    TPL = max(nxt - t for t, nxt in segments(Wm, T)) if use_train else 1      # ticks of the timed region's longest launch
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -533,6 +561,17 @@ def main():
             nb = int(n_dec[t]) * 64
             if not torch.equal(d_dec2[t * tick_bytes:t * tick_bytes + nb], d_dec[t * tick_bytes:t * tick_bytes + nb]):
                 raise SystemExit(f"PARITY FAILURE: train decisions of tick {t} differ from the per-tick launches")
+        # every leaderboard snapshot taken inside (or between) the launches against the snapshot kernel of pass 1
+        snaps_checked = 0
+        if snap_in_train and not os.environ.get("RGB_BENCH_NOCHECK"):
+            for k in range(n_bound):
+                if (k + 1) * SNAPSHOT_EVERY >= T:
+                    break                                            # (the boundary behind the last tick has no reference)
+                a = lb_got[k * G * 32:(k + 1) * G * 32]; b = lb_ref[k * G * 32:(k + 1) * G * 32]
+                if not torch.equal(a, b):
+                    raise SystemExit(f"PARITY FAILURE: leaderboard snapshot {k} (in front of tick {(k + 1) * SNAPSHOT_EVERY}) "
+                                     "differs from the snapshot kernel between per-tick launches")
+                snaps_checked += 1
         # how many decisions of a timed tick went out in the 32-byte compact form, and which kinds stayed full
         tW = min(Wm, T - 1)
         rawW = d_dec2[tW * tick_bytes:tW * tick_bytes + int(n_dec[tW]) * 64].cpu().numpy().view(abi.DECISION_DTYPE)
@@ -541,7 +580,11 @@ def main():
         compact_info = {"fraction": round(float(isc.mean()), 4),
                         "decision_bytes_per_tick": int(isc.sum()) * 32 + int((~isc).sum()) * 64,
                         "full_records_by_kind": {str(k): int(v) for k, v in enumerate(full_by_kind) if v}}
-        train_info = {"ticks_per_launch": SNAPSHOT_EVERY, "blocks_per_tick": plan.blocks_per_tick, "form": eng.train_form(),
+        train_info = {"ticks_per_launch": TPL, "blocks_per_tick": plan.blocks_per_tick, "form": eng.train_form(),
+                      "leaderboard_snapshots": ("rows of the launch (rgb_train_run_snap_device): ordered per server like one "
+                                                "more message; a boundary that ends a launch: rgb_snapshot_train_device"
+                                                if snap_in_train else "rgb_snapshot_device between the launches"),
+                      "leaderboard_snapshots_compared_with_snapshot_kernel": snaps_checked,
                       "compact_decisions": compact_info,
                       "stamps": "written by the stream's producer (rgb_synth_tick_stamped_device) with the messages: "
                                 "nothing of the train's input preparation is outside the timed region except the host's "
@@ -879,7 +922,7 @@ def main():
                     tj = json.load(f)
                     traffic = float(tj["traffic_bytes_per_launch"])
                     if use_train and "traffic_bytes_per_tick" in tj:
-                        traffic = float(tj["traffic_bytes_per_tick"]) * SNAPSHOT_EVERY
+                        traffic = float(tj["traffic_bytes_per_tick"]) * TPL
                     elif not use_train and "per_tick_kernel_same_run" in tj:
                         traffic = float(tj["per_tick_kernel_same_run"]["traffic_bytes_per_launch"])
         except Exception:
@@ -910,7 +953,9 @@ def main():
                 "parallelism": f"hash-sharded groups x{world}, no data-path collective",
                 "oracle_checked_ticks": checked, "state_checksum": f"{checksum_pass2:#018x}",
                 "stream_generation_s": round(gen_s, 2), "hip_graph": graphs is not None,
-                "launch": ("train: one rgb_train_kernel launch per leaderboard period" if use_train
+                "launch": (("train: one rgb_train_kernel launch per %d ticks, leaderboard snapshots every %d ticks as rows "
+                            "of the launch" % (TPL, SNAPSHOT_EVERY)) if snap_in_train else
+                           "train: one rgb_train_kernel launch per leaderboard period" if use_train
                            else "one rgb_tick_classes_kernel launch per tick"),
                 "train": train_info,
                 "per_rank": per_rank,
@@ -924,9 +969,9 @@ def main():
                                  else "; not re-measured in this run"),
                 "kernel": (f"rgb_train_kernel<{N}>" if use_train else f"rgb_tick_classes_kernel<{N}>")
                           if not args.generic_kernel else f"rgb_tick_kernel<{N},generic>",
-                "ticks_per_launch": SNAPSHOT_EVERY if use_train else 1,
-                "algorithmic_bytes_per_launch": launch_bytes * (SNAPSHOT_EVERY if use_train else 1),
-                "avg_launch_us": per_launch_s * 1e6 * (SNAPSHOT_EVERY if use_train else 1),
+                "ticks_per_launch": TPL,
+                "algorithmic_bytes_per_launch": launch_bytes * TPL,
+                "avg_launch_us": per_launch_s * 1e6 * TPL,
                 "algorithmic_bytes_per_tick": launch_bytes, "avg_tick_us": per_launch_s * 1e6,
             },
             "cpu_baseline": cpu_baseline,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGB_ABI_VERSION   6u
+#define RGB_ABI_VERSION   7u
 #define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
 #define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
 #define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
@@ -570,6 +570,30 @@ int  rgb_train_stamp_device(rgb_ctx *ctx, const void *d_msgs, void *d_stamps, ui
 int  rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
                           const void *d_msgs, const void *d_stamps, uint32_t tick_stride, void *d_decisions,
                           void *d_rpcs, uint32_t rpc_ring, void *stream);
+/* Leaderboard snapshots INSIDE a train (ABI v7).  A train that covers several leaderboard periods (ra_leaderboard is
+ * refreshed every few ticks, src/ra_leaderboard.erl:18-26) would pay a kernel boundary per period for the snapshot;
+ * instead the snapshot's rows run as rows of the launch.  To the sequence bytes a snapshot is ONE MORE MESSAGE TO
+ * EVERY SERVER: group by group it waits until every member has applied what came before the boundary, reads the
+ * members' rows (the row of rgb_snapshot_device, bit for bit), and advances their bytes; the messages behind the
+ * boundary carry stamps one higher.
+ *   rgb_train_plan_create_snap   as rgb_train_plan_create; ticks k * snapshot_every (k >= 1) of the plan carry the
+ *                                snapshot "in front of tick k * snapshot_every", ordinal k - 1
+ *   rgb_train_run_snap_device    as rgb_train_run_device (one launch: at most 255 ticks); d_snap_stamps = ordinal-major
+ *                                uint8[rgb_train_seq_bytes()] per snapshot (the value every server's byte must show at
+ *                                that boundary -- the producer's count, rgb_synth_snapshot_mark_device), d_snap_rows =
+ *                                rgb_leaderboard_row[n_groups] per ordinal.  The snapshot in front of the launch's
+ *                                FIRST tick is not part of the launch:
+ *   rgb_snapshot_train_device    rgb_snapshot_device + every sequence byte advanced: a boundary between two launches
+ *                                (stream order does the waiting).  Every boundary of a stamped stream must be taken
+ *                                exactly once, one way or the other. */
+int  rgb_train_plan_create_snap(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t n_ticks, uint32_t snapshot_every,
+                                rgb_train_plan **out);
+int  rgb_train_run_snap_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
+                               const void *d_msgs, const void *d_stamps, uint32_t tick_stride, void *d_decisions,
+                               void *d_rpcs, uint32_t rpc_ring, const void *d_snap_stamps, void *d_snap_rows,
+                               void *stream);
+int  rgb_snapshot_train_device(rgb_ctx *ctx, void *d_rows, void *stream);
+uint32_t rgb_train_seq_bytes(const rgb_ctx *ctx);     /* bytes of the per-server sequence array (and of one d_snap_stamps) */
 int  rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard /* [8] or NULL */);
 uint32_t rgb_train_form(const rgb_ctx *ctx);          /* RGB_TRAIN_FORM_*: how the next train launch will run */
 uint32_t rgb_train_recoveries(const rgb_ctx *ctx);    /* failed train launches of rgb_submit the engine repaired */

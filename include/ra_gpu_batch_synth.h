@@ -56,6 +56,10 @@ int rgb_synth_tick_stamped_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, vo
                                   void *d_kind_counts, void *d_n, void *d_bucket_counts, void *d_stamps,
                                   void *stream);
 int rgb_synth_stamps_resync_device(rgb_ctx *ctx, void *stream);
+/* a leaderboard snapshot boundary in a stamped stream (ra_gpu_batch.h, "Leaderboard snapshots inside a train"): the
+ * producer's counts go to d_snap_stamps (uint8[rgb_train_seq_bytes()], may be NULL) -- what every server's sequence
+ * byte must show at the boundary -- and advance by one; call it between the ticks the boundary separates */
+int rgb_synth_snapshot_mark_device(rgb_ctx *ctx, void *d_snap_stamps, void *stream);
 
 /* Apply the tick that rgb_synth_tick_device just wrote (same stream): one launch of the
  * class-dispatch kernel sized from the family totals the generator left in device memory, so no

@@ -140,6 +140,7 @@ struct rgb_train_plan {
   u32 *d_rows = nullptr;  /* [n_ticks][bpt / RGB_TRAIN_SHARDS]: class << 24 | row of the class */
   u32 n_ticks = 0;
   u32 bpt = 0;            /* blocks per tick: RGB_TRAIN_SHARDS x the longest tick's rows */
+  u32 snap_every = 0;     /* > 0: ticks k x snap_every (k >= 1) carry the rows of a leaderboard snapshot in front of them */
 };
 
 /* A tick ordered by clause family: ONE launch of the class-dispatch kernel. */
@@ -1023,6 +1024,21 @@ int rgb_synth_tick_stamped_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, vo
   return RGB_OK;
 }
 
+int rgb_synth_snapshot_mark_device(rgb_ctx *ctx, void *d_snap_stamps, void *stream) {
+  if (!ctx) return RGB_E_INVAL;
+  if (!ctx->registered) return RGB_E_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const size_t bytes = (size_t)ctx->dev.seq_stride * RGB_TRAIN_SHARDS;
+  if (!ctx->d_synth_sent) {
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth_sent, bytes));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_synth_sent, ctx->dev.seq, bytes, hipMemcpyDeviceToDevice, st));
+  }
+  int lr = rgb_launch_seq_bump(ctx->d_synth_sent, (unsigned char *)d_snap_stamps, (u32)bytes, (void *)st);
+  if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+  return RGB_OK;
+}
+
 int rgb_synth_stamps_resync_device(rgb_ctx *ctx, void *stream) {
   if (!ctx) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
@@ -1089,6 +1105,11 @@ static int train_scratch(rgb_ctx *ctx) {
 }
 
 int rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t n_ticks, rgb_train_plan **out) {
+  return rgb_train_plan_create_snap(ctx, bucket_counts, n_ticks, 0, out);
+}
+
+int rgb_train_plan_create_snap(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t n_ticks, uint32_t snapshot_every,
+                               rgb_train_plan **out) {
   if (!ctx || !out || (!bucket_counts && n_ticks)) return RGB_E_INVAL;
   *out = nullptr;
   if (!ctx->registered) return RGB_E_STATE;
@@ -1102,13 +1123,18 @@ int rgb_train_plan_create(rgb_ctx *ctx, const uint32_t *bucket_counts, uint32_t 
   if (!p) return RGB_E_NOMEM;
   std::vector<rgb_train_tick> ticks(n_ticks);
   u32 rows = 0;
+  const u32 snap_rows = rgb_train_snap_rows(ctx->dev.n_servers / ctx->dev.n_members);
+  auto snap_of = [&](u32 t) -> u32 { return (snapshot_every && t && t % snapshot_every == 0) ? snap_rows : 0u; };
   for (u32 t = 0; t < n_ticks; ++t) {
-    const u32 r = rgb_train_make_tick(bucket_counts + (size_t)t * RGB_N_BUCKETS, ctx->dev.n_members, &ticks[t], nullptr, 0);
+    const u32 r = rgb_train_make_tick(bucket_counts + (size_t)t * RGB_N_BUCKETS, ctx->dev.n_members, &ticks[t], nullptr, 0, snap_of(t));
     if (r > rows) rows = r;
   }
   std::vector<u32> tab((size_t)n_ticks * rows, 0xFFFFFFFFu);
-  for (u32 t = 0; t < n_ticks; ++t)
-    rgb_train_make_tick(bucket_counts + (size_t)t * RGB_N_BUCKETS, ctx->dev.n_members, &ticks[t], tab.data() + (size_t)t * rows, rows);
+  for (u32 t = 0; t < n_ticks; ++t) {
+    rgb_train_make_tick(bucket_counts + (size_t)t * RGB_N_BUCKETS, ctx->dev.n_members, &ticks[t], tab.data() + (size_t)t * rows, rows, snap_of(t));
+    ticks[t].snap = snap_of(t) ? t / snapshot_every : 0u;        /* 1 + ordinal: the snapshot in front of tick k x every is k - 1 */
+  }
+  p->snap_every = snapshot_every;
   p->n_ticks = n_ticks;
   p->bpt = rows * RGB_TRAIN_SHARDS;
   if (n_ticks && rows) {
@@ -1161,7 +1187,31 @@ int rgb_train_stamp_device(rgb_ctx *ctx, const void *d_msgs, void *d_stamps, uin
 int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
                          const void *d_msgs, const void *d_stamps, uint32_t tick_stride, void *d_decisions,
                          void *d_rpcs, uint32_t rpc_ring, void *stream) {
+  return rgb_train_run_snap_device(ctx, plan, first_tick, n_ticks, d_msgs, d_stamps, tick_stride, d_decisions, d_rpcs,
+                                   rpc_ring, nullptr, nullptr, stream);
+}
+
+uint32_t rgb_train_seq_bytes(const rgb_ctx *ctx) {
+  return (ctx && ctx->registered) ? ctx->dev.seq_stride * RGB_TRAIN_SHARDS : 0u;
+}
+
+int rgb_snapshot_train_device(rgb_ctx *ctx, void *d_rows, void *stream) {
+  int rc = rgb_snapshot_device(ctx, d_rows, stream);
+  if (rc) return rc;
+  void *st = stream ? stream : (void *)ctx->stream;
+  int lr = rgb_launch_seq_bump(ctx->dev.seq, nullptr, ctx->dev.seq_stride * RGB_TRAIN_SHARDS, st);
+  if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+  return RGB_OK;
+}
+
+int rgb_train_run_snap_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
+                              const void *d_msgs, const void *d_stamps, uint32_t tick_stride, void *d_decisions,
+                              void *d_rpcs, uint32_t rpc_ring, const void *d_snap_stamps, void *d_snap_rows,
+                              void *stream) {
   if (!ctx || !plan || !d_msgs || !d_stamps || !d_decisions) return RGB_E_INVAL;
+  /* a plan with snapshots advances the sequence bytes at its boundaries: it cannot run without them */
+  if (plan->snap_every && (!d_snap_stamps || !d_snap_rows)) return RGB_E_INVAL;
+  if (!plan->snap_every && (d_snap_stamps || d_snap_rows)) return RGB_E_INVAL;
   if (!ctx->registered || ctx->xcc_state != 1) return RGB_E_STATE;
   if ((uint64_t)first_tick + n_ticks > plan->n_ticks) return RGB_E_INVAL;
   if (n_ticks == 0 || plan->bpt == 0) return RGB_OK;
@@ -1170,6 +1220,15 @@ int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t firs
   u32 per = RGB_TRAIN_MAX_TICKS;
   if ((uint64_t)per * plan->bpt > 0x7FFFFFFFull) per = (u32)(0x7FFFFFFFull / plan->bpt);
   if (per == 0) return RGB_E_INVAL;
+  /* (a snapshot in front of a launch's first tick is outside the launch: the caller splits at tick counts that keep
+   * every boundary inside -- one launch of at most 255 ticks -- or takes that snapshot itself) */
+  if (plan->snap_every) {
+    if (n_ticks > per) return RGB_E_INVAL;
+    /* ticks + the snapshots inside the launch: a server's sequence byte must not come round within it */
+    const u32 last = first_tick + n_ticks - 1u;
+    const u32 inside = last / plan->snap_every - first_tick / plan->snap_every;
+    if (n_ticks + inside > RGB_TRAIN_MAX_TICKS) return RGB_E_INVAL;
+  }
   for (u32 t = first_tick; t < first_tick + n_ticks; t += per) {
     const u32 n = first_tick + n_ticks - t < per ? first_tick + n_ticks - t : per;
     const size_t off = (size_t)t * tick_stride;
@@ -1177,7 +1236,8 @@ int rgb_train_run_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t firs
                               tick_stride, plan->d_ticks + t, plan->d_rows + (size_t)t * (plan->bpt / RGB_TRAIN_SHARDS), n,
                               plan->bpt, (rgb_decision *)d_decisions + off,
                               (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, ctx->n_xcc,
-                              ctx->train_dealt.load(std::memory_order_relaxed) ? 0u : ctx->train_blocks, st);
+                              ctx->train_dealt.load(std::memory_order_relaxed) ? 0u : ctx->train_blocks, st,
+                              (const unsigned char *)d_snap_stamps, (rgb_leaderboard_row *)d_snap_rows);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
   return RGB_OK;

@@ -169,10 +169,18 @@ static inline __host__ __device__ unsigned rgb_seq_index(unsigned server, unsign
  * and each is spread over the tick by its own group order (a sub-bucket that simply sat behind the other one inside
  * the class's rows would meet its servers' next messages less than a tick later). */
 #define RGB_N_PCLASSES (2u * RGB_N_CLASSES)
+/* Plan class RGB_PC_SNAP: the rows of a LEADERBOARD SNAPSHOT taken in front of the tick, inside the launch (row j =
+ * groups 64 j .. 64 j + 63 of every shard) -- rgb_train_snap_slice.  To the sequence bytes a snapshot is one more
+ * message to every server: its rows wait until every member of their groups has applied what came before the
+ * boundary, read the rows, and advance the bytes; the tick's own messages carry stamps one higher. */
+#define RGB_PC_SNAP RGB_N_PCLASSES
+#define RGB_SNAP_LEAD 0.5f          /* ticks: in front of every message class's lead, so that a snapshot row is
+                                       dispatched before the tick's messages to its groups (waits only point back) */
 struct rgb_train_tick {
   u32 n_rows;
   u32 msg_base;                                  /* first message of the tick when the launch has no tick stride (rgb_submit) */
-  u32 pad[14];
+  u32 snap;                                      /* 1 + ordinal of the snapshot in front of this tick, 0 = none */
+  u32 pad[13];
   u32 off[RGB_N_PCLASSES][RGB_TRAIN_SHARDS];    /* first message of (plan class, shard)  */
   u32 cnt[RGB_N_PCLASSES][RGB_TRAIN_SHARDS];    /* its message count                     */
 };
@@ -234,7 +242,8 @@ int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u3
  * sticky error flags, the rest per-launch counters (zeroed here) */
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
-                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream);
+                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream,
+                     const unsigned char *d_snap_stamps = nullptr, rgb_leaderboard_row *d_snap_rows = nullptr);
 u32 rgb_train_resident_blocks(unsigned n_members);
 /* the placement marks of the last dealt launch on d_ctl -> RGB_TRAIN_ERR_PLACEMENT in d_ctl[0] (the next launch does
  * this by itself; the host calls it before it reads the error word) */
@@ -246,7 +255,15 @@ int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsig
 int rgb_launch_train_calibrate(u32 *d_out, void *stream);
 /* host: the plan of one tick from its bucket counts (uint32[RGB_N_BUCKETS]); returns the tick's rows; row_tab (may be
  * NULL: count only) receives them when they fit row_cap */
-u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap);
+u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap,
+                        u32 snap_rows = 0);
+/* rows of a snapshot: 64 groups of every shard per row */
+static inline u32 rgb_train_snap_rows(u32 n_groups) {
+  return ((n_groups + RGB_TRAIN_SHARDS - 1u) / RGB_TRAIN_SHARDS + 63u) / 64u;
+}
+/* every sequence byte + 1 (a snapshot outside a launch: rgb_snapshot_train_device); the generator's marks
+ * (rgb_synth_snapshot_mark_device): out (may be NULL) = sent, sent += 1 */
+int rgb_launch_seq_bump(unsigned char *d_seq, unsigned char *d_out, u32 n_bytes, void *stream);
 int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream);
 int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u32 n, void *stream);
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream);

@@ -2906,7 +2906,86 @@ struct rgb_train_args {
   rgb_rpc *rpcs;
   u32 *ctl;
   u32 tick_stride, rpt, n_ticks, rpc_ring, index_base, n_xcc;
+  const unsigned char *snap_stamps;   /* snapshots inside the launch: the bytes every server must show, laid out like  */
+  rgb_leaderboard_row *snap_rows;     /* dev.seq, one array per snapshot ordinal; the rows, n_groups per ordinal        */
 };
+
+/* One row of an in-launch leaderboard snapshot (plan class RGB_PC_SNAP): lane = one group of shard x.  Same protocol
+ * as a message slice -- poll the members' sequence bytes, read (L2-served), publish the advanced bytes once the loads
+ * have returned -- with nothing to commit: the row is rgb_leaderboard_kernel's, group by group at its own boundary. */
+template <int N>
+__device__ __forceinline__ bool rgb_train_snap_slice(const rgb_dev &dev, u32 x, u32 j, u32 lane,
+                                                     const unsigned char *__restrict__ stamps,
+                                                     rgb_leaderboard_row *__restrict__ rows, u32 *__restrict__ ctl) {
+  const u32 G = dev.n_servers / (u32)N;
+  const u32 gi = j * RGB_TICK_BLOCK + lane;                /* group of the shard */
+  const u32 g = gi * RGB_TRAIN_SHARDS + x;
+  const bool live = g < G;
+  const u32 sbase = live ? rgb_seq_index(g * (u32)N, (unsigned)N, dev.seq_stride) : 0u;   /* the members' bytes follow */
+  unsigned need[N];
+#pragma unroll
+  for (int m = 0; m < N; ++m) need[m] = live ? (unsigned)stamps[sbase + m] : 0u;
+  unsigned spins = 0;
+  bool late = live;
+  for (;;) {
+    if (late) {
+      bool ok = true;
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
+#ifdef RGB_HOST_EMULATION
+        const unsigned cur = dev.seq[sbase + m];
+#else
+        const unsigned cur = __hip_atomic_load(dev.seq + sbase + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        ok = ok && cur == need[m];
+      }
+      late = !ok;
+    }
+    if (__ballot(late) == 0ull) break;
+    spins += 1;
+    bool give_up = spins > RGB_TRAIN_SPIN_LIMIT;
+#ifndef RGB_HOST_EMULATION
+    if ((spins & 15u) == 0u && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) give_up = true;
+    __builtin_amdgcn_s_sleep(RGB_TRAIN_SLEEP);
+    if (spins > 64u) __builtin_amdgcn_s_sleep(127);
+#endif
+    if (give_up) {
+      if (lane == 0) atomicOr(ctl, (u32)RGB_TRAIN_ERR_SPIN);
+      return false;
+    }
+  }
+  if (live) {
+    u32 leader = RGB_NONE, n_leaders = 0;
+    u64 term = 0, lead_term = 0, ci = 0, la = 0, max_ci = 0, max_la = 0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+      const ulonglong2 *hp = reinterpret_cast<const ulonglong2 *>(dev.hot + ((size_t)g * N + m) * RGB_HOT_WORDS);
+      const ulonglong2 h0 = ldg16(true, hp + HOT_P_TERM), h1 = ldg16(true, hp + HOT_P_CI);
+      const u64 ct = h0.x, pk = h0.y;
+      if (ct > term) term = ct;
+      if (h1.x > max_ci) max_ci = h1.x;
+      if (h1.y > max_la) max_la = h1.y;
+      if (pk_get(pk, PK_ROLE_SH, 3) == RGB_ROLE_LEADER) {
+        n_leaders++;
+        if (leader == RGB_NONE || ct > lead_term) { leader = (u32)m; lead_term = ct; ci = h1.x; la = h1.y; }
+      }
+    }
+    rgb_leaderboard_row r;
+    r.leader = leader; r.n_leaders = n_leaders; r.term = term;
+    r.commit_index = leader == RGB_NONE ? max_ci : ci;
+    r.last_applied = leader == RGB_NONE ? max_la : la;
+    rows[g] = r;
+  }
+#ifndef RGB_HOST_EMULATION
+  __builtin_amdgcn_s_waitcnt(0x0F70);     /* every row load has returned (vmcnt 0) before the bytes move */
+  asm volatile("" ::: "memory");
+#endif
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) dev.seq[sbase + m] = (unsigned char)(need[m] + 1u);
+  }
+  return true;
+}
 /* DEALT trains (one block per row, block b serves shard b mod 8): the round-3 dispatch, which needs the dispatcher to
  * deal the blocks of a launch round robin over the XCDs -- block b on XCD (b + r) mod 8, r fixed per launch (what
  * /opt/skills/guides/cdna_hip_programming.md, "XCD-aware blockIdx swizzle", describes as the default and every
@@ -2932,6 +3011,14 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   if (row >= p->n_rows) return;
   const u32 e = args.row_tab[(size_t)t * args.rpt + row];
   const u32 pc = e >> 24;                                  /* plan class = 2 x class + sub-bucket */
+  if (pc == RGB_PC_SNAP) {
+    /* the snapshot in front of this tick; in front of the launch's FIRST tick it is the caller's (outside the launch) */
+    if (t != 0u && p->snap != 0u && args.snap_rows != nullptr)
+      (void)rgb_train_snap_slice<N>(args.dev, x, e & 0xFFFFFFu, threadIdx.x,
+                                    args.snap_stamps + (size_t)(p->snap - 1u) * args.dev.seq_stride * RGB_TRAIN_SHARDS,
+                                    args.snap_rows + (size_t)(p->snap - 1u) * (args.dev.n_servers / (u32)N), args.ctl);
+    return;
+  }
   const int cls = (int)(pc >> 1);
   const u32 off = p->off[pc][x], ncls = p->cnt[pc][x];
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
@@ -3018,11 +3105,21 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
     const rgb_train_tick *p = plan + t;
     const u32 e = A->row_tab[(size_t)t * A->rpt + (k - cum)];
     const u32 pc = e >> 24;                                /* plan class = 2 x class + sub-bucket */
+    u32 *const tk = A->ctl + RGB_TRAIN_CTL_TICKET * (1u + x);
+    if (pc == RGB_PC_SNAP) {
+      if (t != 0u && p->snap != 0u && A->snap_rows != nullptr) {
+        if (!rgb_train_snap_slice<N>(dev, x, e & 0xFFFFFFu, lane,
+                                     A->snap_stamps + (size_t)(p->snap - 1u) * dev.seq_stride * RGB_TRAIN_SHARDS,
+                                     A->snap_rows + (size_t)(p->snap - 1u) * (dev.n_servers / (u32)N), A->ctl))
+          break;
+      }
+      raw = rgb_take_ticket(tk, A->ctl);
+      continue;
+    }
     const int cls = (int)(pc >> 1);
     const u32 off = p->off[pc][x], ncls = p->cnt[pc][x];
     const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
     const u32 lbase = (e & 0xFFFFFFu) * SL;
-    u32 *const tk = A->ctl + RGB_TRAIN_CTL_TICKET * (1u + x);
     if (lbase >= ncls) { raw = rgb_take_ticket(tk, A->ctl); continue; }
     const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
     /* ticks a fixed stride apart with a ring of rpc regions (device-resident streams), or -- tick_stride = 0 -- packed
@@ -3796,9 +3893,11 @@ extern "C" void rgb_train_set_lead(const float *lead) {      /* tuning hook of t
   for (int c = 0; c < RGB_N_CLASSES; ++c) rgb_train_lead[c] = lead[c];
 }
 
-u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap) {
+u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap,
+                        u32 snap_rows) {
   u32 acc = 0;
-  u32 rows_of[RGB_N_PCLASSES];
+  u32 rows_of[RGB_N_PCLASSES + 1u];
+  rows_of[RGB_PC_SNAP] = snap_rows;
   for (unsigned pc = 0; pc < RGB_N_PCLASSES + 2u; ++pc) {      /* (the two sub-buckets of the NOP class only advance acc) */
     const unsigned c = pc >> 1, sub = pc & 1u;
     u32 need = 0;
@@ -3823,9 +3922,10 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
     }
   }
   u32 total = 0;
-  for (unsigned pc = 0; pc < RGB_N_PCLASSES; ++pc) total += rows_of[pc];
+  for (unsigned pc = 0; pc <= RGB_N_PCLASSES; ++pc) total += rows_of[pc];
   out->n_rows = total;
   out->msg_base = 0;
+  out->snap = 0;
   if (row_tab == nullptr || total > row_cap) return total;
   /* merge by key (j + 1/2) / rows(pc) - lead(class): a class whose wavefronts live longer starts that much earlier, so
    * that what lines up from tick to tick is the time a group range's messages COMMIT, not the time they start: a
@@ -3835,8 +3935,14 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
    * themselves, and the waits cascade).  rgb_train_lead[] is in ticks; ties: the heavier class first. */
   /* a merge of the non-empty plan classes in heaviest-first order (the tie break), keys advanced by addition: this runs
    * on the host once per tick of every plan (~4 us for the 65 536 x 5 closed loop) */
-  int act[RGB_N_PCLASSES]; u32 next[RGB_N_PCLASSES]; double key[RGB_N_PCLASSES], step[RGB_N_PCLASSES];
+  int act[RGB_N_PCLASSES + 1]; u32 next[RGB_N_PCLASSES + 1]; double key[RGB_N_PCLASSES + 1], step[RGB_N_PCLASSES + 1];
+  double lead_of[RGB_N_PCLASSES + 1];
   unsigned n_act = 0;
+  if (snap_rows) {                                           /* (first: it wins every tie) */
+    act[0] = (int)RGB_PC_SNAP; next[0] = 0; step[0] = 1.0 / (double)snap_rows; lead_of[0] = (double)RGB_SNAP_LEAD;
+    key[0] = 0.5 * step[0] - lead_of[0];
+    n_act = 1;
+  }
   for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {
     const int c = rgb_class_at(q);
     for (int sub = 0; sub < 2; ++sub) {
@@ -3844,7 +3950,8 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
       if (rows_of[pc] == 0) continue;
       act[n_act] = pc; next[n_act] = 0;
       step[n_act] = 1.0 / (double)rows_of[pc];
-      key[n_act] = 0.5 * step[n_act] - (double)rgb_train_lead[c];
+      lead_of[n_act] = (double)rgb_train_lead[c];
+      key[n_act] = 0.5 * step[n_act] - lead_of[n_act];
       n_act += 1;
     }
   }
@@ -3855,7 +3962,7 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
     row_tab[k] = ((u32)act[best] << 24) | next[best];
     next[best] += 1;
     if (next[best] >= rows_of[act[best]]) key[best] = 1e300;     /* exhausted */
-    else key[best] = (2.0 * next[best] + 1.0) * 0.5 * step[best] - (double)rgb_train_lead[act[best] >> 1];
+    else key[best] = (2.0 * next[best] + 1.0) * 0.5 * step[best] - lead_of[best];
   }
   return total;
 }
@@ -3889,7 +3996,8 @@ u32 rgb_train_resident_blocks(unsigned n_members) {
 
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
-                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream) {
+                     rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream,
+                     const unsigned char *d_snap_stamps, rgb_leaderboard_row *d_snap_rows) {
   (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   /* n_blocks = 0: the DEALT form (one block per row; the caller's calibration showed round-robin dispatch) */
   const bool dealt = n_blocks == 0;
@@ -3914,6 +4022,7 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
   args.dec = d_dec; args.rpcs = d_rpcs; args.ctl = d_ctl; args.tick_stride = tick_stride;
   args.rpt = bpt / RGB_TRAIN_SHARDS; args.n_ticks = n_ticks; args.rpc_ring = rpc_ring ? rpc_ring : 1u;
   args.index_base = index_base; args.n_xcc = n_xcc;
+  args.snap_stamps = d_snap_stamps; args.snap_rows = d_snap_rows;
 #define LAUNCH(NN)                                                                                      \
   case NN:                                                                                              \
     if (dealt) hipLaunchKernelGGL(rgb_train_dealt_kernel<NN>, grid, block, 0, st, args);                \
@@ -3938,6 +4047,20 @@ int rgb_launch_train_seq(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsig
   (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   hipStream_t st = (hipStream_t)stream;
   if (n) hipLaunchKernelGGL(rgb_train_seq_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dev, d_msgs, n, d_seq_cnt, d_stamps);
+  return (int)hipGetLastError();
+}
+
+__global__ void rgb_seq_bump_kernel(unsigned char *__restrict__ seq, unsigned char *__restrict__ out, u32 n) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char c = seq[i];
+  if (out != nullptr) out[i] = c;
+  seq[i] = (unsigned char)(c + 1u);
+}
+
+int rgb_launch_seq_bump(unsigned char *d_seq, unsigned char *d_out, u32 n_bytes, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
+  if (n_bytes) hipLaunchKernelGGL(rgb_seq_bump_kernel, dim3((n_bytes + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d_seq, d_out, n_bytes);
   return (int)hipGetLastError();
 }
 

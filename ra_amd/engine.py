@@ -25,14 +25,17 @@ EXPORTS = [
     "rgb_route", "rgb_submit_trains", "rgb_peek",
     "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status", "rgb_train_form", "rgb_train_recoveries",
+    "rgb_train_plan_create_snap", "rgb_train_run_snap_device", "rgb_snapshot_train_device", "rgb_train_seq_bytes",
 ]
 COMM_EXPORTS = ["rgb_comm_unique_id", "rgb_comm_init_rank", "rgb_comm_destroy", "rgb_comm_n_ranks", "rgb_comm_rank",
                 "rgb_leaderboard_allgather", "rgb_leaderboard_allgather_host", "rgb_comm_last_error"]   # the one collective of the path (RCCL)
 EXPORTS += COMM_EXPORTS
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_tick_buckets_device", "rgb_synth_apply_tick_device",
-                 "rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device"]     # include/ra_gpu_batch_synth.h (bench tooling)
+                 "rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device",
+                 "rgb_synth_snapshot_mark_device"]                                       # include/ra_gpu_batch_synth.h (bench tooling)
 OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device", "rgb_train_form",
-                          "rgb_train_recoveries"} | set(COMM_EXPORTS)
+                          "rgb_train_recoveries", "rgb_train_plan_create_snap", "rgb_train_run_snap_device",
+                          "rgb_snapshot_train_device", "rgb_train_seq_bytes", "rgb_synth_snapshot_mark_device"} | set(COMM_EXPORTS)
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -146,6 +149,13 @@ def lib():
     L.rgb_train_plan_blocks_per_tick.argtypes = [vp]
     L.rgb_train_stamp_device.argtypes = [vp, vp, vp, u32, vp, u32, vp]
     L.rgb_train_run_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, u32, vp]
+    if hasattr(L, "rgb_train_run_snap_device"):
+        L.rgb_train_plan_create_snap.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+        L.rgb_train_run_snap_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, u32, vp, vp, vp]
+        L.rgb_snapshot_train_device.argtypes = [vp, vp, vp]
+        L.rgb_train_seq_bytes.restype = C.c_uint32
+        L.rgb_train_seq_bytes.argtypes = [vp]
+        L.rgb_synth_snapshot_mark_device.argtypes = [vp, vp, vp]
     L.rgb_train_status.argtypes = [vp, C.POINTER(u32), vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     L.rgb_wal_adler32_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, vp]
@@ -156,8 +166,8 @@ def lib():
     L.rgb_wal_frame.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, C.c_uint64, u32]
     L.rgb_wal_scan.argtypes = [vp, C.c_uint64, vp, u32, C.POINTER(C.c_uint32), u64p, C.POINTER(C.c_uint32)]
     L.rgb_wal_validate.argtypes = [vp, vp, C.c_uint64, vp, u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    if L.rgb_abi_version() != abi.ABI_VERSION:
-        raise RuntimeError("ABI version mismatch")
+    if L.rgb_abi_version() != abi.ABI_VERSION and not (os.environ.get("RGB_LIB") and L.rgb_abi_version() == abi.ABI_VERSION - 1):
+        raise RuntimeError("ABI version mismatch")     # (RGB_LIB=<the previous ABI's build>: A/B timing, tools/ only)
     for i, dt in enumerate(abi.STRUCT_DTYPES):
         if L.rgb_struct_size(i) != dt.itemsize:
             raise RuntimeError(f"struct {i}: C size {L.rgb_struct_size(i)} != numpy {dt.itemsize}")
@@ -359,6 +369,29 @@ class RaGpuBatch:
         self._check(self._L.rgb_train_run_device(self._h, plan.h, first_tick, n_ticks, d_msgs, d_stamps, tick_stride,
                                                  d_decisions, d_rpcs, rpc_ring, stream), "rgb_train_run_device")
 
+    def train_plan_snap(self, bucket_counts: np.ndarray, snapshot_every: int) -> "TrainPlan":
+        """A plan whose ticks k * snapshot_every (k >= 1) carry the leaderboard snapshot in front of them."""
+        return TrainPlan(self, bucket_counts, snapshot_every)
+
+    def train_run_snap_device(self, plan: "TrainPlan", first_tick: int, n_ticks: int, d_msgs: int, d_stamps: int,
+                              tick_stride: int, d_decisions: int, d_rpcs: int, rpc_ring: int, d_snap_stamps: int,
+                              d_snap_rows: int, stream: int = 0):
+        self._check(self._L.rgb_train_run_snap_device(self._h, plan.h, first_tick, n_ticks, d_msgs, d_stamps, tick_stride,
+                                                      d_decisions, d_rpcs, rpc_ring, d_snap_stamps, d_snap_rows, stream),
+                    "rgb_train_run_snap_device")
+
+    def snapshot_train_device(self, d_rows: int, stream: int = 0):
+        """rgb_snapshot_device + every sequence byte advanced (a snapshot boundary between two train launches)."""
+        self._check(self._L.rgb_snapshot_train_device(self._h, d_rows, stream or None), "rgb_snapshot_train_device")
+
+    def train_seq_bytes(self) -> int:
+        return int(self._L.rgb_train_seq_bytes(self._h))
+
+    def synth_snapshot_mark_device(self, d_snap_stamps: int = 0, stream: int = 0):
+        """The generator's side of a snapshot boundary: its counts -> d_snap_stamps, then + 1."""
+        self._check(self._L.rgb_synth_snapshot_mark_device(self._h, d_snap_stamps or None, stream or None),
+                    "rgb_synth_snapshot_mark_device")
+
     def train_status(self, check: bool = True):
         """(error flags, XCD of every shard) of the trains run since the last call; the caller has synchronised."""
         flags = C.c_uint32(0)
@@ -495,11 +528,15 @@ class Comm:
 class TrainPlan:
     """Device plan of a train (rgb_train_plan): bucket_counts = uint32[n_ticks][TRAIN_BUCKETS]."""
 
-    def __init__(self, eng: "RaGpuBatch", bucket_counts: np.ndarray):
+    def __init__(self, eng: "RaGpuBatch", bucket_counts: np.ndarray, snapshot_every: int = 0):
         bc = np.ascontiguousarray(bucket_counts, dtype=np.uint32).reshape(-1, TRAIN_BUCKETS)
-        self.eng, self.n_ticks = eng, len(bc)
+        self.eng, self.n_ticks, self.snapshot_every = eng, len(bc), snapshot_every
         h = C.c_void_p()
-        eng._check(eng._L.rgb_train_plan_create(eng._h, bc.ctypes.data, len(bc), C.byref(h)), "rgb_train_plan_create")
+        if snapshot_every:
+            eng._check(eng._L.rgb_train_plan_create_snap(eng._h, bc.ctypes.data, len(bc), snapshot_every, C.byref(h)),
+                       "rgb_train_plan_create_snap")
+        else:
+            eng._check(eng._L.rgb_train_plan_create(eng._h, bc.ctypes.data, len(bc), C.byref(h)), "rgb_train_plan_create")
         self.h = h
         self.blocks_per_tick = int(eng._L.rgb_train_plan_blocks_per_tick(h))
 

@@ -207,6 +207,79 @@ def check_generator_stamps(engine, G, N, T, seed, on_gpu):
     eng.close()
 
 
+def check_snapshots_inside_a_train(engine, G, N, T, every, seed, on_gpu, windows):
+    """Leaderboard snapshots as rows of the launch (rgb_train_plan_create_snap / rgb_train_run_snap_device): the stream
+    is generated with a mark at every boundary (ticks k * every), replayed in `windows` (launches; a boundary at a
+    window's start is taken outside with rgb_snapshot_train_device) -- every decision, every snapshot row and the final
+    state equal the per-tick launches with rgb_snapshot_device between them."""
+    S, tb = G * N, G * N * 64
+    eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
+    eng.set_state(0, W.initial_states(G, N, seed))
+    st0 = eng.get_state()
+    seqb = eng.train_seq_bytes()
+    assert seqb >= S
+    n_snap = (T - 1) // every
+    msgs, dec, dec2 = Buf(T * tb, on_gpu), Buf(T * tb, on_gpu), Buf(T * tb, on_gpu)
+    rpcs = Buf(4 * S * max(N - 1, 1) * 56, on_gpu)
+    dn, bc = Buf(T * 4, on_gpu), Buf(T * engine.TRAIN_BUCKETS * 4, on_gpu)
+    stamps = Buf(T * S, on_gpu)
+    snap_stamps = Buf(max(n_snap, 1) * seqb, on_gpu)
+    rows_ref, rows_got = Buf(max(n_snap, 1) * G * 32, on_gpu), Buf(max(n_snap, 1) * G * 32, on_gpu)
+    for t in range(T):
+        if t and t % every == 0:
+            k = t // every - 1
+            eng.synth_snapshot_mark_device(snap_stamps.ptr + k * seqb)
+            eng.snapshot_device(rows_ref.ptr + k * G * 32)
+        eng.synth_tick_stamped_device(seed, t, msgs.ptr + t * tb, 0, dn.ptr + t * 4, bc.ptr + t * engine.TRAIN_BUCKETS * 4,
+                                      stamps.ptr + t * S)
+        eng.synth_apply_tick_device(msgs.ptr + t * tb, S, dec.ptr + t * tb, rpcs.ptr)
+    eng.synchronize()
+    counts = dn.host().view(np.uint32)[:T].copy()
+    buckets = bc.host().view(np.uint32)[:T * engine.TRAIN_BUCKETS].reshape(T, engine.TRAIN_BUCKETS).copy()
+    sum_end = eng.state_checksum()
+    plan = eng.train_plan_snap(buckets, every)
+    eng.set_state(0, st0)
+    t = 0
+    for n in windows:
+        n = min(n, T - t)
+        if n <= 0:
+            break
+        if t and t % every == 0:                             # the boundary in front of a launch: outside it
+            eng.snapshot_train_device(rows_got.ptr + (t // every - 1) * G * 32)
+        eng.train_run_snap_device(plan, t, n, msgs.ptr, stamps.ptr, S, dec2.ptr, rpcs.ptr, 4, snap_stamps.ptr, rows_got.ptr)
+        t += n
+    assert t == T
+    eng.synchronize()
+    assert eng.train_status()[0] == 0
+    for t in range(T):
+        n = int(counts[t])
+        assert _tick(dec2, t, tb, n, abi.DECISION_DTYPE).tobytes() == _tick(dec, t, tb, n, abi.DECISION_DTYPE).tobytes(), f"tick {t}"
+    assert eng.state_checksum() == sum_end
+    a, b = rows_ref.host()[:n_snap * G * 32], rows_got.host()[:n_snap * G * 32]
+    for k in range(n_snap):
+        assert a[k * G * 32:(k + 1) * G * 32].tobytes() == b[k * G * 32:(k + 1) * G * 32].tobytes(), f"snapshot {k}"
+    assert n_snap >= 2 and a.any()
+    # a plan with snapshots cannot run without their buffers (the sequence bytes would fall behind the stamps)
+    with pytest.raises(engine.RgbError):
+        eng.train_run_device(plan, 0, T, msgs.ptr, stamps.ptr, S, dec2.ptr)
+    plan.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("G,N,T,every,windows", [(192, 5, 14, 4, (14,)), (192, 5, 14, 4, (6, 2, 6)), (70, 3, 10, 3, (10,)),
+                                                 (64, 7, 9, 4, (4, 5))])
+def test_snapshots_inside_a_train_on_the_block_emulation(emulated_engine, G, N, T, every, windows):
+    check_snapshots_inside_a_train(emulated_engine, G, N, T, every, 0x5EED0003, False, windows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,N,T,every,windows", [(4096, 5, 40, 16, (40,)), (4096, 5, 40, 16, (11, 5, 24)), (1000, 3, 20, 4, (20,)),
+                                                 (1024, 7, 18, 8, (18,))])
+def test_snapshots_inside_a_train_on_the_gpu(G, N, T, every, windows):
+    from ra_amd import engine
+    check_snapshots_inside_a_train(engine, G, N, T, every, 0x5EED0003, True, windows)
+
+
 def test_generator_stamps_on_the_block_emulation(emulated_engine):
     check_generator_stamps(emulated_engine, 192, 5, 12, 0x5EED0003, False)
 
