@@ -967,7 +967,8 @@ def main():
                                 "guide's gfx950 x2 correction + WRITE_SIZE)" +
                                 ("; PMC passes of the same gpurun call, in front of this run" if os.environ.get("RGB_TRAFFIC_JSON")
                                  else "; not re-measured in this run"),
-                "kernel": (f"rgb_train_kernel<{N}>" if use_train else f"rgb_tick_classes_kernel<{N}>")
+                "kernel": ((f"rgb_train_dealt_kernel<{N}>" if train_info and train_info.get("form") == "dealt"
+                            else f"rgb_train_kernel<{N}>") if use_train else f"rgb_tick_classes_kernel<{N}>")
                           if not args.generic_kernel else f"rgb_tick_kernel<{N},generic>",
                 "ticks_per_launch": TPL,
                 "algorithmic_bytes_per_launch": launch_bytes * TPL,
