@@ -235,6 +235,7 @@ def main():
     ap.add_argument("--train-form", choices=("auto", "persistent"), default="auto",
                     help="auto: the dealt form where the calibration launch shows round-robin dispatch (every block "
                          "verifies it), else persistent; persistent: RGB_CFG_TRAIN_PERSISTENT")
+    ap.add_argument("--graph", action="store_true", help="capture the timed region into a hipGraph even when it is one or two launches")
     ap.add_argument("--snapshot-kernel", action="store_true",
                     help="train: one launch per leaderboard period with the snapshot KERNEL between the launches (the "
                          "round-3 form; default: the snapshots run as rows of launches of up to 255 ticks)")
@@ -491,7 +492,12 @@ def main():
     # snapshot kernel): the inner loop is launch-bound (the eager host launch rate is ~3.7 us per
     # kernel on this box).  The RCCL all-gather stays outside the graphs, on the same stream.
     graphs = None
-    if not args.no_graph:
+    # a timed region of one or two train launches (the driver's 20-step form: ONE launch) goes eager: a graph launch
+    # costs more than the two kernel launches it replaces (same box, tools/r04_graph_ab.sh: 18.5 us per tick by events
+    # through a graph, 17.8 eager).  --graph forces the graph
+    n_seg = sum(1 for _ in segments(Wm, T))
+    want_graph = not args.no_graph and (args.graph or use_dist or not use_train or n_seg > 2)
+    if want_graph:
         try:
             graphs = []
             if use_dist:

@@ -2524,6 +2524,12 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
   /* a table row of max_runs >= 8 runs holds the whole 128-byte line that is fetched (wave-uniform) */
   const bool RUNS_LDS = TR && RGB_TRAIN_RUNS_LDS && PEERS_LDS && dev.max_runs >= (u32)RGB_RUNS_LDS;
+  /* groups of six and more members (no peers rows in LDS: the area is free): an append_entries_rpc wavefront whose
+   * messages point below the current term's entries (prev_log_term != term in any lane: log-matching repair, the
+   * configs[4] workload) will walk its servers' run tables -- their first line comes with the hot rows (decided
+   * from the messages alone, before any state arrives) and has_log_entry_or_snapshot / drop_existing are served from
+   * LDS instead of one dependent L2 round trip per run */
+  bool AER_RUNS = false;
 #if defined(RGB_X_TRAIN_TIMELINE) && !defined(RGB_HOST_EMULATION)
   /* EXPERIMENT build (tools/train_timeline.py): per-wavefront wall-clock stamps of a train launch */
   u64 tt[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -2572,6 +2578,8 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     if (cls == 2 && active && (((m0.x >> 48) & 0xFFull) & RGB_MF_SEQ2)) m3 = ld16<true>(src + lane * 4u + 3u);
   }
   RGB_TT(1);
+  if (TR && RGB_TRAIN_RUNS_LDS && !PEERS_LDS && cls == 0 && dev.max_runs >= (u32)RGB_RUNS_LDS)
+    AER_RUNS = __ballot(active && m1.y != m0.y) != 0ull;
   const u32 sv = (u32)(m0.x & 0xFFFFFFFFull);
   /* the message addresses a server (a NOP or an out-of-range id touches no state and has no stamp) */
   const bool has_srv = TR && active && sv < dev.n_servers && ((m0.x >> 32) & 0xFFull) != RGB_MSG_NOP;
@@ -2656,6 +2664,16 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
       glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.hot + (size_t)sj * RGB_HOT_WORDS) + ((lane & 7u) ^ ((r >> 1) & 7u)),
                    io + k * RGB_TICK_BLOCK);
     }
+    if (!PEERS_LDS && AER_RUNS) {
+      /* the first line of the 64 run tables behind the 64 hot rows, same shape */
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u32 r = 8 * k + (lane >> 3);
+        const u32 sj = __shfl(srv, (int)r, 64);
+        glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.runs + (size_t)sj * dev.max_runs * 2u) + ((lane & 7u) ^ ((r >> 1) & 7u)),
+                     io + (8 + k) * RGB_TICK_BLOCK);
+      }
+    }
     if (PEERS_LDS && lead_cls) {
       /* the peers rows (one 128-byte line each) of the slice's 32 servers behind the 32 hot rows, same shape */
 #pragma unroll
@@ -2684,7 +2702,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   const ulonglong2 *hrow = io + lane * 8;
   const unsigned hswz = (lane >> 1) & 7u;
   const ulonglong2 *prow = (PEERS_LDS && lead_cls) ? io + 4 * RGB_TICK_BLOCK + lane * 8 : nullptr;
-  const ulonglong2 *rrow = (RUNS_LDS && PEERS_LDS && lead_cls) ? io + 8 * RGB_TICK_BLOCK + lane * 8 : nullptr;
+  const ulonglong2 *rrow = ((RUNS_LDS && PEERS_LDS && lead_cls) || (!PEERS_LDS && AER_RUNS)) ? io + 8 * RGB_TICK_BLOCK + lane * 8 : nullptr;
 #ifndef RGB_HOST_EMULATION
   asm volatile("" ::"v"(pf0), "v"(pf1));   /* the touch loads above stay in the program */
 #endif
@@ -3002,8 +3020,8 @@ __device__ __forceinline__ bool rgb_train_snap_slice(const rgb_dev &dev, u32 x, 
 #define RGB_TRAIN_CTL_MARK 320u
 template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_dealt_kernel(rgb_train_args args) {
-  __shared__ ulonglong2 io[(RGB_TRAIN_RUNS_LDS && rgb_class_slice(1, (unsigned)N) == 32u) ? 12 * RGB_TICK_BLOCK
-                                                                                         : RGB_TICK_BLOCK * RGB_HOT_SLOT];
+  __shared__ ulonglong2 io[!RGB_TRAIN_RUNS_LDS ? RGB_TICK_BLOCK * RGB_HOT_SLOT
+                           : rgb_class_slice(1, (unsigned)N) == 32u ? 12 * RGB_TICK_BLOCK : 16 * RGB_TICK_BLOCK];
   const u32 x = blockIdx.x & (RGB_TRAIN_SHARDS - 1u), k = blockIdx.x / RGB_TRAIN_SHARDS;
   const u32 t = k / args.rpt, row = k - t * args.rpt;
   if (t >= args.n_ticks) return;
@@ -3056,8 +3074,8 @@ template <int N>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(rgb_train_args args) {
   /* records, then hot rows; a leader-side slice: 32 hot rows | 32 peers rows | the first line of 32 run tables
    * (12 KiB: twelve wavefronts per CU -- three per SIMD, what the registers allow -- hold 144 of the 160 KiB) */
-  __shared__ ulonglong2 io[(RGB_TRAIN_RUNS_LDS && rgb_class_slice(1, (unsigned)N) == 32u) ? 12 * RGB_TICK_BLOCK
-                                                                                         : RGB_TICK_BLOCK * RGB_HOT_SLOT];
+  __shared__ ulonglong2 io[!RGB_TRAIN_RUNS_LDS ? RGB_TICK_BLOCK * RGB_HOT_SLOT
+                           : rgb_class_slice(1, (unsigned)N) == 32u ? 12 * RGB_TICK_BLOCK : 16 * RGB_TICK_BLOCK];
   /* the shard this block serves: the XCD it runs on */
   u32 x;
   {

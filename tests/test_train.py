@@ -280,6 +280,73 @@ def test_snapshots_inside_a_train_on_the_gpu(G, N, T, every, windows):
     check_snapshots_inside_a_train(engine, G, N, T, every, 0x5EED0003, True, windows)
 
 
+def check_repair_stream_as_a_train(engine, oracle_lib, G, N, T, on_gpu):
+    """BASELINE configs[4] (7 members, 1 024-entry backlogs over 3-6 term boundaries, wrong prev_log_term half of the
+    time) as ONE train launch: the append_entries_rpc wavefronts of groups of six and more members take the first line
+    of their servers' run tables with the hot rows (prev_log_term != term) and walk it in LDS -- every decision and the
+    final state against the oracle."""
+    seed = 0x5EED0005
+    S = G * N
+    st0 = W.initial_states(G, N, seed, backlog=1024, boundaries=(3, 6))
+    cpu = oracle_lib.Oracle(G, N, max_runs=16)
+    cpu.set_state(0, st0)
+    msgs, decs = [], []
+    for t in range(T):
+        m = W.gen_tick(cpu.get_state(), N, t, seed, W.MIX_CONFIG5, backlog_mode=True)
+        d, _ = cpu.step(m)
+        msgs.append(m); decs.append(d)
+    want_final = cpu.get_state()
+    cpu.close()
+    assert sum(int(((m["kind"] == abi.MSG_AER) & (m["b"] != m["term"])).sum()) for m in msgs) > 0
+    stride = max(len(m) for m in msgs)
+    eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
+    eng.set_state(0, st0)
+    d_msgs, d_dec, d_stamps = Buf(T * stride * 64, on_gpu), Buf(T * stride * 64, on_gpu), Buf(T * stride, on_gpu)
+    d_rpcs = Buf(4 * stride * max(N - 1, 1) * 56, on_gpu)
+    host = np.zeros(T * stride, dtype=abi.MSG_DTYPE)
+    h_st = np.zeros(T * stride, dtype=np.uint8)
+    bcs = np.zeros((T, engine.TRAIN_BUCKETS), dtype=np.uint32)
+    sent = np.zeros(S, dtype=np.uint8)
+    perms = []
+    for t, m in enumerate(msgs):
+        bk = engine.train_bucket(m["kind"], m["flags"], m["server"], N)
+        perm = np.argsort(bk, kind="stable")
+        perms.append(perm)
+        bcs[t] = np.bincount(bk, minlength=engine.TRAIN_BUCKETS)
+        host[t * stride:t * stride + len(m)] = m[perm]
+        srv = m["server"][perm]
+        h_st[t * stride:t * stride + len(m)] = sent[srv]
+        sent[srv] += 1
+    if on_gpu:
+        import torch
+        d_msgs.t[:host.nbytes].copy_(torch.from_numpy(host.view(np.uint8)))
+        d_stamps.t[:h_st.nbytes].copy_(torch.from_numpy(h_st))
+    else:
+        d_msgs.a[:host.nbytes] = host.view(np.uint8)
+        d_stamps.a[:h_st.nbytes] = h_st
+    plan = eng.train_plan(bcs)
+    eng.train_run_device(plan, 0, T, d_msgs.ptr, d_stamps.ptr, stride, d_dec.ptr, d_rpcs.ptr, rpc_ring=4)
+    eng.synchronize()
+    assert eng.train_status()[0] == 0
+    got = abi.expand_decisions(d_dec.host()[:T * stride * 64].view(abi.DECISION_DTYPE).copy())
+    for t in range(T):
+        g = got[t * stride:t * stride + len(msgs[t])]
+        assert g.tobytes() == decs[t][perms[t]].tobytes(), f"tick {t}"
+    assert eng.get_state().tobytes() == want_final.tobytes()
+    plan.close()
+    eng.close()
+
+
+def test_repair_stream_as_a_train_on_the_block_emulation(emulated_engine, oracle_lib):
+    check_repair_stream_as_a_train(emulated_engine, oracle_lib, 96, 7, 8, False)
+
+
+@pytest.mark.gpu
+def test_repair_stream_as_a_train_on_the_gpu(oracle_lib):
+    from ra_amd import engine
+    check_repair_stream_as_a_train(engine, oracle_lib, 4096, 7, 12, True)
+
+
 def test_generator_stamps_on_the_block_emulation(emulated_engine):
     check_generator_stamps(emulated_engine, 192, 5, 12, 0x5EED0003, False)
 
