@@ -2134,11 +2134,53 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 #define FP_TAKEN(cls) do { } while (0)
 #endif
 
+/* The steady-state outcomes of append_entries_rpc and written dirty TWO neighbouring 16-byte pieces of the hot row
+ * (commit / last_index, last_written / pending: one aligned 32-byte unit each).  Stored by the lane itself they are two
+ * instructions that touch 64 lines each; the kernel is bound by the number of its memory requests, so the fast paths
+ * only record what they want stored and the wavefront stores it in PAIRS of lanes: in each of two instructions lanes
+ * 2k and 2k+1 write the two pieces of ONE server -- 32 contiguous bytes, one request -- so an instruction touches 32
+ * lines.  (lanes that took no fast path record nothing) */
+#ifndef RGB_X_PAIR_STORE
+#define RGB_X_PAIR_STORE 1
+#endif
+struct PairSt {
+  ulonglong2 *p;          /* the first piece of the unit */
+  ulonglong2 a, b;
+  unsigned m;             /* bit 0: store a at p, bit 1: store b at p + 1 */
+};
+__device__ __forceinline__ void pair_record(PairSt *ps, ulonglong2 *p, bool sa, const ulonglong2 a, bool sb, const ulonglong2 b) {
+  if (RGB_X_PAIR_STORE && ps != nullptr) {
+    ps->p = p; ps->a = a; ps->b = b; ps->m = (sa ? 1u : 0u) | (sb ? 2u : 0u);
+  } else {
+    if (sa) ST16(p, a);
+    if (sb) ST16(p + 1, b);
+  }
+}
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+  return (u64)(u32)__shfl((int)(u32)v, src, 64) | ((u64)(u32)__shfl((int)(u32)(v >> 32), src, 64) << 32);
+}
+/* executed by the whole wavefront (uniform control flow) */
+__device__ __forceinline__ void pair_store(const PairSt &st, u32 lane) {
+  const int t = (int)(threadIdx.x & ~63u) + (int)(lane & ~1u);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    /* the unit of lane 2j + k: lane 2j stores its first piece, lane 2j + 1 its second */
+    const int src = t + k;
+    const u64 pp = shfl64((u64)(uintptr_t)st.p, src);
+    const unsigned m = (unsigned)__shfl((int)st.m, src, 64);
+    const bool second = (lane & 1u) != 0u;
+    const u64 ax = shfl64(st.a.x, src), ay = shfl64(st.a.y, src), bx = shfl64(st.b.x, src), by = shfl64(st.b.y, src);
+    if (m & (second ? 2u : 1u))
+      ST16(reinterpret_cast<ulonglong2 *>((uintptr_t)pp) + (second ? 1 : 0), second ? make_ulonglong2(bx, by) : make_ulonglong2(ax, ay));
+  }
+}
+
 /* follower, append_entries_rpc from the known leader in the current term, appended right after the last index with
  * entries of the last run's term: ra_log:write of the tail (src/ra_server.erl:1283-1303, 1365-1389; ra_log:write/2
  * src/ra_log.erl:547-599; evaluate_commit_index_follower/2 :2246-2280) */
 __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1, const ulonglong2 m2,
-                                         const ulonglong2 m3, const ulonglong2 *pre, unsigned swz, Dec &out) {
+                                         const ulonglong2 m3, const ulonglong2 *pre, unsigned swz, Dec &out,
+                                         PairSt *pst = nullptr) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
   const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), from = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF), gap = (unsigned)((m0.x >> 56) & 0xFF);
@@ -2174,7 +2216,8 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
   const u64 at = lst < ci ? lst : ci;
   if (at > la) { nla = at; flags |= RGB_F_APPLIED | RGB_F_AUX_EVAL; }     /* apply_to/5: at >= la + 1 */
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS);
-  if (ci != h1.x || nla != la) ST16(ho + HOT_P_CI, make_ulonglong2(ci, nla));
+  static_assert(HOT_P_LI == HOT_P_CI + 1 && (HOT_P_CI & 1) == 0, "commit and last_index pieces: one aligned 32-byte unit");
+  pair_record(pst, ho + HOT_P_CI, ci != h1.x || nla != la, make_ulonglong2(ci, nla), n_entries != 0, make_ulonglong2(li + n_entries, lt));
   if (n_entries == 0) {
     /* the empty rpc at the tail (nothing new to write, :1304-1343): validated, the commit index is the leader's, the
      * success reply carries what is written (append_entries_reply/3 :3624-3631) */
@@ -2183,7 +2226,6 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
     return true;
   }
   flags |= RGB_F_WROTE;
-  ST16(ho + HOT_P_LI, make_ulonglong2(lst, lt));
   make_decision(out, server, RGB_ROLE_FOLLOWER, RGB_NONE, 0, RGB_MSG_AER, flags, 0, 0, fst, lst, 0, ci, nla);
   return true;
 }
@@ -2192,7 +2234,7 @@ __device__ __forceinline__ bool fast_aer(const rgb_dev &dev, const ulonglong2 m0
  * last_written moves to To, the reply goes to the known leader (src/ra_server.erl:1457-1474; ra_log:handle_event
  * src/ra_log.erl:897-920) */
 __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
-                                             const ulonglong2 *pre, unsigned swz, Dec &out) {
+                                             const ulonglong2 *pre, unsigned swz, Dec &out, PairSt *pst = nullptr) {
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
   const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), mflags = (unsigned)((m0.x >> 48) & 0xFF);
   if (wire_kind != RGB_MSG_WRITTEN || server >= dev.n_servers || mflags != 0) FP_DECLINE(2, 1);
@@ -2220,10 +2262,8 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
   if (pend <= li && to + 1 > pend) npend = to + 1;                    /* == li + 1 when everything is confirmed */
   const bool changed = !(h3.x == to && h3.y == term);
   ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS);
-  if (changed) ST16(ho + HOT_P_LW, make_ulonglong2(to, term));
-#ifndef RGB_X_NOPEND      /* EXPERIMENT (breaks parity): what is the second dirty sector of a written event worth? */
-  if (npend != pend) ST16(ho + HOT_P_PEND, make_ulonglong2(h7.x, npend));
-#endif
+  static_assert(HOT_P_PEND == HOT_P_LW + 1 && (HOT_P_LW & 1) == 0, "last_written and pending pieces: one aligned 32-byte unit");
+  pair_record(pst, ho + HOT_P_LW, changed, make_ulonglong2(to, term), npend != pend, make_ulonglong2(h7.x, npend));
   u32 flags = 0;
   u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0;
   unsigned reply_to = RGB_NONE;
@@ -2714,11 +2754,14 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   bool done = false;
 #if RGB_X_FAST
   /* the steady-state outcome of the three bulk kinds first; whoever is left takes the general clause code below */
+  PairSt pst;
+  pst.p = nullptr; pst.a = pst.b = make_ulonglong2(0, 0); pst.m = 0;
   if (active) {
-    if (cls == 0) done = fast_aer(dev, m0, m1, m2, m3, hrow, hswz, d);
+    if (cls == 0) done = fast_aer(dev, m0, m1, m2, m3, hrow, hswz, d, &pst);
     else if (cls == 1) done = fast_aer_reply<N, TR>(dev, m0, m1, hrow, hswz, d, prow, rrow);
-    else if (cls == 2) done = fast_written(dev, m0, m1, hrow, hswz, d);
+    else if (cls == 2) done = fast_written(dev, m0, m1, hrow, hswz, d, &pst);
   }
+  if (RGB_X_PAIR_STORE && (cls == 0 || cls == 2)) pair_store(pst, lane);       /* (wave-uniform) */
 #endif
 #if defined(RGB_PROFILE) && !defined(RGB_HOST_EMULATION)
   u64 tf = 0; unsigned n_fast = 0;
