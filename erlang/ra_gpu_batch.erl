@@ -58,6 +58,7 @@
 -define(F_QUERY_QUORUM, 33554432).
 -define(F_QUERY_APPLY, 67108864).
 -define(F_CANCEL_SNAPSHOT_RETRY, 134217728).
+-define(F_TRANSFER_LEADERSHIP, 536870912).
 
 init() ->
     erlang:load_nif(filename:join(code:priv_dir(ra), "ra_gpu_batch_nif"), 0).
@@ -286,7 +287,8 @@ role(4) -> await_condition.
 
 %% Reconstitute the effects() list ra_server_proc:handle_effects/4 expects from a decision
 %% (reference src/ra_server.erl:178-206 for the vocabulary).  Id = this server's id,
-%% Member = fun(Slot) -> ra_server_id().
+%% Member = fun(Slot) -> ra_server_id(); Member(first_peer) = the first key of the cluster map without Id
+%% (only asked for with F_TRANSFER_LEADERSHIP).
 decision_to_effects(Id, Member, #{flags := F} = D) when F band ?F_INVARIANT =/= 0 ->
     %% the reference would have exited: do exactly that (reason by code, see the header)
     exit({ra_gpu_batch_invariant, Id, maps:get(invariant, D), Member});
@@ -327,4 +329,7 @@ decision_to_effects(Id, Member, #{flags := F, reply_to := To} = D) ->
     Cancels ++ Reply ++ Heartbeats
     ++ [{record_leader_msg, Member(To)} || F band ?F_LEADER_MSG =/= 0]
     ++ [{next_event, info, pipeline_rpcs} || F band ?F_PIPELINE =/= 0]
-    ++ [{aux, eval} || F band ?F_AUX_EVAL =/= 0].
+    ++ [{aux, eval} || F band ?F_AUX_EVAL =/= 0]
+    %% the leader's wal_down condition timed out with the WAL still down (ra_server.erl:660-668): Member(first_peer)
+    %% must resolve to hd(maps:to_list(maps:remove(Id, Cluster))) -- the caller's Member fun knows the cluster map
+    ++ [{next_event, cast, {transfer_leadership, Member(first_peer)}} || F band ?F_TRANSFER_LEADERSHIP =/= 0].

@@ -55,11 +55,17 @@ enum {
   RGB_COND_NONE          = 0,
   RGB_COND_MISSING       = 1,
   RGB_COND_TERM_MISMATCH = 2,
-  RGB_COND_WAL_DOWN      = 3   /* follower whose ra_log:write/2 returned {error, wal_down} (src/ra_server.erl:1377-1385,
+  RGB_COND_WAL_DOWN      = 3,  /* follower whose ra_log:write/2 returned {error, wal_down} (src/ra_server.erl:1377-1385,
                                   wal_down_condition/2 :2232-2233).  The write is host I/O: the host re-uploads the server in
                                   role await_condition with this reason and the log as it was BEFORE the write; from then on
                                   it sets RGB_MF_CAN_WRITE on the server's messages once ra_log:can_write/1 is true again --
                                   the predicate of the reference.  No stored reply: a timeout just returns to follower. */
+  RGB_COND_WAL_DOWN_LEADER = 4 /* leader whose ra_log:append/2 raised wal_down on a {command, _} (src/ra_server.erl:655-672):
+                                  the same predicate (RGB_MF_CAN_WRITE), but the condition carries transition_to => leader
+                                  and a timeout that also returns to leader with [{next_event, cast, {transfer_leadership,
+                                  Peer}}] (RGB_F_TRANSFER_LEADERSHIP) when the log still cannot be written.  The append is
+                                  host I/O: the host re-uploads the server as it was BEFORE the command, in role
+                                  await_condition with this reason (test/ra_server_SUITE.erl:1035-1073, vector W2).       */
 };
 
 /* message kinds (one inbound ra_msg() for one server) */
@@ -175,6 +181,10 @@ typedef struct rgb_msg {
                                            ra_log:resend_pending/2 (src/ra_log.erl:917-919, 1663-1700); the log
                                            cursors are unchanged                                                 */
 
+#define RGB_F_TRANSFER_LEADERSHIP (1u << 29) /* await_condition_timeout of a leader's wal_down condition with the log still
+                                               not writable: [{next_event, cast, {transfer_leadership, PeerId}}] where PeerId is
+                                               the host's hd(maps:to_list(maps:remove(Self, Cluster))) -- raised only when the
+                                               cluster has another member (src/ra_server.erl:660-668, 1932-1945)           */
 #define RGB_F_COMPACT        (1u << 28) /* DEVICE-RESIDENT decision streams only (rgb_run_ticks_device, rgb_train_run_device,
                                            the generator's apply): only the first 32 bytes of this 64-byte slot were written
                                            -- the compact form below; rgb_decision_expand() gives the record back.

@@ -1344,18 +1344,27 @@ static int handle_pre_vote(oserver *sv, const rgb_msg *m, ofx *fx, int *reproces
 static int handle_await_condition(oserver *sv, const rgb_msg *m, ofx *fx, int *reprocess) {
   oscal *s = &sv->s;
   /* condition = #{predicate_fun => fun wal_down_condition/2} (src/ra_server.erl:1377-1385, 2232-2233): the predicate is
-   * ra_log:can_write(Log), host knowledge carried by RGB_MF_CAN_WRITE; the condition map has no timeout effects */
-  if (s->cond_reason == RGB_COND_WAL_DOWN) {
+   * ra_log:can_write(Log), host knowledge carried by RGB_MF_CAN_WRITE.  The follower's condition map has no
+   * transition_to and no timeout (defaults: follower, no effects); the leader's (:660-668) has transition_to => leader
+   * and timeout => #{effects => [{next_event, cast, {transfer_leadership, PeerId}}] (none without a peer),
+   * transition_to => leader} */
+  if (s->cond_reason == RGB_COND_WAL_DOWN || s->cond_reason == RGB_COND_WAL_DOWN_LEADER) {
+    const int to_leader = s->cond_reason == RGB_COND_WAL_DOWN_LEADER;
+    const uint8_t back = to_leader ? RGB_ROLE_LEADER : RGB_ROLE_FOLLOWER;
     switch (m->kind) {
       case RGB_MSG_REQUEST_VOTE: case RGB_MSG_PRE_VOTE_RPC: case RGB_MSG_ELECTION_TIMEOUT:
       case RGB_MSG_WRITTEN: case RGB_MSG_SNAPSHOT_WRITTEN:
         break;                                               /* their own clauses, below */
       case RGB_MSG_AWAIT_TIMEOUT:
-        set_role(s, RGB_ROLE_FOLLOWER, fx);                  /* :1932-1945 with Timeout = #{}: no effects */
+        /* :1932-1945: predicate true -> transition_to, no effects; false -> the timeout's transition_to and effects */
+        if (to_leader && !(m->flags & RGB_MF_CAN_WRITE) &&
+            (s->present_mask & ~(1u << s->self)) != 0)       /* maps:to_list(maps:remove(Self, Cluster)) =/= [] */
+          fx->flags |= RGB_F_TRANSFER_LEADERSHIP;
+        set_role(s, back, fx);
         return 0;
       default:
         if (m->flags & RGB_MF_CAN_WRITE) {                   /* :1950-1955 {next_event, Msg} */
-          set_role(s, RGB_ROLE_FOLLOWER, fx);
+          set_role(s, back, fx);
           *reprocess = 1;
         }
         return 0;
@@ -1428,7 +1437,7 @@ static void process_one(struct ora_ctx *c, uint32_t msg_index, const rgb_msg *m,
   fx.rpcs = rpcs; fx.rpc_cap = rpc_cap; fx.n_rpcs_total = *n_rpcs; fx.msg_index = msg_index;
   uint32_t rpcs_before = *n_rpcs;
   int rc = 0;
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = 0; pass < 3; pass++) {                    /* await_condition -> leader -> follower at most */
     int reprocess = 0;
     switch (sv->s.role) {
       case RGB_ROLE_FOLLOWER:        rc = handle_follower(sv, m, &fx); break;

@@ -22,7 +22,7 @@ DEFAULT_MAX_PIPELINE_COUNT = 4096
 # ra_state()
 ROLE_FOLLOWER, ROLE_CANDIDATE, ROLE_LEADER, ROLE_PRE_VOTE, ROLE_AWAIT_CONDITION = range(5)
 ROLE_NAMES = ["follower", "candidate", "leader", "pre_vote", "await_condition"]
-COND_NONE, COND_MISSING, COND_TERM_MISMATCH, COND_WAL_DOWN = range(4)
+COND_NONE, COND_MISSING, COND_TERM_MISMATCH, COND_WAL_DOWN, COND_WAL_DOWN_LEADER = range(5)
 
 (MSG_NOP, MSG_AER, MSG_AER_REPLY, MSG_REQUEST_VOTE, MSG_VOTE_RESULT, MSG_WRITTEN,
  MSG_PIPELINE_RPCS, MSG_APPEND, MSG_AWAIT_TIMEOUT, MSG_ELECTION_TIMEOUT, MSG_PRE_VOTE_RPC,
@@ -67,6 +67,7 @@ F_SEND_HEARTBEATS = 1 << 24
 F_QUERY_QUORUM = 1 << 25
 F_QUERY_APPLY = 1 << 26
 F_CANCEL_SNAPSHOT_RETRY = 1 << 27
+F_TRANSFER_LEADERSHIP = 1 << 29   # leader's wal_down condition timed out: {transfer_leadership, Peer} (src/ra_server.erl:660-668)
 F_COMPACT = 1 << 28   # device-resident decision streams: the 32-byte compact form (expand_decisions)
 
 (INV_NONE, INV_LEADER_SAW_AER_SAME_TERM, INV_TRUNCATE_BELOW_APPLIED, INV_WRITE_BELOW_APPLIED,

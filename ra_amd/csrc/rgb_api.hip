@@ -415,7 +415,7 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
 static int validate_state(const rgb_ctx *ctx, const rgb_server_state &h) {
   if (h.n_members != ctx->dev.n_members) return RGB_E_INVAL;
   if (h.self >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
-  if (h.role > RGB_ROLE_AWAIT_CONDITION || h.cond_reason > RGB_COND_WAL_DOWN) return RGB_E_INVAL;
+  if (h.role > RGB_ROLE_AWAIT_CONDITION || h.cond_reason > RGB_COND_WAL_DOWN_LEADER) return RGB_E_INVAL;
   if (h.n_runs > RGB_MAX_RUNS || h.votes > 15) return RGB_E_INVAL;
   if (h.voted_for != RGB_NONE && h.voted_for >= RGB_MAX_MEMBERS) return RGB_E_INVAL;
   if (h.leader_id != RGB_NONE && h.leader_id >= RGB_MAX_MEMBERS) return RGB_E_INVAL;

@@ -80,6 +80,7 @@ typedef uint32_t u32;
 #define PK_VOTES_SH     9   /* 4 */
 #define PK_NRUNS_SH     13  /* 5 */
 #define PK_NONVOTER_SH  18  /* 1 */
+#define PK_CONDTO_SH    19  /* 1: the stored condition's transition_to is leader (RGB_COND_WAL_DOWN_LEADER = COND 3 + this bit) */
 #define PK_VOTED_SH     20  /* 4, 0xF = undefined */
 #define PK_LEADER_SH    24  /* 4, 0xF = undefined */
 #define PK_CONDLDR_SH   28  /* 4, 0xF = undefined */

@@ -457,7 +457,7 @@ __device__ __forceinline__ void set_role(Lane &L, unsigned role) {
     L.pk = pk_set(L.pk, PK_STATUS_SH, 8, 0xFF);
     L.pk = pk_set(L.pk, PK_BACKOFF_SH, 1, 0);         /* status => normal for every peer */
   }
-  if (role != RGB_ROLE_AWAIT_CONDITION) L.pk = pk_set(L.pk, PK_COND_SH, 2, RGB_COND_NONE);
+  if (role != RGB_ROLE_AWAIT_CONDITION) L.pk &= ~((3ull << PK_COND_SH) | (1ull << PK_CONDTO_SH));   /* RGB_COND_NONE */
   L.pk = pk_set(L.pk, PK_ROLE_SH, 3, role);
 }
 
@@ -1713,17 +1713,23 @@ __device__ __forceinline__ int handle_pre_vote(Lane &L, bool &reprocess) {
 /* ----------------------------------------------------------- await_condition ---- */
 template <int N, class Lane>
 __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, const u64 *cond_row) {
-  /* wal_down_condition/2 :2232-2233: the predicate is ra_log:can_write/1, which the host knows and passes along */
+  /* wal_down_condition/2 :2232-2233: the predicate is ra_log:can_write/1, which the host knows and passes along.
+   * The follower's condition (:1377-1385) has no transition_to and no timeout map (follower, no effects); the leader's
+   * (:660-668, PK_CONDTO) goes back to leader, on a timeout with [{next_event, cast, {transfer_leadership, Peer}}] */
   const bool wal_down = pk_get(L.pk, PK_COND_SH, 2) == RGB_COND_WAL_DOWN;
   const bool can_write = (L.mflags & RGB_MF_CAN_WRITE) != 0;
+  const unsigned back = pk_get(L.pk, PK_CONDTO_SH, 1) ? RGB_ROLE_LEADER : RGB_ROLE_FOLLOWER;
   switch (L.kind) {
     case RGB_MSG_REQUEST_VOTE:
       set_role(L, RGB_ROLE_FOLLOWER);                                /* :1918-1919 */
       reprocess = true;
       return 0;
     case RGB_MSG_AWAIT_TIMEOUT: {
-      if (wal_down) {                    /* no timeout effects in this condition: back to follower either way */
-        set_role(L, RGB_ROLE_FOLLOWER);
+      if (wal_down) {                    /* :1932-1945: transition_to either way; the leader's timeout map has an effect */
+        if (back == RGB_ROLE_LEADER && !can_write &&
+            (pk_get(L.pk, PK_PRESENT_SH, 8) & ~(1ull << self_of(L))) != 0ull)
+          L.flags |= RGB_F_TRANSFER_LEADERSHIP;
+        set_role(L, back);
         return 0;
       }
       /* :1932-1945: predicate false -> stored effects, back to follower */
@@ -1755,13 +1761,13 @@ __device__ __forceinline__ int handle_await_condition(Lane &L, bool &reprocess, 
         if (h == HLE_OK) pred = true;
         else if (h == HLE_MISMATCH) pred = pk_get(L.pk, PK_COND_SH, 2) == RGB_COND_MISSING;
       }
-      if (pred) { set_role(L, RGB_ROLE_FOLLOWER); reprocess = true; } /* :1950-1955 */
+      if (pred) { set_role(L, wal_down ? back : (unsigned)RGB_ROLE_FOLLOWER); reprocess = true; } /* :1950-1955 */
       return 0;
     }
     default:
       /* the catch-all clause :1950-1959: follower_catchup_cond/3 is false for anything but an append_entries_rpc;
        * the wal_down predicate does not look at the message */
-      if (wal_down && can_write) { set_role(L, RGB_ROLE_FOLLOWER); reprocess = true; }
+      if (wal_down && can_write) { set_role(L, back); reprocess = true; }
       return 0;
   }
 }
@@ -1946,24 +1952,32 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
   const unsigned n_runs0 = L.n_runs;
   unsigned n_rpcs = 0;
   int rc = 0;
-  /* every {next_event, Msg} re-processing of the reference lands in follower, so: non-follower
-   * roles first, then handle_follower once for servers that are (or just became) followers */
-  bool to_follower = role0 == RGB_ROLE_FOLLOWER;
-  if (!to_follower) {
+  /* {next_event, Msg} re-processing of the reference: await_condition hands the message to the condition's
+   * transition_to (follower, or leader for the leader's wal_down condition), every other role change that re-processes
+   * lands in follower.  So: await_condition first, then the other non-follower roles, then handle_follower once for
+   * servers that are (or just became) followers -- one call site per handler */
+  unsigned role1 = role0;
+  bool go = true;
+  if (role0 == RGB_ROLE_AWAIT_CONDITION) {
     bool reprocess = false;
-    switch (role0) {
+    rc = handle_await_condition<N>(L, reprocess, dev.cond + (size_t)L.server * 4);
+    go = !rc && reprocess;
+    if (go) { L.flags |= RGB_F_REPROCESSED; role1 = role_of(L); }
+  }
+  if (go && role1 != RGB_ROLE_FOLLOWER) {
+    bool reprocess = false;
+    switch (role1) {
       case RGB_ROLE_LEADER:          rc = handle_leader<N, PL>(L, reprocess, dev, rpcs,
                                                            (rpc_slot_base + i) * (N > 1 ? N - 1 : 1),
                                                            msg_index_base + i, n_rpcs); break;
       case RGB_ROLE_CANDIDATE:       rc = handle_candidate<N>(L, reprocess); break;
       case RGB_ROLE_PRE_VOTE:        rc = handle_pre_vote<N>(L, reprocess); break;
-      case RGB_ROLE_AWAIT_CONDITION: rc = handle_await_condition<N>(L, reprocess,
-                                                dev.cond + (size_t)L.server * 4); break;
       default: L.flags |= RGB_F_UNHANDLED; break;
     }
-    if (!rc && reprocess) { L.flags |= RGB_F_REPROCESSED; to_follower = true; }
+    go = !rc && reprocess;
+    if (go) L.flags |= RGB_F_REPROCESSED;
   }
-  if (!rc && to_follower) rc = handle_follower<N>(L);
+  if (go) rc = handle_follower<N>(L);
 #ifdef RGB_PROFILE
   if (t_loaded && RGB_KNOB(dev, 16u)) t_loaded[2] = wall_clock64();     /* clause code done (stores of rpc records issued) */
 #endif
@@ -3583,7 +3597,8 @@ __global__ void rgb_pack_kernel(rgb_dev dev, const rgb_server_state *__restrict_
   }
   u64 pk = 0;
   pk = pk_set(pk, PK_ROLE_SH, 3, h.role);
-  pk = pk_set(pk, PK_COND_SH, 2, h.cond_reason);
+  pk = pk_set(pk, PK_COND_SH, 2, h.cond_reason == RGB_COND_WAL_DOWN_LEADER ? RGB_COND_WAL_DOWN : h.cond_reason);
+  pk = pk_set(pk, PK_CONDTO_SH, 1, h.cond_reason == RGB_COND_WAL_DOWN_LEADER ? 1 : 0);
   pk = pk_set(pk, PK_SELF_SH, 4, h.self);
   pk = pk_set(pk, PK_VOTES_SH, 4, h.votes);
   pk = pk_set(pk, PK_NRUNS_SH, 5, nr);
@@ -3658,7 +3673,7 @@ __global__ void rgb_unpack_kernel(rgb_dev dev, rgb_server_state *__restrict__ ou
   if (!(h.first_index <= h.last_index)) { nr = 0; h.first_index = h.last_index + 1; }
   for (unsigned r = 0; r < nr && r < RGB_MAX_RUNS; ++r) { h.run_start[r] = runs[2 * r]; h.run_term[r] = runs[2 * r + 1]; }
   h.role = (uint8_t)pk_get(pk, PK_ROLE_SH, 3);
-  h.cond_reason = (uint8_t)pk_get(pk, PK_COND_SH, 2);
+  h.cond_reason = (uint8_t)(pk_get(pk, PK_COND_SH, 2) + pk_get(pk, PK_CONDTO_SH, 1));   /* 3 + 1 = RGB_COND_WAL_DOWN_LEADER */
   h.self = (uint8_t)pk_get(pk, PK_SELF_SH, 4);
   h.n_members = (uint8_t)N;
   h.voted_for = (uint8_t)slot4to8((unsigned)pk_get(pk, PK_VOTED_SH, 4));
@@ -3742,7 +3757,7 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   x = fnv_word(x, li); x = fnv_word(x, hot[HOT_LT]); x = fnv_word(x, hot[HOT_LWI]);
   x = fnv_word(x, hot[HOT_LWT]); x = fnv_word(x, hot[HOT_SI]); x = fnv_word(x, hot[HOT_ST]);
   x = fnv_word(x, fi);
-  u64 packed = pk_get(pk, PK_ROLE_SH, 3) | (pk_get(pk, PK_COND_SH, 2) << 8) |
+  u64 packed = pk_get(pk, PK_ROLE_SH, 3) | ((pk_get(pk, PK_COND_SH, 2) + pk_get(pk, PK_CONDTO_SH, 1)) << 8) |
                (pk_get(pk, PK_SELF_SH, 4) << 16) | ((u64)N << 24) |
                ((u64)slot4to8((unsigned)pk_get(pk, PK_VOTED_SH, 4)) << 32) |
                ((u64)slot4to8((unsigned)pk_get(pk, PK_LEADER_SH, 4)) << 40) |

@@ -424,6 +424,126 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel
   }
 }
 
+/* ---- small records, the DIRECT form (WAL_X_DIRECT): no funnel ----
+ * Eight lanes per record; lane j handles payload bytes [16 j, 16 j + 16) as they lie: one 16-byte load at the
+ * payload's own alignment, the checksum on exactly those bytes (the piece that starts p bytes into the payload weighs
+ * (len - p - 16) a + b, no masks), one 16-byte store at the destination's own alignment -- gfx950 global loads and
+ * stores take any byte alignment.  A payload that does not end on a piece boundary ends with the piece
+ * [len - 16, len), which overlaps its predecessor: the overlapped bytes are masked out of the sums (what is left
+ * weighs exactly b) and stored twice with the same value.  Payloads under 16 bytes go byte by byte.  Against the
+ * funnel form this trades requests that straddle a 64-byte boundary (one lane in four, both directions) for ~3/4 of
+ * the vector instructions: no rotation, no window, no partial-store chains. */
+typedef v4u v4u_any __attribute__((aligned(1)));
+#ifndef WAL_X_DIRECT
+#define WAL_X_DIRECT 1      /* lane groups that frame in the direct form: 1 = eight lanes per record (mean payload <= 320 B:
+                               0.55 against 0.42-0.44 of the roofline on 256-byte payloads, same box), 2 = sixteen too,
+                               3 = every size; 0 = the funnel form everywhere */
+#endif
+template <int GROUP>
+__global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_direct_kernel(
+    const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data,
+    unsigned char *__restrict__ out, u32 *__restrict__ sums_out, u32 flags) {
+  constexpr u32 PER_BLOCK = WAL_WAVES_PER_BLOCK * 64 / GROUP;
+  constexpr bool UNI = GROUP == 64;                     /* one record per wavefront: descriptor in scalar registers */
+  constexpr int UNROLL = GROUP == 64 ? WAL_UNROLL : 2;
+  const u32 lane = threadIdx.x & (GROUP - 1);
+  u32 e = blockIdx.x * PER_BLOCK + threadIdx.x / GROUP;
+#ifndef RGB_HOST_EMULATION
+  if (UNI) e = (u32)__builtin_amdgcn_readfirstlane((int)e);
+#endif
+  const bool live = e < n;
+  rgb_wal_record r;
+  r.index = r.term = r.data_offset = r.hdr_offset = r.out_offset = 0; r.data_len = r.hdr_len = 0;
+  if (live) r = recs[e];
+  const u32 len = r.data_len;
+  unsigned char *rec = out + r.out_offset;
+  unsigned char *dst = rec + r.hdr_len + 24u;           /* the payload's place in the record */
+  const unsigned char *pay = data + r.data_offset;
+  const unsigned char *hdr = data + r.hdr_offset;
+  u32 hbyte = 0;
+  if (live && lane < r.hdr_len) hbyte = hdr[lane];
+  const u32 n_full = live ? len >> 4 : 0u, rem = live ? len & 15u : 0u;
+  const u32 len_q = len % ADLER_MOD;
+  u32 a_acc = 0, b_acc = 0;
+  constexpr u32 STEP = (16u * GROUP) % ADLER_MOD;
+  /* weight of the byte behind piece j: (len - 16 j - 16) mod 65521, stepped down per round */
+  u32 wq = (len_q + 2u * ADLER_MOD - ((lane << 4) % ADLER_MOD) - 16u) % ADLER_MOD;
+  for (u32 j0 = 0; j0 < n_full; j0 += GROUP * UNROLL) {
+    uint4 v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      const u32 j = j0 + (u32)k * GROUP + lane;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (j < n_full) {
+        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u_any *>(pay + ((size_t)j << 4)));
+        v[k] = make_uint4(t.x, t.y, t.z, t.w);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      const u32 j = j0 + (u32)k * GROUP + lane;
+      if (j < n_full) {
+        v4u t; t.x = v[k].x; t.y = v[k].y; t.z = v[k].z; t.w = v[k].w;
+#if defined(RGB_HOST_EMULATION)
+        *reinterpret_cast<v4u_any *>(dst + ((size_t)j << 4)) = t;
+#else
+        /* streamed past the caches for a record per wavefront, plain for the small-record groups (see store16_stream) */
+        if (UNI) __builtin_nontemporal_store(t, reinterpret_cast<v4u_any *>(dst + ((size_t)j << 4)));
+        else *reinterpret_cast<v4u_any *>(dst + ((size_t)j << 4)) = t;
+#endif
+        u32 a, b;
+        chunk_sums(v[k], a, b);
+        a_acc += a;
+        b_acc += (wq * a + b) % ADLER_MOD;
+        if (b_acc >= 0x7FFF0000u) b_acc %= ADLER_MOD;
+        if (a_acc >= 0x7FFF0000u) a_acc %= ADLER_MOD;
+      }
+      wq = wq >= STEP ? wq - STEP : wq + (ADLER_MOD - STEP);
+    }
+  }
+  if (rem && lane == (n_full & (GROUP - 1))) {           /* the last len mod 16 bytes: they weigh rem .. 1 */
+    uint4 w = make_uint4(0, 0, 0, 0);
+    if (n_full) {
+      const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u_any *>(pay + (len - 16u)));
+      *reinterpret_cast<v4u_any *>(dst + (len - 16u)) = t;
+      w = keep_bytes(make_uint4(t.x, t.y, t.z, t.w), 16u - rem, 16u);
+    } else {
+      u64 lo = 0, hi = 0;                                /* bytes at chunk positions [16 - rem, 16) */
+      for (u32 k = 0; k < rem; ++k) {
+        const u32 c = pay[k], q = 16u - rem + k;
+        dst[k] = (unsigned char)c;
+        if (q < 8u) lo |= (u64)c << (8u * q); else hi |= (u64)c << (8u * (q - 8u));
+      }
+      w = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+    }
+    u32 a, b;
+    chunk_sums(w, a, b);
+    a_acc += a; b_acc += b;                              /* both far from wrapping: one piece */
+  }
+  const u32 a_sum = group_sum<GROUP>(a_acc % ADLER_MOD);
+  const u32 b_sum = group_sum<GROUP>(b_acc % ADLER_MOD);
+  if (!live) return;
+  const u32 ih = (u32)(r.index >> 32), il = (u32)r.index, th = (u32)(r.term >> 32), tl = (u32)r.term;
+  u32 pa = dot4(ih, 0x01010101u, 0); pa = dot4(il, 0x01010101u, pa);
+  pa = dot4(th, 0x01010101u, pa); pa = dot4(tl, 0x01010101u, pa);
+  u32 pb = dot4(ih, 0x100F0E0Du, 0); pb = dot4(il, 0x0C0B0A09u, pb);
+  pb = dot4(th, 0x08070605u, pb); pb = dot4(tl, 0x04030201u, pb);
+  const u32 A = (1u + pa + a_sum) % ADLER_MOD;
+  const u32 B = ((16u + len_q) + (len_q * pa + pb) % ADLER_MOD + b_sum) % ADLER_MOD;
+  const u32 cs = (flags & RGB_WAL_NO_CHECKSUMS) ? 0u : ((B << 16) | A);
+  if (lane < r.hdr_len) rec[lane] = (unsigned char)hbyte;
+  for (u32 j = GROUP + lane; j < r.hdr_len; j += GROUP) rec[j] = hdr[j];
+  if (lane == 0u) {
+    if (sums_out) sums_out[e] = cs;
+    struct __attribute__((packed)) fixed24 { v4u a; u64 b; };
+    fixed24 fx;
+    fx.a.x = __builtin_bswap32(cs); fx.a.y = __builtin_bswap32(len);
+    fx.a.z = __builtin_bswap32(ih); fx.a.w = __builtin_bswap32(il);
+    fx.b = (u64)__builtin_bswap32(th) | ((u64)__builtin_bswap32(tl) << 32);
+    __builtin_memcpy(rec + r.hdr_len, &fx, 24);
+  }
+}
+
 }  // namespace
 
 /* the context only supplies the default stream; rgb_api.hip exports the accessor */
@@ -464,19 +584,34 @@ extern "C" int rgb_wal_frame_device(rgb_ctx *ctx, const void *d_records, uint32_
     /* the smallest payloads: eight lanes per record, eight records per wavefront (the per-record work that does not
      * shrink with the payload -- descriptor, reduction, prefix -- is paid per WAVEFRONT instruction) */
     const u32 per = WAL_WAVES_PER_BLOCK * 64 / 8;
-    hipLaunchKernelGGL(rgb_wal_frame_kernel<8>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                       (unsigned char *)d_out, (u32 *)d_checksums, flags);
+    if (WAL_X_DIRECT >= 1)
+      hipLaunchKernelGGL(rgb_wal_frame_direct_kernel<8>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
+                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
+    else
+      hipLaunchKernelGGL(rgb_wal_frame_kernel<8>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
+                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
   } else if (data_bytes / n < 1024u) {
     const u32 per = WAL_WAVES_PER_BLOCK * 64 / 16;
-    hipLaunchKernelGGL(rgb_wal_frame_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                       (unsigned char *)d_out, (u32 *)d_checksums, flags);
+    if (WAL_X_DIRECT >= 2)
+      hipLaunchKernelGGL(rgb_wal_frame_direct_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
+                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
+    else
+      hipLaunchKernelGGL(rgb_wal_frame_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
+                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
   } else {
     const u32 per = WAL_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(rgb_wal_frame_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                       (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                       (unsigned char *)d_out, (u32 *)d_checksums, flags);
+    if (WAL_X_DIRECT >= 3)
+      hipLaunchKernelGGL(rgb_wal_frame_direct_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
+                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
+    else
+      hipLaunchKernelGGL(rgb_wal_frame_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
+                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
+                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
   }
   return hipGetLastError() == hipSuccess ? RGB_OK : RGB_E_HIP;
 }

@@ -866,6 +866,26 @@ vec("W1", "test/ra_server_SUITE.erl:1004-1033 wal_down_condition_follower", 3, "
          "are the suite's two handle_await_condition calls (can_write false, then true); the timeout and the "
          "heartbeat steps follow src/ra_server.erl:1932-1959 with a condition map that has no timeout effects")
 
+vec("W2", "test/ra_server_SUITE.erl:1035-1073 wal_down_condition_leader", 3, "n1", "base", [
+    dict(reset=True, **step("await_condition", dict(kind="await_timeout"), role="leader", no_reply=True,
+                             state=dict(commit_index=1, current_term=5),
+                             flags_set=["TRANSFER_LEADERSHIP", "ROLE_CHANGED"], flags_clear=["REPROCESSED"])),
+    dict(reset=True, **step("await_condition", dict(kind="await_timeout", can_write=True), role="leader", no_reply=True,
+                             state=dict(commit_index=1, current_term=5),
+                             flags_set=["ROLE_CHANGED"], flags_clear=["TRANSFER_LEADERSHIP", "REPROCESSED"])),
+    dict(reset=True, **step("await_condition", reply("n2", 5, True, 4, 3, 5), role="await_condition",
+                             state_unchanged=True, no_reply=True, flags_clear=["REPROCESSED", "PIPELINE"])),
+    dict(reset=True, **step("await_condition", dict(reply("n2", 5, True, 4, 3, 5), can_write=True), role="leader",
+                             state=dict(commit_index=3, last_applied=3),
+                             flags_set=["REPROCESSED", "PIPELINE", "AUX_EVAL", "APPLIED"], no_reply=True)),
+], tweak=dict(commit_index=1, last_applied=1, role="await_condition", cond_reason="wal_down_leader", peers=L1_PEERS),
+    note="the suite mocks ra_log:append/2 -> error(wal_down): that step is the HOST's (it re-uploads the leader as it "
+         "was before the {command, _}, in await_condition / RGB_COND_WAL_DOWN_LEADER); steps 0-1 are the suite's two "
+         "handle_await_condition(await_condition_timeout, _) calls (can_write false: back to leader with the "
+         "transfer_leadership effect; true: back to leader, no effects); steps 2-3 follow src/ra_server.erl:1950-1959 "
+         "with transition_to => leader: the reply of L1-L2 is dropped while the WAL is down and re-processed by "
+         "handle_leader/2 once it is back")
+
 AGREED_COMMIT = [([4], 4), ([4, 3], 3), ([4, 4, 4], 4), ([4, 4, 3], 4), ([3, 4, 4], 4),
                  ([4, 2, 3], 3)]
 

@@ -50,6 +50,12 @@ def test_wal_down_host_recipe_through_the_c_abi(emulated_engine, oracle_lib):
     G.test_wal_down_host_recipe_keeps_last_applied_and_the_log(emulated_engine, oracle_lib)
 
 
+def test_wal_down_conditions_through_the_c_abi(emulated_engine, oracle_lib):
+    for n, seed in ((3, 71), (5, 72), (7, 73), (1, 74)):
+        G.test_wal_down_conditions_follower_and_leader_match_oracle(emulated_engine, oracle_lib, n, seed)
+    G.test_leader_wal_down_host_recipe(emulated_engine, oracle_lib)
+
+
 def test_sparse_pending_through_the_c_abi(emulated_engine, oracle_lib):
     for seed in range(8):
         G.test_sparse_pending_and_two_range_written_events(emulated_engine, oracle_lib, seed)

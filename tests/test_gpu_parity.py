@@ -194,6 +194,116 @@ def test_wal_down_host_recipe_keeps_last_applied_and_the_log(engine_mod, oracle_
     cpu.close()
 
 
+@pytest.mark.parametrize("n_members,seed", [(3, 71), (5, 72), (7, 73), (1, 74)])
+def test_wal_down_conditions_follower_and_leader_match_oracle(engine_mod, oracle_lib, n_members, seed, groups=160, ticks=5):
+    """await_condition with wal_down_condition/2 in both forms: the follower's (src/ra_server.erl:1377-1385: back to
+    follower, no timeout effects) and the leader's (:660-668: transition_to => leader, the timeout hands out
+    {transfer_leadership, Peer} while the log still cannot be written).  A third of the servers start in one of the
+    two, every message kind arrives at them with and without RGB_MF_CAN_WRITE; a message re-processed by
+    handle_leader/2 may step down and be re-processed once more by handle_follower/2."""
+    rng = np.random.default_rng(seed)
+    G, N = groups, n_members
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    pick = rng.random(G * N) < 0.34
+    st["role"][pick] = abi.ROLE_AWAIT_CONDITION
+    st["cond_reason"][pick] = rng.choice([abi.COND_WAL_DOWN, abi.COND_WAL_DOWN_LEADER], size=int(pick.sum()))
+    st["cond_reason"][~pick & (st["role"] != abi.ROLE_AWAIT_CONDITION)] = abi.COND_NONE
+    cpu = oracle_lib.Oracle(G, N); cpu.set_state(0, st)
+    seen_transfer = seen_leader_reprocess = 0
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=4096, ring_slots=2, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes()      # cond_reason 4 survives the packed word
+        assert gpu.state_checksum() == engine_mod.combine_checksums(oracle_lib.server_checksums(cpu.get_state()))
+        for t in range(ticks):
+            cur = cpu.get_state()
+            msgs = fuzz.random_msgs(rng, cur, N)
+            msgs["flags"] |= np.where(rng.random(len(msgs)) < 0.5, abi.MF_CAN_WRITE, 0).astype(msgs["flags"].dtype)
+            waiting = cur["role"][msgs["server"]] == abi.ROLE_AWAIT_CONDITION
+            timeout = waiting & (rng.random(len(msgs)) < 0.25)
+            msgs["kind"][timeout] = abi.MSG_AWAIT_TIMEOUT
+            do, ro = cpu.step(msgs)
+            dg, rg = gpu.step(msgs)
+            assert dg.tobytes() == do.tobytes(), f"tick {t}: decisions differ"
+            assert fuzz.sort_rpcs(rg).tobytes() == fuzz.sort_rpcs(ro).tobytes(), f"tick {t}: rpcs differ"
+            assert gpu.get_state().tobytes() == cpu.get_state().tobytes(), f"tick {t}: state differs"
+            seen_transfer += int(((dg["flags"] & abi.F_TRANSFER_LEADERSHIP) != 0).sum())
+            was_ldr_cond = cur["cond_reason"][msgs["server"]] == abi.COND_WAL_DOWN_LEADER
+            seen_leader_reprocess += int((was_ldr_cond & ((dg["flags"] & abi.F_REPROCESSED) != 0)).sum())
+            # the effect exists only for the leader's condition, on its timeout, with the WAL still down and a peer to name
+            tl = (dg["flags"] & abi.F_TRANSFER_LEADERSHIP) != 0
+            assert not (tl & ~(was_ldr_cond & (msgs["kind"] == abi.MSG_AWAIT_TIMEOUT) &
+                               ((msgs["flags"] & abi.MF_CAN_WRITE) == 0))).any()
+            assert (dg["role"][tl] == abi.ROLE_LEADER).all()
+            # keep a share of the servers in the two conditions for the next tick
+            if t + 1 < ticks:
+                cur = cpu.get_state()
+                again = rng.random(G * N) < 0.2
+                cur["role"][again] = abi.ROLE_AWAIT_CONDITION
+                cur["cond_reason"][again] = rng.choice([abi.COND_WAL_DOWN, abi.COND_WAL_DOWN_LEADER], size=int(again.sum()))
+                cpu.set_state(0, cur); gpu.set_state(0, cur)
+        assert gpu.state_checksum() == engine_mod.combine_checksums(oracle_lib.server_checksums(cpu.get_state()))
+    cpu.close()
+    if N > 1:
+        assert seen_transfer > 0 and seen_leader_reprocess > 0
+    else:
+        assert seen_transfer == 0          # maps:remove(Self, Cluster) is empty: no effect (src/ra_server.erl:661-662)
+
+
+def test_leader_wal_down_host_recipe(engine_mod, oracle_lib):
+    """The host recipe of INTEGRATION.md for `ra_log:append/2 -> error(wal_down)` on a leader's {command, _}
+    (src/ra_server.erl:655-672): the leader is re-uploaded AS IT WAS BEFORE the command in await_condition /
+    RGB_COND_WAL_DOWN_LEADER.  While the WAL is down a reply is dropped; the timeout returns to leader with the
+    transfer_leadership effect; with the WAL back the reply is re-processed by handle_leader/2 and commits."""
+    rng = np.random.default_rng(34)
+    G, N = 4, 3
+    st = fuzz.random_states(rng, G, N, max_runs=4)
+    s = 0
+    f = st[s:s + 1].copy()
+    f["role"] = abi.ROLE_LEADER; f["cond_reason"] = abi.COND_NONE; f["current_term"] = 3; f["leader_id"] = 0
+    f["voted_for"] = 0; f["first_index"] = 1; f["last_index"] = 10; f["last_term"] = 3
+    f["last_written_index"] = 10; f["last_written_term"] = 3; f["commit_index"] = 6; f["last_applied"] = 6
+    f["snapshot_index"] = abi.UNDEF; f["snapshot_term"] = abi.UNDEF
+    f["n_runs"] = 1; f["run_start"][0][0] = 1; f["run_term"][0][0] = 3; f["pending_first"] = 11; f["n_pending_old"] = 0
+    f["present_mask"] = 7; f["voter_mask"] = 7; f["status_mask"] = 0xFF; f["backoff_mask"] = 0; f["self_nonvoter"] = 0
+    f["match_index"][0][:3] = (10, 6, 6); f["next_index"][0][:3] = (11, 11, 11); f["commit_index_sent"][0][:3] = (6, 6, 6)
+    before = f[0].copy()
+    st[s] = before
+    cpu = oracle_lib.Oracle(G, N); cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=64, ring_slots=2, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        m = np.zeros(1, dtype=abi.MSG_DTYPE)
+        m["server"] = s; m["kind"] = abi.MSG_APPEND; m["from"] = abi.NONE; m["n_entries"] = 1
+        dg, _ = gpu.step(m); do, _ = cpu.step(m)
+        assert dg.tobytes() == do.tobytes() and gpu.get_state(s, 1)["last_index"][0] == 11
+        # ra_log:append/2 raised wal_down: the leader as it was, waiting
+        new = before.copy()
+        new["role"] = abi.ROLE_AWAIT_CONDITION; new["cond_reason"] = abi.COND_WAL_DOWN_LEADER
+        for target in (gpu, cpu):
+            target.set_state(s, new.reshape(1))
+        saved = new.copy()
+        r = np.zeros(1, dtype=abi.MSG_DTYPE)
+        r["server"] = s; r["kind"] = abi.MSG_AER_REPLY; r["from"] = 1; r["term"] = 3; r["flags"] = abi.MF_SUCCESS
+        r["a"] = 11; r["b"] = 10; r["c"] = 3
+        dg, _ = gpu.step(r); do, _ = cpu.step(r)                                 # WAL down: dropped
+        assert dg.tobytes() == do.tobytes() and dg[0]["role"] == abi.ROLE_AWAIT_CONDITION and dg[0]["flags"] == 0
+        assert gpu.get_state(s, 1).tobytes() == saved.reshape(1).tobytes()
+        t = np.zeros(1, dtype=abi.MSG_DTYPE)
+        t["server"] = s; t["kind"] = abi.MSG_AWAIT_TIMEOUT; t["from"] = abi.NONE
+        dg, _ = gpu.step(t); do, _ = cpu.step(t)                                 # timeout, WAL still down
+        assert dg.tobytes() == do.tobytes() and dg[0]["role"] == abi.ROLE_LEADER
+        assert dg[0]["flags"] & abi.F_TRANSFER_LEADERSHIP
+        back = gpu.get_state(s, 1)
+        assert back["cond_reason"][0] == abi.COND_NONE and back["last_index"][0] == 10
+        for target in (gpu, cpu):
+            target.set_state(s, saved.reshape(1))
+        r["flags"] = abi.MF_SUCCESS | abi.MF_CAN_WRITE
+        dg, _ = gpu.step(r); do, _ = cpu.step(r)                                 # WAL back: handle_leader/2 takes the reply
+        assert dg.tobytes() == do.tobytes() and dg[0]["role"] == abi.ROLE_LEADER
+        assert dg[0]["flags"] & abi.F_REPROCESSED and dg[0]["commit_index"] == 10
+        assert gpu.get_state(s, 1).tobytes() == cpu.get_state(s, 1).tobytes()
+    cpu.close()
+
+
 def test_concurrent_producers_and_consumers_on_one_context(engine_mod, oracle_lib, G=256, N=5, P=4, C_=2, per=6):
     """The boundary's threading contract (include/ra_gpu_batch.h): P threads in rgb_submit and C_ threads in rgb_collect
     on ONE context.  Every producer owns a disjoint range of groups, so the order in which the producers' batches

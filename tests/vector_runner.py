@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
 ROLE = {"follower": abi.ROLE_FOLLOWER, "candidate": abi.ROLE_CANDIDATE, "leader": abi.ROLE_LEADER,
         "pre_vote": abi.ROLE_PRE_VOTE, "await_condition": abi.ROLE_AWAIT_CONDITION}
 COND = {"none": abi.COND_NONE, "missing": abi.COND_MISSING, "term_mismatch": abi.COND_TERM_MISMATCH,
-        "wal_down": abi.COND_WAL_DOWN}
+        "wal_down": abi.COND_WAL_DOWN, "wal_down_leader": abi.COND_WAL_DOWN_LEADER}
 FLAG = {k[2:]: getattr(abi, k) for k in dir(abi) if k.startswith("F_")}
 
 

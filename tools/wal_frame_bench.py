@@ -24,8 +24,12 @@ if os.environ.get("WAL_MEMCPY") == "1":
     us = e0.elapsed_time(e1) * 1e3 / 20
     print(json.dumps({"calibration": "torch copy_ of 1 GiB (read + write)", "us": us, "GBps_read_plus_write": 2 * (1 << 30) / (us * 1e-6) / 1e9}))
     del a, b
-for label, n, lo, hi in (("4 KiB payloads", 262144, 4096, 4096), ("1-16 KiB mixed", 131072, 1024, 16384),
-                         ("256 B payloads", 1 << 21, 256, 256)):
+CASES = (("4 KiB payloads", 262144, 4096, 4096), ("1-16 KiB mixed", 131072, 1024, 16384),
+         ("256 B payloads", 1 << 21, 256, 256), ("40-320 B mixed", 1 << 21, 40, 320))
+ONLY = os.environ.get("WAL_CASES")                 # e.g. WAL_CASES="256 B,40-320": substrings of the labels to run
+for label, n, lo, hi in CASES:
+    if ONLY and not any(w.strip() in label for w in ONLY.split(",")):
+        continue
     rng = np.random.default_rng(1)
     lens = rng.integers(lo, hi + 1, size=n).astype(np.uint32)
     offs = 16 + np.concatenate([[0], np.cumsum(lens.astype(np.uint64))])[:-1]
