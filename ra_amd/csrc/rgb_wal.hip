@@ -133,314 +133,28 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_adler32_kern
 /* ---- record framing: checksum + header + payload copy in one pass (src/ra_log_wal.erl:513-537) ----
  *
  * A record is  HeaderData ++ <<Checksum:32, EntryDataLen:32, Idx:64, Term:64>> ++ Payload  at out + out_offset.
- * The payload is READ in 16-byte chunks aligned to the SOURCE (non-temporal, one aligned request per lane; the
- * checksum is taken on these chunks exactly as the checksum kernel does) and WRITTEN in 16-byte chunks aligned to
- * the DESTINATION: destination chunk c is the byte-wise funnel of source chunks c - qd - 1 and c - qd (the shift
- * is constant over the record), and the older of the two arrives from the neighbouring lane through DPP
- * (row_ror / wave_ror), so no byte is loaded twice and no load is misaligned -- a 16-byte load that straddles two
- * aligned granules cost the first version of this kernel 30 % of its rate (588 us vs 401 us per GiB of 4 KiB
- * payloads, same kernel, source and destination in phase).  Only the destination chunks that hold the payload's
- * first and last byte are partial (the rest of those 16 bytes is the prefix, or the neighbouring record, written by
- * another lane group in no particular order): they go as at most four aligned power-of-two stores each.  The 24
- * fixed bytes are two unaligned vector stores by the group's first lane once the checksum is known; HeaderData is
- * copied byte per lane (3 bytes for a known writer). */
-
-/* bytes [lo, hi) of a 16-byte chunk held in registers to its 16-byte aligned place `base`: aligned power-of-two
- * stores (1, 2, 4, 8 bytes going up to the first 8-byte boundary that fits, then 8, 4, 2, 1 coming down) */
-struct halves16 {
-  u64 lo, hi;
-  /* the 8 bytes from chunk byte q on (q and the store's size never straddle the halves).  By value: a lambda that
-   * captured the halves by reference made the compiler select between their ADDRESSES -- a scratch array, a pointer
-   * table in LDS and a flat load in front of every store */
-  __device__ __forceinline__ u64 operator()(u32 q) const { const u64 x = (q & 8u) ? hi : lo; return x >> (8u * (q & 7u)); }
-};
-__device__ __forceinline__ halves16 halves_of(const uint4 w) {
-  return halves16{(u64)w.x | ((u64)w.y << 32), (u64)w.z | ((u64)w.w << 32)};
-}
-/* bytes [lo, 16): the chunk that holds the payload's first byte.  From the top down -- 8, 4, 2, 1 bytes by the bits of
- * 16 - lo -- as a shift chain over one 64-bit word: no extraction at a variable offset (which the compiler once
- * turned into a scratch store of the chunk and loads at computed offsets) */
-__device__ __forceinline__ void store_head16(unsigned char *base, const uint4 w, u32 lo) {
-  const halves16 h = halves_of(w);
-  const u32 n = 16u - lo;                               /* 1..15 bytes */
-  u64 cur = h.hi;
-  u32 e = 16u;                                          /* the bytes still to store end here */
-  if (n & 8u) { *reinterpret_cast<u64 *>(base + 8) = h.hi; cur = h.lo; e = 8u; }
-  if (n & 4u) { *reinterpret_cast<u32 *>(base + e - 4u) = (u32)(cur >> 32); cur <<= 32; e -= 4u; }
-  if (n & 2u) { *reinterpret_cast<unsigned short *>(base + e - 2u) = (unsigned short)(cur >> 48); cur <<= 16; e -= 2u; }
-  if (n & 1u) { base[e - 1u] = (unsigned char)(cur >> 56); }
-}
-/* bytes [0, hi): the chunk that holds the payload's last byte.  From the bottom up, the same chain mirrored */
-__device__ __forceinline__ void store_tail16(unsigned char *base, const uint4 w, u32 hi) {
-  const halves16 h = halves_of(w);
-  u64 cur = h.lo;
-  u32 p = 0;
-  if (hi & 8u) { *reinterpret_cast<u64 *>(base) = h.lo; cur = h.hi; p = 8u; }
-  if (hi & 4u) { *reinterpret_cast<u32 *>(base + p) = (u32)cur; cur >>= 32; p += 4u; }
-  if (hi & 2u) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)cur; cur >>= 16; p += 2u; }
-  if (hi & 1u) { base[p] = (unsigned char)cur; }
-}
-/* bytes [lo, hi), both inside the chunk (a payload shorter than its chunk) */
-__device__ __forceinline__ void store_sub16(unsigned char *base, const uint4 w, u32 lo, u32 hi) {
-  const halves16 sub = halves_of(w);
-  u32 p = lo;
-  if ((p & 1u) && p + 1u <= hi) { base[p] = (unsigned char)sub(p); p += 1u; }
-  if ((p & 2u) && p + 2u <= hi) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
-  if ((p & 4u) && p + 4u <= hi) { *reinterpret_cast<u32 *>(base + p) = (u32)sub(p); p += 4u; }
-  if ((p & 8u) && p + 8u <= hi) { *reinterpret_cast<u64 *>(base + p) = sub(p); p += 8u; }
-  if (p + 8u <= hi) { *reinterpret_cast<u64 *>(base + p) = sub(p); p += 8u; }
-  if (p + 4u <= hi) { *reinterpret_cast<u32 *>(base + p) = (u32)sub(p); p += 4u; }
-  if (p + 2u <= hi) { *reinterpret_cast<unsigned short *>(base + p) = (unsigned short)sub(p); p += 2u; }
-  if (p + 1u <= hi) { base[p] = (unsigned char)sub(p); }
-}
-
-/* whole aligned chunk, written once and not read again by the device.  STREAM (one record per wavefront, KiB-sized
- * payloads): non-temporal.  Small records: a plain store -- every other 128-byte line of the output holds a record
- * boundary whose bytes (prefix, partial chunks) arrive from other instructions, and a line the non-temporal store
- * pushed out early is written to memory twice (256-byte payloads, same box: 396 -> 360 us per 2 M records; 4 KiB
- * payloads the other way round, 418 -> 441 us) */
-template <bool STREAM>
-__device__ __forceinline__ void store16_stream(unsigned char *p, const uint4 w) {
-  v4u t; t.x = w.x; t.y = w.y; t.z = w.z; t.w = w.w;
-#if defined(RGB_HOST_EMULATION)
-  *reinterpret_cast<v4u *>(p) = t;
-#else
-  if (STREAM) __builtin_nontemporal_store(t, reinterpret_cast<v4u *>(p));
-  else *reinterpret_cast<v4u *>(p) = t;
-#endif
-}
-
-/* lane L of a GROUP-lane group receives the value of lane (L - 1) mod GROUP of the same group */
-template <int GROUP>
-__device__ __forceinline__ u32 rot1(u32 v) {
-#ifdef RGB_HOST_EMULATION
-  const int t = (int)threadIdx.x;                       /* the emulation's __shfl takes the lane's number in the block */
-  return __shfl(v, (t & ~(GROUP - 1)) | ((t - 1) & (GROUP - 1)), 64);
-#elif defined(WAL_X_NODPP)
-  const int t = (int)(threadIdx.x & 63u);
-  return __shfl(v, (t & ~(GROUP - 1)) | ((t - 1) & (GROUP - 1)), 64);
-#else
-  static_assert(GROUP == 8 || GROUP == 16 || GROUP == 64, "a DPP row is 16 lanes, a wavefront 64");
-  /* 8-lane groups: right for every lane but the group's first (rot_last serves that one) */
-  if (GROUP <= 16) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
-  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
-#endif
-}
-template <int GROUP>
-__device__ __forceinline__ uint4 rot1(const uint4 v) {
-  return make_uint4(rot1<GROUP>(v.x), rot1<GROUP>(v.y), rot1<GROUP>(v.z), rot1<GROUP>(v.w));
-}
-/* the group's FIRST lane receives the value of the group's last lane (the other lanes: unspecified) */
-template <int GROUP>
-__device__ __forceinline__ u32 rot_last(u32 v) {
-#if defined(RGB_HOST_EMULATION) || defined(WAL_X_NODPP)
-  return rot1<GROUP>(v);
-#else
-  if (GROUP == 8) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x129 /* row_ror:9 */, 0xF, 0xF, false);
-  return rot1<GROUP>(v);
-#endif
-}
-template <int GROUP>
-__device__ __forceinline__ uint4 rot_last(const uint4 v) {
-  if (GROUP != 8) return rot1<GROUP>(v);
-  return make_uint4(rot_last<GROUP>(v.x), rot_last<GROUP>(v.y), rot_last<GROUP>(v.z), rot_last<GROUP>(v.w));
-}
-/* ({hi, lo} >> 8 sb) & 0xFFFFFFFF, sb = 0..3: v_alignbyte_b32 */
-__device__ __forceinline__ u32 alignbyte(u32 hi, u32 lo, u32 sb) {
-#ifdef RGB_HOST_EMULATION
-  return (u32)((((u64)hi << 32) | lo) >> (8u * (sb & 3u)));
-#else
-  return __builtin_amdgcn_alignbyte(hi, lo, sb);
-#endif
-}
-
-/* bytes [o, o + 16) of the 32 bytes p ++ c, o = 0..16 */
-template <bool UNIFORM>
-__device__ __forceinline__ uint4 window16(const uint4 p, const uint4 c, u32 o) {
-  const u32 q = o >> 2, sb = o & 3u;
-  if (UNIFORM) {
-    /* o is the same in every lane of the wavefront: the dword offset selects straight-line code */
-#ifndef RGB_HOST_EMULATION
-    const u32 qs = (u32)__builtin_amdgcn_readfirstlane((int)q);
-#else
-    const u32 qs = q;
-#endif
-    switch (qs) {
-      case 0: return make_uint4(alignbyte(p.y, p.x, sb), alignbyte(p.z, p.y, sb), alignbyte(p.w, p.z, sb), alignbyte(c.x, p.w, sb));
-      case 1: return make_uint4(alignbyte(p.z, p.y, sb), alignbyte(p.w, p.z, sb), alignbyte(c.x, p.w, sb), alignbyte(c.y, c.x, sb));
-      case 2: return make_uint4(alignbyte(p.w, p.z, sb), alignbyte(c.x, p.w, sb), alignbyte(c.y, c.x, sb), alignbyte(c.z, c.y, sb));
-      case 3: return make_uint4(alignbyte(c.x, p.w, sb), alignbyte(c.y, c.x, sb), alignbyte(c.z, c.y, sb), alignbyte(c.w, c.z, sb));
-      default: return c;                                  /* o = 16 */
-    }
-  }
-  /* per-lane offset: byte shift of every neighbouring dword pair, then a three-stage dword selector */
-  const u32 A0 = alignbyte(p.y, p.x, sb), A1 = alignbyte(p.z, p.y, sb), A2 = alignbyte(p.w, p.z, sb),
-            A3 = alignbyte(c.x, p.w, sb), A4 = alignbyte(c.y, c.x, sb), A5 = alignbyte(c.z, c.y, sb),
-            A6 = alignbyte(c.w, c.z, sb);
-  const bool q0 = (q & 1u) != 0, q1 = (q & 2u) != 0, q2 = (q & 4u) != 0;
-  const u32 B0 = q0 ? A1 : A0, B1 = q0 ? A2 : A1, B2 = q0 ? A3 : A2, B3 = q0 ? A4 : A3, B4 = q0 ? A5 : A4, B5 = q0 ? A6 : A5;
-  uint4 e;
-  e.x = q2 ? c.x : q1 ? B2 : B0; e.y = q2 ? c.y : q1 ? B3 : B1;
-  e.z = q2 ? c.z : q1 ? B4 : B2; e.w = q2 ? c.w : q1 ? B5 : B3;
-  return e;
-}
-
-/* destination chunk at stream position dpos (a multiple of 16) of the record whose payload sits at stream positions
- * [ps, pe) = f: a whole chunk is streamed, the chunks that hold the payload's first / last byte go as aligned
- * power-of-two stores.  Everything by value (see halves16). */
-template <bool STREAM>
-__device__ __forceinline__ void emit_chunk(unsigned char *rec_al, u32 ps, u32 pe, u32 dpos, const uint4 f) {
-  if (dpos + 16u > ps && dpos < pe) {                   /* the chunk holds payload bytes */
-    unsigned char *to = rec_al + dpos;
-    const bool head = dpos < ps, tail = dpos + 16u > pe;
-    if (!head && !tail) store16_stream<STREAM>(to, f);
-    else if (!head) store_tail16(to, f, pe - dpos);
-    else if (!tail) store_head16(to, f, ps - dpos);
-    else store_sub16(to, f, ps - dpos, pe - dpos);
-  }
-}
+ * GROUP lanes per record (8 up to a mean payload of 320 bytes, 16 up to 1 KiB, then a wavefront); lane j handles
+ * payload bytes [16 j, 16 j + 16) AS THEY LIE: one 16-byte load at the payload's own alignment (non-temporal), the
+ * checksum on exactly those bytes (the piece that starts p bytes into the payload weighs (len - p - 16) a + b, no
+ * masks), one 16-byte store at the destination's own alignment -- gfx950 global loads and stores take any byte
+ * alignment.  A payload that does not end on a piece boundary ends with the piece [len - 16, len), which overlaps its
+ * predecessor: the overlapped bytes are masked out of the sums (what is left weighs exactly b) and are stored twice
+ * with the same value.  Payloads under 16 bytes go byte by byte.  The 24 fixed bytes are two unaligned vector stores by
+ * the group's first lane once the checksum is known; HeaderData is copied byte per lane (3 bytes for a known writer).
+ *
+ * Rounds 1-3 framed through a FUNNEL (source-aligned loads, destination-aligned stores, the byte shift through DPP
+ * and v_alignbyte, partial chunks as power-of-two store chains) because a first version with misaligned loads was
+ * 30 % slower on 4 KiB payloads.  Measured again in round 4 with the funnel's instruction count out of the way
+ * (profiles/EXPERIMENTS.md): this form is 24 % faster on 256-byte payloads (the funnel was vector-issue bound: ~900
+ * instructions per eight records), 4 % faster on 4 KiB payloads and the same on 0.4-16 KiB mixes, at a third of the code. */
 
 /* mean payload up to which a batch is framed with eight lanes per record (then sixteen up to 1 KiB, then a wavefront) */
 #ifndef WAL_FRAME_EIGHT_MAX
 #define WAL_FRAME_EIGHT_MAX 320u
 #endif
+typedef v4u v4u_any __attribute__((aligned(1)));
 template <int GROUP>
 __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_kernel(
-    const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data,
-    unsigned char *__restrict__ out, u32 *__restrict__ sums_out, u32 flags) {
-  constexpr u32 PER_BLOCK = WAL_WAVES_PER_BLOCK * 64 / GROUP;
-  constexpr bool UNI = GROUP == 64;                     /* one record per wavefront: its shifts are wave-uniform */
-  constexpr int UNROLL = GROUP == 64 ? WAL_UNROLL : 2;  /* small records: 512 / 256 bytes per round and group */
-  const u32 lane = threadIdx.x & (GROUP - 1);
-  u32 e = blockIdx.x * PER_BLOCK + threadIdx.x / GROUP;
-#ifndef RGB_HOST_EMULATION
-  /* one record per wavefront: say so, and the descriptor and everything derived from it live in scalar registers */
-  if (UNI) e = (u32)__builtin_amdgcn_readfirstlane((int)e);
-#endif
-  const bool live = e < n;
-  rgb_wal_record r;
-  r.index = r.term = r.data_offset = r.hdr_offset = r.out_offset = 0; r.data_len = r.hdr_len = 0;
-  if (live) r = recs[e];
-  const u32 len = r.data_len;
-  const u32 prefix = r.hdr_len + 24u;                   /* HeaderData + Checksum, Len, Idx, Term */
-  unsigned char *rec = out + r.out_offset;
-  const u32 lr = (u32)((uintptr_t)rec & 15u);           /* record byte b sits at destination stream position lr + b */
-  unsigned char *rec_al = rec - lr;                     /* destination chunk c is rec_al[16 c .. 16 c + 16) */
-  const unsigned char *pay = data + r.data_offset;
-  const u32 ls = (u32)((uintptr_t)pay & 15u);           /* payload byte p sits at source stream position ls + p */
-  const v4u *src = reinterpret_cast<const v4u *>(pay - ls);
-  const u32 span = ls + len;
-  const u32 n_src = (live && len) ? (span + 15u) >> 4 : 0u;
-  const u32 span_q = span % ADLER_MOD;
-  const u32 ps = lr + prefix, pe = ps + len;            /* the payload at destination positions [ps, pe) */
-  const u32 delta = ps - ls;                            /* destination position = source position + delta (> 0) */
-  const u32 qd = delta >> 4, dm = delta & 15u;
-  /* funnel i = (source chunks i - 1, i) is destination chunk i + qd; one more than the source chunks when the last
-   * source chunk's tail spills into a further destination chunk */
-  const u32 n_fun = n_src ? n_src + (((n_src + qd) << 4) < pe ? 1u : 0u) : 0u;
-  /* HeaderData: one byte per lane, requested now so that it arrives under the payload loads */
-  const unsigned char *hdr = data + r.hdr_offset;
-  u32 hbyte = 0;
-  if (live && lane < r.hdr_len) hbyte = hdr[lane];
-  u32 a_acc = 0, b_acc = 0;
-  uint4 carry = make_uint4(0, 0, 0, 0);                 /* lane 0: the group's last lane's chunk of the previous round */
-  /* weight of the byte behind source chunk i, (span - 16 i - 16) mod 65521, kept per lane and stepped down by
-   * 16 GROUP per chunk instead of two divisions per chunk */
-  constexpr u32 STEP = (16u * GROUP) % ADLER_MOD;
-  u32 wq = (span_q + 2u * ADLER_MOD - ((lane << 4) % ADLER_MOD) - 16u) % ADLER_MOD;
-  for (u32 c0 = 0; c0 < n_fun; c0 += GROUP * UNROLL) {
-    uint4 v[UNROLL];
-#pragma unroll
-    for (int k = 0; k < UNROLL; ++k) {
-      const u32 i = c0 + (u32)k * GROUP + lane;
-      v[k] = make_uint4(0, 0, 0, 0);
-#ifdef WAL_X_NOREAD           /* EXPERIMENT (breaks the output): the write side alone */
-      if (i < n_src) v[k] = make_uint4(i, lane, e, len);
-#else
-      if (i < n_src) { const v4u t = __builtin_nontemporal_load(src + i); v[k] = make_uint4(t.x, t.y, t.z, t.w); }
-#endif
-    }
-#pragma unroll
-    for (int k = 0; k < UNROLL; ++k) {
-      if (c0 + (u32)k * GROUP >= n_fun) break;          /* the same for the whole group: a short last round is cheap */
-      const u32 i = c0 + (u32)k * GROUP + lane;
-      const u32 s = i << 4;
-      if (i < n_src) {
-        uint4 w = v[k];
-        if (s < ls || s + 16u > span) {                 /* bytes in front of the payload / behind it: zero */
-          w = keep_bytes(w, s < ls ? ls - s : 0u, span - s < 16u ? span - s : 16u);
-          v[k] = w;
-        }
-        u32 a, b;
-        chunk_sums(w, a, b);
-        a_acc += a;
-        b_acc += (wq * a + b) % ADLER_MOD;
-        if (b_acc >= 0x7FFF0000u) b_acc %= ADLER_MOD;
-        if (a_acc >= 0x7FFF0000u) a_acc %= ADLER_MOD;
-      }
-      wq = wq >= STEP ? wq - STEP : wq + (ADLER_MOD - STEP);
-    }
-#pragma unroll
-    for (int k = 0; k < UNROLL; ++k) {
-      if (c0 + (u32)k * GROUP >= n_fun) break;
-      const u32 i = c0 + (u32)k * GROUP + lane;
-      /* every lane of the group takes part in the exchange, whatever it loaded */
-      const uint4 rot = rot1<GROUP>(v[k]);
-      const uint4 prev = lane == 0u ? carry : rot;
-      carry = rot_last<GROUP>(v[k]);
-      const uint4 f = window16<UNI>(prev, v[k], 16u - dm);
-#ifdef WAL_X_NOWRITE          /* EXPERIMENT (breaks the output): the read + compute side alone */
-      if (i < n_fun && f.x == 0x12345678u && f.y == 0x9ABCDEF0u) emit_chunk<UNI>(rec_al, ps, pe, (i + qd) << 4, f);
-#else
-      if (i < n_fun) emit_chunk<UNI>(rec_al, ps, pe, (i + qd) << 4, f);
-#endif
-    }
-  }
-  const u32 a_sum = group_sum<GROUP>(a_acc % ADLER_MOD);
-  const u32 b_sum = group_sum<GROUP>(b_acc % ADLER_MOD);
-  if (!live) return;
-  const u32 ih = (u32)(r.index >> 32), il = (u32)r.index, th = (u32)(r.term >> 32), tl = (u32)r.term;
-  u32 pa = dot4(ih, 0x01010101u, 0); pa = dot4(il, 0x01010101u, pa);
-  pa = dot4(th, 0x01010101u, pa); pa = dot4(tl, 0x01010101u, pa);
-  u32 pb = dot4(ih, 0x100F0E0Du, 0); pb = dot4(il, 0x0C0B0A09u, pb);
-  pb = dot4(th, 0x08070605u, pb); pb = dot4(tl, 0x04030201u, pb);
-  const u32 len_q = len % ADLER_MOD;
-  const u32 A = (1u + pa + a_sum) % ADLER_MOD;
-  const u32 B = ((16u + len_q) + (len_q * pa + pb) % ADLER_MOD + b_sum) % ADLER_MOD;
-  const u32 cs = (flags & RGB_WAL_NO_CHECKSUMS) ? 0u : ((B << 16) | A);
-  /* HeaderData verbatim (a known writer's is 3 bytes, a new writer's carries its uid) */
-  if (lane < r.hdr_len) rec[lane] = (unsigned char)hbyte;
-  for (u32 j = GROUP + lane; j < r.hdr_len; j += GROUP) rec[j] = hdr[j];
-  if (lane == 0u) {
-    if (sums_out) sums_out[e] = cs;
-    /* <<Checksum:32, EntryDataLen:32, Idx:64, Term:64>> big endian: 16 + 8 bytes at any alignment (gfx950 global
-     * stores take any alignment) */
-    struct __attribute__((packed)) fixed24 { v4u a; u64 b; };
-    fixed24 fx;
-    fx.a.x = __builtin_bswap32(cs); fx.a.y = __builtin_bswap32(len);
-    fx.a.z = __builtin_bswap32(ih); fx.a.w = __builtin_bswap32(il);
-    fx.b = (u64)__builtin_bswap32(th) | ((u64)__builtin_bswap32(tl) << 32);
-    __builtin_memcpy(rec + r.hdr_len, &fx, 24);
-  }
-}
-
-/* ---- small records, the DIRECT form (WAL_X_DIRECT): no funnel ----
- * Eight lanes per record; lane j handles payload bytes [16 j, 16 j + 16) as they lie: one 16-byte load at the
- * payload's own alignment, the checksum on exactly those bytes (the piece that starts p bytes into the payload weighs
- * (len - p - 16) a + b, no masks), one 16-byte store at the destination's own alignment -- gfx950 global loads and
- * stores take any byte alignment.  A payload that does not end on a piece boundary ends with the piece
- * [len - 16, len), which overlaps its predecessor: the overlapped bytes are masked out of the sums (what is left
- * weighs exactly b) and stored twice with the same value.  Payloads under 16 bytes go byte by byte.  Against the
- * funnel form this trades requests that straddle a 64-byte boundary (one lane in four, both directions) for ~3/4 of
- * the vector instructions: no rotation, no window, no partial-store chains. */
-typedef v4u v4u_any __attribute__((aligned(1)));
-#ifndef WAL_X_DIRECT
-#define WAL_X_DIRECT 1      /* lane groups that frame in the direct form: 1 = eight lanes per record (mean payload <= 320 B:
-                               0.55 against 0.42-0.44 of the roofline on 256-byte payloads, same box), 2 = sixteen too,
-                               3 = every size; 0 = the funnel form everywhere */
-#endif
-template <int GROUP>
-__global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_direct_kernel(
     const rgb_wal_record *__restrict__ recs, u32 n, const unsigned char *__restrict__ data,
     unsigned char *__restrict__ out, u32 *__restrict__ sums_out, u32 flags) {
   constexpr u32 PER_BLOCK = WAL_WAVES_PER_BLOCK * 64 / GROUP;
@@ -487,7 +201,9 @@ __global__ __launch_bounds__(WAL_WAVES_PER_BLOCK * 64) void rgb_wal_frame_direct
 #if defined(RGB_HOST_EMULATION)
         *reinterpret_cast<v4u_any *>(dst + ((size_t)j << 4)) = t;
 #else
-        /* streamed past the caches for a record per wavefront, plain for the small-record groups (see store16_stream) */
+        /* streamed past the caches for a record per wavefront.  Small records: a plain store -- every other 128-byte
+         * line of the output holds a record boundary whose bytes arrive from other instructions, and a line a
+         * non-temporal store pushed out early is written to memory twice (round 3: 396 -> 360 us per 2 M records) */
         if (UNI) __builtin_nontemporal_store(t, reinterpret_cast<v4u_any *>(dst + ((size_t)j << 4)));
         else *reinterpret_cast<v4u_any *>(dst + ((size_t)j << 4)) = t;
 #endif
@@ -580,39 +296,16 @@ extern "C" int rgb_wal_frame_device(rgb_ctx *ctx, const void *d_records, uint32_
   if (out_bytes < 27ull * n) return RGB_E_INVAL;       /* the shortest record is 3 + 24 bytes */
   hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)rgb_ctx_stream(ctx);
   (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
-  if (data_bytes / n <= WAL_FRAME_EIGHT_MAX) {
-    /* the smallest payloads: eight lanes per record, eight records per wavefront (the per-record work that does not
-     * shrink with the payload -- descriptor, reduction, prefix -- is paid per WAVEFRONT instruction) */
-    const u32 per = WAL_WAVES_PER_BLOCK * 64 / 8;
-    if (WAL_X_DIRECT >= 1)
-      hipLaunchKernelGGL(rgb_wal_frame_direct_kernel<8>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
-    else
-      hipLaunchKernelGGL(rgb_wal_frame_kernel<8>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
-  } else if (data_bytes / n < 1024u) {
-    const u32 per = WAL_WAVES_PER_BLOCK * 64 / 16;
-    if (WAL_X_DIRECT >= 2)
-      hipLaunchKernelGGL(rgb_wal_frame_direct_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
-    else
-      hipLaunchKernelGGL(rgb_wal_frame_kernel<16>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
-  } else {
-    const u32 per = WAL_WAVES_PER_BLOCK;
-    if (WAL_X_DIRECT >= 3)
-      hipLaunchKernelGGL(rgb_wal_frame_direct_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
-    else
-      hipLaunchKernelGGL(rgb_wal_frame_kernel<64>, dim3((n + per - 1) / per), dim3(WAL_WAVES_PER_BLOCK * 64), 0, st,
-                         (const rgb_wal_record *)d_records, n, (const unsigned char *)d_data,
-                         (unsigned char *)d_out, (u32 *)d_checksums, flags);
-  }
+  /* lanes per record by the batch's mean payload: the per-record work that does not shrink with the payload --
+   * descriptor, reduction, prefix -- is paid per WAVEFRONT instruction */
+#define WAL_LAUNCH_FRAME(G)                                                                                          \
+  hipLaunchKernelGGL(rgb_wal_frame_kernel<G>, dim3((n + (WAL_WAVES_PER_BLOCK * 64 / G) - 1) / (WAL_WAVES_PER_BLOCK * 64 / G)), \
+                     dim3(WAL_WAVES_PER_BLOCK * 64), 0, st, (const rgb_wal_record *)d_records, n,                   \
+                     (const unsigned char *)d_data, (unsigned char *)d_out, (u32 *)d_checksums, flags)
+  if (data_bytes / n <= WAL_FRAME_EIGHT_MAX) WAL_LAUNCH_FRAME(8);
+  else if (data_bytes / n < 1024u) WAL_LAUNCH_FRAME(16);
+  else WAL_LAUNCH_FRAME(64);
+#undef WAL_LAUNCH_FRAME
   return hipGetLastError() == hipSuccess ? RGB_OK : RGB_E_HIP;
 }
 

@@ -52,7 +52,11 @@ def test_wal_down_host_recipe_through_the_c_abi(emulated_engine, oracle_lib):
 
 def test_wal_down_conditions_through_the_c_abi(emulated_engine, oracle_lib):
     for n, seed in ((3, 71), (5, 72), (7, 73), (1, 74)):
-        G.test_wal_down_conditions_follower_and_leader_match_oracle(emulated_engine, oracle_lib, n, seed)
+        G.test_wal_down_conditions_follower_and_leader_match_oracle(emulated_engine, oracle_lib, n, seed, groups=96, ticks=4)
+    # >= 4096 messages per round: the class-dispatch kernel; then the rounds of one batch as ONE train launch
+    G.test_wal_down_conditions_follower_and_leader_match_oracle(emulated_engine, oracle_lib, 5, 75, groups=1400, ticks=1)
+    G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, 6, G=1200, N=5, batches=1,
+                                                       wal_down_share=0.25)
     G.test_leader_wal_down_host_recipe(emulated_engine, oracle_lib)
 
 

@@ -106,7 +106,8 @@ def test_same_server_messages_are_serialised_in_submission_order(engine_mod, ora
 
 
 @pytest.mark.parametrize("table_runs", [6, 16], ids=["shallow_run_tables", "deep_run_tables"])
-def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, table_runs, G=1500, N=5, batches=3):
+def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, table_runs, G=1500, N=5, batches=3,
+                                                      wal_down_share=0.0):
     """The normal shape of a real batch: a leader's N-1 replies arrive together, so does a follower's append and its
     written event -- four messages per leader, two or three per follower in ONE rgb_submit.  Rounds 2..16 of a big
     batch run as one train launch (rgb_submit_trains counts them); the result is the sequential checker's."""
@@ -114,6 +115,13 @@ def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, tab
     # deep tables (up to 13 in-memory runs): a leader-side train wavefront serves runs 0..7 from LDS and the rest from
     # memory (run_pair in rgb_kernels.hip) -- both sides of that border are walked
     st = fuzz.random_states(rng, G, N, max_runs=table_runs, backlog=24 if table_runs <= 8 else 60)
+    rng2 = np.random.default_rng(4242 + table_runs)
+    if wal_down_share:
+        # a share of the servers waits in one of the two wal_down conditions (the follower's, the leader's): inside a
+        # train their messages are dropped, or -- with RGB_MF_CAN_WRITE -- re-processed by the role they return to
+        pick = rng2.random(G * N) < wal_down_share
+        st["role"][pick] = abi.ROLE_AWAIT_CONDITION
+        st["cond_reason"][pick] = rng2.choice([abi.COND_WAL_DOWN, abi.COND_WAL_DOWN_LEADER], size=int(pick.sum()))
     cpu = oracle_lib.Oracle(G, N, max_runs=16)              # the device's bound: deep tables overflow it now and then
     cpu.set_state(0, st)
     with engine_mod.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16) as gpu:
@@ -124,6 +132,10 @@ def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, tab
             msgs = np.concatenate(parts)
             msgs = msgs[msgs["kind"] != abi.MSG_NOP]
             rng.shuffle(msgs)
+            if wal_down_share:
+                msgs["flags"] |= np.where(rng2.random(len(msgs)) < 0.5, abi.MF_CAN_WRITE, 0).astype(msgs["flags"].dtype)
+                waiting = cpu.get_state()["role"][msgs["server"]] == abi.ROLE_AWAIT_CONDITION
+                msgs["kind"][waiting & (rng2.random(len(msgs)) < 0.2)] = abi.MSG_AWAIT_TIMEOUT
             assert len(msgs) >= 4096
             do, ro = cpu.step(msgs)
             dg, rg = gpu.step(msgs)
@@ -134,6 +146,13 @@ def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, tab
         small = fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.2)
         do, ro = cpu.step(small); dg, rg = gpu.step(small)
         assert_same("small batch (one launch per round)", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+
+
+def test_wal_down_conditions_inside_a_train(engine_mod, oracle_lib):
+    """A quarter of the servers waits in one of the two wal_down conditions while the rounds of a batch run as one
+    train launch: dropped messages, re-processing by handle_follower/2 and by handle_leader/2 (and from there once more
+    by handle_follower/2), the leader's timeout effect -- per-server order by the sequence bytes."""
+    test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, 6, G=1500, N=5, batches=2, wal_down_share=0.25)
 
 
 def wal_down_reupload(before: np.ndarray, dec: np.ndarray) -> np.ndarray:
@@ -194,8 +213,9 @@ def test_wal_down_host_recipe_keeps_last_applied_and_the_log(engine_mod, oracle_
     cpu.close()
 
 
-@pytest.mark.parametrize("n_members,seed", [(3, 71), (5, 72), (7, 73), (1, 74)])
-def test_wal_down_conditions_follower_and_leader_match_oracle(engine_mod, oracle_lib, n_members, seed, groups=160, ticks=5):
+@pytest.mark.parametrize("n_members,seed,groups,ticks", [(3, 71, 160, 5), (5, 72, 160, 5), (7, 73, 160, 5), (1, 74, 160, 5),
+                                                         (5, 75, 1400, 2)])
+def test_wal_down_conditions_follower_and_leader_match_oracle(engine_mod, oracle_lib, n_members, seed, groups, ticks):
     """await_condition with wal_down_condition/2 in both forms: the follower's (src/ra_server.erl:1377-1385: back to
     follower, no timeout effects) and the leader's (:660-668: transition_to => leader, the timeout hands out
     {transfer_leadership, Peer} while the log still cannot be written).  A third of the servers start in one of the
@@ -212,6 +232,7 @@ def test_wal_down_conditions_follower_and_leader_match_oracle(engine_mod, oracle
     seen_transfer = seen_leader_reprocess = 0
     with engine_mod.RaGpuBatch(G, N, ring_capacity=4096, ring_slots=2, max_runs=16) as gpu:
         gpu.set_state(0, st)
+        # (5, 75, 1400, 2): >= 4096 messages per round, rgb_submit takes the class-dispatch kernel
         assert gpu.get_state().tobytes() == cpu.get_state().tobytes()      # cond_reason 4 survives the packed word
         assert gpu.state_checksum() == engine_mod.combine_checksums(oracle_lib.server_checksums(cpu.get_state()))
         for t in range(ticks):

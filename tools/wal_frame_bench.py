@@ -25,7 +25,8 @@ if os.environ.get("WAL_MEMCPY") == "1":
     print(json.dumps({"calibration": "torch copy_ of 1 GiB (read + write)", "us": us, "GBps_read_plus_write": 2 * (1 << 30) / (us * 1e-6) / 1e9}))
     del a, b
 CASES = (("4 KiB payloads", 262144, 4096, 4096), ("1-16 KiB mixed", 131072, 1024, 16384),
-         ("256 B payloads", 1 << 21, 256, 256), ("40-320 B mixed", 1 << 21, 40, 320))
+         ("256 B payloads", 1 << 21, 256, 256), ("40-320 B mixed", 1 << 21, 40, 320),
+         ("400-1000 B mixed", 1 << 20, 400, 1000))
 ONLY = os.environ.get("WAL_CASES")                 # e.g. WAL_CASES="256 B,40-320": substrings of the labels to run
 for label, n, lo, hi in CASES:
     if ONLY and not any(w.strip() in label for w in ONLY.split(",")):
