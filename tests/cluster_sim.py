@@ -22,7 +22,10 @@ gen_statem would route the reference's effects:
 The network between members drops and delays, and reorders between different senders (never between
 the same two members, never duplicating: Erlang distribution); local events (WAL, next_event) are
 reliable and ordered.  Timers (election_timeout, await_condition_timeout) and client commands
-fire at random.  With p_snapshot > 0 members also take snapshots (SNAPSHOT_WRITTEN truncates their logs) and a
+fire at random.  With p_wal_down > 0 a member's WAL goes down for a few ticks now and then: a follower's
+ra_log:write/2 then answers {error, wal_down} and a leader's ra_log:append/2 raises wal_down -- host I/O, so the host
+recipes of INTEGRATION.md put the server into await_condition (RGB_COND_WAL_DOWN / RGB_COND_WAL_DOWN_LEADER) and
+RGB_MF_CAN_WRITE says when ra_log:can_write/1 is true again.  With p_snapshot > 0 members also take snapshots (SNAPSHOT_WRITTEN truncates their logs) and a
 leader whose peer fell behind its snapshot sends it: that transfer is ra_server's business, emulated
 here on the rows and written back with set_state.  The Raft safety properties are checked on what the
 logs still hold after every tick (check_safety)."""
@@ -37,7 +40,8 @@ from ra_amd import abi, effects
 
 class ClusterSim:
     def __init__(self, eng, n_groups, n_members, seed, drop=0.1, max_delay=3,
-                 p_election=0.02, p_command=0.3, p_query=0.05, p_tick=0.3, max_leaders=9, p_snapshot=0.0):
+                 p_election=0.02, p_command=0.3, p_query=0.05, p_tick=0.3, max_leaders=9, p_snapshot=0.0,
+                 p_wal_down=0.0):
         self.eng, self.G, self.N = eng, n_groups, n_members
         self.S = n_groups * n_members
         self.rng = np.random.default_rng(seed)
@@ -45,6 +49,9 @@ class ClusterSim:
         self.p_election, self.p_command, self.p_query, self.p_tick = p_election, p_command, p_query, p_tick
         self.max_leaders = max_leaders
         self.p_snapshot = p_snapshot                     # > 0: members take snapshots at last_applied
+        self.p_wal_down = p_wal_down                     # > 0: per member and tick, its WAL goes down for 2..7 ticks
+        self.wal_injection = p_wal_down > 0              # (stays set after heal(): RGB_MF_CAN_WRITE keeps being passed)
+        self.wal_up_at = np.zeros(self.S, dtype=np.int64)   # first tick at which ra_log:can_write/1 is true again
         self.host = []                                   # host-level snapshot transfers: (deliver_at, what, args)
         self.tick = 0
         self.net = [[] for _ in range(self.S)]          # [(deliver_at, msg)]
@@ -55,7 +62,8 @@ class ClusterSim:
         self.committed = [dict() for _ in range(n_groups)]         # index -> term, once any member committed it
         self.elections = np.zeros(n_groups, dtype=np.int64)
         self.stats = {"msgs": 0, "dropped": 0, "invariants": 0, "commands": 0, "queries_answered": 0,
-                      "snapshots": 0, "installs": 0, "install_refused": 0}
+                      "snapshots": 0, "installs": 0, "install_refused": 0,
+                      "wal_down_follower": 0, "wal_down_leader": 0, "transfer_leadership": 0, "wal_down_reprocessed": 0}
         self.history = []                                # the batches fed to the engine, for replay
         self.leader_contact = np.full(self.S, -10**9, dtype=np.int64)   # tick of the last {record_leader_msg, _}
         self.election_silence = 0                        # ticks without a leader message before a timeout may fire
@@ -78,6 +86,7 @@ class ClusterSim:
         """A reliable network from now on, and election timers that behave: they only fire after a
         silence from the leader (liveness checks)."""
         self.drop = 0.0
+        self.p_wal_down = 0.0
         self.election_silence = 40
 
     def idle(self):
@@ -138,12 +147,19 @@ class ClusterSim:
 
     def step(self):
         self.run_host_events()
+        if self.p_wal_down:
+            hit = (self.rng.random(self.S) < self.p_wal_down) & (self.wal_up_at <= self.tick)
+            self.wal_up_at[hit] = self.tick + 2 + self.rng.integers(0, 6, size=int(hit.sum()))
         batch = [m for m in (self.choose(s) for s in range(self.S)) if m is not None]
+        self.now = self.tick                             # the tick these messages are processed in
         self.tick += 1
         if not batch:
             self.flush_wals()
             return None
         msgs = np.array(batch, dtype=abi.MSG_DTYPE)
+        # ra_log:can_write/1 as the owning process sees it when it hands the message over (wal_down_condition/2)
+        if self.wal_injection:
+            msgs["flags"] |= np.where(self.wal_up_at[msgs["server"]] <= self.now, abi.MF_CAN_WRITE, 0).astype(msgs["flags"].dtype)
         before = self.state
         dec, rpcs = self.eng.step(msgs)
         self.state = after = self.eng.get_state()
@@ -163,6 +179,37 @@ class ClusterSim:
         fl = int(d["flags"]); kind = int(m["kind"])
         if fl & abi.F_LEADER_MSG:
             self.leader_contact[s] = self.tick
+        if fl & abi.F_TRANSFER_LEADERSHIP:
+            # {next_event, cast, {transfer_leadership, Peer}}: ra_server's own clause (not on the batched path); a
+            # leader that declines the hint simply goes on leading, which is what happens here
+            self.stats["transfer_leadership"] += 1
+        if int(st0["role"]) == abi.ROLE_AWAIT_CONDITION and int(st0["cond_reason"]) in (abi.COND_WAL_DOWN, abi.COND_WAL_DOWN_LEADER) \
+                and fl & abi.F_REPROCESSED:
+            self.stats["wal_down_reprocessed"] += 1
+        if self.wal_up_at[s] > self.now and not fl & (abi.F_INVARIANT | abi.F_UNHANDLED):
+            if fl & abi.F_WROTE:
+                # follower: ra_log:write/2 -> {error, wal_down} (src/ra_server.erl:1377-1385): State1 (term, leader_id,
+                # commit_index := LeaderCommit) with the log as it was, Effects0 = [{record_leader_msg, _}] only
+                row = st0.copy()
+                for k in ("current_term", "voted_for", "leader_id"):
+                    row[k] = st1[k]
+                row["commit_index"] = m["c"]
+                row["role"] = abi.ROLE_AWAIT_CONDITION
+                row["cond_reason"] = abi.COND_WAL_DOWN
+                self.edit(s, row)
+                self.stats["wal_down_follower"] += 1
+                return
+            if kind == abi.MSG_APPEND and int(st0["role"]) == abi.ROLE_LEADER and \
+                    int(st1["last_index"]) > int(st0["last_index"]):
+                # leader: ra_log:append/2 raised wal_down (:655-672): the state as it was, nothing pipelined, the
+                # command answered with an error (a new leader's noop is simply lost: nothing commits in its term
+                # until the next command)
+                row = st0.copy()
+                row["role"] = abi.ROLE_AWAIT_CONDITION
+                row["cond_reason"] = abi.COND_WAL_DOWN_LEADER
+                self.edit(s, row)
+                self.stats["wal_down_leader"] += 1
+                return
         peer = lambda slot: g * self.N + int(slot)
         for e in effects.decode(m, d, rpcs, st1, self.N):
             tag = e if isinstance(e, str) else e[0]

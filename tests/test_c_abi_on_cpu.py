@@ -80,3 +80,4 @@ def test_closed_loop_stream_through_the_c_abi(emulated_engine, oracle_lib):
     import test_cluster_safety as CS
     # the GPU test builds its own engine from ra_amd.engine, which is bound to the emulated library here
     CS.test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, 5, 14, True)
+    CS.test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, 5, 15, "wal_down")   # WAL outages: both conditions

@@ -103,8 +103,32 @@ def test_closed_loop_clusters_with_snapshots(oracle_lib, n_members, seed):
     assert int(sim.elections.max()) > 9
 
 
+WAL_DOWN_KW = dict(p_wal_down=0.01, max_leaders=12)
+
+
+@pytest.mark.parametrize("n_members,seed", [(3, 41), (5, 42), (1, 43)])
+def test_closed_loop_clusters_with_wal_outages(oracle_lib, n_members, seed):
+    """The same, with every member's WAL going down for a few ticks now and then: followers whose write is refused and
+    leaders whose append raises wal_down wait in await_condition (the host recipes of INTEGRATION.md, the two
+    wal_down_condition/2 forms of src/ra_server.erl:660-668 and 1377-1385), drop what arrives meanwhile, come back through
+    the condition's transition_to with the message re-processed, or through the timeout (the leader's with the
+    transfer_leadership effect).  Safety on the full logs after every tick, convergence once the WALs stay up."""
+    G = 6
+    cpu = oracle_lib.Oracle(G, n_members)
+    cpu.set_state(0, abi.empty_server_states(G, n_members))
+    sim = run_lossy_then_heal(cpu, G, n_members, seed, lossy_ticks=900, heal_ticks=400, **WAL_DOWN_KW)
+    check_converged(sim, G, n_members)
+    assert sim.stats["wal_down_leader"] > 0, sim.stats
+    if n_members > 1:
+        assert sim.stats["wal_down_follower"] > 0 and sim.stats["transfer_leadership"] > 0, sim.stats
+        assert sim.stats["wal_down_reprocessed"] > 0, sim.stats
+    else:
+        assert sim.stats["transfer_leadership"] == 0     # no peer to hand over to (src/ra_server.erl:661-662)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_members,seed,snapshots", [(3, 11, False), (5, 12, False), (7, 13, False), (5, 14, True)])
+@pytest.mark.parametrize("n_members,seed,snapshots", [(3, 11, False), (5, 12, False), (7, 13, False), (5, 14, True),
+                                                      (5, 15, "wal_down")])
 def test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, n_members, seed, snapshots):
     """The streams a live cluster produces (elections, repairs after drops, overwrites by new leaders,
     stale rpcs) replayed through the HIP engine: decisions, rpcs and states bit-identical
@@ -118,7 +142,7 @@ def test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, n_memb
     cpu = oracle_lib.Oracle(G, n_members)
     st0 = abi.empty_server_states(G, n_members)
     cpu.set_state(0, st0)
-    kw = dict(p_snapshot=0.03, max_leaders=11, drop=0.15) if snapshots else {}
+    kw = dict(p_snapshot=0.03, max_leaders=11, drop=0.15) if snapshots is True else WAL_DOWN_KW if snapshots else {}
     sim = run_lossy_then_heal(cpu, G, n_members, seed, lossy_ticks=250, heal_ticks=150, **kw)
     ref = oracle_lib.Oracle(G, n_members)
     ref.set_state(0, st0)
@@ -137,5 +161,7 @@ def test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, n_memb
             seen |= int(np.bitwise_or.reduce(do["flags"]))
     for f in (abi.F_REPLY, abi.F_WROTE, abi.F_BECAME_LEADER, abi.F_SEND_VOTE_REQUESTS, abi.F_PIPELINE, abi.F_APPLIED):
         assert seen & f, hex(f)
-    if snapshots:
+    if snapshots is True:
         assert seen & abi.F_SEND_SNAPSHOT
+    if snapshots == "wal_down":
+        assert seen & abi.F_TRANSFER_LEADERSHIP and sim.stats["wal_down_follower"] > 0 and sim.stats["wal_down_leader"] > 0
