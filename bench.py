@@ -31,6 +31,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise);
+# must be in the environment before the HIP runtime loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 SNAPSHOT_EVERY = 16
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
