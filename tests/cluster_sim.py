@@ -379,6 +379,14 @@ class ClusterSim:
                 # commit_index may step back below last_applied under a new leader; both bound what is known
                 # committed)
                 ci = max(int(r["commit_index"]), int(r["last_applied"]))
+                if self.wal_injection:
+                    # a refused write leaves the follower with commit_index := LeaderCommit over a log that still
+                    # holds its stale suffix (src/ra_server.erl:1377-1385 keeps State1 with log => Log1) until the
+                    # leader's resend overwrites it.  Harmless in the reference -- a follower only evaluates its
+                    # commit index inside an append_entries_rpc clause that has validated or overwritten the suffix
+                    # (:1331-1376, 2246-2259; written events do not, :1457-1474) -- so with WAL outages only what is
+                    # APPLIED counts as known committed here
+                    ci = int(r["last_applied"])
                 assert int(r["last_applied"]) <= int(r["last_index"])
                 for i in range(max(1, int(r["first_index"])), min(ci, int(r["last_index"])) + 1):
                     t = logs[slot][i]

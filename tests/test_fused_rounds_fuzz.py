@@ -13,21 +13,25 @@ from ra_amd import abi
 from test_gpu_parity import assert_same
 
 
-def _seeds():
-    spec = os.environ.get("RGB_FUZZ_SEEDS")
+def _seeds(var="RGB_FUZZ_SEEDS", default=(300, 301, 302, 307)):
+    spec = os.environ.get(var)
     if spec:
         lo, hi = (int(x) for x in spec.split(":"))
         return list(range(lo, hi))
-    return [300, 301, 302, 307]
+    return list(default)
 
 
-@pytest.mark.parametrize("seed", _seeds())
-def test_fused_rounds_equal_the_sequential_checker(emulated_engine, oracle_lib, seed):
+def _fused_rounds(emulated_engine, oracle_lib, seed, wal_down):
     N = (5, 3, 7, 5)[seed % 4]
     G = {3: 1800, 5: 1100, 7: 800}[N]
     rng = np.random.default_rng(seed)
     deep = (seed // 4) % 2 == 1
     st = fuzz.random_states(rng, G, N, max_runs=16 if deep else 6, backlog=60 if deep else 24)
+    if wal_down:
+        # a fifth of the servers waits in one of the two wal_down conditions (src/ra_server.erl:660-668, 1377-1385)
+        pick = rng.random(G * N) < 0.2
+        st["role"][pick] = abi.ROLE_AWAIT_CONDITION
+        st["cond_reason"][pick] = rng.choice([abi.COND_WAL_DOWN, abi.COND_WAL_DOWN_LEADER], size=int(pick.sum()))
     cpu = oracle_lib.Oracle(G, N, max_runs=16)
     cpu.set_state(0, st)
     with emulated_engine.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16) as gpu:
@@ -37,7 +41,23 @@ def test_fused_rounds_equal_the_sequential_checker(emulated_engine, oracle_lib, 
             msgs = np.concatenate(parts)
             msgs = msgs[msgs["kind"] != abi.MSG_NOP]
             rng.shuffle(msgs)
+            if wal_down:
+                msgs["flags"] |= np.where(rng.random(len(msgs)) < 0.5, abi.MF_CAN_WRITE, 0).astype(msgs["flags"].dtype)
+                waiting = cpu.get_state()["role"][msgs["server"]] == abi.ROLE_AWAIT_CONDITION
+                msgs["kind"][waiting & (rng.random(len(msgs)) < 0.2)] = abi.MSG_AWAIT_TIMEOUT
             do, ro = cpu.step(msgs)
             dg, rg = gpu.step(msgs)
             assert_same(f"seed {seed} batch {b}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
         assert gpu.submit_trains() >= 1
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_fused_rounds_equal_the_sequential_checker(emulated_engine, oracle_lib, seed):
+    _fused_rounds(emulated_engine, oracle_lib, seed, False)
+
+
+@pytest.mark.parametrize("seed", _seeds("RGB_FUZZ_WAL_SEEDS", [500, 503]))
+def test_fused_rounds_with_servers_in_the_wal_down_conditions(emulated_engine, oracle_lib, seed):
+    """The same with servers waiting in the follower's and the leader's wal_down condition, messages with and without
+    RGB_MF_CAN_WRITE and await_condition timeouts (round 4 ran RGB_FUZZ_WAL_SEEDS=500:580 clean)."""
+    _fused_rounds(emulated_engine, oracle_lib, seed, True)
