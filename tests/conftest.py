@@ -30,18 +30,17 @@ def emulated_kernels_so(tmp_path_factory):
     clang = shutil.which("clang++", path="/opt/rocm/lib/llvm/bin") or shutil.which("clang++")
     if clang is None:
         pytest.skip("no clang++ (the emulation build needs __builtin_nontemporal_*)")
-    out = tmp_path_factory.mktemp("emu") / "libkernels_on_cpu.so"
+    tmp = tmp_path_factory.mktemp("emu")
+    out = tmp / "libkernels_on_cpu.so"
     nat = os.path.join(ROOT, "tests", "native")
-    cmd = [clang, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wl,-Bsymbolic", "-DRGB_EMU_FULL_API",
-           "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-function", "-Wno-unused-variable",
-           "-I", os.path.join(nat, "fake_hip"), "-I", os.path.join(ROOT, "include"), "-o", str(out),
-           os.path.join(nat, "api_on_cpu.cpp"), os.path.join(nat, "kernel_on_cpu.cpp"),
-           os.path.join(nat, "wal_on_cpu.cpp"), os.path.join(nat, "comm_on_cpu.cpp")]
+    flags = ["-std=c++17", "-O1", "-fPIC", "-DRGB_EMU_FULL_API",
+             "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-function", "-Wno-unused-variable",
+             "-I", os.path.join(nat, "fake_hip"), "-I", os.path.join(ROOT, "include")]
     # opt-in: compile-time experiment switches of the kernels (tools/build_variants.sh) through the emulation,
     # e.g. RGB_EMU_CXXFLAGS="-DRGB_X_COOPWB=2 -DRGB_X_RPC16=2"
     extra = os.environ.get("RGB_EMU_CXXFLAGS")
     if extra:
-        cmd[1:1] = extra.split()
+        flags = extra.split() + flags
     san = os.environ.get("RGB_EMU_SANITIZE")
     if san:
         # opt-in: a sanitizer over the emulated device code (every global / LDS index the kernels form, every
@@ -50,9 +49,25 @@ def emulated_kernels_so(tmp_path_factory):
         #       ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 pytest tests/test_*_on_cpu.py
         #   RGB_EMU_SANITIZE=undefined LD_PRELOAD=<clang lib dir>/libclang_rt.ubsan_standalone-x86_64.so \
         #       UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 pytest tests/test_*_on_cpu.py
-        cmd[1:1] = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-shared-libsan", "-g"]
+        flags = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-shared-libsan", "-g"] + flags
         if san == "undefined":
-            cmd[1:1] = ["-fno-sanitize-recover=undefined"]
+            flags = ["-fno-sanitize-recover=undefined"] + flags
+    # rgb_kernels.hip instantiates every kernel for eight group sizes: as ONE unit that is three minutes of compile
+    # time, so kernel_on_cpu.cpp is compiled once per group size, all units at once (every external name suffixed by
+    # tests/native/emu_rename.h), beside kernel_dispatch_on_cpu.cpp which owns the plain names
+    units = [("api", "api_on_cpu.cpp", []), ("wal", "wal_on_cpu.cpp", []), ("comm", "comm_on_cpu.cpp", []),
+             ("dispatch", "kernel_dispatch_on_cpu.cpp", [])]
+    units += [("kernel_N%d" % n, "kernel_on_cpu.cpp", ["-DRGB_EMU_ONLY_N=%d" % n]) for n in range(1, 9)]
+    procs = [(name, subprocess.Popen([clang, "-x", "c++", "-c"] + flags + more +
+                                     ["-o", str(tmp / (name + ".o")), os.path.join(nat, src)],
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+             for name, src, more in units]
+    for name, p in procs:
+        err = p.communicate()[1]
+        assert p.returncode == 0, name + ": " + err[-3000:]
+    cmd = [clang, "-shared", "-Wl,-Bsymbolic", "-o", str(out)] + [str(tmp / (name + ".o")) for name, _, _ in units]
+    if san:
+        cmd[1:1] = ["-fsanitize=" + san, "-shared-libsan"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return str(out)

@@ -10,86 +10,18 @@
  * execute as on one workgroup.  What the CPU cannot show is timing, occupancy and cross-workgroup races.
  */
 #define RGB_HOST_EMULATION 1
+/* Split build (tests/conftest.py): this unit is compiled once per group size with -DRGB_EMU_ONLY_N=<n> -- only that N
+ * is instantiated and every external name carries the suffix __N<n> (emu_rename.h); kernel_dispatch_on_cpu.cpp owns
+ * the plain names and forwards by n_members.  Eight small units in parallel instead of one three-minute unit. */
+#ifdef RGB_EMU_ONLY_N
+#define RGB_X_ONLY_N RGB_EMU_ONLY_N
+#include "emu_rename.h"
+#endif
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
-thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
-
-/* ---- block emulation: one ucontext fiber per lane ------------------------------------------------ */
-#include <ucontext.h>
-#include <vector>
-namespace emu {
-namespace {
-struct Fiber { ucontext_t ctx; char *stack; bool done; };
-std::vector<Fiber> fibers;
-ucontext_t sched_ctx;
-int cur = -1;
-const std::function<void()> *body_fn = nullptr;
-unsigned char shfl_buf[1024][16];
-constexpr size_t STACK = 512 * 1024;
-void entry() {
-  (*body_fn)();
-  fibers[cur].done = true;
-  swapcontext(&fibers[cur].ctx, &sched_ctx);
-}
-}  // namespace
-int lane() { return cur < 0 ? 0 : cur; }
-void barrier() {
-  if (cur < 0) return;                                  /* not inside a launch: single lane, nothing to wait for */
-  swapcontext(&fibers[cur].ctx, &sched_ctx);
-}
-void shfl(void *value, size_t size, int src_lane) {
-  if (cur < 0) return;
-  memcpy(shfl_buf[cur], value, size);
-  barrier();
-  memcpy(value, shfl_buf[src_lane], size);
-  barrier();
-}
-unsigned long long ballot(int pred) {
-  if (cur < 0) return pred ? 1ull : 0ull;
-  const unsigned char b = pred ? 1 : 0;
-  memcpy(shfl_buf[cur], &b, 1);
-  barrier();
-  unsigned long long m = 0;
-  for (unsigned i = 0; i < blockDim.x && i < 64; ++i)
-    if (!fibers[i].done && shfl_buf[i][0]) m |= 1ull << i;
-  barrier();
-  return m;
-}
-void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
-  const unsigned nl = block.x;
-  body_fn = &body;
-  blockDim = block; gridDim = grid;
-  if (fibers.size() < nl) {
-    size_t old = fibers.size();
-    fibers.resize(nl);
-    for (size_t i = old; i < nl; ++i) fibers[i].stack = (char *)malloc(STACK);
-  }
-  for (unsigned b = 0; b < grid.x; ++b) {
-    blockIdx = dim3(b);
-    for (unsigned i = 0; i < nl; ++i) {
-      getcontext(&fibers[i].ctx);
-      fibers[i].ctx.uc_stack.ss_sp = fibers[i].stack;
-      fibers[i].ctx.uc_stack.ss_size = STACK;
-      fibers[i].ctx.uc_link = nullptr;
-      fibers[i].done = false;
-      makecontext(&fibers[i].ctx, entry, 0);
-    }
-    bool live = true;
-    while (live) {                                      /* one pass = one barrier interval */
-      live = false;
-      for (unsigned i = 0; i < nl; ++i) {
-        if (fibers[i].done) continue;
-        cur = (int)i;
-        threadIdx = dim3(i);
-        swapcontext(&sched_ctx, &fibers[i].ctx);
-        live = live || !fibers[i].done;
-      }
-    }
-  }
-  cur = -1;
-  body_fn = nullptr;
-}
-}  // namespace emu
+#ifndef RGB_EMU_ONLY_N
+#include "emu_runtime.inc"
+#endif
 #include "../../ra_amd/csrc/rgb_kernels.hip"
 
 namespace {
@@ -175,7 +107,11 @@ int emu_step(void *h, const rgb_msg *msgs, uint32_t n, rgb_decision *dec, rgb_rp
     memset(&d, 0, sizeof d);
     switch (N) {
 #define EMU_N(NN) case NN: run_one<NN>(e->dev, msgs[i], i, e->slots, d, specialised); break;
+#ifdef RGB_EMU_ONLY_N
+      EMU_N(RGB_EMU_ONLY_N)
+#else
       EMU_N(1) EMU_N(2) EMU_N(3) EMU_N(4) EMU_N(5) EMU_N(6) EMU_N(7) EMU_N(8)
+#endif
 #undef EMU_N
       default: return -1;
     }
