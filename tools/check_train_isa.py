@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Static check of the train kernel's publish step (no GPU needed): the sequence byte store must be preceded, on
-every path, by an `s_waitcnt vmcnt(0)` that follows the last state store -- the compiler must neither drop nor move
-the wait of rgb_tick_slice's step 4 -- and the decision stores behind it must NOT each wait for the previous one.
+"""Static check of the train kernels' publish steps (no GPU needed), for the dealt and the persistent form (N = 5):
+every group of sequence byte stores -- the ONE store of a message slice (rgb_tick_slice step 4) and the N stores of a
+leaderboard snapshot row (rgb_train_snap_slice) -- must be preceded, on every path, by an `s_waitcnt vmcnt(0)` with no
+memory operation in between (the compiler must neither drop nor move the wait), and the decision stores behind the
+slice's store must NOT each wait for the previous one.
 usage: python tools/check_train_isa.py [-DFLAG ...]"""
 import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,26 +14,38 @@ with tempfile.TemporaryDirectory() as d:
                            "-DRGB_X_ONLY_N=5", *flags, "-o", out, os.path.join(root, "ra_amd", "csrc", "rgb_kernels.hip")],
                           stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-body, inside = [], False
-for l in lines:
-    if re.match(r"^_ZN\S*rgb_train_kernelILi5E\S*:", l): inside = True; continue
-    if inside:
-        t = l.strip()
-        if t.startswith(".amdhsa_kernel"): break
-        if t and not t.startswith((";", ".")): body.append(t)
-idx = [i for i, t in enumerate(body) if t.startswith("global_store_byte")]
-assert len(idx) == 1, f"expected one sequence byte store, found {len(idx)}"
-i = idx[0]
-# walk back to the wait: only scalar / exec bookkeeping and the byte's own arithmetic may sit in between
-back = body[max(0, i - 12):i]
-w = [k for k, t in enumerate(back) if t.startswith("s_waitcnt") and "vmcnt(0)" in t]
-assert w, "no s_waitcnt vmcnt(0) in front of the sequence byte store:\n" + "\n".join(back)
-between = back[w[-1] + 1:]
-assert not any(t.startswith(("global_", "buffer_", "flat_", "scratch_")) for t in between), "a memory operation between the wait and the byte store"
-after = body[i + 1:]
-nt = [k for k, t in enumerate(after) if t.startswith("global_store_dwordx4") and " nt" in t]
-assert len(nt) >= 4, "decision stores not found"
-waits = [t for t in after[:nt[3]] if t.startswith("s_waitcnt") and "vmcnt" in t]
-print(f"publish: wait {len(between)} instructions before the byte store; vmcnt waits between the byte store and the 4th decision store: {len(waits)}")
-assert len(waits) == 0, "the decision stores wait for each other (vmcnt) -- see rgb_tick_slice step 4"
+MEM = ("global_", "buffer_", "flat_", "scratch_")
+for kern in ("rgb_train_dealt_kernelILi5E", "rgb_train_kernelILi5E"):
+    body, inside = [], False
+    for l in lines:
+        if re.match(rf"^_ZN\S*{kern}\S*:", l): inside = True; continue
+        if inside:
+            t = l.strip()
+            if t.startswith(".amdhsa_kernel"): break
+            if t and not t.startswith((";", ".")): body.append(t)
+    assert body, f"{kern}: not found"
+    idx = [i for i, t in enumerate(body) if t.startswith("global_store_byte")]
+    groups = []                                    # runs of byte stores with only address arithmetic between them
+    for i in idx:
+        if groups and i - groups[-1][-1] <= 4 and not any(t.startswith(MEM) for t in body[groups[-1][-1] + 1:i]):
+            groups[-1].append(i)
+        else:
+            groups.append([i])
+    assert sorted(len(g) for g in groups) == [1, 5], f"{kern}: expected the slice's byte store and a snapshot row's five, found {[len(g) for g in groups]}"
+    for g in groups:
+        i = g[0]
+        back = body[max(0, i - 32):i]
+        w = [k for k, t in enumerate(back) if t.startswith("s_waitcnt") and "vmcnt(0)" in t]
+        assert w, f"{kern}: no s_waitcnt vmcnt(0) in front of the sequence byte store(s) at {i}:\n" + "\n".join(back)
+        between = back[w[-1] + 1:]
+        assert not any(t.startswith(MEM) for t in between), f"{kern}: a memory operation between the wait and the byte store at {i}"
+        if len(g) == 1:
+            after = body[i + 1:]
+            nt = [k for k, t in enumerate(after) if t.startswith("global_store_dwordx4") and " nt" in t]
+            assert len(nt) >= 4, f"{kern}: decision stores not found"
+            waits = [t for t in after[:nt[3]] if t.startswith("s_waitcnt") and "vmcnt" in t]
+            print(f"{kern}: slice publish: wait {len(between)} instructions before the byte store; vmcnt waits between the byte store and the 4th decision store: {len(waits)}")
+            assert len(waits) == 0, f"{kern}: the decision stores wait for each other (vmcnt) -- see rgb_tick_slice step 4"
+        else:
+            print(f"{kern}: snapshot row: wait {len(between)} instructions before its {len(g)} byte stores")
 print("ok")
