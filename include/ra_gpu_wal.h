@@ -78,12 +78,10 @@ typedef struct rgb_wal_record {
 uint64_t rgb_wal_layout(rgb_wal_record *records, uint32_t n, uint64_t base);
 
 /* d_out[out_offset ..) = the framed record, for the n records of d_records.  d_checksums (may be
- * NULL) receives the n checksums as well.  d_data and d_out may have any alignment (the kernel aligns its
- * 16-byte chunks to the addresses, not to the offsets), d_out must hold the highest out_offset + record size;
- * records may not overlap.  The payload is read in 16-byte granules aligned to its ADDRESS: the granules that hold
- * a payload's first and last byte are read whole (never written), i.e. up to 15 bytes on either side of the
- * payload inside the same aligned granule -- always inside the pages the payload itself occupies.  Only the
- * record's own bytes are written.  `flags`: RGB_WAL_NO_CHECKSUMS.  Enqueued on `stream`, no synchronisation. */
+ * NULL) receives the n checksums as well.  d_data and d_out may have any alignment (payloads are read and written
+ * in 16-byte pieces at their own byte alignment), d_out must hold the highest out_offset + record size; records may
+ * not overlap.  Only the payload's own bytes are read, only the record's own bytes are written.  `flags`:
+ * RGB_WAL_NO_CHECKSUMS.  Enqueued on `stream`, no synchronisation. */
 int rgb_wal_frame_device(rgb_ctx *ctx, const void *d_records, uint32_t n, const void *d_data,
                          uint64_t data_bytes, void *d_out, uint64_t out_bytes, void *d_checksums,
                          uint32_t flags, void *stream);
