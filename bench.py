@@ -238,6 +238,14 @@ def main():
     ap.add_argument("--train-form", choices=("auto", "persistent"), default="auto",
                     help="auto: the dealt form where the calibration launch shows round-robin dispatch (every block "
                          "verifies it), else persistent; persistent: RGB_CFG_TRAIN_PERSISTENT")
+    ap.add_argument("--hint", choices=("none", "state", "header"), default="header",
+                    help="the generator's ordering hint (include/ra_gpu_batch_synth.h, rgb_synth_set_hint): none, the "
+                         "owner's state name (round 4), + the owner's O(1) compare of the rpc header with fields it "
+                         "holds (default); it only orders a tick, results are the same")
+    ap.add_argument("--device-plan", action="store_true",
+                    help="build the train's row plan ON THE DEVICE, inside the timed region, from the bucket counts the "
+                         "generator left in device memory (rgb_train_plan_build_device; launches take the persistent "
+                         "form) -- no copy of the counts to the host, no host merge")
     ap.add_argument("--graph", action="store_true", help="capture the timed region into a hipGraph even when it is one or two launches")
     ap.add_argument("--snapshot-kernel", action="store_true",
                     help="train: one launch per leaderboard period with the snapshot KERNEL between the launches (the "
@@ -309,6 +317,11 @@ def main():
                             flags=abi.CFG_TRAIN_PERSISTENT if args.train_form == "persistent" else 0)
     st0 = W.initial_states(G, N, seed)
     eng.set_state(0, st0)
+    hint_level = {"none": 0, "state": 1, "header": 2}[args.hint]
+    if hasattr(engine.lib(), "rgb_synth_set_hint"):
+        eng.synth_set_hint(hint_level)
+    else:                                     # (RGB_LIB = a build of round 4: state-name hint only)
+        hint_level = min(hint_level, 1)
 
     comm = None
     if use_dist:
@@ -423,7 +436,14 @@ def main():
     # the aged state (device, untimed: the order rgb_submit's bucketing would establish on the host path) ----
     plan = d_dec2 = None
     plan_host_ms = None
-    if use_train:
+    device_plan = use_train and args.device_plan
+    if device_plan:
+        # nothing of the plan passes through the host: an empty plan now, every launch's ticks are built by a kernel in
+        # front of it, on the launch stream, inside the timed region (launch_ticks)
+        plan = engine.TrainPlan(eng, None, snapshot_every=SNAPSHOT_EVERY if snap_in_train else 0, device_ticks=T)
+        plan_host_ms = 0.0
+        d_dec2 = torch.zeros(T * tick_bytes, dtype=torch.uint8, device=dev)
+    elif use_train:
         buckets = d_bc.cpu().numpy().reshape(T, engine.TRAIN_BUCKETS).astype(np.uint32)
         assert np.array_equal(buckets.sum(axis=1), counts)
         if os.environ.get("RGB_TRAIN_LEAD"):     # tuning probe: "class:lead,..." in ticks (tools/gpu_ab.sh)
@@ -440,6 +460,8 @@ def main():
 
     def launch_ticks(t, nxt):
         """ticks [t, nxt) on the stream: ONE train launch, or one class-kernel launch per tick"""
+        if device_plan:
+            plan.build_device(t, nxt - t, d_bc.data_ptr() + t * engine.TRAIN_BUCKETS * 4, sptr)
         if snap_in_train:
             eng.train_run_snap_device(plan, t, nxt - t, d_msgs.data_ptr(), d_stamps.data_ptr(), S, d_dec2.data_ptr(),
                                       d_rpcs.data_ptr(), RPC_RING, d_snap_stamps.data_ptr(), lb_got.data_ptr(), sptr)
@@ -548,15 +570,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # (a torch event creates its HIP event at the first record -- 12-15 us of host time that sat inside the timed
+    # region of the driver's 20-step form, profiles/r05_wall_breakdown.txt: both events are recorded once before)
+    ev0.record(stream); ev1.record(stream)
+    torch.cuda.synchronize()
     wall0 = time.perf_counter()
     ev0.record(stream)
+    wall_a = time.perf_counter()
     timed()
+    wall_b = time.perf_counter()
     ev1.record(stream)
+    wall_c = time.perf_counter()
     torch.cuda.synchronize()
+    wall_d = time.perf_counter()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - wall0
+    # where the host's share of the timed region goes (us): event record | enqueue of the launches | event record | wait
+    wall_breakdown = {"record0_us": round((wall_a - wall0) * 1e6, 1), "enqueue_us": round((wall_b - wall_a) * 1e6, 1),
+                      "record1_us": round((wall_c - wall_b) * 1e6, 1), "wait_us": round((wall_d - wall_c) * 1e6, 1)}
     ev_ms = ev0.elapsed_time(ev1)
     elapsed = max(wall, ev_ms / 1e3)
     train_info = None
@@ -589,18 +622,55 @@ def main():
         compact_info = {"fraction": round(float(isc.mean()), 4),
                         "decision_bytes_per_tick": int(isc.sum()) * 32 + int((~isc).sum()) * 64,
                         "full_records_by_kind": {str(k): int(v) for k, v in enumerate(full_by_kind) if v}}
-        train_info = {"ticks_per_launch": TPL, "blocks_per_tick": plan.blocks_per_tick, "form": eng.train_form(),
+        train_info = {"ticks_per_launch": TPL, "blocks_per_tick": plan.blocks_per_tick,
+                      "form": "persistent" if device_plan else eng.train_form(),
                       "leaderboard_snapshots": ("rows of the launch (rgb_train_run_snap_device): ordered per server like one "
                                                 "more message; a boundary that ends a launch: rgb_snapshot_train_device"
                                                 if snap_in_train else "rgb_snapshot_device between the launches"),
                       "leaderboard_snapshots_compared_with_snapshot_kernel": snaps_checked,
                       "compact_decisions": compact_info,
+                      "plan": ("built on the device inside the timed region (rgb_train_plan_build_device: one kernel per "
+                               "launch in front of it, from the generator's bucket counts in device memory); persistent form"
+                               if device_plan else "built on the host before the timed region from the bucket counts "
+                               "(rgb_train_plan_create*): the dealt form needs the rows of a tick for its grid"),
+                      "ordering_hint": {0: "none", 1: "owner's state name",
+                                        2: "owner's state name + its O(1) compare of the rpc header with current_term, "
+                                           "leader_id, last index / term (rgb_synth_set_hint 2); orders the tick only"}[hint_level],
                       "stamps": "written by the stream's producer (rgb_synth_tick_stamped_device) with the messages: "
                                 "nothing of the train's input preparation is outside the timed region except the host's "
                                 "row plan (256 bucket counts per tick)",
                       "plan_host_ms_total": round(plan_host_ms, 3), "plan_host_us_per_tick": round(plan_host_ms * 1e3 / T, 2),
                       "xcd_of_shard": [int(v) for v in xcc], "decisions_compared_with_per_tick_launches": int(n_dec.sum())}
     checksum_pass2 = eng.state_checksum()
+    # the row plan on the device (rgb_train_plan_build_device): what building the timed region's plan costs as ONE kernel
+    # from the generator's bucket counts in device memory, and that its tables are the host's bit for bit (every tick)
+    device_plan_info = None
+    if use_train and not device_plan and rank == 0 and hasattr(engine.lib(), "rgb_train_plan_build_device"):
+        dpl = engine.TrainPlan(eng, None, snapshot_every=SNAPSHOT_EVERY if snap_in_train else 0, device_ticks=T)
+        best = None
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            dpl.build_device(Wm, K, d_bc.data_ptr() + Wm * engine.TRAIN_BUCKETS * 4, sptr)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3
+            best = us if best is None or us < best else best
+        dpl.build_device(0, T, d_bc.data_ptr(), sptr)
+        torch.cuda.synchronize()
+        same = 0
+        for t in range(T):
+            a, b = plan.download(t), dpl.download(t)
+            if all(np.array_equal(x, y) for x, y in zip(a, b)):
+                same += 1
+        dpl.close()
+        device_plan_info = {"build_kernel_us_for_the_timed_ticks": round(best, 2), "timed_ticks": K,
+                            "ticks_whose_tables_equal_the_host_plan": same, "ticks": T,
+                            "note": "--device-plan runs the timed region from it (persistent form, plan kernel inside the "
+                                    "region); this line's region uses the host-built plan in the dealt form"}
+        if same != T:
+            raise SystemExit(f"PLAN MISMATCH: the device-built plan differs from the host's in {T - same} of {T} ticks")
+        train_info["device_plan"] = device_plan_info
     assert checksum_pass2 == checksum_pass1 or os.environ.get("RGB_BENCH_NOCHECK"), "replay diverged from the generation pass"
     per_rank = None
     if use_dist:
@@ -942,6 +1012,7 @@ def main():
             "unit": "decisions/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed * 1e3 / K,
+            "wall_minus_events_us": round((wall - ev_ms / 1e3) * 1e6, 1), "wall_breakdown": wall_breakdown,
             "higher_is_better": True, "scaling": "strong" if args.config4 else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGB_ABI_VERSION   7u
+#define RGB_ABI_VERSION   8u
 #define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
 #define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
 #define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
@@ -488,7 +488,13 @@ uint32_t rgb_comm_rank(const rgb_comm *comm);
 int  rgb_leaderboard_allgather(rgb_ctx *ctx, rgb_comm *comm, const void *d_rows_local, uint32_t n_rows,
                                void *d_rows_all /* n_ranks * n_rows rows */, void *stream);
 /* the same with host buffers (the NIF's form): this context's rows are produced, padded to n_rows >= its group
- * count, gathered and copied to rows_all (n_ranks * n_rows rows); synchronous */
+ * count, gathered and copied to rows_all (n_ranks * n_rows rows); synchronous for the CALLER only -- the locks of
+ * rgb_submit / rgb_collect are held while the snapshot is enqueued, not while the ranks meet (the collective runs on a
+ * side stream).  Collective-safe exits: every rank first takes part in an 8-byte status exchange; if any rank failed
+ * locally (RGB_E_INVAL for n_rows below its group count, RGB_E_NOMEM, ..) no rank starts the gather, the failing rank
+ * returns its own error and the others RGB_E_COMM.  A collective that does not complete within RGB_COMM_TIMEOUT_MS
+ * (environment, default 30 000) is abandoned (ncclCommAbort): RGB_E_COMM, rgb_comm_last_error() says which; destroy
+ * the communicator and create a new one. */
 int  rgb_leaderboard_allgather_host(rgb_ctx *ctx, rgb_comm *comm, uint32_t n_rows, rgb_leaderboard_row *rows_all);
 const char *rgb_comm_last_error(void);
 
@@ -567,6 +573,7 @@ int  rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride
 #define RGB_TRAIN_ERR_PLACEMENT 1u   /* dealt form: a block ran on another XCD than its shard's (the L2s are not coherent) */
 #define RGB_TRAIN_ERR_SPIN      2u   /* a wavefront's dependencies did not commit within the spin bound        */
 #define RGB_TRAIN_ERR_ORDER     4u   /* a message sits in another shard's bucket: the tick is not in bucket order */
+#define RGB_TRAIN_ERR_PLAN      8u   /* rgb_train_plan_build_device: a tick needs more rows than the plan's table holds */
 #define RGB_TRAIN_FORM_NONE       0u /* no train has been set up yet (or the device cannot run them)            */
 #define RGB_TRAIN_FORM_DEALT      1u
 #define RGB_TRAIN_FORM_PERSISTENT 2u
@@ -603,6 +610,30 @@ int  rgb_train_run_snap_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_
                                void *d_rpcs, uint32_t rpc_ring, const void *d_snap_stamps, void *d_snap_rows,
                                void *stream);
 int  rgb_snapshot_train_device(rgb_ctx *ctx, void *d_rows, void *stream);
+/* The plan built ON THE DEVICE (ABI v8): a device-resident producer leaves its bucket counts in device memory
+ * (rgb_synth_tick_*_device: d_bucket_counts; rgb_submit's own device-side bucketing) and nothing of the plan passes
+ * through the host -- the reference has no stop between a mailbox and its handler either
+ * (src/ra_server_proc.erl:1382-1397).
+ *   rgb_train_plan_create_device  an EMPTY plan of n_ticks ticks (snapshot_every as in rgb_train_plan_create_snap; 0 =
+ *                                 none): tables sized for any tick the registered groups can produce (at most one
+ *                                 message per server)
+ *   rgb_train_plan_build_device   ticks [first_tick, first_tick + n_ticks) of the plan from d_bucket_counts =
+ *                                 uint32[n_ticks][RGB_TRAIN_BUCKETS] of exactly those ticks, one kernel on `stream`
+ *                                 (offsets, rows per class, the row table: bit for bit what rgb_train_plan_create
+ *                                 computes on the host).  Enqueue it behind the producer and in front of
+ *                                 rgb_train_run*_device, same stream.
+ * The grid of a DEALT launch is its rows, which only the device knows here: launches of a device-built plan take the
+ * PERSISTENT form (placement by construction, rows from per-shard ticket counters; 2-3 % slower on the 65 536 x 5
+ * closed loop). */
+int  rgb_train_plan_create_device(rgb_ctx *ctx, uint32_t n_ticks, uint32_t snapshot_every, rgb_train_plan **out);
+int  rgb_train_plan_build_device(rgb_ctx *ctx, rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
+                                 const void *d_bucket_counts, void *stream);
+/* inspection (tests, tools): tick `tick` of a plan as it stands on the device -- out_tick = the 16 header words (rows,
+ * message base, snapshot ordinal + 1, padding) followed by off[30][8] and cnt[30][8] (1984 bytes), out_rows = its row
+ * table (plan class << 24 | row of the class), at most rows_cap entries; returns the tick's rows or a negative error.  A plan built on a
+ * stream of the caller's: synchronise that stream first */
+int  rgb_train_plan_download(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t tick, void *out_tick, uint32_t *out_rows,
+                             uint32_t rows_cap);
 uint32_t rgb_train_seq_bytes(const rgb_ctx *ctx);     /* bytes of the per-server sequence array (and of one d_snap_stamps) */
 int  rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard /* [8] or NULL */);
 uint32_t rgb_train_form(const rgb_ctx *ctx);          /* RGB_TRAIN_FORM_*: how the next train launch will run */

@@ -61,6 +61,17 @@ int rgb_synth_stamps_resync_device(rgb_ctx *ctx, void *stream);
  * byte must show at the boundary -- and advance by one; call it between the ticks the boundary separates */
 int rgb_synth_snapshot_mark_device(rgb_ctx *ctx, void *d_snap_stamps, void *stream);
 
+/* The generator's ORDERING HINT for the kinds that carry no success flag (rgb_bucket_hinted, ra_gpu_batch.h "Train
+ * launches"): which messages it sorts into sub-bucket 1 of their (class, shard).  0: none.  1: the owner's gen_statem
+ * state name (an append_entries_rpc / written event whose owner is not in state follower; a written event whose owner
+ * is leader).  2 (default): + what the owner sees by comparing the rpc's HEADER with fields it holds anyway -- an
+ * append_entries_rpc whose term is not the owner's current_term, whose sender is not its leader_id, or whose
+ * (prev_log_index, prev_log_term) is not ra_log's last (index, term), or whose entries open a new term; a written event
+ * of a server that knows no leader.  All O(1) on the ra_server_state() map ra_server_proc holds at the interception
+ * point; the generator reads the same fields from the device rows.  The hint only ORDERS a tick: the
+ * kernels re-check every condition, a wrong or absent hint costs time, never a result. */
+int rgb_synth_set_hint(rgb_ctx *ctx, uint32_t level);
+
 /* Apply the tick that rgb_synth_tick_device just wrote (same stream): one launch of the
  * class-dispatch kernel sized from the family totals the generator left in device memory, so no
  * host round trip is needed between generating a tick and applying it. */

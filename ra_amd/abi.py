@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 CFG_ROUNDS_PER_LAUNCH = 1      # rgb_config.flags: rgb_submit launches one kernel per sub-tick round (A/B measurements)
 CFG_TRAIN_PERSISTENT = 2       # rgb_config.flags: trains always in the persistent form (placement by construction)
 UNDEF = np.uint64(0xFFFFFFFFFFFFFFFF)  # Erlang 'undefined'

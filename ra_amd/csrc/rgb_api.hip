@@ -19,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -115,8 +116,12 @@ struct rgb_ctx {
   /* snapshot / checksum scratch */
   rgb_leaderboard_row *d_rows = nullptr;
   u64 *d_sums = nullptr;
-  void *d_lb_gather = nullptr;      /* rgb_leaderboard_allgather_host: this rank's padded rows | the gathered rows */
+  void *d_lb_gather = nullptr;      /* rgb_leaderboard_allgather_host: this rank's padded rows | the gathered rows | status words */
   size_t lb_gather_bytes = 0;
+  std::mutex lb_mu;                 /* .. one call at a time per context: it owns the buffer, the side stream, the event */
+  hipStream_t lb_stream = nullptr;  /* the collective and its copy-out run HERE, outside the decision path's locks */
+  hipEvent_t lb_event = nullptr;    /* the snapshot on the context's stream -> the side stream */
+  u32 synth_hint = 2;         /* rgb_synth_set_hint */
   u32 *d_synth = nullptr;     /* load-generator scratch (family and bucket counters) */
   unsigned char *d_synth_sent = nullptr;   /* load generator: messages addressed to every server so far, mod 256 (its stamps) */
   /* train launches */
@@ -141,6 +146,8 @@ struct rgb_train_plan {
   u32 n_ticks = 0;
   u32 bpt = 0;            /* blocks per tick: RGB_TRAIN_SHARDS x the longest tick's rows */
   u32 snap_every = 0;     /* > 0: ticks k x snap_every (k >= 1) carry the rows of a leaderboard snapshot in front of them */
+  bool on_device = false; /* rgb_train_plan_create_device: the tables are filled by rgb_train_plan_build_device; its
+                             launches take the persistent form (the host does not know the rows of a tick) */
 };
 
 /* A tick ordered by clause family: ONE launch of the class-dispatch kernel. */
@@ -260,6 +267,8 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->d_lb_gather) (void)hipFree(ctx->d_lb_gather);
+  if (ctx->lb_stream) { (void)hipStreamSynchronize(ctx->lb_stream); (void)hipStreamDestroy(ctx->lb_stream); }
+  if (ctx->lb_event) (void)hipEventDestroy(ctx->lb_event);
   if (ctx->d_synth) (void)hipFree(ctx->d_synth);
   if (ctx->d_synth_sent) (void)hipFree(ctx->d_synth_sent);
   if (ctx->d_train_ctl) (void)hipFree(ctx->d_train_ctl);
@@ -345,6 +354,7 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   d.max_pipeline_count = ctx->cfg.max_pipeline_count;
   d.max_aer_batch = ctx->cfg.max_aer_batch;
   d.dbg = 0; d.dbg_buf = nullptr;
+  d.synth_hint = ctx->synth_hint;
 #ifdef RGB_PROFILE
   /* the profiling build only (libra_gpu_batch_prof.so): knobs from the environment */
   { const char *e = getenv("RGB_DEBUG"); d.dbg = e ? (u32)atoi(e) : 0u; }
@@ -531,11 +541,8 @@ static int enqueue_results(rgb_ctx *ctx, rgb_slot &s) {
     if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
   }
   HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc, s.d_nrpc, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-  if (s.used_train) {
-    int lr = rgb_launch_train_verify(s.d_ctl, ctx->stream);    /* the launch's placement marks -> the error word */
-    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+  if (s.used_train)      /* (the launch's placement marks went into the error word behind it: rgb_launch_train) */
     HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc + 1, s.d_ctl, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-  }
   {
     int lr = rgb_launch_unpermute(s.d_dec, s.d_pos, s.n, s.d_dec_sub, ctx->stream);    /* back to submission order */
     if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
@@ -1050,6 +1057,13 @@ int rgb_synth_stamps_resync_device(rgb_ctx *ctx, void *stream) {
   return RGB_OK;
 }
 
+int rgb_synth_set_hint(rgb_ctx *ctx, uint32_t level) {
+  if (!ctx || level > 2u) return RGB_E_INVAL;
+  ctx->synth_hint = level;
+  ctx->dev.synth_hint = level;       /* (by value in every later launch of the generator) */
+  return RGB_OK;
+}
+
 int rgb_synth_tick_buckets_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, void *d_msgs, void *d_kind_counts,
                                   void *d_n, void *d_bucket_counts, void *stream) {
   return rgb_synth_tick_stamped_device(ctx, seed, tick, d_msgs, d_kind_counts, d_n, d_bucket_counts, nullptr, stream);
@@ -1155,6 +1169,69 @@ int rgb_train_plan_create_snap(rgb_ctx *ctx, const uint32_t *bucket_counts, uint
   return RGB_OK;
 }
 
+int rgb_train_plan_create_device(rgb_ctx *ctx, uint32_t n_ticks, uint32_t snapshot_every, rgb_train_plan **out) {
+  if (!ctx || !out) return RGB_E_INVAL;
+  *out = nullptr;
+  if (!ctx->registered) return RGB_E_STATE;
+  int rc;
+  {
+    std::lock_guard<std::mutex> tl(ctx->train_mu);          /* the one-off calibration uses the stream */
+    rc = train_scratch(ctx);
+  }
+  if (rc) return rc;
+  rgb_train_plan *p = new (std::nothrow) rgb_train_plan();
+  if (!p) return RGB_E_NOMEM;
+  const u32 rows = rgb_train_rows_bound(ctx->dev.n_servers, ctx->dev.n_members, snapshot_every != 0);
+  p->snap_every = snapshot_every;
+  p->n_ticks = n_ticks;
+  p->bpt = rows * RGB_TRAIN_SHARDS;
+  p->on_device = true;
+  if (n_ticks) {
+    hipError_t e = hipMalloc((void **)&p->d_ticks, (size_t)n_ticks * sizeof(rgb_train_tick));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_rows, (size_t)n_ticks * rows * sizeof(u32));
+    /* an unbuilt tick has no rows (a launch over it does nothing) */
+    if (e == hipSuccess) e = hipMemset(p->d_ticks, 0, (size_t)n_ticks * sizeof(rgb_train_tick));
+    if (e == hipSuccess) e = hipMemset(p->d_rows, 0xFF, (size_t)n_ticks * rows * sizeof(u32));
+    if (e != hipSuccess) {
+      ctx->last_hip.store((int)e, std::memory_order_relaxed);
+      if (p->d_ticks) (void)hipFree(p->d_ticks);
+      if (p->d_rows) (void)hipFree(p->d_rows);
+      delete p;
+      return RGB_E_HIP;
+    }
+  }
+  *out = p;
+  return RGB_OK;
+}
+
+int rgb_train_plan_build_device(rgb_ctx *ctx, rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
+                                const void *d_bucket_counts, void *stream) {
+  if (!ctx || !plan || (!d_bucket_counts && n_ticks)) return RGB_E_INVAL;
+  if (!ctx->registered || ctx->xcc_state != 1) return RGB_E_STATE;
+  if (!plan->on_device || (uint64_t)first_tick + n_ticks > plan->n_ticks) return RGB_E_INVAL;
+  void *st = stream ? stream : (void *)ctx->stream;
+  int lr = rgb_launch_train_plan((const u32 *)d_bucket_counts, plan->d_ticks, plan->d_rows, plan->bpt / RGB_TRAIN_SHARDS,
+                                 first_tick, n_ticks, plan->snap_every, ctx->dev.n_servers / ctx->dev.n_members,
+                                 ctx->dev.n_members, ctx->d_train_ctl, st);
+  if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+  return RGB_OK;
+}
+
+int rgb_train_plan_download(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t tick, void *out_tick, uint32_t *out_rows,
+                            uint32_t rows_cap) {
+  if (!ctx || !plan || !out_tick || tick >= plan->n_ticks) return RGB_E_INVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      /* (a build on another stream: the caller has synchronised it) */
+  rgb_train_tick h;
+  HIPCHK(ctx, hipMemcpy(&h, plan->d_ticks + tick, sizeof h, hipMemcpyDeviceToHost));
+  memcpy(out_tick, &h, sizeof h);
+  const u32 rpt = plan->bpt / RGB_TRAIN_SHARDS;
+  const u32 n = h.n_rows < rows_cap ? h.n_rows : rows_cap;
+  if (out_rows && n && h.n_rows <= rpt)
+    HIPCHK(ctx, hipMemcpy(out_rows, plan->d_rows + (size_t)tick * rpt, (size_t)n * sizeof(u32), hipMemcpyDeviceToHost));
+  return (int)h.n_rows;
+}
+
 void rgb_train_plan_destroy(rgb_train_plan *plan) {
   if (!plan) return;
   if (plan->d_ticks) (void)hipFree(plan->d_ticks);
@@ -1236,7 +1313,7 @@ int rgb_train_run_snap_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t
                               tick_stride, plan->d_ticks + t, plan->d_rows + (size_t)t * (plan->bpt / RGB_TRAIN_SHARDS), n,
                               plan->bpt, (rgb_decision *)d_decisions + off,
                               (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, ctx->n_xcc,
-                              ctx->train_dealt.load(std::memory_order_relaxed) ? 0u : ctx->train_blocks, st,
+                              (ctx->train_dealt.load(std::memory_order_relaxed) && !plan->on_device) ? 0u : ctx->train_blocks, st,
                               (const unsigned char *)d_snap_stamps, (rgb_leaderboard_row *)d_snap_rows);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
@@ -1251,10 +1328,7 @@ int rgb_train_status(rgb_ctx *ctx, uint32_t *flags_out, uint32_t *xcc_of_shard) 
       xcc_of_shard[x] = ctx->xcc_state == 1 ? x % ctx->n_xcc : 0xFFFFFFFFu;
   if (!ctx->d_train_ctl) return RGB_OK;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-  {
-    int lr = rgb_launch_train_verify(ctx->d_train_ctl, ctx->stream);   /* the last launch's placement marks */
-    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
-  }
+  /* (every launch verifies its own placement marks behind itself: the error word is final once the stream is idle) */
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   u32 w = 0;
   HIPCHK(ctx, hipMemcpy(&w, ctx->d_train_ctl, sizeof w, hipMemcpyDeviceToHost));
@@ -1304,32 +1378,99 @@ int rgb_snapshot(rgb_ctx *ctx, rgb_leaderboard_row *out) {
 }
 
 /* host-buffer form of the leaderboard all-gather (what the NIF hands out as a binary): this context's rows are
- * produced on the device, padded to n_rows, gathered with rgb_leaderboard_allgather on the context's stream and
- * copied to rows_all (n_ranks * n_rows rows) */
+ * produced on the device, padded to n_rows, gathered and copied to rows_all (n_ranks * n_rows rows).
+ *
+ * The decision path has no exchange step and this call must not give it one (round 5): the locks of rgb_submit /
+ * rgb_collect (rgb_stream_turn) are held only while the snapshot is ENQUEUED on the context's stream; the collective,
+ * its copy-out and the wait run on a side stream behind an event, so a slow or missing rank delays this caller, never a
+ * producer, a consumer or the collector thread of this context.  Every exit is collective-safe: whatever goes wrong
+ * locally (n_rows smaller than this rank's groups, an allocation, the snapshot) is carried into an 8-byte STATUS
+ * all-gather that every rank takes part in first; unless every rank reports RGB_OK nobody starts the payload gather and
+ * all ranks return an error (the first failing rank's).  A collective that does not complete within
+ * RGB_COMM_TIMEOUT_MS (environment, default 30 000) is abandoned with ncclCommAbort: RGB_E_COMM,
+ * rgb_comm_last_error() says so, the communicator has to be re-created. */
+extern "C" int rgb_comm_allgather_bytes(rgb_comm *comm, const void *d_local, uint64_t bytes, void *d_all, void *stream);
+extern "C" int rgb_comm_abort(rgb_comm *comm, const char *why);
+extern "C" void rgb_comm_set_error_text(const char *why);
+
+/* the side stream has drained, or the deadline has passed */
+static bool lb_wait(rgb_ctx *ctx, unsigned timeout_ms) {
+#ifdef RGB_HOST_EMULATION
+  (void)ctx; (void)timeout_ms;
+  return true;
+#else
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(ctx->lb_stream);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) { ctx->last_hip.store((int)q, std::memory_order_relaxed); return false; }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) return false;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+#endif
+}
+
 int rgb_leaderboard_allgather_host(rgb_ctx *ctx, rgb_comm *comm, uint32_t n_rows, rgb_leaderboard_row *rows_all) {
   if (!ctx || !comm || !rows_all) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   const u32 g = ctx->dev.n_servers / ctx->dev.n_members, world = rgb_comm_n_ranks(comm);
-  if (n_rows < g || world == 0) return RGB_E_INVAL;
+  if (world == 0) return RGB_E_INVAL;
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-  rgb_stream_turn turn(ctx);
-  if (turn.rc) return turn.rc;
-  const size_t need = (size_t)n_rows * (world + 1u) * sizeof(rgb_leaderboard_row);
+  unsigned timeout_ms = 30000;
+  if (const char *e = getenv("RGB_COMM_TIMEOUT_MS")) { const long v = atol(e); if (v > 0) timeout_ms = (unsigned)v; }
+  std::lock_guard<std::mutex> one(ctx->lb_mu);
+  /* everything that can fail locally happens in front of the collectives and only sets `mine` */
+  int64_t mine = RGB_OK;
+  if (n_rows < g) mine = RGB_E_INVAL;
+  if (!ctx->lb_stream && hipStreamCreateWithFlags(&ctx->lb_stream, hipStreamNonBlocking) != hipSuccess) return RGB_E_HIP;
+  if (!ctx->lb_event && hipEventCreateWithFlags(&ctx->lb_event, hipEventDisableTiming) != hipSuccess) return RGB_E_HIP;
+  const size_t rows_bytes = (size_t)n_rows * (world + 1u) * sizeof(rgb_leaderboard_row);
+  const size_t need = rows_bytes + (size_t)(world + 1u) * sizeof(int64_t);
   if (ctx->lb_gather_bytes < need) {
+    (void)hipStreamSynchronize(ctx->lb_stream);
     if (ctx->d_lb_gather) (void)hipFree(ctx->d_lb_gather);
     ctx->d_lb_gather = nullptr; ctx->lb_gather_bytes = 0;
-    HIPCHK(ctx, hipMalloc(&ctx->d_lb_gather, need));
-    ctx->lb_gather_bytes = need;
+    /* (room for the status words even when the rows cannot be had: the status exchange must still happen) */
+    if (hipMalloc(&ctx->d_lb_gather, need) == hipSuccess) ctx->lb_gather_bytes = need;
+    else if (hipMalloc(&ctx->d_lb_gather, (size_t)(world + 1u) * sizeof(int64_t)) == hipSuccess) {
+      ctx->lb_gather_bytes = (size_t)(world + 1u) * sizeof(int64_t);
+      if (mine == RGB_OK) mine = RGB_E_NOMEM;
+    } else return RGB_E_NOMEM;               /* (not even 8 bytes per rank: this device is gone) */
   }
-  rgb_leaderboard_row *d_local = (rgb_leaderboard_row *)ctx->d_lb_gather, *d_all = d_local + n_rows;
-  HIPCHK(ctx, hipMemsetAsync(d_local, 0, (size_t)n_rows * sizeof(rgb_leaderboard_row), ctx->stream));
-  int rc = rgb_snapshot_device(ctx, d_local, ctx->stream);
+  const bool have_rows = ctx->lb_gather_bytes >= need;
+  char *base = (char *)ctx->d_lb_gather;
+  rgb_leaderboard_row *d_local = (rgb_leaderboard_row *)base, *d_all = d_local + n_rows;
+  int64_t *d_status = (int64_t *)(base + (have_rows ? rows_bytes : 0)), *d_status_all = d_status + 1;
+  if (mine == RGB_OK) {
+    /* the decision path's locks: only around the ENQUEUE of the snapshot on the context's stream */
+    rgb_stream_turn turn(ctx);
+    if (turn.rc) mine = turn.rc;
+    else if (hipMemsetAsync(d_local, 0, (size_t)n_rows * sizeof(rgb_leaderboard_row), ctx->stream) != hipSuccess) mine = RGB_E_HIP;
+    else {
+      const int rc = rgb_snapshot_device(ctx, d_local, ctx->stream);
+      if (rc) mine = rc;
+      else if (hipEventRecord(ctx->lb_event, ctx->stream) != hipSuccess) mine = RGB_E_HIP;
+    }
+  }
+  if (mine == RGB_OK && hipStreamWaitEvent(ctx->lb_stream, ctx->lb_event, 0) != hipSuccess) mine = RGB_E_HIP;
+  /* 1. the status of every rank */
+  std::vector<int64_t> st(world, 0);
+  HIPCHK(ctx, hipMemcpyAsync(d_status, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->lb_stream));
+  int rc = rgb_comm_allgather_bytes(comm, d_status, sizeof(int64_t), d_status_all, (void *)ctx->lb_stream);
   if (rc) return rc;
-  rc = rgb_leaderboard_allgather(ctx, comm, d_local, n_rows, d_all, ctx->stream);
+  HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status_all, (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->lb_stream));
+  if (!lb_wait(ctx, timeout_ms)) return rgb_comm_abort(comm, "leaderboard all-gather: a rank did not arrive (status exchange timed out; communicator aborted)");
+  for (u32 r = 0; r < world; ++r)
+    if (st[r] != RGB_OK) {
+      if (mine == RGB_OK) rgb_comm_set_error_text("leaderboard all-gather: another rank reported an error; nothing was gathered");
+      return mine != RGB_OK ? (int)mine : RGB_E_COMM;
+    }
+  /* 2. the rows */
+  rc = rgb_comm_allgather_bytes(comm, d_local, (uint64_t)n_rows * sizeof(rgb_leaderboard_row), d_all, (void *)ctx->lb_stream);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(rows_all, d_all, (size_t)n_rows * world * sizeof(rgb_leaderboard_row), hipMemcpyDeviceToHost,
-                             ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                             ctx->lb_stream));
+  if (!lb_wait(ctx, timeout_ms)) return rgb_comm_abort(comm, "leaderboard all-gather: timed out (communicator aborted)");
   return RGB_OK;
 }
 

@@ -34,6 +34,7 @@ typedef int (*fn_comm_init_rank)(nccl_comm_t *, int, nccl_unique_id, int);
 typedef int (*fn_comm_destroy)(nccl_comm_t);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, nccl_comm_t, void *);
 typedef const char *(*fn_error_string)(int);
+typedef int (*fn_comm_abort)(nccl_comm_t);
 
 struct rccl_api {
   fn_get_unique_id get_unique_id = nullptr;
@@ -41,12 +42,14 @@ struct rccl_api {
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_gather all_gather = nullptr;
   fn_error_string error_string = nullptr;
+  fn_comm_abort comm_abort = nullptr;     /* optional */
   bool ok = false;
 };
 
 rccl_api g_rccl;
 std::once_flag g_rccl_once;
 thread_local int g_last_rccl = 0;
+thread_local const char *g_last_text = nullptr;   /* a failure that is not an RCCL code (timeout, a peer's error) */
 
 void load_rccl() {
   /* a copy already in the process wins; then the loader's search path; then the ROCm install */
@@ -60,6 +63,7 @@ void load_rccl() {
   g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
   g_rccl.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
   g_rccl.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
+  g_rccl.comm_abort = (fn_comm_abort)dlsym(h, "ncclCommAbort");
   g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.all_gather;
 }
 
@@ -124,12 +128,36 @@ int rgb_leaderboard_allgather(rgb_ctx *ctx, rgb_comm *comm, const void *d_rows_l
   if (!r) return RGB_E_UNSUPPORTED;
   if (rgb_ctx_set_device(ctx) != RGB_OK) return RGB_E_HIP;
   void *st = stream ? stream : rgb_ctx_stream(ctx);
+  if (!comm->comm) { g_last_text = "the communicator was aborted"; return RGB_E_COMM; }
+  g_last_text = nullptr;
   g_last_rccl = r->all_gather(d_rows_local, d_rows_all, (size_t)n_rows * sizeof(rgb_leaderboard_row), 1 /* ncclUint8 */,
                               comm->comm, st);
   return g_last_rccl ? RGB_E_COMM : RGB_OK;
 }
 
+/* internal (rgb_api.hip, rgb_leaderboard_allgather_host): `bytes` per rank of anything, same transport */
+int rgb_comm_allgather_bytes(rgb_comm *comm, const void *d_local, uint64_t bytes, void *d_all, void *stream) {
+  if (!comm || !d_local || !d_all) return RGB_E_INVAL;
+  const rccl_api *r = rccl();
+  if (!r) return RGB_E_UNSUPPORTED;
+  g_last_text = nullptr;
+  g_last_rccl = r->all_gather(d_local, d_all, (size_t)bytes, 1 /* ncclUint8 */, comm->comm, stream);
+  return g_last_rccl ? RGB_E_COMM : RGB_OK;
+}
+/* internal: give up on a collective that does not complete (a rank never arrived): ncclCommAbort frees the kernels
+ * that spin on the missing peer; the communicator is unusable afterwards (rgb_comm_destroy + a new one) */
+int rgb_comm_abort(rgb_comm *comm, const char *why) {
+  if (!comm) return RGB_E_INVAL;
+  const rccl_api *r = rccl();
+  g_last_text = why;
+  g_last_rccl = 0;
+  if (r && r->comm_abort && comm->comm) { (void)r->comm_abort(comm->comm); comm->comm = nullptr; }
+  return RGB_E_COMM;
+}
+void rgb_comm_set_error_text(const char *why) { g_last_text = why; g_last_rccl = 0; }
+
 const char *rgb_comm_last_error(void) {
+  if (g_last_text) return g_last_text;
   const rccl_api *r = rccl();
   return (r && r->error_string && g_last_rccl) ? r->error_string(g_last_rccl) : "";
 }

@@ -209,6 +209,8 @@ struct rgb_dev {
   unsigned char *seq;   /* train launches: per-server sequence byte (messages applied, mod 256), shard-major:
                            rgb_seq_index().  Only rgb_train_kernel reads or writes it; never reset */
   u32 seq_stride;       /* bytes per shard of seq */
+  u32 synth_hint;  /* the load generator's bucketing hint (rgb_synth_set_hint): 0 none, 1 the owner's state name,
+                      2 (default) + the O(1) header compare an owner can make against the fields it holds */
   u32 dbg;   /* always 0 in the product library.  The -DRGB_PROFILE build (libra_gpu_batch_prof.so, tools/ only)
                 reads RGB_DEBUG: 1 = no state write-back, 2 = no decision store, 8 = no hot-line load (zero
                 state), 16 = per-wave timestamps into dbg_buf; all but 16 break parity */
@@ -258,6 +260,12 @@ int rgb_launch_train_calibrate(u32 *d_out, void *stream);
  * NULL: count only) receives them when they fit row_cap */
 u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap,
                         u32 snap_rows = 0);
+/* the same on the device, one block per tick: ticks [first_tick, first_tick + n_ticks) of d_ticks / d_rows (rpt rows of
+ * table per tick) from d_bucket_counts[n_ticks][RGB_N_BUCKETS]; d_err: the sticky error word (RGB_TRAIN_ERR_PLAN) */
+int rgb_launch_train_plan(const u32 *d_bucket_counts, rgb_train_tick *d_ticks, u32 *d_rows, u32 rpt, u32 first_tick,
+                          u32 n_ticks, u32 snapshot_every, u32 n_groups, u32 n_members, u32 *d_err, void *stream);
+/* rows per tick a table must hold for ANY tick of n_servers servers (at most one message per server) */
+u32 rgb_train_rows_bound(u32 n_servers, u32 n_members, bool with_snapshot);
 /* rows of a snapshot: 64 groups of every shard per row */
 static inline u32 rgb_train_snap_rows(u32 n_groups) {
   return ((n_groups + RGB_TRAIN_SHARDS - 1u) / RGB_TRAIN_SHARDS + 63u) / 64u;

@@ -234,6 +234,9 @@ struct LaneT {
   unsigned q_dirty;       /* bit 0: query_index, bit 1+i: peer slot i */
   unsigned hb_mask;
   unsigned cancel_mask;   /* RGB_F_CANCEL_SNAPSHOT_RETRY: backed-off peers contacted by make_all_rpcs */
+#ifdef RGB_X_DECLINE_HIST
+  const u64 *dbg_hist;    /* tools/train_decline_hist.py: counters of the hist build */
+#endif
 #ifdef RGB_PROFILE
   unsigned prof_nloads;   /* run-table words read by this lane */
   bool prof_noprobe;      /* knob 32: run-table probes answer from the last run (timing experiments only) */
@@ -933,14 +936,30 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
     const int k = find_run(L, nf);
     u64 *runs = const_cast<u64 *>(L.runs);
     if (k > 0) {
-      for (unsigned j = (unsigned)k; j < L.n_runs; ++j) {
-        u64 rs, rt;                                     /* the newest two runs are in registers */
-        if (j == L.n_runs - 1) { rs = L.lrs; rt = L.lrt; }
-        else if (j == L.n_runs - 2) { rs = L.prs; rt = L.prt; }
-        else { rs = ldg8(L.coh, runs + 2 * j); rt = ldg8(L.coh, runs + 2 * j + 1); }
-        runs[2 * (j - k)] = rs;
-        runs[2 * (j - k) + 1] = rt;
+      /* runs k .. n_runs-1 move to the front.  The in-memory ones (k .. n_runs-3) go FOUR AT A TIME -- four independent
+       * 16-byte loads, then four stores (a destination slot lies below every later source: k > 0) -- where round 4
+       * moved them word by word, every load behind the previous store's acknowledgement: in a train a wavefront with
+       * one lane that released ten runs spent 12 us here, and 3 in 4 wavefronts of the NEXT tick held a server that
+       * waited for it (profiles/r05_train_timeline.txt).  The newest two runs are in registers. */
+      ulonglong2 *rp = reinterpret_cast<ulonglong2 *>(runs);
+      const int n_mem = (int)L.n_runs - 2 - k;          /* in-memory runs that stay */
+#ifdef RGB_X_DECLINE_HIST
+      atomicAdd(const_cast<u64 *>(L.dbg_hist) + 96 + (n_mem < 0 ? 0 : n_mem > 15 ? 15 : n_mem), 1ull);
+#endif
+#pragma unroll 1
+      for (int i = 0; i < n_mem; i += 4) {
+        ulonglong2 t0 = make_ulonglong2(0, 0), t1 = t0, t2 = t0, t3 = t0;
+        t0 = ldg16(L.coh, rp + k + i);
+        if (i + 1 < n_mem) t1 = ldg16(L.coh, rp + k + i + 1);
+        if (i + 2 < n_mem) t2 = ldg16(L.coh, rp + k + i + 2);
+        if (i + 3 < n_mem) t3 = ldg16(L.coh, rp + k + i + 3);
+        ST16(rp + i, t0);
+        if (i + 1 < n_mem) ST16(rp + i + 1, t1);
+        if (i + 2 < n_mem) ST16(rp + i + 2, t2);
+        if (i + 3 < n_mem) ST16(rp + i + 3, t3);
       }
+      if ((int)L.n_runs - 2 >= k) ST16(rp + (L.n_runs - 2 - (unsigned)k), make_ulonglong2(L.prs, L.prt));
+      ST16(rp + (L.n_runs - 1 - (unsigned)k), make_ulonglong2(L.lrs, L.lrt));
       L.n_runs -= (unsigned)k;
     }
     if (L.n_runs > 0) runs[0] = nf;
@@ -1877,6 +1896,9 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 #ifdef RGB_PROFILE
   L.prof_noprobe = RGB_KNOB(dev, 32u); L.prof_nloads = 0;
 #endif
+#ifdef RGB_X_DECLINE_HIST
+  L.dbg_hist = dev.dbg_buf;
+#endif
   L.qry_base = dev.qry;
   L.q_loaded = false; L.q_dirty = 0; L.hb_mask = 0;
   L.qself = 0; L.hb_term = L.hb_qi = L.q_consensus = 0; L.cancel_mask = 0;
@@ -2346,20 +2368,32 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   if (first <= li && p >= first && p <= li) {
     if (p >= lrs) t = lrt;
     else if (n_runs >= 2 && p >= prs) t = prt;
-    else if (rrow != nullptr && n_runs <= (unsigned)RGB_RUNS_LDS + 2u) {
-      /* older than the mirrored runs: the in-memory runs (0 .. n_runs-3) are all in the table line the wavefront
-       * fetched into LDS with the rows (train launches; run k at rrow[k ^ swz]) -- the newest one that starts at or
-       * below p holds it (ra_log:fetch_term/2 inside the range, src/ra_log.erl:1186-1200) */
+    else {
+      /* older than the mirrored runs: the newest in-memory run (n_runs-3 .. 0) that starts at or below p holds it
+       * (ra_log:fetch_term/2 inside the range, src/ra_log.erl:1186-1200).  Train launches: runs 0..7 are in the table
+       * line the wavefront fetched into LDS with the rows (run k at rrow[k ^ swz]); the runs behind the line -- a table
+       * of more than ten runs: 3 % of the lanes of the closed loop, but two wavefronts in three had one and ran the
+       * whole general path for it (round 5) -- and every run of a per-tick launch are read from the table itself,
+       * newest first */
       bool found = false;
+      const ulonglong2 *rt = reinterpret_cast<const ulonglong2 *>(dev.runs + (size_t)server * dev.max_runs * 2u);
+      const int lds_runs = rrow != nullptr ? RGB_RUNS_LDS : 0;
+#pragma unroll 1
+      for (int k = (int)n_runs - 3; k >= lds_runs && !found; --k) {
+        const ulonglong2 r = ldg16(TR, rt + k);
+        if (p >= r.x) { t = r.y; found = true; }
+      }
+      if (rrow != nullptr) {
 #pragma unroll
-      for (int k = RGB_RUNS_LDS - 1; k >= 0; --k) {
-        if (!found && (unsigned)k + 3u <= n_runs) {
-          const ulonglong2 r = rrow[(unsigned)k ^ swz];
-          if (p >= r.x) { t = r.y; found = true; }
+        for (int k = RGB_RUNS_LDS - 1; k >= 0; --k) {
+          if (!found && (unsigned)k + 3u <= n_runs) {
+            const ulonglong2 r = rrow[(unsigned)k ^ swz];
+            if (p >= r.x) { t = r.y; found = true; }
+          }
         }
       }
       if (!found) FP_DECLINE(1, 8);
-    } else FP_DECLINE(1, 7);                                         /* more in-memory runs than the line holds: probe */
+    }
   }
   FP_TAKEN(1);
   if (t == UNDEF && si != UNDEF && si == p) t = st;
@@ -2963,7 +2997,11 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
  * resident wavefronts / wavefront life, and the spills' scratch round trips sit on the clause code's dependency chain
  * -- 4 x 128 measured 24-25 us per tick, 3 x 168 19-20 */
 #ifndef RGB_TRAIN_MIN_WAVES
+#ifdef RGB_X_TRAIN_WAVES            /* (a plain number on the command line: tools/build_variants.sh) */
+#define RGB_TRAIN_MIN_WAVES(N) RGB_X_TRAIN_WAVES
+#else
 #define RGB_TRAIN_MIN_WAVES(N) 3
+#endif
 #endif
 #define RGB_TRAIN_CTL_ARRIVE 8u     /* ctl words 8..15: blocks arrived per XCC (devices with fewer XCCs than shards) */
 #define RGB_TRAIN_CTL_TICKET 32u    /* ctl word 32 (1 + x): next row of shard x (one 128-byte line per shard)         */
@@ -3111,10 +3149,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
                                 1u << ((rgb_xcc_id() - x) & (RGB_TRAIN_SHARDS - 1u)));
 }
 
-/* In FRONT of every train launch (where round 3 had a memset node): the rotation marks the previous dealt launch on
- * these control words left must be one bit -- all of them have landed, the launches are ordered by the stream --
- * else RGB_TRAIN_ERR_PLACEMENT (sticky, word 0); then every per-launch word is cleared.  clear = 0: verify only
- * (rgb_train_status and rgb_submit check the LAST launch this way). */
+/* BEHIND every train launch (rgb_launch_train): the rotation marks the dealt launch left on these control words must
+ * be one bit -- all of them have landed, the kernels are ordered by the stream -- else RGB_TRAIN_ERR_PLACEMENT (sticky,
+ * word 0); then every per-launch word is cleared for the next launch.  clear = 0: verify only. */
 __global__ void rgb_train_prolog_kernel(u32 *__restrict__ ctl, u32 clear) {
   if (threadIdx.x < RGB_TRAIN_MARK_WORDS) {
     u32 v = ctl[RGB_TRAIN_CTL_MARK + 32u * threadIdx.x];
@@ -3402,7 +3439,7 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
     } else if (ld.lwi < ld.li && (r & 3) == 0) {
       const u64 a = ld.lwi + 1 > ld.first ? ld.lwi + 1 : ld.first;
       SynMsg w = syn_msg(sid(l), RGB_MSG_WRITTEN, RGB_NONE, 0, ld.lt, a, ld.li, 0);
-      w.off_steady = RGB_X_HINT;                          /* the owner is in state leader (ra_server_proc knows) */
+      w.off_steady = RGB_X_HINT && dev.synth_hint >= 1u;   /* the owner is in state leader (ra_server_proc knows) */
       emit(w);
     } else if (hb_lag >= 0 && (r >> 40) % 3 == 0) {
       /* a follower that has not confirmed the current query index answers the heartbeat */
@@ -3462,12 +3499,21 @@ __device__ __forceinline__ void synth_group(const rgb_dev &dev, u64 seed, u64 ti
         }
       }
       SynMsg w = syn_msg(sid(j), RGB_MSG_AER, l, 0, ld.ct, prev_i, prev_t, ld.ci, n_ent, n_ent, run0);
-      w.off_steady = RGB_X_HINT && pk_get(f.pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER;     /* the receiver's own state name */
+      /* the receiver's own state name; level 2: + what its owner sees by comparing the rpc's header with fields it
+       * holds (current_term, leader_id, ra_log's last index and term: src/ra_server.erl:1283-1303 reads exactly
+       * these) -- not a plain append at the tail from the leader it knows, in the term it is in */
+      bool off = pk_get(f.pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER;
+      if (dev.synth_hint >= 2u)
+        off = off || f.ct != ld.ct || (unsigned)pk_get(f.pk, PK_LEADER_SH, 4) != (unsigned)l || !(f.first <= f.li) ||
+              prev_i != f.li || prev_t != f.lt || (n_ent != 0 && run0 != f.lt);
+      w.off_steady = RGB_X_HINT && dev.synth_hint >= 1u && off;
       emit(w);
     } else if (f.lwi < f.li && f.first <= f.li && (r >> 8) % 10 < 8) {
       const u64 a = f.lwi + 1 > f.first ? f.lwi + 1 : f.first;
       SynMsg w = syn_msg(sid(j), RGB_MSG_WRITTEN, RGB_NONE, 0, f.lt, a, f.li, 0);
-      w.off_steady = RGB_X_HINT && pk_get(f.pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER;
+      bool off = pk_get(f.pk, PK_ROLE_SH, 3) != RGB_ROLE_FOLLOWER;
+      if (dev.synth_hint >= 2u) off = off || (unsigned)pk_get(f.pk, PK_LEADER_SH, 4) == SLOT_NONE4;   /* nobody to reply to */
+      w.off_steady = RGB_X_HINT && dev.synth_hint >= 1u && off;
       emit(w);
     }
   }
@@ -3969,6 +4015,15 @@ extern "C" void rgb_train_set_lead(const float *lead) {      /* tuning hook of t
   for (int c = 0; c < RGB_N_CLASSES; ++c) rgb_train_lead[c] = lead[c];
 }
 
+/* the merge key of row j of a plan class with `rows` rows, as ONE expression for the host's merge and the device's
+ * rank computation (rgb_train_plan_kernel): no contraction into a fused multiply-add, so that both produce the same
+ * doubles and therefore the same table */
+static inline __host__ __device__ double rgb_plan_key(u32 j, double step, double lead) {
+#pragma clang fp contract(off)
+  const double pos = (2.0 * (double)j + 1.0) * 0.5 * step;
+  return pos - lead;
+}
+
 u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap,
                         u32 snap_rows) {
   u32 acc = 0;
@@ -4016,7 +4071,7 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
   unsigned n_act = 0;
   if (snap_rows) {                                           /* (first: it wins every tie) */
     act[0] = (int)RGB_PC_SNAP; next[0] = 0; step[0] = 1.0 / (double)snap_rows; lead_of[0] = (double)RGB_SNAP_LEAD;
-    key[0] = 0.5 * step[0] - lead_of[0];
+    key[0] = rgb_plan_key(0, step[0], lead_of[0]);
     n_act = 1;
   }
   for (unsigned q = 0; q < RGB_N_CLASSES; ++q) {
@@ -4027,7 +4082,7 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
       act[n_act] = pc; next[n_act] = 0;
       step[n_act] = 1.0 / (double)rows_of[pc];
       lead_of[n_act] = (double)rgb_train_lead[c];
-      key[n_act] = 0.5 * step[n_act] - lead_of[n_act];
+      key[n_act] = rgb_plan_key(0, step[n_act], lead_of[n_act]);
       n_act += 1;
     }
   }
@@ -4038,9 +4093,150 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
     row_tab[k] = ((u32)act[best] << 24) | next[best];
     next[best] += 1;
     if (next[best] >= rows_of[act[best]]) key[best] = 1e300;     /* exhausted */
-    else key[best] = (2.0 * next[best] + 1.0) * 0.5 * step[best] - lead_of[best];
+    else key[best] = rgb_plan_key(next[best], step[best], lead_of[best]);
   }
   return total;
+}
+
+/* The same plan built ON THE DEVICE (round 5): one block per tick, from the bucket counts a device-side producer left
+ * in device memory -- no copy of the counts to the host, no host merge, no upload of the tables between the producer
+ * and the launch (rgb_train_plan_build_device).  Offsets = the exclusive prefix sum over the tick's 256 buckets; rows
+ * per plan class = its fullest shard's slices; the row table by RANK: the place of row j of plan class a in the merged
+ * order is the number of rows with a smaller key (or an equal key and an earlier place in the heaviest-first list),
+ * counted class by class with a binary search over that class's keys -- the same keys, as the same doubles
+ * (rgb_plan_key), as the host's merge compares: the two tables are equal bit for bit (tests/test_train.py). */
+struct rgb_plan_leads { float lead[RGB_N_CLASSES]; };
+#ifdef RGB_HOST_EMULATION
+#define RGB_PLAN_THREADS 256      /* (a fiber per lane: the test build keeps the block small) */
+#else
+#define RGB_PLAN_THREADS 1024     /* one row per thread for ticks of up to 1024 rows */
+#endif
+__global__ __launch_bounds__(1024) void rgb_train_plan_kernel(const u32 *__restrict__ bucket_counts,
+                                                             rgb_train_tick *__restrict__ ticks, u32 *__restrict__ rows,
+                                                             u32 rpt, u32 first_tick, u32 snapshot_every, u32 snap_rows_n,
+                                                             u32 n_members, rgb_plan_leads LD, u32 *__restrict__ err) {
+  __shared__ u32 bc[RGB_N_BUCKETS], pre[RGB_N_BUCKETS];
+  __shared__ u32 rows_of[RGB_N_PCLASSES + 1u], cum[RGB_N_PCLASSES + 2u], nb_s[RGB_N_PCLASSES + 1u], n_act_s;
+  __shared__ int act[RGB_N_PCLASSES + 1u];
+  __shared__ double step_s[RGB_N_PCLASSES + 1u], lead_s[RGB_N_PCLASSES + 1u];
+  const u32 t = blockIdx.x, gt = first_tick + t, tid = threadIdx.x;
+  const u32 *cnts = bucket_counts + (size_t)t * RGB_N_BUCKETS;
+  rgb_train_tick *out = ticks + gt;
+  /* exclusive prefix sum over the 256 buckets (Hillis-Steele in LDS: eight steps) */
+  static_assert(RGB_N_BUCKETS == 256u, "one bucket per thread of the first 256");
+  u32 mine = 0;
+  if (tid < RGB_N_BUCKETS) { mine = cnts[tid]; bc[tid] = mine; pre[tid] = mine; }
+  __syncthreads();
+#pragma unroll 1
+  for (u32 d = 1; d < RGB_N_BUCKETS; d <<= 1) {
+    u32 v = 0;
+    if (tid < RGB_N_BUCKETS) v = pre[tid] + (tid >= d ? pre[tid - d] : 0u);
+    __syncthreads();
+    if (tid < RGB_N_BUCKETS) pre[tid] = v;
+    __syncthreads();
+  }
+  if (tid < RGB_N_BUCKETS) pre[tid] -= mine;                    /* inclusive -> exclusive */
+  __syncthreads();
+  const u32 snap_rows = (snapshot_every && gt && gt % snapshot_every == 0u) ? snap_rows_n : 0u;
+  if (tid < RGB_N_PCLASSES) {
+    const u32 pc = tid, c = pc >> 1, sub = pc & 1u;
+    const u32 sl = rgb_class_slice((int)c, n_members);
+    u32 need = 0;
+    for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) {
+      const u32 b = (c * RGB_TRAIN_SHARDS + x) * 2u + sub;       /* the stream is bucket-major: (class, shard, sub) */
+      const u32 n = bc[b];
+      out->off[pc][x] = pre[b]; out->cnt[pc][x] = n;
+      const u32 r = (n + sl - 1u) / sl;
+      need = r > need ? r : need;
+    }
+    rows_of[pc] = need;
+  }
+  if (tid == RGB_N_PCLASSES) rows_of[RGB_PC_SNAP] = snap_rows;
+  __syncthreads();
+  /* the non-empty plan classes in the host's tie-break order -- the snapshot's rows first, then heaviest class first,
+   * sub-bucket 0 before 1 -- one thread per candidate: its place in the list is the number of non-empty candidates in
+   * front of it, its first row the sum of their rows */
+  if (tid <= RGB_N_PCLASSES) {
+    const u32 q = tid;                                          /* 0: snapshot; 1 + 2 x position + sub */
+    const int c = q ? rgb_class_at((q - 1u) >> 1) : 0;
+    const int pc = q ? 2 * c + (int)((q - 1u) & 1u) : (int)RGB_PC_SNAP;
+    const u32 mine_rows = rows_of[pc];
+    u32 pos = 0, first = 0;
+    for (u32 e = 0; e < q; ++e) {
+      const int ce = e ? rgb_class_at((e - 1u) >> 1) : 0;
+      const u32 r = rows_of[e ? 2 * ce + (int)((e - 1u) & 1u) : (int)RGB_PC_SNAP];
+      pos += r ? 1u : 0u; first += r;
+    }
+    if (mine_rows) {
+      act[pos] = pc; nb_s[pos] = mine_rows; cum[pos] = first;
+      step_s[pos] = 1.0 / (double)mine_rows;
+      lead_s[pos] = q ? (double)LD.lead[c] : (double)RGB_SNAP_LEAD;
+    }
+    if (q == RGB_N_PCLASSES) {                                  /* the last candidate closes the list */
+      const u32 n = pos + (mine_rows ? 1u : 0u), total = first + mine_rows;
+      cum[n] = total;
+      n_act_s = n;
+      out->n_rows = total; out->msg_base = 0;
+      out->snap = snap_rows ? gt / snapshot_every : 0u;
+      for (int k = 0; k < 13; ++k) out->pad[k] = 0;
+      if (total > rpt) atomicOr(err, (u32)RGB_TRAIN_ERR_PLAN);     /* the table's rows do not hold this tick */
+    }
+  }
+  __syncthreads();
+  const u32 n_act = n_act_s, total = cum[n_act];
+  if (total > rpt) return;
+  u32 *tab = rows + (size_t)gt * rpt;
+  for (u32 i = tid; i < total; i += blockDim.x) {
+    u32 a = 0;
+#pragma unroll 8
+    for (u32 e = 1; e < n_act; ++e) a += i >= cum[e] ? 1u : 0u;  /* (independent reads: the list is short) */
+    const u32 j = i - cum[a];
+    const double k = rgb_plan_key(j, step_s[a], lead_s[a]);
+    u32 rank = j;
+#pragma unroll 4
+    for (u32 b = 0; b < n_act; ++b) {
+      if (b == a) continue;
+      /* rows of b in front of (a, j): key_b < k, or key_b == k for the classes listed before a.  The keys of a class
+       * are (j' + 1/2) / rows_b - lead_b: the count is about (k + lead_b) rows_b - 1/2 -- estimated in closed form,
+       * then settled by the exact comparison of the keys themselves (the predicate is monotone in j') */
+      const u32 nb = nb_s[b];
+      const double sb = step_s[b], lb = lead_s[b];
+      const double est = (k + lb) * (double)nb - 0.5;
+      u32 lo = est <= 0.0 ? 0u : est >= (double)nb ? nb : (u32)est;
+      for (;;) {                                                   /* lo = the first j' that is not in front */
+        if (lo < nb) {
+          const double kb = rgb_plan_key(lo, sb, lb);
+          if (b < a ? kb <= k : kb < k) { ++lo; continue; }
+        }
+        if (lo > 0u) {
+          const double kb = rgb_plan_key(lo - 1u, sb, lb);
+          if (!(b < a ? kb <= k : kb < k)) { --lo; continue; }
+        }
+        break;
+      }
+      rank += lo;
+    }
+    tab[rank] = ((u32)act[a] << 24) | j;
+  }
+}
+
+int rgb_launch_train_plan(const u32 *d_bucket_counts, rgb_train_tick *d_ticks, u32 *d_rows, u32 rpt, u32 first_tick,
+                          u32 n_ticks, u32 snapshot_every, u32 n_groups, u32 n_members, u32 *d_err, void *stream) {
+  (void)hipGetLastError();
+  if (n_ticks == 0) return 0;
+  rgb_plan_leads ld;
+  for (int c = 0; c < RGB_N_CLASSES; ++c) ld.lead[c] = rgb_train_lead[c];
+  hipLaunchKernelGGL(rgb_train_plan_kernel, dim3(n_ticks), dim3(RGB_PLAN_THREADS), 0, (hipStream_t)stream, d_bucket_counts, d_ticks, d_rows,
+                     rpt, first_tick, snapshot_every, rgb_train_snap_rows(n_groups), n_members, ld, d_err);
+  return (int)hipGetLastError();
+}
+
+u32 rgb_train_rows_bound(u32 n_servers, u32 n_members, bool with_snapshot) {
+  /* a shard holds at most ceil(groups / 8) x members messages per tick; every non-empty plan class may end in a
+   * partial slice; the smallest slice is 32 messages */
+  const u32 groups = n_servers / n_members;
+  const u32 per_shard = ((groups + RGB_TRAIN_SHARDS - 1u) / RGB_TRAIN_SHARDS) * n_members;
+  return (per_shard + 31u) / 32u + RGB_N_PCLASSES + (with_snapshot ? rgb_train_snap_rows(groups) : 0u);
 }
 
 /* blocks a persistent train launch should have: every wavefront slot of the device (occupancy x compute units) */
@@ -4082,9 +4278,9 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
   if (bpt % RGB_TRAIN_SHARDS || n_ticks > RGB_TRAIN_MAX_TICKS) return -1;
   if (n_xcc == 0 || n_xcc > RGB_TRAIN_SHARDS || (n_xcc & (n_xcc - 1u)) != 0 || n_blocks < RGB_TRAIN_SHARDS) return -1;
   hipStream_t st = (hipStream_t)stream;
-  /* the previous launch's rotation marks are verified, then every per-launch word (arrival and ticket counters, the
-   * marks) is cleared; the error word (d_ctl[0]) is sticky until it is read */
+#ifdef RGB_X_PROLOG_FRONT      /* A/B timing only: rounds 3-4 */
   hipLaunchKernelGGL(rgb_train_prolog_kernel, dim3(1), dim3(256), 0, st, d_ctl, 1u);
+#endif
   /* never more blocks than rows: a block without a row only costs its ticket */
   const uint64_t rows = (uint64_t)n_ticks * bpt;
   dim3 grid((u32)(rows < n_blocks ? rows : n_blocks)), block(RGB_TICK_BLOCK);
@@ -4109,6 +4305,14 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
     default: return -1;
   }
 #undef LAUNCH
+  /* BEHIND the launch (round 5; rounds 3-4 ran it in front of the NEXT one, where its launch and its 5 us stood
+   * between the caller's submission and the first tick): this launch's rotation marks are verified -- the error word
+   * (d_ctl[0], sticky until it is read) is final when the stream reaches whatever follows -- and every per-launch word
+   * (arrival and ticket counters, the marks) is cleared for the next launch on these control words, which a context
+   * hands out zeroed */
+#ifndef RGB_X_PROLOG_FRONT
+  hipLaunchKernelGGL(rgb_train_prolog_kernel, dim3(1), dim3(256), 0, st, d_ctl, 1u);
+#endif
   return (int)hipGetLastError();
 }
 

@@ -26,16 +26,19 @@ EXPORTS = [
     "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status", "rgb_train_form", "rgb_train_recoveries",
     "rgb_train_plan_create_snap", "rgb_train_run_snap_device", "rgb_snapshot_train_device", "rgb_train_seq_bytes",
+    "rgb_train_plan_create_device", "rgb_train_plan_build_device", "rgb_train_plan_download",
 ]
 COMM_EXPORTS = ["rgb_comm_unique_id", "rgb_comm_init_rank", "rgb_comm_destroy", "rgb_comm_n_ranks", "rgb_comm_rank",
                 "rgb_leaderboard_allgather", "rgb_leaderboard_allgather_host", "rgb_comm_last_error"]   # the one collective of the path (RCCL)
 EXPORTS += COMM_EXPORTS
 SYNTH_EXPORTS = ["rgb_synth_tick_device", "rgb_synth_tick_buckets_device", "rgb_synth_apply_tick_device",
                  "rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device",
-                 "rgb_synth_snapshot_mark_device"]                                       # include/ra_gpu_batch_synth.h (bench tooling)
+                 "rgb_synth_snapshot_mark_device", "rgb_synth_set_hint"]                                       # include/ra_gpu_batch_synth.h (bench tooling)
 OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_resync_device", "rgb_train_form",
                           "rgb_train_recoveries", "rgb_train_plan_create_snap", "rgb_train_run_snap_device",
-                          "rgb_snapshot_train_device", "rgb_train_seq_bytes", "rgb_synth_snapshot_mark_device"} | set(COMM_EXPORTS)
+                          "rgb_snapshot_train_device", "rgb_train_seq_bytes", "rgb_synth_snapshot_mark_device",
+                          "rgb_synth_set_hint", "rgb_train_plan_create_device", "rgb_train_plan_build_device",
+                          "rgb_train_plan_download"} | set(COMM_EXPORTS)
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -151,6 +154,10 @@ def lib():
     L.rgb_train_run_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, u32, vp]
     if hasattr(L, "rgb_train_run_snap_device"):
         L.rgb_train_plan_create_snap.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+    if hasattr(L, "rgb_train_plan_create_device"):
+        L.rgb_train_plan_create_device.argtypes = [vp, u32, u32, C.POINTER(vp)]
+        L.rgb_train_plan_build_device.argtypes = [vp, vp, u32, u32, vp, vp]
+        L.rgb_train_plan_download.argtypes = [vp, vp, u32, vp, vp, u32]
         L.rgb_train_run_snap_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, u32, vp, vp, vp]
         L.rgb_snapshot_train_device.argtypes = [vp, vp, vp]
         L.rgb_train_seq_bytes.restype = C.c_uint32
@@ -158,6 +165,8 @@ def lib():
         L.rgb_synth_snapshot_mark_device.argtypes = [vp, vp, vp]
     L.rgb_train_status.argtypes = [vp, C.POINTER(u32), vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
+    if hasattr(L, "rgb_synth_set_hint"):
+        L.rgb_synth_set_hint.argtypes = [vp, u32]
     L.rgb_wal_adler32_device.argtypes = [vp, vp, u32, vp, C.c_uint64, vp, vp]
     L.rgb_wal_adler32.argtypes = [vp, vp, u32, vp, C.c_uint64, vp]
     L.rgb_wal_layout.restype = C.c_uint64
@@ -412,6 +421,10 @@ class RaGpuBatch:
     def train_recoveries(self) -> int:
         return int(self._L.rgb_train_recoveries(self._h))
 
+    def synth_set_hint(self, level: int):
+        """The generator's ordering hint (include/ra_gpu_batch_synth.h): 0 none, 1 state name, 2 + header compare."""
+        self._check(self._L.rgb_synth_set_hint(self._h, level), "rgb_synth_set_hint")
+
     def synth_apply_tick_device(self, d_msgs: int, max_msgs: int, d_decisions: int, d_rpcs: int = 0,
                                 stream: int = 0):
         """Apply the tick just generated by synth_tick_device (class-dispatch kernel sized on-device)."""
@@ -528,10 +541,19 @@ class Comm:
 class TrainPlan:
     """Device plan of a train (rgb_train_plan): bucket_counts = uint32[n_ticks][TRAIN_BUCKETS]."""
 
-    def __init__(self, eng: "RaGpuBatch", bucket_counts: np.ndarray, snapshot_every: int = 0):
+    def __init__(self, eng: "RaGpuBatch", bucket_counts, snapshot_every: int = 0, device_ticks: int = 0):
+        """bucket_counts (host array): the plan is built on the host and uploaded.  device_ticks > 0 (bucket_counts =
+        None): an empty plan of that many ticks for build_device() -- rgb_train_plan_create_device."""
+        h = C.c_void_p()
+        if device_ticks:
+            self.eng, self.n_ticks, self.snapshot_every = eng, device_ticks, snapshot_every
+            eng._check(eng._L.rgb_train_plan_create_device(eng._h, device_ticks, snapshot_every, C.byref(h)),
+                       "rgb_train_plan_create_device")
+            self.h = h
+            self.blocks_per_tick = int(eng._L.rgb_train_plan_blocks_per_tick(h))
+            return
         bc = np.ascontiguousarray(bucket_counts, dtype=np.uint32).reshape(-1, TRAIN_BUCKETS)
         self.eng, self.n_ticks, self.snapshot_every = eng, len(bc), snapshot_every
-        h = C.c_void_p()
         if snapshot_every:
             eng._check(eng._L.rgb_train_plan_create_snap(eng._h, bc.ctypes.data, len(bc), snapshot_every, C.byref(h)),
                        "rgb_train_plan_create_snap")
@@ -539,6 +561,22 @@ class TrainPlan:
             eng._check(eng._L.rgb_train_plan_create(eng._h, bc.ctypes.data, len(bc), C.byref(h)), "rgb_train_plan_create")
         self.h = h
         self.blocks_per_tick = int(eng._L.rgb_train_plan_blocks_per_tick(h))
+
+    def download(self, tick: int):
+        """(header words uint32[16], off uint32[30][8], cnt uint32[30][8], row table uint32[n_rows]) of one tick as it
+        stands on the device (rgb_train_plan_download; synchronises)."""
+        raw = np.zeros(496, dtype=np.uint32)                      # sizeof(rgb_train_tick) = 1984
+        rows = np.zeros(max(self.blocks_per_tick // 8, 1), dtype=np.uint32)
+        n = self.eng._L.rgb_train_plan_download(self.eng._h, self.h, tick, raw.ctypes.data, rows.ctypes.data, len(rows))
+        if n < 0:
+            raise RgbError(n, "rgb_train_plan_download")
+        return raw[:16].copy(), raw[16:256].reshape(30, 8).copy(), raw[256:496].reshape(30, 8).copy(), rows[:n].copy()
+
+    def build_device(self, first_tick: int, n_ticks: int, d_bucket_counts: int, stream: int = 0):
+        """Ticks [first_tick, first_tick + n_ticks) from uint32[n_ticks][TRAIN_BUCKETS] in DEVICE memory, one kernel
+        on `stream` (rgb_train_plan_build_device): nothing of the plan passes through the host."""
+        self.eng._check(self.eng._L.rgb_train_plan_build_device(self.eng._h, self.h, first_tick, n_ticks, d_bucket_counts,
+                                                                stream or None), "rgb_train_plan_build_device")
 
     def close(self):
         if self.h:

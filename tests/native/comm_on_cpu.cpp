@@ -44,7 +44,17 @@ int rgb_comm_init_rank(rgb_ctx *ctx, const void *id, uint32_t n_ranks, uint32_t 
 void rgb_comm_destroy(rgb_comm *comm) { free(comm); }
 uint32_t rgb_comm_n_ranks(const rgb_comm *comm) { return comm ? comm->n_ranks : 0; }
 uint32_t rgb_comm_rank(const rgb_comm *comm) { return comm ? comm->rank : 0; }
-const char *rgb_comm_last_error(void) { return ""; }
+static const char *g_text = "";
+const char *rgb_comm_last_error(void) { return g_text; }
+void rgb_comm_set_error_text(const char *why) { g_text = why ? why : ""; }
+int rgb_comm_abort(rgb_comm *comm, const char *why) { (void)comm; g_text = why ? why : ""; return RGB_E_COMM; }
+int rgb_comm_allgather_bytes(rgb_comm *comm, const void *d_local, uint64_t bytes, void *d_all, void *stream) {
+  (void)stream;
+  if (!comm || !d_local || !d_all) return RGB_E_INVAL;
+  if (comm->n_ranks == 1) { if (d_all != d_local) memmove(d_all, d_local, bytes); return RGB_OK; }
+  if (!g_transport) return RGB_E_UNSUPPORTED;
+  return g_transport(d_local, bytes, d_all, comm->n_ranks, comm->rank) ? RGB_E_COMM : RGB_OK;
+}
 
 int rgb_leaderboard_allgather(rgb_ctx *ctx, rgb_comm *comm, const void *d_rows_local, uint32_t n_rows, void *d_rows_all,
                               void *stream) {

@@ -28,6 +28,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
 /* Block emulation (tests/native/kernel_on_cpu.cpp): every lane of a block is a fiber; __syncthreads() hands
  * control back to the scheduler until all live lanes of the block have arrived, __shfl exchanges through a
@@ -84,6 +85,7 @@ static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 /* v_dot4_u32_u8 */
 static inline unsigned emu_udot4(unsigned a, unsigned b, unsigned c) {
   for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xFFu) * ((b >> (8 * k)) & 0xFFu);

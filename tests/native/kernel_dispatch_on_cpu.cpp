@@ -115,6 +115,12 @@ int rgb_launch_count_rpcs__N1(const rgb_decision *d_dec, u32 n, u32 *d_out, void
 int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream) { return rgb_launch_count_rpcs__N1(d_dec, n, d_out, stream); }
 int rgb_launch_unpermute__N1(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream);
 int rgb_launch_unpermute(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream) { return rgb_launch_unpermute__N1(d_dec, d_pos, n, d_out, stream); }
+int rgb_launch_train_plan__N1(const u32 *d_bucket_counts, rgb_train_tick *d_ticks, u32 *d_rows, u32 rpt, u32 first_tick, u32 n_ticks, u32 snapshot_every, u32 n_groups, u32 n_members, u32 *d_err, void *stream);
+int rgb_launch_train_plan(const u32 *d_bucket_counts, rgb_train_tick *d_ticks, u32 *d_rows, u32 rpt, u32 first_tick, u32 n_ticks, u32 snapshot_every, u32 n_groups, u32 n_members, u32 *d_err, void *stream) {
+  return rgb_launch_train_plan__N1(d_bucket_counts, d_ticks, d_rows, rpt, first_tick, n_ticks, snapshot_every, n_groups, n_members, d_err, stream);
+}
+u32 rgb_train_rows_bound__N1(u32 n_servers, u32 n_members, bool with_snapshot);
+u32 rgb_train_rows_bound(u32 n_servers, u32 n_members, bool with_snapshot) { return rgb_train_rows_bound__N1(n_servers, n_members, with_snapshot); }
 /* the row plan reads rgb_train_lead[] of ITS unit: the tuning hook sets every copy, the plan comes from N = 1's */
 u32 rgb_train_make_tick__N1(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap, u32 snap_rows);
 u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_tick *out, u32 *row_tab, u32 row_cap, u32 snap_rows) {

@@ -140,6 +140,35 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
                 assert x.tobytes() == y.tobytes(), f"rpc records of tick {t} message {i}"
         assert eng.get_state().tobytes() == r["st_end"].tobytes(), f"chunk {chunk}: final state differs"
         assert eng.state_checksum() == r["sum_end"]
+    # the plan built ON THE DEVICE from the bucket counts in device memory (rgb_train_plan_build_device): the same
+    # tables as the host's, bit for bit, tick by tick; and a train that runs from it (persistent form) computes the same
+    dbc = Buf(T * engine.TRAIN_BUCKETS * 4, on_gpu)
+    if on_gpu:
+        import torch
+        dbc.t.copy_(torch.from_numpy(r["buckets"].reshape(-1).view(np.uint8).copy()))
+    else:
+        dbc.a[:] = r["buckets"].reshape(-1).view(np.uint8)
+    dplan = engine.TrainPlan(eng, None, device_ticks=T)
+    half = T // 2                                           # built in two calls: ticks [0, half) and [half, T)
+    dplan.build_device(0, half, dbc.ptr)
+    dplan.build_device(half, T - half, dbc.ptr + half * engine.TRAIN_BUCKETS * 4)
+    for t in range(T):
+        hh, ho, hc, hr = plan.download(t)
+        dh, do_, dc, dr = dplan.download(t)
+        assert np.array_equal(hh, dh), f"tick {t}: header {hh} vs {dh}"
+        assert np.array_equal(ho, do_) and np.array_equal(hc, dc), f"tick {t}: offsets / counts"
+        assert np.array_equal(hr, dr), f"tick {t}: row table differs at {np.flatnonzero(hr != dr)[:5]}"
+    eng.set_state(0, r["st_start"])
+    dec3, rpc3 = Buf(T * tb, on_gpu), Buf(T * rs, on_gpu)
+    eng.train_stamp_device(r["msgs"].ptr, stamps.ptr, S, r["counts"])
+    eng.train_run_device(dplan, 0, T, r["msgs"].ptr, stamps.ptr, S, dec3.ptr, rpc3.ptr, rpc_ring=T)
+    eng.synchronize()
+    assert eng.train_status()[0] == 0
+    for t in range(T):
+        got = _tick(dec3, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE)
+        assert got.tobytes() == want_dec[t].tobytes(), f"device-built plan: decisions of tick {t}"
+    assert eng.get_state().tobytes() == r["st_end"].tobytes(), "device-built plan: final state differs"
+    dplan.close()
     plan.close()
     eng.close()
 
@@ -238,6 +267,17 @@ def check_snapshots_inside_a_train(engine, G, N, T, every, seed, on_gpu, windows
     buckets = bc.host().view(np.uint32)[:T * engine.TRAIN_BUCKETS].reshape(T, engine.TRAIN_BUCKETS).copy()
     sum_end = eng.state_checksum()
     plan = eng.train_plan_snap(buckets, every)
+    # the same plan built on the device (the snapshot's rows lead every tick k * every): equal tables; the one-launch
+    # cases replay from the device-built plan (persistent form)
+    dplan = engine.TrainPlan(eng, None, snapshot_every=every, device_ticks=T)
+    dplan.build_device(0, T, bc.ptr)
+    eng.synchronize()
+    for t in range(T):
+        hh, ho, hc, hr = plan.download(t)
+        dh, do_, dc, dr = dplan.download(t)
+        assert np.array_equal(hh, dh) and np.array_equal(ho, do_) and np.array_equal(hc, dc), f"tick {t}: header / offsets"
+        assert np.array_equal(hr, dr), f"tick {t}: row table differs at {np.flatnonzero(hr != dr)[:5]}"
+    run_plan = dplan if len(windows) == 1 else plan
     eng.set_state(0, st0)
     t = 0
     for n in windows:
@@ -246,7 +286,7 @@ def check_snapshots_inside_a_train(engine, G, N, T, every, seed, on_gpu, windows
             break
         if t and t % every == 0:                             # the boundary in front of a launch: outside it
             eng.snapshot_train_device(rows_got.ptr + (t // every - 1) * G * 32)
-        eng.train_run_snap_device(plan, t, n, msgs.ptr, stamps.ptr, S, dec2.ptr, rpcs.ptr, 4, snap_stamps.ptr, rows_got.ptr)
+        eng.train_run_snap_device(run_plan, t, n, msgs.ptr, stamps.ptr, S, dec2.ptr, rpcs.ptr, 4, snap_stamps.ptr, rows_got.ptr)
         t += n
     assert t == T
     eng.synchronize()
@@ -262,6 +302,7 @@ def check_snapshots_inside_a_train(engine, G, N, T, every, seed, on_gpu, windows
     # a plan with snapshots cannot run without their buffers (the sequence bytes would fall behind the stamps)
     with pytest.raises(engine.RgbError):
         eng.train_run_device(plan, 0, T, msgs.ptr, stamps.ptr, S, dec2.ptr)
+    dplan.close()
     plan.close()
     eng.close()
 

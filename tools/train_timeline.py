@@ -11,6 +11,8 @@ T, AGE = int(os.environ.get("TL_TICKS", "16")), int(os.environ.get("TL_AGE", "12
 S = G * N; tb = S * 64
 eng = engine.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64)
 eng.set_state(0, W.initial_states(G, N, 0x5EED0003))
+if os.environ.get("TL_HINT") is not None:
+    eng.synth_set_hint(int(os.environ["TL_HINT"]))
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); sp = stream.cuda_stream
 dm = torch.empty(T * tb, dtype=torch.uint8, device="cuda"); dd = torch.empty(T * tb, dtype=torch.uint8, device="cuda")
 dr = torch.empty(4 * S * 4 * 56, dtype=torch.uint8, device="cuda")
@@ -69,6 +71,34 @@ for c in sorted(set(cls)):
     md = np.median(d, axis=0); p9 = np.percentile(d, 90, axis=0)
     print(f"  {names.get(c, c):>12}: {m.sum():6d} | {md[0]:5.2f} | {md[1]:5.2f} p90 {p9[1]:5.2f} ({np.median(spins[m]):.0f}/{np.percentile(spins[m],90):.0f}) | {md[2]:5.2f} | "
           f"{md[3]:5.2f} p90 {p9[3]:5.2f} | {md[4]:5.2f} | {md[5]:5.2f} | {np.median(us[m,6]-us[m,0]):5.2f}")
+# means and shares: the tick is (wavefronts x MEAN life) / resident wavefronts -- the tails count
+cntl = ((b[:, 7] >> np.uint64(8)) & np.uint64(0xFF)).astype(int)
+tot = (us[mid, 6] - us[mid, 0]).sum()
+print("the same by MEANS: waves | lanes per wave | msg load | dep wait | row fetch | clause | publish | dec store | life | share of all wave-time")
+for c in sorted(set(cls)):
+    m = mid & (cls == c)
+    if not m.any(): continue
+    d = np.diff(us[m], axis=1).mean(axis=0)
+    life = us[m, 6] - us[m, 0]
+    print(f"  {names.get(c, c):>12}: {m.sum():6d} | {cntl[m].mean():5.1f} | {d[0]:5.2f} | {d[1]:5.2f} | {d[2]:5.2f} | {d[3]:5.2f} | {d[4]:5.2f} | {d[5]:5.2f} | "
+          f"{life.mean():5.2f} | {100.0 * life.sum() / tot:5.1f} %")
+ticks_mid = len(set(tick_of[mid]))
+print(f"  all: {mid.sum() / ticks_mid:.0f} wavefronts per tick, mean life {tot / mid.sum():.2f} us, wave-time per tick {tot / ticks_mid:.0f} us "
+      f"(/ 3072 slots = {tot / ticks_mid / 3072:.2f} us per tick if every slot were always busy)")
+# who commits late?  start -> publish above 12 / 14 / 16 us (what the next tick's wavefronts wait for), per class
+pub = us[:, 5] - us[:, 0]; nowait = pub - (us[:, 2] - us[:, 1])
+print("wavefronts per tick whose start->publish exceeds 12 / 14 / 16 us (of which: without their own dependency wait), per class")
+for c in sorted(set(cls)):
+    m = mid & (cls == c)
+    if not m.any(): continue
+    print(f"  {names.get(c, c):>12}: " + "  ".join(f">{x}: {(pub[m] > x).sum() / ticks_mid:6.1f} ({(nowait[m] > x).sum() / ticks_mid:6.1f})" for x in (12, 14, 16)))
+# clause-time histogram of the three bulk classes (fast-path-only wavefronts against the ones that ran the general path)
+for c in (0, 1, 2):
+    m = mid & (cls == c)
+    if not m.any(): continue
+    cl = us[m, 4] - us[m, 3]
+    hist, edges = np.histogram(cl, bins=[0, 1, 2, 3, 4, 6, 8, 12, 100])
+    print(f"  clause time of {names[c]} wavefronts (us bins 0-1-2-3-4-6-8-12+):", (hist / max(m.sum(), 1)).round(3).tolist())
 # resident wavefronts over time
 print("wavefronts in flight / waiting on dependencies, every 10 us:")
 for x in np.arange(0, us[:, 6].max(), 10.0):
