@@ -146,8 +146,15 @@ static uint64_t pid_hash(const ErlNifPid *pid) {
   x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
   return x;
 }
+/* Rebuilds the hash without its tombstones; the capacity follows the LIVE owners (round 5: it doubled on every
+ * rebuild -- ht_used also counts tombstones -- so register / unregister churn from restarting ra_server_procs grew the
+ * table with the number of restarts and made every rebuild an O(slots) walk under own_mu): the same size while the
+ * live entries fill at most a quarter of it, twice the size only when they need the room. */
 static int owner_ht_grow(nif_ctx *c) {                              /* own_mu held */
-  const uint32_t cap = c->ht_cap ? c->ht_cap * 2 : 256;
+  uint32_t n_live = 0;
+  for (uint32_t k = 0; k < c->n_pids; ++k) n_live += c->live[k] ? 1u : 0u;
+  uint32_t cap = c->ht_cap ? c->ht_cap : 256;
+  while ((uint64_t)(n_live + 1u) * 4u > cap) cap *= 2;
   uint32_t *ht = (uint32_t *)enif_alloc((size_t)cap * sizeof(uint32_t));
   if (!ht) return 0;
   memset(ht, 0, (size_t)cap * sizeof(uint32_t));
@@ -158,8 +165,7 @@ static int owner_ht_grow(nif_ctx *c) {                              /* own_mu he
     ht[h] = k + 1;
   }
   if (c->ht) enif_free(c->ht);
-  c->ht = ht; c->ht_cap = cap; c->ht_used = 0;
-  for (uint32_t k = 0; k < c->n_pids; ++k) c->ht_used += c->live[k] ? 1u : 0u;
+  c->ht = ht; c->ht_cap = cap; c->ht_used = n_live;           /* occupied cells = live entries (no tombstones left) */
   return 1;
 }
 static uint32_t owner_find(nif_ctx *c, const ErlNifPid *pid) {      /* own_mu held; slot + 1, 0 = not registered */
@@ -196,7 +202,8 @@ static uint32_t owner_slot(nif_ctx *c, const ErlNifPid *pid) {      /* own_mu he
   c->pids[idx - 1] = *pid; c->live[idx - 1] = 1;
   uint32_t h = (uint32_t)(pid_hash(pid) & (c->ht_cap - 1));
   while (c->ht[h] && c->ht[h] != 0xFFFFFFFFu) h = (h + 1) & (c->ht_cap - 1);
-  c->ht[h] = idx; c->ht_used += 1;
+  if (!c->ht[h]) c->ht_used += 1;                             /* (a reused tombstone was counted when it was first filled) */
+  c->ht[h] = idx;
   return idx;
 }
 
@@ -459,7 +466,11 @@ static void *collector_main(void *arg) {
   enif_free_env(env);
   /* finished by itself (2): collect/1 works again at once, and the next start_collector/2 -- or stop_collector/1, or
    * the destructor -- joins this thread */
-  { int running = 1; atomic_compare_exchange_strong(&c->collector_on, &running, 2); }   /* (a stopper's 4 stays) */
+  /* from running (1) -- or from STARTING (3): the thread can end on an error before start_collector/2 has moved 3 to
+   * 1, and an exit that only looked for 1 was lost there (start_collector then published 1 for a dead thread: collect/1
+   * refused, a new start_collector/2 badarg, although the owner had been told it may start one).  A stopper's 4 stays. */
+  { int st = 1;
+    if (!atomic_compare_exchange_strong(&c->collector_on, &st, 2)) { st = 3; atomic_compare_exchange_strong(&c->collector_on, &st, 2); } }
   enif_release_resource(c);
   return NULL;
 }
@@ -486,7 +497,7 @@ static ERL_NIF_TERM nif_start_collector(ErlNifEnv *env, int argc, const ERL_NIF_
     return mk_error(env, c, RGB_E_NOMEM);
   }
   was = 3;
-  atomic_compare_exchange_strong(&c->collector_on, &was, 1);   /* (a thread that already ended left 2) */
+  atomic_compare_exchange_strong(&c->collector_on, &was, 1);   /* (a thread that already ended moved 3 to 2 itself) */
   return enif_make_atom(env, "ok");
 }
 
