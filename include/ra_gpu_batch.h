@@ -375,6 +375,18 @@ typedef struct rgb_leaderboard_row {
 #define RGB_CFG_ROUNDS_PER_LAUNCH 1u   /* rgb_submit: one kernel launch per sub-tick round, never a train (A/B measurements) */
 #define RGB_CFG_TRAIN_PERSISTENT 2u   /* trains always in the persistent form (placement by construction), also on a device
                                          whose dispatcher deals blocks round robin (see "Train launches") */
+#define RGB_CFG_FUSE_PIPELINE    4u   /* OPT-IN (ABI v8; default off: the decision stream is the reference's event by
+                                         event).  A leader's same-term success reply and its own written event end with
+                                         {next_event, info, pipeline_rpcs} (src/ra_server.erl:552, 744), which the
+                                         gen_statem handles before anything else in its mailbox (:793-801): with this
+                                         flag the SAME decision carries the rpc records of that pipeline_rpcs event
+                                         (make_pipelined_rpc_effects :2285-2346) -- n_rpcs and its rpc slots filled,
+                                         next_index / commit_index_sent advanced, RGB_F_PIPELINE left only when the
+                                         event would re-arm itself (More = true) -- instead of RGB_F_PIPELINE and a second
+                                         message (RGB_MSG_PIPELINE_RPCS) from the host.  State and records equal the two
+                                         steps bit for bit (tests/test_gpu_parity.py); if the event would fail a
+                                         reference assertion the decision is NOT fused (RGB_F_PIPELINE stays: the host's
+                                         message then reports the invariant as always) */
 typedef struct rgb_config {
   uint32_t abi_version;          /* RGB_ABI_VERSION                                             */
   int32_t  device;               /* HIP device ordinal                                          */

@@ -355,6 +355,7 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   d.max_aer_batch = ctx->cfg.max_aer_batch;
   d.dbg = 0; d.dbg_buf = nullptr;
   d.synth_hint = ctx->synth_hint;
+  d.fuse_pipeline = (ctx->cfg.flags & RGB_CFG_FUSE_PIPELINE) ? 1u : 0u;
 #ifdef RGB_PROFILE
   /* the profiling build only (libra_gpu_batch_prof.so): knobs from the environment */
   { const char *e = getenv("RGB_DEBUG"); d.dbg = e ? (u32)atoi(e) : 0u; }

@@ -2150,6 +2150,38 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 #endif
 }
 
+/* RGB_CFG_FUSE_PIPELINE (opt-in, include/ra_gpu_batch.h).  A leader's same-term success reply and its own written
+ * event end with {next_event, info, pipeline_rpcs} (src/ra_server.erl:552, 744), which the gen_statem handles before
+ * anything else in its mailbox (:793-801).  Fused, that event runs HERE, right behind the decision that asked for it:
+ * literally the RGB_MSG_PIPELINE_RPCS message the host would have submitted next, through the same clause code
+ * (process_message<.., RGB_MSG_PIPELINE_RPCS>, rows read back from memory: the first decision has committed), and the
+ * two decisions are merged -- n_rpcs and the rpc slots of the event, its flags (RGB_F_PIPELINE again only when the event
+ * re-arms itself, RGB_F_SEND_SNAPSHOT, ..) over the reply's.  An event that fails a reference assertion is NOT merged:
+ * the reply keeps RGB_F_PIPELINE and the host's message reports the invariant as always.  By construction the state and
+ * the records are those of the two steps.  Outside the class paths on purpose: inside handle_leader the extra live
+ * ranges cost the per-tick class kernel its register budget (66 spilled VGPRs) whether the mode was on or not. */
+template <int N, bool TR>
+__device__ __forceinline__ void fuse_pipeline_step(const rgb_dev &dev, Dec &d, u32 i, rgb_rpc *__restrict__ rpcs,
+                                                   u32 rpc_slot_base, u32 msg_index_base) {
+#ifndef RGB_HOST_EMULATION
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     /* the first decision's state stores have been acknowledged */
+  asm volatile("" ::: "memory");
+#endif
+  const u64 m0x = (d.w[0] & 0xFFFFFFFFull) | ((u64)RGB_MSG_PIPELINE_RPCS << 32) | ((u64)RGB_NONE << 40);
+  Dec e;
+  process_message<N, RGB_MSG_PIPELINE_RPCS, false, TR>(dev, make_ulonglong2(m0x, 0), make_ulonglong2(0, 0), make_ulonglong2(0, 0),
+                                                        make_ulonglong2(0, 0), i, rpcs, rpc_slot_base, msg_index_base, e);
+  const u32 ef = (u32)e.w[1];
+  if (ef & (RGB_F_INVARIANT | RGB_F_UNHANDLED)) return;
+  d.w[0] = (d.w[0] & ~(0xFFull << 48)) | (e.w[0] & (0xFFull << 48));                       /* n_rpcs */
+  d.w[1] = (d.w[1] & ~(u64)RGB_F_PIPELINE) | (u64)ef;                                      /* flags */
+}
+__device__ __forceinline__ bool fuse_wanted(const rgb_dev &dev, const Dec &d) {
+  const unsigned kind = (unsigned)(d.w[0] >> 56), role = (unsigned)((d.w[0] >> 32) & 0xFF);
+  return dev.fuse_pipeline && ((u32)d.w[1] & RGB_F_PIPELINE) && !((u32)d.w[1] & RGB_F_INVARIANT) && role == RGB_ROLE_LEADER &&
+         (kind == RGB_MSG_AER_REPLY || kind == RGB_MSG_WRITTEN);
+}
+
 /* ------------------------------------------------------------------ fast paths ----
  * The three bulk kinds have ONE steady-state outcome each that takes a few dozen instructions, against the ~1000
  * the general clause code executes per wavefront (every rare clause costs its region's bookkeeping even when no
@@ -2324,6 +2356,7 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF);
   if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || peer >= (unsigned)N) FP_DECLINE(1, 1);
   if (mflags != RGB_MF_SUCCESS) FP_DECLINE(1, 2);                    /* a failed reply */
+  if (dev.fuse_pipeline) FP_DECLINE(1, 9);                           /* opt-in fused pipelining: the general path emits the rpcs */
   const ulonglong2 h0 = pre[HOT_P_TERM ^ swz], h1 = pre[HOT_P_CI ^ swz], h2 = pre[HOT_P_LI ^ swz], h3 = pre[HOT_P_LW ^ swz],
                    h4 = pre[HOT_P_SI ^ swz], h5 = pre[HOT_P_FIRST ^ swz], h6 = pre[HOT_P_LRT ^ swz], h7 = pre[HOT_P_PEND ^ swz];
   const u64 ct = h0.x, pk = h0.y, ci0 = h1.x, la = h1.y, li = h2.x, lwi = h3.x, si = h4.x, st = h4.y, first = h5.x,
@@ -2456,6 +2489,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
     const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
                      m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
     process_message<N, KIND>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d);
+    if (fuse_wanted(dev, d)) fuse_pipeline_step<N, false>(dev, d, base + lane, rpcs, rpc_slot_base, msg_index_base);
     (void)compact_decision(d);
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
     io[lane * RGB_IO_SLOT + 1] = make_ulonglong2(d.w[2], d.w[3]);
@@ -2839,6 +2873,10 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #if defined(RGB_PROFILE) && !defined(RGB_HOST_EMULATION)
     if (!TR && RGB_KNOB(dev, 16u)) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
 #endif
+  }
+  if (dev.fuse_pipeline && (cls == 1 || cls == 2)) {     /* opt-in: the pipeline_rpcs event behind the decision */
+    const bool want = active && fuse_wanted(dev, d);
+    if (__ballot(want) != 0ull && want) fuse_pipeline_step<N, TR>(dev, d, base + lane, rpcs, rpc_slot_base, msg_index_base);
   }
   /* the 32-byte form of the decision where its shape allows -- register arithmetic, done HERE so that in a train it
    * runs under the acknowledgements the publish step waits for (behind the publish it kept the wavefront's slot
