@@ -15,10 +15,10 @@
 -module(ra_gpu_batch).
 
 -export([init/0, open/4, register_groups/3, upload_state/3, download_state/3, register_owner/4, unregister_owner/2, owner_slots/1, fan_back_stats/1, route/2,
-         submit/3, collect/1, start_collector/2, stop_collector/1, snapshot/2, wal_checksums/3,
+         submit/3, submit/4, collect/1, start_collector/2, stop_collector/1, snapshot/2, wal_checksums/3,
          comm_unique_id/0, comm_init/4, allgather_leaderboard/2, node_leaderboard/3]).
 -export([wal_batch_checksums/2, wal_frame/4, wal_recover_check/2, wal_frame_batch/3, wal_recover/2]).
--export([encode_msg/3, decode_decision/1, decision_to_effects/3]).
+-export([encode_msg/3, encode_msgs/1, decode_decision/1, decision_to_effects/3]).
 
 -include_lib("ra/src/ra.hrl").
 
@@ -89,6 +89,9 @@ owner_slots(_Ctx) -> erlang:nif_error(not_loaded).
 fan_back_stats(_Ctx) -> erlang:nif_error(not_loaded).
 %% submit/3 may be called from any process; batches above 2048 messages run on a dirty CPU scheduler.
 submit(_Ctx, _MsgsBin, _Tick) -> erlang:nif_error(not_loaded).
+%% submit/4: + the batch's range list, <<First:64/little, Last:64/little>> per entry -- the lower ranges of written
+%% events whose ra_seq has more than two ranges (encode_msgs/2 builds both binaries)
+submit(_Ctx, _MsgsBin, _Tick, _RangesBin) -> erlang:nif_error(not_loaded).
 collect(_Ctx) -> erlang:nif_error(not_loaded).
 start_collector(_Ctx, _Pid) -> erlang:nif_error(not_loaded).
 stop_collector(_Ctx) -> erlang:nif_error(not_loaded).
@@ -178,6 +181,20 @@ wal_recover(Ctx, FileBin) ->
           end, {#{}, []}, Good),
     lists:reverse(Out).
 
+%% encode_msgs([{Server, Msg, Slot}]) -> {MsgsBin, RangesBin} | {fallback, Server}: a whole batch for submit/4 -- the
+%% records in order, and the range list that written events of more than two ranges refer to (empty for most batches:
+%% submit/3 will do).
+encode_msgs(Items) ->
+    encode_msgs(Items, <<>>, <<>>).
+encode_msgs([], Msgs, Ranges) -> {Msgs, Ranges};
+encode_msgs([{Server, Msg, Slot} | Rest], Msgs, Ranges) ->
+    case encode_msg(Server, Msg, Slot) of
+        fallback -> {fallback, Server};
+        {seqx, Record, Lower} ->
+            encode_msgs(Rest, <<Msgs/binary, (Record(byte_size(Ranges) div 16))/binary>>, <<Ranges/binary, Lower/binary>>);
+        Bin when is_binary(Bin) -> encode_msgs(Rest, <<Msgs/binary, Bin/binary>>, Ranges)
+    end.
+
 %% Slot = fun(ra_server_id()) -> 0..7 | 255, the member slot of a server id inside its group.
 %% Returns the 64-byte record, or `fallback` for an event the batched path does not take (the caller runs
 %% ra_server:handle_* itself and re-uploads the server's integers with upload_state/3).  Every message kind
@@ -203,8 +220,10 @@ encode_msg(Server, {ra_log_event, {written, T, Seq}}, _Slot) ->
     %% the written event carries a ra_seq:state() -- a list of indexes and ranges, newest first
     %% (src/ra_log_wal.erl:807, src/ra_log.erl:74,1641; ra_seq.erl:8-12) -- e.g. [{From,To}], [Idx],
     %% {written,0,[0]} or, after ra_log:write_sparse/3, something like [14, {2,9}].  One range, or two
-    %% (RGB_MF_SEQ2 = 8: the lower one rides in the run0_term/run1_term fields), go to the engine; longer
-    %% sequences return `fallback` and the caller lets ra_server handle the event and re-uploads.
+    %% (RGB_MF_SEQ2 = 8: the lower one rides in the run0_term/run1_term fields), fit the record.  A longer
+    %% sequence (ABI v8, RGB_MF_SEQX = 32) keeps its two highest ranges in the record and names the others in
+    %% the batch's range list: {seqx, Record, LowerRanges} -- the record's `c` (first list entry) is filled in
+    %% by encode_msgs/2, which knows where the batch's list stands.  No written event falls back any more.
     case seq_ranges(Seq) of
         [{From, To}] ->
             <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, 0:8, 0:8, T:64/little, From:64/little,
@@ -212,7 +231,14 @@ encode_msg(Server, {ra_log_event, {written, T, Seq}}, _Slot) ->
         [{From2, To2}, {From, To}] ->
             <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, 8:8, 0:8, T:64/little, From:64/little,
               To:64/little, 0:64, 0:64, From2:64/little, To2:64/little>>;
-        _ -> fallback
+        Ranges ->
+            {Lower, [{From2, To2}, {From, To}]} = lists:split(length(Ranges) - 2, Ranges),
+            {seqx,
+             fun(C) ->
+                     <<Server:32/little, ?MSG_WRITTEN:8, ?NONE:8, (8 bor 32):8, 0:8, T:64/little, From:64/little,
+                       To:64/little, C:64/little, (length(Lower)):32/little, 0:32, From2:64/little, To2:64/little>>
+             end,
+             << <<F:64/little, L:64/little>> || {F, L} <- Lower >>}
     end;
 encode_msg(Server, {Peer, #request_vote_result{term = T, vote_granted = G}}, Slot) ->
     Flags = case G of true -> 1; false -> 0 end,

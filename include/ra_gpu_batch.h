@@ -99,6 +99,15 @@ enum {
 #define RGB_MF_FORCE    0x02u  /* APPEND: noop command => Force pipelining (src/ra_server.erl:682-689) */
 #define RGB_MF_SEQ2     0x08u  /* WRITTEN: the written ra_seq has TWO ranges: [run0_term .. run1_term] (the lower one, reusing
                                   those two fields as indexes) and [a .. b] above it, run1_term + 1 < a */
+#define RGB_MF_SEQX     0x20u  /* WRITTEN (with RGB_MF_SEQ2): the written ra_seq has MORE than two ranges.  The two highest ride
+                                  in the record as for RGB_MF_SEQ2; the others -- ascending, non-adjacent, all below
+                                  run0_term -- are entries c .. c + n_entries - 1 of the batch's RANGE LIST ((first, last)
+                                  pairs of uint64: rgb_submit_seq, rgb_set_seq_ranges_device).  A record that names entries
+                                  the list does not hold commits nothing (RGB_INV_WRITTEN_SEQ_LIST).  Served by the
+                                  kind-GENERIC kernel: rgb_submit_seq routes a batch that holds such a record there; a
+                                  device-resident producer runs such a tick with rgb_run_ticks_device WITHOUT kind counts
+                                  (the class-specialised and train kernels report the record RGB_F_UNHANDLED, state
+                                  unchanged) */
 #define RGB_MF_CAN_WRITE 0x10u /* any kind, for a server awaiting RGB_COND_WAL_DOWN: ra_log:can_write(Log) is true */
 #define RGB_MF_TICK     0x04u  /* PIPELINE_RPCS: the leader's tick_timeout -- ra_server:make_rpcs/1: heartbeats for
                                   waiting queries plus one batch-of-1 rpc per stale peer, next_index not advanced
@@ -204,7 +213,8 @@ enum {
   RGB_INV_PIPELINE_PREV_UNDEFINED   = 9, /* make_rpc_effect: no term for NextIdx-1 and no snapshot above it
                                             (case_clause / ?assert(PrevIdx < SnapIdx)) src/ra_server.erl:2392-2408 */
   RGB_INV_WRITTEN_NOT_PREFIX        = 10, /* {ok, Pend} = ra_seq:remove_prefix(..) badmatch  src/ra_log.erl:929 */
-  RGB_INV_LEADER_SAW_HEARTBEAT_SAME_TERM = 11 /* exit(leader_saw_heartbeat_rpc_in_same_term) src/ra_server.erl:898-903 */
+  RGB_INV_LEADER_SAW_HEARTBEAT_SAME_TERM = 11, /* exit(leader_saw_heartbeat_rpc_in_same_term) src/ra_server.erl:898-903 */
+  RGB_INV_WRITTEN_SEQ_LIST          = 12  /* (no reference clause) a RGB_MF_SEQX record names entries its range list does not hold */
 };
 
 /*
@@ -439,6 +449,14 @@ int  rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_sta
  * server are applied in submission order (serialised over sub-ticks); messages for different
  * servers are applied in parallel.  rgb_collect waits for the OLDEST submitted batch. */
 int  rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick);
+/* rgb_submit with the batch's RANGE LIST (ABI v8): written events whose ra_seq has more than two ranges
+ * (RGB_MF_SEQX; src/ra_log.erl:897-944, src/ra_seq.erl:17-66 -- what a WAL that has been rolling over under load
+ * confirms) name their lower ranges in it: ranges = n_ranges x (first, last), copied with the batch.  A record whose
+ * entries are not in the list, not ascending or not below its inline ranges: RGB_E_INVAL, nothing is enqueued. */
+int  rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick, const uint64_t *ranges, uint32_t n_ranges);
+/* the same list for the device-resident entry points (rgb_run_ticks_device, the trains): the launches that follow
+ * read d_ranges (device memory of the caller's, n_ranges pairs; NULL / 0 = none) until the next call */
+int  rgb_set_seq_ranges_device(rgb_ctx *ctx, const void *d_ranges, uint32_t n_ranges);
 int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
                  rgb_rpc *rpc_out, uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out);
 /* Threading (the interception point is per gen_statem, reference src/ra_server_proc.erl:1356-1397, so many

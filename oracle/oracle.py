@@ -43,6 +43,7 @@ def lib():
                                         C.c_void_p]
         L.ora_max_threads.restype = C.c_int
         L.ora_set_max_runs.argtypes = [C.c_void_p, C.c_uint32]
+        L.ora_set_seq_ranges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.ora_agreed_commit.restype = C.c_uint64
         L.ora_agreed_commit.argtypes = [C.c_void_p, C.c_uint32]
         L.ora_server_checksum.restype = C.c_uint64
@@ -244,9 +245,12 @@ class Oracle:
             raise ValueError(f"ora_get_state rc={rc}")
         return out
 
-    def step(self, msgs: np.ndarray, rpc_cap: int | None = None):
+    def step(self, msgs: np.ndarray, rpc_cap: int | None = None, seq_ranges: np.ndarray | None = None):
+        """seq_ranges: the batch's range list (uint64[n][2]: first, last) that RGB_MF_SEQX written events name."""
         m = np.ascontiguousarray(msgs, dtype=abi.MSG_DTYPE)
         n = len(m)
+        r = None if seq_ranges is None else np.ascontiguousarray(seq_ranges, dtype=np.uint64).reshape(-1, 2)
+        self._L.ora_set_seq_ranges(self._h, r.ctypes.data if r is not None and len(r) else None, 0 if r is None else len(r))
         dec = np.zeros(n, dtype=abi.DECISION_DTYPE)
         cap = n * abi.MAX_MEMBERS if rpc_cap is None else rpc_cap
         rpcs = np.zeros(max(cap, 1), dtype=abi.RPC_DTYPE)

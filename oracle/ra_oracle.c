@@ -317,12 +317,16 @@ static int log_set_last_index(olog *l, uint64_t idx) {
 /* The same event for a sequence of two ranges and/or a sparse `pending`: the written sequence and `pending` as
  * explicit index lists, the retry of :931-943 one index at a time from the top of the sequence, and
  * ra_seq:remove_prefix/2 as the two-iterator walk of drop_prefix/2 (src/ra_seq.erl:278-291). */
-static int log_written_sparse(olog *l, uint64_t term, uint64_t lo_s, uint64_t lo_e, int two, uint64_t from, uint64_t to,
-                              int *resend, int *inv) {
+/* (round 5) any number of ranges: `extra` = n_extra (first, last) pairs below the two inline ranges, ascending --
+ * the RGB_MF_SEQX range list of the batch (rgb_submit_seq) */
+static int log_written_sparse(olog *l, uint64_t term, const uint64_t *extra, uint32_t n_extra, uint64_t lo_s, uint64_t lo_e,
+                              int two, uint64_t from, uint64_t to, int *resend, int *inv) {
   size_t nw = (size_t)(to - from + 1) + (two ? (size_t)(lo_e - lo_s + 1) : 0);
+  for (uint32_t k = 0; k < n_extra; k++) nw += (size_t)(extra[2 * k + 1] - extra[2 * k] + 1);
   uint64_t *w = (uint64_t *)malloc((nw ? nw : 1) * sizeof(uint64_t));
   if (!w) return 0;
   size_t n = 0;
+  for (uint32_t k = 0; k < n_extra; k++) for (uint64_t i = extra[2 * k]; i <= extra[2 * k + 1]; i++) w[n++] = i;
   if (two) for (uint64_t i = lo_s; i <= lo_e; i++) w[n++] = i;
   for (uint64_t i = from; i <= to; i++) w[n++] = i;
   int changed = 0;
@@ -366,7 +370,7 @@ static int log_written_sparse(olog *l, uint64_t term, uint64_t lo_s, uint64_t lo
 }
 
 static int log_written(olog *l, uint64_t term, uint64_t from, uint64_t to, int *resend, int *inv) {
-  if (l->pend_idx) return log_written_sparse(l, term, 0, 0, 0, from, to, resend, inv);
+  if (l->pend_idx) return log_written_sparse(l, term, NULL, 0, 0, 0, 0, from, to, resend, inv);
   uint64_t idx = to;
   for (;;) {
     uint64_t t = log_fetch_term(l, idx);
@@ -951,10 +955,24 @@ static int follower_request_vote(oserver *sv, const rgb_msg *m, ofx *fx) {
 
 /* ra_log:handle_event({written,..}) in any role: *changed = last_written moved; the resend
  * request of a not_prefix written event is an effect flag (host I/O); returns an RGB_INV_* */
+/* the RGB_MF_SEQX range list of the batch being stepped (ora_set_seq_ranges: test infrastructure, one list per
+ * process; read-only while a step runs) */
+static const uint64_t *g_seq_ranges = NULL;
+static uint32_t g_n_seq_ranges = 0;
+void ora_set_seq_ranges(ora_ctx *c, const uint64_t *ranges, uint32_t n_ranges) {
+  (void)c;
+  g_seq_ranges = n_ranges ? ranges : NULL; g_n_seq_ranges = n_ranges;
+}
+
 static int srv_written(oserver *sv, const rgb_msg *m, ofx *fx, int *changed) {
   int resend = 0, inv = 0;
-  if (m->flags & RGB_MF_SEQ2)
-    *changed = log_written_sparse(&sv->log, m->term, m->run0_term, m->run1_term, 1, m->a, m->b, &resend, &inv);
+  if (m->flags & RGB_MF_SEQX) {
+    *changed = 0;
+    if (!g_seq_ranges || m->n_entries == 0 || (uint64_t)m->c + m->n_entries > g_n_seq_ranges) return RGB_INV_WRITTEN_SEQ_LIST;
+    *changed = log_written_sparse(&sv->log, m->term, g_seq_ranges + 2 * m->c, m->n_entries, m->run0_term, m->run1_term, 1,
+                                  m->a, m->b, &resend, &inv);
+  } else if (m->flags & RGB_MF_SEQ2)
+    *changed = log_written_sparse(&sv->log, m->term, NULL, 0, m->run0_term, m->run1_term, 1, m->a, m->b, &resend, &inv);
   else
     *changed = log_written(&sv->log, m->term, m->a, m->b, &resend, &inv);
   if (inv) return inv;

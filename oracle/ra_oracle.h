@@ -28,6 +28,8 @@ int      ora_step_parallel(ora_ctx *c, const rgb_msg *msgs, uint32_t n, rgb_deci
 int      ora_max_threads(void);
 /* bound the term-run table like the engine does (0 = unbounded, the default) */
 void     ora_set_max_runs(ora_ctx *c, uint32_t max_runs);
+/* the range list the RGB_MF_SEQX written events of the next steps name ((first, last) pairs; NULL / 0 = none) */
+void     ora_set_seq_ranges(ora_ctx *c, const uint64_t *ranges, uint32_t n_ranges);
 uint64_t ora_agreed_commit(const uint64_t *idxs, uint32_t n);
 uint64_t ora_server_checksum(const rgb_server_state *h);
 size_t   ora_struct_size(int which);

@@ -39,6 +39,7 @@ MF_FORCE = 0x02
 MF_TICK = 0x04
 MF_SEQ2 = 0x08
 MF_CAN_WRITE = 0x10
+MF_SEQX = 0x20       # WRITTEN (with MF_SEQ2): more than two ranges, the lower ones in the batch's range list (c, n_entries)
 
 F_REPLY = 1 << 0
 F_REPLY_SUCCESS = 1 << 1

@@ -297,7 +297,12 @@ static ERL_NIF_TERM submit_body(ErlNifEnv *env, int argc, const ERL_NIF_TERM arg
   if (!get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &b) || b.size % sizeof(rgb_msg) ||
       !enif_get_uint64(env, argv[2], &tick))
     return enif_make_badarg(env);
-  int rc = rgb_submit(c->ctx, (const rgb_msg *)b.data, (uint32_t)(b.size / sizeof(rgb_msg)), tick);
+  /* submit/4: the batch's range list (written events of more than two ranges, RGB_MF_SEQX): <<First:64/little,
+   * Last:64/little>> per entry -- rgb_submit_seq copies it with the batch */
+  ErlNifBinary r; r.size = 0; r.data = NULL;
+  if (argc == 4 && (!enif_inspect_binary(env, argv[3], &r) || r.size % (2 * sizeof(uint64_t)))) return enif_make_badarg(env);
+  int rc = rgb_submit_seq(c->ctx, (const rgb_msg *)b.data, (uint32_t)(b.size / sizeof(rgb_msg)), tick,
+                          r.size ? (const uint64_t *)r.data : NULL, (uint32_t)(r.size / (2 * sizeof(uint64_t))));
   return rc ? mk_error(env, c, rc) : enif_make_atom(env, "ok");
 }
 static ERL_NIF_TERM nif_submit(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[]) {
@@ -660,6 +665,7 @@ static ErlNifFunc nif_funcs[] = {
   {"owner_slots", 1, nif_owner_slots, 0},
   {"fan_back_stats", 1, nif_fan_back_stats, 0},
   {"submit", 3, nif_submit, 0},
+  {"submit", 4, nif_submit, 0},
   {"collect", 1, nif_collect, ERL_NIF_DIRTY_JOB_IO_BOUND},
   {"start_collector", 2, nif_start_collector, 0},
   {"stop_collector", 1, nif_stop_collector, ERL_NIF_DIRTY_JOB_IO_BOUND},

@@ -52,6 +52,10 @@ struct rgb_slot {
   u32 *h_rows = nullptr, *d_rows = nullptr;
   u32 rows_cap = 0;                 /* words of h_rows / d_rows */
   u32 *d_ctl = nullptr;             /* RGB_TRAIN_CTL_WORDS: this slot's train error word + per-launch counters */
+  /* rgb_submit_seq: the batch's range list (written events of more than two ranges, RGB_MF_SEQX) */
+  u64 *h_ranges = nullptr, *d_ranges = nullptr;   /* pinned / device: (first, last) pairs; allocated with the first batch that has any */
+  u32 ranges_cap = 0, n_ranges = 0;
+  bool has_seqx = false;            /* the batch holds a RGB_MF_SEQX record: its rounds run in the kind-generic kernel */
   /* fail-safe: the servers this batch touches and their rows as they were before it (saved while a train is in flight) */
   u32 *h_touched = nullptr, *d_touched = nullptr;   /* pinned / device: ring_capacity ids */
   u32 n_touched = 0;
@@ -151,10 +155,10 @@ struct rgb_train_plan {
 };
 
 /* A tick ordered by clause family: ONE launch of the class-dispatch kernel. */
-static int launch_tick_classes(rgb_ctx *ctx, const rgb_msg *m, rgb_decision *d, rgb_rpc *rpcs,
+static int launch_tick_classes(rgb_ctx *ctx, const rgb_dev &dev, const rgb_msg *m, rgb_decision *d, rgb_rpc *rpcs,
                                const u32 counts[RGB_N_CLASSES], u32 rpc_slot_base, u32 msg_index_base,
                                hipStream_t main) {
-  int rc = rgb_launch_tick_classes(ctx->dev, m, counts, nullptr, 0, d, rpcs, rpc_slot_base, msg_index_base, main);
+  int rc = rgb_launch_tick_classes(dev, m, counts, nullptr, 0, d, rpcs, rpc_slot_base, msg_index_base, main);
   if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   return RGB_OK;
 }
@@ -239,6 +243,9 @@ static void free_slot(rgb_slot &s) {
   if (s.h_rows) (void)hipHostFree(s.h_rows);
   if (s.d_rows) (void)hipFree(s.d_rows);
   if (s.d_ctl) (void)hipFree(s.d_ctl);
+  if (s.h_ranges) (void)hipHostFree(s.h_ranges);
+  if (s.d_ranges) (void)hipFree(s.d_ranges);
+  s.h_ranges = s.d_ranges = nullptr; s.ranges_cap = 0;
   if (s.h_touched) (void)hipHostFree(s.h_touched);
   if (s.d_touched) (void)hipFree(s.d_touched);
   if (s.d_undo) (void)hipFree(s.d_undo);
@@ -356,6 +363,7 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   d.dbg = 0; d.dbg_buf = nullptr;
   d.synth_hint = ctx->synth_hint;
   d.fuse_pipeline = (ctx->cfg.flags & RGB_CFG_FUSE_PIPELINE) ? 1u : 0u;
+  d.seq_ranges = nullptr; d.n_seq_ranges = 0;
 #ifdef RGB_PROFILE
   /* the profiling build only (libra_gpu_batch_prof.so): knobs from the environment */
   { const char *e = getenv("RGB_DEBUG"); d.dbg = e ? (u32)atoi(e) : 0u; }
@@ -499,7 +507,21 @@ static int validate_msg(const rgb_ctx *ctx, const rgb_msg &m) {
   if (m.kind == RGB_MSG_WRITTEN && m.a > m.b) return RGB_E_INVAL;
   if (m.kind == RGB_MSG_WRITTEN && (m.flags & RGB_MF_SEQ2) &&
       !(m.run0_term <= m.run1_term && m.run1_term != RGB_UNDEF && m.run1_term + 1 < m.a)) return RGB_E_INVAL;
+  if (m.kind == RGB_MSG_WRITTEN && (m.flags & RGB_MF_SEQX) && !(m.flags & RGB_MF_SEQ2)) return RGB_E_INVAL;
   return RGB_OK;
+}
+/* a RGB_MF_SEQX record against the batch's range list: entries c .. c + n_entries - 1 exist, are ranges, ascending and
+ * non-adjacent, and the last one ends below the record's lower inline range */
+static int validate_seqx(const rgb_msg &m, const uint64_t *ranges, uint32_t n_ranges) {
+  if (m.kind != RGB_MSG_WRITTEN || !(m.flags & RGB_MF_SEQX)) return RGB_OK;
+  if (!ranges || m.n_entries == 0 || m.c > n_ranges || (uint64_t)m.c + m.n_entries > n_ranges) return RGB_E_INVAL;
+  uint64_t prev_last = 0; bool have = false;
+  for (uint32_t k = 0; k < m.n_entries; ++k) {
+    const uint64_t f = ranges[2 * (m.c + k)], l = ranges[2 * (m.c + k) + 1];
+    if (f > l || l == RGB_UNDEF || (have && !(prev_last + 1 < f))) return RGB_E_INVAL;
+    prev_last = l; have = true;
+  }
+  return prev_last + 1 < m.run0_term ? RGB_OK : RGB_E_INVAL;
 }
 
 static int train_scratch(rgb_ctx *ctx);
@@ -510,25 +532,35 @@ static int train_scratch(rgb_ctx *ctx);
 
 /* the rounds of a batch with one launch per round (the shape of every batch that is not a train, and the replay of
  * one whose train launch failed) */
+/* the device view of one batch: the context's, plus the batch's own range list */
+static rgb_dev slot_dev(const rgb_ctx *ctx, const rgb_slot &s) {
+  rgb_dev d = ctx->dev;
+  d.seq_ranges = s.n_ranges ? s.d_ranges : nullptr;
+  d.n_seq_ranges = s.n_ranges;
+  return d;
+}
+
 static int enqueue_rounds(rgb_ctx *ctx, rgb_slot &s) {
+  const rgb_dev dv = slot_dev(ctx, s);
   for (u32 r = 0; r < s.n_rounds; ++r) {
     const u32 off = s.round_start[r], cnt = s.round_start[r + 1] - s.round_start[r];
     int lr;
-    if (cnt >= 4096) {
-      /* big round: the class-dispatch kernel (specialised path per message kind) */
+    if (cnt >= 4096 && !s.has_seqx) {
+      /* big round: the class-dispatch kernel (specialised path per message kind; written events of more than two
+       * ranges are the generic kernel's: rgb_kernels.hip, LaneT::seqx_ok) */
       u32 cc[RGB_N_CLASSES];
       for (int c = 0; c < RGB_N_CLASSES; ++c) cc[c] = s.round_cc[(size_t)r * RGB_N_CLASSES + c];
-      lr = launch_tick_classes(ctx, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
+      lr = launch_tick_classes(ctx, dv, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
       if (lr) return lr;
       u32 real = 0;
       for (int c = 0; c < RGB_N_CLASSES; ++c) real += cc[c];
       if (real < cnt) {      /* NOP slots sort last: the generic kernel writes their empty decisions */
-        lr = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
+        lr = rgb_launch_tick(dv, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
                              s.d_rpcs, off + real, off + real, ctx->stream);
         if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
       }
     } else {
-      lr = rgb_launch_tick(ctx->dev, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off, ctx->stream);
+      lr = rgb_launch_tick(dv, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off, ctx->stream);
       if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
     }
   }
@@ -583,6 +615,8 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
   }
   HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(s.d_pos, s.h_pos, (size_t)n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if (s.n_ranges)
+    HIPCHK(ctx, hipMemcpyAsync(s.d_ranges, s.h_ranges, (size_t)s.n_ranges * 2u * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
   /* the undo log: the rows of the touched servers as they are before this batch -- while a train is in flight
    * (this batch included) a failed launch must be repairable */
   if (as_train || ctx->trains_in_flight.load(std::memory_order_acquire) != 0) {
@@ -606,7 +640,7 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
     HIPCHK(ctx, hipMemcpyAsync(s.d_plan, s.h_plan, (size_t)s.n_rounds * sizeof(rgb_train_tick), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(s.d_rows, s.h_rows, (size_t)s.n_rounds * rows_max * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(s.d_ctl, 0, sizeof(u32), ctx->stream));    /* this slot's own error word */
-    int lr = rgb_launch_train(ctx->dev, s.d_msgs, s.d_stamps, 0, s.d_plan, s.d_rows, s.n_rounds, rows_max * RGB_TRAIN_SHARDS,
+    int lr = rgb_launch_train(slot_dev(ctx, s), s.d_msgs, s.d_stamps, 0, s.d_plan, s.d_rows, s.n_rounds, rows_max * RGB_TRAIN_SHARDS,
                               s.d_dec, s.d_rpcs, 1, 0, s.d_ctl, ctx->n_xcc,
                               ctx->train_dealt.load(std::memory_order_relaxed) ? 0u : ctx->train_blocks, ctx->stream);
     if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
@@ -635,7 +669,18 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
  * Everything that can fail because of the INPUT fails before step 2; a HIP error in step 3 publishes the batch as
  * failed (rgb_collect returns the error once and the ring moves on). */
 int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
-  if (!ctx || (!msgs && n)) return RGB_E_INVAL;
+  return rgb_submit_seq(ctx, msgs, n, tick, nullptr, 0);
+}
+
+int rgb_set_seq_ranges_device(rgb_ctx *ctx, const void *d_ranges, uint32_t n_ranges) {
+  if (!ctx || (!d_ranges && n_ranges)) return RGB_E_INVAL;
+  ctx->dev.seq_ranges = n_ranges ? (const u64 *)d_ranges : nullptr;
+  ctx->dev.n_seq_ranges = n_ranges;
+  return RGB_OK;
+}
+
+int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick, const uint64_t *ranges, uint32_t n_ranges) {
+  if (!ctx || (!msgs && n) || (!ranges && n_ranges)) return RGB_E_INVAL;
   if (!ctx->registered) return RGB_E_STATE;
   if (n > ctx->cfg.ring_capacity) return RGB_E_INVAL;
   /* the calling thread's current device may be any (one context per GPU, scheduler threads default to device 0):
@@ -650,13 +695,15 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   key_of.resize(n);
   touched.clear();
   u32 n_rounds = n ? 1 : 0;
-  bool any_nop = false, too_many = false;
+  bool any_nop = false, too_many = false, any_seqx = false;
   int bad = RGB_OK;
   const unsigned n_members = ctx->dev.n_members;
   for (u32 i = 0; i < n; ++i) {
     const rgb_msg &m = msgs[i];
     bad = validate_msg(ctx, m);
+    if (!bad) bad = validate_seqx(m, ranges, n_ranges);
     if (bad) break;
+    if (m.kind == RGB_MSG_WRITTEN && (m.flags & RGB_MF_SEQX)) any_seqx = true;
     u32 r = 0;
     if (m.kind != RGB_MSG_NOP) {
       uint16_t &c = seen[m.server];
@@ -674,7 +721,7 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
   if (too_many) return RGB_E_UNSUPPORTED;
   /* several rounds, a batch worth a big launch, no NOP padding, a device that keeps a shard on one XCD: the rounds
    * run as ONE train launch, in bucket order (class, shard, success flag) -- a finer key of the same family order */
-  bool as_train = n_rounds >= 2 && n_rounds <= RGB_SUBMIT_TRAIN_ROUNDS && n >= RGB_SUBMIT_TRAIN_MIN && !any_nop &&
+  bool as_train = n_rounds >= 2 && n_rounds <= RGB_SUBMIT_TRAIN_ROUNDS && n >= RGB_SUBMIT_TRAIN_MIN && !any_nop && !any_seqx &&
                   !(ctx->cfg.flags & RGB_CFG_ROUNDS_PER_LAUNCH);
   if (as_train) {
     std::lock_guard<std::mutex> tl(ctx->train_mu);          /* the one-off calibration uses the stream */
@@ -713,7 +760,8 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
     const u32 cls = (u32)(b % NK) / (as_train ? 2u * RGB_TRAIN_SHARDS : 2u);      /* kind rank; 15 = NOP */
     if (cls < RGB_N_CLASSES) class_counts[(b / NK) * RGB_N_CLASSES + cls] += b1 - b0;
     /* append_entries_reply, {commands}, pipeline_rpcs, request_vote_result, pre_vote_rpc */
-    if (cls == 1 || cls == 3 || cls == 4 || cls == 6 || cls == 9) {
+    /* (+ the leader's written events when their pipeline_rpcs event is fused into them: RGB_CFG_FUSE_PIPELINE) */
+    if (cls == 1 || cls == 3 || cls == 4 || cls == 6 || cls == 9 || (cls == 2 && (ctx->cfg.flags & RGB_CFG_FUSE_PIPELINE))) {
       if (b0 < rpc_lo) rpc_lo = b0;
       rpc_hi = b1 - 1;
     }
@@ -745,6 +793,20 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
       s.h_stamps[p] = (unsigned char)round_of[i];        /* a train's stamps: the device adds the sequence bytes */
     }
     s.n = n; s.tick = tick;
+    s.n_ranges = 0; s.has_seqx = any_seqx;
+    if (n_ranges) {                                            /* the batch's range list travels with it */
+      if (s.ranges_cap < n_ranges) {
+        if (s.h_ranges) (void)hipHostFree(s.h_ranges);
+        if (s.d_ranges) (void)hipFree(s.d_ranges);
+        s.h_ranges = s.d_ranges = nullptr; s.ranges_cap = 0;
+        const u32 cap = n_ranges < 1024u ? 1024u : n_ranges;
+        if (hipHostMalloc((void **)&s.h_ranges, (size_t)cap * 2u * sizeof(u64), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&s.d_ranges, (size_t)cap * 2u * sizeof(u64)) != hipSuccess) {
+          rc = RGB_E_NOMEM;
+        } else s.ranges_cap = cap;
+      }
+      if (rc == RGB_OK) { memcpy(s.h_ranges, ranges, (size_t)n_ranges * 2u * sizeof(u64)); s.n_ranges = n_ranges; }
+    }
     s.used_train = false; s.enqueue_error = 0; s.has_undo = false;
     s.n_rounds = n_rounds;
     s.round_start.swap(start);                                  /* no allocation: the vectors change hands */
@@ -989,7 +1051,7 @@ int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
       u64 total = 0;
       for (u32 k = 1; k < NKIND; ++k) { cc[rgb_class_of_kind(k)] += kind_counts[t * NKIND + k]; total += kind_counts[t * NKIND + k]; }
       if (total > tick_stride || kind_counts[t * NKIND + RGB_MSG_NOP]) return RGB_E_INVAL;
-      int rc = launch_tick_classes(ctx, m + off, d + off, (rgb_rpc *)d_rpcs, cc, 0, (u32)off, st);
+      int rc = launch_tick_classes(ctx, ctx->dev, m + off, d + off, (rgb_rpc *)d_rpcs, cc, 0, (u32)off, st);
       if (rc) return rc;
       continue;
     }

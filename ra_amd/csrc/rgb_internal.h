@@ -209,6 +209,9 @@ struct rgb_dev {
   unsigned char *seq;   /* train launches: per-server sequence byte (messages applied, mod 256), shard-major:
                            rgb_seq_index().  Only rgb_train_kernel reads or writes it; never reset */
   u32 seq_stride;       /* bytes per shard of seq */
+  const u64 *seq_ranges;  /* RGB_MF_SEQX: (first, last) pairs of the launch's range list (rgb_submit_seq: the slot's;
+                             rgb_set_seq_ranges_device: the caller's), or null */
+  u32 n_seq_ranges;
   u32 fuse_pipeline;  /* RGB_CFG_FUSE_PIPELINE: a leader's success reply / written event emits its pipeline_rpcs event's rpcs */
   u32 synth_hint;  /* the load generator's bucketing hint (rgb_synth_set_hint): 0 none, 1 the owner's state name,
                       2 (default) + the O(1) header compare an owner can make against the fields it holds */

@@ -170,9 +170,15 @@ __device__ __forceinline__ unsigned slot4to8(unsigned s) { return s >= 8u ? (uns
 
 /* Everything one lane needs for one message: the server's hot line in registers, the message,
  * the effects being accumulated and the pending (uncommitted) log-table edits. */
-template <bool COH, bool WC = false>
+template <bool COH, bool WC = false, bool SEQX = false>
 struct LaneT {
   static constexpr bool coh = COH;   /* state loads must bypass the CU's L1 (train launch), see ldg8 */
+  /* written events of more than two ranges (RGB_MF_SEQX) are served by the kind-GENERIC kernel only (256 registers):
+   * the walk over a list of ranges keeps three more message words alive through the handlers, which the per-tick
+   * class kernel -- at exactly its 128 registers -- answered with 216 spilled VGPRs (and a class kernel that spills
+   * has returned wrong decisions on the device: tests/test_kernel_resources.py).  rgb_submit routes a batch that
+   * holds such a record to the generic kernel; a specialised path that meets one reports RGB_F_UNHANDLED. */
+  static constexpr bool seqx_ok = SEQX;
   /* WC (groups of six and more members: the kernels that have the registers): the run a table walk ended in is
    * remembered -- number, start, term, start of the next run -- and the next look-up of the same message tries it
    * first.  One append_entries_rpc asks has_log_entry_or_snapshot(prev), drop_existing (run of the first entry, its
@@ -192,6 +198,8 @@ struct LaneT {
   unsigned kind, from, mflags, gap;
   u64 term, a, b, c, run0_term, run1_term;
   /* device */
+  const u64 *seqx;       /* RGB_MF_SEQX: the launch's range list (first, last pairs), or null */
+  u32 n_seqx;
   const u64 *runs;       /* this server's run table (start,term pairs) */
   u64 *peers;            /* this server's peers row                    */
   const ulonglong2 *peers_lds;   /* the same row in LDS (class kernel, leader-side classes, 128-byte rows), or null */
@@ -856,6 +864,95 @@ __device__ __forceinline__ bool written_c2(const Lane &L, bool in_range, u64 fro
   if (ok) c2 = u;
   return ok;
 }
+/* range r of the written sequence, HIGHEST first: r = 0 the record's (a, b); r = 1 its second range (RGB_MF_SEQ2:
+ * run0_term .. run1_term); r >= 2 the ranges of the launch's list (RGB_MF_SEQX: entries c .. c + n_entries - 1,
+ * ascending and all below the record's two -- so the list is walked from its top) */
+template <class Lane>
+__device__ __forceinline__ void written_range(const Lane &L, u32 r, u64 from, u64 to, u64 &f, u64 &t) {
+  if (r == 0) { f = from; t = to; }
+  else if (r == 1) { f = L.run0_term; t = L.run1_term; }
+  else {
+    const u64 *e = L.seqx + 2u * ((u64)L.c + (u64)(L.n_entries - 1u - (r - 2u)));
+    f = e[0]; t = e[1];
+  }
+}
+/* the pending range [ps .. pe], up to the stop index c, lies inside ONE range of the written sequence (or is empty,
+ * or entirely above c: it stays) */
+template <class Lane>
+__device__ __forceinline__ bool pend_range_written_many(const Lane &L, u64 ps, u64 pe, u64 c, u32 n_w, u64 from, u64 to) {
+  if (ps > pe || ps > c) return true;
+  const u64 e = pe < c ? pe : c;
+#pragma unroll 1
+  for (u32 r = 0; r < n_w; ++r) {
+    u64 f, t;
+    written_range(L, r, from, to, f, t);
+    const u64 te = t < c ? t : c;
+    if (f <= c && ps >= f && e <= te) return true;
+  }
+  return false;
+}
+
+/* ra_log:handle_event({written, Term, Seq}) (src/ra_log.erl:897-944) for a sequence of ANY number of ranges
+ * (round 5: one, two inline, or more through the launch's range list) against a `pending` of up to three ranges:
+ * the retry of :931-943 walks the sequence from its top until an index with the event's term (clause 1) or below
+ * the snapshot (clause 2) is found; ra_seq:remove_prefix/2 (src/ra_seq.erl:144-147, 278-291) then asks every pending
+ * range up to that index to lie inside one written range */
+template <class Lane>
+__device__ __forceinline__ int log_written_many(Lane &L, u64 term, u64 from, u64 to, bool &changed) {
+  changed = false;
+  const bool in_range = range_nonempty(L);
+  const bool two = (L.mflags & (RGB_MF_SEQ2 | RGB_MF_SEQX)) != 0;
+  u32 n_w = two ? 2u : 1u;
+  if (L.mflags & RGB_MF_SEQX) {
+    /* the list must be there and hold the entries the record names (a malformed record commits nothing) */
+    if (L.seqx == nullptr || L.n_entries == 0u || (u64)L.c + (u64)L.n_entries > (u64)L.n_seqx) return RGB_INV_WRITTEN_SEQ_LIST;
+    n_w += L.n_entries;
+  }
+  bool have1 = false; u64 c1 = 0;
+  bool have2 = false; u64 c2 = 0;
+  /* the highest range first, then the lower ones: one copy of the walk in the code */
+#pragma unroll 1
+  for (u32 r = 0; r < n_w; ++r) {
+    u64 f, t;
+    written_range(L, r, from, to, f, t);
+    if (in_range && !have1) have1 = written_c1(L, term, f, t, c1);
+    if (!have2) have2 = written_c2(L, in_range, f, t, c2);
+  }
+  const bool first_clause = have1 && (!have2 || c1 > c2);
+  if (!first_clause && !have2) return 0;                  /* the sequence ran out: no change (:934-938) */
+  const u64 c = first_clause ? c1 : c2;
+  /* ra_seq:remove_prefix(W_eff, Pend) */
+  bool prefix = true;
+  const bool sparse = pk_get(L.pk, PK_PENDX_SH, 1) != 0;
+  if (pend_nonempty(L)) prefix = pend_range_written_many(L, L.pend, L.li, c, n_w, from, to);
+  if (sparse && prefix) {
+    const u64 *q = qry_row(L);
+    /* the old ranges as this message has cut them so far (nothing cuts them before a written event, but be exact) */
+#pragma unroll 1
+    for (int k = 0; k < 2 && prefix; ++k) {
+      u64 ps = ldg8(L.coh, q + QRY_PEND_LO + 2 * k), pe = ldg8(L.coh, q + QRY_PEND_LO + 2 * k + 1);
+      if (ps < L.po_floor) ps = L.po_floor;
+      if (L.po_cut != UNDEF && pe >= L.po_cut) pe = L.po_cut - 1;
+      if (L.po_cut == 0) continue;
+      prefix = pend_range_written_many(L, ps, pe, c, n_w, from, to);
+    }
+  }
+  if (!prefix) {
+    if (first_clause) { L.flags |= RGB_F_RESEND_PENDING; return 0; }
+    return RGB_INV_WRITTEN_NOT_PREFIX;
+  }
+  if (pend_nonempty(L)) {
+    if (c + 1 > L.pend) L.pend = c + 1;
+    pend_canon(L);
+  }
+  pend_old_floor(L, c + 1);
+  if (first_clause) {
+    changed = !(L.lwi == c && L.lwt == term);
+    L.lwi = c; L.lwt = term;
+  }
+  return 0;
+}
+
 /* is the pending range [ps..pe], cut at the stop index c, covered by W_eff = ([w2s..w2e] u [from..to]) limited to c?
  * (a contiguous pending range cannot straddle the gap between the two written ranges) */
 __device__ __forceinline__ bool pend_range_written(u64 ps, u64 pe, u64 c, bool two, u64 w2s, u64 w2e, u64 from, u64 to) {
@@ -869,6 +966,15 @@ __device__ __forceinline__ bool pend_range_written(u64 ps, u64 pe, u64 c, bool t
 
 template <class Lane>
 __device__ __forceinline__ int log_written(Lane &L, u64 term, u64 from, u64 to, bool &changed) {
+  /* more than two ranges (RGB_MF_SEQX, round 5): the general walk above -- its own branch, so that the one- and
+   * two-range events every tick carries keep the registers they had (folded into this function the loop over a list
+   * of ranges cost the per-tick class kernel 216 spilled VGPRs) */
+  if (L.mflags & RGB_MF_SEQX) {
+    if (Lane::seqx_ok) return log_written_many(L, term, from, to, changed);
+    changed = false;
+    L.flags |= RGB_F_UNHANDLED;                           /* (a specialised path: the record belongs in the generic kernel) */
+    return 0;
+  }
   changed = false;
   const bool in_range = range_nonempty(L);
   const bool two = (L.mflags & RGB_MF_SEQ2) != 0;
@@ -1854,7 +1960,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
                                                 const ulonglong2 *pre = nullptr, unsigned swz = 0,
                                                 const ulonglong2 *prepeers = nullptr,
                                                 const ulonglong2 *preruns = nullptr) {
-  LaneT<TR, (N >= 6 && KIND == RGB_MSG_AER)> L;   /* (the walk cache costs seven registers: only where it pays) */
+  LaneT<TR, (N >= 6 && KIND == RGB_MSG_AER), (KIND < 0)> L;   /* (the walk cache costs seven registers: only where it pays) */
   L.wc_k = -1; L.wc_start = L.wc_term = L.wc_next = 0;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -1899,6 +2005,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
 #ifdef RGB_X_DECLINE_HIST
   L.dbg_hist = dev.dbg_buf;
 #endif
+  if (decltype(L)::seqx_ok) { L.seqx = dev.seq_ranges; L.n_seqx = dev.n_seq_ranges; } else { L.seqx = nullptr; L.n_seqx = 0; }
   L.qry_base = dev.qry;
   L.q_loaded = false; L.q_dirty = 0; L.hb_mask = 0;
   L.qself = 0; L.hb_term = L.hb_qi = L.q_consensus = 0; L.cancel_mask = 0;

@@ -27,6 +27,7 @@ EXPORTS = [
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status", "rgb_train_form", "rgb_train_recoveries",
     "rgb_train_plan_create_snap", "rgb_train_run_snap_device", "rgb_snapshot_train_device", "rgb_train_seq_bytes",
     "rgb_train_plan_create_device", "rgb_train_plan_build_device", "rgb_train_plan_download",
+    "rgb_submit_seq", "rgb_set_seq_ranges_device",
 ]
 COMM_EXPORTS = ["rgb_comm_unique_id", "rgb_comm_init_rank", "rgb_comm_destroy", "rgb_comm_n_ranks", "rgb_comm_rank",
                 "rgb_leaderboard_allgather", "rgb_leaderboard_allgather_host", "rgb_comm_last_error"]   # the one collective of the path (RCCL)
@@ -38,7 +39,7 @@ OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_res
                           "rgb_train_recoveries", "rgb_train_plan_create_snap", "rgb_train_run_snap_device",
                           "rgb_snapshot_train_device", "rgb_train_seq_bytes", "rgb_synth_snapshot_mark_device",
                           "rgb_synth_set_hint", "rgb_train_plan_create_device", "rgb_train_plan_build_device",
-                          "rgb_train_plan_download"} | set(COMM_EXPORTS)
+                          "rgb_train_plan_download", "rgb_submit_seq", "rgb_set_seq_ranges_device"} | set(COMM_EXPORTS)
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -104,6 +105,9 @@ def lib():
     L.rgb_upload_state.argtypes = [vp, u32, u32, vp]
     L.rgb_download_state.argtypes = [vp, u32, u32, vp]
     L.rgb_submit.argtypes = [vp, vp, u32, C.c_uint64]
+    if hasattr(L, "rgb_submit_seq"):
+        L.rgb_submit_seq.argtypes = [vp, vp, u32, C.c_uint64, vp, u32]
+        L.rgb_set_seq_ranges_device.argtypes = [vp, vp, u32]
     L.rgb_collect.argtypes = [vp, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), u64p]
     L.rgb_run_ticks_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp]
     L.rgb_snapshot.argtypes = [vp, vp]
@@ -258,9 +262,15 @@ class RaGpuBatch:
         return out
 
     # -- host path -------------------------------------------------------------------
-    def submit(self, msgs: np.ndarray, tick: int = 0):
+    def submit(self, msgs: np.ndarray, tick: int = 0, seq_ranges: np.ndarray | None = None):
+        """seq_ranges (uint64[n][2]: first, last): the batch's range list -- the lower ranges of written events of more
+        than two ranges (abi.MF_SEQX: record fields c = first entry, n_entries = how many) -- rgb_submit_seq."""
         m = np.ascontiguousarray(msgs, dtype=abi.MSG_DTYPE)
-        self._check(self._L.rgb_submit(self._h, m.ctypes.data, len(m), tick), "rgb_submit")
+        if seq_ranges is None or len(seq_ranges) == 0:
+            self._check(self._L.rgb_submit(self._h, m.ctypes.data, len(m), tick), "rgb_submit")
+        else:
+            r = np.ascontiguousarray(seq_ranges, dtype=np.uint64).reshape(-1, 2)
+            self._check(self._L.rgb_submit_seq(self._h, m.ctypes.data, len(m), tick, r.ctypes.data, len(r)), "rgb_submit_seq")
 
     def collect(self, cap: int | None = None, rpc_cap: int | None = None, out=None):
         """Wait for the oldest submitted batch.  `out` = (decisions, rpcs) preallocated arrays to
@@ -301,13 +311,13 @@ class RaGpuBatch:
     def in_flight(self) -> int:
         return int(self._L.rgb_in_flight(self._h))
 
-    def step(self, msgs: np.ndarray):
+    def step(self, msgs: np.ndarray, seq_ranges: np.ndarray | None = None):
         """submit + collect: decisions in submission order and the pipelined rpcs."""
         m = np.ascontiguousarray(msgs, dtype=abi.MSG_DTYPE)
         out_d, out_r = [], []
         for off in range(0, max(len(m), 1), self.ring_capacity):
             chunk = m[off:off + self.ring_capacity]
-            self.submit(chunk)
+            self.submit(chunk, seq_ranges=seq_ranges)
             d, r, _ = self.collect(cap=max(len(chunk), 1))
             r = r.copy()
             r["msg_index"] += off

@@ -89,3 +89,27 @@ def test_fused_pipeline_on_the_gpu(oracle_lib, n_members, groups, seed):
         engine.build()
     engine.lib()
     check_fused(engine, oracle_lib, n_members, groups, seed)
+
+
+def test_closed_loop_cluster_with_fused_pipelining(emulated_engine, capsys):
+    """End to end (tests/cluster_sim.py: decisions routed back as the next messages over a lossy network, Raft's safety
+    properties checked on the full logs after every tick, then heal and converge): the same closed loop with and
+    without RGB_CFG_FUSE_PIPELINE.  Fused, the leaders' {next_event, info, pipeline_rpcs} round trips disappear from
+    the message stream: fewer messages for the same replicated commands."""
+    from cluster_sim import ClusterSim
+    import test_cluster_safety as TCS
+    G, N, seed = 6, 3, 77
+    out = {}
+    for name, flags in (("plain", 0), ("fused", abi.CFG_FUSE_PIPELINE)):
+        eng = emulated_engine.RaGpuBatch(G, N, ring_capacity=64, ring_slots=2, max_runs=16, flags=flags)
+        eng.set_state(0, abi.empty_server_states(G, N))
+        sim = TCS.run_lossy_then_heal(eng, G, N, seed, lossy_ticks=300, heal_ticks=200)
+        TCS.check_converged(sim, G, N)
+        loops = sum(int(((h["kind"] == abi.MSG_PIPELINE_RPCS) & (h["flags"] == 0)).sum()) for h in sim.history
+                    if not isinstance(h, tuple))
+        out[name] = dict(msgs=sim.stats["msgs"], ticks=sim.tick, commands=sim.stats["commands"], pipeline_msgs=loops)
+        eng.close()
+    with capsys.disabled():
+        print("\nclosed loop, messages with / without fused pipelining:", out)
+    assert out["fused"]["pipeline_msgs"] < out["plain"]["pipeline_msgs"] * 0.5, out
+    assert out["fused"]["msgs"] < out["plain"]["msgs"], out

@@ -151,7 +151,7 @@ def pending_of(st):
     return out
 
 
-def sparse_history(step_fn, get_state, set_state, seed, steps=200):
+def sparse_history(step_fn, get_state, set_state, seed, steps=200, multi=False, stats=None):
     """Drives `step_fn(msg) -> decision` (the checker, or checker + engine in lock step) and the ra_seq model through
     one random history; yields nothing, asserts equality of last_written, pending and the resend / crash decisions."""
     from ra_log_model import LogModel, seq_expand, seq_from_list
@@ -168,7 +168,7 @@ def sparse_history(step_fn, get_state, set_state, seed, steps=200):
     model.range, model.terms, model.snap, model.lw = None, {}, (snap_idx, term), (snap_idx, term)
     model.last_term = term
     model.pending = seq_from_list(live)
-    n_two, n_resend, n_clause2 = 0, 0, 0
+    n_two, n_resend, n_clause2, n_multi = 0, 0, 0, 0
     for step in range(steps):
         st1 = get_state()[1]
         li, lt = int(st1["last_index"]), int(st1["last_term"])
@@ -224,6 +224,28 @@ def sparse_history(step_fn, get_state, set_state, seed, steps=200):
                     w_lo = list(range(max(1, a - 3 - int(rng.integers(0, 3))), a - 1))
             if w_lo and w_lo[-1] + 1 >= w_hi[0]:
                 w_lo = []
+            # (round 5) sequences of MORE than two ranges (RGB_MF_SEQX: the lower ones ride in the batch's range list):
+            # every pending run (the top one maybe only a prefix), optionally one run split by a hole (not a prefix:
+            # the reference re-sends), optionally one or two ranges of indexes that are not pending any more below them
+            extra = []
+            if multi and runs and rng.random() < 0.5:
+                parts = [list(range(a, b + 1)) for a, b in runs]
+                parts[-1] = parts[-1][:int(rng.integers(1, len(parts[-1]) + 1))]
+                if rng.random() < 0.3:
+                    k = int(rng.integers(0, len(parts)))
+                    if len(parts[k]) >= 3:
+                        h = int(rng.integers(1, len(parts[k]) - 1))
+                        parts[k:k + 1] = [parts[k][:h], parts[k][h + 1:]]
+                lowest = parts[0][0]
+                junk = []
+                for _ in range(int(rng.integers(0, 3))):
+                    hi = lowest - 2 - int(rng.integers(0, 2))
+                    lo = hi - int(rng.integers(0, 3))
+                    if lo >= 1:
+                        junk.insert(0, list(range(lo, hi + 1))); lowest = lo
+                parts = junk + parts
+                if len(parts) >= 3:
+                    extra, w_lo, w_hi = parts[:-2], parts[-2], parts[-1]
             top = w_hi[-1]
             wt = model.fetch_term(min(top, li)) if model.range else None
             if wt is None or rng.random() < 0.15:
@@ -232,8 +254,15 @@ def sparse_history(step_fn, get_state, set_state, seed, steps=200):
             if w_lo:
                 kw.update(flags=abi.MF_SEQ2, run0_term=w_lo[0], run1_term=w_lo[-1])
                 n_two += 1
-            d = step_fn(_msg(abi.MSG_WRITTEN, **kw))
-            seq = seq_from_list(w_lo + w_hi)
+            if extra:
+                # the list carries an unrelated entry in front: the record's c is an offset into it
+                lst = np.array([[1, 1]] + [[e[0], e[-1]] for e in extra], dtype=np.uint64)
+                kw.update(flags=abi.MF_SEQ2 | abi.MF_SEQX, c=1, n_entries=len(extra))
+                d = step_fn(_msg(abi.MSG_WRITTEN, **kw), seq_ranges=lst)
+                n_multi += 1
+            else:
+                d = step_fn(_msg(abi.MSG_WRITTEN, **kw))
+            seq = seq_from_list([i for e in extra for i in e] + w_lo + w_hi)
             if int(d["flags"][0]) & abi.F_INVARIANT:
                 assert int(d["invariant"][0]) == abi.INV_WRITTEN_NOT_PREFIX
                 with pytest.raises(AssertionError):
@@ -255,6 +284,8 @@ def sparse_history(step_fn, get_state, set_state, seed, steps=200):
         st1 = get_state()[1]
         assert (int(st1["last_written_index"]), int(st1["last_written_term"])) == model.lw, f"step {step}"
         assert pending_of(st1) == seq_expand(model.pending), f"step {step}: pending {pending_of(st1)[:8]} vs {seq_expand(model.pending)[:8]}"
+        if stats is not None:
+            stats["multi"] = n_multi
     return n_two, n_resend, n_clause2, False
 
 
@@ -264,6 +295,29 @@ def test_oracle_sparse_pending_matches_ra_seq_model(oracle_lib, seed):
     stats = sparse_history(lambda m: cpu.step(m)[0], cpu.get_state, lambda st: cpu.set_state(0, st), seed)
     cpu.close()
     assert stats is not None
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_oracle_written_events_of_many_ranges_match_the_ra_seq_model(oracle_lib, seed):
+    """(round 5) written events whose ra_seq has three to six ranges (RGB_MF_SEQX + the batch's range list) through the
+    checker against the literal ra_seq model: same last_written, same pending, resend / crash where the model has them."""
+    cpu = oracle_lib.Oracle(1, 3)
+    stats = {}
+    sparse_history(lambda m, seq_ranges=None: cpu.step(m, seq_ranges=seq_ranges)[0], cpu.get_state,
+                   lambda st: cpu.set_state(0, st), 700 + seed, multi=True, stats=stats)
+    cpu.close()
+
+
+def test_many_range_histories_do_produce_many_range_events(oracle_lib):
+    n = 0
+    for seed in range(40):
+        cpu = oracle_lib.Oracle(1, 3)
+        stats = {}
+        sparse_history(lambda m, seq_ranges=None: cpu.step(m, seq_ranges=seq_ranges)[0], cpu.get_state,
+                       lambda st: cpu.set_state(0, st), 700 + seed, multi=True, stats=stats)
+        cpu.close()
+        n += stats.get("multi", 0)
+    assert n > 60, n
 
 
 def test_sparse_histories_cover_the_interesting_cases(oracle_lib):
