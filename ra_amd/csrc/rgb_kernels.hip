@@ -2581,7 +2581,11 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const u32 piece = k * RGB_TICK_BLOCK + lane;        /* 16-byte piece of the 64-message block */
-      v[k] = ld16<true>(src + (piece < last ? piece : last));
+      const u32 r = piece >> 2, q = piece & 3u, rr = r < cnt ? r : cnt - 1u;
+      /* planar streams (dev.ps, see rgb_tick_slice): the halves of record i at 32 i of plane A / plane B */
+      v[k] = ld16<true>(dev.ps ? reinterpret_cast<const ulonglong2 *>(msgs) + (q < 2u ? (size_t)0 : (size_t)dev.ps * 2u) +
+                                     (size_t)(base + rr) * 2u + (q & 1u)
+                               : src + (piece < last ? piece : last));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2611,7 +2615,9 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
     if (j < cnt && (part < 2u || !((u32)io[j * RGB_IO_SLOT].y & RGB_F_COMPACT)))
-      store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+      store16_nt(dev.ps ? (void *)(reinterpret_cast<ulonglong2 *>(dec) + (part < 2u ? (size_t)0 : (size_t)dev.ps * 2u) +
+                                   (size_t)(base + j) * 2u + (part & 1u))
+                        : (void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
   }
 }
 
@@ -2770,6 +2776,13 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   RGB_TT(0);
   if (TR && RGB_X_TICKET_AT == 2 && ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
+  /* PLANAR record streams (dev.ps != 0: RGB_CFG_PLANES, include/ra_gpu_batch.h): record i of the tick is two 32-byte
+   * halves, the first at 32 i of plane A (the tick's first 32 ps bytes), the second at 32 i of plane B behind it --
+   * every index stays what it is.  A wavefront of a class that uses half of its records reads 2 KiB of whole lines
+   * instead of half of every line of 4 KiB; compact decisions go out the same way */
+  const u32 ps = dev.ps;
+  const ulonglong2 *srcA = reinterpret_cast<const ulonglong2 *>(msgs) + (size_t)base * 2u;
+  const ulonglong2 *srcB = srcA + (size_t)ps * 2u;
   /* a train's stamp byte travels with the record copies: requested here, it arrives under their round trip (behind
    * the records' barrier it was a second memory round trip in front of the first poll) */
   unsigned need_raw = 0;
@@ -2782,6 +2795,20 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
      * LDS slots are never consumed. */
     const u32 last = cnt * 4u - 1u;
     const bool half = rgb_half_msg_class(cls);            /* only pieces 0, 1 of every record are asked for */
+    if (ps) {
+      /* planar: copy k brings records 16 k .. 16 k + 15 -- lanes 0..31 their first halves (512 contiguous bytes of
+       * plane A), lanes 32..63 their second halves (512 contiguous bytes of plane B): every 16-lane pass of the
+       * instruction is 256 contiguous bytes (lanes alternating between the planes were measured 6 % slower than
+       * 64-byte records: the address coalescer merges neighbouring lanes only) */
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((u32)k * 16u >= SL) break;
+        const u32 hB = lane >> 5, j = lane & 31u;
+        const u32 r = 16u * (u32)k + (j >> 1);
+        const u32 rr = r < cnt ? r : cnt - 1u;
+        if (!half || hB == 0u) glds16<GLDS_NT>((hB ? srcB : srcA) + rr * 2u + (j & 1u), io + k * RGB_TICK_BLOCK);
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if ((u32)k * 16u >= SL) break;                      /* a 32-message slice is two copies */
@@ -2789,6 +2816,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
       const u32 r = piece >> 2;
       const u32 sp = (r << 2) | ((piece & 3u) ^ ((r >> 2) & 3u));
       if (!half || (sp & 2u) == 0u) glds16<GLDS_NT>(src + (sp < last ? sp : last), io + k * RGB_TICK_BLOCK);
+    }
     }
     glds_wait();
   }
@@ -2798,13 +2826,15 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #endif
   const bool active = lane < cnt;
   const u32 mswz = (lane >> 2) & 3u;
-  const ulonglong2 m0 = io[lane * 4 + (0 ^ mswz)], m1 = io[lane * 4 + (1 ^ mswz)];
-  ulonglong2 m2 = io[lane * 4 + (2 ^ mswz)], m3 = io[lane * 4 + (3 ^ mswz)];
+  /* (planar: record r of copy r / 16 -- first half at 2 (r mod 16), second half 32 positions behind) */
+  const u32 mo = ps ? (lane >> 4) * RGB_TICK_BLOCK + (lane & 15u) * 2u : lane * 4u;
+  const ulonglong2 m0 = io[ps ? mo : mo + (0 ^ mswz)], m1 = io[ps ? mo + 1u : mo + (1 ^ mswz)];
+  ulonglong2 m2 = io[ps ? mo + 32u : mo + (2 ^ mswz)], m3 = io[ps ? mo + 33u : mo + (3 ^ mswz)];
   if (rgb_half_msg_class(cls)) {
     /* the upper half was not loaded: zeros, as the field list of these kinds says -- but for a written event that
      * carries two ranges (RGB_MF_SEQ2: the lower one rides in the record's last piece), which re-reads its record */
     m2 = make_ulonglong2(0, 0); m3 = make_ulonglong2(0, 0);
-    if (cls == 2 && active && (((m0.x >> 48) & 0xFFull) & RGB_MF_SEQ2)) m3 = ld16<true>(src + lane * 4u + 3u);
+    if (cls == 2 && active && (((m0.x >> 48) & 0xFFull) & RGB_MF_SEQ2)) m3 = ld16<true>(ps ? srcB + lane * 2u + 1u : src + lane * 4u + 3u);
   }
   RGB_TT(1);
   if (TR && RGB_TRAIN_RUNS_LDS && !PEERS_LDS && cls == 0 && dev.max_runs >= (u32)RGB_RUNS_LDS)
@@ -2814,13 +2844,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   const bool has_srv = TR && active && sv < dev.n_servers && ((m0.x >> 32) & 0xFFull) != RGB_MSG_NOP;
   unsigned char *seqp = nullptr;
   unsigned need = 0;
-#ifdef RGB_X_TRAIN_NODEPS
-  /* EXPERIMENT (never in the product; breaks parity): no dependency wait -- the upper bound of what overlapping
-   * ticks can give */
-  if (false) {
-#else
   if (TR) {
-#endif
     /* 0. every message of the slice belongs to the shard (= the XCD) this wavefront serves: a tick that is not in
      * bucket order must not be computed on another XCD's lines */
     if (__ballot(has_srv && rgb_shard_of_server(sv, (unsigned)N) != shard) != 0ull) {
@@ -2832,6 +2856,12 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     need = has_srv ? need_raw : 0u;
     unsigned spins = 0;
     bool late = has_srv;
+#ifdef RGB_X_TRAIN_NODEPS
+    /* EXPERIMENT builds (never in the product; break parity): 1 = no poll at all -- the tick without the dependency
+     * waits AND without the poll's round trip (what a sequence tag inside the row would give at best); 2 = one poll
+     * whose answer is ignored -- without the waits only */
+    if (RGB_X_TRAIN_NODEPS == 1) late = false;
+#endif
     for (;;) {
       /* only the lanes that are still waiting poll again; a wavefront that has to wait backs off (thousands of
        * waiting wavefronts polling flat out starve the ones they wait for of L2 bandwidth) */
@@ -2842,6 +2872,9 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
         const unsigned cur = __hip_atomic_load(seqp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
         late = cur != need;
+#ifdef RGB_X_TRAIN_NODEPS
+        if (RGB_X_TRAIN_NODEPS == 2) late = false;
+#endif
       }
       if (__ballot(late) == 0ull) break;
       spins += 1;
@@ -3031,6 +3064,27 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   lds_barrier();
   if (!TR && RGB_KNOB(dev, 2u)) return true;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
+  if (ps) {
+    /* planar: the first halves of the slice's decisions are 32 cnt contiguous bytes of plane A (whole lines, two
+     * instructions); only full records have a second half in plane B */
+    ulonglong2 *dA = reinterpret_cast<ulonglong2 *>(dec) + (size_t)base * 2u, *dB = dA + (size_t)ps * 2u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if ((u32)k * 32u >= SL) break;
+      const u32 piece = k * RGB_TICK_BLOCK + lane;
+      const u32 j = piece >> 1, part = piece & 1u;
+      if (j < cnt) store16_nt((void *)(dA + piece), io[j * RGB_IO_SLOT + part]);
+    }
+    if ((~cmask & __ballot(active)) != 0ull) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if ((u32)k * 32u >= SL) break;
+        const u32 piece = k * RGB_TICK_BLOCK + lane;
+        const u32 j = piece >> 1, part = piece & 1u;
+        if (j < cnt && !((cmask >> j) & 1ull)) store16_nt((void *)(dB + piece), io[j * RGB_IO_SLOT + 2u + part]);
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;
@@ -3043,6 +3097,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     if (j < cnt && (part < 2u || !((cmask >> j) & 1ull)))
       store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
 #endif
+  }
   }
 #if defined(RGB_X_TRAIN_TIMELINE) && !defined(RGB_HOST_EMULATION)
   if (TR && dev.dbg_buf != nullptr && lane == 0 && blockIdx.x < (1u << 20)) {
@@ -3412,7 +3467,7 @@ __global__ void rgb_train_seq_kernel(rgb_dev dev, const rgb_msg *__restrict__ ms
                                      unsigned char *__restrict__ stamps) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u64 w = *reinterpret_cast<const u64 *>(msgs + i);
+  const u64 w = dev.ps ? reinterpret_cast<const u64 *>(msgs)[(size_t)i * 4u] : *reinterpret_cast<const u64 *>(msgs + i);
   const u32 sv = (u32)(w & 0xFFFFFFFFull);
   if (((w >> 32) & 0xFFull) == RGB_MSG_NOP || sv >= dev.n_servers) { stamps[i] = 0; return; }
   const u32 k = rgb_seq_index(sv, dev.n_members, dev.seq_stride);
@@ -3457,14 +3512,16 @@ struct SynMsg {
   bool off_steady;      /* the producer's bucketing hint (rgb_bucket_hinted): never part of the record */
 };
 
-__device__ __forceinline__ void syn_store(rgb_msg *slot, const SynMsg &m) {
-  ulonglong2 *o = reinterpret_cast<ulonglong2 *>(slot);
+/* ps: the plane stride of a planar stream (the record's second half sits 32 ps bytes behind plane A's 32 slot), or 0 */
+__device__ __forceinline__ void syn_store(rgb_msg *out, u32 slot, u32 ps, const SynMsg &m) {
+  ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out) + (size_t)slot * (ps ? 2u : 4u);
+  ulonglong2 *o2 = ps ? o + (size_t)ps * 2u : o + 2;
   u64 w0 = (u64)m.server | ((u64)(m.kind & 0xFF) << 32) | ((u64)(m.from & 0xFF) << 40) |
            ((u64)(m.flags & 0xFF) << 48) | ((u64)(m.gap & 0xFF) << 56);
   o[0] = make_ulonglong2(w0, m.term);
   o[1] = make_ulonglong2(m.a, m.b);
-  o[2] = make_ulonglong2(m.c, (u64)m.n_entries | ((u64)m.n_run0 << 32));
-  o[3] = make_ulonglong2(m.run0, m.run1);
+  o2[0] = make_ulonglong2(m.c, (u64)m.n_entries | ((u64)m.n_run0 << 32));
+  o2[1] = make_ulonglong2(m.run0, m.run1);
 }
 
 __device__ __forceinline__ SynMsg syn_msg(u32 server, unsigned kind, unsigned from, unsigned flags, u64 term,
@@ -3696,7 +3753,7 @@ __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u6
     synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) {
       const unsigned b = bucket(m);
       const u32 slot = blk[b] + atomicAdd(&rank[b], 1u);
-      syn_store(out + slot, m);
+      syn_store(out, slot, dev.ps, m);
       /* the producer's own count of the messages it has addressed to the server = the value of the server's
        * sequence byte the message must find in a train launch (one lane per group, one message per server and
        * tick: nobody else touches the counter) */
