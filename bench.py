@@ -210,9 +210,6 @@ def run_literal(name, ticks, torch, engine, W, abi, dev, local_rank, reps=3):
     }
 
 
-PLANES_DEFAULT = False
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,11 +247,6 @@ def main():
                          "generator left in device memory (rgb_train_plan_build_device; launches take the persistent "
                          "form) -- no copy of the counts to the host, no host merge")
     ap.add_argument("--graph", action="store_true", help="capture the timed region into a hipGraph even when it is one or two launches")
-    ap.add_argument("--planes", dest="planes", action="store_true", default=PLANES_DEFAULT,
-                    help="the device-resident message and decision streams are PLANAR (RGB_CFG_PLANES, include/ra_gpu_batch.h: "
-                         "the halves of record i at 32 i of the tick's plane A / plane B): the generator writes them that way, "
-                         "the kernels read and write them that way; same records, same decisions")
-    ap.add_argument("--no-planes", dest="planes", action="store_false", help="64-byte records (the format of rounds 1-4)")
     ap.add_argument("--snapshot-kernel", action="store_true",
                     help="train: one launch per leaderboard period with the snapshot KERNEL between the launches (the "
                          "round-3 form; default: the snapshots run as rows of launches of up to 255 ticks)")
@@ -321,10 +313,8 @@ def main():
     NK = abi.N_KINDS
     seed = (args.seed ^ (rank * 0x9E3779B97F4A7C15)) & ((1 << 64) - 1)
 
-    planes = bool(args.planes) and hasattr(abi, "CFG_PLANES")
     eng = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=2, ring_capacity=1024,
-                            flags=(abi.CFG_TRAIN_PERSISTENT if args.train_form == "persistent" else 0) |
-                                  (abi.CFG_PLANES if planes else 0))
+                            flags=abi.CFG_TRAIN_PERSISTENT if args.train_form == "persistent" else 0)
     st0 = W.initial_states(G, N, seed)
     eng.set_state(0, st0)
     hint_level = {"none": 0, "state": 1, "header": 2}[args.hint]
@@ -416,15 +406,9 @@ def main():
     alg_bytes = W.algorithmic_bytes_from_counts(kc, N)
     n_runs_hist = np.bincount(st_aged["n_runs"], minlength=17).tolist()
 
-    def tick_records(buf, t, dtype):
-        """the 64-byte records of tick t of a device-resident stream (planar or not)"""
-        nt = int(n_dec[t])
-        if planes:
-            return abi.from_planes(buf[t * tick_bytes:(t + 1) * tick_bytes].cpu().numpy(), nt, S, dtype)
-        return buf[t * tick_bytes:t * tick_bytes + nt * 64].cpu().numpy().view(dtype)
-
     def tick_msgs(t):
-        return tick_records(d_msgs, t, abi.MSG_DTYPE)
+        nt = int(n_dec[t])
+        return d_msgs[t * tick_bytes:t * tick_bytes + nt * 64].cpu().numpy().view(abi.MSG_DTYPE)
 
     # ---- correctness gate (rank 0): the first ticks bit-for-bit against the oracle ----
     checked = 0
@@ -439,7 +423,7 @@ def main():
             for t in range(min(args.check_ticks, T)):
                 want, _ = cpu.step_parallel(first_ticks[t])
                 nt = int(n_dec[t])
-                got = abi.expand_decisions(tick_records(d_dec, t, abi.DECISION_DTYPE))
+                got = abi.expand_decisions(d_dec[t * tick_bytes:t * tick_bytes + nt * 64].cpu().numpy().view(abi.DECISION_DTYPE))
                 if got.tobytes() != want.tobytes():
                     bad = int(np.flatnonzero((got.view(np.uint8).reshape(nt, 64) !=
                                               want.view(np.uint8).reshape(nt, 64)).any(axis=1))[0])
@@ -616,7 +600,7 @@ def main():
                              f"dependency did not commit within the spin bound); xcc of shards {xcc.tolist()}")
         # every decision of every tick of the replay against the generation pass (per-tick launches)
         for t in range(T if not os.environ.get("RGB_BENCH_NOCHECK") else 0):   # NOCHECK: timing probes of broken variants
-            nb = tick_bytes if planes else int(n_dec[t]) * 64
+            nb = int(n_dec[t]) * 64
             if not torch.equal(d_dec2[t * tick_bytes:t * tick_bytes + nb], d_dec[t * tick_bytes:t * tick_bytes + nb]):
                 raise SystemExit(f"PARITY FAILURE: train decisions of tick {t} differ from the per-tick launches")
         # every leaderboard snapshot taken inside (or between) the launches against the snapshot kernel of pass 1
@@ -632,7 +616,7 @@ def main():
                 snaps_checked += 1
         # how many decisions of a timed tick went out in the 32-byte compact form, and which kinds stayed full
         tW = min(Wm, T - 1)
-        rawW = tick_records(d_dec2, tW, abi.DECISION_DTYPE)
+        rawW = d_dec2[tW * tick_bytes:tW * tick_bytes + int(n_dec[tW]) * 64].cpu().numpy().view(abi.DECISION_DTYPE)
         isc = (rawW["flags"] & abi.F_COMPACT) != 0
         full_by_kind = np.bincount(rawW["kind"][~isc], minlength=NK)[:NK]
         compact_info = {"fraction": round(float(isc.mean()), 4),
@@ -1048,8 +1032,6 @@ def main():
                 "leaderboard_allgather_every": SNAPSHOT_EVERY,
                 "parallelism": f"hash-sharded groups x{world}, no data-path collective",
                 "oracle_checked_ticks": checked, "state_checksum": f"{checksum_pass2:#018x}",
-                "record_streams": ("planar (RGB_CFG_PLANES): the halves of record i at 32 i of a tick's plane A / plane B, "
-                                   "written that way by the generator" if planes else "64-byte records"),
                 "stream_generation_s": round(gen_s, 2), "hip_graph": graphs is not None,
                 "launch": (("train: one rgb_train_kernel launch per %d ticks, leaderboard snapshots every %d ticks as rows "
                             "of the launch" % (TPL, SNAPSHOT_EVERY)) if snap_in_train else

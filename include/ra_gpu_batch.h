@@ -385,18 +385,6 @@ typedef struct rgb_leaderboard_row {
 #define RGB_CFG_ROUNDS_PER_LAUNCH 1u   /* rgb_submit: one kernel launch per sub-tick round, never a train (A/B measurements) */
 #define RGB_CFG_TRAIN_PERSISTENT 2u   /* trains always in the persistent form (placement by construction), also on a device
                                          whose dispatcher deals blocks round robin (see "Train launches") */
-#define RGB_CFG_PLANES           8u   /* DEVICE-RESIDENT record streams are PLANAR (round 5): in every tick of the streams
-                                         handed to rgb_run_ticks_device, the train entry points, rgb_train_stamp_device and
-                                         the load generator, record i (rgb_msg or rgb_decision) is two 32-byte halves --
-                                         bytes [0, 32) at 32 i of the tick's plane A (its first 32 x stride bytes), bytes
-                                         [32, 64) at 32 i of plane B right behind it; stride = the call's tick_stride
-                                         (max_msgs; the generator: rgb_n_servers).  A tick still owns 64 x stride bytes and
-                                         every index (stamps, rpc slots, plans) is what it is.  The nine kinds that use half
-                                         of their message record and the compact decisions then move WHOLE 128-byte lines
-                                         (a wavefront's 64 half records are 2 KiB of plane A instead of half of every line of
-                                         4 KiB): fewer memory requests and no half-used sectors per tick.  The second half of a
-                                         compact decision is not written, as before.  rgb_submit / rgb_collect are not
-                                         affected (host batches stay arrays of 64-byte records). */
 #define RGB_CFG_FUSE_PIPELINE    4u   /* OPT-IN (ABI v8; default off: the decision stream is the reference's event by
                                          event).  A leader's same-term success reply and its own written event end with
                                          {next_event, info, pipeline_rpcs} (src/ra_server.erl:552, 744), which the

@@ -12,7 +12,6 @@ ABI_VERSION = 8
 CFG_ROUNDS_PER_LAUNCH = 1      # rgb_config.flags: rgb_submit launches one kernel per sub-tick round (A/B measurements)
 CFG_FUSE_PIPELINE = 4          # rgb_config.flags: a leader's success reply / written event carries its pipeline_rpcs event's rpcs (opt-in)
 CFG_TRAIN_PERSISTENT = 2       # rgb_config.flags: trains always in the persistent form (placement by construction)
-CFG_PLANES = 8                 # rgb_config.flags: device-resident record streams are planar (to_planes / from_planes)
 UNDEF = np.uint64(0xFFFFFFFFFFFFFFFF)  # Erlang 'undefined'
 UNDEF_INT = 0xFFFFFFFFFFFFFFFF
 NONE = 0xFF                            # undefined member slot
@@ -236,24 +235,6 @@ def log_entries(st_row) -> list:
         t = int(st_row["run_term"][r])
         out.extend((i, t) for i in range(a, b + 1))
     return out
-
-
-def to_planes(records: np.ndarray, stride: int) -> np.ndarray:
-    """One tick of a PLANAR device-resident stream (RGB_CFG_PLANES, include/ra_gpu_batch.h) from its 64-byte records:
-    uint8[64 * stride] with bytes [0, 32) of record i at 32 i and bytes [32, 64) at 32 stride + 32 i."""
-    n = len(records)
-    assert records.dtype.itemsize == 64 and n <= stride
-    raw = np.ascontiguousarray(records).view(np.uint8).reshape(n, 64)
-    out = np.zeros((2, stride, 32), dtype=np.uint8)
-    out[0, :n] = raw[:, :32]
-    out[1, :n] = raw[:, 32:]
-    return out.reshape(-1)
-
-
-def from_planes(buf: np.ndarray, n: int, stride: int, dtype) -> np.ndarray:
-    """The first n 64-byte records (dtype) of one tick of a planar stream (the inverse of to_planes)."""
-    b = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)[:64 * stride].reshape(2, stride, 32)
-    return np.ascontiguousarray(np.concatenate([b[0, :n], b[1, :n]], axis=1)).reshape(-1).view(dtype)
 
 
 def expand_decisions(dec: np.ndarray) -> np.ndarray:

@@ -169,14 +169,6 @@ extern "C" {
 
 uint32_t rgb_abi_version(void) { return RGB_ABI_VERSION; }
 
-/* the device view of a launch over DEVICE-RESIDENT record streams: planar (RGB_CFG_PLANES) with the launch's tick
- * stride as the plane stride; every launch of rgb_submit keeps ctx->dev (64-byte records) */
-static rgb_dev stream_dev(const rgb_ctx *ctx, u32 stride) {
-  rgb_dev d = ctx->dev;
-  d.ps = (ctx->cfg.flags & RGB_CFG_PLANES) ? stride : 0u;
-  return d;
-}
-
 size_t rgb_struct_size(int which) {
   switch (which) {
     case 0: return sizeof(rgb_msg);
@@ -370,7 +362,6 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   d.max_aer_batch = ctx->cfg.max_aer_batch;
   d.dbg = 0; d.dbg_buf = nullptr;
   d.synth_hint = ctx->synth_hint;
-  d.ps = 0;
   d.fuse_pipeline = (ctx->cfg.flags & RGB_CFG_FUSE_PIPELINE) ? 1u : 0u;
   d.seq_ranges = nullptr; d.n_seq_ranges = 0;
 #ifdef RGB_PROFILE
@@ -1060,13 +1051,13 @@ int rgb_run_ticks_device(rgb_ctx *ctx, const void *d_msgs, uint32_t tick_stride,
       u64 total = 0;
       for (u32 k = 1; k < NKIND; ++k) { cc[rgb_class_of_kind(k)] += kind_counts[t * NKIND + k]; total += kind_counts[t * NKIND + k]; }
       if (total > tick_stride || kind_counts[t * NKIND + RGB_MSG_NOP]) return RGB_E_INVAL;
-      int rc = launch_tick_classes(ctx, stream_dev(ctx, tick_stride), m + off, d + off, (rgb_rpc *)d_rpcs, cc, 0, (u32)off, st);
+      int rc = launch_tick_classes(ctx, ctx->dev, m + off, d + off, (rgb_rpc *)d_rpcs, cc, 0, (u32)off, st);
       if (rc) return rc;
       continue;
     }
     u32 cnt = tick_counts ? tick_counts[t] : tick_stride;
     if (cnt > tick_stride) return RGB_E_INVAL;
-    int rc = rgb_launch_tick(stream_dev(ctx, tick_stride), -1, m + off, cnt, dn ? dn + t : nullptr, d + off, (rgb_rpc *)d_rpcs, 0,
+    int rc = rgb_launch_tick(ctx->dev, -1, m + off, cnt, dn ? dn + t : nullptr, d + off, (rgb_rpc *)d_rpcs, 0,
                              (u32)off, st);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
@@ -1096,8 +1087,7 @@ int rgb_synth_tick_stamped_device(rgb_ctx *ctx, uint64_t seed, uint64_t tick, vo
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_synth_sent, bytes));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_synth_sent, ctx->dev.seq, bytes, hipMemcpyDeviceToDevice, (hipStream_t)st));
   }
-  /* (a planar stream's plane stride is the generator's largest tick: one message per server) */
-  int rc = rgb_launch_synth(stream_dev(ctx, ctx->dev.n_servers), seed, tick, (rgb_msg *)d_msgs, ctx->d_synth, (u32 *)d_kind_counts,
+  int rc = rgb_launch_synth(ctx->dev, seed, tick, (rgb_msg *)d_msgs, ctx->d_synth, (u32 *)d_kind_counts,
                             (u32 *)d_n, (u32 *)d_bucket_counts, (unsigned char *)d_stamps,
                             d_stamps ? ctx->d_synth_sent : nullptr, st);
   if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
@@ -1327,7 +1317,7 @@ int rgb_train_stamp_device(rgb_ctx *ctx, const void *d_msgs, void *d_stamps, uin
                              hipMemcpyDeviceToDevice, st));
   for (u32 t = 0; t < n_ticks; ++t) {
     if (tick_counts[t] > tick_stride) return RGB_E_INVAL;
-    int rc = rgb_launch_train_seq(stream_dev(ctx, tick_stride), m + (size_t)t * tick_stride, tick_counts[t], ctx->d_seq_cnt,
+    int rc = rgb_launch_train_seq(ctx->dev, m + (size_t)t * tick_stride, tick_counts[t], ctx->d_seq_cnt,
                                   sp + (size_t)t * tick_stride, st);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }
@@ -1382,7 +1372,7 @@ int rgb_train_run_snap_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t
   for (u32 t = first_tick; t < first_tick + n_ticks; t += per) {
     const u32 n = first_tick + n_ticks - t < per ? first_tick + n_ticks - t : per;
     const size_t off = (size_t)t * tick_stride;
-    int rc = rgb_launch_train(stream_dev(ctx, tick_stride), (const rgb_msg *)d_msgs + off, (const unsigned char *)d_stamps + off,
+    int rc = rgb_launch_train(ctx->dev, (const rgb_msg *)d_msgs + off, (const unsigned char *)d_stamps + off,
                               tick_stride, plan->d_ticks + t, plan->d_rows + (size_t)t * (plan->bpt / RGB_TRAIN_SHARDS), n,
                               plan->bpt, (rgb_decision *)d_decisions + off,
                               (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, ctx->n_xcc,
@@ -1420,7 +1410,7 @@ int rgb_synth_apply_tick_device(rgb_ctx *ctx, const void *d_msgs, uint32_t max_m
   if (!ctx || !d_msgs || !d_decisions) return RGB_E_INVAL;
   if (!ctx->registered || !ctx->d_synth) return RGB_E_STATE;
   void *st = stream ? stream : (void *)ctx->stream;
-  int rc = rgb_launch_tick_classes(stream_dev(ctx, max_msgs), (const rgb_msg *)d_msgs, nullptr, ctx->d_synth, max_msgs,
+  int rc = rgb_launch_tick_classes(ctx->dev, (const rgb_msg *)d_msgs, nullptr, ctx->d_synth, max_msgs,
                                    (rgb_decision *)d_decisions, (rgb_rpc *)d_rpcs, 0, 0, st);
   if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   return RGB_OK;

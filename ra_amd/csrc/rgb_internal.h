@@ -215,8 +215,6 @@ struct rgb_dev {
   u32 fuse_pipeline;  /* RGB_CFG_FUSE_PIPELINE: a leader's success reply / written event emits its pipeline_rpcs event's rpcs */
   u32 synth_hint;  /* the load generator's bucketing hint (rgb_synth_set_hint): 0 none, 1 the owner's state name,
                       2 (default) + the O(1) header compare an owner can make against the fields it holds */
-  u32 ps;    /* PLANAR record streams (RGB_CFG_PLANES): the plane stride in records of THIS launch's message and
-                decision streams = its tick stride; 0 = 64-byte records (every launch of rgb_submit) */
   u32 dbg;   /* always 0 in the product library.  The -DRGB_PROFILE build (libra_gpu_batch_prof.so, tools/ only)
                 reads RGB_DEBUG: 1 = no state write-back, 2 = no decision store, 8 = no hot-line load (zero
                 state), 16 = per-wave timestamps into dbg_buf; all but 16 break parity */

@@ -65,8 +65,24 @@ __host__ __device__ constexpr bool rgb_lead_class(int c) { return c == 1 || c ==
 __host__ __device__ constexpr bool rgb_half_msg_class(int c) {
   return RGB_X_HALFMSG && (c == 2 || c == 4 || c == 5 || c == 6 || c == 7 || c == 11 || c == 12 || c == 13 || c == 14);
 }
-__host__ __device__ constexpr u32 rgb_class_slice(int c, unsigned n_members) {
+__host__ __device__ __forceinline__ constexpr u32 rgb_class_slice(int c, unsigned n_members) {
   return (RGB_X_LEAD32 && rgb_lead_class(c) && ((3u * n_members + 7u) & ~7u) == 16u) ? 32u : (u32)RGB_TICK_BLOCK;
+}
+/* TRAIN launches: the leader-side classes of groups of six to eight members (peers rows of 192 bytes) take 32 messages
+ * too -- their wavefronts fetch the 32 peers rows cooperatively into LDS (12 lanes per row, 256 bytes of LDS each)
+ * beside the 32 hot rows and the first line of the 32 run tables (16 KiB, what these kernels allocate anyway), where
+ * every lane used to read its row from memory with eleven 16-byte loads of its own (round 5; BASELINE configs[4]) */
+#ifndef RGB_X_LEAD32_WIDE
+#define RGB_X_LEAD32_WIDE 1
+#endif
+#ifndef RGB_TRAIN_RUNS_LDS
+#define RGB_TRAIN_RUNS_LDS 1      /* the first line of a train wavefront's run tables comes into LDS with its rows */
+#endif
+__host__ __device__ __forceinline__ constexpr bool rgb_wide_peers(unsigned n_members) { return ((3u * n_members + 7u) & ~7u) == 24u; }
+__host__ __device__ __forceinline__ constexpr u32 rgb_train_class_slice(int c, unsigned n_members) {
+  /* (16 KiB of LDS per wavefront: the kernels built without the run-table line allocate less) */
+  return (RGB_X_LEAD32 && RGB_X_LEAD32_WIDE && RGB_TRAIN_RUNS_LDS && rgb_lead_class(c) && rgb_wide_peers(n_members)) ? 32u
+                                                                                                                  : rgb_class_slice(c, n_members);
 }
 
 
@@ -257,10 +273,12 @@ __device__ __forceinline__ void load_peers(Lane &L) {
   if (L.peers_loaded) return;
   constexpr int PS = (3 * N + 7) & ~7;
   u64 w[PS];
-  if (PS == 16 && L.peers_lds != nullptr) {
+  if ((PS == 16 || PS == 24) && L.peers_lds != nullptr) {
+    /* (192-byte rows -- six to eight members, train launches -- lie in 256-byte LDS rows, piece p at p ^ 2 swz) */
+    const unsigned sw = PS == 24 ? L.peers_swz << 1 : L.peers_swz;
 #pragma unroll
     for (int k = 0; k < PS / 2; ++k) {
-      if (2 * k < 3 * N) { ulonglong2 v = L.peers_lds[(unsigned)k ^ L.peers_swz]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+      if (2 * k < 3 * N) { ulonglong2 v = L.peers_lds[(unsigned)k ^ sw]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
     }
   } else {
     const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(L.peers);
@@ -328,7 +346,7 @@ __device__ __forceinline__ bool range_nonempty(const Lane &L) { return L.first <
  * run, on the critical path of the wavefront's life.  The table is read-only for these kinds (a leader never truncates
  * its own log; a pushed run stays in registers until the commit). */
 #define RGB_RUNS_LDS 8
-#ifndef RGB_TRAIN_RUNS_LDS
+#ifndef RGB_TRAIN_RUNS_LDS     /* (default set in front of rgb_train_class_slice) */
 #define RGB_TRAIN_RUNS_LDS 1
 #endif
 /* (start, term) of in-memory run k */
@@ -2478,8 +2496,9 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   /* piece i of the peers row = (match_index, next_index) of member i */
   u64 wm[N], wn[N];
   if (prow != nullptr) {
+    const unsigned psw = rgb_wide_peers((unsigned)N) ? swz << 1 : swz;      /* (wide rows: 256 bytes of LDS each) */
 #pragma unroll
-    for (int k = 0; k < N; ++k) { const ulonglong2 v = prow[(unsigned)k ^ swz]; wm[k] = v.x; wn[k] = v.y; }
+    for (int k = 0; k < N; ++k) { const ulonglong2 v = prow[(unsigned)k ^ psw]; wm[k] = v.x; wn[k] = v.y; }
   } else {
     const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(peers);
 #pragma unroll
@@ -2581,11 +2600,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const u32 piece = k * RGB_TICK_BLOCK + lane;        /* 16-byte piece of the 64-message block */
-      const u32 r = piece >> 2, q = piece & 3u, rr = r < cnt ? r : cnt - 1u;
-      /* planar streams (dev.ps, see rgb_tick_slice): the halves of record i at 32 i of plane A / plane B */
-      v[k] = ld16<true>(dev.ps ? reinterpret_cast<const ulonglong2 *>(msgs) + (q < 2u ? (size_t)0 : (size_t)dev.ps * 2u) +
-                                     (size_t)(base + rr) * 2u + (q & 1u)
-                               : src + (piece < last ? piece : last));
+      v[k] = ld16<true>(src + (piece < last ? piece : last));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2615,9 +2630,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
     const u32 piece = k * RGB_TICK_BLOCK + lane;
     const u32 j = piece >> 2, part = piece & 3u;
     if (j < cnt && (part < 2u || !((u32)io[j * RGB_IO_SLOT].y & RGB_F_COMPACT)))
-      store16_nt(dev.ps ? (void *)(reinterpret_cast<ulonglong2 *>(dec) + (part < 2u ? (size_t)0 : (size_t)dev.ps * 2u) +
-                                   (size_t)(base + j) * 2u + (part & 1u))
-                        : (void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
+      store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
   }
 }
 
@@ -2757,8 +2770,11 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #endif
   const bool lead_cls = rgb_lead_class(cls);              /* append_entries_reply, append, pipeline_rpcs */
   constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
+  /* train launches of groups of six to eight members: the leader-side slices are 32 messages as well, their 192-byte
+   * peers rows come into LDS cooperatively (rgb_train_class_slice) */
+  constexpr bool PEERS_WIDE = TR && rgb_train_class_slice(1, (unsigned)N) == 32u && !PEERS_LDS;
   /* a table row of max_runs >= 8 runs holds the whole 128-byte line that is fetched (wave-uniform) */
-  const bool RUNS_LDS = TR && RGB_TRAIN_RUNS_LDS && PEERS_LDS && dev.max_runs >= (u32)RGB_RUNS_LDS;
+  const bool RUNS_LDS = TR && RGB_TRAIN_RUNS_LDS && (PEERS_LDS || PEERS_WIDE) && dev.max_runs >= (u32)RGB_RUNS_LDS;
   /* groups of six and more members (no peers rows in LDS: the area is free): an append_entries_rpc wavefront whose
    * messages point below the current term's entries (prev_log_term != term in any lane: log-matching repair, the
    * configs[4] workload) will walk its servers' run tables -- their first line comes with the hot rows (decided
@@ -2776,13 +2792,6 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   RGB_TT(0);
   if (TR && RGB_X_TICKET_AT == 2 && ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
   const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(msgs + base);
-  /* PLANAR record streams (dev.ps != 0: RGB_CFG_PLANES, include/ra_gpu_batch.h): record i of the tick is two 32-byte
-   * halves, the first at 32 i of plane A (the tick's first 32 ps bytes), the second at 32 i of plane B behind it --
-   * every index stays what it is.  A wavefront of a class that uses half of its records reads 2 KiB of whole lines
-   * instead of half of every line of 4 KiB; compact decisions go out the same way */
-  const u32 ps = dev.ps;
-  const ulonglong2 *srcA = reinterpret_cast<const ulonglong2 *>(msgs) + (size_t)base * 2u;
-  const ulonglong2 *srcB = srcA + (size_t)ps * 2u;
   /* a train's stamp byte travels with the record copies: requested here, it arrives under their round trip (behind
    * the records' barrier it was a second memory round trip in front of the first poll) */
   unsigned need_raw = 0;
@@ -2795,20 +2804,6 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
      * LDS slots are never consumed. */
     const u32 last = cnt * 4u - 1u;
     const bool half = rgb_half_msg_class(cls);            /* only pieces 0, 1 of every record are asked for */
-    if (ps) {
-      /* planar: copy k brings records 16 k .. 16 k + 15 -- lanes 0..31 their first halves (512 contiguous bytes of
-       * plane A), lanes 32..63 their second halves (512 contiguous bytes of plane B): every 16-lane pass of the
-       * instruction is 256 contiguous bytes (lanes alternating between the planes were measured 6 % slower than
-       * 64-byte records: the address coalescer merges neighbouring lanes only) */
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if ((u32)k * 16u >= SL) break;
-        const u32 hB = lane >> 5, j = lane & 31u;
-        const u32 r = 16u * (u32)k + (j >> 1);
-        const u32 rr = r < cnt ? r : cnt - 1u;
-        if (!half || hB == 0u) glds16<GLDS_NT>((hB ? srcB : srcA) + rr * 2u + (j & 1u), io + k * RGB_TICK_BLOCK);
-      }
-    } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if ((u32)k * 16u >= SL) break;                      /* a 32-message slice is two copies */
@@ -2816,7 +2811,6 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
       const u32 r = piece >> 2;
       const u32 sp = (r << 2) | ((piece & 3u) ^ ((r >> 2) & 3u));
       if (!half || (sp & 2u) == 0u) glds16<GLDS_NT>(src + (sp < last ? sp : last), io + k * RGB_TICK_BLOCK);
-    }
     }
     glds_wait();
   }
@@ -2826,15 +2820,13 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #endif
   const bool active = lane < cnt;
   const u32 mswz = (lane >> 2) & 3u;
-  /* (planar: record r of copy r / 16 -- first half at 2 (r mod 16), second half 32 positions behind) */
-  const u32 mo = ps ? (lane >> 4) * RGB_TICK_BLOCK + (lane & 15u) * 2u : lane * 4u;
-  const ulonglong2 m0 = io[ps ? mo : mo + (0 ^ mswz)], m1 = io[ps ? mo + 1u : mo + (1 ^ mswz)];
-  ulonglong2 m2 = io[ps ? mo + 32u : mo + (2 ^ mswz)], m3 = io[ps ? mo + 33u : mo + (3 ^ mswz)];
+  const ulonglong2 m0 = io[lane * 4 + (0 ^ mswz)], m1 = io[lane * 4 + (1 ^ mswz)];
+  ulonglong2 m2 = io[lane * 4 + (2 ^ mswz)], m3 = io[lane * 4 + (3 ^ mswz)];
   if (rgb_half_msg_class(cls)) {
     /* the upper half was not loaded: zeros, as the field list of these kinds says -- but for a written event that
      * carries two ranges (RGB_MF_SEQ2: the lower one rides in the record's last piece), which re-reads its record */
     m2 = make_ulonglong2(0, 0); m3 = make_ulonglong2(0, 0);
-    if (cls == 2 && active && (((m0.x >> 48) & 0xFFull) & RGB_MF_SEQ2)) m3 = ld16<true>(ps ? srcB + lane * 2u + 1u : src + lane * 4u + 3u);
+    if (cls == 2 && active && (((m0.x >> 48) & 0xFFull) & RGB_MF_SEQ2)) m3 = ld16<true>(src + lane * 4u + 3u);
   }
   RGB_TT(1);
   if (TR && RGB_TRAIN_RUNS_LDS && !PEERS_LDS && cls == 0 && dev.max_runs >= (u32)RGB_RUNS_LDS)
@@ -2857,9 +2849,10 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     unsigned spins = 0;
     bool late = has_srv;
 #ifdef RGB_X_TRAIN_NODEPS
-    /* EXPERIMENT builds (never in the product; break parity): 1 = no poll at all -- the tick without the dependency
-     * waits AND without the poll's round trip (what a sequence tag inside the row would give at best); 2 = one poll
-     * whose answer is ignored -- without the waits only */
+    /* EXPERIMENT builds (never in the product; break parity; bench.py --snapshot-kernel: the rows of an in-launch
+     * snapshot wait for exact bytes): 1 = no poll at all -- the tick without the dependency waits AND without the
+     * poll's round trip (what a sequence tag inside the row could give at best); 2 = one poll whose answer is
+     * ignored -- without the waits only.  Round 5, same box: 17.46 us per tick, 16.72 with 2, 16.36 with 1 */
     if (RGB_X_TRAIN_NODEPS == 1) late = false;
 #endif
     for (;;) {
@@ -2911,7 +2904,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
      * lines, so the row's line(s) are in the cache when the lane loads the row into registers (a second
      * full-latency round trip otherwise; keeping the whole row in registers across the fetch costs
      * spills on the pipelining paths) */
-    if (lead_cls && !PEERS_LDS) {
+    if (lead_cls && !PEERS_LDS && !PEERS_WIDE) {
       const u64 *pp = dev.peers + (size_t)srv * dev.peer_stride;
       pf0 = ldg8(TR, pp);
       if (3 * N > 16) pf1 = ldg8(TR, pp + 16);
@@ -2934,6 +2927,28 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
         const u32 sj = __shfl(srv, (int)r, 64);
         glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.runs + (size_t)sj * dev.max_runs * 2u) + ((lane & 7u) ^ ((r >> 1) & 7u)),
                      io + (8 + k) * RGB_TICK_BLOCK);
+      }
+    }
+    if (PEERS_WIDE && lead_cls) {
+      /* the 192-byte peers rows of the slice's 32 servers: four rows per instruction, 16 lanes a row of which twelve
+       * fetch (256 bytes of LDS per row, behind the 32 hot rows); piece p of row r sits at position p ^ 2 ((r >> 1) & 7)
+       * -- the owners' 16-byte reads collide in pairs only -- and the first line of the 32 run tables behind them */
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u32 r = 4 * k + (lane >> 4);
+        const u32 sj = __shfl(srv, (int)r, 64);
+        const u32 pcx = (lane & 15u) ^ (((r >> 1) & 7u) << 1);
+        if (pcx < 12u)
+          glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.peers + (size_t)sj * 24u) + pcx, io + (4 + k) * RGB_TICK_BLOCK);
+      }
+      if (RUNS_LDS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32 r = 8 * k + (lane >> 3);
+          const u32 sj = __shfl(srv, (int)r, 64);
+          glds16<ROWS>(reinterpret_cast<const ulonglong2 *>(dev.runs + (size_t)sj * dev.max_runs * 2u) + ((lane & 7u) ^ ((r >> 1) & 7u)),
+                       io + (12 + k) * RGB_TICK_BLOCK);
+        }
       }
     }
     if (PEERS_LDS && lead_cls) {
@@ -2963,8 +2978,10 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   if (TR && RGB_X_TICKET_AT == 1 && ticket_ctr != nullptr) *next_ticket = rgb_take_ticket(ticket_ctr, ctl);
   const ulonglong2 *hrow = io + lane * 8;
   const unsigned hswz = (lane >> 1) & 7u;
-  const ulonglong2 *prow = (PEERS_LDS && lead_cls) ? io + 4 * RGB_TICK_BLOCK + lane * 8 : nullptr;
-  const ulonglong2 *rrow = ((RUNS_LDS && PEERS_LDS && lead_cls) || (!PEERS_LDS && AER_RUNS)) ? io + 8 * RGB_TICK_BLOCK + lane * 8 : nullptr;
+  const ulonglong2 *prow = (PEERS_LDS && lead_cls) ? io + 4 * RGB_TICK_BLOCK + lane * 8
+                           : (PEERS_WIDE && lead_cls) ? io + 4 * RGB_TICK_BLOCK + lane * 16 : nullptr;
+  const ulonglong2 *rrow = (RUNS_LDS && PEERS_WIDE && lead_cls) ? io + 12 * RGB_TICK_BLOCK + lane * 8
+                           : ((RUNS_LDS && PEERS_LDS && lead_cls) || (!PEERS_LDS && AER_RUNS)) ? io + 8 * RGB_TICK_BLOCK + lane * 8 : nullptr;
 #ifndef RGB_HOST_EMULATION
   asm volatile("" ::"v"(pf0), "v"(pf1));   /* the touch loads above stay in the program */
 #endif
@@ -3064,27 +3081,6 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   lds_barrier();
   if (!TR && RGB_KNOB(dev, 2u)) return true;
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
-  if (ps) {
-    /* planar: the first halves of the slice's decisions are 32 cnt contiguous bytes of plane A (whole lines, two
-     * instructions); only full records have a second half in plane B */
-    ulonglong2 *dA = reinterpret_cast<ulonglong2 *>(dec) + (size_t)base * 2u, *dB = dA + (size_t)ps * 2u;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if ((u32)k * 32u >= SL) break;
-      const u32 piece = k * RGB_TICK_BLOCK + lane;
-      const u32 j = piece >> 1, part = piece & 1u;
-      if (j < cnt) store16_nt((void *)(dA + piece), io[j * RGB_IO_SLOT + part]);
-    }
-    if ((~cmask & __ballot(active)) != 0ull) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if ((u32)k * 32u >= SL) break;
-        const u32 piece = k * RGB_TICK_BLOCK + lane;
-        const u32 j = piece >> 1, part = piece & 1u;
-        if (j < cnt && !((cmask >> j) & 1ull)) store16_nt((void *)(dB + piece), io[j * RGB_IO_SLOT + 2u + part]);
-      }
-    }
-  } else {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const u32 piece = k * RGB_TICK_BLOCK + lane;
@@ -3097,7 +3093,6 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     if (j < cnt && (part < 2u || !((cmask >> j) & 1ull)))
       store16_nt((void *)(dst + piece), io[j * RGB_IO_SLOT + part]);
 #endif
-  }
   }
 #if defined(RGB_X_TRAIN_TIMELINE) && !defined(RGB_HOST_EMULATION)
   if (TR && dev.dbg_buf != nullptr && lane == 0 && blockIdx.x < (1u << 20)) {
@@ -3318,11 +3313,18 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   __shared__ ulonglong2 io[!RGB_TRAIN_RUNS_LDS ? RGB_TICK_BLOCK * RGB_HOT_SLOT
                            : rgb_class_slice(1, (unsigned)N) == 32u ? 12 * RGB_TICK_BLOCK : 16 * RGB_TICK_BLOCK];
   const u32 x = blockIdx.x & (RGB_TRAIN_SHARDS - 1u), k = blockIdx.x / RGB_TRAIN_SHARDS;
-  const u32 t = k / args.rpt, row = k - t * args.rpt;
-  if (t >= args.n_ticks) return;
-  const rgb_train_tick *p = args.plan + t;
-  if (row >= p->n_rows) return;
-  const u32 e = args.row_tab[(size_t)t * args.rpt + row];
+  const u32 rpt = args.rpt, n_ticks = args.n_ticks;
+  const u32 t = k / rpt, row = k - t * rpt;
+  /* The block's prologue is a chain of scalar-memory round trips in front of the first record load, and a wavefront
+   * slot is held all the while (the launch is bound by wave-time over slots): the tick's header and the row's table
+   * entry are requested TOGETHER, from clamped addresses, and looked at once both are here -- written with an early
+   * return between them they were two round trips (and the kernel arguments behind each return a third and fourth) */
+  const u32 tc = t < n_ticks ? t : n_ticks - 1u;           /* (a launch has at least one tick) */
+  const rgb_train_tick *p = args.plan + tc;
+  const u32 n_rows = p->n_rows;
+  const u32 e = args.row_tab[(size_t)tc * rpt + row];
+  /* (bitwise: both loads are wanted by the one decision; no table entry is all ones -- its class byte is <= 30) */
+  if ((t >= n_ticks) | (row >= n_rows) | (e == 0xFFFFFFFFu)) return;
   const u32 pc = e >> 24;                                  /* plan class = 2 x class + sub-bucket */
   if (pc == RGB_PC_SNAP) {
     /* the snapshot in front of this tick; in front of the launch's FIRST tick it is the caller's (outside the launch) */
@@ -3334,8 +3336,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   }
   const int cls = (int)(pc >> 1);
   const u32 off = p->off[pc][x], ncls = p->cnt[pc][x];
-  constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
-  const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
+  const u32 SL = rgb_train_class_slice(cls, (unsigned)N);
   const u32 lbase = (e & 0xFFFFFFu) * SL;
   if (lbase >= ncls) return;
   const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
@@ -3387,7 +3388,6 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   }
   u32 raw = rgb_take_ticket(args.ctl + RGB_TRAIN_CTL_TICKET * (1u + x), args.ctl);
   u32 t = 0, cum = 0;
-  constexpr bool PEERS_LDS = rgb_class_slice(1, (unsigned)N) == 32u;
   for (;;) {
 #if defined(RGB_HOST_EMULATION) || !defined(__HIP_DEVICE_COMPILE__)   /* (the host pass only parses the kernel) */
     const rgb_train_args *A = &args;
@@ -3430,7 +3430,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
     }
     const int cls = (int)(pc >> 1);
     const u32 off = p->off[pc][x], ncls = p->cnt[pc][x];
-    const u32 SL = (PEERS_LDS && rgb_lead_class(cls)) ? 32u : (u32)RGB_TICK_BLOCK;
+    const u32 SL = rgb_train_class_slice(cls, (unsigned)N);
     const u32 lbase = (e & 0xFFFFFFu) * SL;
     if (lbase >= ncls) { raw = rgb_take_ticket(tk, A->ctl); continue; }
     const u32 cnt = ncls - lbase < SL ? ncls - lbase : SL;
@@ -3467,7 +3467,7 @@ __global__ void rgb_train_seq_kernel(rgb_dev dev, const rgb_msg *__restrict__ ms
                                      unsigned char *__restrict__ stamps) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u64 w = dev.ps ? reinterpret_cast<const u64 *>(msgs)[(size_t)i * 4u] : *reinterpret_cast<const u64 *>(msgs + i);
+  const u64 w = *reinterpret_cast<const u64 *>(msgs + i);
   const u32 sv = (u32)(w & 0xFFFFFFFFull);
   if (((w >> 32) & 0xFFull) == RGB_MSG_NOP || sv >= dev.n_servers) { stamps[i] = 0; return; }
   const u32 k = rgb_seq_index(sv, dev.n_members, dev.seq_stride);
@@ -3512,16 +3512,14 @@ struct SynMsg {
   bool off_steady;      /* the producer's bucketing hint (rgb_bucket_hinted): never part of the record */
 };
 
-/* ps: the plane stride of a planar stream (the record's second half sits 32 ps bytes behind plane A's 32 slot), or 0 */
-__device__ __forceinline__ void syn_store(rgb_msg *out, u32 slot, u32 ps, const SynMsg &m) {
-  ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out) + (size_t)slot * (ps ? 2u : 4u);
-  ulonglong2 *o2 = ps ? o + (size_t)ps * 2u : o + 2;
+__device__ __forceinline__ void syn_store(rgb_msg *slot, const SynMsg &m) {
+  ulonglong2 *o = reinterpret_cast<ulonglong2 *>(slot);
   u64 w0 = (u64)m.server | ((u64)(m.kind & 0xFF) << 32) | ((u64)(m.from & 0xFF) << 40) |
            ((u64)(m.flags & 0xFF) << 48) | ((u64)(m.gap & 0xFF) << 56);
   o[0] = make_ulonglong2(w0, m.term);
   o[1] = make_ulonglong2(m.a, m.b);
-  o2[0] = make_ulonglong2(m.c, (u64)m.n_entries | ((u64)m.n_run0 << 32));
-  o2[1] = make_ulonglong2(m.run0, m.run1);
+  o[2] = make_ulonglong2(m.c, (u64)m.n_entries | ((u64)m.n_run0 << 32));
+  o[3] = make_ulonglong2(m.run0, m.run1);
 }
 
 __device__ __forceinline__ SynMsg syn_msg(u32 server, unsigned kind, unsigned from, unsigned flags, u64 term,
@@ -3753,7 +3751,7 @@ __global__ __launch_bounds__(64) void rgb_synth_kernel(rgb_dev dev, u64 seed, u6
     synth_group<N>(dev, seed, tick, g, [&](const SynMsg &m) {
       const unsigned b = bucket(m);
       const u32 slot = blk[b] + atomicAdd(&rank[b], 1u);
-      syn_store(out, slot, dev.ps, m);
+      syn_store(out + slot, m);
       /* the producer's own count of the messages it has addressed to the server = the value of the server's
        * sequence byte the message must find in a train launch (one lane per group, one message per server and
        * tick: nobody else touches the counter) */
@@ -4243,7 +4241,7 @@ u32 rgb_train_make_tick(const u32 *bucket_counts, unsigned n_members, rgb_train_
           before += (y < x ? bucket_counts[(c * RGB_TRAIN_SHARDS + y) * 2u] + bucket_counts[(c * RGB_TRAIN_SHARDS + y) * 2u + 1u] : 0u);
         if (sub) before += bucket_counts[(c * RGB_TRAIN_SHARDS + x) * 2u];
         out->off[pc][x] = acc + before; out->cnt[pc][x] = n;
-        const u32 sl = rgb_class_slice((int)c, n_members);
+        const u32 sl = rgb_train_class_slice((int)c, n_members);
         const u32 r = (n + sl - 1) / sl;
         if (r > need) need = r;
       }
@@ -4342,7 +4340,7 @@ __global__ __launch_bounds__(1024) void rgb_train_plan_kernel(const u32 *__restr
   const u32 snap_rows = (snapshot_every && gt && gt % snapshot_every == 0u) ? snap_rows_n : 0u;
   if (tid < RGB_N_PCLASSES) {
     const u32 pc = tid, c = pc >> 1, sub = pc & 1u;
-    const u32 sl = rgb_class_slice((int)c, n_members);
+    const u32 sl = rgb_train_class_slice((int)c, n_members);
     u32 need = 0;
     for (u32 x = 0; x < RGB_TRAIN_SHARDS; ++x) {
       const u32 b = (c * RGB_TRAIN_SHARDS + x) * 2u + sub;       /* the stream is bucket-major: (class, shard, sub) */

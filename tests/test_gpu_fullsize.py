@@ -130,6 +130,76 @@ def test_config5_repair_backlogs_at_16384_groups(engine_mod, oracle_lib):
     cpu.close()
 
 
+def test_config5_repair_backlogs_at_full_size(engine_mod, oracle_lib):
+    """VERDICT round 4, "What's weak" 1 (i): SURVEY 8(d) config 5 at its BASELINE size -- 65 536 groups x 7 -- as a
+    test of its own (bench.py checks the same configuration in the driver's run): 8 ticks of the log-matching repair
+    stream, every decision, every rpc record, the whole final state and the checksum of checksums."""
+    from ra_amd import workload as W
+    G, N, seed, ticks = 65536, 7, 0x5EED0005, 8
+    st = W.initial_states(G, N, seed, backlog=1024, boundaries=(3, 6))
+    cpu = oracle_lib.Oracle(G, N, max_runs=16)
+    cpu.set_state(0, st)
+    n_dec = 0
+    with engine_mod.RaGpuBatch(G, N, max_runs=16, ring_capacity=G * N, ring_slots=2) as gpu:
+        gpu.set_state(0, st)
+        for t in range(ticks):
+            m = W.gen_tick(cpu.get_state(), N, t, seed, W.MIX_CONFIG5, backlog_mode=True)
+            do, ro = cpu.step_parallel(m) if hasattr(cpu, "step_parallel") else cpu.step(m)
+            dg, rg = gpu.step(m)
+            if dg.tobytes() != do.tobytes():
+                bad = int(np.flatnonzero((dg.view(np.uint8).reshape(-1, 64) != do.view(np.uint8).reshape(-1, 64)).any(axis=1))[0])
+                raise AssertionError(f"tick {t} slot {bad}: msg={m[bad]}\n gpu={dg[bad]}\n cpu={do[bad]}")
+            assert fuzz.sort_rpcs(rg).tobytes() == fuzz.sort_rpcs(ro).tobytes(), f"tick {t}: rpcs differ"
+            n_dec += len(m)
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes(), "final state differs"
+        assert gpu.state_checksum() == checksum_of_checksums(oracle_lib.server_checksums(cpu.get_state()))
+    assert n_dec > ticks * 80_000
+    cpu.close()
+
+
+def test_config4_one_rank_of_262144_groups_hashed_over_eight(engine_mod, oracle_lib):
+    """VERDICT round 4, "What's weak" 1 (ii): BASELINE configs[3] -- 262 144 groups x 5 hashed over 8 GPUs -- has one
+    rank's share on one GPU: the groups rgb_route (= shard.owner, splitmix64) gives rank 3 of 8, the closed-loop stream
+    over them for 32 ticks against the oracle (every decision, checksums, the final state), and the rank's leaderboard
+    rows at the two 16-tick boundaries against the host restatement over the oracle's state."""
+    import torch
+    from ra_amd import shard
+    from ra_amd import workload as W
+    total, world, rank, N, seed = 262144, 8, 3, 5, 0x5EED0004
+    mine = shard.local_group_ids(total, world, rank)
+    lib = engine_mod.lib()
+    assert all(lib.rgb_route(int(g), world) == rank for g in mine[:2000])
+    assert 0.9 * total / world < len(mine) < 1.1 * total / world
+    G = len(mine)
+    S = G * N
+    st0 = W.initial_states(G, N, seed)
+    cpu = oracle_lib.Oracle(G, N, max_runs=16)
+    cpu.set_state(0, st0)
+    stream = torch.cuda.Stream()
+    sp = stream.cuda_stream
+    with engine_mod.RaGpuBatch(G, N, max_runs=16, ring_slots=1, ring_capacity=64) as gpu:
+        gpu.set_state(0, st0)
+        dm = torch.zeros(S * 64, dtype=torch.uint8, device="cuda")
+        dd = torch.zeros(S * 64, dtype=torch.uint8, device="cuda")
+        dr = torch.zeros(S * (N - 1) * 56, dtype=torch.uint8, device="cuda")
+        dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for t in range(32):
+            gpu.synth_tick_device(seed, t, dm.data_ptr(), 0, dn.data_ptr(), sp)
+            gpu.synth_apply_tick_device(dm.data_ptr(), S, dd.data_ptr(), dr.data_ptr(), sp)
+            stream.synchronize()
+            n = int(dn.item())
+            msgs = dm[:n * 64].cpu().numpy().view(abi.MSG_DTYPE)
+            got = abi.expand_decisions(dd[:n * 64].cpu().numpy().view(abi.DECISION_DTYPE))
+            want, _ = cpu.step_parallel(msgs)
+            assert got.tobytes() == want.tobytes(), f"tick {t}: decisions differ"
+            if (t + 1) % 16 == 0:
+                rows = gpu.snapshot()
+                assert rows.tobytes() == shard.leaderboard_rows_from_states(cpu.get_state(), N).tobytes(), f"leaderboard after tick {t}"
+                assert gpu.state_checksum() == checksum_of_checksums(oracle_lib.server_checksums(cpu.get_state()))
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes(), "final state differs"
+    cpu.close()
+
+
 def test_config3_trains_against_the_oracle_at_full_size(engine_mod, oracle_lib):
     """VERDICT round 3, "What's weak" 1: rgb_train_kernel at 65 536 x 5 against the ORACLE itself (not through the
     per-tick launches): 64 ageing ticks, then 64 ticks generated by the stamping load generator and replayed from the

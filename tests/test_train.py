@@ -38,13 +38,10 @@ class Buf:
             torch.cuda.synchronize()
 
 
-def _generate(engine, G, N, T, seed, on_gpu, max_runs=16, age=0, planes=False):
-    """T generator ticks applied one by one with the per-tick class kernel.  Returns everything a train needs.
-    planes: the context's device-resident streams are planar (RGB_CFG_PLANES) -- the generator writes them that way,
-    every consumer reads them that way, _tick() hands the tests the 64-byte records"""
+def _generate(engine, G, N, T, seed, on_gpu, max_runs=16, age=0):
+    """T generator ticks applied one by one with the per-tick class kernel.  Returns everything a train needs."""
     S = G * N
-    eng = engine.RaGpuBatch(G, N, max_runs=max_runs, ring_slots=1, ring_capacity=64,
-                            flags=abi.CFG_PLANES if planes else 0)
+    eng = engine.RaGpuBatch(G, N, max_runs=max_runs, ring_slots=1, ring_capacity=64)
     st0 = W.initial_states(G, N, seed)
     eng.set_state(0, st0)
     tb = S * 64
@@ -69,36 +66,20 @@ def _generate(engine, G, N, T, seed, on_gpu, max_runs=16, age=0, planes=False):
     assert np.array_equal(buckets.sum(axis=1), counts)
     kinds = kc.host().view(np.uint32)[:T * abi.N_KINDS].reshape(T, abi.N_KINDS).copy()
     return dict(eng=eng, S=S, tb=tb, rs=rs, msgs=msgs, dec=dec, rpcs=rpcs, counts=counts, buckets=buckets, kinds=kinds,
-                st_start=st_start, st_end=eng.get_state(), sum_end=eng.state_checksum(), planes=planes)
+                st_start=st_start, st_end=eng.get_state(), sum_end=eng.state_checksum())
 
 
-def _tick(buf, t, tb, n, dtype, planes=False):
-    if planes:
-        a = abi.from_planes(buf.host()[t * tb:(t + 1) * tb], n, tb // 64, dtype).copy()
-    else:
-        a = buf.host()[t * tb:t * tb + n * 64].view(dtype).copy()
+def _tick(buf, t, tb, n, dtype):
+    a = buf.host()[t * tb:t * tb + n * 64].view(dtype).copy()
     return abi.expand_decisions(a) if dtype is abi.DECISION_DTYPE else a      # device streams hold compact records
 
 
-def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_gpu, chunks=(None,), age=0, planes=False):
-    r = _generate(engine, G, N, T, seed, on_gpu, age=age, planes=planes)
+def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_gpu, chunks=(None,), age=0):
+    r = _generate(engine, G, N, T, seed, on_gpu, age=age)
     eng, S, tb, rs = r["eng"], r["S"], r["tb"], r["rs"]
-    want_dec = [_tick(r["dec"], t, tb, int(r["counts"][t]), abi.DECISION_DTYPE, planes) for t in range(T)]
+    want_dec = [_tick(r["dec"], t, tb, int(r["counts"][t]), abi.DECISION_DTYPE) for t in range(T)]
     want_rpc = r["rpcs"].host()[:T * rs].copy()
-    plain = [_tick(r["msgs"], t, tb, int(r["counts"][t]), abi.MSG_DTYPE, planes) for t in range(T)]
-    if planes:
-        # the planar stream is the record stream of a context without the flag, re-laid: same generator, same seed
-        r0 = _generate(engine, G, N, T, seed, on_gpu, age=age)
-        for t in range(T):
-            n_t = int(r["counts"][t])
-            assert n_t == int(r0["counts"][t])
-            assert _tick(r0["msgs"], t, tb, n_t, abi.MSG_DTYPE).tobytes() == plain[t].tobytes()
-            assert _tick(r0["dec"], t, tb, n_t, abi.DECISION_DTYPE).tobytes() == want_dec[t].tobytes()
-            a = r["msgs"].host()[t * tb:(t + 1) * tb]
-            assert np.array_equal(a[:32 * n_t], abi.to_planes(plain[t], S)[:32 * n_t])
-            assert np.array_equal(a[32 * S:32 * S + 32 * n_t], abi.to_planes(plain[t], S)[32 * S:32 * S + 32 * n_t])
-        assert r0["st_end"].tobytes() == r["st_end"].tobytes()
-        r0["eng"].close()
+    plain = [_tick(r["msgs"], t, tb, int(r["counts"][t]), abi.MSG_DTYPE) for t in range(T)]
     # rgb_run_ticks_device over the same stream: the class-dispatch kernel (kind counts) and the kind-generic kernel
     for kinds in (r["kinds"], None):
         eng.set_state(0, r["st_start"])
@@ -106,7 +87,7 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
         eng.run_ticks_device(r["msgs"].ptr, S, T, dec1.ptr, 0, tick_counts=r["counts"], kind_counts=kinds)
         eng.synchronize()
         for t in range(T):
-            got = _tick(dec1, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE, planes)
+            got = _tick(dec1, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE)
             assert got.tobytes() == want_dec[t].tobytes(), f"rgb_run_ticks_device (kind counts: {kinds is not None}) tick {t}"
         assert eng.get_state().tobytes() == r["st_end"].tobytes()
     for t in range(T):      # the ticks are in bucket order, which keeps every class (and every (class, shard)) contiguous
@@ -145,13 +126,13 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
         # (the sequence bytes are never reset: not by rgb_upload_state either)
         st_h = stamps.host()
         for t in range(T):
-            got = _tick(dec2, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE, planes)
+            got = _tick(dec2, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE)
             if got.tobytes() != want_dec[t].tobytes():
                 bad = int(np.flatnonzero((got.view(np.uint8).reshape(-1, 64) !=
                                           want_dec[t].view(np.uint8).reshape(-1, 64)).any(axis=1))[0])
                 raise AssertionError(f"chunk {chunk}: tick {t} slot {bad}: msg={plain[t][bad]}\n train={got[bad]}\n "
                                      f"per-tick={want_dec[t][bad]}")
-            assert _tick(r["msgs"], t, tb, int(r["counts"][t]), abi.MSG_DTYPE, planes).tobytes() == plain[t].tobytes()
+            assert _tick(r["msgs"], t, tb, int(r["counts"][t]), abi.MSG_DTYPE).tobytes() == plain[t].tobytes()
             n_t = int(r["counts"][t])
             assert np.array_equal(st_h[t * S:t * S + n_t], (seen[plain[t]["server"]] & 255).astype(np.uint8)), f"stamps of tick {t}"
             seen[plain[t]["server"]] += 1
@@ -195,7 +176,7 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
     eng.synchronize()
     assert eng.train_status()[0] == 0
     for t in range(T):
-        got = _tick(dec3, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE, planes)
+        got = _tick(dec3, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE)
         assert got.tobytes() == want_dec[t].tobytes(), f"device-built plan: decisions of tick {t}"
     assert eng.get_state().tobytes() == r["st_end"].tobytes(), "device-built plan: final state differs"
     dplan.close()
@@ -206,13 +187,6 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
 @pytest.mark.parametrize("G,N,T,seed", [(192, 5, 20, 0x5EED0003), (96, 3, 12, 7), (64, 7, 10, 11)])
 def test_train_on_the_block_emulation(emulated_engine, oracle_lib, G, N, T, seed):
     check_train_equals_per_tick_launches(emulated_engine, oracle_lib, G, N, T, seed, False, chunks=(None, 3))
-
-
-@pytest.mark.parametrize("G,N,T,seed", [(192, 5, 20, 0x5EED0003), (96, 3, 12, 7), (67, 7, 10, 11), (33, 1, 6, 5)])
-def test_planar_streams_on_the_block_emulation(emulated_engine, oracle_lib, G, N, T, seed):
-    """RGB_CFG_PLANES: the generator, the per-tick kernels (class-dispatch and kind-generic), the stamping pass and the
-    trains over planar streams = the same records as 64-byte streams, the oracle's decisions, the same final state"""
-    check_train_equals_per_tick_launches(emulated_engine, oracle_lib, G, N, T, seed, False, chunks=(None, 3), planes=True)
 
 
 def test_train_with_a_wrong_stamp_fails_in_bounded_time(emulated_engine):
@@ -503,12 +477,3 @@ def test_train_on_the_gpu(oracle_lib, G, N, T, seed, age):
     """Real races: thousands of wavefronts of neighbouring ticks in flight together, every decision compared."""
     from ra_amd import engine
     check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, True, chunks=(None, 16, 5), age=age)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("G,N,T,seed,age", [(2048, 5, 24, 0x5EED0003, 0), (1000, 3, 16, 7, 0), (1024, 7, 12, 11, 0),
-                                            (16384, 5, 48, 0x5EED0003, 64)])
-def test_planar_streams_on_the_gpu(oracle_lib, G, N, T, seed, age):
-    """RGB_CFG_PLANES on the device: planar streams = the 64-byte record streams, the oracle, the same final state"""
-    from ra_amd import engine
-    check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, True, chunks=(None, 16, 5), age=age, planes=True)
