@@ -244,8 +244,8 @@ def main():
                          "holds (default); it only orders a tick, results are the same")
     ap.add_argument("--device-plan", action="store_true",
                     help="build the train's row plan ON THE DEVICE, inside the timed region, from the bucket counts the "
-                         "generator left in device memory (rgb_train_plan_build_device; launches take the persistent "
-                         "form) -- no copy of the counts to the host, no host merge")
+                         "generator left in device memory (rgb_train_plan_build_device; the grid of a dealt launch is "
+                         "then the rows bound of a tick) -- no copy of the counts to the host, no host merge")
     ap.add_argument("--graph", action="store_true", help="capture the timed region into a hipGraph even when it is one or two launches")
     ap.add_argument("--snapshot-kernel", action="store_true",
                     help="train: one launch per leaderboard period with the snapshot KERNEL between the launches (the "
@@ -623,14 +623,14 @@ def main():
                         "decision_bytes_per_tick": int(isc.sum()) * 32 + int((~isc).sum()) * 64,
                         "full_records_by_kind": {str(k): int(v) for k, v in enumerate(full_by_kind) if v}}
         train_info = {"ticks_per_launch": TPL, "blocks_per_tick": plan.blocks_per_tick,
-                      "form": "persistent" if device_plan else eng.train_form(),
+                      "form": eng.train_form(),
                       "leaderboard_snapshots": ("rows of the launch (rgb_train_run_snap_device): ordered per server like one "
                                                 "more message; a boundary that ends a launch: rgb_snapshot_train_device"
                                                 if snap_in_train else "rgb_snapshot_device between the launches"),
                       "leaderboard_snapshots_compared_with_snapshot_kernel": snaps_checked,
                       "compact_decisions": compact_info,
                       "plan": ("built on the device inside the timed region (rgb_train_plan_build_device: one kernel per "
-                               "launch in front of it, from the generator's bucket counts in device memory); persistent form"
+                               "launch in front of it, from the generator's bucket counts in device memory); grid = the rows bound of a tick"
                                if device_plan else "built on the host before the timed region from the bucket counts "
                                "(rgb_train_plan_create*): the dealt form needs the rows of a tick for its grid"),
                       "ordering_hint": {0: "none", 1: "owner's state name",
@@ -666,7 +666,7 @@ def main():
         dpl.close()
         device_plan_info = {"build_kernel_us_for_the_timed_ticks": round(best, 2), "timed_ticks": K,
                             "ticks_whose_tables_equal_the_host_plan": same, "ticks": T,
-                            "note": "--device-plan runs the timed region from it (persistent form, plan kernel inside the "
+                            "note": "--device-plan runs the timed region from it (plan kernel inside the "
                                     "region); this line's region uses the host-built plan in the dealt form"}
         if same != T:
             raise SystemExit(f"PLAN MISMATCH: the device-built plan differs from the host's in {T - same} of {T} ticks")

@@ -652,9 +652,10 @@ int  rgb_snapshot_train_device(rgb_ctx *ctx, void *d_rows, void *stream);
  *                                 (offsets, rows per class, the row table: bit for bit what rgb_train_plan_create
  *                                 computes on the host).  Enqueue it behind the producer and in front of
  *                                 rgb_train_run*_device, same stream.
- * The grid of a DEALT launch is its rows, which only the device knows here: launches of a device-built plan take the
- * PERSISTENT form (placement by construction, rows from per-shard ticket counters; 2-3 % slower on the 65 536 x 5
- * closed loop). */
+ * Launches of a device-built plan take the form the context's other trains take.  DEALT: the grid is the rows BOUND
+ * of a tick (any tick the registered groups can produce), not the tick's rows, which only the device knows -- the
+ * blocks behind a tick's real rows find an empty table entry and exit (65 536 x 5 closed loop: 11.5 k blocks per tick
+ * instead of 5.2 k, +1 % per tick; the persistent form, rows from per-shard ticket counters: +4 %). */
 int  rgb_train_plan_create_device(rgb_ctx *ctx, uint32_t n_ticks, uint32_t snapshot_every, rgb_train_plan **out);
 int  rgb_train_plan_build_device(rgb_ctx *ctx, rgb_train_plan *plan, uint32_t first_tick, uint32_t n_ticks,
                                  const void *d_bucket_counts, void *stream);

@@ -1376,7 +1376,9 @@ int rgb_train_run_snap_device(rgb_ctx *ctx, const rgb_train_plan *plan, uint32_t
                               tick_stride, plan->d_ticks + t, plan->d_rows + (size_t)t * (plan->bpt / RGB_TRAIN_SHARDS), n,
                               plan->bpt, (rgb_decision *)d_decisions + off,
                               (rgb_rpc *)d_rpcs, rpc_ring, (u32)off, ctx->d_train_ctl, ctx->n_xcc,
-                              (ctx->train_dealt.load(std::memory_order_relaxed) && !plan->on_device) ? 0u : ctx->train_blocks, st,
+                              /* (a device-built plan runs in the dealt form too: its grid is the rows BOUND of a tick --
+                               * rgb_train_rows_bound -- the blocks behind a tick's real rows find an empty table entry and exit) */
+                              ctx->train_dealt.load(std::memory_order_relaxed) ? 0u : ctx->train_blocks, st,
                               (const unsigned char *)d_snap_stamps, (rgb_leaderboard_row *)d_snap_rows);
     if (rc) { ctx->last_hip.store(rc, std::memory_order_relaxed); return RGB_E_HIP; }
   }

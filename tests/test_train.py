@@ -184,7 +184,7 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
     eng.close()
 
 
-@pytest.mark.parametrize("G,N,T,seed", [(192, 5, 20, 0x5EED0003), (96, 3, 12, 7), (64, 7, 10, 11)])
+@pytest.mark.parametrize("G,N,T,seed", [(192, 5, 20, 0x5EED0003), (96, 3, 12, 7), (64, 7, 10, 11), (72, 6, 8, 13), (80, 8, 8, 17)])
 def test_train_on_the_block_emulation(emulated_engine, oracle_lib, G, N, T, seed):
     check_train_equals_per_tick_launches(emulated_engine, oracle_lib, G, N, T, seed, False, chunks=(None, 3))
 
@@ -472,7 +472,8 @@ def test_train_bucket_matches_the_c_function(emulated_engine):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("G,N,T,seed,age", [(2048, 5, 24, 0x5EED0003, 0), (1024, 3, 16, 7, 0), (1024, 7, 12, 11, 0),
-                                            (16384, 5, 48, 0x5EED0003, 64)])
+                                            (16384, 5, 48, 0x5EED0003, 64), (1000, 6, 12, 13, 8), (1536, 8, 12, 17, 8),
+                                            (8192, 7, 24, 19, 32)])
 def test_train_on_the_gpu(oracle_lib, G, N, T, seed, age):
     """Real races: thousands of wavefronts of neighbouring ticks in flight together, every decision compared."""
     from ra_amd import engine
