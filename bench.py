@@ -857,6 +857,32 @@ def main():
                                             "back to back (no pipelining), best of 3; both forms end in the same state"}
         except Exception as e:                                              # noqa: BLE001 - reported, not raised
             host_path["rounds4"] = {"error": f"{type(e).__name__}: {e}"}
+        # the same shape at the size of ONE scheduler's mailbox drain: the four ticks' messages of the first 1 024
+        # groups (~13 k messages, four rounds) -- what a round trip costs when the launches, not the copies, are the
+        # time: this is where fusing the rounds into one train launch is meant to pay
+        try:
+            small = np.concatenate([m[m["server"] < 1024 * N] for m in first_ticks[:4]])
+            lat = {}
+            for label, flags in (("fused_train", 0), ("launch_per_round", abi.CFG_ROUNDS_PER_LAUNCH)):
+                eng_s = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=2, ring_capacity=1 << 16, flags=flags)
+                bufs_s = (np.empty(1 << 16, dtype=abi.DECISION_DTYPE), np.empty((1 << 16) * max(N - 1, 1), dtype=abi.RPC_DTYPE))
+                eng_s.set_state(0, st_aged)
+                for _ in range(20):
+                    eng_s.submit(small); eng_s.collect(out=bufs_s)
+                ts = []
+                for _ in range(200):
+                    t0 = time.perf_counter()
+                    eng_s.submit(small); eng_s.collect(out=bufs_s)
+                    ts.append(time.perf_counter() - t0)
+                ts.sort()
+                lat[label] = {"round_trip_us_p50": round(ts[len(ts) // 2] * 1e6, 1), "round_trip_us_p10": round(ts[len(ts) // 10] * 1e6, 1),
+                              "trains": eng_s.submit_trains()}
+                eng_s.close()
+            host_path["rounds4_small"] = {"batch_messages": int(len(small)), **lat,
+                                          "note": "submit + collect of one small four-round batch, 200 round trips after 20 of "
+                                                  "warm-up (the state moves on; same batch every time)"}
+        except Exception as e:                                              # noqa: BLE001 - reported, not raised
+            host_path["rounds4_small"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- second kernel of the path's neighbourhood, rank 0, N=1: batched WAL entry
     # checksums, 262 144 entries x 4 KiB = 1 GiB resident in HBM (four times the Infinity Cache); reported
