@@ -831,13 +831,13 @@ def main():
             host_path["threads4"] = {"error": f"{type(e).__name__}: {e}"}
         # the normal shape of a real batch: several messages per server in ONE submit (a leader's N-1 replies arrive
         # together).  Four consecutive ticks per batch = four sub-tick rounds: fused into one train launch, and -- same
-        # batches, RGB_CFG_ROUNDS_PER_LAUNCH -- one launch per round
+        # batches, the default since round 5 -- one launch per round (fused: RGB_CFG_SUBMIT_TRAINS)
         try:
             RB = 1 << 20
             big = [np.concatenate(first_ticks[i:i + 4]) for i in range(0, 12, 4)]
             big = [b for b in big if len(b) <= RB]
             rounds4 = {}
-            for label, flags in (("fused_train", 0), ("launch_per_round", abi.CFG_ROUNDS_PER_LAUNCH)):
+            for label, flags in (("fused_train", getattr(abi, "CFG_SUBMIT_TRAINS", 0)), ("launch_per_round", abi.CFG_ROUNDS_PER_LAUNCH)):
                 eng_r = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=2, ring_capacity=RB, flags=flags)
                 bufs_r = (np.empty(RB, dtype=abi.DECISION_DTYPE), np.empty(RB * max(N - 1, 1), dtype=abi.RPC_DTYPE))
                 best_r, sums = 0.0, []
@@ -863,7 +863,7 @@ def main():
         try:
             small = np.concatenate([m[m["server"] < 1024 * N] for m in first_ticks[:4]])
             lat = {}
-            for label, flags in (("fused_train", 0), ("launch_per_round", abi.CFG_ROUNDS_PER_LAUNCH)):
+            for label, flags in (("fused_train", getattr(abi, "CFG_SUBMIT_TRAINS", 0)), ("launch_per_round", abi.CFG_ROUNDS_PER_LAUNCH)):
                 eng_s = engine.RaGpuBatch(G, N, device=local_rank, max_runs=16, ring_slots=2, ring_capacity=1 << 16, flags=flags)
                 bufs_s = (np.empty(1 << 16, dtype=abi.DECISION_DTYPE), np.empty((1 << 16) * max(N - 1, 1), dtype=abi.RPC_DTYPE))
                 eng_s.set_state(0, st_aged)

@@ -382,7 +382,16 @@ typedef struct rgb_leaderboard_row {
   uint64_t last_applied;  /* the leader's last_applied (max over members when no leader)       */
 } rgb_leaderboard_row;
 
-#define RGB_CFG_ROUNDS_PER_LAUNCH 1u   /* rgb_submit: one kernel launch per sub-tick round, never a train (A/B measurements) */
+#define RGB_CFG_ROUNDS_PER_LAUNCH 1u   /* rgb_submit: one kernel launch per sub-tick round, never a train -- the DEFAULT since
+                                          round 5 (the flag is accepted and changes nothing; it wins over RGB_CFG_SUBMIT_TRAINS) */
+#define RGB_CFG_SUBMIT_TRAINS    16u  /* OPT-IN (round 5; the default of rounds 3-4): rgb_submit runs the sub-tick rounds of a
+                                         batch (2..16 rounds, >= 4096 messages) as ONE train launch (see "Train launches",
+                                         "Fail-safe").  Bit-identical results; measured no faster than one launch per round on
+                                         this path -- 54.7 against 55.8 M decisions/s on 856 k-message batches of four rounds,
+                                         318 against 312 us for the round trip of a 13.5 k-message batch of four rounds
+                                         (bench.py, host_path.rounds4 / rounds4_small): the host path is bound by the host's
+                                         passes over the batch and the two copies, not by launches -- so the simpler form,
+                                         whose progress does not rest on how the dispatcher places blocks, is the default */
 #define RGB_CFG_TRAIN_PERSISTENT 2u   /* trains always in the persistent form (placement by construction), also on a device
                                          whose dispatcher deals blocks round robin (see "Train launches") */
 #define RGB_CFG_FUSE_PIPELINE    4u   /* OPT-IN (ABI v8; default off: the decision stream is the reference's event by
@@ -481,9 +490,10 @@ int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
  * or after; a caller that needs "after batch X" lets that rgb_submit return (or collects X) first.  The *_device
  * entry points take the CALLER's stream and are ordered by it alone. */
 /* Sub-tick rounds: a batch that holds several messages for one server is applied in rounds (round r = every server's
- * r-th message).  A batch of at least 4096 messages with 2..16 rounds and no NOP padding runs its rounds as ONE train
- * launch (see "Train launches" below: the per-server sequence bytes order a server's messages) instead of one launch
- * per round; rgb_submit_trains counts the batches that did.  Results are identical either way. */
+ * r-th message), one launch per round.  With RGB_CFG_SUBMIT_TRAINS (opt-in since round 5) a batch of at least 4096
+ * messages with 2..16 rounds and no NOP padding runs its rounds as ONE train launch instead (see "Train launches" below:
+ * the per-server sequence bytes order a server's messages); rgb_submit_trains counts the batches that did.  Results
+ * are identical either way. */
 uint32_t rgb_submit_trains(const rgb_ctx *ctx);
 /* sizes of the oldest batch in flight (waits for it, consumes nothing): decisions and rpc records rgb_collect will
  * hand out next -- a caller that allocates per batch (the NIF's binaries) sizes them from this */

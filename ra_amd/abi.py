@@ -9,7 +9,8 @@ from __future__ import annotations
 import numpy as np
 
 ABI_VERSION = 8
-CFG_ROUNDS_PER_LAUNCH = 1      # rgb_config.flags: rgb_submit launches one kernel per sub-tick round (A/B measurements)
+CFG_ROUNDS_PER_LAUNCH = 1      # rgb_config.flags: rgb_submit launches one kernel per sub-tick round (the default since round 5)
+CFG_SUBMIT_TRAINS = 16         # rgb_config.flags: opt-in -- rgb_submit fuses the sub-tick rounds of a batch into one train launch
 CFG_FUSE_PIPELINE = 4          # rgb_config.flags: a leader's success reply / written event carries its pipeline_rpcs event's rpcs (opt-in)
 CFG_TRAIN_PERSISTENT = 2       # rgb_config.flags: trains always in the persistent form (placement by construction)
 UNDEF = np.uint64(0xFFFFFFFFFFFFFFFF)  # Erlang 'undefined'

@@ -722,7 +722,7 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
   /* several rounds, a batch worth a big launch, no NOP padding, a device that keeps a shard on one XCD: the rounds
    * run as ONE train launch, in bucket order (class, shard, success flag) -- a finer key of the same family order */
   bool as_train = n_rounds >= 2 && n_rounds <= RGB_SUBMIT_TRAIN_ROUNDS && n >= RGB_SUBMIT_TRAIN_MIN && !any_nop && !any_seqx &&
-                  !(ctx->cfg.flags & RGB_CFG_ROUNDS_PER_LAUNCH);
+                  (ctx->cfg.flags & RGB_CFG_SUBMIT_TRAINS) && !(ctx->cfg.flags & RGB_CFG_ROUNDS_PER_LAUNCH);
   if (as_train) {
     std::lock_guard<std::mutex> tl(ctx->train_mu);          /* the one-off calibration uses the stream */
     const int ts = train_scratch(ctx);

@@ -217,7 +217,7 @@ class RaGpuBatch:
             cfg["max_pipeline_count"] = max_pipeline_count
         if max_aer_batch:
             cfg["max_aer_batch"] = max_aer_batch
-        cfg["flags"] = flags                    # abi.CFG_ROUNDS_PER_LAUNCH: never fuse sub-tick rounds into a train
+        cfg["flags"] = flags                    # abi.CFG_SUBMIT_TRAINS: fuse the sub-tick rounds of a batch into a train
         h = C.c_void_p()
         rc = self._L.rgb_open(cfg.ctypes.data, C.byref(h))
         if rc:

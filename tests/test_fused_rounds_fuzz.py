@@ -34,7 +34,7 @@ def _fused_rounds(emulated_engine, oracle_lib, seed, wal_down):
         st["cond_reason"][pick] = rng.choice([abi.COND_WAL_DOWN, abi.COND_WAL_DOWN_LEADER], size=int(pick.sum()))
     cpu = oracle_lib.Oracle(G, N, max_runs=16)
     cpu.set_state(0, st)
-    with emulated_engine.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16) as gpu:
+    with emulated_engine.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16, flags=abi.CFG_SUBMIT_TRAINS) as gpu:
         gpu.set_state(0, st)
         for b in range(2):
             parts = [fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.9) for _ in range(4)]

@@ -144,7 +144,7 @@ def test_config5_repair_backlogs_at_full_size(engine_mod, oracle_lib):
         gpu.set_state(0, st)
         for t in range(ticks):
             m = W.gen_tick(cpu.get_state(), N, t, seed, W.MIX_CONFIG5, backlog_mode=True)
-            do, ro = cpu.step_parallel(m) if hasattr(cpu, "step_parallel") else cpu.step(m)
+            do, ro = cpu.step(m)
             dg, rg = gpu.step(m)
             if dg.tobytes() != do.tobytes():
                 bad = int(np.flatnonzero((dg.view(np.uint8).reshape(-1, 64) != do.view(np.uint8).reshape(-1, 64)).any(axis=1))[0])

@@ -124,7 +124,7 @@ def test_rounds_of_one_batch_run_as_one_train_launch(engine_mod, oracle_lib, tab
         st["cond_reason"][pick] = rng2.choice([abi.COND_WAL_DOWN, abi.COND_WAL_DOWN_LEADER], size=int(pick.sum()))
     cpu = oracle_lib.Oracle(G, N, max_runs=16)              # the device's bound: deep tables overflow it now and then
     cpu.set_state(0, st)
-    with engine_mod.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16) as gpu:
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16, flags=abi.CFG_SUBMIT_TRAINS) as gpu:
         gpu.set_state(0, st)
         fused = 0
         for b in range(batches):

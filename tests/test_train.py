@@ -420,7 +420,7 @@ def check_failed_train_is_repaired(engine, oracle_lib, G, N, seed, faults):
     st = fuzz.random_states(rng, G, N, max_runs=6, backlog=24)
     cpu = oracle_lib.Oracle(G, N, max_runs=16)
     cpu.set_state(0, st)
-    with engine.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=4, max_runs=16) as gpu:
+    with engine.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=4, max_runs=16, flags=abi.CFG_SUBMIT_TRAINS) as gpu:
         gpu.set_state(0, st)
         for fault in faults:
             batches, want = [], []
