@@ -388,7 +388,7 @@ int rgb_register_groups(rgb_ctx *ctx, uint32_t n_groups, uint32_t n_members) {
   HIPCHK(ctx, hipMalloc((void **)&d.cond, (size_t)S * 4 * sizeof(u64)));
   HIPCHK(ctx, hipMalloc((void **)&d.qry, (size_t)S * RGB_QRY_WORDS * sizeof(u64)));
   HIPCHK(ctx, hipMemsetAsync(d.runs, 0, (size_t)S * d.max_runs * 2 * sizeof(u64), ctx->stream));
-  d.seq_stride = (((n_groups + RGB_TRAIN_SHARDS - 1u) / RGB_TRAIN_SHARDS) * n_members + 255u) & ~255u;
+  d.seq_stride = (((n_groups + RGB_TRAIN_SHARDS - 1u) / RGB_TRAIN_SHARDS) * n_members * RGB_SEQ_SPREAD + 255u) & ~255u;
   HIPCHK(ctx, hipMalloc((void **)&d.seq, (size_t)d.seq_stride * RGB_TRAIN_SHARDS));
   HIPCHK(ctx, hipMemsetAsync(d.seq, 0, (size_t)d.seq_stride * RGB_TRAIN_SHARDS, ctx->stream));
   ctx->stage_cap = S < 16384u ? S : 16384u;

@@ -158,9 +158,16 @@ static inline __host__ __device__ unsigned rgb_bucket_hinted(unsigned kind, unsi
 }
 /* position of a server's sequence byte: the bytes of one shard are contiguous, so an XCD's L2 never holds a line of
  * the array that another XCD writes */
+/* RGB_SEQ_SPREAD: bytes between two servers' sequence bytes (1 = packed, the product).  A tick's wavefronts publish with
+ * 214 k one-byte stores onto the array's lines, 84 per line and tick when packed; spreading them (A/B builds of round 5:
+ * 4 -> +3 % per tick, 16 -> +12 %) is worse -- a wavefront's polls and stores then touch more lines, and it is the lines
+ * a wavefront touches that cost (profiles/EXPERIMENTS.md, round 5) */
+#ifndef RGB_SEQ_SPREAD
+#define RGB_SEQ_SPREAD 1u
+#endif
 static inline __host__ __device__ unsigned rgb_seq_index(unsigned server, unsigned n_members, unsigned seq_stride) {
   const unsigned g = server / n_members, m = server - g * n_members;
-  return (g & (RGB_TRAIN_SHARDS - 1u)) * seq_stride + (g / RGB_TRAIN_SHARDS) * n_members + m;
+  return (g & (RGB_TRAIN_SHARDS - 1u)) * seq_stride + ((g / RGB_TRAIN_SHARDS) * n_members + m) * RGB_SEQ_SPREAD;
 }
 #define RGB_TRAIN_MAX_TICKS 255u   /* ticks per launch: the values a sequence byte takes within one launch are distinct */
 /* one tick of a train: rows of RGB_TRAIN_SHARDS blocks; row r of class c serves slice r of every shard (the row table

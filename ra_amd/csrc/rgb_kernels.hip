@@ -2853,7 +2853,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
      * snapshot wait for exact bytes): 1 = no poll at all -- the tick without the dependency waits AND without the
      * poll's round trip (what a sequence tag inside the row could give at best); 2 = one poll whose answer is
      * ignored -- without the waits only.  Round 5, same box: 17.46 us per tick, 16.72 with 2, 16.36 with 1 */
-    if (RGB_X_TRAIN_NODEPS == 1) late = false;
+    if (RGB_X_TRAIN_NODEPS == 1 || RGB_X_TRAIN_NODEPS == 3) late = false;
 #endif
     for (;;) {
       /* only the lanes that are still waiting poll again; a wavefront that has to wait backs off (thousands of
@@ -3052,7 +3052,21 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("" ::: "memory");
 #endif
+#if defined(RGB_X_TRAIN_NODEPS) && RGB_X_TRAIN_NODEPS == 3
+    /* EXPERIMENT (with NODEPS = 1's missing poll): no sequence-byte store either -- what all of the byte traffic costs */
+    if (RGB_X_TRAIN_NODEPS == 1)
+#endif
+#if defined(RGB_X_XOR_PUBLISH) && !defined(RGB_HOST_EMULATION)
+    /* EXPERIMENT: the byte advanced by a fire-and-forget atomic XOR on its dword (old value = need, known) instead of a
+     * one-byte store */
+    if (has_srv && seqp != nullptr) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>(seqp);
+      (void)__hip_atomic_fetch_xor(reinterpret_cast<u32 *>(a & ~(uintptr_t)3), ((need ^ (need + 1u)) & 0xFFu) << (8u * (unsigned)(a & 3u)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#else
     if (has_srv && seqp != nullptr) *seqp = (unsigned char)(need + 1u);
+#endif
     /* persistent train: the wavefront's NEXT row is requested now -- behind the publish (the atomic's return must not
      * sit in front of the sequence bytes) and under the decision stores; rgb_train_kernel consumes it at the top of
      * its loop.  Not earlier: a ticket held while this slice runs would start its row a whole wavefront life late,
@@ -3080,6 +3094,9 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   }
   lds_barrier();
   if (!TR && RGB_KNOB(dev, 2u)) return true;
+#ifdef RGB_X_TRAIN_NODEC      /* EXPERIMENT (breaks the output): no decision stores -- what the decision stream costs a tick */
+  if (TR) return true;
+#endif
   ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(dec + base);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -3232,7 +3249,7 @@ __device__ __forceinline__ bool rgb_train_snap_slice(const rgb_dev &dev, u32 x, 
   const u32 sbase = live ? rgb_seq_index(g * (u32)N, (unsigned)N, dev.seq_stride) : 0u;   /* the members' bytes follow */
   unsigned need[N];
 #pragma unroll
-  for (int m = 0; m < N; ++m) need[m] = live ? (unsigned)stamps[sbase + m] : 0u;
+  for (int m = 0; m < N; ++m) need[m] = live ? (unsigned)stamps[sbase + m * RGB_SEQ_SPREAD] : 0u;
   unsigned spins = 0;
   bool late = live;
   for (;;) {
@@ -3241,9 +3258,9 @@ __device__ __forceinline__ bool rgb_train_snap_slice(const rgb_dev &dev, u32 x, 
 #pragma unroll
       for (int m = 0; m < N; ++m) {
 #ifdef RGB_HOST_EMULATION
-        const unsigned cur = dev.seq[sbase + m];
+        const unsigned cur = dev.seq[sbase + m * RGB_SEQ_SPREAD];
 #else
-        const unsigned cur = __hip_atomic_load(dev.seq + sbase + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned cur = __hip_atomic_load(dev.seq + sbase + m * RGB_SEQ_SPREAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
         ok = ok && cur == need[m];
       }
@@ -3290,7 +3307,7 @@ __device__ __forceinline__ bool rgb_train_snap_slice(const rgb_dev &dev, u32 x, 
 #endif
   if (live) {
 #pragma unroll
-    for (int m = 0; m < N; ++m) dev.seq[sbase + m] = (unsigned char)(need[m] + 1u);
+    for (int m = 0; m < N; ++m) dev.seq[sbase + m * RGB_SEQ_SPREAD] = (unsigned char)(need[m] + 1u);
   }
   return true;
 }

@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 5, call 30: the sequence bytes 4 and 16 bytes apart (RGB_SEQ_SPREAD) against packed -- fewer partial writes per line
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; OUT=gpurun_out/r05ad; mkdir -p $OUT
+V=$R/ra_amd/csrc/variants
+Q="--no-cpu-baseline --no-host-path --literal-ticks 0 --members 5 --check-ticks 2"
+one() { # name lib extra-args
+  local name=$1 lib=$2; shift 2
+  RGB_LIB=$V/$lib.so timeout 100 python bench.py $Q "$@" > $OUT/$name.json 2> $OUT/$name.err
+  python - $OUT/$name.json $name <<'PY' | tee -a $OUT/summary.txt
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
+    print(f"{sys.argv[2]:18s} {r['avg_tick_us']:7.2f} us/tick by events, frac {r['frac']:.4f}, wall us/step {d['ms_per_step']*1e3:7.2f}")
+except Exception as e:
+    print(sys.argv[2], "FAILED", e); print(open(sys.argv[1].replace('.json', '.err')).read()[-600:])
+PY
+}
+D="--steps 20 --warmup 5"
+L="--steps 192 --warmup 16"
+for i in 1 2; do
+  one cur_long_$i cur $L
+  one spread4_long_$i spread4 $L
+  one spread16_long_$i spread16 $L
+done
+one cur_drv cur $D
+one spread4_drv spread4 $D
+one spread16_drv spread16 $D
