@@ -61,3 +61,27 @@ def test_fused_rounds_with_servers_in_the_wal_down_conditions(emulated_engine, o
     """The same with servers waiting in the follower's and the leader's wal_down condition, messages with and without
     RGB_MF_CAN_WRITE and await_condition timeouts (round 4 ran RGB_FUZZ_WAL_SEEDS=500:580 and 700:760 clean)."""
     _fused_rounds(emulated_engine, oracle_lib, seed, True)
+
+
+def test_rounds_are_fused_only_on_request(emulated_engine, oracle_lib):
+    """Round 5: one launch per sub-tick round is rgb_submit's default; RGB_CFG_SUBMIT_TRAINS opts in to one train launch
+    per batch; RGB_CFG_ROUNDS_PER_LAUNCH wins over it.  The same batch gives the same decisions, rpc records and state
+    in all three contexts (and the checker's)."""
+    N, G = 5, 1100
+    rng = np.random.default_rng(4711)
+    st = fuzz.random_states(rng, G, N, max_runs=6, backlog=24)
+    cpu = oracle_lib.Oracle(G, N, max_runs=16)
+    cpu.set_state(0, st)
+    parts = [fuzz.random_msgs(rng, st, N, frac=0.9) for _ in range(4)]
+    msgs = np.concatenate(parts)
+    msgs = msgs[msgs["kind"] != abi.MSG_NOP]
+    rng.shuffle(msgs)
+    assert len(msgs) >= 4096
+    do, ro = cpu.step(msgs)
+    for flags, want_trains in ((0, 0), (abi.CFG_SUBMIT_TRAINS, 1), (abi.CFG_SUBMIT_TRAINS | abi.CFG_ROUNDS_PER_LAUNCH, 0)):
+        with emulated_engine.RaGpuBatch(G, N, ring_capacity=65536, ring_slots=2, max_runs=16, flags=flags) as gpu:
+            gpu.set_state(0, st)
+            dg, rg = gpu.step(msgs)
+            assert_same(f"flags {flags}", dg, rg, gpu.get_state(), do, ro, cpu.get_state())
+            assert gpu.submit_trains() == want_trains, f"flags {flags}: {gpu.submit_trains()} batches ran as trains"
+    cpu.close()
