@@ -1028,6 +1028,11 @@ def main():
                     traffic = float(tj["traffic_bytes_per_launch"])
                     if use_train and "traffic_bytes_per_tick" in tj:
                         traffic = float(tj["traffic_bytes_per_tick"]) * TPL
+                        # the driver's form (one 20-tick launch): the PMC passes of 20-tick launches, when the file has them
+                        short = tj.get("closed_loop_20_tick_launches_the_drivers_form")
+                        if short and TPL <= 2 * int(short.get("ticks_per_launch", 0)):
+                            traffic = float(short["traffic_bytes_per_tick"]) * TPL
+                            traffic_src += " (closed_loop_20_tick_launches_the_drivers_form)"
                     elif not use_train and "per_tick_kernel_same_run" in tj:
                         traffic = float(tj["per_tick_kernel_same_run"]["traffic_bytes_per_launch"])
         except Exception:
