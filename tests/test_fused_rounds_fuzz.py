@@ -2,7 +2,9 @@
 fused into one train launch -- on the CPU emulation: random states (shallow and deep run tables), random messages of
 every kind, 3 / 5 / 7 members, the checker bounded like the device.  Four seeds run with the suite; more with
 RGB_FUZZ_SEEDS=lo:hi (round 3 ran 312:432 clean after seed 27 of the GPU twin had found the range-lost corner of
-ra_log:write; round 4 ran 600:720 clean on its final sources)."""
+ra_log:write; round 4 ran 600:720 clean on its final sources; round 5 ran 900:972 and
+RGB_FUZZ_WAL_SEEDS=900:924 clean on its final sources -- the leader-side slices of 32 of groups of seven included --
+and the train tests under ASan)."""
 import os
 
 import numpy as np
