@@ -15,7 +15,8 @@ for off in range(first, first + n):
     os.environ["RGB_FUZZ_SEED_OFFSET"] = str(off)
     for runs in (6, 16):
         try:
-            G.test_rounds_of_one_batch_run_as_one_train_launch(engine, O, runs, G=1500 if off % 2 else 2400, N=(5, 3)[off % 3 == 0])
+            N = (5, 3, 7, 6)[off % 4]            # (groups of six and seven: the leader-side slices of 32 with LDS peers rows)
+            G.test_rounds_of_one_batch_run_as_one_train_launch(engine, O, runs, G=(1500 if off % 2 else 2400) * 5 // N, N=N)
         except AssertionError as e:
             bad += 1
             print(f"offset {off} table_runs {runs}: {str(e)[:400]}")
