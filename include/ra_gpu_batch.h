@@ -655,8 +655,12 @@ int  rgb_snapshot_train_device(rgb_ctx *ctx, void *d_rows, void *stream);
  * through the host -- the reference has no stop between a mailbox and its handler either
  * (src/ra_server_proc.erl:1382-1397).
  *   rgb_train_plan_create_device  an EMPTY plan of n_ticks ticks (snapshot_every as in rgb_train_plan_create_snap; 0 =
- *                                 none): tables sized for any tick the registered groups can produce (at most one
- *                                 message per server)
+ *                                 none): tables sized for any tick of the registered groups (at most one message
+ *                                 per server) whose message classes are spread evenly over the eight shards -- what
+ *                                 hashing groups over the shards gives.  A tick skewed so that different classes peak
+ *                                 in different shards can need up to eight times the rows: it is REFUSED (built as an
+ *                                 empty tick, the launch reports RGB_TRAIN_ERR_PLAN through rgb_train_status and the
+ *                                 ticks behind it do not run), never mis-run
  *   rgb_train_plan_build_device   ticks [first_tick, first_tick + n_ticks) of the plan from d_bucket_counts =
  *                                 uint32[n_ticks][RGB_TRAIN_BUCKETS] of exactly those ticks, one kernel on `stream`
  *                                 (offsets, rows per class, the row table: bit for bit what rgb_train_plan_create

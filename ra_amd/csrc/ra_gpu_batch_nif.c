@@ -474,8 +474,13 @@ static void *collector_main(void *arg) {
   /* from running (1) -- or from STARTING (3): the thread can end on an error before start_collector/2 has moved 3 to
    * 1, and an exit that only looked for 1 was lost there (start_collector then published 1 for a dead thread: collect/1
    * refused, a new start_collector/2 badarg, although the owner had been told it may start one).  A stopper's 4 stays. */
-  { int st = 1;
-    if (!atomic_compare_exchange_strong(&c->collector_on, &st, 2)) { st = 3; atomic_compare_exchange_strong(&c->collector_on, &st, 2); } }
+  /* (a loop: between a failed CAS from 1 and the CAS from 3, start_collector/2 can move 3 to 1 -- tried once each, both
+   * failed and 1 stayed for a dead thread) */
+  for (;;) {
+    int st = atomic_load(&c->collector_on);
+    if (st != 1 && st != 3) break;                           /* a stopper's 4: it joins this thread */
+    if (atomic_compare_exchange_strong(&c->collector_on, &st, 2)) break;
+  }
   enif_release_resource(c);
   return NULL;
 }

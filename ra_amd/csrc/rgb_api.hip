@@ -122,6 +122,9 @@ struct rgb_ctx {
   u64 *d_sums = nullptr;
   void *d_lb_gather = nullptr;      /* rgb_leaderboard_allgather_host: this rank's padded rows | the gathered rows | status words */
   size_t lb_gather_bytes = 0;
+  void *h_lb_pinned = nullptr;      /* pinned twin of the copy-outs (status words | gathered rows): the side stream's device-to-host
+                                       copies land HERE, never in a caller's pageable buffer that a timed-out call has given back */
+  size_t lb_pinned_bytes = 0;
   std::mutex lb_mu;                 /* .. one call at a time per context: it owns the buffer, the side stream, the event */
   hipStream_t lb_stream = nullptr;  /* the collective and its copy-out run HERE, outside the decision path's locks */
   hipEvent_t lb_event = nullptr;    /* the snapshot on the context's stream -> the side stream */
@@ -273,8 +276,9 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
-  if (ctx->d_lb_gather) (void)hipFree(ctx->d_lb_gather);
   if (ctx->lb_stream) { (void)hipStreamSynchronize(ctx->lb_stream); (void)hipStreamDestroy(ctx->lb_stream); }
+  if (ctx->d_lb_gather) (void)hipFree(ctx->d_lb_gather);
+  if (ctx->h_lb_pinned) (void)hipHostFree(ctx->h_lb_pinned);
   if (ctx->lb_event) (void)hipEventDestroy(ctx->lb_event);
   if (ctx->d_synth) (void)hipFree(ctx->d_synth);
   if (ctx->d_synth_sent) (void)hipFree(ctx->d_synth_sent);
@@ -674,6 +678,8 @@ int rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick) {
 
 int rgb_set_seq_ranges_device(rgb_ctx *ctx, const void *d_ranges, uint32_t n_ranges) {
   if (!ctx || (!d_ranges && n_ranges)) return RGB_E_INVAL;
+  /* submit threads copy ctx->dev for their launches (slot_dev) under the enqueue lock: the list changes under it too */
+  std::lock_guard<std::mutex> b(ctx->enqueue_mu);
   ctx->dev.seq_ranges = n_ranges ? (const u64 *)d_ranges : nullptr;
   ctx->dev.n_seq_ranges = n_ranges;
   return RGB_OK;
@@ -1518,24 +1524,50 @@ int rgb_leaderboard_allgather_host(rgb_ctx *ctx, rgb_comm *comm, uint32_t n_rows
     }
   }
   if (mine == RGB_OK && hipStreamWaitEvent(ctx->lb_stream, ctx->lb_event, 0) != hipSuccess) mine = RGB_E_HIP;
-  /* 1. the status of every rank */
-  std::vector<int64_t> st(world, 0);
-  HIPCHK(ctx, hipMemcpyAsync(d_status, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->lb_stream));
+  /* the copy-outs go through PINNED memory owned by the context (a pageable destination makes hipMemcpyAsync either
+   * synchronous -- a missing rank would block inside the copy, in front of the timeout -- or leaves a copy queued
+   * behind the aborted collective that later writes into memory the caller has got back) */
+  const size_t pin_need = (size_t)(world + 1u) * sizeof(int64_t) + (size_t)n_rows * world * sizeof(rgb_leaderboard_row);
+  if (ctx->lb_pinned_bytes < pin_need) {
+    (void)hipStreamSynchronize(ctx->lb_stream);
+    if (ctx->h_lb_pinned) (void)hipHostFree(ctx->h_lb_pinned);
+    ctx->h_lb_pinned = nullptr; ctx->lb_pinned_bytes = 0;
+    if (hipHostMalloc(&ctx->h_lb_pinned, pin_need, hipHostMallocDefault) == hipSuccess) ctx->lb_pinned_bytes = pin_need;
+    else if (hipHostMalloc(&ctx->h_lb_pinned, (size_t)(world + 1u) * sizeof(int64_t), hipHostMallocDefault) == hipSuccess) {
+      ctx->lb_pinned_bytes = (size_t)(world + 1u) * sizeof(int64_t);
+      if (mine == RGB_OK) mine = RGB_E_NOMEM;
+    } else return RGB_E_NOMEM;
+  }
+  int64_t *h_mine = (int64_t *)ctx->h_lb_pinned, *h_status = h_mine + 1;
+  rgb_leaderboard_row *h_rows = (rgb_leaderboard_row *)(h_status + world);
+  /* after a timeout: the communicator is aborted (its kernels leave the stream), then the side stream is DRAINED, so
+   * that nothing of this call is still queued when the caller gets its buffers back */
+  auto give_up = [&](const char *why) {
+    const int rc = rgb_comm_abort(comm, why);
+    (void)hipStreamSynchronize(ctx->lb_stream);
+    return rc;
+  };
+  /* 1. the status of every rank.  (A HIP call that fails HERE -- between the collectives -- means this device is gone;
+   * the other ranks then leave through their timeout, which is what it is for.) */
+  *h_mine = mine;
+  HIPCHK(ctx, hipMemcpyAsync(d_status, h_mine, sizeof mine, hipMemcpyHostToDevice, ctx->lb_stream));
   int rc = rgb_comm_allgather_bytes(comm, d_status, sizeof(int64_t), d_status_all, (void *)ctx->lb_stream);
-  if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status_all, (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->lb_stream));
-  if (!lb_wait(ctx, timeout_ms)) return rgb_comm_abort(comm, "leaderboard all-gather: a rank did not arrive (status exchange timed out; communicator aborted)");
+  if (rc) { (void)hipStreamSynchronize(ctx->lb_stream); return rc; }
+  if (hipMemcpyAsync(h_status, d_status_all, (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->lb_stream) != hipSuccess)
+    return give_up("leaderboard all-gather: the status copy-out failed (communicator aborted)");
+  if (!lb_wait(ctx, timeout_ms)) return give_up("leaderboard all-gather: a rank did not arrive (status exchange timed out; communicator aborted)");
   for (u32 r = 0; r < world; ++r)
-    if (st[r] != RGB_OK) {
+    if (h_status[r] != RGB_OK) {
       if (mine == RGB_OK) rgb_comm_set_error_text("leaderboard all-gather: another rank reported an error; nothing was gathered");
       return mine != RGB_OK ? (int)mine : RGB_E_COMM;
     }
   /* 2. the rows */
   rc = rgb_comm_allgather_bytes(comm, d_local, (uint64_t)n_rows * sizeof(rgb_leaderboard_row), d_all, (void *)ctx->lb_stream);
-  if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(rows_all, d_all, (size_t)n_rows * world * sizeof(rgb_leaderboard_row), hipMemcpyDeviceToHost,
-                             ctx->lb_stream));
-  if (!lb_wait(ctx, timeout_ms)) return rgb_comm_abort(comm, "leaderboard all-gather: timed out (communicator aborted)");
+  if (rc) { (void)hipStreamSynchronize(ctx->lb_stream); return rc; }
+  if (hipMemcpyAsync(h_rows, d_all, (size_t)n_rows * world * sizeof(rgb_leaderboard_row), hipMemcpyDeviceToHost, ctx->lb_stream) != hipSuccess)
+    return give_up("leaderboard all-gather: the copy-out failed (communicator aborted)");
+  if (!lb_wait(ctx, timeout_ms)) return give_up("leaderboard all-gather: timed out (communicator aborted)");
+  memcpy(rows_all, h_rows, (size_t)n_rows * world * sizeof(rgb_leaderboard_row));     /* only now: the side stream is idle */
   return RGB_OK;
 }
 

@@ -140,6 +140,7 @@ int rgb_comm_allgather_bytes(rgb_comm *comm, const void *d_local, uint64_t bytes
   if (!comm || !d_local || !d_all) return RGB_E_INVAL;
   const rccl_api *r = rccl();
   if (!r) return RGB_E_UNSUPPORTED;
+  if (!comm->comm) { g_last_text = "the communicator was aborted"; return RGB_E_COMM; }
   g_last_text = nullptr;
   g_last_rccl = r->all_gather(d_local, d_all, (size_t)bytes, 1 /* ncclUint8 */, comm->comm, stream);
   return g_last_rccl ? RGB_E_COMM : RGB_OK;

@@ -4399,7 +4399,12 @@ __global__ __launch_bounds__(1024) void rgb_train_plan_kernel(const u32 *__restr
       const u32 n = pos + (mine_rows ? 1u : 0u), total = first + mine_rows;
       cum[n] = total;
       n_act_s = n;
-      out->n_rows = total; out->msg_base = 0;
+      /* a tick whose rows do not fit the table (rgb_train_rows_bound is the bound of a tick whose classes are spread
+       * evenly over the shards; a tick skewed so that different classes peak in different shards can need up to eight
+       * times as many) becomes an EMPTY tick: no block of the launch looks at table entries that were never written
+       * (the dealt form reads row < n_rows only, the persistent form's tickets run out at once), the launch fails
+       * with RGB_TRAIN_ERR_PLAN and the ticks behind it give up on the error word instead of running stale rows */
+      out->n_rows = total > rpt ? 0u : total; out->msg_base = 0;
       out->snap = snap_rows ? gt / snapshot_every : 0u;
       for (int k = 0; k < 13; ++k) out->pad[k] = 0;
       if (total > rpt) atomicOr(err, (u32)RGB_TRAIN_ERR_PLAN);     /* the table's rows do not hold this tick */
@@ -4456,7 +4461,12 @@ int rgb_launch_train_plan(const u32 *d_bucket_counts, rgb_train_tick *d_ticks, u
 
 u32 rgb_train_rows_bound(u32 n_servers, u32 n_members, bool with_snapshot) {
   /* a shard holds at most ceil(groups / 8) x members messages per tick; every non-empty plan class may end in a
-   * partial slice; the smallest slice is 32 messages */
+   * partial slice; the smallest slice is 32 messages.  This bounds every tick whose plan classes have their fullest
+   * shard in common (what hashing groups over the shards gives); the worst case over ALL ticks -- class k filling
+   * shard k and nothing else -- is eight times that, and a table sized for it would make every launch of the dealt
+   * form eight times as many (empty) blocks.  A tick beyond the bound is refused, not mis-run: rgb_train_plan_kernel
+   * writes it as an empty tick and raises RGB_TRAIN_ERR_PLAN, rgb_train_make_tick returns its row count without
+   * writing the table */
   const u32 groups = n_servers / n_members;
   const u32 per_shard = ((groups + RGB_TRAIN_SHARDS - 1u) / RGB_TRAIN_SHARDS) * n_members;
   return (per_shard + 31u) / 32u + RGB_N_PCLASSES + (with_snapshot ? rgb_train_snap_rows(groups) : 0u);

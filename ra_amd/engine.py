@@ -158,15 +158,15 @@ def lib():
     L.rgb_train_run_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, u32, vp]
     if hasattr(L, "rgb_train_run_snap_device"):
         L.rgb_train_plan_create_snap.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
-    if hasattr(L, "rgb_train_plan_create_device"):
-        L.rgb_train_plan_create_device.argtypes = [vp, u32, u32, C.POINTER(vp)]
-        L.rgb_train_plan_build_device.argtypes = [vp, vp, u32, u32, vp, vp]
-        L.rgb_train_plan_download.argtypes = [vp, vp, u32, vp, vp, u32]
         L.rgb_train_run_snap_device.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp, u32, vp, vp, vp]
         L.rgb_snapshot_train_device.argtypes = [vp, vp, vp]
         L.rgb_train_seq_bytes.restype = C.c_uint32
         L.rgb_train_seq_bytes.argtypes = [vp]
         L.rgb_synth_snapshot_mark_device.argtypes = [vp, vp, vp]
+    if hasattr(L, "rgb_train_plan_create_device"):          # ABI v8
+        L.rgb_train_plan_create_device.argtypes = [vp, u32, u32, C.POINTER(vp)]
+        L.rgb_train_plan_build_device.argtypes = [vp, vp, u32, u32, vp, vp]
+        L.rgb_train_plan_download.argtypes = [vp, vp, u32, vp, vp, u32]
     L.rgb_train_status.argtypes = [vp, C.POINTER(u32), vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     if hasattr(L, "rgb_synth_set_hint"):
