@@ -56,6 +56,33 @@ __global__ __launch_bounds__(64) void rd_kernel(const char *base, u32 n_units, u
   for (int k = 0; k < 8; ++k) acc += io[k * 64 + lane].x;
   if (acc == 0x1234567ull) sink[0] = acc;
 }
+// the train's state access: a 128-byte row is gathered (LDS-DMA, sc1), then WB_LANES x 16 bytes of it are written back
+// (plain stores, the line is in the L2): what do partial write-backs do to the read side's latency?
+template <int WB_LANES>
+__global__ __launch_bounds__(64) void rw_kernel(char *base, u32 n_units, u32 n_pow2, u64 *sink) {
+  __shared__ ulonglong2 io[64 * 8];
+  const u32 lane = threadIdx.x;
+  const u32 first = blockIdx.x * 64;
+  u32 rows[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const u32 u = first + k * 8 + lane / 8;
+    rows[k] = perm(u < n_units ? u : 0, n_pow2);
+    glds16<16>(base + (size_t)rows[k] * 128 + (lane % 8) * 16, io + k * 64);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::: "memory");
+  __syncthreads();
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const ulonglong2 v = io[k * 64 + lane];
+    acc += v.x;
+    if ((int)(lane % 8) < WB_LANES)
+      *reinterpret_cast<ulonglong2 *>(base + (size_t)rows[k] * 128 + (lane % 8) * 16) = make_ulonglong2(v.x + 1, v.y);
+  }
+  if (acc == 0x1234567ull) sink[0] = acc;
+}
 __global__ __launch_bounds__(64) void rd1_kernel(const unsigned char *base, u32 n_units, u32 n_pow2, u64 *sink) {
   // unit = 64 contiguous bytes read by one wavefront instruction (agent-scope byte loads, like the poll)
   const u32 lane = threadIdx.x;
@@ -114,6 +141,8 @@ int main(int argc, char **argv) {
   RD("rd128", 8, 128, 16, 128) RD("rd128nt", 8, 128, 2, 128) RD("rd64", 4, 128, 2, 64) RD("rd32", 2, 128, 2, 32) RD("rd64sc1", 4, 128, 16, 64)
   WR("wr16", 1, 128, false, 16) WR("wr32", 2, 128, false, 32) WR("wr64nt", 4, 128, true, 64) WR("wr32nt", 2, 128, true, 32)
   WR("wr128", 8, 128, false, 128)
+#define RW(NAME, W) if (!strcmp(what, NAME)) { hipLaunchKernelGGL((rw_kernel<W>), dim3((n_units + 63) / 64), dim3(64), 0, 0, d, n_units, n_pow2, sink); bytes = (double)n_units * (128 + 16 * W); }
+  RW("rw0", 0) RW("rw16", 1) RW("rw32", 2) RW("rw64", 4) RW("rw128", 8)
   if (!strcmp(what, "rd1")) { hipLaunchKernelGGL(rd1_kernel, dim3((n_units + 7) / 8), dim3(64), 0, 0, (unsigned char *)d, n_units, n_pow2 * 2u, sink); bytes = (double)n_units * 64; }
   if (!strcmp(what, "wr1")) { hipLaunchKernelGGL(wr1_kernel, dim3((n_units + 511) / 512), dim3(64), 0, 0, (unsigned char *)d, n_units, 1u << 19); bytes = (double)n_units; }
   CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
