@@ -55,7 +55,7 @@ struct rgb_slot {
   /* rgb_submit_seq: the batch's range list (written events of more than two ranges, RGB_MF_SEQX) */
   u64 *h_ranges = nullptr, *d_ranges = nullptr;   /* pinned / device: (first, last) pairs; allocated with the first batch that has any */
   u32 ranges_cap = 0, n_ranges = 0;
-  bool has_seqx = false;            /* the batch holds a RGB_MF_SEQX record: its rounds run in the kind-generic kernel */
+  bool has_seqx = false;            /* the batch holds a RGB_MF_SEQX record: its written class runs in the written-only kernel that takes range lists */
   /* fail-safe: the servers this batch touches and their rows as they were before it (saved while a train is in flight) */
   u32 *h_touched = nullptr, *d_touched = nullptr;   /* pinned / device: ring_capacity ids */
   u32 n_touched = 0;
@@ -546,26 +546,46 @@ static rgb_dev slot_dev(const rgb_ctx *ctx, const rgb_slot &s) {
 
 static int enqueue_rounds(rgb_ctx *ctx, rgb_slot &s) {
   const rgb_dev dv = slot_dev(ctx, s);
+  auto fail = [&](int lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; };
   for (u32 r = 0; r < s.n_rounds; ++r) {
     const u32 off = s.round_start[r], cnt = s.round_start[r + 1] - s.round_start[r];
+    /* every round, whatever its size, runs the class-dispatch kernel -- a path specialised per message kind, no
+     * scratch for any group size (round 6: rounds under 4 096 messages used to take the kind-generic kernel, the one
+     * kernel of the library that spills: 110 .. 1 402 VGPRs for groups of 5 .. 8) */
+    u32 cc[RGB_N_CLASSES], real = 0, before_written = 0;
+    for (int c = 0; c < RGB_N_CLASSES; ++c) {
+      cc[c] = s.round_cc[(size_t)r * RGB_N_CLASSES + c];
+      real += cc[c];
+      if (c < 2) before_written += cc[c];
+    }
     int lr;
-    if (cnt >= 4096 && !s.has_seqx) {
-      /* big round: the class-dispatch kernel (specialised path per message kind; written events of more than two
-       * ranges are the generic kernel's: rgb_kernels.hip, LaneT::seqx_ok) */
-      u32 cc[RGB_N_CLASSES];
-      for (int c = 0; c < RGB_N_CLASSES; ++c) cc[c] = s.round_cc[(size_t)r * RGB_N_CLASSES + c];
+    if (!s.has_seqx || cc[2] == 0) {
       lr = launch_tick_classes(ctx, dv, s.d_msgs + off, s.d_dec + off, s.d_rpcs, cc, off, off, ctx->stream);
       if (lr) return lr;
-      u32 real = 0;
-      for (int c = 0; c < RGB_N_CLASSES; ++c) real += cc[c];
-      if (real < cnt) {      /* NOP slots sort last: the generic kernel writes their empty decisions */
-        lr = rgb_launch_tick(dv, -1, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
-                             s.d_rpcs, off + real, off + real, ctx->stream);
-        if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
-      }
     } else {
-      lr = rgb_launch_tick(dv, -1, s.d_msgs + off, cnt, nullptr, s.d_dec + off, s.d_rpcs, off, off, ctx->stream);
-      if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
+      /* a batch of rgb_submit_seq: its written events may carry range lists (RGB_MF_SEQX), which the class kernel's
+       * written path does not take -- the classes in front of the written class, the written class through the
+       * written-only kernel that does, the classes behind it (each launch sees its own part of the round: the class
+       * offsets of a plan count from the first class that has messages) */
+      u32 head[RGB_N_CLASSES] = {0}, tail[RGB_N_CLASSES] = {0};
+      head[0] = cc[0]; head[1] = cc[1];
+      for (int c = 3; c < RGB_N_CLASSES; ++c) tail[c] = cc[c];
+      if (before_written) {
+        lr = launch_tick_classes(ctx, dv, s.d_msgs + off, s.d_dec + off, s.d_rpcs, head, off, off, ctx->stream);
+        if (lr) return lr;
+      }
+      const u32 w0 = off + before_written, t0 = w0 + cc[2];
+      lr = rgb_launch_tick(dv, RGB_TICK_CLS_WRITTEN_SEQX, s.d_msgs + w0, cc[2], nullptr, s.d_dec + w0, s.d_rpcs, w0, w0, ctx->stream);
+      if (lr) return fail(lr);
+      if (real > before_written + cc[2]) {
+        lr = launch_tick_classes(ctx, dv, s.d_msgs + t0, s.d_dec + t0, s.d_rpcs, tail, t0, t0, ctx->stream);
+        if (lr) return lr;
+      }
+    }
+    if (real < cnt) {      /* NOP slots sort last: their empty decisions */
+      lr = rgb_launch_tick(dv, RGB_TICK_CLS_NOP, s.d_msgs + off + real, cnt - real, nullptr, s.d_dec + off + real,
+                           s.d_rpcs, off + real, off + real, ctx->stream);
+      if (lr) return fail(lr);
     }
   }
   return RGB_OK;

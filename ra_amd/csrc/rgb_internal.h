@@ -232,7 +232,10 @@ struct rgb_dev {
 /* d_rpcs: n * max(N-1,1) fixed slots (message i owns slots [i*(N-1), (i+1)*(N-1))), or NULL */
 /* d_n: optional device-resident message count (min(n, *d_n) messages are processed).
  * cls: -1 = generic kernel (any kinds), 0..3 = the kernel specialised for that class's kind (every
- * message of the slice must have it).  rpc_slot_base: fixed-slot index of the slice's message 0. */
+ * message of the slice must have it), RGB_TICK_CLS_WRITTEN_SEQX = written events that may carry a range list,
+ * RGB_TICK_CLS_NOP = NOP slots only.  rpc_slot_base: fixed-slot index of the slice's message 0. */
+#define RGB_TICK_CLS_WRITTEN_SEQX 32
+#define RGB_TICK_CLS_NOP 33
 int rgb_launch_tick(const rgb_dev &dev, int cls, const rgb_msg *d_msgs, u32 n, const u32 *d_n,
                     rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_slot_base, u32 msg_index_base, void *stream);
 /* family-ordered tick, ONE launch: counts[] (host) or d_family_totals (device, RGB_N_FAMILIES u32,

@@ -189,11 +189,11 @@ __device__ __forceinline__ unsigned slot4to8(unsigned s) { return s >= 8u ? (uns
 template <bool COH, bool WC = false, bool SEQX = false>
 struct LaneT {
   static constexpr bool coh = COH;   /* state loads must bypass the CU's L1 (train launch), see ldg8 */
-  /* written events of more than two ranges (RGB_MF_SEQX) are served by the kind-GENERIC kernel only (256 registers):
-   * the walk over a list of ranges keeps three more message words alive through the handlers, which the per-tick
-   * class kernel -- at exactly its 128 registers -- answered with 216 spilled VGPRs (and a class kernel that spills
-   * has returned wrong decisions on the device: tests/test_kernel_resources.py).  rgb_submit routes a batch that
-   * holds such a record to the generic kernel; a specialised path that meets one reports RGB_F_UNHANDLED. */
+  /* written events of more than two ranges (RGB_MF_SEQX) are served by the kind-generic kernel and by the written-only
+   * kernel rgb_tick_kernel<N, RGB_MSG_WRITTEN, true> (256 registers each): the walk over a list of ranges keeps three
+   * more message words alive through the handlers, which the per-tick class kernel -- at exactly its 128 registers --
+   * answered with 216 spilled VGPRs.  rgb_submit routes the written class of a batch that holds such a record to the
+   * written-only kernel (enqueue_rounds); any other specialised path that meets one reports RGB_F_UNHANDLED. */
   static constexpr bool seqx_ok = SEQX;
   /* WC (groups of six and more members: the kernels that have the registers): the run a table walk ended in is
    * remembered -- number, start, term, start of the next run -- and the next look-up of the same message tries it
@@ -1970,7 +1970,9 @@ __device__ __forceinline__ bool compact_decision(Dec &d) {
 /* One message against one server: everything between "message words in registers" and
  * "decision words in registers".  State loads/stores go straight to the server's lines. */
 /* TR = the multi-tick train launch: state loads bypass the L1 (LaneT<true>::coh, see ldg8). */
-template <int N, int KIND, bool PRE = false, bool TR = false>
+/* SEQXP: written events of more than two ranges (RGB_MF_SEQX) are understood -- the kind-generic kernel, and the
+ * written-only kernel rgb_submit_seq's batches run their written class through (rgb_tick_kernel<N, WRITTEN, true>) */
+template <int N, int KIND, bool PRE = false, bool TR = false, bool SEQXP = (KIND < 0)>
 __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                 const ulonglong2 m2, const ulonglong2 m3, u32 i,
                                                 rgb_rpc *__restrict__ rpcs, u32 rpc_slot_base,
@@ -1978,7 +1980,7 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
                                                 const ulonglong2 *pre = nullptr, unsigned swz = 0,
                                                 const ulonglong2 *prepeers = nullptr,
                                                 const ulonglong2 *preruns = nullptr) {
-  LaneT<TR, (N >= 6 && KIND == RGB_MSG_AER), (KIND < 0)> L;   /* (the walk cache costs seven registers: only where it pays) */
+  LaneT<TR, (N >= 6 && KIND == RGB_MSG_AER), SEQXP> L;   /* (the walk cache costs seven registers: only where it pays) */
   L.wc_k = -1; L.wc_start = L.wc_term = L.wc_next = 0;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -2578,7 +2580,7 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
 #define RGB_IO_SLOT 5   /* 16-byte units per LDS record slot: 64 B payload + 16 B pad */
 #define RGB_HOT_SLOT 9  /* 16-byte units reserved per lane in the class kernel's LDS area (rows use 8, unpadded) */
 
-template <int N, int KIND>
+template <int N, int KIND, bool SEQXP = (KIND < 0)>
 __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs,
                                                                   u32 n, const u32 *__restrict__ n_dev,
                                                                   rgb_decision *__restrict__ dec,
@@ -2614,7 +2616,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_MIN_WAVES(N)) void rgb_tick_ker
   if (active) {
     const ulonglong2 m0 = io[lane * RGB_IO_SLOT + 0], m1 = io[lane * RGB_IO_SLOT + 1],
                      m2 = io[lane * RGB_IO_SLOT + 2], m3 = io[lane * RGB_IO_SLOT + 3];
-    process_message<N, KIND>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d);
+    process_message<N, KIND, false, false, SEQXP>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d);
     if (fuse_wanted(dev, d)) fuse_pipeline_step<N, false>(dev, d, base + lane, rpcs, rpc_slot_base, msg_index_base);
     (void)compact_decision(d);
     io[lane * RGB_IO_SLOT + 0] = make_ulonglong2(d.w[0], d.w[1]);
@@ -3221,6 +3223,12 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_CLASS_MIN_WAVES(N)) void rgb_ti
 #define RGB_TRAIN_MIN_WAVES(N) 3
 #endif
 #endif
+/* the PERSISTENT form of groups of eight members: 167 registers + 2 spilled (12 bytes of scratch) at three wavefronts per
+ * SIMD; its 16 KiB of LDS per wavefront admit ten per compute unit anyway, so it is compiled for two per SIMD (eight per
+ * unit) and no scratch -- every hot kernel of every group size is scratch-free (tests/test_kernel_resources.py) */
+#ifndef RGB_TRAIN_PERSIST_MIN_WAVES
+#define RGB_TRAIN_PERSIST_MIN_WAVES(N) ((N) >= 8 ? 2 : RGB_TRAIN_MIN_WAVES(N))
+#endif
 #define RGB_TRAIN_CTL_ARRIVE 8u     /* ctl words 8..15: blocks arrived per XCC (devices with fewer XCCs than shards) */
 #define RGB_TRAIN_CTL_TICKET 32u    /* ctl word 32 (1 + x): next row of shard x (one 128-byte line per shard)         */
 /* the kernel's one argument.  The persistent loop re-reads it from the kernarg segment through a pointer the compiler
@@ -3389,7 +3397,7 @@ __global__ void rgb_train_prolog_kernel(u32 *__restrict__ ctl, u32 clear) {
 }
 
 template <int N>
-__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_train_kernel(rgb_train_args args) {
+__global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_PERSIST_MIN_WAVES(N)) void rgb_train_kernel(rgb_train_args args) {
   /* records, then hot rows; a leader-side slice: 32 hot rows | 32 peers rows | the first line of 32 run tables
    * (12 KiB: twelve wavefronts per CU -- three per SIMD, what the registers allow -- hold 144 of the 160 KiB) */
   __shared__ ulonglong2 io[!RGB_TRAIN_RUNS_LDS ? RGB_TICK_BLOCK * RGB_HOT_SLOT
@@ -4137,13 +4145,13 @@ __global__ void rgb_undo_kernel(rgb_dev dev, const u32 *__restrict__ ids, u32 n,
 #define RGB_LAUNCH_ALL_N LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
 #endif
 
-template <int KIND>
+template <int KIND, bool SEQXP = (KIND < 0)>
 static int launch_tick_kind(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, const u32 *d_n, rgb_decision *d_dec,
                             rgb_rpc *d_rpcs, u32 rpc_slot_base, u32 msg_index_base, hipStream_t st) {
   dim3 grid((n + RGB_TICK_BLOCK - 1) / RGB_TICK_BLOCK), block(RGB_TICK_BLOCK);
 #define LAUNCH(NN)                                                                                   \
   case NN:                                                                                           \
-    hipLaunchKernelGGL((rgb_tick_kernel<NN, KIND>), grid, block, 0, st, dev, d_msgs, n, d_n, d_dec,   \
+    hipLaunchKernelGGL((rgb_tick_kernel<NN, KIND, SEQXP>), grid, block, 0, st, dev, d_msgs, n, d_n, d_dec, \
                        d_rpcs, rpc_slot_base, msg_index_base);                                       \
     break;
   switch (dev.n_members) {
@@ -4164,6 +4172,10 @@ int rgb_launch_tick(const rgb_dev &dev, int cls, const rgb_msg *d_msgs, u32 n, c
     case 1: return launch_tick_kind<RGB_MSG_AER_REPLY>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
     case 2: return launch_tick_kind<RGB_MSG_WRITTEN>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
     case 3: return launch_tick_kind<RGB_MSG_APPEND>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
+    /* written events that may carry more than two ranges (RGB_MF_SEQX: the written class of an rgb_submit_seq batch) */
+    case RGB_TICK_CLS_WRITTEN_SEQX: return launch_tick_kind<RGB_MSG_WRITTEN, true>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
+    /* NOP slots only (the tail of a round of rgb_submit): their empty decisions */
+    case RGB_TICK_CLS_NOP: return launch_tick_kind<RGB_MSG_NOP>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
     default: return launch_tick_kind<-1>(dev, d_msgs, n, d_n, d_dec, d_rpcs, rpc_slot_base, msg_index_base, st);
   }
 }

@@ -875,3 +875,26 @@ def test_written_event_for_a_live_index_below_the_snapshot(engine_mod, oracle_li
         s = step(PM._msg(abi.MSG_WRITTEN, term=2, a=16, b=16))
         assert PM.pending_of(s) == [] and (int(s["last_written_index"]), int(s["last_written_term"])) == (16, 2)
     cpu.close()
+
+
+def test_forced_spill_class_kernel_is_bit_exact():
+    """The per-tick class kernel compiled against a 96-register budget -- FORCED spills: ~1 500 spill instructions, 196
+    bytes of scratch per lane -- must return the oracle's decisions on the device (round 5 saw a spilling build of this
+    kernel return wrong decisions in lanes 0-15; round 6 could not make it happen again: tests/test_kernel_resources.py).
+    The variant library is built here (one group size: about a minute) and run in its own process (one library per
+    process): three ticks of the generator's stream over 16 384 five-member groups, every decision against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "ra_amd", "csrc", "variants", "spill5.so")
+    srcs = [os.path.join(root, "ra_amd", "csrc", f) for f in ("rgb_kernels.hip", "rgb_api.hip", "rgb_internal.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        r = subprocess.run(["bash", os.path.join(root, "tools", "build_variants.sh"), "spill5:-DRGB_CLASS_MIN_WAVES(N)=5"],
+                           capture_output=True, text=True, env=dict(os.environ, ONLY_N="5"))
+        assert os.path.exists(so) and "built spill5" in r.stdout, r.stdout + r.stderr
+    env = dict(os.environ, RGB_LIB=so, G="16384", T="3")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "parity_tick0.py")], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("tick ")]
+    assert len(lines) == 3 and all(ln.endswith(" 0 mismatches") for ln in lines), r.stdout[-2000:]
