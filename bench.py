@@ -242,10 +242,14 @@ def main():
                     help="the generator's ordering hint (include/ra_gpu_batch_synth.h, rgb_synth_set_hint): none, the "
                          "owner's state name (round 4), + the owner's O(1) compare of the rpc header with fields it "
                          "holds (default); it only orders a tick, results are the same")
-    ap.add_argument("--device-plan", action="store_true",
-                    help="build the train's row plan ON THE DEVICE, inside the timed region, from the bucket counts the "
-                         "generator left in device memory (rgb_train_plan_build_device; the grid of a dealt launch is "
-                         "then the rows bound of a tick) -- no copy of the counts to the host, no host merge")
+    ap.add_argument("--plan", choices=("producer", "host", "region"), default="producer",
+                    help="where the train's row plan is built.  producer (default): ON THE DEVICE by the stream's producer -- "
+                         "one rgb_train_plan_build_device kernel behind the generator, from the bucket counts it left in "
+                         "device memory: nothing of the plan passes through the host, no copy of the counts, and no plan "
+                         "kernel in front of a launch (the grid of a dealt launch is the rows bound of a tick); host: "
+                         "rgb_train_plan_create* from a host copy of the counts (rounds 3-5); region: the device build as "
+                         "one kernel per launch INSIDE the timed region, in front of the launch")
+    ap.add_argument("--device-plan", action="store_true", help="= --plan region (round 5's flag)")
     ap.add_argument("--graph", action="store_true", help="capture the timed region into a hipGraph even when it is one or two launches")
     ap.add_argument("--snapshot-kernel", action="store_true",
                     help="train: one launch per leaderboard period with the snapshot KERNEL between the launches (the "
@@ -436,12 +440,21 @@ def main():
     # the aged state (device, untimed: the order rgb_submit's bucketing would establish on the host path) ----
     plan = d_dec2 = None
     plan_host_ms = None
-    device_plan = use_train and args.device_plan
-    if device_plan:
-        # nothing of the plan passes through the host: an empty plan now, every launch's ticks are built by a kernel in
-        # front of it, on the launch stream, inside the timed region (launch_ticks)
+    plan_mode = "region" if args.device_plan else args.plan
+    if use_train and plan_mode != "host" and not hasattr(engine.lib(), "rgb_train_plan_build_device"):
+        plan_mode = "host"                                         # (RGB_LIB=<a build of an earlier ABI>)
+    device_plan = use_train and plan_mode == "region"
+    producer_plan = use_train and plan_mode == "producer"
+    if device_plan or producer_plan:
+        # nothing of the plan passes through the host.  region: an empty plan now, every launch's ticks are built by a
+        # kernel in front of it, on the launch stream, inside the timed region (launch_ticks).  producer: the whole
+        # stream's plan by ONE kernel here, behind the generator that left the counts in device memory -- the producer
+        # of a device-resident stream hands over messages, stamps AND plan; the timed region is launches only
         plan = engine.TrainPlan(eng, None, snapshot_every=SNAPSHOT_EVERY if snap_in_train else 0, device_ticks=T)
         plan_host_ms = 0.0
+        if producer_plan:
+            plan.build_device(0, T, d_bc.data_ptr(), sptr)
+            torch.cuda.synchronize()
         d_dec2 = torch.zeros(T * tick_bytes, dtype=torch.uint8, device=dev)
     elif use_train:
         buckets = d_bc.cpu().numpy().reshape(T, engine.TRAIN_BUCKETS).astype(np.uint32)
@@ -631,21 +644,36 @@ def main():
                       "compact_decisions": compact_info,
                       "plan": ("built on the device inside the timed region (rgb_train_plan_build_device: one kernel per "
                                "launch in front of it, from the generator's bucket counts in device memory); grid = the rows bound of a tick"
-                               if device_plan else "built on the host before the timed region from the bucket counts "
+                               if device_plan else
+                               "built on the device by the stream's producer (ONE rgb_train_plan_build_device kernel behind the "
+                               "generator, from the bucket counts it left in device memory; no host copy of the counts, no plan "
+                               "kernel in the timed region); grid = the rows bound of a tick"
+                               if producer_plan else "built on the host before the timed region from the bucket counts "
                                "(rgb_train_plan_create*): the dealt form needs the rows of a tick for its grid"),
                       "ordering_hint": {0: "none", 1: "owner's state name",
                                         2: "owner's state name + its O(1) compare of the rpc header with current_term, "
                                            "leader_id, last index / term (rgb_synth_set_hint 2); orders the tick only"}[hint_level],
-                      "stamps": "written by the stream's producer (rgb_synth_tick_stamped_device) with the messages: "
-                                "nothing of the train's input preparation is outside the timed region except the host's "
-                                "row plan (256 bucket counts per tick)",
+                      "stamps": "written by the stream's producer (rgb_synth_tick_stamped_device) with the messages" +
+                                ("; the row plan by the producer as well, on the device" if producer_plan else
+                                 ": nothing of the train's input preparation is outside the timed region except the "
+                                 "row plan (256 bucket counts per tick)"),
                       "plan_host_ms_total": round(plan_host_ms, 3), "plan_host_us_per_tick": round(plan_host_ms * 1e3 / T, 2),
                       "xcd_of_shard": [int(v) for v in xcc], "decisions_compared_with_per_tick_launches": int(n_dec.sum())}
     checksum_pass2 = eng.state_checksum()
     # the row plan on the device (rgb_train_plan_build_device): what building the timed region's plan costs as ONE kernel
     # from the generator's bucket counts in device memory, and that its tables are the host's bit for bit (every tick)
     device_plan_info = None
-    if use_train and not device_plan and rank == 0 and hasattr(engine.lib(), "rgb_train_plan_build_device"):
+    if producer_plan and rank == 0:
+        # behind the timed region: the producer's plan against the host's merge of the same counts, every tick
+        buckets = d_bc.cpu().numpy().reshape(T, engine.TRAIN_BUCKETS).astype(np.uint32)
+        assert np.array_equal(buckets.sum(axis=1), counts)
+        hpl = (eng.train_plan_snap(buckets, SNAPSHOT_EVERY) if snap_in_train else eng.train_plan(buckets))
+        same = sum(1 for t in range(T) if all(np.array_equal(x, y) for x, y in zip(hpl.download(t), plan.download(t))))
+        hpl.close()
+        if same != T:
+            raise SystemExit(f"PLAN MISMATCH: the device-built plan differs from the host's in {T - same} of {T} ticks")
+        train_info["device_plan"] = {"ticks_whose_tables_equal_the_host_plan": same, "ticks": T}
+    if use_train and not device_plan and not producer_plan and rank == 0 and hasattr(engine.lib(), "rgb_train_plan_build_device"):
         dpl = engine.TrainPlan(eng, None, snapshot_every=SNAPSHOT_EVERY if snap_in_train else 0, device_ticks=T)
         best = None
         for _ in range(5):
@@ -877,6 +905,40 @@ def main():
                 ts.sort()
                 lat[label] = {"round_trip_us_p50": round(ts[len(ts) // 2] * 1e6, 1), "round_trip_us_p10": round(ts[len(ts) // 10] * 1e6, 1),
                               "trains": eng_s.submit_trains()}
+                # where the round trip goes: rgb_submit (validation, rounds, bucket sort into the pinned slot, enqueue of the
+                # copy in + one launch per round + count / un-permute kernels + copies out), the device's part behind it
+                # (until the stream is idle), rgb_collect (event wait, copy-out of decisions and rpc records)
+                bd = [[], [], []]
+                for _ in range(100):
+                    t0 = time.perf_counter(); eng_s.submit(small)
+                    t1 = time.perf_counter(); eng_s.synchronize()
+                    t2 = time.perf_counter(); eng_s.collect(out=bufs_s)
+                    t3 = time.perf_counter()
+                    bd[0].append(t1 - t0); bd[1].append(t2 - t1); bd[2].append(t3 - t2)
+                lat[label]["breakdown_us_p50"] = {k: round(sorted(v)[len(v) // 2] * 1e6, 1)
+                                                  for k, v in zip(("rgb_submit", "device_behind_submit", "rgb_collect"), bd)}
+                if label == "fused_train" and hasattr(eng_s, "inject_train_fault"):
+                    # what a FAILED train launch costs (asked for in rounds 4 and 5): the next batch's launch is made to
+                    # fail its placement check (two messages bucketed under each other's shard); rgb_submit / rgb_collect
+                    # repair it -- undo log back, the batch again with one launch per round -- and the context goes over
+                    # to the PERSISTENT form for good: the failed batch's own round trip, then the round trips after it
+                    form0, rec0 = eng_s.train_form(), eng_s.train_recoveries()
+                    eng_s.inject_train_fault(2)
+                    t0 = time.perf_counter()
+                    eng_s.submit(small); eng_s.collect(out=bufs_s)
+                    t_fault = time.perf_counter() - t0
+                    ts2 = []
+                    for _ in range(100):
+                        t0 = time.perf_counter()
+                        eng_s.submit(small); eng_s.collect(out=bufs_s)
+                        ts2.append(time.perf_counter() - t0)
+                    ts2.sort()
+                    lat["after_injected_placement_failure"] = {
+                        "failed_batch_round_trip_us": round(t_fault * 1e6, 1), "recoveries": eng_s.train_recoveries() - rec0,
+                        "form_before": form0, "form_after": eng_s.train_form(),
+                        "round_trip_us_p50_after": round(ts2[len(ts2) // 2] * 1e6, 1),
+                        "note": "repair = the undo log restored + the batch re-run with one launch per round; later batches run "
+                                "the persistent train form"}
                 eng_s.close()
             host_path["rounds4_small"] = {"batch_messages": int(len(small)), **lat,
                                           "note": "submit + collect of one small four-round batch, 200 round trips after 20 of "

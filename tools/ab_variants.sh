@@ -3,7 +3,7 @@
 # in the driver's form and in the long form, interleaved and repeated so that a box's drift shows; every decision of
 # the timed replay is compared with the per-tick launches of the generation pass (bench.py), except for variants whose
 # name starts with x_ (timing probes that break parity).
-#   gpurun -- 'bash tools/r06_ab.sh TAG [reps]'
+#   gpurun -- 'bash tools/ab_variants.sh TAG [reps]'
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; TAG=${1:-r06ab}; REPS=${2:-2}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 V=$R/ra_amd/csrc/variants

@@ -2,7 +2,7 @@
 # Build experiment variants of the library into ra_amd/csrc/variants/ (git-ignored, they travel with gpurun):
 #   tools/build_variants.sh name1:"-DFLAG=1 -DOTHER=2" name2:"..."
 # Every variant instantiates N=5 only (-DRGB_X_ONLY_N=5): bench.py --members 5 with RGB_LIB=<variant>.
-# tools/knob_sweep.sh times every variants/*.so with the same command on the same box.
+# tools/ab_variants.sh times every variants/*.so with the same commands on the same box (interleaved, repeated).
 set -u
 cd "$(dirname "$0")/../ra_amd/csrc"
 mkdir -p variants
