@@ -454,6 +454,8 @@ def main():
         plan_host_ms = 0.0
         if producer_plan:
             plan.build_device(0, T, d_bc.data_ptr(), sptr)
+            if hasattr(plan, "fit") and hasattr(engine.lib(), "rgb_train_plan_fit"):
+                plan.fit(0, T, sptr)      # four bytes per tick come back (its rows): the launches' grids are the rows, not the bound
             torch.cuda.synchronize()
         d_dec2 = torch.zeros(T * tick_bytes, dtype=torch.uint8, device=dev)
     elif use_train:
@@ -647,7 +649,8 @@ def main():
                                if device_plan else
                                "built on the device by the stream's producer (ONE rgb_train_plan_build_device kernel behind the "
                                "generator, from the bucket counts it left in device memory; no host copy of the counts, no plan "
-                               "kernel in the timed region); grid = the rows bound of a tick"
+                               "kernel in the timed region); the host is told the rows of every tick (rgb_train_plan_fit: 4 bytes "
+                               "per tick) and sizes the launches' grids by them"
                                if producer_plan else "built on the host before the timed region from the bucket counts "
                                "(rgb_train_plan_create*): the dealt form needs the rows of a tick for its grid"),
                       "ordering_hint": {0: "none", 1: "owner's state name",
@@ -919,9 +922,9 @@ def main():
                                                   for k, v in zip(("rgb_submit", "device_behind_submit", "rgb_collect"), bd)}
                 if label == "fused_train" and hasattr(eng_s, "inject_train_fault"):
                     # what a FAILED train launch costs (asked for in rounds 4 and 5): the next batch's launch is made to
-                    # fail its placement check (two messages bucketed under each other's shard); rgb_submit / rgb_collect
-                    # repair it -- undo log back, the batch again with one launch per round -- and the context goes over
-                    # to the PERSISTENT form for good: the failed batch's own round trip, then the round trips after it
+                    # fail (two messages bucketed under each other's shard: the order check of every wavefront);
+                    # rgb_submit / rgb_collect repair it -- undo log back, the batch again with one launch per round:
+                    # the failed batch's own round trip, then the round trips after it
                     form0, rec0 = eng_s.train_form(), eng_s.train_recoveries()
                     eng_s.inject_train_fault(2)
                     t0 = time.perf_counter()
@@ -933,12 +936,13 @@ def main():
                         eng_s.submit(small); eng_s.collect(out=bufs_s)
                         ts2.append(time.perf_counter() - t0)
                     ts2.sort()
-                    lat["after_injected_placement_failure"] = {
+                    lat["after_injected_train_failure"] = {
                         "failed_batch_round_trip_us": round(t_fault * 1e6, 1), "recoveries": eng_s.train_recoveries() - rec0,
                         "form_before": form0, "form_after": eng_s.train_form(),
                         "round_trip_us_p50_after": round(ts2[len(ts2) // 2] * 1e6, 1),
-                        "note": "repair = the undo log restored + the batch re-run with one launch per round; later batches run "
-                                "the persistent train form"}
+                        "note": "repair = the undo log restored + the batch re-run with one launch per round (a mis-bucketed "
+                                "pair of messages: RGB_TRAIN_ERR_ORDER; a PLACEMENT failure would also move the context to "
+                                "the persistent form)"}
                 eng_s.close()
             host_path["rounds4_small"] = {"batch_messages": int(len(small)), **lat,
                                           "note": "submit + collect of one small four-round batch, 200 round trips after 20 of "

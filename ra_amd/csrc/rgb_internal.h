@@ -260,7 +260,8 @@ int rgb_launch_synth(const rgb_dev &dev, u64 seed, u64 tick, rgb_msg *d_msgs, u3
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
                      rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream,
-                     const unsigned char *d_snap_stamps = nullptr, rgb_leaderboard_row *d_snap_rows = nullptr);
+                     const unsigned char *d_snap_stamps = nullptr, rgb_leaderboard_row *d_snap_rows = nullptr,
+                     u32 tab_rpt = 0 /* rows per tick of d_row_tab when it is more than bpt / RGB_TRAIN_SHARDS */);
 u32 rgb_train_resident_blocks(unsigned n_members);
 /* the placement marks of the last dealt launch on d_ctl -> RGB_TRAIN_ERR_PLACEMENT in d_ctl[0] (the next launch does
  * this by itself; the host calls it before it reads the error word) */

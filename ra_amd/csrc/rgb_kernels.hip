@@ -72,6 +72,9 @@ __host__ __device__ __forceinline__ constexpr u32 rgb_class_slice(int c, unsigne
  * too -- their wavefronts fetch the 32 peers rows cooperatively into LDS (12 lanes per row, 256 bytes of LDS each)
  * beside the 32 hot rows and the first line of the 32 run tables (16 KiB, what these kernels allocate anyway), where
  * every lane used to read its row from memory with eleven 16-byte loads of its own (round 5; BASELINE configs[4]) */
+#ifndef RGB_X_NORPC
+#define RGB_X_NORPC 0             /* 1: PROBE (breaks the output) -- no rpc record is stored: what the records' stores cost a tick */
+#endif
 #ifndef RGB_X_LEAD32_WIDE
 #define RGB_X_LEAD32_WIDE 1
 #endif
@@ -1191,7 +1194,7 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
        * message and commit_index does not move after pipelining, so the commit step stores L.ci itself (ten
        * VGPRs fewer across the loop for N = 5) */
       L.dcs_ci |= 1u << i;
-      if (rpcs != nullptr) {
+      if (rpcs != nullptr && !RGB_X_NORPC) {
         /* fixed slot: this message's (n_out-1)-th record; 56 B = 7 x 8-B stores */
         u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
         ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
@@ -1336,7 +1339,7 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
       new_ni = to + 1;
     }
     n_out += 1;
-    if (rpcs != nullptr) {
+    if (rpcs != nullptr && !RGB_X_NORPC) {
       u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
       ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
       ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
@@ -3245,6 +3248,9 @@ struct rgb_train_args {
   rgb_rpc *rpcs;
   u32 *ctl;
   u32 tick_stride, rpt, n_ticks, rpc_ring, index_base, n_xcc;
+  u32 tab_rpt;                        /* rows per tick of row_tab (>= rpt, the rows per tick of the dealt GRID: a device-built
+                                         plan's table is sized by the rows bound, its grid by the rows its ticks have when
+                                         the host has been told -- rgb_train_plan_fit) */
   const unsigned char *snap_stamps;   /* snapshots inside the launch: the bytes every server must show, laid out like  */
   rgb_leaderboard_row *snap_rows;     /* dev.seq, one array per snapshot ordinal; the rows, n_groups per ordinal        */
 };
@@ -3353,7 +3359,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_MIN_WAVES(N)) void rgb_tr
   const u32 tc = t < n_ticks ? t : n_ticks - 1u;           /* (a launch has at least one tick) */
   const rgb_train_tick *p = args.plan + tc;
   const u32 n_rows = p->n_rows;
-  const u32 e = args.row_tab[(size_t)tc * rpt + row];
+  const u32 e = args.row_tab[(size_t)tc * args.tab_rpt + row];
   /* (bitwise: both loads are wanted by the one decision; no table entry is all ones -- its class byte is <= 30) */
   if ((t >= n_ticks) | (row >= n_rows) | (e == 0xFFFFFFFFu)) return;
   const u32 pc = e >> 24;                                  /* plan class = 2 x class + sub-bucket */
@@ -3446,7 +3452,7 @@ __global__ __launch_bounds__(RGB_TICK_BLOCK, RGB_TRAIN_PERSIST_MIN_WAVES(N)) voi
     }
     if (t >= n_ticks) break;
     const rgb_train_tick *p = plan + t;
-    const u32 e = A->row_tab[(size_t)t * A->rpt + (k - cum)];
+    const u32 e = A->row_tab[(size_t)t * A->tab_rpt + (k - cum)];
     const u32 pc = e >> 24;                                /* plan class = 2 x class + sub-bucket */
     u32 *const tk = A->ctl + RGB_TRAIN_CTL_TICKET * (1u + x);
     if (pc == RGB_PC_SNAP) {
@@ -4514,7 +4520,7 @@ u32 rgb_train_resident_blocks(unsigned n_members) {
 int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride,
                      const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec,
                      rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream,
-                     const unsigned char *d_snap_stamps, rgb_leaderboard_row *d_snap_rows) {
+                     const unsigned char *d_snap_stamps, rgb_leaderboard_row *d_snap_rows, u32 tab_rpt) {
   (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   /* n_blocks = 0: the DEALT form (one block per row; the caller's calibration showed round-robin dispatch) */
   const bool dealt = n_blocks == 0;
@@ -4538,6 +4544,8 @@ int rgb_launch_train(const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned c
   args.dev = dev; args.msgs = d_msgs; args.stamps = d_stamps; args.plan = d_plan; args.row_tab = d_row_tab;
   args.dec = d_dec; args.rpcs = d_rpcs; args.ctl = d_ctl; args.tick_stride = tick_stride;
   args.rpt = bpt / RGB_TRAIN_SHARDS; args.n_ticks = n_ticks; args.rpc_ring = rpc_ring ? rpc_ring : 1u;
+  args.tab_rpt = tab_rpt ? tab_rpt : args.rpt;
+  if (args.tab_rpt < args.rpt) return -1;
   args.index_base = index_base; args.n_xcc = n_xcc;
   args.snap_stamps = d_snap_stamps; args.snap_rows = d_snap_rows;
 #define LAUNCH(NN)                                                                                      \

@@ -26,7 +26,7 @@ EXPORTS = [
     "rgb_train_bucket", "rgb_train_plan_create", "rgb_train_plan_destroy", "rgb_train_plan_blocks_per_tick",
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status", "rgb_train_form", "rgb_train_recoveries",
     "rgb_train_plan_create_snap", "rgb_train_run_snap_device", "rgb_snapshot_train_device", "rgb_train_seq_bytes",
-    "rgb_train_plan_create_device", "rgb_train_plan_build_device", "rgb_train_plan_download",
+    "rgb_train_plan_create_device", "rgb_train_plan_build_device", "rgb_train_plan_download", "rgb_train_plan_fit",
     "rgb_submit_seq", "rgb_set_seq_ranges_device",
 ]
 COMM_EXPORTS = ["rgb_comm_unique_id", "rgb_comm_init_rank", "rgb_comm_destroy", "rgb_comm_n_ranks", "rgb_comm_rank",
@@ -39,7 +39,7 @@ OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_res
                           "rgb_train_recoveries", "rgb_train_plan_create_snap", "rgb_train_run_snap_device",
                           "rgb_snapshot_train_device", "rgb_train_seq_bytes", "rgb_synth_snapshot_mark_device",
                           "rgb_synth_set_hint", "rgb_train_plan_create_device", "rgb_train_plan_build_device",
-                          "rgb_train_plan_download", "rgb_submit_seq", "rgb_set_seq_ranges_device"} | set(COMM_EXPORTS)
+                          "rgb_train_plan_download", "rgb_train_plan_fit", "rgb_submit_seq", "rgb_set_seq_ranges_device"} | set(COMM_EXPORTS)
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -167,6 +167,8 @@ def lib():
         L.rgb_train_plan_create_device.argtypes = [vp, u32, u32, C.POINTER(vp)]
         L.rgb_train_plan_build_device.argtypes = [vp, vp, u32, u32, vp, vp]
         L.rgb_train_plan_download.argtypes = [vp, vp, u32, vp, vp, u32]
+    if hasattr(L, "rgb_train_plan_fit"):
+        L.rgb_train_plan_fit.argtypes = [vp, vp, u32, u32, vp]
     L.rgb_train_status.argtypes = [vp, C.POINTER(u32), vp]
     L.rgb_synth_apply_tick_device.argtypes = [vp, vp, u32, vp, vp, vp]
     if hasattr(L, "rgb_synth_set_hint"):
@@ -587,6 +589,11 @@ class TrainPlan:
         on `stream` (rgb_train_plan_build_device): nothing of the plan passes through the host."""
         self.eng._check(self.eng._L.rgb_train_plan_build_device(self.eng._h, self.h, first_tick, n_ticks, d_bucket_counts,
                                                                 stream or None), "rgb_train_plan_build_device")
+
+    def fit(self, first_tick: int, n_ticks: int, stream: int = 0):
+        """Tell the host the rows of the built ticks (rgb_train_plan_fit: 4 bytes per tick come back; synchronises):
+        launches over them take a grid of their rows instead of the rows bound."""
+        self.eng._check(self.eng._L.rgb_train_plan_fit(self.eng._h, self.h, first_tick, n_ticks, stream or None), "rgb_train_plan_fit")
 
     def close(self):
         if self.h:

@@ -42,8 +42,8 @@ DISPATCH(int, rgb_launch_tick_classes, P_CLS, A_CLS, dev.n_members, -1)
 DISPATCH(int, rgb_launch_synth, P_SYN, A_SYN, dev.n_members, -1)
 
 /* (the default arguments of the declaration in rgb_internal.h belong to the plain name only) */
-#define P_TRAIN (const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride, const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream, const unsigned char *d_snap_stamps, rgb_leaderboard_row *d_snap_rows)
-#define A_TRAIN (dev, d_msgs, d_stamps, tick_stride, d_plan, d_row_tab, n_ticks, bpt, d_dec, d_rpcs, rpc_ring, index_base, d_ctl, n_xcc, n_blocks, stream, d_snap_stamps, d_snap_rows)
+#define P_TRAIN (const rgb_dev &dev, const rgb_msg *d_msgs, const unsigned char *d_stamps, u32 tick_stride, const rgb_train_tick *d_plan, const u32 *d_row_tab, u32 n_ticks, u32 bpt, rgb_decision *d_dec, rgb_rpc *d_rpcs, u32 rpc_ring, u32 index_base, u32 *d_ctl, u32 n_xcc, u32 n_blocks, void *stream, const unsigned char *d_snap_stamps, rgb_leaderboard_row *d_snap_rows, u32 tab_rpt)
+#define A_TRAIN (dev, d_msgs, d_stamps, tick_stride, d_plan, d_row_tab, n_ticks, bpt, d_dec, d_rpcs, rpc_ring, index_base, d_ctl, n_xcc, n_blocks, stream, d_snap_stamps, d_snap_rows, tab_rpt)
 #define DECL_rgb_launch_train(n) DECLN(int, rgb_launch_train, n, P_TRAIN)
 #define CASE_rgb_launch_train(n) CASEN(rgb_launch_train, n, A_TRAIN)
 DISPATCH(int, rgb_launch_train, P_TRAIN, A_TRAIN, dev.n_members, -1)

@@ -179,6 +179,18 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
         got = _tick(dec3, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE)
         assert got.tobytes() == want_dec[t].tobytes(), f"device-built plan: decisions of tick {t}"
     assert eng.get_state().tobytes() == r["st_end"].tobytes(), "device-built plan: final state differs"
+    # the same plan once the host has been told its ticks' rows (rgb_train_plan_fit): the grid is the rows, not the bound
+    dplan.fit(0, T)
+    eng.set_state(0, r["st_start"])
+    dec4, rpc4 = Buf(T * tb, on_gpu), Buf(T * rs, on_gpu)
+    eng.train_stamp_device(r["msgs"].ptr, stamps.ptr, S, r["counts"])
+    eng.train_run_device(dplan, 0, T, r["msgs"].ptr, stamps.ptr, S, dec4.ptr, rpc4.ptr, rpc_ring=T)
+    eng.synchronize()
+    assert eng.train_status()[0] == 0
+    for t in range(T):
+        got = _tick(dec4, t, tb, int(r["counts"][t]), abi.DECISION_DTYPE)
+        assert got.tobytes() == want_dec[t].tobytes(), f"device-built plan, fitted grid: decisions of tick {t}"
+    assert eng.get_state().tobytes() == r["st_end"].tobytes(), "device-built plan, fitted grid: final state differs"
     dplan.close()
     plan.close()
     eng.close()
