@@ -103,6 +103,47 @@ __device__ __forceinline__ void store16_nt(void *p, ulonglong2 v) {
 #define ST16(ptr, val) do { *(ptr) = (val); } while (0)
 #define ST8(ptr, val) do { *(ptr) = (val); } while (0)
 
+/* One 56-byte rgb_rpc record (seven words, 8-byte aligned: records are 56 bytes apart) as three 16-byte stores and one
+ * of 8 -- gfx950 takes a 16-byte store at any dword alignment -- instead of seven 8-byte stores (round 6: the records'
+ * stores, 28 instructions per pipelining lane on the longest-lived wavefronts of a tick, cost 6-7 % of it by the
+ * no-store probe; RGB_X_RPC_ST8 = 1 is the old form for A/B timing) */
+#ifndef RGB_X_RPC_ST8
+#define RGB_X_RPC_ST8 0
+#endif
+typedef unsigned long long rgb_u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void store_rpc(rgb_rpc *slot, u64 w0, u64 w1, u64 w2, u64 w3, u64 w4, u64 w5, u64 w6) {
+  u64 *o = reinterpret_cast<u64 *>(slot);
+#if RGB_X_RPC_ST8 || defined(RGB_HOST_EMULATION)
+  ST8(o + 0, w0); ST8(o + 1, w1); ST8(o + 2, w2); ST8(o + 3, w3); ST8(o + 4, w4); ST8(o + 5, w5); ST8(o + 6, w6);
+#else
+  rgb_u64x2_a8 a, b, c;
+  a.x = w0; a.y = w1; b.x = w2; b.y = w3; c.x = w4; c.y = w5;
+  *reinterpret_cast<rgb_u64x2_a8 *>(o + 0) = a;
+  *reinterpret_cast<rgb_u64x2_a8 *>(o + 2) = b;
+  *reinterpret_cast<rgb_u64x2_a8 *>(o + 4) = c;
+  ST8(o + 6, w6);
+#endif
+}
+/* Deferred rpc records (round 6).  The records are OUTPUT: no later message reads them, yet stored where they are made
+ * -- inside the clause code of the longest-lived wavefronts of a tick ({commands}: four records per lane) -- they stand
+ * in front of the wavefront's publish twice: their issue, and their acknowledgements in the wait before it.  A train
+ * wavefront keeps what it cannot recompute (32 bytes per record) in LDS and stores the records BEHIND its publish, like
+ * its decisions.  Same records, same slots.  RGB_X_RPC_DEFER = 0: the direct form, A/B timing */
+#ifndef RGB_X_RPC_DEFER
+#define RGB_X_RPC_DEFER 1
+#endif
+template <class Lane>
+__device__ __forceinline__ void emit_rpc(Lane &L, rgb_rpc *rpcs, u32 slot_base, unsigned ord, u32 msg_index, u64 w1,
+                                         u64 rp_idx, u64 rp_term, u64 new_ni) {
+  if (rpcs == nullptr || RGB_X_NORPC) return;
+  if (RGB_X_RPC_DEFER && L.rpc_stash != nullptr && ord < 4u) {
+    L.rpc_stash[2u * ord] = make_ulonglong2(w1, rp_idx);
+    L.rpc_stash[2u * ord + 1u] = make_ulonglong2(rp_term, new_ni);
+    return;
+  }
+  store_rpc(rpcs + (size_t)slot_base + ord, (u64)msg_index | ((u64)L.server << 32), w1, L.ct, rp_idx, rp_term, L.ci, new_ni);
+}
+
 /* -DRGB_X_MARK: comment markers around every class path in the assembly (tools/class_isa.py counts per class) */
 #if defined(RGB_X_MARK) && !defined(RGB_HOST_EMULATION)
 #define RGB_MARK(what, rank) asm volatile("; RGB_MARK " what " %0" ::"n"(rank));
@@ -225,6 +266,9 @@ struct LaneT {
   unsigned peers_swz;            /* piece p of that row sits at position p ^ peers_swz */
   const ulonglong2 *runs_lds;    /* runs 0..RGB_RUNS_LDS-1 of the run table in LDS (train launches, leader-side classes:
                                   * fetched with the hot row; run k at position k ^ peers_swz), or null */
+  ulonglong2 *rpc_stash;         /* train launches, leader-side classes of groups of <= 5 members: the message's rpc records
+                                  * (<= 4) wait HERE -- 32 bytes each in the lane's own hot row in LDS, dead once the row is
+                                  * in registers -- until the wavefront has published (emit_rpc, rgb_tick_slice), or null */
   u32 max_runs;
   /* effects */
   u32 flags;
@@ -1194,13 +1238,9 @@ __device__ __forceinline__ int pipeline_rpcs(Lane &L, bool force, u32 max_pipe, 
        * message and commit_index does not move after pipelining, so the commit step stores L.ci itself (ten
        * VGPRs fewer across the loop for N = 5) */
       L.dcs_ci |= 1u << i;
-      if (rpcs != nullptr && !RGB_X_NORPC) {
-        /* fixed slot: this message's (n_out-1)-th record; 56 B = 7 x 8-B stores */
-        u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
-        ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
-        ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
-        ST8(o + 2, L.ct); ST8(o + 3, rp_idx); ST8(o + 4, rp_term); ST8(o + 5, L.ci); ST8(o + 6, new_ni);
-      }
+      /* fixed slot: this message's (n_out-1)-th record */
+      emit_rpc(L, rpcs, slot_base, n_out - 1u, msg_index, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16),
+               rp_idx, rp_term, new_ni);
     }
   }
   return 0;
@@ -1339,12 +1379,8 @@ __device__ __forceinline__ int make_all_rpcs(Lane &L, unsigned &n_out, rgb_rpc *
       new_ni = to + 1;
     }
     n_out += 1;
-    if (rpcs != nullptr && !RGB_X_NORPC) {
-      u64 *o = reinterpret_cast<u64 *>(rpcs + (size_t)slot_base + (n_out - 1));
-      ST8(o + 0, (u64)msg_index | ((u64)L.server << 32));
-      ST8(o + 1, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16));
-      ST8(o + 2, L.ct); ST8(o + 3, rp_idx); ST8(o + 4, rp_term); ST8(o + 5, L.ci); ST8(o + 6, new_ni);
-    }
+    emit_rpc(L, rpcs, slot_base, n_out - 1u, msg_index, (u64)(unsigned)i | ((u64)kind << 8) | ((u64)(n_ent & 0xFFFFu) << 16),
+             rp_idx, rp_term, new_ni);
   }
   return 0;
 }
@@ -1982,8 +2018,9 @@ __device__ __forceinline__ void process_message(const rgb_dev &dev, const ulongl
                                                 u32 msg_index_base, Dec &out, u64 *t_loaded = nullptr,
                                                 const ulonglong2 *pre = nullptr, unsigned swz = 0,
                                                 const ulonglong2 *prepeers = nullptr,
-                                                const ulonglong2 *preruns = nullptr) {
-  LaneT<TR, (N >= 6 && KIND == RGB_MSG_AER), SEQXP> L;   /* (the walk cache costs seven registers: only where it pays) */
+                                                const ulonglong2 *preruns = nullptr, ulonglong2 *rpc_stash = nullptr) {
+  LaneT<TR, (N >= 6 && KIND == RGB_MSG_AER), SEQXP> L;
+  L.rpc_stash = rpc_stash;   /* (the walk cache costs seven registers: only where it pays) */
   L.wc_k = -1; L.wc_start = L.wc_term = L.wc_next = 0;
   L.server = (u32)(m0.x & 0xFFFFFFFFull);
   /* KIND >= 0: compile-time message kind -- the clause switches fold and only that kind's path
@@ -3001,6 +3038,14 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #ifdef RGB_PROFILE
   if (!TR) tlp = tl;
 #endif
+  /* deferred rpc records (emit_rpc): a train's leader-side wavefronts of groups of <= 5 members (<= 4 records per
+   * message) park them in the lane's own hot row -- read into registers before anything is parked -- and store them
+   * behind the publish; what a record takes from the server, its current term, is read HERE (a leader that emits
+   * records does not change its term in the same message) */
+  const bool STASH = TR && RGB_X_RPC_DEFER && PEERS_LDS && lead_cls && rpcs != nullptr && N <= 5;
+  ulonglong2 *stash = STASH ? io + lane * 8 : nullptr;
+  u64 ct0 = 0;
+  if (STASH) ct0 = hrow[HOT_P_TERM ^ hswz].x;
   bool done = false;
 #if RGB_X_FAST
   /* the steady-state outcome of the three bulk kinds first; whoever is left takes the general clause code below */
@@ -3022,7 +3067,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   case RANK:                                                                                            \
     RGB_MARK("begin", RANK)                                                                             \
     process_message<N, KIND, PRE, TR>(dev, m0, m1, m2, m3, base + lane, rpcs, rpc_slot_base, msg_index_base, d, tlp, \
-                                      hrow, hswz, prow, rrow);                                          \
+                                      hrow, hswz, prow, rrow, stash);                                   \
     RGB_MARK("end", RANK)                                                                               \
     break;
     switch (cls) {
@@ -3091,6 +3136,21 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #else
       (void)__hip_atomic_fetch_or(const_cast<u32 *>(place_word), place_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+    }
+  }
+  if (STASH) {
+    /* the parked rpc records, behind the publish (fire and forget, like the decisions below) */
+    const unsigned n_rp = active ? (unsigned)((d.w[0] >> 48) & 0xFFull) : 0u;
+    if (__ballot(n_rp != 0u) != 0ull) {
+      rgb_rpc *slot0 = rpcs + (size_t)(rpc_slot_base + base + lane) * (N > 1 ? N - 1 : 1);
+      const u64 w0 = (u64)(msg_index_base + base + lane) | ((d.w[0] & 0xFFFFFFFFull) << 32);
+#pragma unroll
+      for (unsigned j = 0; j < (N > 1 ? (unsigned)N - 1u : 1u) && j < 4u; ++j) {
+        if (j < n_rp) {
+          const ulonglong2 a = stash[2u * j], b = stash[2u * j + 1u];
+          store_rpc(slot0 + j, w0, a.x, ct0, a.y, b.x, d.w[6], b.y);
+        }
+      }
     }
   }
   RGB_TT(5);

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 6: (A) the producer-built device plan against the host-built plan, same box, both forms; (B) what the rpc
-# records' stores cost (probe, breaks the output) and what the compact decision form is worth (parity kept)
+# round 6: the producer-built device plan (fitted grid: rgb_train_plan_fit) against the host-built plan and against the
+# device build inside the region, same box, both forms (variants/pro.so = the product's sources, N = 5 only)
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; OUT=$R/gpurun_out/${1:-r06e}; mkdir -p $OUT
 V=$R/ra_amd/csrc/variants
@@ -27,8 +27,4 @@ done
 for rep in 1 2; do
   one host_long_$rep pro $L --plan host
   one producer_long_$rep pro $L --plan producer
-  one norpc_long_$rep x_norpc $L --plan host
-  one nocompact_long_$rep nocompact $L --plan host
-  one norpc_drv_$rep x_norpc $D --plan host
-  one nocompact_drv_$rep nocompact $D --plan host
 done
