@@ -266,9 +266,9 @@ struct LaneT {
   unsigned peers_swz;            /* piece p of that row sits at position p ^ peers_swz */
   const ulonglong2 *runs_lds;    /* runs 0..RGB_RUNS_LDS-1 of the run table in LDS (train launches, leader-side classes:
                                   * fetched with the hot row; run k at position k ^ peers_swz), or null */
-  ulonglong2 *rpc_stash;         /* train launches, leader-side classes of groups of <= 5 members: the message's rpc records
-                                  * (<= 4) wait HERE -- 32 bytes each in the lane's own hot row in LDS, dead once the row is
-                                  * in registers -- until the wavefront has published (emit_rpc, rgb_tick_slice), or null */
+  ulonglong2 *rpc_stash;         /* train launches, leader-side classes: the message's first four rpc records wait HERE
+                                  * -- 32 bytes each in the lane's own hot row in LDS, dead once the row is in registers --
+                                  * until the wavefront has published (emit_rpc, rgb_tick_slice), or null */
   u32 max_runs;
   /* effects */
   u32 flags;
@@ -3038,11 +3038,12 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
 #ifdef RGB_PROFILE
   if (!TR) tlp = tl;
 #endif
-  /* deferred rpc records (emit_rpc): a train's leader-side wavefronts of groups of <= 5 members (<= 4 records per
-   * message) park them in the lane's own hot row -- read into registers before anything is parked -- and store them
-   * behind the publish; what a record takes from the server, its current term, is read HERE (a leader that emits
-   * records does not change its term in the same message) */
-  const bool STASH = TR && RGB_X_RPC_DEFER && PEERS_LDS && lead_cls && rpcs != nullptr && N <= 5;
+  /* deferred rpc records (emit_rpc): a train's leader-side wavefronts (32-message slices: the hot rows lie at the
+   * front of the staging area whatever the group size) park the first four records of a message in the lane's own hot
+   * row -- read into registers before anything is parked -- and store them behind the publish; a fifth and sixth
+   * record (groups of six and more members) are stored where they are made.  What a record takes from the server, its
+   * current term, is read HERE (a leader that emits records does not change its term in the same message) */
+  const bool STASH = TR && RGB_X_RPC_DEFER && (PEERS_LDS || PEERS_WIDE) && lead_cls && rpcs != nullptr;
   ulonglong2 *stash = STASH ? io + lane * 8 : nullptr;
   u64 ct0 = 0;
   if (STASH) ct0 = hrow[HOT_P_TERM ^ hswz].x;
