@@ -1,11 +1,13 @@
 #!/bin/bash
-# literal config 5 (65 536 x 7, repair) on every ra_amd/csrc/variants/c5_*.so (ONLY_N=7 builds), interleaved, oracle-checked
+# one literal configuration of bench.py (tools/cfg5_probe.py: oracle-checked, then timed as per-tick launches and as ONE
+# train) on every ra_amd/csrc/variants/PREFIX*.so, interleaved, three times:
+#   gpurun -- 'bash tools/ab_literal.sh TAG PREFIX CONFIG'      (config 5 needs ONLY_N=7 builds, configs 2 / 3 N = 5)
 set -u
-R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; OUT=$R/gpurun_out/${1:-r06c5}; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; OUT=$R/gpurun_out/${1:-r06lit}; PRE=${2:-c5_}; CFG=${3:-5}; mkdir -p $OUT
 for rep in 1 2 3; do
-  for v in ra_amd/csrc/variants/c5_*.so; do
+  for v in ra_amd/csrc/variants/${PRE}*.so; do
     n=$(basename $v .so)
-    RGB_LIB=$R/$v timeout 300 python tools/cfg5_probe.py 5 32 2> $OUT/${n}_$rep.err | tail -1 > $OUT/${n}_$rep.json
+    RGB_LIB=$R/$v timeout 300 python tools/cfg5_probe.py $CFG 32 2> $OUT/${n}_$rep.err | tail -1 > $OUT/${n}_$rep.json
     python - $OUT/${n}_$rep.json ${n}_$rep <<'PY' | tee -a $OUT/summary.txt
 import json, sys
 try:
