@@ -1350,7 +1350,16 @@ void rgb_train_plan_destroy(rgb_train_plan *plan) {
   delete plan;
 }
 
-uint32_t rgb_train_plan_blocks_per_tick(const rgb_train_plan *plan) { return plan ? plan->bpt : 0; }
+uint32_t rgb_train_plan_blocks_per_tick(const rgb_train_plan *plan) {
+  if (!plan) return 0;
+  if (plan->on_device && !plan->rows_fit.empty()) {
+    /* a device-built plan whose ticks the host has all been told (rgb_train_plan_fit): its longest tick, not the bound */
+    u32 mx = 0;
+    for (u32 r : plan->rows_fit) { if (r == 0xFFFFFFFFu) return plan->bpt; if (r > mx) mx = r; }
+    if (mx * RGB_TRAIN_SHARDS <= plan->bpt) return (mx ? mx : 1u) * RGB_TRAIN_SHARDS;
+  }
+  return plan->bpt;
+}
 
 int rgb_train_stamp_device(rgb_ctx *ctx, const void *d_msgs, void *d_stamps, uint32_t tick_stride,
                            const uint32_t *tick_counts, uint32_t n_ticks, void *stream) {

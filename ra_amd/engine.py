@@ -594,6 +594,7 @@ class TrainPlan:
         """Tell the host the rows of the built ticks (rgb_train_plan_fit: 4 bytes per tick come back; synchronises):
         launches over them take a grid of their rows instead of the rows bound."""
         self.eng._check(self.eng._L.rgb_train_plan_fit(self.eng._h, self.h, first_tick, n_ticks, stream or None), "rgb_train_plan_fit")
+        self.blocks_per_tick = int(self.eng._L.rgb_train_plan_blocks_per_tick(self.h))
 
     def close(self):
         if self.h:
