@@ -18,6 +18,7 @@ struct rgb_comm {
   rgb_ctx *ctx;
   uint32_t n_ranks, rank;
   unsigned char id[RGB_COMM_ID_BYTES];
+  int aborted;                       /* rgb_comm_abort: the product's ncclCommAbort leaves the communicator unusable */
 };
 
 extern "C" {
@@ -47,10 +48,11 @@ uint32_t rgb_comm_rank(const rgb_comm *comm) { return comm ? comm->rank : 0; }
 static const char *g_text = "";
 const char *rgb_comm_last_error(void) { return g_text; }
 void rgb_comm_set_error_text(const char *why) { g_text = why ? why : ""; }
-int rgb_comm_abort(rgb_comm *comm, const char *why) { (void)comm; g_text = why ? why : ""; return RGB_E_COMM; }
+int rgb_comm_abort(rgb_comm *comm, const char *why) { if (comm) comm->aborted = 1; g_text = why ? why : ""; return RGB_E_COMM; }
 int rgb_comm_allgather_bytes(rgb_comm *comm, const void *d_local, uint64_t bytes, void *d_all, void *stream) {
   (void)stream;
   if (!comm || !d_local || !d_all) return RGB_E_INVAL;
+  if (comm->aborted) { g_text = "the communicator was aborted"; return RGB_E_COMM; }
   if (comm->n_ranks == 1) { if (d_all != d_local) memmove(d_all, d_local, bytes); return RGB_OK; }
   if (!g_transport) return RGB_E_UNSUPPORTED;
   return g_transport(d_local, bytes, d_all, comm->n_ranks, comm->rank) ? RGB_E_COMM : RGB_OK;

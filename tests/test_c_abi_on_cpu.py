@@ -81,3 +81,34 @@ def test_closed_loop_stream_through_the_c_abi(emulated_engine, oracle_lib):
     # the GPU test builds its own engine from ra_amd.engine, which is bound to the emulated library here
     CS.test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, 5, 14, True)
     CS.test_gpu_gives_identical_decisions_on_closed_loop_streams(oracle_lib, 5, 15, "wal_down")   # WAL outages: both conditions
+
+
+def test_leaderboard_allgather_host_gives_up_on_a_missing_rank(emulated_engine, monkeypatch):
+    """rgb_leaderboard_allgather_host (what the NIF hands out as a binary) when a rank never arrives: the call returns
+    RGB_E_COMM with the reason, the communicator is left aborted (the next call says so), and the caller's buffer is
+    untouched -- the copy-outs land in pinned memory owned by the context and reach the caller only behind a successful
+    wait (round-5 advisor finding).  On the CPU build the wait's time-out is played by RGB_EMU_LB_TIMEOUT; the real
+    RCCL form needs two GPUs."""
+    import ctypes as C
+    engine = emulated_engine
+    G, N = 24, 3
+    eng = engine.RaGpuBatch(G, N, max_runs=8, ring_slots=1, ring_capacity=64)
+    L = engine.lib()
+    L.rgb_leaderboard_allgather_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    comm = engine.Comm(eng, engine.comm_unique_id(), 1, 0)
+    rows = np.zeros(G, dtype=abi.LEADERBOARD_DTYPE)
+    assert L.rgb_leaderboard_allgather_host(eng._h, comm.h, G, rows.ctypes.data) == 0          # the healthy path, one rank
+    want = eng.snapshot()
+    assert rows.tobytes() == want.tobytes()
+    sentinel = np.full(G * abi.LEADERBOARD_DTYPE.itemsize, 0xA5, dtype=np.uint8)
+    monkeypatch.setenv("RGB_EMU_LB_TIMEOUT", "1")
+    rc = L.rgb_leaderboard_allgather_host(eng._h, comm.h, G, sentinel.ctypes.data)
+    assert rc == abi.E_COMM, rc
+    assert b"did not arrive" in L.rgb_comm_last_error() or b"timed out" in L.rgb_comm_last_error()
+    assert (sentinel == 0xA5).all(), "a timed-out all-gather wrote into the caller's buffer"
+    monkeypatch.delenv("RGB_EMU_LB_TIMEOUT")
+    rc = L.rgb_leaderboard_allgather_host(eng._h, comm.h, G, sentinel.ctypes.data)
+    assert rc == abi.E_COMM and b"aborted" in L.rgb_comm_last_error()
+    assert (sentinel == 0xA5).all()
+    comm.close()
+    eng.close()
