@@ -3091,6 +3091,9 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
     if (!TR && RGB_KNOB(dev, 16u)) { t2 = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2b = wall_clock64(); }
 #endif
   }
+  /* records parked by THIS message's clause code (the fused event below stores its own records directly and replaces
+   * the decision's count: what is flushed behind the publish is what was parked, not what the merged decision says) */
+  const unsigned n_parked = (STASH && active) ? (unsigned)((d.w[0] >> 48) & 0xFFull) : 0u;
   if (dev.fuse_pipeline && (cls == 1 || cls == 2)) {     /* opt-in: the pipeline_rpcs event behind the decision */
     const bool want = active && fuse_wanted(dev, d);
     if (__ballot(want) != 0ull && want) fuse_pipeline_step<N, TR>(dev, d, base + lane, rpcs, rpc_slot_base, msg_index_base);
@@ -3144,7 +3147,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   }
   if (STASH) {
     /* the parked rpc records, behind the publish (fire and forget, like the decisions below) */
-    const unsigned n_rp = active ? (unsigned)((d.w[0] >> 48) & 0xFFull) : 0u;
+    const unsigned n_rp = n_parked;
     if (__ballot(n_rp != 0u) != 0ull) {
       rgb_rpc *slot0 = rpcs + (size_t)(rpc_slot_base + base + lane) * (N > 1 ? N - 1 : 1);
       const u64 w0 = (u64)(msg_index_base + base + lane) | ((d.w[0] & 0xFFFFFFFFull) << 32);

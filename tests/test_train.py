@@ -38,10 +38,10 @@ class Buf:
             torch.cuda.synchronize()
 
 
-def _generate(engine, G, N, T, seed, on_gpu, max_runs=16, age=0):
+def _generate(engine, G, N, T, seed, on_gpu, max_runs=16, age=0, flags=0):
     """T generator ticks applied one by one with the per-tick class kernel.  Returns everything a train needs."""
     S = G * N
-    eng = engine.RaGpuBatch(G, N, max_runs=max_runs, ring_slots=1, ring_capacity=64)
+    eng = engine.RaGpuBatch(G, N, max_runs=max_runs, ring_slots=1, ring_capacity=64, flags=flags)
     st0 = W.initial_states(G, N, seed)
     eng.set_state(0, st0)
     tb = S * 64
@@ -74,8 +74,8 @@ def _tick(buf, t, tb, n, dtype):
     return abi.expand_decisions(a) if dtype is abi.DECISION_DTYPE else a      # device streams hold compact records
 
 
-def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_gpu, chunks=(None,), age=0):
-    r = _generate(engine, G, N, T, seed, on_gpu, age=age)
+def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_gpu, chunks=(None,), age=0, flags=0):
+    r = _generate(engine, G, N, T, seed, on_gpu, age=age, flags=flags)
     eng, S, tb, rs = r["eng"], r["S"], r["tb"], r["rs"]
     want_dec = [_tick(r["dec"], t, tb, int(r["counts"][t]), abi.DECISION_DTYPE) for t in range(T)]
     want_rpc = r["rpcs"].host()[:T * rs].copy()
@@ -199,6 +199,15 @@ def check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, on_g
 @pytest.mark.parametrize("G,N,T,seed", [(192, 5, 20, 0x5EED0003), (96, 3, 12, 7), (64, 7, 10, 11), (72, 6, 8, 13), (80, 8, 8, 17)])
 def test_train_on_the_block_emulation(emulated_engine, oracle_lib, G, N, T, seed):
     check_train_equals_per_tick_launches(emulated_engine, oracle_lib, G, N, T, seed, False, chunks=(None, 3))
+
+
+@pytest.mark.parametrize("G,N,T,seed", [(160, 5, 12, 21), (64, 7, 8, 23)])
+def test_fused_pipelining_inside_a_train_on_the_block_emulation(emulated_engine, G, N, T, seed):
+    """RGB_CFG_FUSE_PIPELINE inside train launches: a fused event stores its rpc records itself while the message's own
+    records wait in LDS for the publish (emit_rpc) -- the train's decisions, rpc records and state must be those of the
+    per-tick launches of the same (fused) engine.  (The checker does not fuse: no oracle leg here; the fused semantics
+    themselves are tests/test_fused_pipeline.py.)"""
+    check_train_equals_per_tick_launches(emulated_engine, None, G, N, T, seed, False, chunks=(None, 3), flags=abi.CFG_FUSE_PIPELINE)
 
 
 def test_train_with_a_wrong_stamp_fails_in_bounded_time(emulated_engine):
@@ -490,3 +499,11 @@ def test_train_on_the_gpu(oracle_lib, G, N, T, seed, age):
     """Real races: thousands of wavefronts of neighbouring ticks in flight together, every decision compared."""
     from ra_amd import engine
     check_train_equals_per_tick_launches(engine, oracle_lib, G, N, T, seed, True, chunks=(None, 16, 5), age=age)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,N,T,seed,age", [(4096, 5, 24, 0x5EED0003, 32), (2048, 7, 12, 29, 16)])
+def test_fused_pipelining_inside_a_train_on_the_gpu(G, N, T, seed, age):
+    """RGB_CFG_FUSE_PIPELINE inside train launches on the device (see the emulation test of the same name)."""
+    from ra_amd import engine
+    check_train_equals_per_tick_launches(engine, None, G, N, T, seed, True, chunks=(None, 5), age=age, flags=abi.CFG_FUSE_PIPELINE)
