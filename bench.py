@@ -53,7 +53,7 @@ LITERAL = {
 }
 
 
-def run_literal(name, ticks, torch, engine, W, abi, dev, local_rank, reps=3):
+def run_literal(name, ticks, torch, engine, W, abi, dev, local_rank, reps=3, on_train=None):
     """One literal SURVEY 8(d) configuration: the host generator (ra_amd/workload.gen_tick) produces tick t from
     the CHECKER's state after tick t-1 (the oracle is the state evolver here and nothing else), the stored ticks
     are applied on the device once untimed with EVERY decision and the final state compared with the oracle's,
@@ -178,6 +178,8 @@ def run_literal(name, ticks, torch, engine, W, abi, dev, local_rank, reps=3):
                     ms = e0.elapsed_time(e1)
                     best_t = ms if best_t is None else min(best_t, ms)
             train = {"us_per_tick": best_t * 1e3 / ticks, "blocks_per_tick": plan.blocks_per_tick}
+            if on_train is not None:                      # tools/cfg5_probe.py: the last train launch's per-wavefront stamps
+                on_train(eng, ticks, plan.blocks_per_tick)
             plan.close()
     finally:
         eng.close()

@@ -1151,21 +1151,28 @@ __device__ __forceinline__ bool log_snapshot_written(Lane &L, u64 idx, u64 term)
  * descending order statistic nth = n/2+1 by rank counting (branch-free, no memory) */
 template <int N>
 __device__ __forceinline__ u64 agreed_commit(const u64 (&v)[N], const bool (&use)[N], int n) {
-  const int nth = n / 2 + 1;
-  u64 res = UNDEF;
+  /* the (n / 2 + 1)-th largest of the n used values.  Round 6: a SORT of the N candidates -- the unused ones as zeros,
+   * which sort behind every used value or tie with used zeros -- by an odd-even transposition network, N (N - 1) / 2
+   * compare-exchanges = as many 64-bit compares, then the pick of position n / 2; rounds 1-5 counted ranks (for every
+   * value how many are greater / not smaller: 2 N^2 64-bit compares, 72 of the 110 in the reply fast path of groups of
+   * five, the longest of the three bulk fast paths).  Same order statistic, value by value. */
+  if (n <= 0) return UNDEF;
+  u64 a[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    if (!use[i]) continue;
-    int greater = 0, geq = 0;
+  for (int i = 0; i < N; ++i) a[i] = use[i] ? v[i] : 0ull;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      if (!use[j]) continue;
-      greater += v[j] > v[i];
-      geq += v[j] >= v[i];
+  for (int r = 0; r < N; ++r) {
+#pragma unroll
+    for (int i = r & 1; i + 1 < N; i += 2) {
+      const bool sw = a[i + 1] > a[i];                    /* descending */
+      const u64 hi = sw ? a[i + 1] : a[i], lo = sw ? a[i] : a[i + 1];
+      a[i] = hi; a[i + 1] = lo;
     }
-    /* v[i] is the nth largest iff greater < nth <= geq */
-    if (greater < nth && nth <= geq) res = v[i];
   }
+  const int k = n / 2;                                    /* position of the (n / 2 + 1)-th largest */
+  u64 res = a[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) res = (k == i) ? a[i] : res;
   return res;
 }
 
@@ -2513,7 +2520,12 @@ __device__ __forceinline__ bool fast_written(const rgb_dev &dev, const ulonglong
 /* leader, {Peer, #append_entries_reply{success = true}} of the current term from a member: match / next index of the
  * peer, evaluate_quorum/2, apply (src/ra_server.erl:532-571, 3633-3688); the term of the agreed index must be
  * answerable from the two newest runs (else the general path probes the run table) */
-template <int N, bool TR = false>
+/* PROW: the caller has the peers row in LDS for every lane (prow is not null): the path from memory is not compiled.
+ * Round 6: the preconditions are ONE predicate and one branch (eight early returns before: eight exec-mask regions in
+ * front of the work), the quorum is a sort (agreed_commit): 762 -> ~450 static instructions, 110 -> ~50 64-bit compares
+ * in the train kernel of groups of five -- the reply wavefronts are a quarter of a closed-loop tick's wave-time and
+ * four fifths of the literal config 3's, and their clause code is arithmetic. */
+template <int N, bool TR = false, bool PROW = false>
 __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglong2 m0, const ulonglong2 m1,
                                                const ulonglong2 *pre, unsigned swz, Dec &out,
                                                const ulonglong2 *prow = nullptr,
@@ -2521,23 +2533,33 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   const u32 server = (u32)(m0.x & 0xFFFFFFFFull);
   const unsigned wire_kind = (unsigned)((m0.x >> 32) & 0xFF), peer = (unsigned)((m0.x >> 40) & 0xFF);
   const unsigned mflags = (unsigned)((m0.x >> 48) & 0xFF);
-  if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || peer >= (unsigned)N) FP_DECLINE(1, 1);
-  if (mflags != RGB_MF_SUCCESS) FP_DECLINE(1, 2);                    /* a failed reply */
-  if (dev.fuse_pipeline) FP_DECLINE(1, 9);                           /* opt-in fused pipelining: the general path emits the rpcs */
   const ulonglong2 h0 = pre[HOT_P_TERM ^ swz], h1 = pre[HOT_P_CI ^ swz], h2 = pre[HOT_P_LI ^ swz], h3 = pre[HOT_P_LW ^ swz],
                    h4 = pre[HOT_P_SI ^ swz], h5 = pre[HOT_P_FIRST ^ swz], h6 = pre[HOT_P_LRT ^ swz], h7 = pre[HOT_P_PEND ^ swz];
   const u64 ct = h0.x, pk = h0.y, ci0 = h1.x, la = h1.y, li = h2.x, lwi = h3.x, si = h4.x, st = h4.y, first = h5.x,
             lrs = h5.y, lrt = h6.x, prs = h6.y, prt = h7.x;
   const unsigned present = (unsigned)pk_get(pk, PK_PRESENT_SH, 8), voters = (unsigned)pk_get(pk, PK_VOTER_SH, 8);
   const unsigned self = (unsigned)pk_get(pk, PK_SELF_SH, 4), n_runs = (unsigned)pk_get(pk, PK_NRUNS_SH, 5);
+#if defined(RGB_X_DECLINE_HIST) && !defined(RGB_HOST_EMULATION)
+  if (wire_kind != RGB_MSG_AER_REPLY || server >= dev.n_servers || peer >= (unsigned)N) FP_DECLINE(1, 1);
+  if (mflags != RGB_MF_SUCCESS) FP_DECLINE(1, 2);                    /* a failed reply */
+  if (dev.fuse_pipeline) FP_DECLINE(1, 9);                           /* opt-in fused pipelining: the general path emits the rpcs */
   if (pk_get(pk, PK_ROLE_SH, 3) != RGB_ROLE_LEADER) FP_DECLINE(1, 3);
   if (m0.y != ct) FP_DECLINE(1, 4);
   if (!((present >> peer) & 1u)) FP_DECLINE(1, 5);
   if (n_runs < 2 && (h6.y | h7.x) != 0) FP_DECLINE(1, 6);
+#else
+  /* the message is a success reply (not fused: the general path emits the rpcs then) from a member, to a leader, in
+   * its current term; a row the commit would not have to canonicalise */
+  const bool ok = (wire_kind == RGB_MSG_AER_REPLY) & (server < dev.n_servers) & (peer < (unsigned)N) &
+                  (mflags == RGB_MF_SUCCESS) & (dev.fuse_pipeline == 0u) &
+                  (pk_get(pk, PK_ROLE_SH, 3) == RGB_ROLE_LEADER) & (m0.y == ct) & (((present >> (peer & 7u)) & 1u) != 0u) &
+                  !((n_runs < 2) & ((h6.y | h7.x) != 0));
+  if (!ok) return false;
+#endif
   u64 *peers = dev.peers + (size_t)server * dev.peer_stride;
   /* piece i of the peers row = (match_index, next_index) of member i */
   u64 wm[N], wn[N];
-  if (prow != nullptr) {
+  if (PROW || prow != nullptr) {
     const unsigned psw = rgb_wide_peers((unsigned)N) ? swz << 1 : swz;      /* (wide rows: 256 bytes of LDS each) */
 #pragma unroll
     for (int k = 0; k < N; ++k) { const ulonglong2 v = prow[(unsigned)k ^ psw]; wm[k] = v.x; wn[k] = v.y; }
@@ -2548,15 +2570,25 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   }
   /* match_index / next_index of the peer only move forward (:540-547) */
   u64 mi_new = 0, ni_new = 0; bool mi_dirty = false, ni_dirty = false;
+  if (PROW) {
+    /* the peer's own piece once more, by its (per-lane) position: two 64-bit compares instead of N predicated pairs */
+    const unsigned psw = rgb_wide_peers((unsigned)N) ? swz << 1 : swz;
+    const ulonglong2 pv = prow[peer ^ psw];
+    mi_dirty = m1.y > pv.x; ni_dirty = m1.x > pv.y;
+    mi_new = mi_dirty ? m1.y : pv.x; ni_new = ni_dirty ? m1.x : pv.y;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    if ((unsigned)i != peer) continue;
-    mi_new = wm[i]; ni_new = wn[i];
-    if (m1.y > wm[i]) { mi_new = m1.y; mi_dirty = true; wm[i] = m1.y; }
-    if (m1.x > wn[i]) { ni_new = m1.x; ni_dirty = true; }
+    for (int i = 0; i < N; ++i) wm[i] = ((unsigned)i == peer) ? mi_new : wm[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if ((unsigned)i != peer) continue;
+      mi_new = wm[i]; ni_new = wn[i];
+      if (m1.y > wm[i]) { mi_new = m1.y; mi_dirty = true; wm[i] = m1.y; }
+      if (m1.x > wn[i]) { ni_new = m1.x; ni_dirty = true; }
+    }
   }
   /* agreed_commit/1 over the voters' match indexes and the leader's last written index: descending order statistic
-   * n/2 + 1 by rank counting */
+   * n/2 + 1 */
   u64 v[N + 1]; bool use[N + 1]; int n = 1;
   v[N] = lwi; use[N] = true;
 #pragma unroll
@@ -2603,10 +2635,9 @@ __device__ __forceinline__ bool fast_aer_reply(const rgb_dev &dev, const ulonglo
   if (t != UNDEF && t == ct) ci = p;                                 /* Raft 5.4.2; NO max() */
   if (ci > ci0) flags |= RGB_F_AUX_EVAL;
   if (ci > la) { const u64 to = li < ci ? li : ci; if (to >= la + 1) { nla = to; flags |= RGB_F_APPLIED; } }
-  /* the two words are one 16-byte piece of the row */
-  if (mi_dirty && ni_dirty) ST16(reinterpret_cast<ulonglong2 *>(peers) + peer, make_ulonglong2(mi_new, ni_new));
-  else if (mi_dirty) ST8(peers + PEER_MI(peer, N), mi_new);
-  else if (ni_dirty) ST8(peers + PEER_NI(peer, N), ni_new);
+  /* the two words are one 16-byte piece of the row: stored whole when either moved (the other keeps its value; a 16-byte
+   * and an 8-byte store cost the fabric the same 32-byte write) */
+  if (mi_dirty | ni_dirty) ST16(reinterpret_cast<ulonglong2 *>(peers) + peer, make_ulonglong2(mi_new, ni_new));
   if (ci != ci0 || nla != la)
     ST16(reinterpret_cast<ulonglong2 *>(dev.hot + (size_t)server * RGB_HOT_WORDS) + HOT_P_CI, make_ulonglong2(ci, nla));
   make_decision(out, server, RGB_ROLE_LEADER, RGB_NONE, 0, RGB_MSG_AER_REPLY, flags, 0, 0, 0, 0, 0, ci, nla);
@@ -3057,7 +3088,7 @@ __device__ __forceinline__ bool rgb_tick_slice(const rgb_dev &dev, ulonglong2 *i
   pst.p = nullptr; pst.a = pst.b = make_ulonglong2(0, 0); pst.m = 0;
   if (active) {
     if (cls == 0) done = fast_aer(dev, m0, m1, m2, m3, hrow, hswz, d, &pst);
-    else if (cls == 1) done = fast_aer_reply<N, TR>(dev, m0, m1, hrow, hswz, d, prow, rrow);
+    else if (cls == 1) done = fast_aer_reply<N, TR, (PEERS_LDS || PEERS_WIDE)>(dev, m0, m1, hrow, hswz, d, prow, rrow);
     else if (cls == 2) done = fast_written(dev, m0, m1, hrow, hswz, d, &pst);
   }
   if (RGB_X_PAIR_STORE && (cls == 0 || cls == 2)) pair_store(pst, lane);       /* (wave-uniform) */

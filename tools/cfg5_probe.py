@@ -11,6 +11,11 @@ name = sys.argv[1] if len(sys.argv) > 1 else "5"
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 torch.cuda.set_device(0)
 torch.cuda.set_stream(torch.cuda.Stream(device=0))      # (the graphs of run_literal are captured on the current stream)
-r = bench.run_literal(name, ticks, torch, engine, W, abi, torch.device("cuda", 0), 0)
+cb = None
+if os.environ.get("RGB_LITERAL_TIMELINE"):        # RGB_LIB = a -DRGB_X_TRAIN_TIMELINE build: where the train's wavefronts spend their lives
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import timeline_stats
+    cb = timeline_stats.report
+r = bench.run_literal(name, ticks, torch, engine, W, abi, torch.device("cuda", 0), 0, on_train=cb)
 print(json.dumps({k: r[k] for k in ("us_per_tick", "frac", "value", "launch", "final_state_equal", "oracle_checked_decisions",
                                     "per_tick_launches", "train_launch")}))
