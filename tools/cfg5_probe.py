@@ -16,6 +16,18 @@ if os.environ.get("RGB_LITERAL_TIMELINE"):        # RGB_LIB = a -DRGB_X_TRAIN_TI
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import timeline_stats
     cb = timeline_stats.report
+if os.environ.get("RGB_LITERAL_HIST"):            # RGB_LIB = a -DRGB_X_DECLINE_HIST build: why lanes decline the three bulk fast paths
+    def cb(eng, ticks_, bpt):                     # (counters of every launch of this engine so far: per-tick passes and trains)
+        import ctypes as C
+        import numpy as np
+        L = engine.lib(); L.rgb_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        buf = np.zeros(128, dtype=np.uint64)
+        assert L.rgb_debug_read(eng._h, buf.ctypes.data, 128) == 0
+        for c, nm in ((0, "append_entries_rpc"), (1, "append_entries_reply"), (2, "written")):
+            row = buf[c * 32:(c + 1) * 32].astype(np.int64); tot = int(row.sum())
+            if tot:
+                print(f"class {c} {nm}: {tot} lanes reached the fast path, taken {row[0] / tot:.3f}; declines by reason:",
+                      {k: round(int(row[k]) / tot, 4) for k in range(1, 32) if row[k]})
 r = bench.run_literal(name, ticks, torch, engine, W, abi, torch.device("cuda", 0), 0, on_train=cb)
 print(json.dumps({k: r[k] for k in ("us_per_tick", "frac", "value", "launch", "final_state_equal", "oracle_checked_decisions",
                                     "per_tick_launches", "train_launch")}))
