@@ -3,9 +3,9 @@
 # in the driver's form and in the long form, interleaved and repeated so that a box's drift shows; every decision of
 # the timed replay is compared with the per-tick launches of the generation pass (bench.py), except for variants whose
 # name starts with x_ (timing probes that break parity).
-#   gpurun -- 'bash tools/ab_variants.sh TAG [reps]'
+#   gpurun -- 'bash tools/ab_variants.sh TAG [reps] [PREFIX]'      (PREFIX: only variants/PREFIX*.so)
 set -u
-R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; TAG=${1:-r06ab}; REPS=${2:-2}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; TAG=${1:-r06ab}; REPS=${2:-2}; PRE=${3:-}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 V=$R/ra_amd/csrc/variants
 t0=$(date +%s); stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" | tee -a $OUT/summary.txt; }
 Q="--no-cpu-baseline --no-host-path --literal-ticks 0 --members 5"
@@ -25,7 +25,7 @@ PY
 L="--steps 192 --warmup 16"
 D="--steps 20 --warmup 5"
 for rep in $(seq 1 $REPS); do
-  for v in $V/*.so; do n=$(basename $v .so); one ${n}_drv_$rep $n $D; done
-  for v in $V/*.so; do n=$(basename $v .so); one ${n}_long_$rep $n $L; done
+  for v in $V/${PRE}*.so; do n=$(basename $v .so); one ${n}_drv_$rep $n $D; done
+  for v in $V/${PRE}*.so; do n=$(basename $v .so); one ${n}_long_$rep $n $L; done
 done
 stamp done
