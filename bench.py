@@ -804,10 +804,29 @@ def main():
             while pending:
                 eng_h.collect(out=bufs); pending -= 1
             best = max(best, nd / (time.perf_counter() - t0))
+        # the same with rgb_collect_view / rgb_release (ABI v9): the consumer reads decisions and rpc records where the
+        # device wrote them (the pinned slot), nothing is copied out
+        best_v = 0.0
+        for rep in range(3):
+            eng_h.set_state(0, st_aged)
+            pending, nd = 0, 0
+            t0 = time.perf_counter()
+            for m in first_ticks[:12]:
+                for i in range(0, len(m), BATCH):
+                    while pending >= 3:
+                        eng_h.release(eng_h.collect_view()[3]); pending -= 1
+                    eng_h.submit(m[i:i + BATCH]); pending += 1; nd += len(m[i:i + BATCH])
+            while pending:
+                eng_h.release(eng_h.collect_view()[3]); pending -= 1
+            best_v = max(best_v, nd / (time.perf_counter() - t0))
         eng_h.close()
         host_path = {"value": best, "unit": "decisions/s", "batch": BATCH,
-                     "note": "first 12 ticks through rgb_submit/rgb_collect (ctypes caller, pinned ring, "
-                             "PCIe both ways, 64-B message in / 64-B decision + rpc records out), best of 3"}
+                     "note": "first 12 ticks through rgb_submit/rgb_collect from ONE thread (ctypes caller, pinned ring, "
+                             "PCIe both ways, 64-B message in / 64-B decision + compacted rpc records out, both written "
+                             "into the pinned slot by the device), best of 3",
+                     "collect_view": {"value": best_v, "unit": "decisions/s",
+                                      "note": "the same from one thread with rgb_collect_view + rgb_release: results read in "
+                                              "place, no copy out of the slot"}}
         # four producer threads and two consumer threads on one context (the boundary's threading contract: producers
         # prepare their batches in parallel, the stream's work is enqueued in ticket order, consumers copy different
         # batches at once).  The batches of the first 12 ticks are dealt round robin to the producers, so the order
@@ -922,6 +941,13 @@ def main():
                     bd[0].append(t1 - t0); bd[1].append(t2 - t1); bd[2].append(t3 - t2)
                 lat[label]["breakdown_us_p50"] = {k: round(sorted(v)[len(v) // 2] * 1e6, 1)
                                                   for k, v in zip(("rgb_submit", "device_behind_submit", "rgb_collect"), bd)}
+                tv = []
+                for _ in range(200):
+                    t0 = time.perf_counter()
+                    eng_s.submit(small); eng_s.release(eng_s.collect_view()[3])
+                    tv.append(time.perf_counter() - t0)
+                tv.sort()
+                lat[label]["collect_view_round_trip_us_p50"] = round(tv[len(tv) // 2] * 1e6, 1)
                 if label == "fused_train" and hasattr(eng_s, "inject_train_fault"):
                     # what a FAILED train launch costs (asked for in rounds 4 and 5): the next batch's launch is made to
                     # fail (two messages bucketed under each other's shard: the order check of every wavefront);

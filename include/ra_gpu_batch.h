@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGB_ABI_VERSION   8u
+#define RGB_ABI_VERSION   9u
 #define RGB_UNDEF         UINT64_MAX   /* Erlang 'undefined' (index or term)            */
 #define RGB_NONE          0xFFu        /* undefined ra_server_id() (member slot)        */
 #define RGB_MAX_MEMBERS   8u           /* members per Raft group held on the device     */
@@ -454,7 +454,8 @@ int  rgb_upload_state(rgb_ctx *ctx, uint32_t first, uint32_t n, const rgb_server
 int  rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_state *out);
 
 /* Asynchronous host path: copy n messages into the pinned staging ring, enqueue
- * H2D + transition kernel(s) + D2H on the context's stream and return.  Messages for the same
+ * H2D + transition kernel(s) + the results kernels (which write decisions and rpc records into the slot's pinned host
+ * buffers: no D2H copy command) on the context's stream and return.  Messages for the same
  * server are applied in submission order (serialised over sub-ticks); messages for different
  * servers are applied in parallel.  rgb_collect waits for the OLDEST submitted batch. */
 int  rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick);
@@ -468,6 +469,23 @@ int  rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick
 int  rgb_set_seq_ranges_device(rgb_ctx *ctx, const void *d_ranges, uint32_t n_ranges);
 int  rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out,
                  rgb_rpc *rpc_out, uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out);
+/* rgb_collect without the copy (ABI v9).  A batch's results are WRITTEN BY THE DEVICE into the slot's pinned host
+ * buffers in exactly the form rgb_collect hands out -- full decisions in submission order, the rpc records compacted
+ * and ordered by (msg_index, peer) -- so a consumer that can read them where they lie (a NIF that wraps them in
+ * resource binaries, a C caller that walks them once) takes the oldest batch as a VIEW: pointers into the slot, valid
+ * until rgb_release(ctx, view.slot).  A held slot is not free: rgb_submit returns RGB_E_FULL when the ring comes round
+ * to it.  Same errors and the same threading contract as rgb_collect (each batch is handed out exactly once). */
+typedef struct rgb_view {
+  const rgb_decision *decisions;   /* n records, submission order */
+  const rgb_rpc *rpcs;             /* n_rpcs records, ordered by (msg_index, peer) */
+  uint64_t tick;
+  uint32_t n;
+  uint32_t n_rpcs;
+  uint32_t slot;                   /* for rgb_release */
+  uint32_t _pad;
+} rgb_view;
+int  rgb_collect_view(rgb_ctx *ctx, rgb_view *view);
+int  rgb_release(rgb_ctx *ctx, uint32_t slot);
 /* Threading (the interception point is per gen_statem, reference src/ra_server_proc.erl:1356-1397, so many
  * scheduler threads reach the boundary at once).
  * rgb_submit may be called from any number of threads.  Callers prepare their batches IN PARALLEL (validation, the

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 CFG_ROUNDS_PER_LAUNCH = 1      # rgb_config.flags: rgb_submit launches one kernel per sub-tick round (the default since round 5)
 CFG_SUBMIT_TRAINS = 16         # rgb_config.flags: opt-in -- rgb_submit fuses the sub-tick rounds of a batch into one train launch
 CFG_FUSE_PIPELINE = 4          # rgb_config.flags: a leader's success reply / written event carries its pipeline_rpcs event's rpcs (opt-in)
@@ -152,9 +152,12 @@ WAL_END_ZEROS, WAL_END_DATA, WAL_END_CAP = 0, 1, 2
 WAL_CLEAN, WAL_DROPPED_LAST, WAL_CORRUPT = 0, 1, 2
 WAL_FILE_HEADER = b"RAWA\x01"
 
+# rgb_view (ABI v9, rgb_collect_view): pointers into the pinned slot the device wrote
+VIEW_DTYPE = np.dtype([("decisions", "<u8"), ("rpcs", "<u8"), ("tick", "<u8"), ("n", "<u4"), ("n_rpcs", "<u4"),
+                       ("slot", "<u4"), ("_pad", "<u4")])
 STRUCT_DTYPES = [MSG_DTYPE, DECISION_DTYPE, RPC_DTYPE, SERVER_STATE_DTYPE, LEADERBOARD_DTYPE,
-                 CONFIG_DTYPE]
-EXPECTED_SIZES = [64, 64, 56, 704, 32, 32]
+                 CONFIG_DTYPE, VIEW_DTYPE]
+EXPECTED_SIZES = [64, 64, 56, 704, 32, 32, 40]
 for _dt, _sz in zip(STRUCT_DTYPES, EXPECTED_SIZES):
     assert _dt.itemsize == _sz, (_dt, _dt.itemsize, _sz)
 

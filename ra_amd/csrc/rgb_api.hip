@@ -23,8 +23,47 @@
 #include <new>
 #include <vector>
 
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
+
 #include "rgb_internal.h"
 #include "../../include/ra_gpu_batch_synth.h"
+
+/* Host copies of the staging ring.  One rgb_submit + rgb_collect moves every message twice and every decision once
+ * through the calling thread; with plain stores each destination line is first READ (read for ownership) -- a third of
+ * the thread's memory traffic, and one thread of the host path runs at the memory bandwidth of its core.  Batches too
+ * big to stay in the cache anyway are written with streaming stores (no ownership read; the device's DMA and the
+ * consumer read them from memory either way). */
+#define RGB_STREAM_COPY_MIN (1u << 20)      /* bytes: smaller batches are consumed from the cache */
+static inline void copy_msg(rgb_msg *dst, const rgb_msg *src, bool stream) {
+#if defined(__x86_64__)
+  if (stream) {                                              /* dst: a 64-byte slot of the pinned buffer (aligned) */
+    const __m128i *q = reinterpret_cast<const __m128i *>(src);
+    __m128i *d = reinterpret_cast<__m128i *>(dst);
+    const __m128i a = _mm_loadu_si128(q), b = _mm_loadu_si128(q + 1), c = _mm_loadu_si128(q + 2), e = _mm_loadu_si128(q + 3);
+    _mm_stream_si128(d, a); _mm_stream_si128(d + 1, b); _mm_stream_si128(d + 2, c); _mm_stream_si128(d + 3, e);
+    return;
+  }
+#endif
+  (void)stream;
+  *dst = *src;
+}
+static inline void copy_out(void *dst, const void *src, size_t bytes) {
+#if defined(__x86_64__)
+  if (bytes >= RGB_STREAM_COPY_MIN && ((uintptr_t)dst & 15u) == 0 && (bytes & 63u) == 0) {
+    const __m128i *q = reinterpret_cast<const __m128i *>(src);
+    __m128i *d = reinterpret_cast<__m128i *>(dst);
+    for (size_t k = 0; k < bytes / 16u; k += 4) {
+      const __m128i a = _mm_loadu_si128(q + k), b = _mm_loadu_si128(q + k + 1), c = _mm_loadu_si128(q + k + 2), e = _mm_loadu_si128(q + k + 3);
+      _mm_stream_si128(d + k, a); _mm_stream_si128(d + k + 1, b); _mm_stream_si128(d + k + 2, c); _mm_stream_si128(d + k + 3, e);
+    }
+    _mm_sfence();
+    return;
+  }
+#endif
+  memcpy(dst, src, bytes);
+}
 
 #define HIPCHK(ctx, expr)                          \
   do {                                             \
@@ -36,16 +75,15 @@
   } while (0)
 
 struct rgb_slot {
-  rgb_msg *h_msgs = nullptr;        /* pinned */
-  rgb_decision *h_dec = nullptr;    /* pinned */
-  rgb_msg *d_msgs = nullptr;
+  rgb_msg *h_msgs = nullptr;        /* pinned: the batch in device order, then h_pos -- ONE copy to the device */
+  rgb_decision *h_dec = nullptr;    /* pinned: WRITTEN BY THE DEVICE (rgb_results_kernel): full records, submission order */
+  rgb_msg *d_msgs = nullptr;        /* (capacity x (64 + 4) bytes: d_pos lies behind the batch's messages) */
   rgb_decision *d_dec = nullptr;
-  rgb_decision *d_dec_sub = nullptr;   /* the decisions in submission order (rgb_unpermute_kernel), what goes to h_dec */
-  u32 *h_pos = nullptr, *d_pos = nullptr;   /* pinned / device: device position of submitted message i */
-  rgb_rpc *d_rpcs = nullptr;
-  rgb_rpc *h_rpcs = nullptr;        /* pinned: the fixed rpc slots of device positions [rpc_lo, rpc_lo+rpc_cnt) */
-  u32 rpc_lo = 0, rpc_cnt = 0;
-  u32 *h_nrpc = nullptr, *d_nrpc = nullptr;   /* pinned / device: the batch's rpc record count (rgb_count_rpcs_kernel) */
+  u32 *h_pos = nullptr, *d_pos = nullptr;   /* = (u32 *)(h_msgs + n) / (d_msgs + n): device position of submitted message i */
+  rgb_rpc *d_rpcs = nullptr;        /* the fixed rpc slots: (N-1) per device position */
+  rgb_rpc *h_rpcs = nullptr;        /* pinned: WRITTEN BY THE DEVICE: the batch's records compacted, (message, slot) order, msg_index set */
+  u32 *h_nrpc = nullptr;            /* pinned header, written by the device: [0] records, [1] train error word, [2] over-count flag */
+  u32 *d_res = nullptr;             /* rgb_launch_results' scratch: block sums + error word */
   /* sub-tick rounds as ONE train launch: stamps, per-round plan and row table (pinned staging + device) */
   unsigned char *h_stamps = nullptr, *d_stamps = nullptr;
   rgb_train_tick *h_plan = nullptr, *d_plan = nullptr;
@@ -70,7 +108,6 @@ struct rgb_slot {
    * copied out).  Producers take slots in ring order and consumers hand them back in any order, so fullness is the
    * state of the NEXT slot, not a count. */
   std::atomic<int> state{0};
-  std::vector<u32> perm;            /* device position -> submission index */
   u32 n = 0;
   uint64_t tick = 0;
   hipEvent_t done = nullptr;
@@ -182,6 +219,7 @@ size_t rgb_struct_size(int which) {
     case 3: return sizeof(rgb_server_state);
     case 4: return sizeof(rgb_leaderboard_row);
     case 5: return sizeof(rgb_config);
+    case 6: return sizeof(rgb_view);
     default: return 0;
   }
 }
@@ -234,13 +272,10 @@ static void free_slot(rgb_slot &s) {
   if (s.h_dec) (void)hipHostFree(s.h_dec);
   if (s.d_msgs) (void)hipFree(s.d_msgs);
   if (s.d_dec) (void)hipFree(s.d_dec);
-  if (s.d_dec_sub) (void)hipFree(s.d_dec_sub);
-  if (s.h_pos) (void)hipHostFree(s.h_pos);
-  if (s.d_pos) (void)hipFree(s.d_pos);
   if (s.d_rpcs) (void)hipFree(s.d_rpcs);
   if (s.h_rpcs) (void)hipHostFree(s.h_rpcs);
   if (s.h_nrpc) (void)hipHostFree(s.h_nrpc);
-  if (s.d_nrpc) (void)hipFree(s.d_nrpc);
+  if (s.d_res) (void)hipFree(s.d_res);
   if (s.h_stamps) (void)hipHostFree(s.h_stamps);
   if (s.d_stamps) (void)hipFree(s.d_stamps);
   if (s.h_plan) (void)hipHostFree(s.h_plan);
@@ -256,10 +291,10 @@ static void free_slot(rgb_slot &s) {
   if (s.d_undo) (void)hipFree(s.d_undo);
   if (s.done) (void)hipEventDestroy(s.done);
   s.h_msgs = nullptr; s.h_dec = nullptr; s.d_msgs = nullptr; s.d_dec = nullptr; s.d_rpcs = nullptr; s.h_rpcs = nullptr;
-  s.h_nrpc = s.d_nrpc = nullptr;
+  s.h_nrpc = nullptr; s.d_res = nullptr;
   s.h_stamps = s.d_stamps = nullptr; s.h_plan = s.d_plan = nullptr; s.h_rows = s.d_rows = nullptr; s.done = nullptr;
   s.d_ctl = nullptr; s.h_touched = s.d_touched = nullptr; s.d_undo = nullptr;
-  s.d_dec_sub = nullptr; s.h_pos = s.d_pos = nullptr;
+  s.h_pos = s.d_pos = nullptr;
 }
 
 void rgb_close(rgb_ctx *ctx) {
@@ -322,18 +357,18 @@ uint32_t rgb_n_servers(const rgb_ctx *ctx) { return ctx ? ctx->dev.n_servers : 0
 
 static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   const u32 cap = ctx->cfg.ring_capacity;
-  HIPCHK(ctx, hipHostMalloc((void **)&s.h_msgs, (size_t)cap * sizeof(rgb_msg), hipHostMallocDefault));
+  /* messages + positions: one pinned block, one device block, one copy per batch (the positions of a batch of n
+   * messages lie behind its n-th message) */
+  HIPCHK(ctx, hipHostMalloc((void **)&s.h_msgs, (size_t)cap * (sizeof(rgb_msg) + sizeof(u32)), hipHostMallocDefault));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_dec, (size_t)cap * sizeof(rgb_decision), hipHostMallocDefault));
-  HIPCHK(ctx, hipMalloc((void **)&s.d_msgs, (size_t)cap * sizeof(rgb_msg)));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_msgs, (size_t)cap * (sizeof(rgb_msg) + sizeof(u32))));
   HIPCHK(ctx, hipMalloc((void **)&s.d_dec, (size_t)cap * sizeof(rgb_decision)));
-  HIPCHK(ctx, hipMalloc((void **)&s.d_dec_sub, (size_t)cap * sizeof(rgb_decision)));
-  HIPCHK(ctx, hipHostMalloc((void **)&s.h_pos, (size_t)cap * sizeof(u32), hipHostMallocDefault));
-  HIPCHK(ctx, hipMalloc((void **)&s.d_pos, (size_t)cap * sizeof(u32)));
+  s.h_pos = reinterpret_cast<u32 *>(s.h_msgs + cap); s.d_pos = reinterpret_cast<u32 *>(s.d_msgs + cap);
   HIPCHK(ctx, hipMalloc((void **)&s.d_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc)));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc), hipHostMallocDefault));
   HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_nrpc, 64, hipHostMallocDefault));
-  HIPCHK(ctx, hipMalloc((void **)&s.d_nrpc, 64));
+  HIPCHK(ctx, hipMalloc((void **)&s.d_res, ((size_t)rgb_results_blocks(cap) + 1u) * sizeof(u32)));
   /* fused sub-tick rounds (at most RGB_SUBMIT_TRAIN_ROUNDS of them per batch) */
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_stamps, cap, hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_stamps, cap));
@@ -347,7 +382,6 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   HIPCHK(ctx, hipMemsetAsync(s.d_ctl, 0, RGB_TRAIN_CTL_WORDS * sizeof(u32), ctx->stream));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_touched, (size_t)cap * sizeof(u32), hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_touched, (size_t)cap * sizeof(u32)));
-  s.perm.reserve(cap);              /* nothing allocates between taking the ticket and publishing the slot */
   return RGB_OK;
 }
 
@@ -593,23 +627,13 @@ static int enqueue_rounds(rgb_ctx *ctx, rgb_slot &s) {
   return RGB_OK;
 }
 
-/* what comes back: the rpc count, the decisions, the span of rpc slots, a train's error word; then the slot's event */
+/* what comes back, written by the device into the slot's pinned buffers (rgb_launch_results: no copy command): the
+ * decisions in submission order, the rpc records compacted, the header (records, a train's error word -- the launch's
+ * placement marks went into it: rgb_launch_train); then the slot's event */
 static int enqueue_results(rgb_ctx *ctx, rgb_slot &s) {
-  {
-    int lr = rgb_launch_count_rpcs(s.d_dec, s.n, s.d_nrpc, ctx->stream);
-    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
-  }
-  HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc, s.d_nrpc, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-  if (s.used_train)      /* (the launch's placement marks went into the error word behind it: rgb_launch_train) */
-    HIPCHK(ctx, hipMemcpyAsync(s.h_nrpc + 1, s.d_ctl, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-  {
-    int lr = rgb_launch_unpermute(s.d_dec, s.d_pos, s.n, s.d_dec_sub, ctx->stream);    /* back to submission order */
-    if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
-  }
-  HIPCHK(ctx, hipMemcpyAsync(s.h_dec, s.d_dec_sub, (size_t)s.n * sizeof(rgb_decision), hipMemcpyDeviceToHost, ctx->stream));
-  if (s.rpc_cnt)
-    HIPCHK(ctx, hipMemcpyAsync(s.h_rpcs, s.d_rpcs + (size_t)s.rpc_lo * ctx->rpc_stride,
-                               (size_t)s.rpc_cnt * ctx->rpc_stride * sizeof(rgb_rpc), hipMemcpyDeviceToHost, ctx->stream));
+  int lr = rgb_launch_results(s.d_dec, s.d_pos, s.n, s.d_rpcs, ctx->rpc_stride, s.d_res, s.used_train ? s.d_ctl : nullptr,
+                              s.h_dec, s.h_rpcs, s.h_nrpc, ctx->stream);
+  if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
   HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
   return RGB_OK;
 }
@@ -618,7 +642,7 @@ static int enqueue_results(rgb_ctx *ctx, rgb_slot &s) {
 static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max) {
   HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
   const u32 n = s.n;
-  s.h_nrpc[0] = 0; s.h_nrpc[1] = 0;
+  s.h_nrpc[0] = 0; s.h_nrpc[1] = 0; s.h_nrpc[2] = 0;
   if (!n) { HIPCHK(ctx, hipEventRecord(s.done, ctx->stream)); return RGB_OK; }
   u32 fault = 0;
   if (as_train) {
@@ -633,14 +657,16 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
           const rgb_train_tick &t0 = s.h_plan[0];
           if (t0.cnt[c][x] == 0 || t0.cnt[c][x + 1] == 0) continue;
           const u32 a = t0.msg_base + t0.off[c][x], b = t0.msg_base + t0.off[c][x + 1];
-          std::swap(s.h_msgs[a], s.h_msgs[b]); std::swap(s.h_stamps[a], s.h_stamps[b]); std::swap(s.perm[a], s.perm[b]);
-          s.h_pos[s.perm[a]] = a; s.h_pos[s.perm[b]] = b;
+          std::swap(s.h_msgs[a], s.h_msgs[b]); std::swap(s.h_stamps[a], s.h_stamps[b]);
+          for (u32 i = 0; i < n; ++i) {                       /* (the submitted messages that sit at a and b) */
+            if (s.h_pos[i] == a) s.h_pos[i] = b;
+            else if (s.h_pos[i] == b) s.h_pos[i] = a;
+          }
           done = true;
         }
     }
   }
-  HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * sizeof(rgb_msg), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(s.d_pos, s.h_pos, (size_t)n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * (sizeof(rgb_msg) + sizeof(u32)), hipMemcpyHostToDevice, ctx->stream));   /* + h_pos */
   if (s.n_ranges)
     HIPCHK(ctx, hipMemcpyAsync(s.d_ranges, s.h_ranges, (size_t)s.n_ranges * 2u * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
   /* the undo log: the rows of the touched servers as they are before this batch -- while a train is in flight
@@ -682,6 +708,37 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
   return rc;
 }
 
+/* pass 1 of rgb_submit, compiled per group size: the bucket key holds the server's shard = (server / n_members) mod 8,
+ * a division by a constant here (a multiply) instead of one by a run-time value per message; the per-thread scratch
+ * comes in as plain pointers (a thread_local std::vector is reached through its guard function at every use) */
+struct submit_scan { u32 n_rounds = 0; bool any_nop = false, too_many = false, any_seqx = false; int bad = RGB_OK; };
+extern "C++" {
+template <unsigned NM>
+static void submit_pass1(const rgb_ctx *ctx, const rgb_msg *msgs, u32 n, const uint64_t *ranges, uint32_t n_ranges,
+                         uint16_t *seen, uint16_t *key_of, u32 *round_of, std::vector<u32> &touched, submit_scan &sc) {
+  u32 n_rounds = sc.n_rounds;
+  for (u32 i = 0; i < n; ++i) {
+    const rgb_msg &m = msgs[i];
+    int bad = validate_msg(ctx, m);
+    if (!bad) bad = validate_seqx(m, ranges, n_ranges);
+    if (bad) { sc.bad = bad; break; }
+    if (m.kind == RGB_MSG_WRITTEN && (m.flags & RGB_MF_SEQX)) sc.any_seqx = true;
+    u32 r = 0;
+    if (m.kind != RGB_MSG_NOP) {
+      uint16_t &c = seen[m.server];
+      if (c == 0) touched.push_back(m.server);
+      r = c;
+      if (c == 0xFFFF) { sc.too_many = true; break; }
+      c++;
+    } else sc.any_nop = true;
+    round_of[i] = r;
+    key_of[i] = (uint16_t)rgb_bucket(m.kind, m.flags, m.kind != RGB_MSG_NOP ? m.server : 0u, NM);
+    if (r + 1 > n_rounds) n_rounds = r + 1;
+  }
+  sc.n_rounds = n_rounds;
+}
+}  // extern "C++"
+
 /* The sub-tick rounds of one batch run as ONE train launch (reference: the mailbox of a member is FIFO,
  * src/ra_server_proc.erl:1356-1397 -- a leader's N-1 replies land in one batch, so rounds > 1 are the normal shape):
  * round r = tick r of the train, every round in bucket order, the per-server sequence bytes order a server's
@@ -722,28 +779,19 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
   round_of.resize(n);
   key_of.resize(n);
   touched.clear();
-  u32 n_rounds = n ? 1 : 0;
-  bool any_nop = false, too_many = false, any_seqx = false;
-  int bad = RGB_OK;
+  if (touched.capacity() < n) touched.reserve(n);
   const unsigned n_members = ctx->dev.n_members;
-  for (u32 i = 0; i < n; ++i) {
-    const rgb_msg &m = msgs[i];
-    bad = validate_msg(ctx, m);
-    if (!bad) bad = validate_seqx(m, ranges, n_ranges);
-    if (bad) break;
-    if (m.kind == RGB_MSG_WRITTEN && (m.flags & RGB_MF_SEQX)) any_seqx = true;
-    u32 r = 0;
-    if (m.kind != RGB_MSG_NOP) {
-      uint16_t &c = seen[m.server];
-      if (c == 0) touched.push_back(m.server);
-      r = c;
-      if (c == 0xFFFF) { too_many = true; break; }
-      c++;
-    } else any_nop = true;
-    round_of[i] = r;
-    key_of[i] = (uint16_t)rgb_bucket(m.kind, m.flags, m.kind != RGB_MSG_NOP ? m.server : 0u, n_members);
-    if (r + 1 > n_rounds) n_rounds = r + 1;
+  submit_scan sc;
+  sc.n_rounds = n ? 1 : 0;
+  switch (n_members) {
+#define RGB_SCAN_N(NM) case NM: submit_pass1<NM>(ctx, msgs, n, ranges, n_ranges, seen.data(), key_of.data(), round_of.data(), touched, sc); break;
+    RGB_SCAN_N(1) RGB_SCAN_N(2) RGB_SCAN_N(3) RGB_SCAN_N(4) RGB_SCAN_N(5) RGB_SCAN_N(6) RGB_SCAN_N(7) RGB_SCAN_N(8)
+#undef RGB_SCAN_N
+    default: return RGB_E_STATE;
   }
+  u32 n_rounds = sc.n_rounds;
+  const bool any_nop = sc.any_nop, too_many = sc.too_many, any_seqx = sc.any_seqx;
+  const int bad = sc.bad;
   for (u32 t : touched) seen[t] = 0;
   if (bad) return bad;
   if (too_many) return RGB_E_UNSUPPORTED;
@@ -769,9 +817,11 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
   std::vector<u32> bucket_counts;
   std::vector<u32> start(n_rounds + 1, 0);
   std::vector<u32> bucket((size_t)n_rounds * NK + 1, 0);
+  const u32 *const ro = round_of.data();                 /* (plain pointers: see submit_pass1) */
+  const uint16_t *const ko = key_of.data();
   for (u32 i = 0; i < n; ++i) {
-    start[round_of[i] + 1]++;
-    bucket[(size_t)round_of[i] * NK + family(key_of[i]) + 1]++;
+    start[ro[i] + 1]++;
+    bucket[(size_t)ro[i] * NK + family(ko[i]) + 1]++;
   }
   for (u32 r = 0; r < n_rounds; ++r) start[r + 1] += start[r];
   if (as_train) bucket_counts.assign(bucket.begin() + 1, bucket.end());      /* per (round, bucket), before the scan */
@@ -781,18 +831,11 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
    * failed launch) and the span of device positions whose kind can emit rpc records.  A bucket holds one class, so
    * both follow from the bucket bounds (bucket[b] .. bucket[b + 1] before the scatter below moves them) */
   std::vector<u32> class_counts((size_t)n_rounds * RGB_N_CLASSES, 0);
-  u32 rpc_lo = n, rpc_hi = 0;
   for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) {
     const u32 b0 = bucket[b], b1 = bucket[b + 1];
     if (b1 == b0) continue;
     const u32 cls = (u32)(b % NK) / (as_train ? 2u * RGB_TRAIN_SHARDS : 2u);      /* kind rank; 15 = NOP */
     if (cls < RGB_N_CLASSES) class_counts[(b / NK) * RGB_N_CLASSES + cls] += b1 - b0;
-    /* append_entries_reply, {commands}, pipeline_rpcs, request_vote_result, pre_vote_rpc */
-    /* (+ the leader's written events when their pipeline_rpcs event is fused into them: RGB_CFG_FUSE_PIPELINE) */
-    if (cls == 1 || cls == 3 || cls == 4 || cls == 6 || cls == 9 || (cls == 2 && (ctx->cfg.flags & RGB_CFG_FUSE_PIPELINE))) {
-      if (b0 < rpc_lo) rpc_lo = b0;
-      rpc_hi = b1 - 1;
-    }
   }
   /* ---- 2. the slot and the ticket.  From here to the publication nothing returns early and whatever throws is
    * caught: the ticket must be honoured (enqueue_turn advances, the slot is published -- as failed if need be) or
@@ -812,14 +855,17 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
   int rc = RGB_OK;
   u32 rows_max = 0;
   try {
-    s.perm.resize(n);                                           /* within the capacity reserved by alloc_slot */
+    s.h_pos = reinterpret_cast<u32 *>(s.h_msgs + n); s.d_pos = reinterpret_cast<u32 *>(s.d_msgs + n);
+    const bool stream_copy = (size_t)n * sizeof(rgb_msg) >= RGB_STREAM_COPY_MIN;
     for (u32 i = 0; i < n; ++i) {
-      u32 p = bucket[(size_t)round_of[i] * NK + family(key_of[i])]++;
-      s.perm[p] = i;
+      u32 p = bucket[(size_t)ro[i] * NK + family(ko[i])]++;
       s.h_pos[i] = p;
-      s.h_msgs[p] = msgs[i];
-      s.h_stamps[p] = (unsigned char)round_of[i];        /* a train's stamps: the device adds the sequence bytes */
+      copy_msg(&s.h_msgs[p], &msgs[i], stream_copy);
+      if (as_train) s.h_stamps[p] = (unsigned char)ro[i];   /* a train's stamps: the device adds the sequence bytes */
     }
+#if defined(__x86_64__)
+    if (stream_copy) _mm_sfence();                        /* (the streaming stores are ordered before the copy command) */
+#endif
     s.n = n; s.tick = tick;
     s.n_ranges = 0; s.has_seqx = any_seqx;
     if (n_ranges) {                                            /* the batch's range list travels with it */
@@ -841,7 +887,6 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
     s.round_cc.swap(class_counts);
     s.n_touched = (u32)touched.size();
     if (s.n_touched) memcpy(s.h_touched, touched.data(), (size_t)s.n_touched * sizeof(u32));
-    s.rpc_lo = rpc_lo < n ? rpc_lo : 0; s.rpc_cnt = rpc_lo < n ? rpc_hi - rpc_lo + 1 : 0;
     if (as_train) {                                            /* the plan of every round: slot-local, no lock */
       for (u32 r = 0; r < n_rounds; ++r) {
         const u32 rows = rgb_train_make_tick(bucket_counts.data() + (size_t)r * RGB_N_BUCKETS, n_members, &s.h_plan[r], nullptr, 0);
@@ -871,7 +916,7 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
     }
     if (rc != RGB_OK) {
       /* published as failed: rgb_collect reports the error once and the ring moves on */
-      s.enqueue_error = rc; s.n = 0; s.rpc_cnt = 0; s.used_train = false; s.has_undo = false;
+      s.enqueue_error = rc; s.n = 0; s.used_train = false; s.has_undo = false;
       (void)hipEventRecord(s.done, ctx->stream);
     }
     /* publish: everything written to the slot above happens-before the consumer's acquire load */
@@ -928,79 +973,98 @@ static int settle_trains(rgb_ctx *ctx) {
   return RGB_OK;
 }
 
-/* rgb_collect: the oldest published batch.  Under collect_mu only: wait for the batch, size check, take the slot;
- * the copy back to submission order runs outside the lock, so several consumers copy different batches at once. */
+/* The oldest published batch, taken out of the ring (state 3: the caller's until it is given back).  Under collect_mu
+ * only: wait for the batch, size check, take the slot.  cap / rpc_cap: the caller's buffers (rgb_collect), or
+ * 0xFFFFFFFF for a caller that reads the slot in place (rgb_collect_view). */
+static int take_oldest(rgb_ctx *ctx, bool have_out, uint32_t cap, bool have_rpc_out, uint32_t rpc_cap, uint32_t *n_out,
+                       uint32_t *n_rpc_out, rgb_slot **taken, u32 *n_rpc_taken) {
+  std::lock_guard<std::mutex> lk(ctx->collect_mu);
+  if (ctx->in_flight.load(std::memory_order_acquire) == 0) return RGB_E_EMPTY;
+  rgb_slot &s = ctx->ring_mem[ctx->tail];
+  HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+  HIPCHK(ctx, hipEventSynchronize(s.done));
+  int fail = s.enqueue_error;
+  if (!fail && s.used_train && s.h_nrpc[1] != 0) {
+    /* the train launch of this batch failed (its error word came back with the results): repair the device
+     * state and run this batch and everything enqueued behind it again, one launch per round */
+    std::lock_guard<std::mutex> el(ctx->enqueue_mu);
+    fail = settle_trains(ctx);
+  }
+  if (!fail && s.used_train) {
+    s.used_train = false;
+    ctx->trains_in_flight.fetch_sub(1, std::memory_order_release);
+  }
+  /* a message reported more records than it has slots (a kind that cannot emit rpcs did): unrecoverable for this
+   * batch -- it is consumed all the same, so the ring moves on and the caller sees the error once */
+  if (!fail && s.n && s.h_nrpc[2] != 0) fail = RGB_E_STATE;
+  if (fail) {
+    if (s.used_train) { s.used_train = false; ctx->trains_in_flight.fetch_sub(1, std::memory_order_release); }
+    s.enqueue_error = 0;
+    ctx->tail = (ctx->tail + 1) % ctx->ring_size;
+    ctx->in_flight.fetch_sub(1, std::memory_order_release);
+    s.state.store(0, std::memory_order_release);
+    return fail;
+  }
+  const u32 n_rpc = s.n ? s.h_nrpc[0] : 0u;                /* counted on the device */
+  /* a buffer that is too small leaves the batch in the ring: the sizes it needs are reported and the
+   * caller retries (nothing is dropped, the ring is not wedged) */
+  if (s.n > cap || (s.n && !have_out) || (have_rpc_out && n_rpc > rpc_cap)) {
+    if (n_out) *n_out = s.n;
+    if (n_rpc_out) *n_rpc_out = n_rpc;
+    return (s.n > cap || (s.n && !have_out)) ? RGB_E_INVAL : RGB_E_FULL;
+  }
+  s.state.store(3, std::memory_order_relaxed);              /* mine: the next consumer takes the next slot */
+  ctx->tail = (ctx->tail + 1) % ctx->ring_size;
+  ctx->in_flight.fetch_sub(1, std::memory_order_release);
+  *taken = &s;
+  *n_rpc_taken = n_rpc;
+  return RGB_OK;
+}
+
+/* rgb_collect: the oldest published batch, copied out.  The device wrote both parts into the pinned slot in the order
+ * they are handed out (rgb_results_kernel): the decisions in submission order, the rpc records by (msg_index, peer) --
+ * two sequential copies, outside the lock, so several consumers copy different batches at once. */
 int rgb_collect(rgb_ctx *ctx, rgb_decision *out, uint32_t cap, uint32_t *n_out, rgb_rpc *rpc_out,
                 uint32_t rpc_cap, uint32_t *n_rpc_out, uint64_t *tick_out) {
   if (!ctx) return RGB_E_INVAL;
   if (n_out) *n_out = 0;
   if (n_rpc_out) *n_rpc_out = 0;
-  rgb_slot *sp;
+  rgb_slot *sp = nullptr;
   u32 n_rpc = 0;
-  {
-    std::lock_guard<std::mutex> lk(ctx->collect_mu);
-    if (ctx->in_flight.load(std::memory_order_acquire) == 0) return RGB_E_EMPTY;
-    sp = &ctx->ring_mem[ctx->tail];
-    rgb_slot &s = *sp;
-    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    HIPCHK(ctx, hipEventSynchronize(s.done));
-    int fail = s.enqueue_error;
-    if (!fail && s.used_train && s.h_nrpc[1] != 0) {
-      /* the train launch of this batch failed (its error word came back with the results): repair the device
-       * state and run this batch and everything enqueued behind it again, one launch per round */
-      std::lock_guard<std::mutex> el(ctx->enqueue_mu);
-      fail = settle_trains(ctx);
-    }
-    if (!fail && s.used_train) {
-      s.used_train = false;
-      ctx->trains_in_flight.fetch_sub(1, std::memory_order_release);
-    }
-    if (fail) {
-      if (s.used_train) { s.used_train = false; ctx->trains_in_flight.fetch_sub(1, std::memory_order_release); }
-      s.enqueue_error = 0;
-      ctx->tail = (ctx->tail + 1) % ctx->ring_size;
-      ctx->in_flight.fetch_sub(1, std::memory_order_release);
-      s.state.store(0, std::memory_order_release);
-      return fail;
-    }
-    n_rpc = s.n ? s.h_nrpc[0] : 0u;                        /* counted on the device */
-    /* a buffer that is too small leaves the batch in the ring: the sizes it needs are reported and the
-     * caller retries (nothing is dropped, the ring is not wedged) */
-    if (s.n > cap || (s.n && !out) || (rpc_out && n_rpc > rpc_cap)) {
-      if (n_out) *n_out = s.n;
-      if (n_rpc_out) *n_rpc_out = n_rpc;
-      return (s.n > cap || (s.n && !out)) ? RGB_E_INVAL : RGB_E_FULL;
-    }
-    s.state.store(3, std::memory_order_relaxed);            /* mine: the next consumer takes the next slot */
-    ctx->tail = (ctx->tail + 1) % ctx->ring_size;
-    ctx->in_flight.fetch_sub(1, std::memory_order_release);
-  }
+  const int rc = take_oldest(ctx, out != nullptr, cap, rpc_out != nullptr, rpc_cap, n_out, n_rpc_out, &sp, &n_rpc);
+  if (rc != RGB_OK) return rc;
   rgb_slot &s = *sp;
-  /* the decisions came back in submission order (rgb_unpermute_kernel): one sequential copy */
-  if (s.n) memcpy(out, s.h_dec, (size_t)s.n * sizeof(rgb_decision));
-  int rc_out = RGB_OK;
-  if (n_rpc && rpc_out) {
-    u32 k = 0;
-    for (u32 i = 0; i < s.n && rc_out == RGB_OK; ++i) {      /* ordered by (msg_index, peer) */
-      const u32 p = s.h_pos[i];                              /* where the message ran on the device */
-      const u32 nr = s.h_dec[i].n_rpcs;
-      if (!nr) continue;
-      /* a kind that cannot emit rpcs did: unrecoverable for this batch -- it is consumed all the same, so
-       * the ring moves on and the caller sees the error once */
-      if (p < s.rpc_lo || p >= s.rpc_lo + s.rpc_cnt || nr > ctx->rpc_stride) { rc_out = RGB_E_STATE; break; }
-      for (u32 q = 0; q < nr; ++q) {
-        rgb_rpc r = s.h_rpcs[(size_t)(p - s.rpc_lo) * ctx->rpc_stride + q];
-        r.msg_index = i;
-        rpc_out[k++] = r;
-      }
-    }
-  }
+  if (s.n) copy_out(out, s.h_dec, (size_t)s.n * sizeof(rgb_decision));
+  if (n_rpc && rpc_out) memcpy(rpc_out, s.h_rpcs, (size_t)n_rpc * sizeof(rgb_rpc));
   if (n_out) *n_out = s.n;
   if (n_rpc_out) *n_rpc_out = n_rpc;
   if (tick_out) *tick_out = s.tick;
   /* release: the slot's buffers are free for the producer whose turn it is */
   s.state.store(0, std::memory_order_release);
-  return rc_out;
+  return RGB_OK;
+}
+
+/* rgb_collect_view (ABI v9): the oldest published batch IN PLACE -- pointers into the pinned slot the device wrote, no
+ * copy.  The slot is the caller's until rgb_release(view.slot). */
+int rgb_collect_view(rgb_ctx *ctx, rgb_view *view) {
+  if (!ctx || !view) return RGB_E_INVAL;
+  memset(view, 0, sizeof *view);
+  rgb_slot *sp = nullptr;
+  u32 n_rpc = 0;
+  const int rc = take_oldest(ctx, true, 0xFFFFFFFFu, true, 0xFFFFFFFFu, nullptr, nullptr, &sp, &n_rpc);
+  if (rc != RGB_OK) return rc;
+  view->decisions = sp->h_dec; view->n = sp->n;
+  view->rpcs = sp->h_rpcs; view->n_rpcs = n_rpc;
+  view->tick = sp->tick;
+  view->slot = (uint32_t)(sp - ctx->ring_mem.get());
+  return RGB_OK;
+}
+
+int rgb_release(rgb_ctx *ctx, uint32_t slot) {
+  if (!ctx || slot >= ctx->ring_size) return RGB_E_INVAL;
+  int held = 3;
+  /* release: the slot's buffers are free for the producer whose turn it is */
+  return ctx->ring_mem[slot].state.compare_exchange_strong(held, 0, std::memory_order_release) ? RGB_OK : RGB_E_STATE;
 }
 
 /* Sizes of the OLDEST batch in flight (waits for it like rgb_collect, consumes nothing): what a caller needs to

@@ -297,6 +297,12 @@ int rgb_launch_checksum(const rgb_dev &dev, u32 first, u32 n, u64 *d_out, void *
  * order to submission order (d_pos[i] = device position of submitted message i) */
 int rgb_launch_stamp_rounds(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_stamps, void *stream);
 int rgb_launch_unpermute(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream);
+/* a batch's results written by the device into the slot's pinned host buffers: decisions expanded and in submission
+ * order, rpc records compacted in (message, slot) order with msg_index = the submission index, header = {records,
+ * train error word, over-count flag}; d_scratch = rgb_results_blocks(n) + 1 words */
+u32 rgb_results_blocks(u32 n);
+int rgb_launch_results(const rgb_decision *d_dec, const u32 *d_pos, u32 n, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch,
+                       const u32 *d_ctl, rgb_decision *out_dec, rgb_rpc *out_rpcs, u32 *out_hdr, void *stream);
 /* undo log: rgb_undo_pieces(dev) 16-byte pieces per server (every row + the sequence byte) of the n servers d_ids
  * name, saved to (restore = 0) or written back from (restore = 1) d_undo */
 u32 rgb_undo_pieces(const rgb_dev &dev);

@@ -4210,6 +4210,114 @@ __global__ void rgb_unpermute_kernel(const ulonglong2 *__restrict__ dec, const u
   dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = e;
 }
 
+/* ---- what a batch of rgb_submit hands back, written by the device INTO THE PINNED SLOT (round 6) ----
+ * Two kernels behind a batch's launches replace count + un-permute + three device-to-host copies:
+ *   rgb_results_sums_kernel   rpc records per block of RGB_RES_BLOCK messages, in SUBMISSION order
+ *   rgb_results_kernel        every block: its base = the sums in front of it; the decisions of its messages
+ *                             expanded, in submission order; its rpc records COMPACTED in (message, slot) order with
+ *                             msg_index = the submission index (what rgb_collect used to do record by record on the
+ *                             host) -- both staged in LDS and written out as contiguous 16- / 8-byte-per-lane stores
+ *                             straight into host memory (hipHostMalloc: the device writes across PCIe; visible to the
+ *                             host once the slot's event has completed).  The last block leaves the header:
+ *                             [0] rpc records, [1] the train launch's error word, [2] a message reported more
+ *                             records than it has slots (a kind that cannot emit rpcs did).
+ * Before: the decisions went device -> device (un-permute) -> host, and the rpc records as the SPAN of fixed slots
+ * between the first and the last class that can emit any -- (N-1) x 56 bytes per message of nearly the whole batch,
+ * 3.5 x the decisions' bytes for groups of five, almost all of it empty slots. */
+#define RGB_RES_BLOCK 128u
+#define RGB_RES_MAX_STRIDE 7u       /* rpc slots per message: groups of up to eight members */
+__global__ __launch_bounds__(RGB_RES_BLOCK) void rgb_results_sums_kernel(const rgb_decision *__restrict__ dec, const u32 *__restrict__ pos,
+                                                                         u32 n, u32 rpc_stride, u32 *__restrict__ block_sums,
+                                                                         u32 *__restrict__ err) {
+  __shared__ u32 part[RGB_RES_BLOCK / 64u];
+  const u32 i = blockIdx.x * RGB_RES_BLOCK + threadIdx.x;
+  u32 v = i < n ? (u32)((reinterpret_cast<const u64 *>(dec + pos[i])[0] >> 48) & 0xFFull) : 0u;
+  if (v > rpc_stride) { atomicOr(err, 1u); v = rpc_stride; }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 t = 0;
+#pragma unroll
+    for (u32 w = 0; w < RGB_RES_BLOCK / 64u; ++w) t += part[w];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(RGB_RES_BLOCK) void rgb_results_kernel(const ulonglong2 *__restrict__ dec, const u32 *__restrict__ pos, u32 n,
+                                                                    const u32 *__restrict__ block_sums, const u64 *__restrict__ rpcs,
+                                                                    u32 rpc_stride, const u32 *__restrict__ err, const u32 *__restrict__ ctl,
+                                                                    ulonglong2 *__restrict__ out_dec, u64 *__restrict__ out_rpcs,
+                                                                    u32 *__restrict__ out_hdr) {
+  __shared__ ulonglong2 sdec[RGB_RES_BLOCK * 4u];                              /* 8 KiB */
+  __shared__ u64 srec[RGB_RES_BLOCK * RGB_RES_MAX_STRIDE * 7u];                /* 49 KiB */
+  __shared__ u32 sscan[RGB_RES_BLOCK];
+  __shared__ u32 sred[RGB_RES_BLOCK];
+  const u32 tid = threadIdx.x, b = blockIdx.x;
+  const u32 i = b * RGB_RES_BLOCK + tid;
+  /* the records in front of this block */
+  u32 partial = 0;
+  for (u32 k = tid; k < b; k += RGB_RES_BLOCK) partial += block_sums[k];
+  sred[tid] = partial;
+  /* this lane's decision (expanded: rgb_decision_expand of include/ra_gpu_batch.h) and its record count */
+  u32 nr = 0, p = 0;
+  if (i < n) {
+    p = pos[i];
+    const ulonglong2 *src = dec + (size_t)p * 4u;
+    ulonglong2 a = src[0], bb = src[1], c, e;
+    nr = (u32)((a.x >> 48) & 0xFFull);
+    if (nr > rpc_stride) nr = rpc_stride;
+    const u32 flags = (u32)a.y;
+    if (flags & RGB_F_COMPACT) {
+      const u32 aux = (u32)(a.y >> 32), f = flags & ~(u32)RGB_F_COMPACT;
+      const u64 A = bb.x, B = bb.y;
+      u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0, ci, la;
+      if (f & RGB_F_REPLY) {
+        w3 = A + 1ull; w2 = B; w4 = A - (u64)(aux & 0xFFu); w5 = B - (u64)((aux >> 8) & 0xFu);
+        ci = A + (u64)((aux >> 12) & 0x3FFu) - 512ull; la = A + 1ull - (u64)((aux >> 22) & 0x3FFu);
+      } else if (f & RGB_F_WROTE) {
+        w4 = A; w3 = A - (u64)(aux & 0xFFFFu); ci = B; la = A - (u64)(aux >> 16);
+      } else { ci = A; la = B; }
+      a.y = (u64)f;
+      bb = make_ulonglong2(w2, w3); c = make_ulonglong2(w4, w5); e = make_ulonglong2(ci, la);
+    } else { c = src[2]; e = src[3]; }
+    sdec[tid * 4u + 0u] = a; sdec[tid * 4u + 1u] = bb; sdec[tid * 4u + 2u] = c; sdec[tid * 4u + 3u] = e;
+  }
+  sscan[tid] = nr;
+  __syncthreads();
+  /* inclusive scan of the counts, tree sum of the partials (128 lanes: seven steps each) */
+  for (u32 o = 1; o < RGB_RES_BLOCK; o <<= 1) {
+    const u32 add = tid >= o ? sscan[tid - o] : 0u;
+    const u32 r2 = (tid + o < RGB_RES_BLOCK && (tid & (2u * o - 1u)) == 0u) ? sred[tid + o] : 0u;
+    __syncthreads();
+    sscan[tid] += add;
+    sred[tid] += r2;
+    __syncthreads();
+  }
+  const u32 base = sred[0], mine = sscan[RGB_RES_BLOCK - 1u], off = sscan[tid] - nr;
+  /* the records of this lane's message, slot order, msg_index := the submission index */
+  for (u32 q = 0; q < nr; ++q) {
+    const u64 *r = rpcs + ((size_t)p * rpc_stride + q) * 7u;
+    u64 *d = srec + (size_t)(off + q) * 7u;
+    d[0] = (r[0] & 0xFFFFFFFF00000000ull) | (u64)i;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) d[k] = r[k];
+  }
+  __syncthreads();
+  /* out: contiguous stores, lane stride 16 / 8 bytes */
+  const u32 first = b * RGB_RES_BLOCK, cnt = n - first < RGB_RES_BLOCK ? n - first : RGB_RES_BLOCK;
+  ulonglong2 *od = out_dec + (size_t)first * 4u;
+  for (u32 k = tid; k < cnt * 4u; k += RGB_RES_BLOCK) od[k] = sdec[k];
+  u64 *orp = out_rpcs + (size_t)base * 7u;
+  for (u32 k = tid; k < mine * 7u; k += RGB_RES_BLOCK) orp[k] = srec[k];
+  if (b == gridDim.x - 1u && tid == 0u) {
+    out_hdr[0] = base + mine;
+    out_hdr[1] = ctl ? ctl[0] : 0u;
+    out_hdr[2] = err[0];
+  }
+}
+
 /* Undo log of a batch (rgb_submit's fail-safe, rgb_api.hip): every row of the servers ids[0..n) -- hot, peers, run
  * table, cond, qry, sequence byte -- copied to undo (restore = 0) or back (restore = 1), one lane per 16-byte piece */
 __host__ __device__ __forceinline__ u32 rgb_undo_pieces_of(const rgb_dev &dev) {
@@ -4730,6 +4838,25 @@ int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *st
   hipError_t e = hipMemsetAsync(d_out, 0, sizeof(u32), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   if (n) hipLaunchKernelGGL(rgb_count_rpcs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_dec, n, d_out);
+  return (int)hipGetLastError();
+}
+
+u32 rgb_results_blocks(u32 n) { return (n + RGB_RES_BLOCK - 1u) / RGB_RES_BLOCK; }
+
+/* d_scratch: rgb_results_blocks(capacity) + 1 words (the block sums, then the error word); out_*: the slot's PINNED
+ * host buffers (or device memory: the kernel does not care); d_ctl: the train launch's error word, or NULL */
+int rgb_launch_results(const rgb_decision *d_dec, const u32 *d_pos, u32 n, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch,
+                       const u32 *d_ctl, rgb_decision *out_dec, rgb_rpc *out_rpcs, u32 *out_hdr, void *stream) {
+  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
+  if (n == 0 || rpc_stride > RGB_RES_MAX_STRIDE) return n == 0 ? 0 : 1;   /* (hipErrorInvalidValue) */
+  const u32 nb = rgb_results_blocks(n);
+  u32 *err = d_scratch + nb;
+  hipError_t e = hipMemsetAsync(err, 0, sizeof(u32), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(rgb_results_sums_kernel, dim3(nb), dim3(RGB_RES_BLOCK), 0, (hipStream_t)stream, d_dec, d_pos, n, rpc_stride, d_scratch, err);
+  hipLaunchKernelGGL(rgb_results_kernel, dim3(nb), dim3(RGB_RES_BLOCK), 0, (hipStream_t)stream, reinterpret_cast<const ulonglong2 *>(d_dec),
+                     d_pos, n, (const u32 *)d_scratch, reinterpret_cast<const u64 *>(d_rpcs), rpc_stride, (const u32 *)err, d_ctl,
+                     reinterpret_cast<ulonglong2 *>(out_dec), reinterpret_cast<u64 *>(out_rpcs), out_hdr);
   return (int)hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "rgb_train_stamp_device", "rgb_train_run_device", "rgb_train_status", "rgb_train_form", "rgb_train_recoveries",
     "rgb_train_plan_create_snap", "rgb_train_run_snap_device", "rgb_snapshot_train_device", "rgb_train_seq_bytes",
     "rgb_train_plan_create_device", "rgb_train_plan_build_device", "rgb_train_plan_download", "rgb_train_plan_fit",
-    "rgb_submit_seq", "rgb_set_seq_ranges_device",
+    "rgb_submit_seq", "rgb_set_seq_ranges_device", "rgb_collect_view", "rgb_release",
 ]
 COMM_EXPORTS = ["rgb_comm_unique_id", "rgb_comm_init_rank", "rgb_comm_destroy", "rgb_comm_n_ranks", "rgb_comm_rank",
                 "rgb_leaderboard_allgather", "rgb_leaderboard_allgather_host", "rgb_comm_last_error"]   # the one collective of the path (RCCL)
@@ -39,7 +39,8 @@ OPTIONAL_IN_OLD_BUILDS = {"rgb_synth_tick_stamped_device", "rgb_synth_stamps_res
                           "rgb_train_recoveries", "rgb_train_plan_create_snap", "rgb_train_run_snap_device",
                           "rgb_snapshot_train_device", "rgb_train_seq_bytes", "rgb_synth_snapshot_mark_device",
                           "rgb_synth_set_hint", "rgb_train_plan_create_device", "rgb_train_plan_build_device",
-                          "rgb_train_plan_download", "rgb_train_plan_fit", "rgb_submit_seq", "rgb_set_seq_ranges_device"} | set(COMM_EXPORTS)
+                          "rgb_train_plan_download", "rgb_train_plan_fit", "rgb_submit_seq", "rgb_set_seq_ranges_device",
+                          "rgb_collect_view", "rgb_release"} | set(COMM_EXPORTS)
 WAL_EXPORTS = ["rgb_wal_adler32_device", "rgb_wal_adler32", "rgb_wal_layout", "rgb_wal_frame_device",
                "rgb_wal_frame", "rgb_wal_scan", "rgb_wal_validate"]                            # include/ra_gpu_wal.h
 
@@ -109,6 +110,9 @@ def lib():
         L.rgb_submit_seq.argtypes = [vp, vp, u32, C.c_uint64, vp, u32]
         L.rgb_set_seq_ranges_device.argtypes = [vp, vp, u32]
     L.rgb_collect.argtypes = [vp, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32), u64p]
+    if hasattr(L, "rgb_collect_view"):
+        L.rgb_collect_view.argtypes = [vp, vp]
+        L.rgb_release.argtypes = [vp, u32]
     L.rgb_run_ticks_device.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp]
     L.rgb_snapshot.argtypes = [vp, vp]
     L.rgb_snapshot_device.argtypes = [vp, vp, vp]
@@ -184,6 +188,8 @@ def lib():
     if L.rgb_abi_version() != abi.ABI_VERSION and not (os.environ.get("RGB_LIB") and L.rgb_abi_version() == abi.ABI_VERSION - 1):
         raise RuntimeError("ABI version mismatch")     # (RGB_LIB=<the previous ABI's build>: A/B timing, tools/ only)
     for i, dt in enumerate(abi.STRUCT_DTYPES):
+        if os.environ.get("RGB_LIB") and i >= 6 and L.rgb_abi_version() < abi.ABI_VERSION:
+            continue                                       # (an older A/B build has no rgb_view)
         if L.rgb_struct_size(i) != dt.itemsize:
             raise RuntimeError(f"struct {i}: C size {L.rgb_struct_size(i)} != numpy {dt.itemsize}")
     _lib = L
@@ -297,6 +303,24 @@ class RaGpuBatch:
                                      rpc_cap, C.byref(nr), C.byref(tick))
         self._check(rc, "rgb_collect")
         return dec[:n.value], rpcs[:nr.value], tick.value
+
+    def collect_view(self):
+        """The oldest submitted batch IN PLACE (rgb_collect_view, ABI v9): (decisions, rpcs, tick, slot) where the two
+        arrays are numpy views of the pinned slot the device wrote -- no copy.  They are valid until release(slot);
+        the slot is not free for rgb_submit before that."""
+        v = np.zeros(1, dtype=abi.VIEW_DTYPE)
+        self._check(self._L.rgb_collect_view(self._h, v.ctypes.data), "rgb_collect_view")
+        n, nr = int(v["n"][0]), int(v["n_rpcs"][0])
+
+        def arr(ptr, count, dt):
+            if not count:
+                return np.empty(0, dtype=dt)
+            buf = (C.c_char * (count * dt.itemsize)).from_address(int(ptr))
+            return np.frombuffer(buf, dtype=dt, count=count)
+        return arr(v["decisions"][0], n, abi.DECISION_DTYPE), arr(v["rpcs"][0], nr, abi.RPC_DTYPE), int(v["tick"][0]), int(v["slot"][0])
+
+    def release(self, slot: int):
+        self._check(self._L.rgb_release(self._h, slot), "rgb_release")
 
     def wait(self, timeout_ms: int = 1000) -> bool:
         """Park until a batch is in flight (True) or the timeout / a wake() passes (False)."""

@@ -29,6 +29,7 @@ def test_random_ticks_through_the_c_abi(emulated_engine, oracle_lib, n_members, 
 def test_sub_ticks_ring_and_overflow(emulated_engine, oracle_lib):
     G.test_same_server_messages_are_serialised_in_submission_order(emulated_engine, oracle_lib)
     G.test_pipelined_ring_keeps_batches_in_order(emulated_engine, oracle_lib)
+    G.test_collect_view_hands_out_the_slot_in_place(emulated_engine, oracle_lib)
     G.test_run_table_overflow_is_flagged(emulated_engine)
     G.test_leaderboard_snapshot(emulated_engine)
     for n_run0 in (3, 1, 2):

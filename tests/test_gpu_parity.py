@@ -423,6 +423,50 @@ def test_pipelined_ring_keeps_batches_in_order(engine_mod, oracle_lib):
             gpu.collect()                               # nothing submitted
 
 
+def test_collect_view_hands_out_the_slot_in_place(engine_mod, oracle_lib):
+    """rgb_collect_view (ABI v9): the oldest batch as pointers into the pinned slot the device wrote -- decisions in
+    submission order, rpc records compacted by (msg_index, peer) -- equal to the sequential checker's; the slot stays
+    the caller's until rgb_release: the ring is full while it is held, a second release is refused."""
+    rng = np.random.default_rng(77)
+    G, N = 96, 5
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=4096, ring_slots=2, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        total_rpcs = 0
+        for t in range(4):
+            # several messages per server in one batch (sub-tick rounds), shuffled: the view is in SUBMISSION order
+            msgs = np.concatenate([fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.6) for _ in range(3)])
+            rng.shuffle(msgs)
+            do, ro = cpu.step(msgs)
+            gpu.submit(msgs, tick=7 + t)
+            dv, rv, tick, slot = gpu.collect_view()
+            assert tick == 7 + t and len(dv) == len(msgs)
+            assert dv.tobytes() == do.tobytes()
+            assert len(rv) == len(ro) and fuzz.sort_rpcs(rv.copy()).tobytes() == fuzz.sort_rpcs(ro).tobytes()
+            assert np.all(np.diff(rv["msg_index"].astype(np.int64)) >= 0), "records are ordered by msg_index"
+            total_rpcs += len(rv)
+            if t == 0:
+                # the held slot is not free: the ring (two slots) takes one more batch, then it is full
+                nop = np.zeros(4, dtype=abi.MSG_DTYPE)
+                gpu.submit(nop)
+                with pytest.raises(engine_mod.RgbError) as e:
+                    gpu.submit(nop)
+                assert e.value.code == abi.E_FULL
+                assert dv.tobytes() == do.tobytes()          # ... and its contents are untouched
+                gpu.release(slot)
+                gpu.collect()                                # the NOP batch
+            else:
+                gpu.release(slot)
+            with pytest.raises(engine_mod.RgbError) as e:
+                gpu.release(slot)                            # not held any more
+            assert e.value.code == abi.E_STATE
+        assert total_rpcs > 0
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes()
+    cpu.close()
+
+
 def test_device_resident_ticks_match_host_path(engine_mod, oracle_lib):
     import torch
     rng = np.random.default_rng(21)
