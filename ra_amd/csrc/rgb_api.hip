@@ -369,6 +369,7 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_nrpc, 64, hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_res, ((size_t)rgb_results_blocks(cap) + 1u) * sizeof(u32)));
+  HIPCHK(ctx, hipMemsetAsync(s.d_res, 0, ((size_t)rgb_results_blocks(cap) + 1u) * sizeof(u32), ctx->stream));   /* (the error word) */
   /* fused sub-tick rounds (at most RGB_SUBMIT_TRAIN_ROUNDS of them per batch) */
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_stamps, cap, hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_stamps, cap));
@@ -631,7 +632,7 @@ static int enqueue_rounds(rgb_ctx *ctx, rgb_slot &s) {
  * decisions in submission order, the rpc records compacted, the header (records, a train's error word -- the launch's
  * placement marks went into it: rgb_launch_train); then the slot's event */
 static int enqueue_results(rgb_ctx *ctx, rgb_slot &s) {
-  int lr = rgb_launch_results(s.d_dec, s.d_pos, s.n, s.d_rpcs, ctx->rpc_stride, s.d_res, s.used_train ? s.d_ctl : nullptr,
+  int lr = rgb_launch_results(s.d_dec, s.d_pos, s.n, ctx->cfg.ring_capacity, s.d_rpcs, ctx->rpc_stride, s.d_res, s.used_train ? s.d_ctl : nullptr,
                               s.h_dec, s.h_rpcs, s.h_nrpc, ctx->stream);
   if (lr) { ctx->last_hip.store(lr, std::memory_order_relaxed); return RGB_E_HIP; }
   HIPCHK(ctx, hipEventRecord(s.done, ctx->stream));
@@ -819,11 +820,22 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
   std::vector<u32> bucket((size_t)n_rounds * NK + 1, 0);
   const u32 *const ro = round_of.data();                 /* (plain pointers: see submit_pass1) */
   const uint16_t *const ko = key_of.data();
-  for (u32 i = 0; i < n; ++i) {
-    start[ro[i] + 1]++;
-    bucket[(size_t)ro[i] * NK + family(ko[i]) + 1]++;
+  /* (runs of one bucket -- a mailbox drain is clustered by kind -- are counted in a register: an increment per
+   * message on ONE counter is a store-to-load chain, five cycles a message) */
+  {
+    size_t cur = (size_t)-1; u32 run = 0;
+    for (u32 i = 0; i < n; ++i) {
+      const size_t b = (size_t)ro[i] * NK + family(ko[i]) + 1;
+      if (b != cur) { if (run) bucket[cur] += run; cur = b; run = 0; }
+      run++;
+    }
+    if (run) bucket[cur] += run;
   }
-  for (u32 r = 0; r < n_rounds; ++r) start[r + 1] += start[r];
+  for (u32 r = 0; r < n_rounds; ++r) {                   /* a round = its buckets */
+    u32 t = 0;
+    for (u32 k = 0; k < NK; ++k) t += bucket[(size_t)r * NK + k + 1];
+    start[r + 1] = start[r] + t;
+  }
   if (as_train) bucket_counts.assign(bucket.begin() + 1, bucket.end());      /* per (round, bucket), before the scan */
   for (size_t b = 0; b < (size_t)n_rounds * NK; ++b) bucket[b + 1] += bucket[b];
 
@@ -857,11 +869,17 @@ int rgb_submit_seq(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick,
   try {
     s.h_pos = reinterpret_cast<u32 *>(s.h_msgs + n); s.d_pos = reinterpret_cast<u32 *>(s.d_msgs + n);
     const bool stream_copy = (size_t)n * sizeof(rgb_msg) >= RGB_STREAM_COPY_MIN;
-    for (u32 i = 0; i < n; ++i) {
-      u32 p = bucket[(size_t)ro[i] * NK + family(ko[i])]++;
-      s.h_pos[i] = p;
-      copy_msg(&s.h_msgs[p], &msgs[i], stream_copy);
-      if (as_train) s.h_stamps[p] = (unsigned char)ro[i];   /* a train's stamps: the device adds the sequence bytes */
+    {
+      size_t cur = (size_t)-1; u32 next = 0;                  /* (the current bucket's cursor lives in a register) */
+      for (u32 i = 0; i < n; ++i) {
+        const size_t b = (size_t)ro[i] * NK + family(ko[i]);
+        if (b != cur) { if (cur != (size_t)-1) bucket[cur] = next; cur = b; next = bucket[b]; }
+        const u32 p = next++;
+        s.h_pos[i] = p;
+        copy_msg(&s.h_msgs[p], &msgs[i], stream_copy);
+        if (as_train) s.h_stamps[p] = (unsigned char)ro[i];   /* a train's stamps: the device adds the sequence bytes */
+      }
+      if (cur != (size_t)-1) bucket[cur] = next;
     }
 #if defined(__x86_64__)
     if (stream_copy) _mm_sfence();                        /* (the streaming stores are ordered before the copy command) */

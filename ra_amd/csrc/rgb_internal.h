@@ -291,17 +291,14 @@ int rgb_launch_seq_bump(unsigned char *d_seq, unsigned char *d_out, u32 n_bytes,
 int rgb_launch_pack(const rgb_dev &dev, const rgb_server_state *d_in, u32 first, u32 n, void *stream);
 int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u32 n, void *stream);
 int rgb_launch_leaderboard(const rgb_dev &dev, rgb_leaderboard_row *d_rows, void *stream);
-int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream);
 int rgb_launch_checksum(const rgb_dev &dev, u32 first, u32 n, u64 *d_out, void *stream);
-/* rgb_submit: stamps = sequence byte before the launch + the round the host wrote into d_stamps; decisions from device
- * order to submission order (d_pos[i] = device position of submitted message i) */
+/* rgb_submit: stamps = sequence byte before the launch + the round the host wrote into d_stamps */
 int rgb_launch_stamp_rounds(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, unsigned char *d_stamps, void *stream);
-int rgb_launch_unpermute(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream);
 /* a batch's results written by the device into the slot's pinned host buffers: decisions expanded and in submission
- * order, rpc records compacted in (message, slot) order with msg_index = the submission index, header = {records,
- * train error word, over-count flag}; d_scratch = rgb_results_blocks(n) + 1 words */
+ * order (d_pos[i] = device position of submitted message i), rpc records compacted in (message, slot) order with msg_index = the submission index, header = {records,
+ * train error word, over-count flag}; d_scratch = rgb_results_blocks(cap) + 1 words, ZERO when allocated */
 u32 rgb_results_blocks(u32 n);
-int rgb_launch_results(const rgb_decision *d_dec, const u32 *d_pos, u32 n, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch,
+int rgb_launch_results(const rgb_decision *d_dec, const u32 *d_pos, u32 n, u32 cap, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch,
                        const u32 *d_ctl, rgb_decision *out_dec, rgb_rpc *out_rpcs, u32 *out_hdr, void *stream);
 /* undo log: rgb_undo_pieces(dev) 16-byte pieces per server (every row + the sequence byte) of the n servers d_ids
  * name, saved to (restore = 0) or written back from (restore = 1) d_undo */

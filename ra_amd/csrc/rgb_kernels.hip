@@ -4170,13 +4170,12 @@ __global__ void rgb_checksum_kernel(rgb_dev dev, u32 first, u32 n, u64 *__restri
   out[k] = x;
 }
 
-/* rgb_submit's host side made lighter (two tiny kernels around a batch's launches):
+/* rgb_submit's host side made lighter:
  * rgb_stamp_rounds_kernel   a train's stamps from what the device knows: in = the round of every message (the host's
  *                           sub-tick round, one byte), out = the server's sequence byte as it stands before the launch +
  *                           the round (a server's rounds in one batch are 0, 1, 2, ..: its r-th message finds exactly
  *                           that) -- no host mirror of the sequence bytes, no per-message random access on the host
- * rgb_unpermute_kernel      decisions from device order (round, bucket) back to submission order before the copy to the
- *                           host: rgb_collect hands them out with one sequential memcpy */
+ * (decisions back to submission order, rpc records compacted: rgb_results_kernel below) */
 __global__ void rgb_stamp_rounds_kernel(rgb_dev dev, const rgb_msg *__restrict__ msgs, u32 n, unsigned char *__restrict__ stamps) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -4185,31 +4184,6 @@ __global__ void rgb_stamp_rounds_kernel(rgb_dev dev, const rgb_msg *__restrict__
   if (((w >> 32) & 0xFFull) == RGB_MSG_NOP || sv >= dev.n_servers) { stamps[i] = 0; return; }
   stamps[i] = (unsigned char)(dev.seq[rgb_seq_index(sv, dev.n_members, dev.seq_stride)] + stamps[i]);
 }
-__global__ void rgb_unpermute_kernel(const ulonglong2 *__restrict__ dec, const u32 *__restrict__ pos, u32 n,
-                                     ulonglong2 *__restrict__ out) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const ulonglong2 *src = dec + (size_t)pos[i] * 4u;
-  ulonglong2 a = src[0], b = src[1], c, e;
-  const u32 flags = (u32)a.y;
-  if (flags & RGB_F_COMPACT) {
-    /* rgb_decision_expand (include/ra_gpu_batch.h): the host path always hands out full records */
-    const u32 aux = (u32)(a.y >> 32), f = flags & ~(u32)RGB_F_COMPACT;
-    const u64 A = b.x, B = b.y;
-    u64 w2 = 0, w3 = 0, w4 = 0, w5 = 0, ci, la;
-    if (f & RGB_F_REPLY) {
-      w3 = A + 1ull; w2 = B; w4 = A - (u64)(aux & 0xFFu); w5 = B - (u64)((aux >> 8) & 0xFu);
-      ci = A + (u64)((aux >> 12) & 0x3FFu) - 512ull; la = A + 1ull - (u64)((aux >> 22) & 0x3FFu);
-    } else if (f & RGB_F_WROTE) {
-      w4 = A; w3 = A - (u64)(aux & 0xFFFFu); ci = B; la = A - (u64)(aux >> 16);
-    } else { ci = A; la = B; }
-    a.y = (u64)f;
-    b = make_ulonglong2(w2, w3); c = make_ulonglong2(w4, w5); e = make_ulonglong2(ci, la);
-  } else { c = src[2]; e = src[3]; }
-  ulonglong2 *dst = out + (size_t)i * 4u;
-  dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = e;
-}
-
 /* ---- what a batch of rgb_submit hands back, written by the device INTO THE PINNED SLOT (round 6) ----
  * Two kernels behind a batch's launches replace count + un-permute + three device-to-host copies:
  *   rgb_results_sums_kernel   rpc records per block of RGB_RES_BLOCK messages, in SUBMISSION order
@@ -4247,7 +4221,7 @@ __global__ __launch_bounds__(RGB_RES_BLOCK) void rgb_results_sums_kernel(const r
 
 __global__ __launch_bounds__(RGB_RES_BLOCK) void rgb_results_kernel(const ulonglong2 *__restrict__ dec, const u32 *__restrict__ pos, u32 n,
                                                                     const u32 *__restrict__ block_sums, const u64 *__restrict__ rpcs,
-                                                                    u32 rpc_stride, const u32 *__restrict__ err, const u32 *__restrict__ ctl,
+                                                                    u32 rpc_stride, u32 *__restrict__ err, const u32 *__restrict__ ctl,
                                                                     ulonglong2 *__restrict__ out_dec, u64 *__restrict__ out_rpcs,
                                                                     u32 *__restrict__ out_hdr) {
   __shared__ ulonglong2 sdec[RGB_RES_BLOCK * 4u];                              /* 8 KiB */
@@ -4315,6 +4289,7 @@ __global__ __launch_bounds__(RGB_RES_BLOCK) void rgb_results_kernel(const ulongl
     out_hdr[0] = base + mine;
     out_hdr[1] = ctl ? ctl[0] : 0u;
     out_hdr[2] = err[0];
+    err[0] = 0u;                      /* for the slot's next batch (no memset command in front of every batch) */
   }
 }
 
@@ -4823,39 +4798,20 @@ int rgb_launch_unpack(const rgb_dev &dev, rgb_server_state *d_out, u32 first, u3
   return (int)hipGetLastError();
 }
 
-/* sum of rgb_decision.n_rpcs over a batch (byte 6 of the record's first word): rgb_collect sizes the rpc buffer from
- * four bytes instead of walking the batch's decisions under its lock */
-__global__ void rgb_count_rpcs_kernel(const rgb_decision *__restrict__ dec, u32 n, u32 *__restrict__ out) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 v = i < n ? (u32)((reinterpret_cast<const u64 *>(dec + i)[0] >> 48) & 0xFFull) : 0u;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  if ((threadIdx.x & 63u) == 0u && v) atomicAdd(out, v);
-}
-
-int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream) {
-  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
-  hipError_t e = hipMemsetAsync(d_out, 0, sizeof(u32), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  if (n) hipLaunchKernelGGL(rgb_count_rpcs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_dec, n, d_out);
-  return (int)hipGetLastError();
-}
-
 u32 rgb_results_blocks(u32 n) { return (n + RGB_RES_BLOCK - 1u) / RGB_RES_BLOCK; }
 
-/* d_scratch: rgb_results_blocks(capacity) + 1 words (the block sums, then the error word); out_*: the slot's PINNED
+/* d_scratch: rgb_results_blocks(cap) + 1 words (the block sums, then the error word at the END: zero when allocated,
+ * cleared again by every launch; cap = the slot's capacity, n <= cap); out_*: the slot's PINNED
  * host buffers (or device memory: the kernel does not care); d_ctl: the train launch's error word, or NULL */
-int rgb_launch_results(const rgb_decision *d_dec, const u32 *d_pos, u32 n, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch,
+int rgb_launch_results(const rgb_decision *d_dec, const u32 *d_pos, u32 n, u32 cap, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch,
                        const u32 *d_ctl, rgb_decision *out_dec, rgb_rpc *out_rpcs, u32 *out_hdr, void *stream) {
   (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
   if (n == 0 || rpc_stride > RGB_RES_MAX_STRIDE) return n == 0 ? 0 : 1;   /* (hipErrorInvalidValue) */
   const u32 nb = rgb_results_blocks(n);
-  u32 *err = d_scratch + nb;
-  hipError_t e = hipMemsetAsync(err, 0, sizeof(u32), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
+  u32 *err = d_scratch + rgb_results_blocks(cap);       /* (zero at allocation; the results kernel leaves it zero) */
   hipLaunchKernelGGL(rgb_results_sums_kernel, dim3(nb), dim3(RGB_RES_BLOCK), 0, (hipStream_t)stream, d_dec, d_pos, n, rpc_stride, d_scratch, err);
   hipLaunchKernelGGL(rgb_results_kernel, dim3(nb), dim3(RGB_RES_BLOCK), 0, (hipStream_t)stream, reinterpret_cast<const ulonglong2 *>(d_dec),
-                     d_pos, n, (const u32 *)d_scratch, reinterpret_cast<const u64 *>(d_rpcs), rpc_stride, (const u32 *)err, d_ctl,
+                     d_pos, n, (const u32 *)d_scratch, reinterpret_cast<const u64 *>(d_rpcs), rpc_stride, err, d_ctl,
                      reinterpret_cast<ulonglong2 *>(out_dec), reinterpret_cast<u64 *>(out_rpcs), out_hdr);
   return (int)hipGetLastError();
 }
@@ -4892,9 +4848,3 @@ int rgb_launch_stamp_rounds(const rgb_dev &dev, const rgb_msg *d_msgs, u32 n, un
   return (int)hipGetLastError();
 }
 
-int rgb_launch_unpermute(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream) {
-  (void)hipGetLastError();   /* a stale error of an earlier call in this thread is not this launch's */
-  if (n) hipLaunchKernelGGL(rgb_unpermute_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
-                            reinterpret_cast<const ulonglong2 *>(d_dec), d_pos, n, reinterpret_cast<ulonglong2 *>(d_out));
-  return (int)hipGetLastError();
-}

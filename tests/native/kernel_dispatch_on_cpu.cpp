@@ -111,15 +111,11 @@ int rgb_launch_train_calibrate__N1(u32 *d_out, void *stream);
 int rgb_launch_train_calibrate(u32 *d_out, void *stream) { return rgb_launch_train_calibrate__N1(d_out, stream); }
 int rgb_launch_seq_bump__N1(unsigned char *d_seq, unsigned char *d_out, u32 n_bytes, void *stream);
 int rgb_launch_seq_bump(unsigned char *d_seq, unsigned char *d_out, u32 n_bytes, void *stream) { return rgb_launch_seq_bump__N1(d_seq, d_out, n_bytes, stream); }
-int rgb_launch_count_rpcs__N1(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream);
-int rgb_launch_count_rpcs(const rgb_decision *d_dec, u32 n, u32 *d_out, void *stream) { return rgb_launch_count_rpcs__N1(d_dec, n, d_out, stream); }
-int rgb_launch_unpermute__N1(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream);
-int rgb_launch_unpermute(const rgb_decision *d_dec, const u32 *d_pos, u32 n, rgb_decision *d_out, void *stream) { return rgb_launch_unpermute__N1(d_dec, d_pos, n, d_out, stream); }
 u32 rgb_results_blocks__N1(u32 n);
 u32 rgb_results_blocks(u32 n) { return rgb_results_blocks__N1(n); }
-int rgb_launch_results__N1(const rgb_decision *d_dec, const u32 *d_pos, u32 n, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch, const u32 *d_ctl, rgb_decision *out_dec, rgb_rpc *out_rpcs, u32 *out_hdr, void *stream);
-int rgb_launch_results(const rgb_decision *d_dec, const u32 *d_pos, u32 n, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch, const u32 *d_ctl, rgb_decision *out_dec, rgb_rpc *out_rpcs, u32 *out_hdr, void *stream) {
-  return rgb_launch_results__N1(d_dec, d_pos, n, d_rpcs, rpc_stride, d_scratch, d_ctl, out_dec, out_rpcs, out_hdr, stream);
+int rgb_launch_results__N1(const rgb_decision *d_dec, const u32 *d_pos, u32 n, u32 cap, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch, const u32 *d_ctl, rgb_decision *out_dec, rgb_rpc *out_rpcs, u32 *out_hdr, void *stream);
+int rgb_launch_results(const rgb_decision *d_dec, const u32 *d_pos, u32 n, u32 cap, const rgb_rpc *d_rpcs, u32 rpc_stride, u32 *d_scratch, const u32 *d_ctl, rgb_decision *out_dec, rgb_rpc *out_rpcs, u32 *out_hdr, void *stream) {
+  return rgb_launch_results__N1(d_dec, d_pos, n, cap, d_rpcs, rpc_stride, d_scratch, d_ctl, out_dec, out_rpcs, out_hdr, stream);
 }
 int rgb_launch_train_plan__N1(const u32 *d_bucket_counts, rgb_train_tick *d_ticks, u32 *d_rows, u32 rpt, u32 first_tick, u32 n_ticks, u32 snapshot_every, u32 n_groups, u32 n_members, u32 *d_err, void *stream);
 int rgb_launch_train_plan(const u32 *d_bucket_counts, rgb_train_tick *d_ticks, u32 *d_rows, u32 rpt, u32 first_tick, u32 n_ticks, u32 snapshot_every, u32 n_groups, u32 n_members, u32 *d_err, void *stream) {
