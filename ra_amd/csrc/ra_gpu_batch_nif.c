@@ -349,14 +349,20 @@ static void send_batch(ErlNifEnv *env, const ErlNifPid *to, uint64_t tick, uint3
  * per owner and list the owners in order of first appearance, (2) append every decision (submission order is kept
  * inside an owner) and its rpc records -- rgb_collect returns them ordered by msg_index -- to the owner's binaries,
  * with msg_index rewritten to the decision's position inside that owner's DecisionsBin. */
-static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint32_t nr, ErlNifBinary *dec, ErlNifBinary *rpc) {
-  const rgb_decision *d = (const rgb_decision *)dec->data;
-  const rgb_rpc *r = (const rgb_rpc *)rpc->data;
-  (void)nr;
+/* d / r: the batch where the device wrote it -- the pinned ring slot of an rgb_collect_view (ABI v9), read ONCE here
+ * and released by the caller afterwards: the decisions are copied a single time, straight into the per-owner binaries
+ * (through rgb_collect they were copied into a batch binary first and regrouped from there). */
+static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint32_t nr, const rgb_decision *d, const rgb_rpc *r) {
   enif_mutex_lock(c->own_mu);
   if (c->n_pids == 0) {
     enif_mutex_unlock(c->own_mu);
-    send_batch(env, &c->owner, tick, n, dec, rpc);
+    /* no owner table: the whole batch to the default owner, as two binaries */
+    ErlNifBinary dec, rpc;
+    if (!enif_alloc_binary((size_t)n * sizeof(rgb_decision), &dec)) return RGB_E_NOMEM;
+    if (!enif_alloc_binary((size_t)nr * sizeof(rgb_rpc), &rpc)) { enif_release_binary(&dec); return RGB_E_NOMEM; }
+    if (n) memcpy(dec.data, d, (size_t)n * sizeof(rgb_decision));
+    if (nr) memcpy(rpc.data, r, (size_t)nr * sizeof(rgb_rpc));
+    send_batch(env, &c->owner, tick, n, &dec, &rpc);
     return RGB_OK;
   }
   /* Under the lock only what depends on the owner table: owner of every decision and the pids involved (copied).
@@ -366,7 +372,7 @@ static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint3
   const uint32_t n_own = c->n_pids + 1;                       /* bucket 0 = default owner */
   if (c->tix_cap < n_own) {
     uint32_t *t2 = (uint32_t *)enif_alloc((size_t)n_own * 2 * sizeof(uint32_t));
-    if (!t2) { enif_mutex_unlock(c->own_mu); enif_release_binary(dec); enif_release_binary(rpc); return RGB_E_NOMEM; }
+    if (!t2) { enif_mutex_unlock(c->own_mu); return RGB_E_NOMEM; }
     memset(t2, 0, (size_t)n_own * 2 * sizeof(uint32_t));
     if (c->tix) enif_free(c->tix);
     c->tix = t2; c->tix_cap = n_own; c->tix_gen = 0;
@@ -438,23 +444,26 @@ static int fan_back(nif_ctx *c, ErlNifEnv *env, uint64_t tick, uint32_t n, uint3
   }
   if (to) enif_free(to);
   if (own) enif_free(own);
-  enif_release_binary(dec); enif_release_binary(rpc);
   return rc;
 }
 
-/* the collector thread: owns rgb_collect, parks in rgb_wait while nothing is in flight */
+/* the collector thread: owns the consumer side of the ring, parks in rgb_wait while nothing is in flight.  It takes
+ * every batch as a VIEW (rgb_collect_view: pointers into the pinned slot the device wrote), fans it out from there and
+ * gives the slot back */
 static void *collector_main(void *arg) {
   nif_ctx *c = (nif_ctx *)arg;
   ErlNifEnv *env = enif_alloc_env();
   while (!atomic_load(&c->stop)) {
     if (rgb_wait(c->ctx, 250) != RGB_OK) continue;            /* timeout or rgb_wake: re-check stop */
-    ErlNifBinary dec, rpc; uint32_t n = 0, nr = 0; uint64_t tick = 0;
-    int rc = do_collect(c, &dec, &rpc, &n, &nr, &tick);
+    rgb_view v;
+    int rc = rgb_collect_view(c->ctx, &v);
     if (rc == RGB_E_EMPTY) continue;
     if (rc == RGB_OK) {
+      const uint32_t n = v.n;
       struct timespec a, b;
       clock_gettime(CLOCK_MONOTONIC, &a);
-      rc = fan_back(c, env, tick, n, nr, &dec, &rpc);
+      rc = fan_back(c, env, v.tick, v.n, v.n_rpcs, v.decisions, v.rpcs);
+      (void)rgb_release(c->ctx, v.slot);
       clock_gettime(CLOCK_MONOTONIC, &b);
       atomic_fetch_add(&c->fb_ns, (unsigned long long)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec)));
       atomic_fetch_add(&c->fb_decisions, (unsigned long long)n);
