@@ -28,6 +28,13 @@ if os.environ.get("RGB_LITERAL_HIST"):            # RGB_LIB = a -DRGB_X_DECLINE_
             if tot:
                 print(f"class {c} {nm}: {tot} lanes reached the fast path, taken {row[0] / tot:.3f}; declines by reason:",
                       {k: round(int(row[k]) / tot, 4) for k in range(1, 32) if row[k]})
+if os.environ.get("RGB_TRAIN_LEAD"):              # ordering probe: "class:lead,..." in ticks over the defaults (rgb_train_lead)
+    import ctypes as C
+    import numpy as np
+    lead = np.array([0.0, 0.15, 0.10, 0.08, 0.08, 0, 0, 0, 0, 0, 0, 0.25, 0, 0, 0], dtype=np.float32)
+    for kv in os.environ["RGB_TRAIN_LEAD"].split(","):
+        c, v = kv.split(":"); lead[int(c)] = float(v)
+    engine.lib().rgb_train_set_lead(lead.ctypes.data_as(C.c_void_p))
 r = bench.run_literal(name, ticks, torch, engine, W, abi, torch.device("cuda", 0), 0, on_train=cb)
 print(json.dumps({k: r[k] for k in ("us_per_tick", "frac", "value", "launch", "final_state_equal", "oracle_checked_decisions",
                                     "per_tick_launches", "train_launch")}))
