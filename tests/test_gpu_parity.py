@@ -464,6 +464,18 @@ def test_collect_view_hands_out_the_slot_in_place(engine_mod, oracle_lib):
             assert e.value.code == abi.E_STATE
         assert total_rpcs > 0
         assert gpu.get_state().tobytes() == cpu.get_state().tobytes()
+        # nothing in flight: the view form reports it like rgb_collect; a slot the ring does not have is refused
+        with pytest.raises(engine_mod.RgbError) as e:
+            gpu.collect_view()
+        assert e.value.code == abi.E_EMPTY
+        with pytest.raises(engine_mod.RgbError) as e:
+            gpu.release(99)
+        assert e.value.code == abi.E_INVAL
+        # an empty batch is a batch: zero decisions, zero records, its tick
+        gpu.submit(np.zeros(0, dtype=abi.MSG_DTYPE), tick=41)
+        dv, rv, tick, slot = gpu.collect_view()
+        assert (len(dv), len(rv), tick) == (0, 0, 41)
+        gpu.release(slot)
     cpu.close()
 
 
