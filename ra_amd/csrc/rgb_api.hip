@@ -36,6 +36,9 @@
  * big to stay in the cache anyway are written with streaming stores (no ownership read; the device's DMA and the
  * consumer read them from memory either way). */
 #define RGB_STREAM_COPY_MIN (1u << 20)      /* bytes: smaller batches are consumed from the cache */
+#ifndef RGB_COPY_STREAM_MIN
+#define RGB_COPY_STREAM_MIN (2u << 20)      /* bytes: batches below it keep their copy on the decision stream (two API calls and an event hand-over less on a latency-bound round trip) */
+#endif
 static inline void copy_msg(rgb_msg *dst, const rgb_msg *src, bool stream) {
 #if defined(__x86_64__)
   if (stream) {                                              /* dst: a 64-byte slot of the pinned buffer (aligned) */
@@ -111,6 +114,7 @@ struct rgb_slot {
   u32 n = 0;
   uint64_t tick = 0;
   hipEvent_t done = nullptr;
+  hipEvent_t copied = nullptr;      /* the batch's messages are on the device (recorded on the copy stream) */
 };
 
 /* Threading contract of the staging ring: any number of threads may call rgb_submit -- they
@@ -164,6 +168,10 @@ struct rgb_ctx {
   size_t lb_pinned_bytes = 0;
   std::mutex lb_mu;                 /* .. one call at a time per context: it owns the buffer, the side stream, the event */
   hipStream_t lb_stream = nullptr;  /* the collective and its copy-out run HERE, outside the decision path's locks */
+  /* the H2D copy of a BIG batch runs here and the decision stream waits for its event: PCIe is full duplex, and the
+   * copy in of batch k + 1 then runs under the kernels of batch k and under its results kernel's stores to the host
+   * (one stream serialised them: 131 072-message batches were 180 us in + 15 us of kernels + 170 us out) */
+  hipStream_t copy_stream = nullptr;
   hipEvent_t lb_event = nullptr;    /* the snapshot on the context's stream -> the side stream */
   u32 synth_hint = 2;         /* rgb_synth_set_hint */
   u32 *d_synth = nullptr;     /* load-generator scratch (family and bucket counters) */
@@ -290,6 +298,8 @@ static void free_slot(rgb_slot &s) {
   if (s.d_touched) (void)hipFree(s.d_touched);
   if (s.d_undo) (void)hipFree(s.d_undo);
   if (s.done) (void)hipEventDestroy(s.done);
+  if (s.copied) (void)hipEventDestroy(s.copied);
+  s.copied = nullptr;
   s.h_msgs = nullptr; s.h_dec = nullptr; s.d_msgs = nullptr; s.d_dec = nullptr; s.d_rpcs = nullptr; s.h_rpcs = nullptr;
   s.h_nrpc = nullptr; s.d_res = nullptr;
   s.h_stamps = s.d_stamps = nullptr; s.h_plan = s.d_plan = nullptr; s.h_rows = s.d_rows = nullptr; s.done = nullptr;
@@ -314,6 +324,7 @@ void rgb_close(rgb_ctx *ctx) {
   if (ctx->d_rows) (void)hipFree(ctx->d_rows);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->lb_stream) { (void)hipStreamSynchronize(ctx->lb_stream); (void)hipStreamDestroy(ctx->lb_stream); }
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->d_lb_gather) (void)hipFree(ctx->d_lb_gather);
   if (ctx->h_lb_pinned) (void)hipHostFree(ctx->h_lb_pinned);
   if (ctx->lb_event) (void)hipEventDestroy(ctx->lb_event);
@@ -347,6 +358,7 @@ int rgb_open(const rgb_config *cfg_in, rgb_ctx **out) {
   memset(&ctx->dev, 0, sizeof ctx->dev);
   e = hipSetDevice(cfg.device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
 
   if (e != hipSuccess) { delete ctx; return RGB_E_HIP; }
   *out = ctx;
@@ -367,6 +379,7 @@ static int alloc_slot(rgb_ctx *ctx, rgb_slot &s) {
   HIPCHK(ctx, hipMalloc((void **)&s.d_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc)));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_rpcs, (size_t)ctx->rpc_cap * sizeof(rgb_rpc), hipHostMallocDefault));
   HIPCHK(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void **)&s.h_nrpc, 64, hipHostMallocDefault));
   HIPCHK(ctx, hipMalloc((void **)&s.d_res, ((size_t)rgb_results_blocks(cap) + 1u) * sizeof(u32)));
   HIPCHK(ctx, hipMemsetAsync(s.d_res, 0, ((size_t)rgb_results_blocks(cap) + 1u) * sizeof(u32), ctx->stream));   /* (the error word) */
@@ -667,7 +680,17 @@ static int enqueue_batch(rgb_ctx *ctx, rgb_slot &s, bool as_train, u32 rows_max)
         }
     }
   }
-  HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, (size_t)n * (sizeof(rgb_msg) + sizeof(u32)), hipMemcpyHostToDevice, ctx->stream));   /* + h_pos */
+  {
+    const size_t bytes = (size_t)n * (sizeof(rgb_msg) + sizeof(u32));                               /* messages + h_pos */
+    if (bytes >= RGB_COPY_STREAM_MIN) {
+      /* (the slot's device buffers are free: its previous batch was collected, i.e. its event had completed) */
+      HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+      HIPCHK(ctx, hipEventRecord(s.copied, ctx->copy_stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
+    } else {
+      HIPCHK(ctx, hipMemcpyAsync(s.d_msgs, s.h_msgs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
   if (s.n_ranges)
     HIPCHK(ctx, hipMemcpyAsync(s.d_ranges, s.h_ranges, (size_t)s.n_ranges * 2u * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
   /* the undo log: the rows of the touched servers as they are before this batch -- while a train is in flight
