@@ -37,6 +37,11 @@ def test_sub_ticks_ring_and_overflow(emulated_engine, oracle_lib):
     G.test_write_that_ends_below_a_sparse_range_leaves_no_range(emulated_engine, oracle_lib)
 
 
+def test_big_batches_through_the_c_abi(emulated_engine, oracle_lib):
+    """(the emulation has one stream: what this checks on the CPU is the enqueue logic and the ring with three big batches in flight)"""
+    G.test_big_batches_pipelined_through_the_copy_stream(emulated_engine, oracle_lib, ticks=3)
+
+
 def test_rounds_as_one_train_launch_through_the_c_abi(emulated_engine, oracle_lib):
     G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, 6, G=1200, N=5, batches=2)
     G.test_rounds_of_one_batch_run_as_one_train_launch(emulated_engine, oracle_lib, 16, G=1200, N=5, batches=1)

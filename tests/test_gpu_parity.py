@@ -479,6 +479,37 @@ def test_collect_view_hands_out_the_slot_in_place(engine_mod, oracle_lib):
     cpu.close()
 
 
+def test_big_batches_pipelined_through_the_copy_stream(engine_mod, oracle_lib, G=8192, N=5, ticks=4):
+    """Batches of 2 MB and more copy in on their own stream (batch k + 1 under batch k's kernels and results stores):
+    three of them in flight at once, every decision, rpc record and the final state equal to the sequential checker's."""
+    rng = np.random.default_rng(2026)
+    st = fuzz.random_states(rng, G, N, max_runs=6)
+    cpu = oracle_lib.Oracle(G, N)
+    cpu.set_state(0, st)
+    batches, want = [], []
+    for t in range(ticks):
+        m = fuzz.random_msgs(rng, cpu.get_state(), N, frac=0.95)
+        m = m[m["kind"] != abi.MSG_NOP]
+        assert len(m) * 68 >= (2 << 20), "the batch must be big enough for the copy stream"
+        batches.append(m)
+        want.append(cpu.step(m))
+    with engine_mod.RaGpuBatch(G, N, ring_capacity=G * N, ring_slots=4, max_runs=16) as gpu:
+        gpu.set_state(0, st)
+        got, pending = [], 0
+        for t, m in enumerate(batches):
+            while pending >= 3:
+                got.append(gpu.collect()); pending -= 1
+            gpu.submit(m, tick=t); pending += 1
+        while pending:
+            got.append(gpu.collect()); pending -= 1
+        for t, ((dg, rg, tick), (do, ro)) in enumerate(zip(got, want)):
+            assert tick == t
+            assert dg.tobytes() == do.tobytes(), f"batch {t}: decisions differ"
+            assert fuzz.sort_rpcs(rg.copy()).tobytes() == fuzz.sort_rpcs(ro).tobytes(), f"batch {t}: rpc records differ"
+        assert gpu.get_state().tobytes() == cpu.get_state().tobytes()
+    cpu.close()
+
+
 def test_device_resident_ticks_match_host_path(engine_mod, oracle_lib):
     import torch
     rng = np.random.default_rng(21)
