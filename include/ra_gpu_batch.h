@@ -455,7 +455,8 @@ int  rgb_download_state(rgb_ctx *ctx, uint32_t first, uint32_t n, rgb_server_sta
 
 /* Asynchronous host path: copy n messages into the pinned staging ring, enqueue
  * H2D + transition kernel(s) + the results kernels (which write decisions and rpc records into the slot's pinned host
- * buffers: no D2H copy command) on the context's stream and return.  Messages for the same
+ * buffers: no D2H copy command) on the context's stream and return.  (The H2D copy of a batch of 2 MB and more runs
+ * on a second stream the decision stream waits for: PCIe carries batch k + 1 in while batch k's results go out.)  Messages for the same
  * server are applied in submission order (serialised over sub-ticks); messages for different
  * servers are applied in parallel.  rgb_collect waits for the OLDEST submitted batch. */
 int  rgb_submit(rgb_ctx *ctx, const rgb_msg *msgs, uint32_t n, uint64_t tick);
